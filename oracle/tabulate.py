@@ -1,0 +1,305 @@
+"""
+Oracle: SAM records -> per-pair positive / negative variant lists.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Restates, from
+``/root/reference/graphkir/hisat2.py``:
+
+* ``pairMates``        <- readPair 228-276
+* ``passesFilter``     <- filterRead 541-578
+* ``walkRecord``       <- recordToRawVariant 279-515, readZs 518-527, readMd 530-538
+* ``resolveVariants``  <- findVariantId 581-606, recordToVariants 657-689,
+                          errorCorrection 609-654 (pileup, optional)
+* ``windowBounds``     <- getVariantsBoundary 692-713
+* ``positiveNegative`` <- getPNFromVariantList 716-800
+* ``tabulate``         <- extractVariant 803-844, getNH 95-100
+
+Written as an explicit cursor machine over tokenised CIGAR / MD / Zs instead
+of the reference's nested closures; behaviour (including the `0` MD tokens,
+the Zs line-up rule and the final consumption asserts) is the same and is
+pinned by tests/golden (fixture T1/T2).
+"""
+from __future__ import annotations
+
+import bisect
+import copy
+import re
+from typing import Iterable, Iterator
+
+from kir_graph_amd.msa2hisat import Variant
+
+_CIGAR_RE = re.compile(r"(\d+)(\w)")
+_MD_RE = re.compile(r"\d+|.")
+_NH_RE = re.compile(r"NH:i:(\d+)")
+
+
+def pairMates(lines: Iterable[str], warn=None) -> Iterator[tuple[str, str]]:
+    """Name-collated SAM lines -> (later mate, earlier mate) pairs (readPair 228-276)."""
+    pending: dict[tuple[str, str, str, int], str] = {}
+    for line in lines:
+        if not line or line[0] == "@" or line.startswith("[bam_sort_core]"):
+            continue
+        qname, flag_s, ref, pos, _, _, rnext, pnext = line.split("\t")[:8]
+        if rnext != "=":
+            continue
+        flag = int(flag_s)
+        sec = flag & 256
+        mate_key = (qname, ref, pnext, sec)
+        other = pending.get(mate_key)
+        if other is None:
+            pending[(qname, ref, pos, sec)] = line
+            continue
+        both = int(other.split("\t")[1]) | flag
+        if both & 192 != 192:  # need READ1 and READ2 between the two records
+            if warn:
+                warn(line, other)
+            continue
+        del pending[mate_key]
+        yield line, other
+
+
+def passesFilter(line: str, max_nm: int = 4) -> bool:
+    """Proper pair and NM present and <= 4 (filterRead 541-578)."""
+    cols = line.strip().split("\t")
+    if not int(cols[1]) & 2:
+        return False
+    nm = None
+    for c in cols[11:]:
+        if c.startswith("NM"):
+            nm = int(c[5:])
+    return nm is not None and nm <= max_nm
+
+
+def _tags(cols: list[str]):
+    md: list = []
+    zs: list[tuple[int, str, str]] = []
+    got_md = got_zs = False
+    for c in cols:
+        if not got_zs and c.startswith("Zs"):
+            zs = [(int(a), b, d) for a, b, d in (x.split("|") for x in c[5:].split(","))]
+            got_zs = True
+        if not got_md and c.startswith("MD"):
+            md = [int(t) if t.isdigit() else t for t in _MD_RE.findall(c[5:])]
+            got_md = True
+    return md, zs
+
+
+class _Walk:
+    """Cursor state shared by the CIGAR ops of one record."""
+
+    def __init__(self, ref: str, start: int, seq: str, md: list, zs: list):
+        self.ref, self.seq, self.md, self.zs = ref, seq, md, zs
+        self.pos = start      # reference cursor
+        self.ri = 0           # read cursor
+        self.mi = 0           # MD token cursor
+        self.carry = 0        # matched bases owed by the last MD number
+        self.zi = 0           # Zs entry cursor
+        self.zpos = 0         # read offset after the last consumed Zs entry
+        self.out: list[Variant] = []
+
+    def skip_zero(self) -> None:
+        if self.mi < len(self.md) and self.md[self.mi] == 0:
+            self.mi += 1
+
+    def zs_id(self, kind: str) -> str:
+        if self.zi < len(self.zs):
+            gap, typ, name = self.zs[self.zi]
+            if typ == kind and self.ri + self.carry == self.zpos + gap:
+                self.zpos += gap + (1 if kind == "S" else 0)
+                self.zi += 1
+                return name
+        return "unknown"
+
+    def op_match(self, n: int) -> None:
+        done = 0  # offset inside this op up to which events were emitted
+        md = self.md
+        while True:
+            if self.carry <= done and self.mi < len(md) and type(md[self.mi]) is int:
+                self.carry += md[self.mi]
+                self.mi += 1
+            if self.carry >= n:
+                self.carry -= n
+                self.out.append(Variant(typ="match", ref=self.ref, pos=self.pos + done, length=n - done))
+                return
+            base = self.seq[self.ri + self.carry]
+            if md[self.mi] == 0:
+                self.mi += 1
+            assert str(md[self.mi]) in "ACGT"
+            assert str(md[self.mi]) != base
+            self.mi += 1
+            if self.carry > done:
+                self.out.append(Variant(typ="match", ref=self.ref, pos=self.pos + done,
+                                        length=self.carry - done))
+            self.out.append(Variant(typ="single", ref=self.ref, pos=self.pos + self.carry, length=1,
+                                    val=base, id=self.zs_id("S")))
+            self.carry += 1
+            done = self.carry
+            if self.carry == n:
+                self.carry = 0
+                return
+
+    def op_insert(self, n: int) -> None:
+        self.out.append(Variant(typ="insertion", ref=self.ref, pos=self.pos, length=n,
+                                val=self.seq[self.ri:self.ri + n], id=self.zs_id("I")))
+
+    def op_delete(self, n: int) -> None:
+        md = self.md
+        assert md[self.mi] == "^"
+        self.mi += 1
+        while self.mi < len(md) and type(md[self.mi]) is not int and str(md[self.mi]) in "ACGT":
+            self.mi += 1
+        self.out.append(Variant(typ="deletion", ref=self.ref, pos=self.pos, length=n, val=n,
+                                id=self.zs_id("D")))
+
+
+def walkRecord(line: str) -> tuple[list[Variant], list[int]]:
+    """One SAM record -> alternating match / single / insertion / deletion variants + soft clips."""
+    cols = line.strip().split("\t")
+    md, zs = _tags(cols[11:])
+    w = _Walk(cols[2], int(cols[3]) - 1, cols[9], md, zs)
+    clips = [0, 0]
+    for k, (n_s, op) in enumerate(_CIGAR_RE.findall(cols[5])):
+        n = int(n_s)
+        w.skip_zero()
+        if op == "M":
+            w.op_match(n)
+        elif op == "I":
+            w.op_insert(n)
+        elif op == "D":
+            w.op_delete(n)
+        elif op == "S":
+            clips[0 if k == 0 else 1] = n
+            w.zpos += n
+        elif op == "N":
+            raise NotImplementedError("Cannot typing with splicing")
+        else:
+            raise NotImplementedError
+        if op in "MND":
+            w.pos += n
+        if op in "MIS":
+            w.ri += n
+    w.skip_zero()
+    assert w.zi == len(w.zs)
+    assert w.mi == len(w.md)
+    assert w.ri == len(w.seq)
+    return w.out, clips
+
+
+def pileupCorrect(v: Variant, pileup: dict) -> Variant:
+    """Optional SNP correction from per-position base ratios (hisat2.errorCorrection 609-654)."""
+    if v.typ != "single":
+        return v
+    p = pileup.get((v.ref, v.pos))
+    if not p or p["all"] < 20 or p.get(str(v.val), 0) > 0.2:
+        return v
+    bases = [(b, r) for b, r in p.items() if b != "all"]
+    if any(r >= 0.8 for _, r in bases):
+        v.val = max(bases, key=lambda t: t[1])[0]
+    else:
+        v.val = "N"
+    return v
+
+
+class NovelCounter:
+    """Stand-in for the reference's process-wide ``Variant.novel_id`` (msa2hisat.py:37)."""
+
+    def __init__(self, start: int = 0):
+        self.next = start
+
+    def take(self) -> int:
+        n = self.next
+        self.next += 1
+        return n
+
+
+def resolveVariants(line: str, known: dict[Variant, Variant], novel: NovelCounter,
+                    pileup: dict | None = None) -> list[Variant]:
+    """Walk + id assignment; a soft-clipped record yields [] before any id is assigned."""
+    found, clips = walkRecord(line)
+    if clips[0] + clips[1] > 0:
+        return []
+    if pileup:
+        found = [pileupCorrect(v, pileup) for v in found]
+    out = []
+    for v in found:
+        hit = known.get(v)
+        if hit is not None:
+            out.append(hit)
+        elif v.typ == "match":
+            out.append(v)
+        else:
+            v.id = f"nv{novel.take()}"
+            known[v] = v
+            out.append(v)
+    return sorted(out)
+
+
+def windowBounds(read_vars: list[Variant], index_vars: list[Variant]) -> tuple[int, int, int]:
+    """[lo, hi) over the sorted index list and the right reference edge (692-713, 743)."""
+    first, last = read_vars[0], read_vars[-1]
+    right = last.pos + last.length
+    lo = bisect.bisect_left(index_vars, Variant(ref=first.ref, pos=first.pos, typ="single", val="A"))
+    hi = bisect.bisect_left(index_vars, Variant(ref=first.ref, pos=right, typ="single", val="T"))
+    return lo, hi, right
+
+
+def positiveNegative(read_vars: list[Variant], index_vars: list[Variant]
+                     ) -> tuple[list[Variant], list[Variant]]:
+    """Positive = non-match variants of the mate; negative = window minus them (716-800)."""
+    if not read_vars:
+        return [], []
+    lo, hi, right = windowBounds(read_vars, index_vars)
+    assert lo <= hi
+    for v in read_vars:
+        if v.typ in ("insertion", "deletion") and str(v.id).startswith("nv"):
+            return [], []
+    skip: set[Variant] = set()
+    for v in read_vars:
+        if v.val == "N":
+            for b in "ATCG":
+                alt = copy.deepcopy(v)
+                alt.val = b
+                skip.add(alt)
+    pos_vars = [v for v in read_vars if v.typ != "match"]
+    skip.update(pos_vars)
+    neg_vars = []
+    for v in index_vars[lo:hi]:
+        if v in skip:
+            continue
+        if v.typ == "deletion" and v.pos + int(v.val) + 10 >= right:  # type: ignore[arg-type]
+            continue
+        neg_vars.append(v)
+    return pos_vars, neg_vars
+
+
+def nhOf(line: str) -> int:
+    m = _NH_RE.search(line)
+    return int(m.group(1)) if m else 1
+
+
+def tabulate(pairs: Iterable[tuple[str, str]], index_vars: list[Variant],
+             novel: NovelCounter | None = None, pileup: dict | None = None) -> dict:
+    """Filtered mate pairs -> {"variants": [...], "reads": [dict...]} (extractVariant 803-844)."""
+    novel = novel or NovelCounter()
+    known = {v: v for v in index_vars}
+    reads = []
+    for left, right in pairs:
+        lv = resolveVariants(left, known, novel, pileup)
+        rv = resolveVariants(right, known, novel, pileup)
+        lp, ln = positiveNegative(lv, index_vars)
+        rp, rn = positiveNegative(rv, index_vars)
+        reads.append({
+            "lpv": [v.id for v in lp if v.id is not None],
+            "lnv": [v.id for v in ln if v.id is not None],
+            "rpv": [v.id for v in rp if v.id is not None],
+            "rnv": [v.id for v in rn if v.id is not None],
+            "l_sam": left, "r_sam": right,
+            "multiple": nhOf(left), "backbone": left.split("\t")[2],
+        })
+    return {"variants": list(known.values()), "reads": reads}
+
+
+def tabulateLines(lines: Iterable[str], index_vars: list[Variant],
+                  novel: NovelCounter | None = None) -> dict:
+    """readPair + filterRead + extractVariant in one call (extractVariantFromBam 923-932)."""
+    pairs = (p for p in pairMates(lines) if passesFilter(p[0]) and passesFilter(p[1]))
+    return tabulate(pairs, index_vars, novel)
