@@ -1,0 +1,185 @@
+/*
+ * graphkir_hip.h -- C ABI of the MI355X (gfx950) Graph-KIR allele-typing hot path.
+ *
+ * The reference (linnil1/KIR_graph) is pure Python and has no FFI; its plug-in
+ * surface for this path is the Python API listed in SURVEY.md section 8(b).
+ * This header is what a ctypes binding on the reference side would bind; every
+ * entry point names the reference code it replaces.  Conventions:
+ *   - plain C, opaque handles, caller-provided host buffers, no torch types;
+ *   - every function returns 0 on success, a negative code on error, and
+ *     gk_last_error() gives the message (thread-local);
+ *   - device buffers are addressed by opaque 64-bit device pointers obtained
+ *     from gk_malloc (so a host language only needs integers);
+ *   - nothing here falls back to the CPU: without a HIP device every compute
+ *     call fails with GK_ERR_NO_DEVICE.
+ */
+#ifndef GRAPHKIR_HIP_H
+#define GRAPHKIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GK_ABI_VERSION 1
+
+#define GK_OK 0
+#define GK_ERR_NO_DEVICE (-1)
+#define GK_ERR_HIP (-2)
+#define GK_ERR_ARG (-3)
+#define GK_ERR_ASSERT (-4)   /* a reference `assert` would have fired (e.g. window lo > hi) */
+#define GK_ERR_CAPACITY (-5)
+
+/* ---- packed alignment record: 64 bytes per mate, 2 consecutive mates = 1 pair.
+ * mate 0 of a pair is the record emitted as `left` by readPair (hisat2.py:270),
+ * i.e. the LATER line of the name-collated stream; mate 1 the earlier one.
+ * It carries exactly the fields recordToRawVariant / filterRead / getNH read
+ * from the SAM text (hisat2.py:342-350, 551-569, 95-100). */
+#define GK_MAX_CIG 10
+#define GK_MAX_MM 4
+#define GK_MAX_INS 4
+#define GK_CIG_M 0
+#define GK_CIG_I 1
+#define GK_CIG_D 2
+#define GK_CIG_S 4
+#define GK_NM_ABSENT 255
+
+typedef struct gk_mm {
+  uint16_t ref_off; /* reference offset of the mismatch from pos0 */
+  uint8_t base;     /* read base (ASCII) */
+  uint8_t rsv;
+} gk_mm;
+
+typedef struct gk_mate {
+  uint32_t pos0;  /* 0-based leftmost reference position (POS-1) */
+  uint16_t flag;  /* SAM FLAG */
+  uint8_t ref;    /* backbone ordinal in sorted-name order */
+  uint8_t nh;     /* NH:i (1 when absent), saturated at 255 */
+  uint8_t nm;     /* NM:i saturated at 254, GK_NM_ABSENT when the tag is missing */
+  uint8_t n_cig;  /* CIGAR ops stored (0 when filterRead already rejects the mate) */
+  uint8_t n_mm;   /* MD mismatches stored */
+  uint8_t n_ins;  /* inserted strings stored */
+  uint16_t cig[GK_MAX_CIG]; /* len << 4 | op */
+  gk_mm mm[GK_MAX_MM];
+  uint32_t ins[GK_MAX_INS]; /* string-table id of the k-th I op */
+} gk_mate;
+
+typedef struct gk_ctx gk_ctx;
+typedef struct gk_index gk_index;
+typedef struct gk_tab gk_tab;
+typedef struct gk_lut gk_lut;
+typedef uint64_t gk_dptr; /* device address */
+
+/* ---- runtime ------------------------------------------------------------ */
+int gk_abi_version(void);
+const char* gk_last_error(void);
+int gk_device_count(int* n);
+int gk_ctx_create(int device, gk_ctx** out);
+int gk_ctx_destroy(gk_ctx* ctx);
+int gk_sync(gk_ctx* ctx);
+int gk_malloc(gk_ctx* ctx, size_t bytes, gk_dptr* out);
+int gk_free(gk_ctx* ctx, gk_dptr p);
+int gk_memset(gk_ctx* ctx, gk_dptr p, int value, size_t bytes);
+int gk_h2d(gk_ctx* ctx, gk_dptr dst, const void* src, size_t bytes);
+int gk_d2h(gk_ctx* ctx, void* dst, gk_dptr src, size_t bytes);
+int gk_d2d(gk_ctx* ctx, gk_dptr dst, gk_dptr src, size_t bytes);
+/* HIP-event timing on the context stream (bench.py roofline leg). */
+int gk_timer_start(gk_ctx* ctx);
+int gk_timer_stop_ms(gk_ctx* ctx, float* ms);
+
+/* ---- index: replaces getVariants() (hisat2.py:183-203) as a device table.
+ * key[v] = ref:8 | pos:24 | type:2 | val:30 sorted ascending (msa2hisat.py:48-53). */
+int gk_index_create(gk_ctx* ctx, const uint64_t* key, int32_t n_var, const int32_t* gene_vbeg,
+                    int32_t n_gene, gk_index** out);
+int gk_index_destroy(gk_index* idx);
+
+/* ---- tabulation: replaces filterRead + extractVariant (hisat2.py:541-578, 803-844).
+ * d_mates: 2*n_pairs gk_mate records resident in HBM.  On return the handle owns:
+ *   n_valid pairs that pass filterRead on both mates, in input order;
+ *   CSR lists per valid pair in the order lpv, rpv, lnv, rnv (variant ordinals:
+ *   < n_var = index ordinal, >= n_var = n_var + rank of the novel variant in
+ *   first-appearance order, i.e. id "nv{novel_base + rank}");
+ *   the novel variants' keys in that order. */
+typedef struct gk_tab_info {
+  int64_t n_pairs;
+  int64_t n_valid;
+  int64_t n_ids;
+  int32_t n_novel;
+  int32_t err_flags;    /* bit0: window lo > hi somewhere (reference assert, hisat2.py:744) */
+  gk_dptr d_pair_src;   /* int32 [n_valid] input pair index */
+  gk_dptr d_off;        /* uint32 [4*n_valid+1] */
+  gk_dptr d_ids;        /* uint32 [n_ids] */
+  gk_dptr d_pair_gene;  /* uint8 [n_valid] backbone ordinal */
+  gk_dptr d_pair_nh;    /* uint8 [n_valid] */
+  gk_dptr d_novel_key;  /* uint64 [n_novel] */
+} gk_tab_info;
+int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates, int64_t n_pairs, gk_tab** out);
+int gk_tab_get_info(gk_tab* tab, gk_tab_info* info);
+int gk_tab_destroy(gk_tab* tab);
+
+/* ---- ordered selection: stable compaction of [0,n) where flag != 0.
+ * Used for removeMultipleMapped + groupReads (hisat2.py:943-948, kir_typing.py:15-20)
+ * and removeEmptyReads (typing_mulit_allele.py:274-281). */
+int gk_select_gene(gk_ctx* ctx, gk_tab* tab, int gene, int multiple, gk_dptr d_rows_out, int64_t* n_out);
+int gk_select_nonempty(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag,
+                       gk_dptr d_rows_out, int64_t* n_out);
+
+/* ---- variant error correction: AlleleTyping.errorCorrection (typing_mulit_allele.py:302-338).
+ * d_vflag uint8 [n_var + n_novel]: bit0 = dropped from positive lists, bit1 = from negative lists.
+ * gk_variant_count tallies the surviving ids of the given rows into d_cnt (uint32 [2][n_var+n_novel],
+ * positives then negatives); gk_variant_correct applies the <3 / <20 % thresholds to d_vflag. */
+int gk_variant_count(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag,
+                     gk_dptr d_cnt);
+int gk_variant_correct(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag);
+
+/* ---- compatibility: reads2AlleleProb (typing_mulit_allele.py:340-381).
+ * d_mask uint32 [vend-vbeg][words]: allele bit rows of the gene's index variants.
+ * Outputs are column-major [allele][row] with leading dimension n_rows:
+ *   d_probs double (ordered product lpv, rpv, lnv, rnv of 0.999 / 0.001), may be 0;
+ *   d_miss uint8 (#mismatching ids, saturated 255), may be 0;  d_nvar uint16 [n_rows], may be 0. */
+int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag,
+              int32_t vbeg, int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele,
+              gk_dptr d_probs, gk_dptr d_miss, gk_dptr d_nvar);
+
+/* ---- log10 through a value table: log_probs = np.log10(probs) (typing_mulit_allele.py:263).
+ * The distinct probability bit patterns are collected on the device, the HOST evaluates
+ * numpy.log10 on them (so the bits are the reference's on this machine) and the table is applied
+ * on the device. */
+int gk_lut_create(gk_ctx* ctx, int32_t log2_capacity, gk_lut** out);
+int gk_lut_destroy(gk_lut* lut);
+int gk_lut_collect(gk_lut* lut, gk_dptr d_vals, int64_t n);              /* insert, async */
+int gk_lut_pending(gk_lut* lut, int32_t* n_total, int32_t* n_known);     /* syncs */
+int gk_lut_export(gk_lut* lut, int32_t first, int32_t count, double* keys_out);
+int gk_lut_define(gk_lut* lut, int32_t first, int32_t count, const double* log_vals);
+int gk_lut_apply(gk_lut* lut, gk_dptr d_in, gk_dptr d_out, int64_t n);
+
+/* ---- likelihood search: AlleleTyping.addCandidate (typing_mulit_allele.py:478-598).
+ * L is column-major double [n_allele][ld] (ld >= n_rows).  Reductions over rows follow
+ * numpy's add.reduce tree exactly (8192-row chunks, pairwise blocks of 128, 8 strided
+ * accumulators) so that ranks and ties are the reference's.
+ *   gk_maxsum: out[t*n_cols + j] = sum_r max(L[r, cols[j]], max_k L[r, ids[t*c_prev + k]])
+ *              (c_prev == 0: plain column sums, line 514; else lines 540-542)
+ *   gk_fraction: frac[k*c + j] = (sum_r [L[r,ids[k,j]] == max_j'] / #argmax) / n_rows (575-580)
+ *   gk_setmax:  P[t][r] = max_k L[r, ids[t*c + k]]  (allele_prob, line 569), column-major [t][ld] */
+int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets,
+              int32_t c_prev, const int32_t* cols, int32_t n_cols, double* out);
+int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids,
+                int32_t n_sets, int32_t c, double* frac_out);
+int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets,
+              int32_t c, gk_dptr d_P);
+
+/* ---- EM strategy: typing_em.py:68-188.
+ * gk_em_sets: per-row candidate-allele bit sets (getCandidateAllelePerRead + getMostFreqAllele).
+ * gk_em_run:  SQUAREM EM on weighted distinct sets (hisatEMnp 107-188), one workgroup. */
+int gk_em_sets(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, int32_t vbeg, int32_t vend,
+               gk_dptr d_mask, int32_t words, gk_dptr d_sets_out /* uint32 [n_rows][words] */);
+int gk_em_run(gk_ctx* ctx, const uint32_t* sets, const double* weight, int32_t n_sets, int32_t words,
+              int32_t n_allele, int32_t iter_max, double diff_threshold, double* prob_out,
+              int32_t* iters_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHKIR_HIP_H */

@@ -1,0 +1,230 @@
+"""
+ctypes binding of ``libgraphkir_hip.so`` (C ABI: ``include/graphkir_hip.h``).
+
+There is deliberately no fallback: if the library is missing, or no HIP device
+is visible when a context is created, the typing path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+LIB_NAME = "libgraphkir_hip.so"
+_lib = None
+
+
+class GkError(RuntimeError):
+    """Error reported by the native library."""
+
+
+class GkNoDevice(GkError):
+    """No HIP device: the typing path cannot run (there is no CPU fallback)."""
+
+
+# gk_mate (include/graphkir_hip.h): 64 bytes, mm is an array of 4 {u16 ref_off, u8 base, u8 rsv}
+_MM = np.dtype([("ref_off", "<u2"), ("base", "u1"), ("rsv", "u1")])
+MATE_DTYPE = np.dtype([
+    ("pos0", "<u4"), ("flag", "<u2"), ("ref", "u1"), ("nh", "u1"),
+    ("nm", "u1"), ("n_cig", "u1"), ("n_mm", "u1"), ("n_ins", "u1"),
+    ("cig", "<u2", (10,)), ("mm", _MM, (4,)), ("ins", "<u4", (4,)),
+])
+assert MATE_DTYPE.itemsize == 64
+
+CIG_M, CIG_I, CIG_D, CIG_S = 0, 1, 2, 4
+NM_ABSENT = 255
+MAX_CIG, MAX_MM, MAX_INS, MAX_EV = 10, 4, 4, 4
+
+
+class TabInfo(C.Structure):
+    _fields_ = [
+        ("n_pairs", C.c_int64), ("n_valid", C.c_int64), ("n_ids", C.c_int64),
+        ("n_novel", C.c_int32), ("err_flags", C.c_int32),
+        ("d_pair_src", C.c_uint64), ("d_off", C.c_uint64), ("d_ids", C.c_uint64),
+        ("d_pair_gene", C.c_uint64), ("d_pair_nh", C.c_uint64), ("d_novel_key", C.c_uint64),
+    ]
+
+
+def libPath() -> Path:
+    return Path(__file__).resolve().parent / LIB_NAME
+
+
+_SIGS = {
+    "gk_abi_version": (C.c_int, []),
+    "gk_last_error": (C.c_char_p, []),
+    "gk_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "gk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "gk_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "gk_sync": (C.c_int, [C.c_void_p]),
+    "gk_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "gk_free": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "gk_memset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_size_t]),
+    "gk_h2d": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]),
+    "gk_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t]),
+    "gk_d2d": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_size_t]),
+    "gk_timer_start": (C.c_int, [C.c_void_p]),
+    "gk_timer_stop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "gk_index_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "gk_index_destroy": (C.c_int, [C.c_void_p]),
+    "gk_tabulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_void_p)]),
+    "gk_tab_get_info": (C.c_int, [C.c_void_p, C.POINTER(TabInfo)]),
+    "gk_tab_destroy": (C.c_int, [C.c_void_p]),
+    "gk_select_gene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_int64)]),
+    "gk_select_nonempty": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint64,
+                                     C.POINTER(C.c_int64)]),
+    "gk_variant_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint64]),
+    "gk_variant_correct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "gk_compat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_int32, C.c_int32,
+                            C.c_uint64, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "gk_lut_create": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "gk_lut_destroy": (C.c_int, [C.c_void_p]),
+    "gk_lut_collect": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64]),
+    "gk_lut_pending": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gk_lut_export": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "gk_lut_define": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "gk_lut_apply": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64]),
+    "gk_maxsum": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                            C.c_void_p, C.c_int32, C.c_void_p]),
+    "gk_fraction": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                              C.c_void_p]),
+    "gk_setmax": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                            C.c_uint64]),
+    "gk_em_sets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_uint64,
+                             C.c_int32, C.c_uint64]),
+    "gk_em_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                            C.c_double, C.c_void_p, C.POINTER(C.c_int32)]),
+}
+
+EXPORTED = sorted(_SIGS)
+
+
+def lib():
+    """Load the native library once; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        path = libPath()
+        if not path.exists():
+            raise GkError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). The typing path has no CPU fallback.")
+        handle = C.CDLL(str(path))
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.gk_abi_version() != 1:
+            raise GkError("libgraphkir_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc == 0:
+        return
+    msg = lib().gk_last_error().decode(errors="replace")
+    if rc == -1:
+        raise GkNoDevice(msg)
+    if rc == -4:
+        raise AssertionError(msg)
+    raise GkError(f"[{rc}] {msg}")
+
+
+def _np_ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+class DeviceBuffer:
+    """A typed allocation in HBM."""
+
+    def __init__(self, dev: "Device", shape, dtype):
+        self.dev = dev
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_uint64()
+        check(lib().gk_malloc(dev.ctx, max(self.nbytes, 16), C.byref(p)))
+        self.ptr = p.value
+
+    @property
+    def size(self) -> int:
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def upload(self, a: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.nbytes == self.nbytes, (a.shape, self.shape)
+        if a.nbytes:
+            check(lib().gk_h2d(self.dev.ctx, self.ptr, _np_ptr(a), a.nbytes))
+        return self
+
+    def download(self, count: int | None = None, offset: int = 0) -> np.ndarray:
+        n = self.size - offset if count is None else count
+        out = np.empty(n, dtype=self.dtype)
+        if n:
+            check(lib().gk_d2h(self.dev.ctx, _np_ptr(out), self.ptr + offset * self.dtype.itemsize, out.nbytes))
+        return out if count is not None or len(self.shape) == 1 else out.reshape(self.shape)
+
+    def zero(self) -> "DeviceBuffer":
+        check(lib().gk_memset(self.dev.ctx, self.ptr, 0, self.nbytes))
+        return self
+
+    def free(self) -> None:
+        if self.ptr:
+            lib().gk_free(self.dev.ctx, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Device:
+    """One HIP device context (one process drives one GPU)."""
+
+    def __init__(self, ordinal: int | None = None):
+        if ordinal is None:
+            ordinal = int(os.environ.get("LOCAL_RANK", "0"))
+            n = deviceCount()
+            ordinal = ordinal % n if n else 0
+        ctx = C.c_void_p()
+        check(lib().gk_ctx_create(ordinal, C.byref(ctx)))
+        self.ctx = ctx
+        self.ordinal = ordinal
+
+    def alloc(self, shape, dtype) -> DeviceBuffer:
+        return DeviceBuffer(self, shape, dtype)
+
+    def put(self, a: np.ndarray) -> DeviceBuffer:
+        a = np.ascontiguousarray(a)
+        return DeviceBuffer(self, a.shape, a.dtype).upload(a)
+
+    def view(self, ptr: int, count: int, dtype) -> np.ndarray:
+        """Download ``count`` items of ``dtype`` from a raw device address."""
+        out = np.empty(count, dtype=dtype)
+        if count:
+            check(lib().gk_d2h(self.ctx, _np_ptr(out), ptr, out.nbytes))
+        return out
+
+    def sync(self) -> None:
+        check(lib().gk_sync(self.ctx))
+
+    def timerStart(self) -> None:
+        check(lib().gk_timer_start(self.ctx))
+
+    def timerStopMs(self) -> float:
+        ms = C.c_float()
+        check(lib().gk_timer_stop_ms(self.ctx, C.byref(ms)))
+        return float(ms.value)
+
+    def close(self) -> None:
+        if self.ctx:
+            lib().gk_ctx_destroy(self.ctx)
+            self.ctx = None
+
+
+def deviceCount() -> int:
+    n = C.c_int()
+    rc = lib().gk_device_count(C.byref(n))
+    return int(n.value) if rc == 0 else 0

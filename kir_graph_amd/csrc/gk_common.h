@@ -1,0 +1,94 @@
+// Internal helpers shared by the HIP translation units of libgraphkir_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "graphkir_hip.h"
+
+void gk_set_error(const char* fmt, ...);
+
+#define GK_HIP(call)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      gk_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return GK_ERR_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+#define GK_REQUIRE(cond, msg)                        \
+  do {                                               \
+    if (!(cond)) {                                   \
+      gk_set_error("%s (%s:%d)", msg, __FILE__, __LINE__); \
+      return GK_ERR_ARG;                             \
+    }                                                \
+  } while (0)
+
+struct gk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // small reusable device scratch (scan partials, counters)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  // pinned host staging for small parameter arrays
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+};
+
+int gk_ctx_scratch(gk_ctx* ctx, size_t bytes, void** out);
+
+struct gk_index {
+  gk_ctx* ctx = nullptr;
+  uint64_t* d_key = nullptr;
+  int32_t* d_gene_vbeg = nullptr;
+  int32_t n_var = 0, n_gene = 0;
+  std::vector<int32_t> gene_vbeg;
+};
+
+struct gk_tab {
+  gk_ctx* ctx = nullptr;
+  gk_index* idx = nullptr;
+  int64_t n_pairs = 0, n_valid = 0, n_ids = 0;
+  int32_t n_novel = 0, err_flags = 0;
+  int32_t* d_pair_src = nullptr;
+  uint32_t* d_off = nullptr;
+  uint32_t* d_ids = nullptr;
+  uint8_t* d_pair_gene = nullptr;
+  uint8_t* d_pair_nh = nullptr;
+  uint64_t* d_novel_key = nullptr;
+};
+
+template <typename T>
+static inline T* gk_ptr(gk_dptr p) {
+  return reinterpret_cast<T*>(static_cast<uintptr_t>(p));
+}
+static inline gk_dptr gk_addr(const void* p) { return static_cast<gk_dptr>(reinterpret_cast<uintptr_t>(p)); }
+
+// ---- device scan / compaction primitives (gk_scan.hip)
+// exclusive scan of uint32 in place; total written to *d_total (device) if non-null
+int gk_scan_u32(gk_ctx* ctx, uint32_t* d_data, int64_t n, uint32_t* d_total);
+// stable compaction: out[k] = values[i] (or i when values == nullptr) for the k-th i with flag[i] != 0
+int gk_compact(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int64_t n, int32_t* d_out,
+               int64_t* n_out);
+
+// ---- packed key helpers (host + device)
+#define GK_KEY_REF_SHIFT 56
+#define GK_KEY_POS_SHIFT 32
+#define GK_KEY_TYP_SHIFT 30
+#define GK_KEY_VAL_MASK 0x3FFFFFFFull
+#define GK_TYP_INS 0ull
+#define GK_TYP_SINGLE 1ull
+#define GK_TYP_DEL 2ull
+__host__ __device__ static inline uint64_t gk_make_key(uint32_t ref, uint32_t pos, uint64_t typ, uint32_t val) {
+  return ((uint64_t)ref << GK_KEY_REF_SHIFT) | ((uint64_t)(pos & 0xFFFFFFu) << GK_KEY_POS_SHIFT) |
+         (typ << GK_KEY_TYP_SHIFT) | ((uint64_t)val & GK_KEY_VAL_MASK);
+}
+__host__ __device__ static inline uint32_t gk_key_pos(uint64_t k) { return (uint32_t)(k >> GK_KEY_POS_SHIFT) & 0xFFFFFFu; }
+__host__ __device__ static inline uint32_t gk_key_typ(uint64_t k) { return (uint32_t)(k >> GK_KEY_TYP_SHIFT) & 3u; }
+__host__ __device__ static inline uint32_t gk_key_val(uint64_t k) { return (uint32_t)(k & GK_KEY_VAL_MASK); }

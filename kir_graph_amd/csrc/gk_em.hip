@@ -1,0 +1,197 @@
+// EM strategy ("report" / "em"): typing_em.py:68-188.
+//
+//   gk_em_sets  getCandidateAllelePerRead 68-87 + getMostFreqAllele 90-104 as bit-set algebra:
+//               mate set  = AND of the positive variants' allele rows, minus OR of the negative rows
+//                           (empty when the mate has no positive variant);
+//               pair set  = L & R when that is non-empty (alleles named twice), else L | R.
+//   gk_em_run   hisatEMnp 107-188 on DISTINCT sets with multiplicities.  The reference builds a
+//               dense 0/1 read x allele float matrix and sweeps it 3-4 times per iteration; reads
+//               with equal candidate sets contribute identical rows, so the device keeps one row
+//               per distinct set (weights = multiplicity) and runs the whole SQUAREM loop inside a
+//               single workgroup (no launch per iteration).  Sums are evaluated in a fixed order, so
+//               results are run-to-run deterministic; they agree with numpy's row-sequential sums to
+//               rounding (tolerance 1e-5 relative per BASELINE.json north_star).
+#include "gk_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxWords = 16;    // up to 512 alleles per gene
+constexpr int kMaxAllele = kMaxWords * 32;
+
+__global__ __launch_bounds__(kThreads) void em_sets_kernel(const int32_t* rows, int64_t n_rows, const uint32_t* off,
+                                                           const uint32_t* ids, int vbeg, int vend,
+                                                           const uint32_t* mask, int words, uint32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n_rows) return;
+  const int64_t row = rows[i];
+  uint32_t side[2][kMaxWords];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    // list order in the CSR: lpv, rpv, lnv, rnv
+    const uint32_t pb = off[4 * row + s], pe = off[4 * row + s + 1];
+    const uint32_t nb = off[4 * row + 2 + s], ne = off[4 * row + 2 + s + 1];
+    const bool any_pos = pe > pb;
+#pragma unroll
+    for (int w = 0; w < kMaxWords; ++w) side[s][w] = (any_pos && w < words) ? 0xFFFFFFFFu : 0u;
+    for (uint32_t k = pb; k < pe; ++k) {
+      const int v = (int)ids[k];
+      const bool indexed = v >= vbeg && v < vend;
+#pragma unroll
+      for (int w = 0; w < kMaxWords; ++w)
+        if (w < words) side[s][w] &= indexed ? mask[(int64_t)(v - vbeg) * words + w] : 0u;
+    }
+    if (any_pos) {
+      for (uint32_t k = nb; k < ne; ++k) {
+        const int v = (int)ids[k];
+        if (v < vbeg || v >= vend) continue;
+#pragma unroll
+        for (int w = 0; w < kMaxWords; ++w)
+          if (w < words) side[s][w] &= ~mask[(int64_t)(v - vbeg) * words + w];
+      }
+    }
+  }
+  uint32_t both = 0;
+#pragma unroll
+  for (int w = 0; w < kMaxWords; ++w) both |= side[0][w] & side[1][w];
+#pragma unroll
+  for (int w = 0; w < kMaxWords; ++w)
+    if (w < words) out[i * words + w] = both ? (side[0][w] & side[1][w]) : (side[0][w] | side[1][w]);
+}
+
+struct EmShared {
+  double p[kMaxAllele], p1[kMaxAllele], p2[kMaxAllele], p3[kMaxAllele];
+  double scalar[4];
+  int flag;
+};
+
+// next(p): q[a] = sum_u w_u * p[a] / (sum_{b in u} p[b]) over sets containing a, then normalise
+__device__ void em_step(const uint32_t* sets, const double* weight, double* scale, int n_sets, int words, int n_allele,
+                        const double* in, double* out, double* scalar) {
+  const int tid = threadIdx.x;
+  for (int u = tid; u < n_sets; u += kThreads) {
+    double tot = 0.0;
+    for (int w = 0; w < words; ++w) {
+      uint32_t bits = sets[u * words + w];
+      while (bits) {
+        const int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        tot += in[w * 32 + b];
+      }
+    }
+    scale[u] = tot != 0.0 ? weight[u] / tot : 0.0;
+  }
+  __syncthreads();
+  for (int a = tid; a < n_allele; a += kThreads) {
+    const int w = a >> 5;
+    const uint32_t bit = 1u << (a & 31);
+    double s = 0.0;
+    for (int u = 0; u < n_sets; ++u)
+      if (sets[u * words + w] & bit) s += scale[u];
+    out[a] = in[a] * s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int a = 0; a < n_allele; ++a) tot += out[a];
+    scalar[0] = tot;
+  }
+  __syncthreads();
+  const double tot = scalar[0];
+  for (int a = tid; a < n_allele; a += kThreads) out[a] = out[a] / tot;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void em_kernel(const uint32_t* sets, const double* weight, double* scale,
+                                                      int n_sets, int words, int n_allele, int iter_max,
+                                                      double diff_threshold, double* prob_out, int* iters_out) {
+  __shared__ EmShared sh;
+  const int tid = threadIdx.x;
+  for (int a = tid; a < n_allele; a += kThreads) sh.p3[a] = 1.0;
+  __syncthreads();
+  em_step(sets, weight, scale, n_sets, words, n_allele, sh.p3, sh.p, sh.scalar);
+  int iters = 0;
+  for (iters = 0; iters < iter_max; ++iters) {
+    em_step(sets, weight, scale, n_sets, words, n_allele, sh.p, sh.p1, sh.scalar);
+    em_step(sets, weight, scale, n_sets, words, n_allele, sh.p1, sh.p2, sh.scalar);
+    if (tid == 0) {
+      double rs = 0.0, vs = 0.0;
+      for (int a = 0; a < n_allele; ++a) {
+        const double r = sh.p1[a] - sh.p[a];
+        const double v = sh.p2[a] - sh.p1[a] - r;
+        rs += r * r;
+        vs += v * v;
+      }
+      sh.scalar[1] = rs;
+      sh.scalar[2] = vs;
+    }
+    __syncthreads();
+    const double rs = sh.scalar[1], vs = sh.scalar[2];
+    if (vs > 0.0) {
+      const double g = -sqrt(rs / vs);
+      for (int a = tid; a < n_allele; a += kThreads) {
+        const double r = sh.p1[a] - sh.p[a];
+        const double v = sh.p2[a] - sh.p1[a] - r;
+        const double x = sh.p[a] - r * g * 2 + v * (g * g);
+        sh.p3[a] = x > 0.0 ? x : 0.0;
+      }
+      __syncthreads();
+      em_step(sets, weight, scale, n_sets, words, n_allele, sh.p3, sh.p1, sh.scalar);
+    }
+    if (tid == 0) {
+      double d = 0.0;
+      for (int a = 0; a < n_allele; ++a) d += fabs(sh.p[a] - sh.p1[a]);
+      sh.flag = d <= diff_threshold;
+    }
+    __syncthreads();
+    if (sh.flag) break;
+    for (int a = tid; a < n_allele; a += kThreads) sh.p[a] = sh.p1[a];
+    __syncthreads();
+  }
+  for (int a = tid; a < n_allele; a += kThreads) prob_out[a] = sh.p[a];
+  if (tid == 0) *iters_out = iters;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gk_em_sets(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, int32_t vbeg, int32_t vend, gk_dptr d_mask,
+               int32_t words, gk_dptr d_sets_out) {
+  GK_REQUIRE(ctx && tab, "null pointer");
+  GK_REQUIRE(words >= 1 && words <= kMaxWords, "more than 512 alleles per gene are not supported by the EM kernel");
+  if (!n_rows) return GK_OK;
+  hipLaunchKernelGGL(em_sets_kernel, dim3((unsigned)((n_rows + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     ctx->stream, gk_ptr<int32_t>(d_rows), n_rows, tab->d_off, tab->d_ids, vbeg, vend,
+                     gk_ptr<uint32_t>(d_mask), words, gk_ptr<uint32_t>(d_sets_out));
+  GK_HIP(hipGetLastError());
+  return GK_OK;
+}
+
+int gk_em_run(gk_ctx* ctx, const uint32_t* sets, const double* weight, int32_t n_sets, int32_t words, int32_t n_allele,
+              int32_t iter_max, double diff_threshold, double* prob_out, int32_t* iters_out) {
+  GK_REQUIRE(ctx && sets && weight && prob_out && iters_out, "null pointer");
+  GK_REQUIRE(n_sets > 0 && words >= 1 && words <= kMaxWords && n_allele >= 1 && n_allele <= words * 32,
+             "bad EM geometry");
+  hipStream_t st = ctx->stream;
+  uint32_t* d_sets = nullptr;
+  double *d_w = nullptr, *d_scale = nullptr, *d_prob = nullptr;
+  int* d_it = nullptr;
+  GK_HIP(hipMalloc((void**)&d_sets, (size_t)n_sets * words * sizeof(uint32_t)));
+  GK_HIP(hipMalloc((void**)&d_w, (size_t)n_sets * sizeof(double)));
+  GK_HIP(hipMalloc((void**)&d_scale, (size_t)n_sets * sizeof(double)));
+  GK_HIP(hipMalloc((void**)&d_prob, (size_t)n_allele * sizeof(double)));
+  GK_HIP(hipMalloc((void**)&d_it, sizeof(int)));
+  GK_HIP(hipMemcpyAsync(d_sets, sets, (size_t)n_sets * words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  GK_HIP(hipMemcpyAsync(d_w, weight, (size_t)n_sets * sizeof(double), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(em_kernel, dim3(1), dim3(kThreads), 0, st, d_sets, d_w, d_scale, n_sets, words, n_allele, iter_max,
+                     diff_threshold, d_prob, d_it);
+  GK_HIP(hipGetLastError());
+  GK_HIP(hipMemcpyAsync(prob_out, d_prob, (size_t)n_allele * sizeof(double), hipMemcpyDeviceToHost, st));
+  GK_HIP(hipMemcpyAsync(iters_out, d_it, sizeof(int), hipMemcpyDeviceToHost, st));
+  GK_HIP(hipStreamSynchronize(st));
+  hipFree(d_sets); hipFree(d_w); hipFree(d_scale); hipFree(d_prob); hipFree(d_it);
+  return GK_OK;
+}
+
+}  // extern "C"

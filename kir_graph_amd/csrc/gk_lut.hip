@@ -1,0 +1,167 @@
+// log10 through a value table (typing_mulit_allele.py:263  log_probs = np.log10(probs)).
+//
+// The read x allele probabilities take few distinct bit patterns (products of 0.999 / 0.001 in a
+// handful of orders).  The device collects the distinct patterns in a hash set, the host evaluates
+// numpy.log10 on them -- so the result bits are the reference's on the same machine, whatever
+// libm / SVML numpy dispatches to -- and the device maps every element through the table.
+#include "gk_common.h"
+
+struct gk_lut {
+  gk_ctx* ctx = nullptr;
+  uint32_t log2cap = 0;
+  uint64_t* d_keys = nullptr;   // slot -> bit pattern (kEmptyKey when free)
+  uint32_t* d_slot_idx = nullptr;  // slot -> dense index
+  uint64_t* d_list = nullptr;   // dense index -> bit pattern (insertion order, racy but stable after the kernel)
+  double* d_vals = nullptr;     // dense index -> log10
+  uint32_t* d_count = nullptr;  // number of dense entries
+  int32_t n_known = 0;          // entries with a defined value
+};
+
+namespace {
+
+constexpr int kThreads = 256;
+// 0x7FF8dead... is a NaN payload no product of 0.999 / 0.001 can produce
+constexpr uint64_t kEmptyKey = 0x7FF8DEADBEEF0001ull;
+
+__device__ inline uint32_t hash64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+__global__ __launch_bounds__(kThreads) void lut_collect(const uint64_t* vals, int64_t n, uint64_t* keys,
+                                                        uint32_t* slot_idx, uint64_t* list, uint32_t* count,
+                                                        uint32_t mask) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  uint64_t last = kEmptyKey;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    const uint64_t k = vals[i];
+    if (k == last) continue;   // runs of equal values are common along a column
+    last = k;
+    uint32_t s = hash64(k) & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+      const uint64_t cur = keys[s];
+      if (cur == k) break;
+      if (cur == kEmptyKey) {
+        const unsigned long long prev = atomicCAS((unsigned long long*)&keys[s], (unsigned long long)kEmptyKey,
+                                                  (unsigned long long)k);
+        if (prev == kEmptyKey) {
+          const uint32_t idx = atomicAdd(count, 1u);
+          slot_idx[s] = idx;
+          if (idx <= mask) list[idx] = k;
+          break;
+        }
+        if (prev == k) break;
+      }
+      s = (s + 1) & mask;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void lut_apply(const uint64_t* in, double* out, int64_t n, const uint64_t* keys,
+                                                      const uint32_t* slot_idx, const double* table, uint32_t mask) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    const uint64_t k = in[i];
+    uint32_t s = hash64(k) & mask;
+    double v = __longlong_as_double(0x7FF8000000000000ll);
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+      const uint64_t cur = keys[s];
+      if (cur == k) { v = table[slot_idx[s]]; break; }
+      if (cur == kEmptyKey) break;
+      s = (s + 1) & mask;
+    }
+    out[i] = v;
+  }
+}
+
+__global__ void fill_keys(uint64_t* keys, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] = kEmptyKey;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gk_lut_create(gk_ctx* ctx, int32_t log2_capacity, gk_lut** out) {
+  GK_REQUIRE(ctx && out && log2_capacity >= 10 && log2_capacity <= 26, "bad table capacity");
+  gk_lut* l = new gk_lut();
+  l->ctx = ctx; l->log2cap = (uint32_t)log2_capacity;
+  const size_t cap = 1ull << log2_capacity;
+  GK_HIP(hipMalloc((void**)&l->d_keys, cap * sizeof(uint64_t)));
+  GK_HIP(hipMalloc((void**)&l->d_slot_idx, cap * sizeof(uint32_t)));
+  GK_HIP(hipMalloc((void**)&l->d_list, cap * sizeof(uint64_t)));
+  GK_HIP(hipMalloc((void**)&l->d_vals, cap * sizeof(double)));
+  GK_HIP(hipMalloc((void**)&l->d_count, sizeof(uint32_t)));
+  GK_HIP(hipMemsetAsync(l->d_count, 0, sizeof(uint32_t), ctx->stream));
+  hipLaunchKernelGGL(fill_keys, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, l->d_keys, (uint64_t)cap);
+  GK_HIP(hipGetLastError());
+  *out = l;
+  return GK_OK;
+}
+
+int gk_lut_destroy(gk_lut* l) {
+  if (!l) return GK_OK;
+  hipStreamSynchronize(l->ctx->stream);
+  hipFree(l->d_keys); hipFree(l->d_slot_idx); hipFree(l->d_list); hipFree(l->d_vals); hipFree(l->d_count);
+  delete l;
+  return GK_OK;
+}
+
+int gk_lut_collect(gk_lut* l, gk_dptr d_vals, int64_t n) {
+  GK_REQUIRE(l, "null table");
+  if (n <= 0) return GK_OK;
+  int64_t want = (n + kThreads - 1) / kThreads;
+  unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(lut_collect, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_vals), n,
+                     l->d_keys, l->d_slot_idx, l->d_list, l->d_count, (uint32_t)((1ull << l->log2cap) - 1));
+  GK_HIP(hipGetLastError());
+  return GK_OK;
+}
+
+int gk_lut_pending(gk_lut* l, int32_t* n_total, int32_t* n_known) {
+  GK_REQUIRE(l && n_total && n_known, "null pointer");
+  uint32_t c = 0;
+  GK_HIP(hipMemcpyAsync(&c, l->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, l->ctx->stream));
+  GK_HIP(hipStreamSynchronize(l->ctx->stream));
+  if ((uint64_t)c * 2 > (1ull << l->log2cap)) {
+    gk_set_error("probability value table overflow (%u distinct values)", c);
+    return GK_ERR_CAPACITY;
+  }
+  *n_total = (int32_t)c;
+  *n_known = l->n_known;
+  return GK_OK;
+}
+
+int gk_lut_export(gk_lut* l, int32_t first, int32_t count, double* keys_out) {
+  GK_REQUIRE(l && keys_out && first >= 0 && count >= 0, "bad arguments");
+  if (!count) return GK_OK;
+  GK_HIP(hipMemcpyAsync(keys_out, l->d_list + first, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                        l->ctx->stream));
+  GK_HIP(hipStreamSynchronize(l->ctx->stream));
+  return GK_OK;
+}
+
+int gk_lut_define(gk_lut* l, int32_t first, int32_t count, const double* log_vals) {
+  GK_REQUIRE(l && log_vals && first == l->n_known && count >= 0, "values must be defined in order");
+  if (!count) return GK_OK;
+  GK_HIP(hipMemcpyAsync(l->d_vals + first, log_vals, (size_t)count * sizeof(double), hipMemcpyHostToDevice,
+                        l->ctx->stream));
+  GK_HIP(hipStreamSynchronize(l->ctx->stream));
+  l->n_known = first + count;
+  return GK_OK;
+}
+
+int gk_lut_apply(gk_lut* l, gk_dptr d_in, gk_dptr d_out, int64_t n) {
+  GK_REQUIRE(l, "null table");
+  if (n <= 0) return GK_OK;
+  int64_t want = (n + kThreads - 1) / kThreads;
+  unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(lut_apply, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_in),
+                     gk_ptr<double>(d_out), n, l->d_keys, l->d_slot_idx, l->d_vals,
+                     (uint32_t)((1ull << l->log2cap) - 1));
+  GK_HIP(hipGetLastError());
+  return GK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// Exclusive scan and stable compaction on the context stream (wave64 shuffles + LDS).
+#include "gk_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kItems = 8;
+constexpr int kTile = kThreads * kItems;
+
+__device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// each block scans kTile elements exclusively in place and emits its total
+__global__ __launch_bounds__(kThreads) void scan_tiles(uint32_t* data, int64_t n, uint32_t* tile_sum) {
+  __shared__ uint32_t wave_tot[kThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)tid * kItems;
+  uint32_t v[kItems];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    int64_t i = base + k;
+    v[k] = i < n ? data[i] : 0u;
+    sum += v[k];
+  }
+  uint32_t incl = wave_incl_scan(sum, lane);
+  if (lane == 63) wave_tot[wid] = incl;
+  __syncthreads();
+  uint32_t off = 0;
+  for (int w = 0; w < wid; ++w) off += wave_tot[w];
+  uint32_t run = off + incl - sum;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    int64_t i = base + k;
+    if (i < n) data[i] = run;
+    run += v[k];
+  }
+  if (tid == kThreads - 1) tile_sum[blockIdx.x] = off + incl;
+}
+
+__global__ __launch_bounds__(kThreads) void add_tile_offsets(uint32_t* data, int64_t n, const uint32_t* tile_off) {
+  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kItems;
+  const uint32_t off = tile_off[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    int64_t i = base + k;
+    if (i < n) data[i] += off;
+  }
+}
+
+
+__global__ __launch_bounds__(kThreads) void flags_to_u32(const uint32_t* flag, uint32_t* out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) out[i] = flag[i] != 0;
+}
+
+__global__ __launch_bounds__(kThreads) void scatter_selected(const uint32_t* flag, const uint32_t* pos,
+                                                             const int32_t* values, int64_t n, int32_t* out) {
+  int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n && flag[i]) out[pos[i]] = values ? values[i] : (int32_t)i;
+}
+
+}  // namespace
+
+static int scan_rec(gk_ctx* ctx, uint32_t* d, int64_t n, uint32_t* sums_area, uint32_t* d_total) {
+  // sums_area: scratch large enough for all levels
+  int64_t tiles = (n + kTile - 1) / kTile;
+  if (tiles <= 0) {
+    if (d_total) GK_HIP(hipMemsetAsync(d_total, 0, sizeof(uint32_t), ctx->stream));
+    return GK_OK;
+  }
+  hipLaunchKernelGGL(scan_tiles, dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, d, n, sums_area);
+  if (tiles > 1) {
+    int rc = scan_rec(ctx, sums_area, tiles, sums_area + tiles, d_total);
+    if (rc) return rc;
+    hipLaunchKernelGGL(add_tile_offsets, dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, d, n, sums_area);
+  } else if (d_total) {
+    GK_HIP(hipMemcpyAsync(d_total, sums_area, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  GK_HIP(hipGetLastError());
+  return GK_OK;
+}
+
+int gk_scan_u32(gk_ctx* ctx, uint32_t* d_data, int64_t n, uint32_t* d_total) {
+  // scratch for tile sums of every level: tiles + tiles/kTile + ... <= tiles + tiles/1024 + 64
+  int64_t tiles = (n + kTile - 1) / kTile;
+  size_t need = (size_t)(tiles + tiles / 1024 + 4096) * sizeof(uint32_t);
+  // a private allocation: the context scratch may be in use by the caller
+  static thread_local uint32_t* area = nullptr;
+  static thread_local size_t area_bytes = 0;
+  if (need > area_bytes) {
+    GK_HIP(hipStreamSynchronize(ctx->stream));
+    if (area) GK_HIP(hipFree(area));
+    GK_HIP(hipMalloc((void**)&area, need * 2));
+    area_bytes = need * 2;
+  }
+  return scan_rec(ctx, d_data, n, area, d_total);
+}
+
+int gk_compact(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int64_t n, int32_t* d_out,
+               int64_t* n_out) {
+  if (n <= 0) {
+    if (n_out) *n_out = 0;
+    return GK_OK;
+  }
+  uint32_t* pos = nullptr;
+  GK_HIP(hipMalloc((void**)&pos, (size_t)(n + 1) * sizeof(uint32_t)));
+  unsigned blocks = (unsigned)((n + kThreads - 1) / kThreads);
+  hipLaunchKernelGGL(flags_to_u32, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, n);
+  int rc = gk_scan_u32(ctx, pos, n, pos + n);
+  if (rc) {
+    hipFree(pos);
+    return rc;
+  }
+  hipLaunchKernelGGL(scatter_selected, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, d_values, n, d_out);
+  uint32_t total = 0;
+  GK_HIP(hipMemcpyAsync(&total, pos + n, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  GK_HIP(hipStreamSynchronize(ctx->stream));
+  GK_HIP(hipFree(pos));
+  if (n_out) *n_out = total;
+  return GK_OK;
+}

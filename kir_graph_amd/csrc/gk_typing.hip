@@ -1,0 +1,217 @@
+// Per-gene read selection, variant error correction and the read x allele compatibility table.
+//
+//   gk_select_gene      removeMultipleMapped + groupReads      hisat2.py:943-948, kir_typing.py:15-20
+//   gk_variant_count /
+//   gk_variant_correct  AlleleTyping.errorCorrection            typing_mulit_allele.py:302-338
+//   gk_select_nonempty  AlleleTyping.removeEmptyReads           typing_mulit_allele.py:274-281
+//   gk_compat           reads2AlleleProb / read2Onehot / onehot2Prob   typing_mulit_allele.py:287-300, 340-381
+//
+// Compatibility kernel: one wavefront per read pair, lanes = alleles (3 allele slots per lane up
+// to 192 alleles per pass).  The pair's variant ordinals are wave-uniform, every lane tests its
+// allele bit in the variant's bit row and multiplies 0.999 / 0.001 in the reference's factor
+// order (lpv, rpv, lnv, rnv), so the double product is bit-identical to numpy's sequential
+// multiply.reduce.  Bit rows of the gene are staged in LDS when they fit.
+#include "gk_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+inline unsigned nblk(int64_t n, int t = kThreads) { return (unsigned)((n + t - 1) / t); }
+
+__global__ __launch_bounds__(kThreads) void flag_gene(const uint8_t* gene, const uint8_t* nh, int64_t n, int g,
+                                                      int multiple, uint32_t* flag) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) flag[i] = (gene[i] == g) && (multiple || nh[i] == 1);
+}
+
+// one thread per list (4 lists per row): tally surviving ids
+__global__ __launch_bounds__(kThreads) void count_ids(const int32_t* rows, int64_t n_rows, const uint32_t* off,
+                                                      const uint32_t* ids, const uint8_t* vflag, uint32_t* cnt_pos,
+                                                      uint32_t* cnt_neg) {
+  const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (t >= 4 * n_rows) return;
+  const int64_t row = rows[t >> 2];
+  const int list = (int)(t & 3);
+  const uint32_t b = off[4 * row + list], e = off[4 * row + list + 1];
+  const bool positive = list < 2;
+  const uint8_t bit = positive ? 1 : 2;
+  uint32_t* cnt = positive ? cnt_pos : cnt_neg;
+  for (uint32_t k = b; k < e; ++k) {
+    const uint32_t v = ids[k];
+    if (!(vflag[v] & bit)) atomicAdd(&cnt[v], 1u);
+  }
+}
+
+// thresholds of errorCorrection: P+N < 3 drops both sides, P/(P+N) < 0.2 drops positives,
+// N/(P+N) < 0.2 drops negatives.  x/(x+y) < 0.2 in IEEE double <=> 5x < x+y for counts < 2^50.
+__global__ __launch_bounds__(kThreads) void apply_correction(const uint32_t* cnt_pos, const uint32_t* cnt_neg,
+                                                             int64_t n, uint8_t* vflag) {
+  const int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (v >= n) return;
+  const uint64_t p = cnt_pos[v], q = cnt_neg[v];
+  if (p + q == 0) return;
+  uint8_t f = vflag[v];
+  if (p + q < 3) {
+    f |= 3;
+  } else {
+    if (5 * p < p + q) f |= 1;
+    if (5 * q < p + q) f |= 2;
+  }
+  vflag[v] = f;
+}
+
+__global__ __launch_bounds__(kThreads) void flag_nonempty(const int32_t* rows, int64_t n_rows, const uint32_t* off,
+                                                          const uint32_t* ids, const uint8_t* vflag, uint32_t* flag) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n_rows) return;
+  const int64_t row = rows[i];
+  const uint32_t b = off[4 * row], mid = off[4 * row + 2], e = off[4 * row + 4];
+  uint32_t alive = 0;
+  for (uint32_t k = b; k < e && !alive; ++k) alive = !(vflag[ids[k]] & (k < mid ? 1 : 2));
+  flag[i] = alive;
+}
+
+constexpr int kSlots = 3;   // alleles per lane and pass: 192 alleles per pass
+constexpr int kWavesPerBlock = 4;
+
+__global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, int64_t n_rows, const uint32_t* off,
+                                                          const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
+                                                          const uint32_t* mask, int words, int n_allele, int a_base,
+                                                          int lds_rows, double* probs, uint8_t* miss_out,
+                                                          uint16_t* nvar_out) {
+  extern __shared__ uint32_t lds_mask[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // stage the gene's bit rows (all words) when they fit
+  const int n_stage = lds_rows * words;
+  for (int i = tid; i < n_stage; i += kThreads) lds_mask[i] = mask[i];
+  __syncthreads();
+
+  int a[kSlots];
+  bool live[kSlots];
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    a[s] = a_base + lane + 64 * s;
+    live[s] = a[s] < n_allele;
+  }
+  const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wid;
+  const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t i = wave_global; i < n_rows; i += wave_stride) {
+    const int64_t row = rows[i];
+    const uint32_t b = off[4 * row], mid = off[4 * row + 2], e = off[4 * row + 4];
+    double p[kSlots];
+    uint32_t miss[kSlots];
+    uint32_t nvar = 0;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) { p[s] = 1.0; miss[s] = 0; }
+    bool first = true;
+    for (uint32_t k = b; k < e; ++k) {
+      const uint32_t v = ids[k];
+      const bool positive = k < mid;
+      if (vflag[v] & (positive ? 1 : 2)) continue;   // wave-uniform
+      const int local = (int)v - vbeg;
+      const bool indexed = (int)v < vend && local >= 0;   // novel variants carry no allele
+#pragma unroll
+      for (int s = 0; s < kSlots; ++s) {
+        uint32_t w = 0;
+        if (indexed && live[s]) {
+          const int wi = local * words + (a[s] >> 5);
+          w = local < lds_rows ? lds_mask[wi] : mask[wi];
+        }
+        const bool has = (w >> (a[s] & 31)) & 1u;
+        const bool hit = positive ? has : !has;
+        const double f = hit ? 0.999 : 0.001;
+        p[s] = first ? f : p[s] * f;
+        miss[s] += hit ? 0u : 1u;
+      }
+      first = false;
+      ++nvar;
+    }
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+      if (live[s]) {
+        const int64_t o = (int64_t)a[s] * n_rows + i;
+        if (probs) probs[o] = p[s];
+        if (miss_out) miss_out[o] = (uint8_t)min(miss[s], 255u);
+      }
+    }
+    if (nvar_out && lane == 0 && a_base == 0) nvar_out[i] = (uint16_t)min(nvar, 65535u);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gk_select_gene(gk_ctx* ctx, gk_tab* tab, int gene, int multiple, gk_dptr d_rows_out, int64_t* n_out) {
+  GK_REQUIRE(ctx && tab && n_out, "null pointer");
+  const int64_t n = tab->n_valid;
+  if (n == 0) { *n_out = 0; return GK_OK; }
+  uint32_t* flag = nullptr;
+  GK_HIP(hipMalloc((void**)&flag, (size_t)n * sizeof(uint32_t)));
+  hipLaunchKernelGGL(flag_gene, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream, tab->d_pair_gene, tab->d_pair_nh, n,
+                     gene, multiple, flag);
+  int rc = gk_compact(ctx, flag, nullptr, n, gk_ptr<int32_t>(d_rows_out), n_out);
+  hipFree(flag);
+  return rc;
+}
+
+int gk_select_nonempty(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, gk_dptr d_rows_out,
+                       int64_t* n_out) {
+  GK_REQUIRE(ctx && tab && n_out, "null pointer");
+  if (n_rows == 0) { *n_out = 0; return GK_OK; }
+  uint32_t* flag = nullptr;
+  GK_HIP(hipMalloc((void**)&flag, (size_t)n_rows * sizeof(uint32_t)));
+  hipLaunchKernelGGL(flag_nonempty, dim3(nblk(n_rows)), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
+                     n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), flag);
+  int rc = gk_compact(ctx, flag, gk_ptr<int32_t>(d_rows), n_rows, gk_ptr<int32_t>(d_rows_out), n_out);
+  hipFree(flag);
+  return rc;
+}
+
+int gk_variant_count(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, gk_dptr d_cnt) {
+  GK_REQUIRE(ctx && tab, "null pointer");
+  const int64_t nv = (int64_t)tab->idx->n_var + tab->n_novel;
+  uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
+  GK_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * nv) * sizeof(uint32_t), ctx->stream));
+  if (n_rows)
+    hipLaunchKernelGGL(count_ids, dim3(nblk(4 * n_rows)), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
+                       n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), cnt, cnt + nv);
+  GK_HIP(hipGetLastError());
+  return GK_OK;
+}
+
+int gk_variant_correct(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag) {
+  GK_REQUIRE(ctx && tab, "null pointer");
+  const int64_t nv = (int64_t)tab->idx->n_var + tab->n_novel;
+  uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
+  if (nv)
+    hipLaunchKernelGGL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, ctx->stream, cnt, cnt + nv, nv,
+                       gk_ptr<uint8_t>(d_vflag));
+  GK_HIP(hipGetLastError());
+  return GK_OK;
+}
+
+int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg, int32_t vend,
+              gk_dptr d_mask, int32_t words, int32_t n_allele, gk_dptr d_probs, gk_dptr d_miss, gk_dptr d_nvar) {
+  GK_REQUIRE(ctx && tab, "null pointer");
+  GK_REQUIRE(words >= 1 && n_allele >= 0 && n_allele <= words * 32 && vend >= vbeg, "bad mask geometry");
+  if (n_rows == 0 || n_allele == 0) return GK_OK;
+  const int n_v = vend - vbeg;
+  // LDS budget: 64 KiB of bit rows per workgroup keeps two workgroups per CU
+  int lds_rows = n_v;
+  const size_t budget = 64 * 1024;
+  if ((size_t)lds_rows * words * 4 > budget) lds_rows = (int)(budget / ((size_t)words * 4));
+  const size_t lds_bytes = (size_t)lds_rows * words * 4;
+  int64_t want = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  unsigned blocks = (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
+  for (int a_base = 0; a_base < n_allele; a_base += 64 * kSlots) {
+    hipLaunchKernelGGL(compat_kernel, dim3(blocks), dim3(kThreads), lds_bytes, ctx->stream, gk_ptr<int32_t>(d_rows),
+                       n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, gk_ptr<uint32_t>(d_mask),
+                       words, n_allele, a_base, lds_rows, gk_ptr<double>(d_probs), gk_ptr<uint8_t>(d_miss),
+                       gk_ptr<uint16_t>(d_nvar));
+  }
+  GK_HIP(hipGetLastError());
+  return GK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+"""
+Device-resident state of the typing path and thin wrappers over the C ABI.
+
+Layout in HBM (one sample at a time per GPU; sizes for 1 M pairs, ~2 k alleles):
+
+* index keys ``u64[V]`` + per-gene allele bit rows ``u32[V_g][A_g/32]`` (< 1 MB, resident for the run)
+* mate records ``64 B x 2 x pairs``  (128 MB)
+* tabulation CSR: ``u32`` offsets ``[4 x valid + 1]`` and ``u32`` variant ordinals (~50 per pair)
+* per gene: row list ``i32[R]``, variant flags ``u8[V + novel]``,
+  probabilities / log-probabilities column-major ``f64[A][R]`` (so every reduction over reads
+  is a coalesced stream and matches numpy's contiguous-axis summation)
+
+Reference call sites are cited in ``include/graphkir_hip.h``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Device, DeviceBuffer, TabInfo, check, lib
+from .index import GkIndex, KEY_POS_SHIFT, KEY_TYP_SHIFT, KEY_VAL_MASK
+from .msa2hisat import Variant
+
+TYPE_OF_RANK = {0: "insertion", 1: "single", 2: "deletion"}
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class DeviceIndex:
+    """Index tables in HBM (``gk_index``) + allele bit rows per gene."""
+
+    def __init__(self, dev: Device, index: GkIndex):
+        self.dev, self.host = dev, index
+        h = C.c_void_p()
+        key = np.ascontiguousarray(index.key, dtype=np.uint64)
+        vbeg = _i32(index.gene_vbeg)
+        check(lib().gk_index_create(dev.ctx, key.ctypes.data, len(key), vbeg.ctypes.data, len(index.genes),
+                                    C.byref(h)))
+        self.handle = h
+        self.masks = [dev.put(t.mask) for t in index.tables]
+
+    def close(self) -> None:
+        if self.handle:
+            lib().gk_index_destroy(self.handle)
+            self.handle = None
+
+
+class Tabulation:
+    """Result of ``gk_tabulate`` for one sample (replaces the ``.variant.json`` hand-off)."""
+
+    def __init__(self, dindex: DeviceIndex, mates, novel_base: int = 0):
+        self.dev, self.dindex = dindex.dev, dindex
+        if isinstance(mates, np.ndarray):
+            assert mates.dtype == _lib.MATE_DTYPE
+            self.mates = self.dev.put(mates)
+        else:
+            self.mates = mates
+        self.n_pairs = self.mates.size // 2
+        h = C.c_void_p()
+        check(lib().gk_tabulate(self.dev.ctx, dindex.handle, self.mates.ptr, self.n_pairs, C.byref(h)))
+        self.handle = h
+        info = TabInfo()
+        check(lib().gk_tab_get_info(h, C.byref(info)))
+        self.info = info
+        self.n_valid, self.n_ids, self.n_novel = int(info.n_valid), int(info.n_ids), int(info.n_novel)
+        self.novel_base = novel_base
+        if info.err_flags & 1:
+            raise AssertionError("variant window has left > right (graphkir/hisat2.py:744)")
+        self._novel_keys = None
+
+    @property
+    def n_var_total(self) -> int:
+        return self.dindex.host.n_variant + self.n_novel
+
+    def close(self) -> None:
+        if self.handle:
+            lib().gk_tab_destroy(self.handle)
+            self.handle = None
+
+    # ---- host views (outputs / tests)
+    def offsets(self) -> np.ndarray:
+        return self.dev.view(self.info.d_off, 4 * self.n_valid + 1, np.uint32)
+
+    def ids(self) -> np.ndarray:
+        return self.dev.view(self.info.d_ids, self.n_ids, np.uint32)
+
+    def pairSrc(self) -> np.ndarray:
+        return self.dev.view(self.info.d_pair_src, self.n_valid, np.int32)
+
+    def pairGene(self) -> np.ndarray:
+        return self.dev.view(self.info.d_pair_gene, self.n_valid, np.uint8)
+
+    def pairNH(self) -> np.ndarray:
+        return self.dev.view(self.info.d_pair_nh, self.n_valid, np.uint8)
+
+    def novelKeys(self) -> np.ndarray:
+        if self._novel_keys is None:
+            self._novel_keys = self.dev.view(self.info.d_novel_key, self.n_novel, np.uint64)
+        return self._novel_keys
+
+    def novelVariants(self, ins_strings: list[str]) -> list[Variant]:
+        """Novel variants in first-appearance order, ids ``nv{novel_base + rank}`` (hisat2.py:597-602)."""
+        genes = self.dindex.host.genes
+        out = []
+        for rank, k in enumerate(self.novelKeys().tolist()):
+            ref = genes[k >> 56]
+            pos = (k >> KEY_POS_SHIFT) & 0xFFFFFF
+            typ = TYPE_OF_RANK[(k >> KEY_TYP_SHIFT) & 3]
+            val = k & KEY_VAL_MASK
+            if typ == "single":
+                v = Variant(pos=pos, typ=typ, ref=ref, val=chr(val), length=1)
+            elif typ == "deletion":
+                v = Variant(pos=pos, typ=typ, ref=ref, val=int(val), length=int(val))
+            else:
+                s = ins_strings[val]
+                v = Variant(pos=pos, typ=typ, ref=ref, val=s, length=len(s))
+            v.id = f"nv{self.novel_base + rank}"
+            out.append(v)
+        return out
+
+    def idNames(self) -> list[str]:
+        """Ordinal -> variant id string for index + novel variants."""
+        names = [str(v.id) for v in self.dindex.host.variants]
+        names += [f"nv{self.novel_base + r}" for r in range(self.n_novel)]
+        return names
+
+    # ---- selections
+    def selectGene(self, gene: int, multiple: bool = False) -> tuple[DeviceBuffer, int]:
+        rows = self.dev.alloc(max(self.n_valid, 1), np.int32)
+        n = C.c_int64()
+        check(lib().gk_select_gene(self.dev.ctx, self.handle, gene, int(multiple), rows.ptr, C.byref(n)))
+        return rows, int(n.value)
+
+    def selectNonEmpty(self, rows: DeviceBuffer, n_rows: int, vflag: DeviceBuffer) -> tuple[DeviceBuffer, int]:
+        out = self.dev.alloc(max(n_rows, 1), np.int32)
+        n = C.c_int64()
+        check(lib().gk_select_nonempty(self.dev.ctx, self.handle, rows.ptr, n_rows, vflag.ptr, out.ptr, C.byref(n)))
+        return out, int(n.value)
+
+    def countVariants(self, rows: DeviceBuffer, n_rows: int, vflag: DeviceBuffer, cnt: DeviceBuffer) -> None:
+        check(lib().gk_variant_count(self.dev.ctx, self.handle, rows.ptr, n_rows, vflag.ptr, cnt.ptr))
+
+    def correctVariants(self, cnt: DeviceBuffer, vflag: DeviceBuffer) -> None:
+        check(lib().gk_variant_correct(self.dev.ctx, self.handle, cnt.ptr, vflag.ptr))
+
+    def errorCorrection(self, rows: DeviceBuffer, n_rows: int, vflag: DeviceBuffer) -> None:
+        """One pass of ``AlleleTyping.errorCorrection`` on the lists as filtered by ``vflag``."""
+        cnt = self.dev.alloc(2 * self.n_var_total, np.uint32)
+        self.countVariants(rows, n_rows, vflag, cnt)
+        self.correctVariants(cnt, vflag)
+        cnt.free()
+
+
+class LogTable:
+    """``numpy.log10`` applied through a device value table (see ``csrc/gk_lut.hip``)."""
+
+    def __init__(self, dev: Device, log2_capacity: int = 20):
+        self.dev = dev
+        h = C.c_void_p()
+        check(lib().gk_lut_create(dev.ctx, log2_capacity, C.byref(h)))
+        self.handle = h
+        self.n_host_evals = 0
+
+    def collect(self, buf: DeviceBuffer, n: int) -> None:
+        check(lib().gk_lut_collect(self.handle, buf.ptr, n))
+
+    def resolve(self) -> int:
+        """Evaluate numpy.log10 for values first seen since the last call; returns how many."""
+        tot, known = C.c_int32(), C.c_int32()
+        check(lib().gk_lut_pending(self.handle, C.byref(tot), C.byref(known)))
+        new = tot.value - known.value
+        if new > 0:
+            keys = np.empty(new, dtype=np.float64)
+            check(lib().gk_lut_export(self.handle, known.value, new, keys.ctypes.data))
+            with np.errstate(divide="ignore"):
+                vals = np.log10(keys)
+            check(lib().gk_lut_define(self.handle, known.value, new, vals.ctypes.data))
+            self.n_host_evals += new
+        return max(new, 0)
+
+    def apply(self, src: DeviceBuffer, dst: DeviceBuffer, n: int) -> None:
+        check(lib().gk_lut_apply(self.handle, src.ptr, dst.ptr, n))
+
+    def close(self) -> None:
+        if self.handle:
+            lib().gk_lut_destroy(self.handle)
+            self.handle = None
+
+
+class DeviceModel:
+    """Read x allele log-likelihood table of one gene in HBM + its reductions."""
+
+    def __init__(self, tab: Tabulation, rows: DeviceBuffer, n_rows: int, vflag: DeviceBuffer,
+                 vbeg: int, vend: int, mask: DeviceBuffer, words: int, n_allele: int, logs: LogTable,
+                 want_miss: bool = False):
+        self.tab, self.dev = tab, tab.dev
+        self.rows, self.n_rows, self.n_allele = rows, n_rows, n_allele
+        self.vflag = vflag
+        self.probs = self.L = self.miss = self.nvar = None
+        if n_rows == 0 or n_allele == 0:
+            return
+        self.probs = self.dev.alloc((n_allele, n_rows), np.float64)
+        if want_miss:
+            self.miss = self.dev.alloc((n_allele, n_rows), np.uint8)
+            self.nvar = self.dev.alloc(n_rows, np.uint16)
+        check(lib().gk_compat(self.dev.ctx, tab.handle, rows.ptr, n_rows, vflag.ptr, vbeg, vend, mask.ptr, words,
+                              n_allele, self.probs.ptr, self.miss.ptr if self.miss else 0,
+                              self.nvar.ptr if self.nvar else 0))
+        logs.collect(self.probs, n_allele * n_rows)
+        self._logs = logs
+
+    def finishLog(self) -> None:
+        """Second half of construction, after ``LogTable.resolve()``."""
+        if self.probs is None or self.L is not None:
+            return
+        self.L = self.dev.alloc((self.n_allele, self.n_rows), np.float64)
+        self._logs.apply(self.probs, self.L, self.n_allele * self.n_rows)
+
+    # ---- reductions (numpy summation tree on the device)
+    def maxsum(self, prev_ids: np.ndarray | None, cols: np.ndarray) -> np.ndarray:
+        cols = _i32(cols)
+        if prev_ids is None or prev_ids.size == 0:
+            n_sets, c_prev, ids_p = 1, 0, None
+        else:
+            prev_ids = _i32(prev_ids)
+            n_sets, c_prev = prev_ids.shape
+            ids_p = prev_ids.ctypes.data
+        out = np.empty((n_sets, len(cols)), dtype=np.float64)
+        check(lib().gk_maxsum(self.dev.ctx, self.L.ptr, self.n_rows, self.n_rows, ids_p, n_sets, c_prev,
+                              cols.ctypes.data, len(cols), out.ctypes.data))
+        return out
+
+    def colsum(self, cols: np.ndarray) -> np.ndarray:
+        return self.maxsum(None, cols)[0]
+
+    def fraction(self, ids: np.ndarray) -> np.ndarray:
+        ids = _i32(ids)
+        out = np.empty(ids.shape, dtype=np.float64)
+        check(lib().gk_fraction(self.dev.ctx, self.L.ptr, self.n_rows, self.n_rows, ids.ctypes.data, ids.shape[0],
+                                ids.shape[1], out.ctypes.data))
+        return out
+
+    def setmax(self, ids: np.ndarray) -> np.ndarray:
+        """Host copy of allele_prob (R x T) for the given sets -- API parity only, not on the hot path."""
+        ids = _i32(ids)
+        buf = self.dev.alloc((ids.shape[0], self.n_rows), np.float64)
+        check(lib().gk_setmax(self.dev.ctx, self.L.ptr, self.n_rows, self.n_rows, ids.ctypes.data, ids.shape[0],
+                              ids.shape[1], buf.ptr))
+        out = buf.download().reshape(ids.shape[0], self.n_rows).T
+        buf.free()
+        return out
+
+    def hostProbs(self) -> np.ndarray:
+        return self.probs.download().reshape(self.n_allele, self.n_rows).T if self.probs else np.array([])
+
+    def hostLogProbs(self) -> np.ndarray:
+        return self.L.download().reshape(self.n_allele, self.n_rows).T if self.L else np.array([])
+
+    def free(self) -> None:
+        for b in (self.probs, self.L, self.miss, self.nvar):
+            if b is not None:
+                b.free()

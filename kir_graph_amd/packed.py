@@ -1,0 +1,309 @@
+"""
+Packed alignment records: the device's input format (``gk_mate``, 64 bytes).
+
+Two producers, one format (``include/graphkir_hip.h``):
+
+* ``packPairs``  -- SAM text pairs -> records.  This is pure decoding of the
+  fields the reference reads from the text (``graphkir/hisat2.py:342-350``
+  POS/CIGAR/SEQ/MD/Zs, ``551-569`` FLAG/NM, ``95-100`` NH).  The CIGAR / MD /
+  Zs consistency checks of ``recordToRawVariant`` (asserts at 416-417, 461,
+  512-514; ``NotImplementedError`` for ``N`` at 499-502) are evaluated here,
+  because they are properties of the text; the variant walk itself runs on the
+  device (``csrc/gk_tabulate.hip``).
+* ``packSample`` -- synthetic event arrays (``synth.SynthSample``) -> records,
+  vectorised, for large inputs.
+
+Inserted sequences are interned in ``InsTable``: ids below ``n_index`` are the
+rank of the string among the index's insertion alleles (that rank is the
+``val`` field of the variant key), larger ids are novel strings in first-seen
+order.
+"""
+from __future__ import annotations
+
+import re
+
+import numpy as np
+
+from ._lib import MATE_DTYPE, CIG_M, CIG_I, CIG_D, CIG_S, NM_ABSENT, MAX_CIG, MAX_MM, MAX_INS, MAX_EV
+from .index import GkIndex
+
+_CIGAR = re.compile(r"(\d+)(\w)")
+_MDTOK = re.compile(r"\d+|.")
+_NH = re.compile(r"NH:i:(\d+)")
+MAX_OPLEN = 4095
+
+
+class PackCapacityError(ValueError):
+    """A filter-passing record does not fit the fixed-size device record."""
+
+
+class InsTable:
+    """Inserted-sequence interning shared by index and reads."""
+
+    def __init__(self, index: GkIndex):
+        self.strings = list(index.ins_strings)
+        self.ids = dict(index.ins_id)
+        self.n_index = len(self.strings)
+
+    def intern(self, s: str) -> int:
+        i = self.ids.get(s)
+        if i is None:
+            i = len(self.strings)
+            self.ids[s] = i
+            self.strings.append(s)
+        return i
+
+
+def _decodeTags(cols: list[str]):
+    nm = None
+    md = zs = None
+    for c in cols:
+        if c.startswith("NM"):
+            nm = int(c[5:])
+        elif md is None and c.startswith("MD"):
+            md = c[5:]
+        elif zs is None and c.startswith("Zs"):
+            zs = c[5:]
+    return nm, md, zs
+
+
+def _passes(flag: int, nm) -> bool:
+    return bool(flag & 2) and nm is not None and nm <= 4
+
+
+def _walkText(pos0: int, cigar: str, seq: str, md_s: str | None, zs_s: str | None, table: InsTable):
+    """Co-walk CIGAR / MD / Zs text; returns (ops, mismatches, insertion ids, clipped)."""
+    md = [int(t) if t.isdigit() else t for t in _MDTOK.findall(md_s)] if md_s is not None else []
+    zs = [(int(a), b) for a, b, _ in (x.split("|") for x in zs_s.split(","))] if zs_s else []
+    ops: list[tuple[int, int]] = []
+    mms: list[tuple[int, int]] = []
+    ins: list[int] = []
+    ref = 0          # reference offset from pos0
+    ri = 0           # read offset
+    mi = 0           # MD cursor
+    owed = 0         # matched bases still owed by the last MD number
+    zi = zpos = 0
+    clipped = False
+
+    def take_zs(kind: str) -> None:
+        nonlocal zi, zpos
+        if zi < len(zs) and zs[zi][1] == kind and ri + owed == zpos + zs[zi][0]:
+            zpos += zs[zi][0] + (1 if kind == "S" else 0)
+            zi += 1
+
+    for k, (n_s, op) in enumerate(_CIGAR.findall(cigar)):
+        n = int(n_s)
+        if mi < len(md) and md[mi] == 0:
+            mi += 1
+        if op == "M":
+            ops.append((CIG_M, n))
+            done = 0
+            while True:
+                if owed <= done and mi < len(md) and type(md[mi]) is int:
+                    owed += md[mi]
+                    mi += 1
+                if owed >= n:
+                    owed -= n
+                    break
+                base = seq[ri + owed]
+                if md[mi] == 0:
+                    mi += 1
+                assert str(md[mi]) in "ACGT", "MD mismatch token is not a base"
+                assert str(md[mi]) != base, "MD reference base equals the read base"
+                mi += 1
+                take_zs("S")
+                mms.append((ref + owed, ord(base)))
+                owed += 1
+                done = owed
+                if owed == n:
+                    owed = 0
+                    break
+            ref += n
+            ri += n
+        elif op == "I":
+            ops.append((CIG_I, n))
+            take_zs("I")
+            ins.append(table.intern(seq[ri:ri + n]))
+            ri += n
+        elif op == "D":
+            ops.append((CIG_D, n))
+            assert md[mi] == "^", "MD has no deletion at a D op"
+            mi += 1
+            while mi < len(md) and type(md[mi]) is not int and str(md[mi]) in "ACGT":
+                mi += 1
+            take_zs("D")
+            ref += n
+        elif op == "S":
+            clipped = True
+            zpos += n
+            ri += n
+        elif op == "N":
+            raise NotImplementedError("Cannot typing with splicing")
+        else:
+            raise NotImplementedError
+    if mi < len(md) and md[mi] == 0:
+        mi += 1
+    assert zi == len(zs), "Zs entries do not line up with the alignment"
+    assert mi == len(md), "MD not fully consumed"
+    assert ri == len(seq), "CIGAR does not cover the read"
+    return ops, mms, ins, clipped
+
+
+def packPairs(pairs, index: GkIndex, table: InsTable | None = None) -> tuple[np.ndarray, InsTable]:
+    """[(left_line, right_line)] -> mate records (2 per pair, left first)."""
+    table = table or InsTable(index)
+    pairs = list(pairs)
+    rec = np.zeros(2 * len(pairs), dtype=MATE_DTYPE)
+    for p, pair in enumerate(pairs):
+        heads = []
+        for line in pair:
+            cols = line.strip().split("\t")
+            nm, md, zs = _decodeTags(cols[11:])
+            heads.append((cols, nm, md, zs))
+        both = all(_passes(int(c[1]), nm) for c, nm, _, _ in heads)
+        for side, (cols, nm, md, zs) in enumerate(heads):
+            r = rec[2 * p + side]
+            gid = index.gene_id.get(cols[2])
+            if gid is None:
+                raise ValueError(f"reference {cols[2]!r} is not a backbone of the index")
+            r["pos0"] = int(cols[3]) - 1
+            r["flag"] = int(cols[1]) & 0xFFFF
+            r["ref"] = gid
+            m = _NH.search(pair[side])
+            r["nh"] = min(int(m.group(1)), 255) if m else 1
+            r["nm"] = NM_ABSENT if nm is None else min(nm, 254)
+            if not both:
+                continue
+            ops, mms, ins, clipped = _walkText(int(cols[3]) - 1, cols[5], cols[9], md, zs, table)
+            if clipped:
+                r["n_cig"] = 1
+                r["cig"][0] = CIG_S
+                continue
+            n_ev = len(mms) + sum(1 for o, _ in ops if o in (CIG_I, CIG_D))
+            if (len(ops) > MAX_CIG or len(mms) > MAX_MM or len(ins) > MAX_INS or n_ev > MAX_EV
+                    or any(n > MAX_OPLEN for _, n in ops) or any(off > 0xFFFF for off, _ in mms)):
+                raise PackCapacityError(f"record does not fit gk_mate: {cols[0]} {cols[5]}")
+            r["n_cig"], r["n_mm"], r["n_ins"] = len(ops), len(mms), len(ins)
+            for i, (o, n) in enumerate(ops):
+                r["cig"][i] = (n << 4) | o
+            for i, (off, b) in enumerate(mms):
+                r["mm"][i]["ref_off"] = off
+                r["mm"][i]["base"] = b
+            for i, s in enumerate(ins):
+                r["ins"][i] = s
+    return rec, table
+
+
+def packSample(sample, index: GkIndex, table: InsTable | None = None) -> tuple[np.ndarray, InsTable]:
+    """Vectorised ``synth.SynthSample`` -> mate records in readPair emission order.
+
+    The synthetic stream lists READ1 then READ2 of each name, so the pair is emitted when
+    READ2 is seen: left = READ2 (mate index 2r+1), right = READ1 (2r).
+    """
+    from .synth import EV_SINGLE, EV_INS, EV_DEL
+    table = table or InsTable(index)
+    n = sample.n_pairs
+    n_m = 2 * n
+    gmap = np.array([index.gene_id[g] for g in sample.index.genes], dtype=np.uint8)
+    ins_map = np.array([table.intern(s) for s in sample.ins_strings], dtype=np.uint32) \
+        if sample.ins_strings else np.zeros(1, np.uint32)
+    rec = np.zeros(n_m, dtype=MATE_DTYPE)
+    # source mate for each record slot: slot 2r <- mate 2r+1, slot 2r+1 <- mate 2r
+    src = np.arange(n_m) ^ 1
+    pair = np.arange(n_m) >> 1
+    rec["pos0"] = sample.pos0[src]
+    rec["flag"] = sample.flag[src] | np.where(sample.pair_secondary[pair], 256, 0).astype(np.uint16)
+    rec["ref"] = gmap[sample.pair_gene[pair]]
+    rec["nh"] = sample.pair_nh[pair]
+    nm = sample.nm[src]
+    rec["nm"] = np.where(nm < 0, NM_ABSENT, np.minimum(nm, 254)).astype(np.uint8)
+    flag = rec["flag"]
+    ok = ((flag & 2) != 0) & (nm >= 0) & (nm <= 4)
+    ok_pair = ok[0::2] & ok[1::2]
+    walk = np.repeat(ok_pair, 2)
+    clipped = (sample.clip[src].sum(axis=1) > 0) & walk
+    rec["n_cig"][clipped] = 1
+    cig = rec["cig"]
+    cig[clipped, 0] = CIG_S
+    todo = walk & ~clipped
+
+    ev_cnt = (sample.ev_off[1:] - sample.ev_off[:-1])[src]
+    if np.any(todo & (ev_cnt > MAX_EV)):
+        raise PackCapacityError("a filter-passing synthetic mate has more than 4 events")
+    # flatten the events of the records to pack
+    slots = np.nonzero(todo)[0]
+    cnt = ev_cnt[slots]
+    tot = int(cnt.sum())
+    span = sample.span[src]
+    if tot:
+        rep = np.repeat(np.arange(len(slots)), cnt)
+        within = np.arange(tot) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        e_idx = np.repeat(sample.ev_off[:-1][src][slots], cnt) + within
+        kind = sample.ev_kind[e_idx]
+        epos = sample.ev_pos[e_idx].astype(np.int64)
+        eval_ = sample.ev_val[e_idx].astype(np.int64)
+        slot_of = slots[rep]
+        off = epos - rec["pos0"][slot_of].astype(np.int64)
+        # mismatches
+        is_s = kind == EV_SINGLE
+        s_rank = _rankWithin(rep, is_s)
+        ss = slot_of[is_s]
+        mm = rec["mm"]
+        mm["ref_off"][ss, s_rank[is_s]] = off[is_s]
+        mm["base"][ss, s_rank[is_s]] = eval_[is_s]
+        np.add.at(rec["n_mm"], ss, 1)
+        # insertions
+        is_i = kind == EV_INS
+        i_rank = _rankWithin(rep, is_i)
+        si = slot_of[is_i]
+        rec["ins"][si, i_rank[is_i]] = ins_map[eval_[is_i]]
+        np.add.at(rec["n_ins"], si, 1)
+        # CIGAR: every indel event contributes M(gap) + I/D
+        is_x = ~is_s
+        x_rank = _rankWithin(rep, is_x)
+        sx = slot_of[is_x]
+        xoff = off[is_x]
+        xk = kind[is_x]
+        xlen = np.where(xk == EV_DEL, eval_[is_x], 0)
+        if sample.ins_strings:
+            ilen = np.array([len(s) for s in sample.ins_strings], dtype=np.int64)
+            xlen_ins = np.where(xk == EV_INS, ilen[np.where(xk == EV_INS, eval_[is_x], 0)], 0)
+        else:
+            xlen_ins = np.zeros(len(xk), dtype=np.int64)
+        # reference offset where the previous indel of the same record ended
+        prev_end = np.zeros(len(xk), dtype=np.int64)
+        same = np.zeros(len(xk), dtype=bool)
+        if len(xk) > 1:
+            same[1:] = sx[1:] == sx[:-1]
+            prev_end[1:] = np.where(same[1:], (xoff + xlen)[:-1], 0)
+        gap = xoff - prev_end
+        xr = x_rank[is_x]
+        cig[sx, 2 * xr] = ((gap << 4) | CIG_M).astype(np.uint16)
+        oplen = np.where(xk == EV_DEL, xlen, xlen_ins)
+        cig[sx, 2 * xr + 1] = ((oplen << 4) | np.where(xk == EV_DEL, CIG_D, CIG_I)).astype(np.uint16)
+        n_x = np.bincount(sx, minlength=n_m)
+        last_end = np.zeros(n_m, dtype=np.int64)
+        # last indel end per record = max over its indels of (off + dellen)
+        np.maximum.at(last_end, sx, xoff + xlen)
+    else:
+        n_x = np.zeros(n_m, dtype=np.int64)
+        last_end = np.zeros(n_m, dtype=np.int64)
+    fin = span.astype(np.int64) - last_end
+    t = np.nonzero(todo)[0]
+    cig[t, 2 * n_x[t]] = ((fin[t] << 4) | CIG_M).astype(np.uint16)
+    rec["n_cig"][t] = (2 * n_x[t] + 1).astype(np.uint8)
+    if np.any(fin[t] <= 0):
+        raise PackCapacityError("synthetic mate ends in an indel")
+    return rec, table
+
+
+def _rankWithin(group: np.ndarray, sel: np.ndarray) -> np.ndarray:
+    """For non-decreasing ``group`` ids: rank of each element among the selected ones of its group."""
+    n = len(group)
+    if not n:
+        return np.zeros(0, dtype=np.int64)
+    before = np.cumsum(sel) - sel               # selected elements before i, globally
+    start = np.ones(n, dtype=bool)
+    start[1:] = group[1:] != group[:-1]
+    first = np.maximum.accumulate(np.where(start, np.arange(n), 0))
+    return (before - before[first]).astype(np.int64)
