@@ -116,6 +116,10 @@ typedef struct gk_tab_info {
   gk_dptr d_novel_key;  /* uint64 [n_novel] */
 } gk_tab_info;
 int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates, int64_t n_pairs, gk_tab** out);
+/* Same handle from host CSR lists (the `.variant.json` hand-off of hisat2.py:847-866 loaded by
+ * loadReadsAndVariantsData): off[4*n_valid+1] in list order lpv, rpv, lnv, rnv; ordinals < n_var_total. */
+int gk_tab_from_csr(gk_ctx* ctx, int32_t n_var_total, int64_t n_valid, const uint32_t* off, const uint32_t* ids,
+                    const uint8_t* pair_gene, const uint8_t* pair_nh, gk_tab** out);
 int gk_tab_get_info(gk_tab* tab, gk_tab_info* info);
 int gk_tab_destroy(gk_tab* tab);
 

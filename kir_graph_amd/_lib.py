@@ -69,6 +69,8 @@ _SIGS = {
     "gk_index_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "gk_index_destroy": (C.c_int, [C.c_void_p]),
     "gk_tabulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_void_p)]),
+    "gk_tab_from_csr": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.POINTER(C.c_void_p)]),
     "gk_tab_get_info": (C.c_int, [C.c_void_p, C.POINTER(TabInfo)]),
     "gk_tab_destroy": (C.c_int, [C.c_void_p]),
     "gk_select_gene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_int64)]),

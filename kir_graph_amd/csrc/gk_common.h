@@ -54,6 +54,7 @@ struct gk_index {
 struct gk_tab {
   gk_ctx* ctx = nullptr;
   gk_index* idx = nullptr;
+  int32_t n_var = 0;   // index variants (ordinals >= n_var are novel)
   int64_t n_pairs = 0, n_valid = 0, n_ids = 0;
   int32_t n_novel = 0, err_flags = 0;
   int32_t* d_pair_src = nullptr;

@@ -339,7 +339,7 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
   const int64_t n_mates = 2 * n_pairs;
   hipStream_t st = ctx->stream;
   gk_tab* tab = new gk_tab();
-  tab->ctx = ctx; tab->idx = idx; tab->n_pairs = n_pairs;
+  tab->ctx = ctx; tab->idx = idx; tab->n_pairs = n_pairs; tab->n_var = idx->n_var;
 
   // novel hash table: at most kMaxEv novel events per mate, load factor <= 0.5, >= 2^16 slots
   uint32_t log2cap = 16;
@@ -423,6 +423,31 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
     gk_tab_destroy(tab);
     return GK_ERR_CAPACITY;
   }
+  *out = tab;
+  return GK_OK;
+}
+
+int gk_tab_from_csr(gk_ctx* ctx, int32_t n_var_total, int64_t n_valid, const uint32_t* off, const uint32_t* ids,
+                    const uint8_t* pair_gene, const uint8_t* pair_nh, gk_tab** out) {
+  GK_REQUIRE(ctx && out && off && pair_gene && pair_nh && n_valid >= 0 && n_var_total >= 0, "bad CSR arguments");
+  const int64_t n_ids = off[4 * n_valid];
+  for (int64_t i = 0; i < 4 * n_valid; ++i) GK_REQUIRE(off[i] <= off[i + 1], "CSR offsets must be non-decreasing");
+  for (int64_t i = 0; i < n_ids; ++i) GK_REQUIRE(ids[i] < (uint32_t)n_var_total, "variant ordinal out of range");
+  gk_tab* tab = new gk_tab();
+  tab->ctx = ctx; tab->n_pairs = n_valid; tab->n_valid = n_valid; tab->n_ids = n_ids;
+  tab->n_var = n_var_total; tab->n_novel = 0;
+  hipStream_t st = ctx->stream;
+  GK_HIP(hipMalloc((void**)&tab->d_off, (size_t)(4 * n_valid + 1) * sizeof(uint32_t)));
+  GK_HIP(hipMalloc((void**)&tab->d_ids, (size_t)(n_ids + 1) * sizeof(uint32_t)));
+  GK_HIP(hipMalloc((void**)&tab->d_pair_gene, (size_t)n_valid + 1));
+  GK_HIP(hipMalloc((void**)&tab->d_pair_nh, (size_t)n_valid + 1));
+  GK_HIP(hipMemcpyAsync(tab->d_off, off, (size_t)(4 * n_valid + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  if (n_ids) GK_HIP(hipMemcpyAsync(tab->d_ids, ids, (size_t)n_ids * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  if (n_valid) {
+    GK_HIP(hipMemcpyAsync(tab->d_pair_gene, pair_gene, (size_t)n_valid, hipMemcpyHostToDevice, st));
+    GK_HIP(hipMemcpyAsync(tab->d_pair_nh, pair_nh, (size_t)n_valid, hipMemcpyHostToDevice, st));
+  }
+  GK_HIP(hipStreamSynchronize(st));
   *out = tab;
   return GK_OK;
 }

@@ -170,7 +170,7 @@ int gk_select_nonempty(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows,
 
 int gk_variant_count(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, gk_dptr d_cnt) {
   GK_REQUIRE(ctx && tab, "null pointer");
-  const int64_t nv = (int64_t)tab->idx->n_var + tab->n_novel;
+  const int64_t nv = (int64_t)tab->n_var + tab->n_novel;
   uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
   GK_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * nv) * sizeof(uint32_t), ctx->stream));
   if (n_rows)
@@ -182,7 +182,7 @@ int gk_variant_count(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, g
 
 int gk_variant_correct(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag) {
   GK_REQUIRE(ctx && tab, "null pointer");
-  const int64_t nv = (int64_t)tab->idx->n_var + tab->n_novel;
+  const int64_t nv = (int64_t)tab->n_var + tab->n_novel;
   uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
   if (nv)
     hipLaunchKernelGGL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, ctx->stream, cnt, cnt + nv, nv,

@@ -74,6 +74,9 @@ class Tabulation:
 
     @property
     def n_var_total(self) -> int:
+        override = getattr(self, "_id_names", None)
+        if override is not None:
+            return len(override)
         return self.dindex.host.n_variant + self.n_novel
 
     def close(self) -> None:
@@ -124,6 +127,9 @@ class Tabulation:
 
     def idNames(self) -> list[str]:
         """Ordinal -> variant id string for index + novel variants."""
+        override = getattr(self, "_id_names", None)
+        if override is not None:
+            return override
         names = [str(v.id) for v in self.dindex.host.variants]
         names += [f"nv{self.novel_base + r}" for r in range(self.n_novel)]
         return names

@@ -1,0 +1,257 @@
+"""
+Host-side mirror of the tabulation stage interface (``graphkir/hisat2.py``).
+
+Same names and argument meaning as the reference for the functions the
+pipeline calls -- ``getVariants``, ``readPair``, ``filterRead``,
+``extractVariant``, ``extractVariantFromBam``, ``loadReadsAndVariantsData``,
+``writeReadsAndVariantsData``, ``removeMultipleMapped`` -- but the per-pair
+variant walk runs on the GPU (``csrc/gk_tabulate.hip``) over packed records.
+
+``SampleData`` is the in-memory hand-off between tabulation and typing: the
+device CSR plus the variant table.  The reference hands the same information
+over as ``{name}.variant.json`` (hisat2.py:847-866); that file is still
+written/read for compatibility, but typing does not need to go through it.
+"""
+from __future__ import annotations
+
+import json
+import re
+from dataclasses import asdict, dataclass, field
+from typing import Iterable, Iterator, TypedDict
+
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import Device, check, lib
+from .engine import DeviceIndex, Tabulation
+from .index import GkIndex, getVariants  # noqa: F401  (re-export: reference name)
+from .msa2hisat import Variant
+from .packed import InsTable, packPairs
+from .utils import logger
+
+
+@dataclass
+class PairRead:
+    """One read pair with its positive / negative variant ids (hisat2.py:24-52)."""
+
+    l_sam: str = ""
+    r_sam: str = ""
+    multiple: int = 1
+    backbone: str = ""
+    lpv: list[str] = field(default_factory=list)
+    lnv: list[str] = field(default_factory=list)
+    rpv: list[str] = field(default_factory=list)
+    rnv: list[str] = field(default_factory=list)
+
+
+class ReadsAndVariantsData(TypedDict):
+    variants: list[Variant]
+    reads: list[PairRead]
+
+
+# ---------------------------------------------------------------- text side
+def getNH(sam_info: str) -> int:
+    m = re.search(r"NH:i:(\d+)", sam_info)
+    return int(m.group(1)) if m else 1
+
+
+def readSamLines(sam_file: str) -> Iterator[str]:
+    """Name-collated SAM text (what ``samtools sort -n -O SAM`` prints, hisat2.py:103-110)."""
+    import gzip
+    opener = gzip.open if sam_file.endswith(".gz") else open
+    with opener(sam_file, "rt") as f:
+        for line in f:
+            yield line.rstrip("\n")
+
+
+def readBam(bam_file: str) -> Iterable[str]:
+    """``.sam`` / ``.sam.gz`` are read directly; ``.bam`` goes through samtools like the reference."""
+    if bam_file.endswith((".sam", ".sam.gz")):
+        return readSamLines(bam_file)
+    from .external_tools import runTool
+    proc = runTool("samtools", ["samtools", "sort", "-n", bam_file, "-O", "SAM"], capture_output=True)
+    return str(proc.stdout).split("\n")
+
+
+def pairLines(lines: Iterable[str]) -> Iterator[tuple[str, str]]:
+    """Mate pairing of ``readPair`` (hisat2.py:228-276) on an iterable of SAM lines."""
+    waiting: dict[tuple[str, str, str, int], str] = {}
+    n_reads = n_pairs = 0
+    for line in lines:
+        if not line or line.startswith("@") or line.startswith("[bam_sort_core]"):
+            continue
+        f = line.split("\t", 8)
+        if f[6] != "=":
+            continue
+        n_reads += 1
+        flag = int(f[1])
+        sec = flag & 256
+        want = (f[0], f[2], f[7], sec)
+        mate = waiting.get(want)
+        if mate is None:
+            waiting[(f[0], f[2], f[3], sec)] = line
+            continue
+        if (int(mate.split("\t", 2)[1]) | flag) & 192 != 192:
+            logger.warning(f"[Graph] Read Pair strange case: {line} {mate}")
+            continue
+        del waiting[want]
+        n_pairs += 1
+        yield line, mate
+    logger.info(f"[Graph] Reads: {n_reads} Pairs: {n_pairs}")
+
+
+def readPair(bam_file: str) -> Iterator[tuple[str, str]]:
+    return pairLines(readBam(bam_file))
+
+
+def filterRead(line: str, num_editdist: int = 4) -> bool:
+    """Concordant pair flag and NM <= 4 (hisat2.py:541-578); the device applies the same test."""
+    cols = line.strip().split("\t")
+    if not int(cols[1]) & 2:
+        return False
+    nm = None
+    for c in cols[11:]:
+        if c.startswith("NM"):
+            nm = int(c[5:])
+    return nm is not None and nm <= num_editdist
+
+
+# ---------------------------------------------------------------- device hand-off
+class SampleData:
+    """Tabulated sample: device CSR (``Tabulation``) + variant table + gene tables."""
+
+    def __init__(self, tab: Tabulation, index: GkIndex, novel: list[Variant], pairs_text=None):
+        self.tab, self.index, self.novel = tab, index, novel
+        self.pairs_text = pairs_text  # [(l_sam, r_sam)] of the input pairs, when available
+        self._reads = None
+
+    @property
+    def variants(self) -> list[Variant]:
+        return self.index.variants + self.novel
+
+    def variantsOfGene(self, gene: str) -> list[Variant]:
+        g = self.index.gene_id.get(gene)
+        out = []
+        if g is not None:
+            t = self.index.tables[g]
+            out = self.index.variants[t.vbeg:t.vend]
+        return out + [v for v in self.novel if v.ref == gene]
+
+    def reads(self) -> list[PairRead]:
+        """Materialise ``PairRead`` objects (outputs / API parity; not on the typing path)."""
+        if self._reads is None:
+            tab = self.tab
+            off, ids = tab.offsets().astype(np.int64), tab.ids()
+            names = np.array(tab.idNames(), dtype=object)
+            genes, nh = tab.pairGene(), tab.pairNH()
+            src = tab.pairSrc() if tab.info.d_pair_src else np.arange(tab.n_valid)
+            out = []
+            for i in range(tab.n_valid):
+                o = off[4 * i:4 * i + 5]
+                l_sam = r_sam = ""
+                if self.pairs_text is not None:
+                    l_sam, r_sam = self.pairs_text[int(src[i])]
+                out.append(PairRead(
+                    l_sam=l_sam, r_sam=r_sam, multiple=int(nh[i]), backbone=self.index.genes[int(genes[i])],
+                    lpv=list(names[ids[o[0]:o[1]]]), rpv=list(names[ids[o[1]:o[2]]]),
+                    lnv=list(names[ids[o[2]:o[3]]]), rnv=list(names[ids[o[3]:o[4]]])))
+            self._reads = out
+        return self._reads
+
+    def asDict(self) -> ReadsAndVariantsData:
+        return {"variants": self.variants, "reads": self.reads()}
+
+    @classmethod
+    def fromHost(cls, dev: Device, data: ReadsAndVariantsData) -> "SampleData":
+        """Upload ``{"variants", "reads"}`` (e.g. a loaded ``.variant.json``) as a device CSR."""
+        known = sorted(v for v in data["variants"] if not str(v.id).startswith("nv"))
+        novel = [v for v in data["variants"] if str(v.id).startswith("nv")]
+        genes = sorted(set(v.ref for v in data["variants"]) | set(r.backbone for r in data["reads"]))
+        index = GkIndex.fromVariants(known, genes=genes)
+        ordinal = {str(v.id): i for i, v in enumerate(index.variants + novel)}
+        reads = data["reads"]
+        n = len(reads)
+        off = np.zeros(4 * n + 1, dtype=np.uint32)
+        flat: list[int] = []
+        for i, r in enumerate(reads):
+            for k, lst in enumerate((r.lpv, r.rpv, r.lnv, r.rnv)):
+                flat.extend(ordinal[v] for v in lst)
+                off[4 * i + k + 1] = len(flat)
+        ids = np.array(flat, dtype=np.uint32)
+        gene = np.array([index.gene_id[r.backbone] for r in reads], dtype=np.uint8)
+        nh = np.array([min(int(r.multiple), 255) for r in reads], dtype=np.uint8)
+        dindex = DeviceIndex(dev, index)
+        tab = Tabulation.__new__(Tabulation)
+        tab.dev, tab.dindex, tab.mates, tab.n_pairs = dev, dindex, None, n
+        h = C.c_void_p()
+        check(lib().gk_tab_from_csr(dev.ctx, len(ordinal), n, off.ctypes.data, ids.ctypes.data if len(ids) else None,
+                                    gene.ctypes.data if n else None, nh.ctypes.data if n else None, C.byref(h)))
+        tab.handle = h
+        info = _lib.TabInfo()
+        check(lib().gk_tab_get_info(h, C.byref(info)))
+        tab.info = info
+        tab.n_valid, tab.n_ids = n, int(info.n_ids)
+        tab.n_novel, tab.novel_base, tab._novel_keys = len(novel), 0, None
+        tab._id_names = [str(v.id) for v in index.variants + novel]
+        self = cls(tab, index, novel)
+        self._reads = list(reads)
+        return self
+
+
+def extractVariant(pair_reads: Iterable[tuple[str, str]], index: GkIndex | list[Variant], dev: Device | None = None,
+                   dindex: DeviceIndex | None = None, pileup=None) -> SampleData:
+    """SAM pairs -> tabulated sample on the device (extractVariant, hisat2.py:803-844).
+
+    Pairs are decoded to packed records on the host, then filterRead + the variant walk +
+    positive/negative extraction run in ``gk_tabulate``.
+    """
+    if pileup is not None:
+        raise NotImplementedError("pileup error correction is disabled in the CLI (graphkir/main.py:149); "
+                                  "not implemented on the device path")
+    if not isinstance(index, GkIndex):
+        index = GkIndex.fromVariants(index)
+    dev = dev or Device()
+    dindex = dindex or DeviceIndex(dev, index)
+    pairs = list(pair_reads)
+    rec, table = packPairs(pairs, index)
+    base = Variant.novel_id
+    tab = Tabulation(dindex, rec, novel_base=base)
+    novel = tab.novelVariants(table.strings)
+    Variant.novel_id = base + tab.n_novel
+    logger.info(f"[Graph] Filterd pairs: {tab.n_valid}")
+    return SampleData(tab, index, novel, pairs_text=pairs)
+
+
+def writeReadsAndVariantsData(reads_data: ReadsAndVariantsData, filename: str) -> None:
+    with open(filename, "w") as f:
+        json.dump({"variants": [asdict(v) for v in reads_data["variants"]],
+                   "reads": [asdict(r) for r in reads_data["reads"]]}, f)
+
+
+def loadReadsAndVariantsData(filename: str) -> ReadsAndVariantsData:
+    with open(filename) as f:
+        raw = json.load(f)
+    return {"variants": [Variant(**v) for v in raw["variants"]],
+            "reads": [PairRead(**r) for r in raw["reads"]]}
+
+
+def removeMultipleMapped(reads_data: ReadsAndVariantsData) -> ReadsAndVariantsData:
+    return {"variants": reads_data["variants"],
+            "reads": [r for r in reads_data["reads"] if r.multiple == 1]}
+
+
+def extractVariantFromBam(index: str, bam_file: str, output_prefix: str, error_correction: bool = True,
+                          dev: Device | None = None) -> SampleData:
+    """index + name-sorted alignments -> ``{output_prefix}.json`` (hisat2.py:904-940).
+
+    The filtered ``.bam`` / ``.no_multi.bam`` rewrites of the reference need samtools; when the
+    input is SAM text they are written as ``.sam`` / ``.no_multi.sam`` instead.
+    """
+    if error_correction:
+        raise NotImplementedError("error_correction=True (pileup) is not implemented; the CLI passes False")
+    gk = GkIndex.load(index)
+    data = extractVariant(readPair(bam_file), gk, dev=dev)
+    logger.debug(f"[Graph] Save allele per reads in {output_prefix}.json")
+    writeReadsAndVariantsData(data.asDict(), f"{output_prefix}.json")
+    return data

@@ -1,0 +1,204 @@
+"""
+Strategy plug-in surface of the typing stage -- drop-in for ``graphkir/kir_typing.py``.
+
+``selectKirTypingModel(method, filename_variant_json, **kwargs)`` (207-228) keeps its signature;
+``filename_variant_json`` may also be a ``hisat2.SampleData`` that is already on the device (the
+pipeline passes that, skipping the JSON round trip).  Methods: ``full`` (alias ``pv``),
+``exonfirst[_<threshold>]`` (alias ``pv_exonfirst_<threshold>``), ``em`` (alias ``report`` -- the
+reference CLI forwards ``report`` to a factory that does not know it, main.py:192 / kir_typing.py:228).
+"""
+from __future__ import annotations
+
+import json
+from typing import Any
+
+import numpy as np
+
+from ._lib import Device
+from .hisat2 import SampleData, loadReadsAndVariantsData
+from .typing_em import Hisat2AlleleResult, hisat2TypingPerGene
+from .typing_mulit_allele import (AlleleTyping, AlleleTypingExonFirst, ReadSet, isHetrozygous,
+                                  sharedLogTable)
+from .utils import NumpyEncoder, logger
+
+_device: Device | None = None
+
+
+def defaultDevice() -> Device:
+    """One context per process (LOCAL_RANK picks the GPU)."""
+    global _device
+    if _device is None:
+        _device = Device()
+    return _device
+
+
+def _sample(source, dev: Device | None) -> SampleData:
+    if isinstance(source, SampleData):
+        return source
+    return SampleData.fromHost(dev or defaultDevice(), loadReadsAndVariantsData(source))
+
+
+class Typing:
+    """Common driver: loop genes of the CN table, collect calls and low-depth warnings (31-74)."""
+
+    def __init__(self) -> None:
+        self._result: dict[str, Any] = {}
+
+    def typingPerGene(self, gene: str, cn: int) -> tuple[list[str], int]:
+        raise NotImplementedError
+
+    def typing(self, gene_cn: dict[str, int], min_reads_num: int = 100) -> tuple[list[str], list[str]]:
+        predict_alleles, warning_genes = [], []
+        for gene, cn in gene_cn.items():
+            if not cn:
+                continue
+            alleles, reads_num = self.typingPerGene(gene, int(cn))
+            predict_alleles.extend(alleles)
+            if reads_num < min_reads_num:
+                warning_genes.append(gene)
+        return predict_alleles, warning_genes
+
+    def save(self, filename: str) -> None:
+        with open(filename, "w") as f:
+            json.dump(self._result, f, cls=NumpyEncoder)
+
+    def getAllPossibleTyping(self) -> list[dict[Any, Any]]:
+        raise NotImplementedError
+
+
+class _GeneView:
+    """Per-gene handles into a tabulated sample."""
+
+    def __init__(self, data: SampleData, gene: str, multiple: bool):
+        self.data, self.gene = data, gene
+        idx = data.index
+        g = idx.gene_id.get(gene)
+        self.g = g
+        tab = data.tab
+        if g is None:
+            self.rows, self.n_rows = tab.dev.alloc(1, np.int32), 0
+            self.vbeg = self.n_span = 0
+            self.mask, self.alleles, self.variants = None, [], []
+            return
+        t = idx.tables[g]
+        self.rows, self.n_rows = tab.selectGene(g, multiple)
+        self.vbeg, self.n_span = t.vbeg, t.vend - t.vbeg
+        self.mask = tab.dindex.masks[g]
+        self.alleles = t.alleles
+        self.variants = data.variantsOfGene(gene)
+
+    def exonFlags(self) -> np.ndarray:
+        idx, tab = self.data.index, self.data.tab
+        flags = np.full(tab.n_var_total, 3, dtype=np.uint8)
+        flags[:idx.n_variant][idx.in_exon.astype(bool)] = 0
+        return flags
+
+
+class TypingWithPosNegAllele(Typing):
+    """Likelihood typing with positive / negative variants (77-150)."""
+
+    def __init__(self, filename_variant_json, top_n: int = 300, multiple: bool = False, exon_first: bool = False,
+                 exon_only: bool = False, exon_candidate_threshold: float = .9, variant_correction: bool = False,
+                 device: Device | None = None):
+        super().__init__()
+        self._data = _sample(filename_variant_json, device)
+        self._multiple = multiple
+        self._top_n = top_n
+        self._exon_first, self._exon_only = exon_first, exon_only
+        self._exon_candidate_threshold = exon_candidate_threshold
+        self._variant_correction = variant_correction
+        self._logs = sharedLogTable(self._data.tab.dev)
+
+    def typingPerGene(self, gene: str, cn: int) -> tuple[list[str], int]:
+        logger.debug(f"[Allele] {gene=} {cn=}")
+        force_homo = False if isHetrozygous(gene) else None
+        view = _GeneView(self._data, gene, self._multiple)
+        pure_gene = gene.split("*")[0]
+        if view.g is None or not view.alleles:
+            # gene absent from the sample's variants: the reference yields "fail" calls (or crashes
+            # in createHomoResult for cn >= 2 with automatic zygosity; soft-fail here)
+            self._result[gene] = []
+            return [f"{pure_gene}*"] * cn, 0
+        reads = ReadSet(self._data.tab, view.rows, view.n_rows)
+        if not self._exon_first and not self._exon_only:
+            typ: AlleleTyping = AlleleTyping(
+                reads, view.variants, force_homo=force_homo, top_n=self._top_n,
+                variant_correction=self._variant_correction, logs=self._logs, _vbeg=view.vbeg,
+                _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles)
+        else:
+            typ = AlleleTypingExonFirst(
+                reads, view.variants, force_homo=force_homo, top_n=self._top_n, exon_only=self._exon_only,
+                candidate_set_threshold=self._exon_candidate_threshold, logs=self._logs, _vbeg=view.vbeg,
+                _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles, _exon_flags=view.exonFlags())
+        res = typ.typing(cn)
+        self._result[gene] = typ.result
+        alleles = [a if a != "fail" else f"{pure_gene}*" for a in res.selectBest()]
+        return alleles, typ.getReadsNum()
+
+    def getAllPossibleTyping(self) -> list[dict[Any, Any]]:
+        rows = []
+        for gene, result in self._result.items():
+            if not result:
+                continue
+            for rank, (value, alleles) in enumerate(result[-1].selectAllPossible(.9)):
+                row = {"gene": gene, "rank": rank, "value": value}
+                for i, allele in enumerate(alleles):
+                    row[str(i + 1)] = allele
+                rows.append(row)
+        return rows
+
+
+class TypingWithReport(Typing):
+    """Abundance typing by the HISAT-genotype EM (153-204)."""
+
+    def __init__(self, filename_variant_json, device: Device | None = None):
+        super().__init__()
+        self._data = _sample(filename_variant_json, device)
+
+    def typingPerGene(self, gene: str, cn: int) -> tuple[list[str], int]:
+        view = _GeneView(self._data, gene, multiple=False)
+        pure_gene = gene.split("*")[0]
+        report: list[Hisat2AlleleResult] = []
+        if view.g is not None and view.alleles and view.n_rows:
+            t = self._data.index.tables[view.g]
+            report = hisat2TypingPerGene(self._data.tab, view.rows, view.n_rows, view.vbeg, view.vbeg + view.n_span,
+                                         view.mask, t.words, view.alleles)
+        # descending abundance; ties by allele name (the reference leaves them to set order)
+        report.sort(key=lambda r: (-r.prob, r.allele))
+        if not report:
+            self._result[gene] = report
+            return [f"{pure_gene}*"] * cn, view.n_rows   # the reference raises AxisError here
+        est_prob = 1 / cn
+        called = []
+        for rec in report:
+            pred = max(1, round(rec.prob / est_prob))
+            called.extend([rec.allele] * min(cn, pred))
+            rec.cn = pred
+            cn -= pred
+            if cn <= 0:
+                break
+        self._result[gene] = report
+        return called, view.n_rows
+
+    def getAllPossibleTyping(self) -> list[dict[Any, Any]]:
+        raise NotImplementedError
+
+
+def selectKirTypingModel(method: str, filename_variant_json, **kwargs: Any) -> Typing:
+    """Select and initialise the typing strategy (207-228)."""
+    if method in ("full", "pv"):
+        return TypingWithPosNegAllele(filename_variant_json, **kwargs)
+    if method.startswith("pv_exonfirst"):
+        method = method[len("pv_"):]
+    if method.startswith("exonfirst"):
+        fields = method.split("_")
+        threshold = 0.0
+        if len(fields) == 2:
+            threshold = float(method[len("exonfirst_"):])
+        return TypingWithPosNegAllele(filename_variant_json, exon_first=True,
+                                      exon_candidate_threshold=threshold, **kwargs)
+    if method in ("em", "report"):
+        kwargs.pop("top_n", None)
+        kwargs.pop("variant_correction", None)
+        return TypingWithReport(filename_variant_json, **kwargs)
+    raise NotImplementedError

@@ -1,0 +1,621 @@
+"""
+Multi-allele likelihood typing on the GPU -- drop-in for
+``graphkir/typing_mulit_allele.py`` (the file name keeps the reference's spelling).
+
+Same classes and attributes as the reference (``TypingResult``, ``AlleleTyping``,
+``AlleleTypingExonFirst``, ``isHetrozygous``, ``isHomozygous``; attributes
+``probs / log_probs / reads / variants / allele_to_id / id_to_allele / result /
+top_n`` that ``novel_discover.py:58-64,273-274`` reads), but:
+
+* reads x alleles tables live in HBM (``engine.DeviceModel``); ``probs`` /
+  ``log_probs`` / ``allele_prob`` are fetched only when somebody asks;
+* the T x R x A temporary of ``addCandidate`` (540-542) never exists: the
+  device forms ``max`` and the read reduction in one pass with numpy's
+  summation tree, the host only ranks T x A scores with the same numpy calls
+  as the reference (``argsort``), so ties break identically;
+* the per-set statistics (569-580) are computed without the R x K x CN gathers.
+
+Host work per copy-number step is O(T x A) numpy, never O(reads).
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from dataclasses import dataclass, field
+from itertools import chain
+from typing import Iterable, Optional
+
+import numpy as np
+
+from ._lib import Device, DeviceBuffer
+from .engine import DeviceModel, LogTable, Tabulation
+from .index import buildMask
+from .msa2hisat import Variant
+from .utils import logger
+
+_default_logs: dict[int, LogTable] = {}
+
+
+def sharedLogTable(dev: Device) -> LogTable:
+    """One log10 value table per device context (values recur across genes and samples)."""
+    t = _default_logs.get(id(dev))
+    if t is None:
+        t = _default_logs[id(dev)] = LogTable(dev)
+    return t
+
+
+@dataclass
+class TypingResult:
+    """Result of one copy-number step (typing_mulit_allele.py:27-58)."""
+
+    n: int
+    value: np.ndarray
+    value_sum_indv: np.ndarray
+    allele_id: np.ndarray
+    allele_name: list[list[str]]
+    allele_prob: "np.ndarray | LazyAlleleProb"
+    fraction: np.ndarray
+    fraction_uniq: np.ndarray
+    allele_name_group: list[list[list[str]]] = field(default_factory=list)
+
+    def isFail(self) -> bool:
+        return not len(self.value)
+
+    def selectBest(self, filter_fraction: bool = True, filter_minor: bool = False) -> list[str]:
+        ids: Iterable[int] = range(len(self.fraction))
+        if filter_fraction:
+            floor = (1 / self.n) / 2
+            ids = [i for i in ids if all(f >= floor for f in self.fraction[i])]
+        if filter_minor:
+            ids = [i for i in ids
+                   if np.abs(self.value_sum_indv[i]).min() / np.abs(self.value_sum_indv[i]).max() > 0.8]
+        best = (list(ids) or [0])[0]
+        if not self.isFail():
+            logger.debug(f"[Allele] Select best rank: {best}")
+            assert len(self.allele_name[best]) == self.n
+            return self.allele_name[best]
+        logger.warning("[Allele] No candidates found. Return fail")
+        return ["fail"] * self.n
+
+    def print(self, num: int = 100, top_threshold: float = 0.9) -> None:
+        if self.isFail():
+            print("Fail Alleles:", ["fail"] * self.n)   # the reference prints this to stdout (line 125)
+            return
+        if not logger.isEnabledFor(10):
+            return
+        lines = [f"Allele_num =  {self.n}"]
+        for k, rank in enumerate(self.topRank(top_threshold)):
+            if k > num:
+                break
+            lines.append(f"Rank {rank} probility {self.value[rank]} sum {self.value_sum_indv[rank].sum()}")
+            for i in range(self.n):
+                lines.append(f"  id {self.allele_id[rank][i]:3}   name {self.allele_name[rank][i]:20s}"
+                             f"   fraction {self.fraction[rank][i]:.5f}   sum {self.value_sum_indv[rank][i]:8.3f}")
+        logger.debug("[Allele] " + "\n".join(lines))
+
+    def setNameGroup(self, allele_group_mapping: dict[str, list[str]]) -> None:
+        self.allele_name_group = [[allele_group_mapping[a] for a in row] for row in self.allele_name]
+
+    def sortByScoreAndEveness(self, preserve_topn: int = -1) -> "TypingResult":
+        if preserve_topn == -1:
+            preserve_topn = self.value.shape[0]
+        order = rankScore(self.value, self.value_sum_indv, self.fraction)[:preserve_topn]
+        return TypingResult(
+            n=self.n, value=self.value[order], value_sum_indv=self.value_sum_indv[order],
+            allele_id=self.allele_id[order], allele_name=[self.allele_name[i] for i in order],
+            allele_prob=takeColumns(self.allele_prob, order),
+            fraction=self.fraction[order], fraction_uniq=self.fraction_uniq[order])
+
+    def topRank(self, threshold: float = 0.9) -> Iterable[int]:
+        assert not self.isFail()
+        best = self.value[0]
+        return [0] + [int(i) for i in np.nonzero(self.value[1:] * threshold >= best)[0] + 1]
+
+    def selectAllPossible(self, threshold: float = 0.9) -> list[tuple[float, list[str]]]:
+        if self.isFail():
+            return []
+        return [(self.value[r], self.allele_name[r]) for r in self.topRank(threshold)]
+
+
+class LazyAlleleProb:
+    """``allele_prob`` (reads x sets) evaluated on the device only when it is read."""
+
+    def __init__(self, parts: list[tuple[DeviceModel, np.ndarray]]):
+        self.parts = parts  # [(model, ids [k x c])] concatenated along sets
+
+    @property
+    def shape(self) -> tuple[int, int]:
+        return (self.parts[0][0].n_rows, sum(len(ids) for _, ids in self.parts))
+
+    def __array__(self, dtype=None, copy=None):
+        cols = [m.setmax(ids) for m, ids in self.parts if len(ids)]
+        out = np.concatenate(cols, axis=1) if cols else np.zeros((0, 0))
+        return out.astype(dtype) if dtype is not None else out
+
+
+def takeColumns(prob, order: np.ndarray):
+    if not isinstance(prob, LazyAlleleProb):
+        return prob[:, order]
+    bounds = np.cumsum([0] + [len(ids) for _, ids in prob.parts])
+    parts = []
+    # keep the requested order: one part per run of consecutive picks from the same source
+    for o in order:
+        k = int(np.searchsorted(bounds, o, side="right") - 1)
+        m, ids = prob.parts[k]
+        row = ids[o - bounds[k]][None, :]
+        if parts and parts[-1][0] is m:
+            parts[-1] = (m, np.concatenate([parts[-1][1], row]))
+        else:
+            parts.append((m, row))
+    return LazyAlleleProb(parts or [(prob.parts[0][0], prob.parts[0][1][:0])])
+
+
+def rankScore(value: np.ndarray, value_sum_indv: np.ndarray, fraction: np.ndarray) -> np.ndarray:
+    """Stable order by (-value, -sum of per-allele sums, abundance unevenness) (202-214).
+
+    ``np.lexsort`` is a stable multi-key sort, i.e. the same order as Python's ``sorted`` on the
+    key tuples that the reference uses.
+    """
+    uneven = np.abs(fraction - fraction.mean(axis=1, keepdims=True)).sum(axis=1)
+    return np.lexsort((uneven, -value_sum_indv.sum(axis=1), -value))
+
+
+def firstOccurrence(ids: np.ndarray, n_allele: int) -> np.ndarray:
+    """Mask of the first occurrence of every allele multiset (uniqueAllele 456-476), vectorised."""
+    srt = np.sort(ids, axis=1).astype(np.int64)
+    bits = max(1, int(n_allele - 1).bit_length())
+    if bits * ids.shape[1] > 62:
+        seen, keep = set(), np.zeros(len(ids), dtype=bool)
+        for i, row in enumerate(map(tuple, srt)):
+            keep[i] = row not in seen
+            seen.add(row)
+        return keep
+    key = np.zeros(len(ids), dtype=np.int64)
+    for j in range(ids.shape[1]):
+        key = (key << bits) | srt[:, j]
+    _, first = np.unique(key, return_index=True)
+    keep = np.zeros(len(ids), dtype=bool)
+    keep[first] = True
+    return keep
+
+
+# ---------------------------------------------------------------- device read set
+class ReadSet:
+    """Ordered reads of one gene on the device: row list + variant drop flags."""
+
+    def __init__(self, tab: Tabulation, rows: DeviceBuffer, n_rows: int, vflag: DeviceBuffer | None = None):
+        self.tab, self.rows, self.n_rows = tab, rows, n_rows
+        self.vflag = vflag if vflag is not None else tab.dev.alloc(max(tab.n_var_total, 1), np.uint8).zero()
+
+    @classmethod
+    def fromLists(cls, dev: Device, reads, variants: list[Variant]) -> tuple["ReadSet", dict[str, int]]:
+        """Upload host ``PairRead`` lists (drop-in constructor path)."""
+        import ctypes as C
+        from . import _lib
+        from ._lib import check, lib
+        ordinal = {str(v.id): i for i, v in enumerate(variants)}
+        n = len(reads)
+        off = np.zeros(4 * n + 1, dtype=np.uint32)
+        flat: list[int] = []
+        for i, r in enumerate(reads):
+            for k, lst in enumerate((r.lpv, r.rpv, r.lnv, r.rnv)):
+                flat.extend(ordinal[v] for v in lst)
+                off[4 * i + k + 1] = len(flat)
+        ids = np.array(flat, dtype=np.uint32)
+        zeros = np.zeros(max(n, 1), dtype=np.uint8)
+        ones = np.ones(max(n, 1), dtype=np.uint8)
+        tab = Tabulation.__new__(Tabulation)
+        tab.dev, tab.dindex, tab.mates, tab.n_pairs = dev, None, None, n
+        h = C.c_void_p()
+        check(lib().gk_tab_from_csr(dev.ctx, max(len(variants), 1), n, off.ctypes.data,
+                                    ids.ctypes.data if len(ids) else None, zeros.ctypes.data, ones.ctypes.data,
+                                    C.byref(h)))
+        tab.handle = h
+        info = _lib.TabInfo()
+        check(lib().gk_tab_get_info(h, C.byref(info)))
+        tab.info, tab.n_valid, tab.n_ids = info, n, int(info.n_ids)
+        tab.n_novel, tab.novel_base, tab._novel_keys = 0, 0, None
+        tab._id_names = [str(v.id) for v in variants] or ["-"]
+        rows = dev.put(np.arange(max(n, 1), dtype=np.int32))
+        return cls(tab, rows, n), ordinal
+
+    def copyFlags(self) -> DeviceBuffer:
+        from ._lib import check, lib
+        out = self.tab.dev.alloc(self.vflag.shape, np.uint8)
+        check(lib().gk_d2d(self.tab.dev.ctx, out.ptr, self.vflag.ptr, self.vflag.nbytes))
+        return out
+
+    def hostReads(self, template=None) -> list:
+        """Surviving reads with surviving ids as ``PairRead`` objects (API parity)."""
+        from .hisat2 import PairRead
+        tab = self.tab
+        rows = self.rows.download(self.n_rows) if self.n_rows else np.zeros(0, np.int32)
+        off, ids = tab.offsets().astype(np.int64), tab.ids()
+        flag = self.vflag.download()
+        names = np.array(tab.idNames(), dtype=object)
+        out = []
+        for r in rows:
+            o = off[4 * r:4 * r + 5]
+            lists = []
+            for k, bit in ((0, 1), (1, 1), (2, 2), (3, 2)):
+                seg = ids[o[k]:o[k + 1]]
+                lists.append(list(names[seg[(flag[seg] & bit) == 0]]))
+            base = template[int(r)] if template is not None else None
+            out.append(PairRead(l_sam=getattr(base, "l_sam", ""), r_sam=getattr(base, "r_sam", ""),
+                                multiple=getattr(base, "multiple", 1), backbone=getattr(base, "backbone", ""),
+                                lpv=lists[0], rpv=lists[1], lnv=lists[2], rnv=lists[3]))
+        return out
+
+
+class AlleleTyping:
+    """Likelihood model and greedy multi-allele search of one gene (217-619).
+
+    Ordinal convention: the read lists hold variant ordinals of the owning ``Tabulation``;
+    ``variants[:n_span]`` are the variants with ordinals ``[vbeg, vbeg + n_span)`` (for a list-built
+    model that is simply every variant, ``vbeg = 0``); ordinals outside carry no allele (novel).
+    """
+
+    def __init__(self, reads, variants: list[Variant], force_homo: bool | None = None, top_n: int = 300,
+                 no_empty: bool = True, variant_correction: bool = True, *, device: Device | None = None,
+                 logs: LogTable | None = None, _vbeg: int = 0, _n_span: int | None = None,
+                 _mask: DeviceBuffer | None = None, _alleles: list[str] | None = None, _defer_log: bool = False):
+        self.top_n = top_n
+        self._no_empty = no_empty
+        self.force_homo = force_homo
+        if not no_empty:
+            raise NotImplementedError("no_empty=False is not used by the pipeline and not implemented on the device")
+        self.variants: dict[str, Variant] = {str(v.id): v for v in variants}
+        names = _alleles if _alleles is not None else sorted(self.collectAlleleNames(variants))
+        self.id_to_allele: dict[int, str] = dict(enumerate(names))
+        self.allele_to_id: dict[str, int] = {a: i for i, a in self.id_to_allele.items()}
+        self.result: list[TypingResult] = []
+
+        if isinstance(reads, ReadSet):
+            rs = reads
+            self._template = None
+        else:
+            device = device or Device()
+            self._template = list(reads)
+            rs, _ = ReadSet.fromLists(device, self._template, variants)
+        self._dev = rs.tab.dev
+        self._logs = logs or sharedLogTable(self._dev)
+        tab = rs.tab
+        if variant_correction:
+            tab.errorCorrection(rs.rows, rs.n_rows, rs.vflag)
+        rows, n_rows = tab.selectNonEmpty(rs.rows, rs.n_rows, rs.vflag)
+        self._readset = ReadSet(tab, rows, n_rows, rs.vflag)
+        n_allele = len(names)
+        words = max(1, (n_allele + 31) // 32)
+        n_span = len(variants) if _n_span is None else _n_span
+        if _mask is None:
+            _mask = self._dev.put(buildMask(variants[:n_span], names))
+        self._model = DeviceModel(tab, rows, n_rows, rs.vflag, _vbeg, _vbeg + n_span, _mask, words, n_allele,
+                                  self._logs)
+        self._colsum_all: np.ndarray | None = None
+        self._reads_cache = None
+        if not _defer_log:
+            self.finish()
+        if n_rows == 0:
+            logger.warning("[Allele] Error: Empty reads for typing (or Maybe read depth is too low)")
+
+    def finish(self) -> None:
+        """Complete construction after the shared log table has been resolved."""
+        self._logs.resolve()
+        self._model.finishLog()
+
+    # ---- reference attribute surface (lazy)
+    @property
+    def probs(self) -> np.ndarray:
+        return self._model.hostProbs()
+
+    @property
+    def log_probs(self) -> np.ndarray:
+        return self._model.hostLogProbs()
+
+    @property
+    def reads(self) -> list:
+        if self._reads_cache is None:
+            self._reads_cache = self._readset.hostReads(self._template)
+        return self._reads_cache
+
+    def getReadsNum(self) -> int:
+        return self._model.n_rows
+
+    @staticmethod
+    def collectAlleleNames(variants: list[Variant]) -> set[str]:
+        return set(chain.from_iterable(v.allele for v in variants))
+
+    def mapAlleleIDs(self, list_ids: np.ndarray) -> list[list[str]]:
+        return [[self.id_to_allele[int(i)] for i in ids] for ids in list_ids]
+
+    def fork(self) -> "AlleleTyping":
+        """Fresh search state on the same device tables (stands in for ``copy.deepcopy``, line 742)."""
+        other = object.__new__(type(self))
+        other.__dict__.update(self.__dict__)
+        other.result = []
+        return other
+
+    # ---- search
+    def typing(self, cn: int) -> TypingResult:
+        if cn < 1:
+            raise ValueError(f"CN should be >= 1, got {cn}")
+        homo = self._isHomozygous(cn) if self.force_homo is None else self.force_homo
+        self.result = []
+        if homo:
+            self.addCandidate()
+            self.addHomoResultForCn(cn)
+        else:
+            for _ in range(cn):
+                self.addCandidate()
+        self.result[-1].print()
+        return self.result[-1]
+
+    def addHomoResultForCn(self, cn: int) -> None:
+        if cn > 1:
+            self.result.append(self.createHomoResult(self.result[0], cn))
+
+    @staticmethod
+    def createHomoResult(cn1_result: TypingResult, cn: int) -> TypingResult:
+        if cn <= 1:
+            raise ValueError(f"CN should be > 1, got {cn}")
+        if cn1_result.isFail():
+            # documented deviation: the reference raises numpy.AxisError here
+            e = np.array([])
+            return TypingResult(cn, e, e, e, [], e, e, e)
+        m = len(cn1_result.value)
+        return TypingResult(
+            n=cn, value=cn1_result.value * cn,
+            value_sum_indv=np.repeat(cn1_result.value_sum_indv, cn, axis=1),
+            allele_id=np.repeat(cn1_result.allele_id, cn, axis=1),
+            allele_name=[[row[0]] * cn for row in cn1_result.allele_name],
+            allele_prob=cn1_result.allele_prob,
+            fraction=np.ones((m, cn)) / cn, fraction_uniq=np.ones((m, cn)) / cn)
+
+    @staticmethod
+    def uniqueAllele(data: np.ndarray) -> np.ndarray:
+        return firstOccurrence(np.asarray(data), int(np.max(data)) + 1 if np.size(data) else 1)
+
+    def _colsums(self) -> np.ndarray:
+        if self._colsum_all is None:
+            self._colsum_all = self._model.colsum(np.arange(self._model.n_allele))
+        return self._colsum_all
+
+    def addCandidate(self, candidate_allele: Optional[list[str]] = None) -> TypingResult:
+        m = self._model
+        if not m.n_rows:
+            logger.warning("[Allele] Empty reads for typing. Skip")
+            e = np.array([])
+            self.result.append(TypingResult(len(self.result) + 1, e, e, e, [], e, e, e))
+            return self.result[-1]
+        if candidate_allele is None:
+            cols = np.arange(m.n_allele)
+        else:
+            cols = np.array([self.allele_to_id[a] for a in candidate_allele])
+
+        if not self.result:
+            score = self._colsums()[cols]                       # = log_probs[:, cols].sum(axis=0)
+            top = np.argsort(score)[::-1][:self.top_n]
+            top_ids = cols[:, None][top]
+            res = TypingResult(
+                n=1, value=score[top], value_sum_indv=score[top][:, None], allele_id=top_ids,
+                allele_name=self.mapAlleleIDs(top_ids), allele_prob=LazyAlleleProb([(m, top_ids)]),
+                fraction=np.ones(top_ids.shape), fraction_uniq=np.ones(top_ids.shape))
+            self.result.append(res)
+            return res
+
+        prev = self.result[-1]
+        prev_ids = np.asarray(prev.allele_id)
+        score = m.maxsum(prev_ids, cols).flatten()
+        ids = np.hstack([np.repeat(prev_ids, len(cols), axis=0), np.tile(cols, len(prev_ids))[:, None]])
+        first = firstOccurrence(ids, m.n_allele)
+        ids, score = ids[first], score[first]
+        top = np.argsort(score)[::-1][:max(self.top_n, score.shape[0] // 5)]
+        top_ids = ids[top]
+        res = TypingResult(
+            n=prev.n + 1, value=score[top],
+            value_sum_indv=self._colsums()[top_ids],            # = log_probs[:, ids].sum(axis=0)
+            allele_id=top_ids, allele_name=[], allele_prob=LazyAlleleProb([(m, top_ids)]),
+            fraction=m.fraction(top_ids), fraction_uniq=np.ones(top_ids.shape))
+        order = rankScore(res.value, res.value_sum_indv, res.fraction)[:self.top_n]
+        kept = top_ids[order]
+        res = TypingResult(
+            n=res.n, value=res.value[order], value_sum_indv=res.value_sum_indv[order], allele_id=kept,
+            allele_name=self.mapAlleleIDs(kept), allele_prob=LazyAlleleProb([(m, kept)]),
+            fraction=res.fraction[order], fraction_uniq=res.fraction_uniq[order])
+        self.result.append(res)
+        return res
+
+    # ---- homozygosity test on device counts
+    def _variantCounts(self) -> tuple[np.ndarray, np.ndarray]:
+        rs = self._readset
+        tab = rs.tab
+        cnt = self._dev.alloc(2 * tab.n_var_total, np.uint32)
+        tab.countVariants(rs.rows, rs.n_rows, rs.vflag, cnt)
+        c = cnt.download()
+        cnt.free()
+        return c[:tab.n_var_total], c[tab.n_var_total:]
+
+    def _isHomozygous(self, cn: int) -> bool:
+        """isHomozygous (807-857) from per-variant positive / negative tallies of the kept reads."""
+        if cn <= 1:
+            return False
+        pos, neg = self._variantCounts()
+        names = self._readset.tab.idNames()
+        site: dict[int, dict[str, int]] = defaultdict(lambda: defaultdict(int))
+        for o in np.nonzero(pos + neg)[0]:
+            v = self.variants.get(names[o])
+            if v is None or v.typ == "deletion":
+                continue
+            if pos[o]:
+                site[v.pos][str(v.val)] += int(pos[o])
+            if neg[o]:
+                site[v.pos][f"*{v.val}"] += int(neg[o])
+        hits = 0
+        for obs in site.values():
+            if len(obs) <= 1 or all("*" in k for k in obs):
+                continue
+            counts = [c for c in sorted(obs.values(), reverse=True) if c > 3]
+            total = sum(counts)
+            if total < 20:
+                continue
+            major = [c / total for c in counts if c / total > 0.1]
+            if len(major) == 1:
+                continue
+            if major[1] > (1 / (cn * 2)):
+                hits += 1
+        return hits == 0
+
+
+class AlleleTypingExonFirst(AlleleTyping):
+    """Exon variants select candidate allele groups, the full model refines them (622-797)."""
+
+    def __init__(self, reads, variants: list[Variant], top_n: int = 300, exon_only: bool = False,
+                 candidate_set_threshold: float = 1.0, variant_correction: bool = True,
+                 force_homo: bool | None = None, *, device: Device | None = None, logs: LogTable | None = None,
+                 _vbeg: int = 0, _n_span: int | None = None, _mask: DeviceBuffer | None = None,
+                 _alleles: list[str] | None = None, _exon_flags: np.ndarray | None = None):
+        if isinstance(reads, ReadSet):
+            base = reads
+            template = None
+        else:
+            device = device or Device()
+            template = list(reads)
+            base, _ = ReadSet.fromLists(device, template, variants)
+        tab = base.tab
+        dev = tab.dev
+        n_span = len(variants) if _n_span is None else _n_span
+        # exon reads = same rows, non-exon ids masked out (removeIntronVariant 703-714)
+        if _exon_flags is None:
+            in_exon = {str(v.id) for v in variants if v.in_exon}
+            _exon_flags = np.array([0 if n in in_exon else 3 for n in tab.idNames()], dtype=np.uint8)
+        exon_flags = dev.put(_exon_flags)
+        if variant_correction:
+            tab.errorCorrection(base.rows, base.n_rows, exon_flags)
+        exon_set = ReadSet(tab, base.rows, base.n_rows, exon_flags)
+
+        # alleles sharing one exon-variant set become one group (649-659)
+        exon_variants = [v for v in variants if v.in_exon]
+        groups = self.aggrVariantsByAllele(exon_variants)
+        rest = self.collectAlleleNames(variants) - self.collectAlleleNames(exon_variants)
+        if rest:
+            groups[tuple()] = sorted(rest)
+        self.allele_group = {"|".join(a): a for a in groups.values()}
+        inverse = self.createInverseMapping(self.allele_group)
+        grouped = self.removeDuplicateAllele(variants, inverse)
+        group_names = sorted(self.collectAlleleNames(grouped))
+        exon_mask = dev.put(buildMask(grouped[:n_span], group_names))
+        # the base class runs errorCorrection once more on the exon lists (line 664: default True)
+        super().__init__(exon_set, grouped, force_homo=force_homo, top_n=top_n, logs=logs,
+                         _vbeg=_vbeg, _n_span=n_span, _mask=exon_mask, _alleles=group_names, _defer_log=True)
+        self._template = template
+        self.candidate_set_threshold = candidate_set_threshold
+        if not exon_only:
+            full_set = ReadSet(tab, base.rows, base.n_rows, base.vflag)
+            self.full_model: AlleleTyping | None = AlleleTyping(
+                full_set, variants, force_homo=force_homo, top_n=top_n // 5,
+                variant_correction=variant_correction, logs=logs, _vbeg=_vbeg, _n_span=n_span, _mask=_mask,
+                _alleles=_alleles, _defer_log=True)
+            self.full_model._template = template
+        else:
+            self.full_model = None
+        self.finish()
+        if self.full_model is not None:
+            self.full_model.finish()
+
+    @staticmethod
+    def aggrVariantsByAllele(variants: list[Variant]) -> dict[tuple[str, ...], list[str]]:
+        per_allele: dict[str, list[str]] = defaultdict(list)
+        for v in variants:
+            for a in v.allele:
+                per_allele[a].append(str(v.id))
+        by_set: dict[tuple[str, ...], list[str]] = defaultdict(list)
+        for a, ids in per_allele.items():
+            by_set[tuple(sorted(set(ids)))].append(a)
+        return by_set
+
+    @staticmethod
+    def createInverseMapping(allele_group: dict[str, list[str]]) -> dict[str, str]:
+        return {a: g for g, members in allele_group.items() for a in members}
+
+    @staticmethod
+    def removeDuplicateAllele(variants: list[Variant], allele_map: dict[str, str]) -> list[Variant]:
+        import copy
+        out = []
+        for v in variants:
+            w = copy.copy(v)
+            w.allele = list(set(filter(None, [allele_map.get(a, "") for a in v.allele])))
+            out.append(w)
+        return out
+
+    def typingIntron(self, exon_candidates: list[list[str]]) -> AlleleTyping:
+        assert self.full_model
+        model = self.full_model.fork()
+        for cand in exon_candidates:
+            model.addCandidate(cand)
+        return model
+
+    def typing(self, cn: int) -> TypingResult:
+        result = super().typing(cn)
+        result.setNameGroup(self.allele_group)
+        logger.debug("[Allele] Typing exon:")
+        if self.full_model is None:
+            return result
+        assert cn == result.n
+        if not result.value.shape[0]:
+            logger.warning("[Allele] Cannot typing with exon-only reads. Typing with exon+intron")
+            return self.full_model.typing(cn)
+        finals = []
+        for i in result.topRank(threshold=self.candidate_set_threshold):
+            logger.debug(f"[Allele] Exon-first: Typing Intron of candidate {i}")
+            model = self.typingIntron(result.allele_name_group[i])
+            self.result.extend(model.result)
+            finals.append(model.result[-1])
+        logger.debug(f"[Allele] Intron Candidate {len(finals)} Done")
+        merged = TypingResult(
+            n=finals[0].n,
+            value=np.concatenate([f.value for f in finals]),
+            value_sum_indv=np.concatenate([f.value_sum_indv for f in finals]),
+            allele_id=np.concatenate([f.allele_id for f in finals]),
+            allele_name=list(chain.from_iterable(f.allele_name for f in finals)),
+            allele_prob=LazyAlleleProb([p for f in finals for p in f.allele_prob.parts]),
+            fraction=np.concatenate([f.fraction for f in finals]),
+            fraction_uniq=np.concatenate([f.fraction for f in finals]),
+        ).sortByScoreAndEveness()
+        self.result.append(merged)
+        logger.debug("[Allele] Typing intron + exon")
+        merged.print()
+        return merged
+
+
+def isHetrozygous(gene: str) -> bool:
+    """Genes typed as heterozygous by name (800-804)."""
+    return "2DL1S1" in gene or "2DL5" in gene
+
+
+def isHomozygous(reads, variants_map: dict[str, Variant], cn: int) -> bool:
+    """Host version on ``PairRead`` lists, same rule as ``AlleleTyping._isHomozygous`` (807-857)."""
+    if cn <= 1:
+        return False
+    site: dict[int, dict[str, int]] = defaultdict(lambda: defaultdict(int))
+    for r in reads:
+        for vid in chain(r.lpv, r.rpv):
+            v = variants_map[vid]
+            if v.typ != "deletion":
+                site[v.pos][str(v.val)] += 1
+        for vid in chain(r.lnv, r.rnv):
+            v = variants_map[vid]
+            if v.typ != "deletion":
+                site[v.pos][f"*{v.val}"] += 1
+    hits = 0
+    for obs in site.values():
+        if len(obs) <= 1 or all("*" in k for k in obs):
+            continue
+        counts = [c for c in sorted(obs.values(), reverse=True) if c > 3]
+        total = sum(counts)
+        if total < 20:
+            continue
+        major = [c / total for c in counts if c / total > 0.1]
+        if len(major) == 1:
+            continue
+        if major[1] > (1 / (cn * 2)):
+            hits += 1
+    return hits == 0

@@ -1,0 +1,77 @@
+"""GPU parity: full / exon-first / EM strategies through the drop-in API vs the CPU oracle."""
+import copy
+
+import numpy as np
+import pytest
+
+from kir_graph_amd import packed, synth
+from kir_graph_amd.engine import DeviceIndex, Tabulation
+from kir_graph_amd.hisat2 import SampleData
+from kir_graph_amd.kir_typing import selectKirTypingModel
+from oracle import tabulate as ot, typing as oty, em as oem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tabulated(device, small_case):
+    sidx, gidx, sample = small_case
+    rec, table = packed.packSample(sample, gidx)
+    dindex = DeviceIndex(device, gidx)
+    tab = Tabulation(dindex, rec)
+    data = SampleData(tab, gidx, tab.novelVariants(table.strings))
+    ref = ot.tabulateLines(synth.toSamLines(sample), gidx.variants)
+    return data, ref, sample
+
+
+def same_result(a, b):
+    assert a.n == b.n
+    for f in ("value", "value_sum_indv", "allele_id", "fraction", "fraction_uniq"):
+        x, y = np.asarray(getattr(a, f)), np.asarray(getattr(b, f))
+        assert x.shape == y.shape, (f, x.shape, y.shape)
+        assert np.array_equal(x, y), f
+    assert a.allele_name == b.allele_name
+    assert np.array_equal(np.asarray(a.allele_prob), b.allele_prob)
+
+
+@pytest.mark.parametrize("method", ["full", "exonfirst_1", "exonfirst_0.9"])
+def test_likelihood_strategies(tabulated, method):
+    data, ref, sample = tabulated
+    gpu = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
+    got = gpu.typing(sample.gene_cn)
+    cpu = oty.makeTyper(method, copy.deepcopy(ref), top_n=600, variant_correction=True)
+    want = cpu.typing(sample.gene_cn)
+    assert got == want
+    for gene, steps in cpu.results.items():
+        assert len(gpu._result[gene]) == len(steps), gene
+        for a, b in zip(gpu._result[gene], steps):
+            same_result(a, b)
+    assert gpu.getAllPossibleTyping() == cpu.allPossible()
+
+
+def test_em_strategy(tabulated):
+    data, ref, sample = tabulated
+    gpu = selectKirTypingModel("report", data)
+    got = gpu.typing(sample.gene_cn)
+    cpu = oem.ReportTyper(copy.deepcopy(ref))
+    want = cpu.typing(sample.gene_cn)
+    for gene, report in cpu.results.items():
+        a = {r.allele: (r.count, r.prob) for r in gpu._result[gene]}
+        b = {r["allele"]: (r["count"], r["prob"]) for r in report}
+        assert a.keys() == b.keys()
+        for k in a:
+            assert a[k][0] == b[k][0]
+            assert a[k][1] == pytest.approx(b[k][1], rel=1e-5, abs=1e-9)   # tolerance of BASELINE.json north_star
+    assert sorted(got[0]) == sorted(want[0])
+    assert got[1] == want[1]
+
+
+def test_json_roundtrip_path(device, tabulated, tmp_path):
+    """selectKirTypingModel(method, '<file>.json') -- the reference's calling convention."""
+    from kir_graph_amd.hisat2 import writeReadsAndVariantsData
+    data, ref, sample = tabulated
+    path = str(tmp_path / "s.variant.json")
+    writeReadsAndVariantsData(data.asDict(), path)
+    a = selectKirTypingModel("full", path, top_n=600, variant_correction=True, device=device).typing(sample.gene_cn)
+    b = selectKirTypingModel("full", data, top_n=600, variant_correction=True).typing(sample.gene_cn)
+    assert a == b
