@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""
+bench.py -- typed 150 bp PE reads/s of the Graph-KIR hot path on MI355X.
+
+One "step" = one synthetic sample (BASELINE.json configs[1]: 2 M reads = 1 M pairs, ~2 k alleles in
+15 genes, --allele-strategy pv == full, top_n 600, variant correction on) taken from packed
+alignment records ALREADY RESIDENT IN HBM to per-gene allele calls on the host:
+tabulation (gk_tabulate) -> per gene: error correction, compatibility table, log table, greedy
+multi-allele likelihood search -> allele selection.  N > 1: every rank types its own sample(s)
+(cohort sharding, no data-path collective), value = reads of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel, HIP-event time measured in this run (gk_prof_*), algorithmic bytes
+  cpu_baseline  the oracle (CPU restatement of the reference) on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_inputs(seed: int, n_pairs: int, index_seed: int = 2022):
+    from kir_graph_amd import synth, packed
+    from kir_graph_amd.index import GkIndex
+    t = time.time()
+    sidx = synth.makeIndex(seed=index_seed)
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    by_gene = {}
+    for v in sidx.variants:
+        by_gene.setdefault(v.ref, []).append(v)
+    sample = synth.makeSample(sidx, seed=seed, n_pairs=n_pairs, variants_by_gene=by_gene)
+    rec, table = packed.packSample(sample, gidx)
+    log(f"[bench] inputs: {len(gidx.variants)} variants, {sum(len(t.alleles) for t in gidx.tables)} alleles, "
+        f"{n_pairs} pairs in {time.time() - t:.1f}s")
+    return sidx, gidx, sample, rec, table
+
+
+def one_step(dev, dindex, gidx, mates_buf, table, gene_cn, method):
+    """Tabulation + typing of one sample whose records are resident in HBM."""
+    from kir_graph_amd.engine import Tabulation
+    from kir_graph_amd.hisat2 import SampleData
+    from kir_graph_amd.kir_typing import selectKirTypingModel
+    tab = Tabulation(dindex, mates_buf)
+    data = SampleData(tab, gidx, None, ins_strings=table.strings)
+    typer = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
+    calls, warn = typer.typing(gene_cn)
+    n_valid = tab.n_valid
+    tab.close()
+    return calls, warn, n_valid, typer
+
+
+def cpu_baseline(sidx, gidx, gene_cn, method, n_pairs, seed):
+    """Oracle on a bounded sample of the same workload (single core)."""
+    from kir_graph_amd import synth
+    from oracle import tabulate as ot, typing as oty
+    sample = synth.makeSample(sidx, seed=seed, n_pairs=n_pairs, gene_cn=gene_cn)
+    lines = synth.toSamLines(sample, with_zs=False)
+    t0 = time.time()
+    data = ot.tabulateLines(lines, gidx.variants)
+    t1 = time.time()
+    typer = oty.makeTyper("full" if method in ("pv", "full") else method, data, top_n=600, variant_correction=True)
+    typer.typing(gene_cn)
+    t2 = time.time()
+    return {"value": 2 * n_pairs / (t2 - t0), "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": f"{n_pairs} pairs of the same synthetic workload (oracle: tabulate {t1 - t0:.1f}s + "
+                      f"typing {t2 - t1:.1f}s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per sample (config 2: 1e6)")
+    ap.add_argument("--method", default="pv")
+    ap.add_argument("--cpu-pairs", type=int, default=6000, help="pairs for the CPU baseline sample (0 = skip)")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--profile-host", action="store_true", help="cProfile one extra step to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        torch.cuda.set_device(local_rank)
+        dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_
+
+    from kir_graph_amd import _lib
+    from kir_graph_amd.engine import DeviceIndex
+    dev = _lib.Device(local_rank if world > 1 else 0)
+    sidx, gidx, sample, rec, table = build_inputs(seed=1031 + rank, n_pairs=args.pairs)
+    gene_cn = sample.gene_cn
+    dindex = DeviceIndex(dev, gidx)
+    mates = dev.put(rec)
+    dev.sync()
+
+    def barrier():
+        dev.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(dev, dindex, gidx, mates, table, gene_cn, args.method)
+    if args.profile_host:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        one_step(dev, dindex, gidx, mates, table, gene_cn, args.method)
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
+    dev.profEnable(True)
+    dev.profCollect()
+    barrier()
+    t0 = time.perf_counter()
+    n_valid = 0
+    for _ in range(args.steps):
+        calls, warn, n_valid, typer = one_step(dev, dindex, gidx, mates, table, gene_cn, args.method)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = dev.profCollect()
+    dev.profEnable(False)
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        reads_per_step = 2 * args.pairs * world
+        value = reads_per_step / (elapsed / args.steps)
+        total_kernel_ms = sum(v[1] for v in prof.values())
+        dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, 0.0))
+        if args.verbose:
+            for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+                log(f"[bench] {k:18s} launches {n:6d}  total {ms:9.3f} ms  avg {ms / n:8.4f} ms")
+            log(f"[bench] kernel time {total_kernel_ms / args.steps:.2f} ms of {ms_per_step:.2f} ms per step")
+        roof = roofline(dom, typer, args)
+        out = {
+            "metric": "typed 150 bp PE reads/s (pileup+EM) per GPU; achieved HBM GB/s vs roofline",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: 1 synthetic sample per GPU, {2 * args.pairs} 150 bp PE reads, "
+                                   f"synthetic example_index-shaped index ({sum(len(t.alleles) for t in gidx.tables)} "
+                                   f"alleles, 15 genes), --allele-strategy {args.method}, top_n 600",
+                       "pairs_per_sample": args.pairs, "pairs_passing_filter": int(n_valid),
+                       "parallelism": f"samples sharded over {world} GPU(s), no data-path collective"},
+            "roofline": roof,
+            "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
+        }
+        if args.cpu_pairs:
+            out["cpu_baseline"] = cpu_baseline(sidx, gidx, gene_cn, args.method, args.cpu_pairs, seed=99)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline(dom, typer, args):
+    """Roofline entry of the dominant kernel (algorithmic bytes stated in DESIGN.md)."""
+    name, (launches, total_ms) = dom
+    avg_s = total_ms / max(launches, 1) / 1e3
+    bytes_per_launch = None
+    try:
+        from kir_graph_amd import roofmodel
+        bytes_per_launch = roofmodel.algorithmicBytes(name, typer)
+    except Exception as e:  # noqa: BLE001
+        log(f"[bench] roofline model unavailable: {e}")
+    achieved = (bytes_per_launch / avg_s / 1e9) if (bytes_per_launch and avg_s > 0) else None
+    return {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
+            "launches": launches, "avg_launch_ms": total_ms / max(launches, 1)}
+
+
+if __name__ == "__main__":
+    main()

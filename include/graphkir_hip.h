@@ -32,14 +32,16 @@ extern "C" {
 #define GK_ERR_ASSERT (-4)   /* a reference `assert` would have fired (e.g. window lo > hi) */
 #define GK_ERR_CAPACITY (-5)
 
-/* ---- packed alignment record: 64 bytes per mate, 2 consecutive mates = 1 pair.
+/* ---- packed alignment record: 128 bytes per mate, 2 consecutive mates = 1 pair.
  * mate 0 of a pair is the record emitted as `left` by readPair (hisat2.py:270),
  * i.e. the LATER line of the name-collated stream; mate 1 the earlier one.
  * It carries exactly the fields recordToRawVariant / filterRead / getNH read
  * from the SAM text (hisat2.py:342-350, 551-569, 95-100). */
-#define GK_MAX_CIG 10
-#define GK_MAX_MM 4
-#define GK_MAX_INS 4
+#define GK_MAX_CIG 14
+#define GK_MAX_MM 16
+#define GK_MAX_INS 6
+#define GK_MAX_EVENTS 22 /* mismatches + I ops + D ops of one mate (NM excludes graph variants, so NM <= 4
+                            does not bound them) */
 #define GK_CIG_M 0
 #define GK_CIG_I 1
 #define GK_CIG_D 2
@@ -88,6 +90,12 @@ int gk_d2d(gk_ctx* ctx, gk_dptr dst, gk_dptr src, size_t bytes);
 /* HIP-event timing on the context stream (bench.py roofline leg). */
 int gk_timer_start(gk_ctx* ctx);
 int gk_timer_stop_ms(gk_ctx* ctx, float* ms);
+/* Per-kernel HIP-event spans on the context stream: enable, run, then collect launches / total ms
+ * per kernel id (names via gk_prof_kernel_name). */
+int gk_prof_enable(gk_ctx* ctx, int on);
+int gk_prof_kernel_count(void);
+const char* gk_prof_kernel_name(int id);
+int gk_prof_collect(gk_ctx* ctx, int64_t* launches, double* total_ms);
 
 /* ---- index: replaces getVariants() (hisat2.py:183-203) as a device table.
  * key[v] = ref:8 | pos:24 | type:2 | val:30 sorted ascending (msa2hisat.py:48-53). */

@@ -24,18 +24,18 @@ class GkNoDevice(GkError):
     """No HIP device: the typing path cannot run (there is no CPU fallback)."""
 
 
-# gk_mate (include/graphkir_hip.h): 64 bytes, mm is an array of 4 {u16 ref_off, u8 base, u8 rsv}
+# gk_mate (include/graphkir_hip.h): 128 bytes, mm is an array of 16 {u16 ref_off, u8 base, u8 rsv}
 _MM = np.dtype([("ref_off", "<u2"), ("base", "u1"), ("rsv", "u1")])
 MATE_DTYPE = np.dtype([
     ("pos0", "<u4"), ("flag", "<u2"), ("ref", "u1"), ("nh", "u1"),
     ("nm", "u1"), ("n_cig", "u1"), ("n_mm", "u1"), ("n_ins", "u1"),
-    ("cig", "<u2", (10,)), ("mm", _MM, (4,)), ("ins", "<u4", (4,)),
+    ("cig", "<u2", (14,)), ("mm", _MM, (16,)), ("ins", "<u4", (6,)),
 ])
-assert MATE_DTYPE.itemsize == 64
+assert MATE_DTYPE.itemsize == 128
 
 CIG_M, CIG_I, CIG_D, CIG_S = 0, 1, 2, 4
 NM_ABSENT = 255
-MAX_CIG, MAX_MM, MAX_INS, MAX_EV = 10, 4, 4, 4
+MAX_CIG, MAX_MM, MAX_INS, MAX_EV = 14, 16, 6, 22
 
 
 class TabInfo(C.Structure):
@@ -66,6 +66,10 @@ _SIGS = {
     "gk_d2d": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_size_t]),
     "gk_timer_start": (C.c_int, [C.c_void_p]),
     "gk_timer_stop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "gk_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "gk_prof_kernel_count": (C.c_int, []),
+    "gk_prof_kernel_name": (C.c_char_p, [C.c_int]),
+    "gk_prof_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gk_index_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "gk_index_destroy": (C.c_int, [C.c_void_p]),
     "gk_tabulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_void_p)]),
@@ -219,6 +223,18 @@ class Device:
         ms = C.c_float()
         check(lib().gk_timer_stop_ms(self.ctx, C.byref(ms)))
         return float(ms.value)
+
+    def profEnable(self, on: bool = True) -> None:
+        check(lib().gk_prof_enable(self.ctx, int(on)))
+
+    def profCollect(self) -> dict[str, tuple[int, float]]:
+        """{kernel name: (launches, total ms)} of the spans recorded since the last call."""
+        n = lib().gk_prof_kernel_count()
+        launches = np.zeros(n, dtype=np.int64)
+        total = np.zeros(n, dtype=np.float64)
+        check(lib().gk_prof_collect(self.ctx, launches.ctypes.data, total.ctypes.data))
+        return {lib().gk_prof_kernel_name(i).decode(): (int(launches[i]), float(total[i]))
+                for i in range(n) if launches[i]}
 
     def close(self) -> None:
         if self.ctx:

@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <unordered_map>
 #include <vector>
 
 #include "graphkir_hip.h"
@@ -39,9 +41,39 @@ struct gk_ctx {
   // pinned host staging for small parameter arrays
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  // caching allocator state (gk_pool_*)
+  std::multimap<size_t, void*> pool_free;
+  std::unordered_map<void*, size_t> pool_live;
+  size_t pool_cached_bytes = 0;
+  // optional per-kernel timing with HIP events on `stream` (bench.py roofline leg)
+  bool prof_on = false;
+  struct ProfSpan { int id; hipEvent_t a, b; };
+  std::vector<ProfSpan> prof_spans;
+  std::vector<hipEvent_t> prof_pool;
 };
 
+// kernel ids for gk_prof_*
+enum {
+  GK_K_TAB_COUNT = 0, GK_K_TAB_EMIT, GK_K_SCAN, GK_K_NOVEL, GK_K_COUNT_IDS, GK_K_SELECT, GK_K_COMPAT,
+  GK_K_LUT_COLLECT, GK_K_LUT_APPLY, GK_K_MAXSUM, GK_K_COMBINE, GK_K_FRACTION, GK_K_SETMAX, GK_K_EM_SETS,
+  GK_K_EM_RUN, GK_K_N
+};
+void gk_prof_begin(gk_ctx* ctx, int id);
+void gk_prof_end(gk_ctx* ctx);
+#define GK_PROF(ctx, id, launch) \
+  do {                           \
+    gk_prof_begin((ctx), (id));  \
+    launch;                      \
+    gk_prof_end((ctx));          \
+  } while (0)
+
 int gk_ctx_scratch(gk_ctx* ctx, size_t bytes, void** out);
+
+// Stream-ordered caching allocator: freed blocks are kept per size class and handed out again
+// without hipMalloc / hipFree (both synchronise the device).  Safe because every kernel and copy
+// of a context runs on its single stream.
+hipError_t gk_pool_malloc(gk_ctx* ctx, void** out, size_t bytes);
+void gk_pool_free(gk_ctx* ctx, void* p);
 
 struct gk_index {
   gk_ctx* ctx = nullptr;

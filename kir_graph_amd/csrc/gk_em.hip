@@ -161,9 +161,9 @@ int gk_em_sets(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, int32_t
   GK_REQUIRE(ctx && tab, "null pointer");
   GK_REQUIRE(words >= 1 && words <= kMaxWords, "more than 512 alleles per gene are not supported by the EM kernel");
   if (!n_rows) return GK_OK;
-  hipLaunchKernelGGL(em_sets_kernel, dim3((unsigned)((n_rows + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+  GK_PROF(ctx, GK_K_EM_SETS, hipLaunchKernelGGL(em_sets_kernel, dim3((unsigned)((n_rows + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                      ctx->stream, gk_ptr<int32_t>(d_rows), n_rows, tab->d_off, tab->d_ids, vbeg, vend,
-                     gk_ptr<uint32_t>(d_mask), words, gk_ptr<uint32_t>(d_sets_out));
+                     gk_ptr<uint32_t>(d_mask), words, gk_ptr<uint32_t>(d_sets_out)));
   GK_HIP(hipGetLastError());
   return GK_OK;
 }
@@ -177,20 +177,20 @@ int gk_em_run(gk_ctx* ctx, const uint32_t* sets, const double* weight, int32_t n
   uint32_t* d_sets = nullptr;
   double *d_w = nullptr, *d_scale = nullptr, *d_prob = nullptr;
   int* d_it = nullptr;
-  GK_HIP(hipMalloc((void**)&d_sets, (size_t)n_sets * words * sizeof(uint32_t)));
-  GK_HIP(hipMalloc((void**)&d_w, (size_t)n_sets * sizeof(double)));
-  GK_HIP(hipMalloc((void**)&d_scale, (size_t)n_sets * sizeof(double)));
-  GK_HIP(hipMalloc((void**)&d_prob, (size_t)n_allele * sizeof(double)));
-  GK_HIP(hipMalloc((void**)&d_it, sizeof(int)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_sets, (size_t)n_sets * words * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_w, (size_t)n_sets * sizeof(double)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_scale, (size_t)n_sets * sizeof(double)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_prob, (size_t)n_allele * sizeof(double)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_it, sizeof(int)));
   GK_HIP(hipMemcpyAsync(d_sets, sets, (size_t)n_sets * words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   GK_HIP(hipMemcpyAsync(d_w, weight, (size_t)n_sets * sizeof(double), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(em_kernel, dim3(1), dim3(kThreads), 0, st, d_sets, d_w, d_scale, n_sets, words, n_allele, iter_max,
-                     diff_threshold, d_prob, d_it);
+  GK_PROF(ctx, GK_K_EM_RUN, hipLaunchKernelGGL(em_kernel, dim3(1), dim3(kThreads), 0, st, d_sets, d_w, d_scale, n_sets, words, n_allele, iter_max,
+                     diff_threshold, d_prob, d_it));
   GK_HIP(hipGetLastError());
   GK_HIP(hipMemcpyAsync(prob_out, d_prob, (size_t)n_allele * sizeof(double), hipMemcpyDeviceToHost, st));
   GK_HIP(hipMemcpyAsync(iters_out, d_it, sizeof(int), hipMemcpyDeviceToHost, st));
   GK_HIP(hipStreamSynchronize(st));
-  hipFree(d_sets); hipFree(d_w); hipFree(d_scale); hipFree(d_prob); hipFree(d_it);
+  gk_pool_free(ctx,d_sets); gk_pool_free(ctx,d_w); gk_pool_free(ctx,d_scale); gk_pool_free(ctx,d_prob); gk_pool_free(ctx,d_it);
   return GK_OK;
 }
 

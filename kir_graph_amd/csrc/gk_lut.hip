@@ -113,8 +113,9 @@ int gk_lut_collect(gk_lut* l, gk_dptr d_vals, int64_t n) {
   if (n <= 0) return GK_OK;
   int64_t want = (n + kThreads - 1) / kThreads;
   unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(lut_collect, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_vals), n,
-                     l->d_keys, l->d_slot_idx, l->d_list, l->d_count, (uint32_t)((1ull << l->log2cap) - 1));
+  gk_ctx* ctx = l->ctx;
+  GK_PROF(ctx, GK_K_LUT_COLLECT, hipLaunchKernelGGL(lut_collect, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_vals), n,
+                     l->d_keys, l->d_slot_idx, l->d_list, l->d_count, (uint32_t)((1ull << l->log2cap) - 1)));
   GK_HIP(hipGetLastError());
   return GK_OK;
 }
@@ -157,9 +158,10 @@ int gk_lut_apply(gk_lut* l, gk_dptr d_in, gk_dptr d_out, int64_t n) {
   if (n <= 0) return GK_OK;
   int64_t want = (n + kThreads - 1) / kThreads;
   unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(lut_apply, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_in),
+  gk_ctx* ctx = l->ctx;
+  GK_PROF(ctx, GK_K_LUT_APPLY, hipLaunchKernelGGL(lut_apply, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_in),
                      gk_ptr<double>(d_out), n, l->d_keys, l->d_slot_idx, l->d_vals,
-                     (uint32_t)((1ull << l->log2cap) - 1));
+                     (uint32_t)((1ull << l->log2cap) - 1)));
   GK_HIP(hipGetLastError());
   return GK_OK;
 }

@@ -50,6 +50,8 @@ int gk_ctx_destroy(gk_ctx* ctx) {
   if (!ctx) return GK_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->pool_free) hipFree(kv.second);
+  for (auto& kv : ctx->pool_live) hipFree(kv.first);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   hipEventDestroy(ctx->ev0);
@@ -69,7 +71,7 @@ int gk_malloc(gk_ctx* ctx, size_t bytes, gk_dptr* out) {
   GK_REQUIRE(ctx && out, "null pointer");
   GK_HIP(hipSetDevice(ctx->device));
   void* p = nullptr;
-  GK_HIP(hipMalloc(&p, bytes ? bytes : 16));
+  GK_HIP(gk_pool_malloc(ctx, &p, bytes ? bytes : 16));
   *out = gk_addr(p);
   return GK_OK;
 }
@@ -77,8 +79,7 @@ int gk_malloc(gk_ctx* ctx, size_t bytes, gk_dptr* out) {
 int gk_free(gk_ctx* ctx, gk_dptr p) {
   GK_REQUIRE(ctx, "null context");
   if (!p) return GK_OK;
-  GK_HIP(hipStreamSynchronize(ctx->stream));
-  GK_HIP(hipFree(gk_ptr<void>(p)));
+  gk_pool_free(ctx, gk_ptr<void>(p));
   return GK_OK;
 }
 
@@ -127,6 +128,104 @@ int gk_timer_stop_ms(gk_ctx* ctx, float* ms) {
 }
 
 }  // extern "C"
+
+static size_t pool_class(size_t bytes) {
+  if (bytes < 256) return 256;
+  if (bytes <= (1u << 20)) {   // powers of two up to 1 MiB
+    size_t c = 256;
+    while (c < bytes) c <<= 1;
+    return c;
+  }
+  const size_t step = 1u << 20;  // then multiples of 1 MiB
+  return (bytes + step - 1) / step * step;
+}
+
+hipError_t gk_pool_malloc(gk_ctx* ctx, void** out, size_t bytes) {
+  const size_t cls = pool_class(bytes);
+  auto it = ctx->pool_free.find(cls);
+  if (it != ctx->pool_free.end()) {
+    *out = it->second;
+    ctx->pool_free.erase(it);
+    ctx->pool_cached_bytes -= cls;
+    ctx->pool_live[*out] = cls;
+    return hipSuccess;
+  }
+  hipError_t e = hipMalloc(out, cls);
+  if (e != hipSuccess && ctx->pool_cached_bytes) {   // give the cache back and retry once
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->pool_free) hipFree(kv.second);
+    ctx->pool_free.clear();
+    ctx->pool_cached_bytes = 0;
+    e = hipMalloc(out, cls);
+  }
+  if (e == hipSuccess) ctx->pool_live[*out] = cls;
+  return e;
+}
+
+void gk_pool_free(gk_ctx* ctx, void* p) {
+  if (!p) return;
+  auto it = ctx->pool_live.find(p);
+  if (it == ctx->pool_live.end()) {   // not ours
+    hipFree(p);
+    return;
+  }
+  const size_t cls = it->second;
+  ctx->pool_live.erase(it);
+  ctx->pool_free.emplace(cls, p);
+  ctx->pool_cached_bytes += cls;
+}
+
+void gk_prof_begin(gk_ctx* ctx, int id) {
+  if (!ctx->prof_on) return;
+  gk_ctx::ProfSpan sp;
+  sp.id = id;
+  for (hipEvent_t* e : {&sp.a, &sp.b}) {
+    if (!ctx->prof_pool.empty()) {
+      *e = ctx->prof_pool.back();
+      ctx->prof_pool.pop_back();
+    } else {
+      hipEventCreate(e);
+    }
+  }
+  hipEventRecord(sp.a, ctx->stream);
+  ctx->prof_spans.push_back(sp);
+}
+
+void gk_prof_end(gk_ctx* ctx) {
+  if (!ctx->prof_on || ctx->prof_spans.empty()) return;
+  hipEventRecord(ctx->prof_spans.back().b, ctx->stream);
+}
+
+static const char* kKernelNames[GK_K_N] = {
+    "tab_count", "tab_emit", "scan", "novel_rank", "count_ids", "select", "compat_kernel", "lut_collect",
+    "lut_apply", "maxsum_chunks", "combine_chunks", "fraction_chunks", "setmax_kernel", "em_sets_kernel", "em_kernel"};
+
+extern "C" int gk_prof_enable(gk_ctx* ctx, int on) {
+  GK_REQUIRE(ctx, "null context");
+  ctx->prof_on = on != 0;
+  return GK_OK;
+}
+
+extern "C" int gk_prof_kernel_count(void) { return GK_K_N; }
+extern "C" const char* gk_prof_kernel_name(int id) { return id >= 0 && id < GK_K_N ? kKernelNames[id] : ""; }
+
+// launches[id], total_ms[id] for id < GK_K_N; clears the recorded spans
+extern "C" int gk_prof_collect(gk_ctx* ctx, int64_t* launches, double* total_ms) {
+  GK_REQUIRE(ctx && launches && total_ms, "null pointer");
+  GK_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < GK_K_N; ++i) { launches[i] = 0; total_ms[i] = 0.0; }
+  for (auto& sp : ctx->prof_spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+      launches[sp.id] += 1;
+      total_ms[sp.id] += ms;
+    }
+    ctx->prof_pool.push_back(sp.a);
+    ctx->prof_pool.push_back(sp.b);
+  }
+  ctx->prof_spans.clear();
+  return GK_OK;
+}
 
 int gk_ctx_scratch(gk_ctx* ctx, size_t bytes, void** out) {
   if (bytes > ctx->scratch_bytes) {

@@ -75,11 +75,11 @@ static int scan_rec(gk_ctx* ctx, uint32_t* d, int64_t n, uint32_t* sums_area, ui
     if (d_total) GK_HIP(hipMemsetAsync(d_total, 0, sizeof(uint32_t), ctx->stream));
     return GK_OK;
   }
-  hipLaunchKernelGGL(scan_tiles, dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, d, n, sums_area);
+  GK_PROF(ctx, GK_K_SCAN, hipLaunchKernelGGL(scan_tiles, dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, d, n, sums_area));
   if (tiles > 1) {
     int rc = scan_rec(ctx, sums_area, tiles, sums_area + tiles, d_total);
     if (rc) return rc;
-    hipLaunchKernelGGL(add_tile_offsets, dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, d, n, sums_area);
+    GK_PROF(ctx, GK_K_SCAN, hipLaunchKernelGGL(add_tile_offsets, dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, d, n, sums_area));
   } else if (d_total) {
     GK_HIP(hipMemcpyAsync(d_total, sums_area, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
   }
@@ -91,16 +91,11 @@ int gk_scan_u32(gk_ctx* ctx, uint32_t* d_data, int64_t n, uint32_t* d_total) {
   // scratch for tile sums of every level: tiles + tiles/kTile + ... <= tiles + tiles/1024 + 64
   int64_t tiles = (n + kTile - 1) / kTile;
   size_t need = (size_t)(tiles + tiles / 1024 + 4096) * sizeof(uint32_t);
-  // a private allocation: the context scratch may be in use by the caller
-  static thread_local uint32_t* area = nullptr;
-  static thread_local size_t area_bytes = 0;
-  if (need > area_bytes) {
-    GK_HIP(hipStreamSynchronize(ctx->stream));
-    if (area) GK_HIP(hipFree(area));
-    GK_HIP(hipMalloc((void**)&area, need * 2));
-    area_bytes = need * 2;
-  }
-  return scan_rec(ctx, d_data, n, area, d_total);
+  uint32_t* area = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&area, need));
+  const int rc = scan_rec(ctx, d_data, n, area, d_total);
+  gk_pool_free(ctx, area);   // stream-ordered reuse
+  return rc;
 }
 
 int gk_compact(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int64_t n, int32_t* d_out,
@@ -110,19 +105,19 @@ int gk_compact(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int
     return GK_OK;
   }
   uint32_t* pos = nullptr;
-  GK_HIP(hipMalloc((void**)&pos, (size_t)(n + 1) * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&pos, (size_t)(n + 1) * sizeof(uint32_t)));
   unsigned blocks = (unsigned)((n + kThreads - 1) / kThreads);
-  hipLaunchKernelGGL(flags_to_u32, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, n);
+  GK_PROF(ctx, GK_K_SCAN, hipLaunchKernelGGL(flags_to_u32, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, n));
   int rc = gk_scan_u32(ctx, pos, n, pos + n);
   if (rc) {
-    hipFree(pos);
+    gk_pool_free(ctx,pos);
     return rc;
   }
-  hipLaunchKernelGGL(scatter_selected, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, d_values, n, d_out);
+  GK_PROF(ctx, GK_K_SCAN, hipLaunchKernelGGL(scatter_selected, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, d_values, n, d_out));
   uint32_t total = 0;
   GK_HIP(hipMemcpyAsync(&total, pos + n, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   GK_HIP(hipStreamSynchronize(ctx->stream));
-  GK_HIP(hipFree(pos));
+  gk_pool_free(ctx, pos);
   if (n_out) *n_out = total;
   return GK_OK;
 }

@@ -17,9 +17,11 @@
 // (lane j owns rows == j mod 8), which leaves one accumulator register per output and lets every
 // lane carry a TT x TA register tile.  The recursion stack lives in the same 8 lanes (lane s holds
 // stack slot s), so the whole tree runs without dynamically indexed registers.  L is column-major
-// [allele][row]: row blocks are staged through LDS with coalesced 512-byte wave loads, the previous
-// set's row-wise max is formed while staging (no R x T temporary in HBM, the reference
-// materialises T x R x A).
+// [allele][row]: row blocks are staged through LDS with coalesced 512-byte wave loads (next block
+// prefetched into registers while the current one is reduced), the previous set's row-wise max is
+// formed while staging (no R x T temporary in HBM; the reference materialises T x R x A).
+// Work is split over workgroups by output tile AND by row span: every workgroup owns one sub-tree
+// of <= 1024 rows of the numpy recursion, a second small kernel finishes the tree per chunk.
 #include <algorithm>
 
 #include "gk_common.h"
@@ -29,13 +31,21 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kBlockRows = 128;   // numpy PW_BLOCKSIZE
 constexpr int kChunkRows = 8192;  // numpy buffer size for add.reduce
+constexpr int kSpanRows = 1024;   // rows of the recursion sub-tree owned by one workgroup
+constexpr int kMaxSpans = 16;     // sub-trees per chunk (span sizes are in (512, 1024])
 constexpr int kLD = kBlockRows + 8;  // LDS column stride (doubles): +64 B de-phases the 4 allele groups
 constexpr int TT = 4, TA = 4;
 constexpr int kTileT = 8 * TT;    // 32 sets per workgroup
 constexpr int kTileA = 4 * TA;    // 16 candidate columns per workgroup
 constexpr int kMaxC = 8;          // alleles per set (copy number) supported
+constexpr int kLPer = kTileA * kBlockRows / kThreads;   // 8 staged L values per thread
+constexpr int kPPer = kTileT * kBlockRows / kThreads;   // 16 staged P values per thread
 
-struct Op { int32_t kind, a, b, c; };   // kind 0: LEAF(start=a, len=b, slot=c); kind 1: ADD(slot a += slot b)
+// one leaf of the recursion: rows [start, start+len) relative to the span, result pushed to stack
+// slot `slot`, then `n_add` times "slot (s-1) += slot s" walking down from `slot`
+struct Leaf { int32_t start, len, slot, n_add; };
+struct Span { int64_t row0; int32_t leaf_begin, leaf_end; int32_t chunk, pad; };
+struct TopOp { int32_t dst, src; };
 
 __device__ inline double vmax(double a, double b) {
   double r;
@@ -51,12 +61,12 @@ __device__ inline double group_sum8(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(kThreads) void maxsum_chunks(const double* __restrict__ L, int64_t n_rows, int64_t ld,
+__global__ __launch_bounds__(kThreads) void maxsum_chunks(const double* __restrict__ L, int64_t ld,
                                                           const int32_t* __restrict__ ids, int n_sets, int c_prev,
                                                           const int32_t* __restrict__ cols, int n_cols,
-                                                          const Op* __restrict__ ops_full, int n_ops_full,
-                                                          const Op* __restrict__ ops_tail, int n_ops_tail,
-                                                          int n_chunks, double* __restrict__ partial) {
+                                                          const Span* __restrict__ spans,
+                                                          const Leaf* __restrict__ leaves,
+                                                          double* __restrict__ partial) {
   __shared__ double Pt[kTileT * kLD];
   __shared__ double Lt[kTileA * kLD];
   __shared__ int32_t p_col[kTileT * kMaxC];
@@ -67,11 +77,7 @@ __global__ __launch_bounds__(kThreads) void maxsum_chunks(const double* __restri
   const int tiles_a = (n_cols + kTileA - 1) / kTileA;
   const int tile_t = blockIdx.x / tiles_a, tile_a = blockIdx.x % tiles_a;
   const int t0 = tile_t * kTileT, a0 = tile_a * kTileA;
-  const int chunk = blockIdx.y;
-  const int64_t chunk_row0 = (int64_t)chunk * kChunkRows;
-  const bool tail = (chunk == n_chunks - 1) && (n_rows - chunk_row0 < kChunkRows);
-  const Op* ops = tail ? ops_tail : ops_full;
-  const int n_ops = tail ? n_ops_tail : n_ops_full;
+  const Span span = spans[blockIdx.y];
 
   for (int i = tid; i < kTileT * kMaxC; i += kThreads) {
     const int t = t0 + i / kMaxC, k = i % kMaxC;
@@ -80,6 +86,32 @@ __global__ __launch_bounds__(kThreads) void maxsum_chunks(const double* __restri
   if (tid < kTileA) l_col[tid] = (a0 + tid < n_cols) ? cols[a0 + tid] : -1;
   __syncthreads();
 
+  const int srow = tid & (kBlockRows - 1);   // staged row of this thread
+  const int scol = tid >> 7;                 // first staged column (0/1), then +2 per step
+  double pre_l[kLPer], pre_p[kPPer];
+
+  auto prefetch = [&](const Leaf& lf) {
+    const int64_t r = span.row0 + lf.start + srow;
+    const bool in = srow < lf.len;
+#pragma unroll
+    for (int q = 0; q < kLPer; ++q) {
+      const int cidx = l_col[scol + 2 * q];
+      pre_l[q] = (in && cidx >= 0) ? L[(int64_t)cidx * ld + r] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < kPPer; ++q) {
+      double v = -__builtin_huge_val();
+      if (in) {
+        const int t = scol + 2 * q;
+        for (int k = 0; k < c_prev; ++k) {
+          const int cidx = p_col[t * kMaxC + k];
+          if (cidx >= 0) v = vmax(v, L[(int64_t)cidx * ld + r]);
+        }
+      }
+      pre_p[q] = v;
+    }
+  };
+
   const int t_loc = (wid * 2 + gt) * TT;   // first of TT consecutive sets of this lane
   double st[TT][TA];
 #pragma unroll
@@ -87,92 +119,86 @@ __global__ __launch_bounds__(kThreads) void maxsum_chunks(const double* __restri
 #pragma unroll
     for (int y = 0; y < TA; ++y) st[x][y] = 0.0;
 
-  for (int o = 0; o < n_ops; ++o) {
-    const Op op = ops[o];
-    if (op.kind == 0) {
-      const int64_t r0 = chunk_row0 + op.a;
-      const int len = op.b;
-      // ---- stage rows [r0, r0+len) : candidate columns and the previous sets' row-wise max
-      __syncthreads();
-      for (int i = tid; i < kTileA * kBlockRows; i += kThreads) {
-        const int col = i >> 7, row = i & (kBlockRows - 1);
-        const int cidx = l_col[col];
-        double v = 0.0;
-        if (row < len && cidx >= 0) v = L[(int64_t)cidx * ld + r0 + row];
-        Lt[col * kLD + row] = v;
-      }
-      for (int i = tid; i < kTileT * kBlockRows; i += kThreads) {
-        const int t = i >> 7, row = i & (kBlockRows - 1);
-        double v = -__builtin_huge_val();
-        if (row < len) {
-          for (int k = 0; k < c_prev; ++k) {
-            const int cidx = p_col[t * kMaxC + k];
-            if (cidx >= 0) v = vmax(v, L[(int64_t)cidx * ld + r0 + row]);
-          }
+  Leaf lf = leaves[span.leaf_begin];
+  prefetch(lf);
+  for (int li = span.leaf_begin; li < span.leaf_end; ++li) {
+    // ---- publish the prefetched rows, start fetching the next leaf
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kLPer; ++q) Lt[(scol + 2 * q) * kLD + srow] = pre_l[q];
+#pragma unroll
+    for (int q = 0; q < kPPer; ++q) Pt[(scol + 2 * q) * kLD + srow] = pre_p[q];
+    __syncthreads();
+    const Leaf cur = lf;
+    if (li + 1 < span.leaf_end) {
+      lf = leaves[li + 1];
+      prefetch(lf);
+    }
+    const int len = cur.len;
+    // ---- numpy pairwise block: 8 strided accumulators = 8 lanes
+    double acc[TT][TA];
+    const int n8 = len - (len & 7);
+    if (len < 8) {
+#pragma unroll
+      for (int x = 0; x < TT; ++x)
+#pragma unroll
+        for (int y = 0; y < TA; ++y) acc[x][y] = 0.0;
+      for (int r = 0; r < len; ++r) {
+#pragma unroll
+        for (int x = 0; x < TT; ++x) {
+          const double p = Pt[(t_loc + x) * kLD + r];
+#pragma unroll
+          for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p, Lt[(ga + 4 * y) * kLD + r]);
         }
-        Pt[t * kLD + row] = v;
       }
-      __syncthreads();
-      // ---- numpy pairwise block: 8 strided accumulators = 8 lanes
-      double acc[TT][TA];
-      const int n8 = len - (len & 7);
-      if (len < 8) {
+    } else {
+      {
+        double p[TT], l[TA];
+#pragma unroll
+        for (int x = 0; x < TT; ++x) p[x] = Pt[(t_loc + x) * kLD + j];
+#pragma unroll
+        for (int y = 0; y < TA; ++y) l[y] = Lt[(ga + 4 * y) * kLD + j];
 #pragma unroll
         for (int x = 0; x < TT; ++x)
 #pragma unroll
-          for (int y = 0; y < TA; ++y) acc[x][y] = 0.0;
-        for (int r = 0; r < len; ++r) {
+          for (int y = 0; y < TA; ++y) acc[x][y] = vmax(p[x], l[y]);
+      }
+      for (int r = 8 + j; r < n8; r += 8) {
+        double p[TT], l[TA];
 #pragma unroll
-          for (int x = 0; x < TT; ++x) {
-            const double p = Pt[(t_loc + x) * kLD + r];
+        for (int x = 0; x < TT; ++x) p[x] = Pt[(t_loc + x) * kLD + r];
 #pragma unroll
-            for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p, Lt[(ga + 4 * y) * kLD + r]);
-          }
-        }
-      } else {
-        {
-          double p[TT], l[TA];
-#pragma unroll
-          for (int x = 0; x < TT; ++x) p[x] = Pt[(t_loc + x) * kLD + j];
-#pragma unroll
-          for (int y = 0; y < TA; ++y) l[y] = Lt[(ga + 4 * y) * kLD + j];
-#pragma unroll
-          for (int x = 0; x < TT; ++x)
-#pragma unroll
-            for (int y = 0; y < TA; ++y) acc[x][y] = vmax(p[x], l[y]);
-        }
-        for (int r = 8 + j; r < n8; r += 8) {
-          double p[TT], l[TA];
-#pragma unroll
-          for (int x = 0; x < TT; ++x) p[x] = Pt[(t_loc + x) * kLD + r];
-#pragma unroll
-          for (int y = 0; y < TA; ++y) l[y] = Lt[(ga + 4 * y) * kLD + r];
-#pragma unroll
-          for (int x = 0; x < TT; ++x)
-#pragma unroll
-            for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p[x], l[y]);
-        }
+        for (int y = 0; y < TA; ++y) l[y] = Lt[(ga + 4 * y) * kLD + r];
 #pragma unroll
         for (int x = 0; x < TT; ++x)
 #pragma unroll
-          for (int y = 0; y < TA; ++y) acc[x][y] = group_sum8(acc[x][y]);
-        for (int r = n8; r < len; ++r) {   // sequential tail, same in every lane
+          for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p[x], l[y]);
+      }
 #pragma unroll
-          for (int x = 0; x < TT; ++x) {
-            const double p = Pt[(t_loc + x) * kLD + r];
+      for (int x = 0; x < TT; ++x)
 #pragma unroll
-            for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p, Lt[(ga + 4 * y) * kLD + r]);
-          }
+        for (int y = 0; y < TA; ++y) acc[x][y] = group_sum8(acc[x][y]);
+      for (int r = n8; r < len; ++r) {   // sequential tail, same in every lane
+#pragma unroll
+        for (int x = 0; x < TT; ++x) {
+          const double p = Pt[(t_loc + x) * kLD + r];
+#pragma unroll
+          for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p, Lt[(ga + 4 * y) * kLD + r]);
         }
       }
-      const bool mine = (j == op.c);
+    }
+    // ---- push on the lane stack, then fold finished sub-trees
+    {
+      const bool mine = (j == cur.slot);
 #pragma unroll
       for (int x = 0; x < TT; ++x)
 #pragma unroll
         for (int y = 0; y < TA; ++y) st[x][y] = mine ? acc[x][y] : st[x][y];
-    } else {
-      const int src = (lane & ~7) | op.b;
-      const bool mine = (j == op.a);
+    }
+    for (int k = 0; k < cur.n_add; ++k) {
+      const int s = cur.slot - k;          // slot (s-1) += slot s
+      const int src = (lane & ~7) | s;
+      const bool mine = (j == s - 1);
 #pragma unroll
       for (int x = 0; x < TT; ++x)
 #pragma unroll
@@ -189,40 +215,50 @@ __global__ __launch_bounds__(kThreads) void maxsum_chunks(const double* __restri
 #pragma unroll
       for (int y = 0; y < TA; ++y) {
         const int a = a0 + ga + 4 * y;
-        if (t < n_sets && a < n_cols) partial[((int64_t)chunk * n_sets + t) * n_cols + a] = st[x][y];
+        if (t < n_sets && a < n_cols) partial[((int64_t)blockIdx.y * n_sets + t) * n_cols + a] = st[x][y];
       }
     }
   }
 }
 
-// chunk sums are accumulated sequentially (numpy's outer reduce loop)
-__global__ __launch_bounds__(kThreads) void combine_chunks(const double* partial, int64_t n_out, int n_chunks,
-                                                           double scale_div, double* out) {
+// finish the tree: fold the spans of each chunk with that chunk's program, then accumulate the
+// chunk sums sequentially (numpy's outer reduce loop)
+__global__ __launch_bounds__(kThreads) void combine_chunks(const double* __restrict__ partial, int64_t n_out,
+                                                           int n_chunks, const int32_t* __restrict__ chunk_span0,
+                                                           const int32_t* __restrict__ chunk_op0,
+                                                           const TopOp* __restrict__ top, double scale_div,
+                                                           double* __restrict__ out) {
   const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (o >= n_out) return;
-  double r = partial[o];
-  for (int q = 1; q < n_chunks; ++q) r += partial[(int64_t)q * n_out + o];
-  out[o] = scale_div != 0.0 ? r / scale_div : r;
+  double total = 0.0;
+  for (int q = 0; q < n_chunks; ++q) {
+    const int s0 = chunk_span0[q], s1 = chunk_span0[q + 1];
+    double p[kMaxSpans];
+    for (int s = s0; s < s1; ++s) p[s - s0] = partial[(int64_t)s * n_out + o];
+    for (int k = chunk_op0[q]; k < chunk_op0[q + 1]; ++k) p[top[k].dst] += p[top[k].src];
+    total = q == 0 ? p[0] : total + p[0];
+  }
+  out[o] = scale_div != 0.0 ? total / scale_div : total;
 }
 
-// abundance share: one 8-lane group per allele set, rows read straight from HBM/L2
-__global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __restrict__ L, int64_t n_rows, int64_t ld,
+// abundance share: one 8-lane group per allele set, rows read straight from L2 / HBM
+__global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __restrict__ L, int64_t ld,
                                                             const int32_t* __restrict__ ids, int n_sets, int c,
-                                                            const Op* __restrict__ ops_full, int n_ops_full,
-                                                            const Op* __restrict__ ops_tail, int n_ops_tail,
-                                                            int n_chunks, double* __restrict__ partial) {
+                                                            const Span* __restrict__ spans,
+                                                            const Leaf* __restrict__ leaves,
+                                                            double* __restrict__ partial) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int j = lane & 7;
   const int k = blockIdx.x * (kThreads / 8) + (tid >> 3);
-  const int chunk = blockIdx.y;
-  const int64_t chunk_row0 = (int64_t)chunk * kChunkRows;
-  const bool tail = (chunk == n_chunks - 1) && (n_rows - chunk_row0 < kChunkRows);
-  const Op* ops = tail ? ops_tail : ops_full;
-  const int n_ops = tail ? n_ops_tail : n_ops_full;
+  const Span span = spans[blockIdx.y];
   const bool live = k < n_sets;
   const double* colp[kMaxC];
 #pragma unroll
   for (int q = 0; q < kMaxC; ++q) colp[q] = L + (int64_t)((live && q < c) ? ids[k * c + q] : 0) * ld;
+  double inv[kMaxC + 1];
+#pragma unroll
+  for (int q = 1; q <= kMaxC; ++q) inv[q] = 1.0 / (double)q;   // exact IEEE quotients, as numpy's bool / int
+  inv[0] = 0.0;
   double st[kMaxC];
 #pragma unroll
   for (int q = 0; q < kMaxC; ++q) st[q] = 0.0;
@@ -238,47 +274,51 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
     int cnt = 0;
 #pragma unroll
     for (int q = 0; q < kMaxC; ++q) cnt += (q < c && v[q] == best) ? 1 : 0;
-    const double share = 1.0 / (double)cnt;
+    double share = inv[1];
+#pragma unroll
+    for (int q = 2; q <= kMaxC; ++q) share = cnt == q ? inv[q] : share;
 #pragma unroll
     for (int q = 0; q < kMaxC; ++q) out_t[q] = (q < c && v[q] == best) ? share : 0.0;
   };
 
-  for (int o = 0; o < n_ops; ++o) {
-    const Op op = ops[o];
-    if (op.kind == 0) {
-      const int64_t r0 = chunk_row0 + op.a;
-      const int len = op.b;
-      const int n8 = len - (len & 7);
-      double acc[kMaxC], t[kMaxC];
-      if (len < 8) {
+  for (int li = span.leaf_begin; li < span.leaf_end; ++li) {
+    const Leaf cur = leaves[li];
+    const int64_t r0 = span.row0 + cur.start;
+    const int len = cur.len;
+    const int n8 = len - (len & 7);
+    double acc[kMaxC], t[kMaxC];
+    if (len < 8) {
 #pragma unroll
-        for (int q = 0; q < kMaxC; ++q) acc[q] = 0.0;
-        for (int r = 0; r < len; ++r) {
-          terms(r0 + r, t);
+      for (int q = 0; q < kMaxC; ++q) acc[q] = 0.0;
+      for (int r = 0; r < len; ++r) {
+        terms(r0 + r, t);
 #pragma unroll
-          for (int q = 0; q < kMaxC; ++q) acc[q] += t[q];
-        }
-      } else {
-        terms(r0 + j, acc);
-        for (int r = 8 + j; r < n8; r += 8) {
-          terms(r0 + r, t);
-#pragma unroll
-          for (int q = 0; q < kMaxC; ++q) acc[q] += t[q];
-        }
-#pragma unroll
-        for (int q = 0; q < kMaxC; ++q) acc[q] = group_sum8(acc[q]);
-        for (int r = n8; r < len; ++r) {
-          terms(r0 + r, t);
-#pragma unroll
-          for (int q = 0; q < kMaxC; ++q) acc[q] += t[q];
-        }
+        for (int q = 0; q < kMaxC; ++q) acc[q] += t[q];
       }
-      const bool mine = (j == op.c);
+    } else {
+      terms(r0 + j, acc);
+      for (int r = 8 + j; r < n8; r += 8) {
+        terms(r0 + r, t);
+#pragma unroll
+        for (int q = 0; q < kMaxC; ++q) acc[q] += t[q];
+      }
+#pragma unroll
+      for (int q = 0; q < kMaxC; ++q) acc[q] = group_sum8(acc[q]);
+      for (int r = n8; r < len; ++r) {
+        terms(r0 + r, t);
+#pragma unroll
+        for (int q = 0; q < kMaxC; ++q) acc[q] += t[q];
+      }
+    }
+    {
+      const bool mine = (j == cur.slot);
 #pragma unroll
       for (int q = 0; q < kMaxC; ++q) st[q] = mine ? acc[q] : st[q];
-    } else {
-      const int src = (lane & ~7) | op.b;
-      const bool mine = (j == op.a);
+    }
+    for (int a = 0; a < cur.n_add; ++a) {
+      const int s = cur.slot - a;
+      const int src = (lane & ~7) | s;
+      const bool mine = (j == s - 1);
 #pragma unroll
       for (int q = 0; q < kMaxC; ++q) {
         const double other = __shfl(st[q], src, 64);
@@ -289,7 +329,7 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
   if (j == 0 && live) {
 #pragma unroll
     for (int q = 0; q < kMaxC; ++q)
-      if (q < c) partial[((int64_t)chunk * n_sets + k) * c + q] = st[q];
+      if (q < c) partial[((int64_t)blockIdx.y * n_sets + k) * c + q] = st[q];
   }
 }
 
@@ -304,37 +344,106 @@ __global__ __launch_bounds__(kThreads) void setmax_kernel(const double* __restri
   }
 }
 
-// numpy pairwise_sum recursion for one chunk, as a post-order stack program
-void build_plan(int start, int n, int slot, std::vector<Op>& ops) {
+// ---------------------------------------------------------------------------------------------
+// host: numpy pairwise_sum recursion as span / leaf / top programs
+struct Program {
+  std::vector<Leaf> leaves;
+  std::vector<Span> spans;
+  std::vector<int32_t> chunk_span0, chunk_op0;
+  std::vector<TopOp> top;
+};
+
+// leaves of a span in post-order; a leaf that completes right sub-trees folds them immediately
+void span_leaves(int start, int n, int slot, std::vector<Leaf>& out) {
   if (n <= kBlockRows) {
-    ops.push_back(Op{0, start, n, slot});
+    out.push_back(Leaf{start, n, slot, 0});
     return;
   }
   int n2 = n / 2;
   n2 -= n2 % 8;
-  build_plan(start, n2, slot, ops);
-  build_plan(start + n2, n - n2, slot + 1, ops);
-  ops.push_back(Op{1, slot, slot + 1, 0});
+  span_leaves(start, n2, slot, out);
+  span_leaves(start + n2, n - n2, slot + 1, out);
+  out.back().n_add += 1;   // after the right child finished: slot += slot + 1
 }
 
-struct Plans {
-  Op* d_ops = nullptr;   // full plan followed by tail plan
-  int n_full = 0, n_tail = 0, n_chunks = 0;
+// returns the (chunk-relative) span index that holds the node's sum
+int chunk_nodes(Program& p, int chunk, int64_t chunk_row0, int start, int n, int first_span) {
+  if (n <= kSpanRows) {
+    Span s;
+    s.row0 = chunk_row0 + start;
+    s.leaf_begin = (int32_t)p.leaves.size();
+    span_leaves(0, n, 0, p.leaves);
+    s.leaf_end = (int32_t)p.leaves.size();
+    s.chunk = chunk;
+    s.pad = 0;
+    p.spans.push_back(s);
+    return (int)p.spans.size() - 1 - first_span;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  const int a = chunk_nodes(p, chunk, chunk_row0, start, n2, first_span);
+  const int b = chunk_nodes(p, chunk, chunk_row0, start + n2, n - n2, first_span);
+  p.top.push_back(TopOp{a, b});
+  return a;
+}
+
+void build_program(int64_t n_rows, Program& p) {
+  const int n_chunks = (int)((n_rows + kChunkRows - 1) / kChunkRows);
+  for (int q = 0; q < n_chunks; ++q) {
+    const int64_t row0 = (int64_t)q * kChunkRows;
+    const int n = (int)std::min<int64_t>(kChunkRows, n_rows - row0);
+    p.chunk_span0.push_back((int32_t)p.spans.size());
+    p.chunk_op0.push_back((int32_t)p.top.size());
+    chunk_nodes(p, q, row0, 0, n, (int)p.spans.size());
+  }
+  p.chunk_span0.push_back((int32_t)p.spans.size());
+  p.chunk_op0.push_back((int32_t)p.top.size());
+}
+
+struct DeviceProgram {
+  char* base = nullptr;
+  Leaf* leaves = nullptr;
+  Span* spans = nullptr;
+  int32_t *chunk_span0 = nullptr, *chunk_op0 = nullptr;
+  TopOp* top = nullptr;
+  int32_t *ids = nullptr, *cols = nullptr;
+  int n_spans = 0, n_chunks = 0;
 };
 
-int make_plans(gk_ctx* ctx, int64_t n_rows, Plans& p) {
-  std::vector<Op> full, tail;
-  build_plan(0, kChunkRows, 0, full);
-  p.n_chunks = (int)((n_rows + kChunkRows - 1) / kChunkRows);
-  const int rem = (int)(n_rows - (int64_t)(p.n_chunks - 1) * kChunkRows);
-  if (rem < kChunkRows) build_plan(0, rem, 0, tail);
-  p.n_full = (int)full.size();
-  p.n_tail = (int)tail.size();
-  std::vector<Op> all(full);
-  all.insert(all.end(), tail.begin(), tail.end());
-  GK_HIP(hipMalloc((void**)&p.d_ops, all.size() * sizeof(Op)));
-  GK_HIP(hipMemcpyAsync(p.d_ops, all.data(), all.size() * sizeof(Op), hipMemcpyHostToDevice, ctx->stream));
-  GK_HIP(hipStreamSynchronize(ctx->stream));
+template <typename T>
+size_t put(std::vector<char>& buf, const T* src, size_t n) {
+  const size_t off = (buf.size() + 15) / 16 * 16;
+  buf.resize(off + std::max<size_t>(n, 1) * sizeof(T));
+  if (n) memcpy(buf.data() + off, src, n * sizeof(T));
+  return off;
+}
+
+int upload_program(gk_ctx* ctx, int64_t n_rows, const int32_t* ids, size_t n_ids, const int32_t* cols, size_t n_cols,
+                   DeviceProgram& d) {
+  Program p;
+  build_program(n_rows, p);
+  for (size_t q = 0; q + 1 < p.chunk_span0.size(); ++q)
+    GK_REQUIRE(p.chunk_span0[q + 1] - p.chunk_span0[q] <= kMaxSpans, "too many spans in a chunk");
+  std::vector<char> buf;
+  const size_t o_leaf = put(buf, p.leaves.data(), p.leaves.size());
+  const size_t o_span = put(buf, p.spans.data(), p.spans.size());
+  const size_t o_cs = put(buf, p.chunk_span0.data(), p.chunk_span0.size());
+  const size_t o_co = put(buf, p.chunk_op0.data(), p.chunk_op0.size());
+  const size_t o_top = put(buf, p.top.data(), p.top.size());
+  const size_t o_ids = put(buf, ids, n_ids);
+  const size_t o_cols = put(buf, cols, n_cols);
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d.base, buf.size()));
+  GK_HIP(hipMemcpyAsync(d.base, buf.data(), buf.size(), hipMemcpyHostToDevice, ctx->stream));
+  GK_HIP(hipStreamSynchronize(ctx->stream));   // buf is pageable and goes out of scope
+  d.leaves = (Leaf*)(d.base + o_leaf);
+  d.spans = (Span*)(d.base + o_span);
+  d.chunk_span0 = (int32_t*)(d.base + o_cs);
+  d.chunk_op0 = (int32_t*)(d.base + o_co);
+  d.top = (TopOp*)(d.base + o_top);
+  d.ids = (int32_t*)(d.base + o_ids);
+  d.cols = (int32_t*)(d.base + o_cols);
+  d.n_spans = (int)p.spans.size();
+  d.n_chunks = (int)p.chunk_span0.size() - 1;
   return GK_OK;
 }
 
@@ -347,29 +456,28 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   GK_REQUIRE(ctx && cols && out && n_rows > 0 && ld >= n_rows && n_cols > 0, "bad maxsum arguments");
   GK_REQUIRE(c_prev >= 0 && c_prev <= kMaxC, "copy number beyond supported set size");
   GK_REQUIRE(n_sets >= 1 && (c_prev == 0 || ids), "missing previous sets");
-  Plans pl;
-  int rc = make_plans(ctx, n_rows, pl);
+  DeviceProgram dp;
+  int rc = upload_program(ctx, n_rows, ids, (size_t)n_sets * c_prev, cols, (size_t)n_cols, dp);
   if (rc) return rc;
   hipStream_t st = ctx->stream;
-  int32_t *d_ids = nullptr, *d_cols = nullptr;
   double *d_partial = nullptr, *d_out = nullptr;
   const int64_t n_out = (int64_t)n_sets * n_cols;
-  GK_HIP(hipMalloc((void**)&d_ids, (size_t)std::max<int64_t>(1, (int64_t)n_sets * c_prev) * sizeof(int32_t)));
-  GK_HIP(hipMalloc((void**)&d_cols, (size_t)n_cols * sizeof(int32_t)));
-  GK_HIP(hipMalloc((void**)&d_partial, (size_t)n_out * pl.n_chunks * sizeof(double)));
-  GK_HIP(hipMalloc((void**)&d_out, (size_t)n_out * sizeof(double)));
-  if (c_prev) GK_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n_sets * c_prev * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  GK_HIP(hipMemcpyAsync(d_cols, cols, (size_t)n_cols * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * dp.n_spans * sizeof(double)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_out * sizeof(double)));
   const int tiles_t = (n_sets + kTileT - 1) / kTileT, tiles_a = (n_cols + kTileA - 1) / kTileA;
-  hipLaunchKernelGGL(maxsum_chunks, dim3((unsigned)(tiles_t * tiles_a), (unsigned)pl.n_chunks), dim3(kThreads), 0, st,
-                     gk_ptr<double>(d_L), n_rows, ld, d_ids, n_sets, c_prev, d_cols, n_cols, pl.d_ops, pl.n_full,
-                     pl.d_ops + pl.n_full, pl.n_tail, pl.n_chunks, d_partial);
-  hipLaunchKernelGGL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
-                     d_partial, n_out, pl.n_chunks, 0.0, d_out);
+  GK_PROF(ctx, GK_K_MAXSUM,
+          hipLaunchKernelGGL(maxsum_chunks, dim3((unsigned)(tiles_t * tiles_a), (unsigned)dp.n_spans), dim3(kThreads),
+                             0, st, gk_ptr<double>(d_L), ld, dp.ids, n_sets, c_prev, dp.cols, n_cols, dp.spans,
+                             dp.leaves, d_partial));
+  GK_PROF(ctx, GK_K_COMBINE,
+          hipLaunchKernelGGL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                             d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, 0.0, d_out));
   GK_HIP(hipGetLastError());
   GK_HIP(hipMemcpyAsync(out, d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
   GK_HIP(hipStreamSynchronize(st));
-  hipFree(d_ids); hipFree(d_cols); hipFree(d_partial); hipFree(d_out); hipFree(pl.d_ops);
+  gk_pool_free(ctx, d_partial);
+  gk_pool_free(ctx, d_out);
+  gk_pool_free(ctx, dp.base);
   return GK_OK;
 }
 
@@ -377,27 +485,28 @@ int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int3
                 double* frac_out) {
   GK_REQUIRE(ctx && ids && frac_out && n_rows > 0 && ld >= n_rows && n_sets > 0, "bad fraction arguments");
   GK_REQUIRE(c >= 1 && c <= kMaxC, "copy number beyond supported set size");
-  Plans pl;
-  int rc = make_plans(ctx, n_rows, pl);
+  DeviceProgram dp;
+  int rc = upload_program(ctx, n_rows, ids, (size_t)n_sets * c, nullptr, 0, dp);
   if (rc) return rc;
   hipStream_t st = ctx->stream;
-  int32_t* d_ids = nullptr;
   double *d_partial = nullptr, *d_out = nullptr;
   const int64_t n_out = (int64_t)n_sets * c;
-  GK_HIP(hipMalloc((void**)&d_ids, (size_t)n_out * sizeof(int32_t)));
-  GK_HIP(hipMalloc((void**)&d_partial, (size_t)n_out * pl.n_chunks * sizeof(double)));
-  GK_HIP(hipMalloc((void**)&d_out, (size_t)n_out * sizeof(double)));
-  GK_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n_out * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * dp.n_spans * sizeof(double)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_out * sizeof(double)));
   const int per_block = kThreads / 8;
-  hipLaunchKernelGGL(fraction_chunks, dim3((unsigned)((n_sets + per_block - 1) / per_block), (unsigned)pl.n_chunks),
-                     dim3(kThreads), 0, st, gk_ptr<double>(d_L), n_rows, ld, d_ids, n_sets, c, pl.d_ops, pl.n_full,
-                     pl.d_ops + pl.n_full, pl.n_tail, pl.n_chunks, d_partial);
-  hipLaunchKernelGGL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
-                     d_partial, n_out, pl.n_chunks, (double)n_rows, d_out);
+  GK_PROF(ctx, GK_K_FRACTION,
+          hipLaunchKernelGGL(fraction_chunks, dim3((unsigned)((n_sets + per_block - 1) / per_block), (unsigned)dp.n_spans),
+                             dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld, dp.ids, n_sets, c, dp.spans, dp.leaves,
+                             d_partial));
+  GK_PROF(ctx, GK_K_COMBINE,
+          hipLaunchKernelGGL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                             d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, (double)n_rows, d_out));
   GK_HIP(hipGetLastError());
   GK_HIP(hipMemcpyAsync(frac_out, d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
   GK_HIP(hipStreamSynchronize(st));
-  hipFree(d_ids); hipFree(d_partial); hipFree(d_out); hipFree(pl.d_ops);
+  gk_pool_free(ctx, d_partial);
+  gk_pool_free(ctx, d_out);
+  gk_pool_free(ctx, dp.base);
   return GK_OK;
 }
 
@@ -406,15 +515,16 @@ int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   GK_REQUIRE(ctx && ids && n_rows > 0 && ld >= n_rows && n_sets > 0 && c >= 1 && c <= kMaxC, "bad setmax arguments");
   hipStream_t st = ctx->stream;
   int32_t* d_ids = nullptr;
-  GK_HIP(hipMalloc((void**)&d_ids, (size_t)n_sets * c * sizeof(int32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_ids, (size_t)n_sets * c * sizeof(int32_t)));
   GK_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n_sets * c * sizeof(int32_t), hipMemcpyHostToDevice, st));
   int64_t want = (n_rows + kThreads - 1) / kThreads;
   unsigned bx = (unsigned)(want < 1024 ? want : 1024);
-  hipLaunchKernelGGL(setmax_kernel, dim3(bx, (unsigned)n_sets), dim3(kThreads), 0, st, gk_ptr<double>(d_L), n_rows, ld,
-                     d_ids, n_sets, c, gk_ptr<double>(d_P));
+  GK_PROF(ctx, GK_K_SETMAX,
+          hipLaunchKernelGGL(setmax_kernel, dim3(bx, (unsigned)n_sets), dim3(kThreads), 0, st, gk_ptr<double>(d_L), n_rows,
+                             ld, d_ids, n_sets, c, gk_ptr<double>(d_P)));
   GK_HIP(hipGetLastError());
   GK_HIP(hipStreamSynchronize(st));
-  hipFree(d_ids);
+  gk_pool_free(ctx, d_ids);
   return GK_OK;
 }
 

@@ -20,14 +20,13 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxEv = 4;
+constexpr int kMaxEv = GK_MAX_EVENTS;
 constexpr uint64_t kEmpty = ~0ull;
 
 struct Events {
   int n;
-  uint32_t pos[kMaxEv];
-  uint32_t len[kMaxEv];   // walker length: 1 single, k insertion / deletion
-  uint64_t key[kMaxEv];
+  uint64_t key[kMaxEv];   // position / type / value of every non-match event (private memory)
+  uint32_t last_len;      // walker length of the last event: 1 single, k insertion / deletion
   bool clipped;
   bool overflow;
   bool last_is_event;     // last walk element is events[n-1]; otherwise a match ending at ref_end
@@ -36,8 +35,14 @@ struct Events {
 
 __device__ inline uint4 load16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 
+constexpr int kMateWords = sizeof(gk_mate) / 4;   // 32
+constexpr int kCigWord = 3;                         // uint16 cig[] starts at byte 12
+constexpr int kMmWord = kCigWord + GK_MAX_CIG / 2;  // 10
+constexpr int kInsWord = kMmWord + GK_MAX_MM;       // 26
+static_assert(sizeof(gk_mate) == 128 && kInsWord + GK_MAX_INS == kMateWords, "gk_mate layout");
+
 struct MateRegs {
-  uint32_t w[16];
+  uint32_t w[kMateWords];
   __device__ uint32_t pos0() const { return w[0]; }
   __device__ uint32_t flag() const { return w[1] & 0xFFFFu; }
   __device__ uint32_t ref() const { return (w[1] >> 16) & 0xFFu; }
@@ -47,18 +52,18 @@ struct MateRegs {
   __device__ uint32_t n_mm() const { return (w[2] >> 16) & 0xFFu; }
   __device__ uint32_t n_ins() const { return w[2] >> 24; }
   __device__ uint32_t cig(int i) const {  // uint16 array starting at byte 12
-    uint32_t word = w[3 + (i >> 1)];
+    uint32_t word = w[kCigWord + (i >> 1)];
     return (i & 1) ? (word >> 16) : (word & 0xFFFFu);
   }
-  __device__ uint32_t mm_off(int i) const { return w[8 + i] & 0xFFFFu; }
-  __device__ uint32_t mm_base(int i) const { return (w[8 + i] >> 16) & 0xFFu; }
-  __device__ uint32_t ins(int i) const { return w[12 + i]; }
+  __device__ uint32_t mm_off(int i) const { return w[kMmWord + i] & 0xFFFFu; }
+  __device__ uint32_t mm_base(int i) const { return (w[kMmWord + i] >> 16) & 0xFFu; }
+  __device__ uint32_t ins(int i) const { return w[kInsWord + i]; }
 };
 
 __device__ inline void load_mate(const gk_mate* mates, int64_t m, MateRegs& r) {
   const uint4* p = reinterpret_cast<const uint4*>(mates + m);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < kMateWords / 4; ++k) {
     uint4 v = p[k];
     r.w[4 * k + 0] = v.x; r.w[4 * k + 1] = v.y; r.w[4 * k + 2] = v.z; r.w[4 * k + 3] = v.w;
   }
@@ -69,8 +74,10 @@ __device__ inline bool mate_passes(const MateRegs& r) {
 }
 
 __device__ inline void push_event(Events& ev, uint32_t pos, uint32_t len, uint64_t key) {
+  (void)pos;
   if (ev.n < kMaxEv) {
-    ev.pos[ev.n] = pos; ev.len[ev.n] = len; ev.key[ev.n] = key;
+    ev.key[ev.n] = key;
+    ev.last_len = len;
     ev.n++;
   } else {
     ev.overflow = true;
@@ -180,7 +187,7 @@ __device__ inline void resolve(const Events& ev, const MateRegs& r, const uint64
   }
   if (ev.last_is_event && ev.n > 0) {
     const int e = ev.n - 1;
-    rs.right = ev.pos[e] + (rs.ord[e] >= 0 ? 0u : ev.len[e]);  // index records carry length 0
+    rs.right = gk_key_pos(ev.key[e]) + (rs.ord[e] >= 0 ? 0u : ev.last_len);  // index records carry length 0
   } else {
     rs.right = ev.ref_end;
   }
@@ -195,7 +202,7 @@ __device__ inline bool negative_kept(uint64_t k, int i, const Events& ev, const 
   for (int e = 0; e < ev.n; ++e) {
     if (rs.ord[e] == i) return false;
     if (gk_key_typ(ev.key[e]) == GK_TYP_SINGLE && gk_key_val(ev.key[e]) == 'N' && typ == GK_TYP_SINGLE &&
-        pos == ev.pos[e] && (val == 'A' || val == 'C' || val == 'G' || val == 'T'))
+        pos == gk_key_pos(ev.key[e]) && (val == 'A' || val == 'C' || val == 'G' || val == 'T'))
       return false;
   }
   if (typ == GK_TYP_DEL && pos + val + 10u >= rs.right) return false;
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
   const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   const bool in = m < n_mates;
   MateRegs r;
-  if (in) load_mate(mates, m, r); else { for (int k = 0; k < 16; ++k) r.w[k] = 0; }
+  if (in) load_mate(mates, m, r); else { for (int k = 0; k < kMateWords; ++k) r.w[k] = 0; }
   const bool ok = in && mate_passes(r);
   const bool ok_other = __shfl_xor((int)ok, 1, 64) != 0;
   const bool pair_ok = ok && ok_other;
@@ -316,25 +323,27 @@ int gk_index_create(gk_ctx* ctx, const uint64_t* key, int32_t n_var, const int32
   gk_index* idx = new gk_index();
   idx->ctx = ctx; idx->n_var = n_var; idx->n_gene = n_gene;
   idx->gene_vbeg.assign(gene_vbeg, gene_vbeg + n_gene + 1);
-  GK_HIP(hipMalloc((void**)&idx->d_key, (size_t)(n_var + 1) * sizeof(uint64_t)));
-  GK_HIP(hipMalloc((void**)&idx->d_gene_vbeg, (size_t)(n_gene + 1) * sizeof(int32_t)));
-  GK_HIP(hipMemcpy(idx->d_key, key, (size_t)n_var * sizeof(uint64_t), hipMemcpyHostToDevice));
-  GK_HIP(hipMemcpy(idx->d_gene_vbeg, gene_vbeg, (size_t)(n_gene + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_key, (size_t)(n_var + 1) * sizeof(uint64_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_gene_vbeg, (size_t)(n_gene + 1) * sizeof(int32_t)));
+  GK_HIP(hipMemcpyAsync(idx->d_key, key, (size_t)n_var * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  GK_HIP(hipMemcpyAsync(idx->d_gene_vbeg, gene_vbeg, (size_t)(n_gene + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  GK_HIP(hipStreamSynchronize(ctx->stream));
   *out = idx;
   return GK_OK;
 }
 
 int gk_index_destroy(gk_index* idx) {
   if (!idx) return GK_OK;
-  hipFree(idx->d_key);
-  hipFree(idx->d_gene_vbeg);
+  gk_ctx* ctx = idx->ctx;
+  gk_pool_free(ctx,idx->d_key);
+  gk_pool_free(ctx,idx->d_gene_vbeg);
   delete idx;
   return GK_OK;
 }
 
 int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, gk_tab** out) {
   GK_REQUIRE(ctx && idx && out && n_pairs >= 0, "bad tabulate arguments");
-  GK_REQUIRE(n_pairs < (1ll << 28), "more than 2^28 pairs per call");
+  GK_REQUIRE(n_pairs < (1ll << 26), "more than 2^26 pairs per call");
   const gk_mate* mates = gk_ptr<const gk_mate>(d_mates_p);
   const int64_t n_mates = 2 * n_pairs;
   hipStream_t st = ctx->stream;
@@ -349,22 +358,22 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
   NovelTable nt;
   const size_t cap = 1ull << log2cap;
   nt.mask = (uint32_t)(cap - 1);
-  GK_HIP(hipMalloc((void**)&nt.keys, cap * sizeof(uint64_t)));
-  GK_HIP(hipMalloc((void**)&nt.seq, cap * sizeof(uint32_t)));
-  GK_HIP(hipMalloc((void**)&nt.rank, cap * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&nt.keys, cap * sizeof(uint64_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&nt.seq, cap * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&nt.rank, cap * sizeof(uint32_t)));
   GK_HIP(hipMemsetAsync(nt.keys, 0xFF, cap * sizeof(uint64_t), st));
   GK_HIP(hipMemsetAsync(nt.seq, 0xFF, cap * sizeof(uint32_t), st));
 
   uint32_t *cnt = nullptr, *valid = nullptr;
   int* d_err = nullptr;
-  GK_HIP(hipMalloc((void**)&cnt, (size_t)(4 * n_pairs + 2) * sizeof(uint32_t)));
-  GK_HIP(hipMalloc((void**)&valid, (size_t)(n_pairs + 1) * sizeof(uint32_t)));
-  GK_HIP(hipMalloc((void**)&d_err, sizeof(int)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&cnt, (size_t)(4 * n_pairs + 2) * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&valid, (size_t)(n_pairs + 1) * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_err, sizeof(int)));
   GK_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
 
   if (n_mates) {
-    hipLaunchKernelGGL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, idx->d_key,
-                       idx->n_var, nt, cnt, valid, d_err);
+    GK_PROF(ctx, GK_K_TAB_COUNT, hipLaunchKernelGGL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, idx->d_key,
+                       idx->n_var, nt, cnt, valid, d_err));
   }
   // offsets over input pairs (invalid pairs contribute zeros)
   int rc = gk_scan_u32(ctx, cnt, 4 * n_pairs, cnt + 4 * n_pairs);
@@ -374,11 +383,11 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
   const int64_t n_seq = n_mates * kMaxEv;
   const int64_t n_words = (n_seq + 31) / 32 + 1;
   uint32_t *bitmap = nullptr, *prefix = nullptr;
-  GK_HIP(hipMalloc((void**)&bitmap, (size_t)n_words * sizeof(uint32_t)));
-  GK_HIP(hipMalloc((void**)&prefix, (size_t)(n_words + 1) * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&bitmap, (size_t)n_words * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&prefix, (size_t)(n_words + 1) * sizeof(uint32_t)));
   GK_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_words * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(novel_mark, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap);
-  hipLaunchKernelGGL(bitmap_popc, dim3(nblk(n_words)), dim3(kThreads), 0, st, bitmap, prefix, n_words);
+  GK_PROF(ctx, GK_K_NOVEL, hipLaunchKernelGGL(novel_mark, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap));
+  GK_PROF(ctx, GK_K_NOVEL, hipLaunchKernelGGL(bitmap_popc, dim3(nblk(n_words)), dim3(kThreads), 0, st, bitmap, prefix, n_words));
   rc = gk_scan_u32(ctx, prefix, n_words, prefix + n_words);
   if (rc) return rc;
 
@@ -396,28 +405,28 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
     return GK_ERR_CAPACITY;
   }
 
-  GK_HIP(hipMalloc((void**)&tab->d_novel_key, (size_t)(tab->n_novel + 1) * sizeof(uint64_t)));
-  hipLaunchKernelGGL(novel_assign, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap, prefix,
-                     tab->d_novel_key);
+  GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_novel_key, (size_t)(tab->n_novel + 1) * sizeof(uint64_t)));
+  GK_PROF(ctx, GK_K_NOVEL, hipLaunchKernelGGL(novel_assign, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap, prefix,
+                     tab->d_novel_key));
 
-  GK_HIP(hipMalloc((void**)&tab->d_ids, (size_t)(tab->n_ids + 1) * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_ids, (size_t)(tab->n_ids + 1) * sizeof(uint32_t)));
   if (n_mates) {
-    hipLaunchKernelGGL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, idx->d_key, idx->n_var,
-                       nt, cnt, valid, tab->d_ids);
+    GK_PROF(ctx, GK_K_TAB_EMIT, hipLaunchKernelGGL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, idx->d_key, idx->n_var,
+                       nt, cnt, valid, tab->d_ids));
   }
   // compact valid pairs (order preserving)
-  GK_HIP(hipMalloc((void**)&tab->d_pair_src, (size_t)(n_pairs + 1) * sizeof(int32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_pair_src, (size_t)(n_pairs + 1) * sizeof(int32_t)));
   rc = gk_compact(ctx, valid, nullptr, n_pairs, tab->d_pair_src, &tab->n_valid);
   if (rc) return rc;
-  GK_HIP(hipMalloc((void**)&tab->d_off, (size_t)(4 * tab->n_valid + 1) * sizeof(uint32_t)));
-  GK_HIP(hipMalloc((void**)&tab->d_pair_gene, (size_t)tab->n_valid + 1));
-  GK_HIP(hipMalloc((void**)&tab->d_pair_nh, (size_t)tab->n_valid + 1));
-  hipLaunchKernelGGL(gather_pairs, dim3(nblk(tab->n_valid + 1)), dim3(kThreads), 0, st, mates, tab->d_pair_src,
-                     tab->n_valid, cnt, tab->d_off, tab->d_pair_gene, tab->d_pair_nh, (uint32_t)tab->n_ids);
+  GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_off, (size_t)(4 * tab->n_valid + 1) * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_pair_gene, (size_t)tab->n_valid + 1));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_pair_nh, (size_t)tab->n_valid + 1));
+  GK_PROF(ctx, GK_K_SELECT, hipLaunchKernelGGL(gather_pairs, dim3(nblk(tab->n_valid + 1)), dim3(kThreads), 0, st, mates, tab->d_pair_src,
+                     tab->n_valid, cnt, tab->d_off, tab->d_pair_gene, tab->d_pair_nh, (uint32_t)tab->n_ids));
   GK_HIP(hipGetLastError());
   GK_HIP(hipStreamSynchronize(st));
-  hipFree(cnt); hipFree(valid); hipFree(d_err); hipFree(bitmap); hipFree(prefix);
-  hipFree(nt.keys); hipFree(nt.seq); hipFree(nt.rank);
+  gk_pool_free(ctx,cnt); gk_pool_free(ctx,valid); gk_pool_free(ctx,d_err); gk_pool_free(ctx,bitmap); gk_pool_free(ctx,prefix);
+  gk_pool_free(ctx,nt.keys); gk_pool_free(ctx,nt.seq); gk_pool_free(ctx,nt.rank);
   if (err & 2) {
     gk_set_error("a filter-passing mate carries more than %d variant events", kMaxEv);
     gk_tab_destroy(tab);
@@ -437,10 +446,10 @@ int gk_tab_from_csr(gk_ctx* ctx, int32_t n_var_total, int64_t n_valid, const uin
   tab->ctx = ctx; tab->n_pairs = n_valid; tab->n_valid = n_valid; tab->n_ids = n_ids;
   tab->n_var = n_var_total; tab->n_novel = 0;
   hipStream_t st = ctx->stream;
-  GK_HIP(hipMalloc((void**)&tab->d_off, (size_t)(4 * n_valid + 1) * sizeof(uint32_t)));
-  GK_HIP(hipMalloc((void**)&tab->d_ids, (size_t)(n_ids + 1) * sizeof(uint32_t)));
-  GK_HIP(hipMalloc((void**)&tab->d_pair_gene, (size_t)n_valid + 1));
-  GK_HIP(hipMalloc((void**)&tab->d_pair_nh, (size_t)n_valid + 1));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_off, (size_t)(4 * n_valid + 1) * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_ids, (size_t)(n_ids + 1) * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_pair_gene, (size_t)n_valid + 1));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_pair_nh, (size_t)n_valid + 1));
   GK_HIP(hipMemcpyAsync(tab->d_off, off, (size_t)(4 * n_valid + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   if (n_ids) GK_HIP(hipMemcpyAsync(tab->d_ids, ids, (size_t)n_ids * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   if (n_valid) {
@@ -464,8 +473,9 @@ int gk_tab_get_info(gk_tab* tab, gk_tab_info* info) {
 
 int gk_tab_destroy(gk_tab* tab) {
   if (!tab) return GK_OK;
-  hipFree(tab->d_pair_src); hipFree(tab->d_off); hipFree(tab->d_ids);
-  hipFree(tab->d_pair_gene); hipFree(tab->d_pair_nh); hipFree(tab->d_novel_key);
+  gk_ctx* ctx = tab->ctx;
+  gk_pool_free(ctx,tab->d_pair_src); gk_pool_free(ctx,tab->d_off); gk_pool_free(ctx,tab->d_ids);
+  gk_pool_free(ctx,tab->d_pair_gene); gk_pool_free(ctx,tab->d_pair_nh); gk_pool_free(ctx,tab->d_novel_key);
   delete tab;
   return GK_OK;
 }

@@ -147,11 +147,11 @@ int gk_select_gene(gk_ctx* ctx, gk_tab* tab, int gene, int multiple, gk_dptr d_r
   const int64_t n = tab->n_valid;
   if (n == 0) { *n_out = 0; return GK_OK; }
   uint32_t* flag = nullptr;
-  GK_HIP(hipMalloc((void**)&flag, (size_t)n * sizeof(uint32_t)));
-  hipLaunchKernelGGL(flag_gene, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream, tab->d_pair_gene, tab->d_pair_nh, n,
-                     gene, multiple, flag);
+  GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)n * sizeof(uint32_t)));
+  GK_PROF(ctx, GK_K_SELECT, hipLaunchKernelGGL(flag_gene, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream, tab->d_pair_gene, tab->d_pair_nh, n,
+                     gene, multiple, flag));
   int rc = gk_compact(ctx, flag, nullptr, n, gk_ptr<int32_t>(d_rows_out), n_out);
-  hipFree(flag);
+  gk_pool_free(ctx,flag);
   return rc;
 }
 
@@ -160,11 +160,11 @@ int gk_select_nonempty(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows,
   GK_REQUIRE(ctx && tab && n_out, "null pointer");
   if (n_rows == 0) { *n_out = 0; return GK_OK; }
   uint32_t* flag = nullptr;
-  GK_HIP(hipMalloc((void**)&flag, (size_t)n_rows * sizeof(uint32_t)));
-  hipLaunchKernelGGL(flag_nonempty, dim3(nblk(n_rows)), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
-                     n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), flag);
+  GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)n_rows * sizeof(uint32_t)));
+  GK_PROF(ctx, GK_K_SELECT, hipLaunchKernelGGL(flag_nonempty, dim3(nblk(n_rows)), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
+                     n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), flag));
   int rc = gk_compact(ctx, flag, gk_ptr<int32_t>(d_rows), n_rows, gk_ptr<int32_t>(d_rows_out), n_out);
-  hipFree(flag);
+  gk_pool_free(ctx,flag);
   return rc;
 }
 
@@ -174,8 +174,8 @@ int gk_variant_count(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, g
   uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
   GK_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * nv) * sizeof(uint32_t), ctx->stream));
   if (n_rows)
-    hipLaunchKernelGGL(count_ids, dim3(nblk(4 * n_rows)), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
-                       n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), cnt, cnt + nv);
+    GK_PROF(ctx, GK_K_COUNT_IDS, hipLaunchKernelGGL(count_ids, dim3(nblk(4 * n_rows)), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
+                       n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), cnt, cnt + nv));
   GK_HIP(hipGetLastError());
   return GK_OK;
 }
@@ -185,8 +185,8 @@ int gk_variant_correct(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag)
   const int64_t nv = (int64_t)tab->n_var + tab->n_novel;
   uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
   if (nv)
-    hipLaunchKernelGGL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, ctx->stream, cnt, cnt + nv, nv,
-                       gk_ptr<uint8_t>(d_vflag));
+    GK_PROF(ctx, GK_K_COUNT_IDS, hipLaunchKernelGGL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, ctx->stream, cnt, cnt + nv, nv,
+                       gk_ptr<uint8_t>(d_vflag)));
   GK_HIP(hipGetLastError());
   return GK_OK;
 }
@@ -205,10 +205,10 @@ int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr 
   int64_t want = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
   unsigned blocks = (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
   for (int a_base = 0; a_base < n_allele; a_base += 64 * kSlots) {
-    hipLaunchKernelGGL(compat_kernel, dim3(blocks), dim3(kThreads), lds_bytes, ctx->stream, gk_ptr<int32_t>(d_rows),
+    GK_PROF(ctx, GK_K_COMPAT, hipLaunchKernelGGL(compat_kernel, dim3(blocks), dim3(kThreads), lds_bytes, ctx->stream, gk_ptr<int32_t>(d_rows),
                        n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, gk_ptr<uint32_t>(d_mask),
                        words, n_allele, a_base, lds_rows, gk_ptr<double>(d_probs), gk_ptr<uint8_t>(d_miss),
-                       gk_ptr<uint16_t>(d_nvar));
+                       gk_ptr<uint16_t>(d_nvar)));
   }
   GK_HIP(hipGetLastError());
   return GK_OK;

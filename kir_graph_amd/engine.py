@@ -132,7 +132,47 @@ class Tabulation:
             return override
         names = [str(v.id) for v in self.dindex.host.variants]
         names += [f"nv{self.novel_base + r}" for r in range(self.n_novel)]
+        self._id_names = names
         return names
+
+    def labelCodes(self, ordinals):
+        """Vectorised (pos, label code, is_deletion) of ordinals; equal codes <=> equal ``str(val)``.
+
+        None for list-built tabulations (no packed keys); callers then use ``describe``.
+        """
+        if getattr(self, "_variant_src", None) is not None:
+            return None
+        keys_all = getattr(self, "_keys_all", None)
+        if keys_all is None:
+            keys_all = self._keys_all = np.concatenate([self.dindex.host.key, self.novelKeys()])
+        k = keys_all[np.asarray(ordinals, dtype=np.int64)].astype(np.int64)
+        typ = (k >> KEY_TYP_SHIFT) & 3
+        val = k & KEY_VAL_MASK
+        ins_code = getattr(self, "_ins_code", None)
+        if ins_code is None:
+            strings = getattr(self, "ins_strings", None) or self.dindex.host.ins_strings
+            # a one-base insertion prints like a SNP of that base (str(val) is the key in the reference)
+            ins_code = self._ins_code = np.array(
+                [ord(s) if len(s) == 1 else 256 + i for i, s in enumerate(strings)] or [0], dtype=np.int64)
+        code = np.where(typ == 0, ins_code[np.minimum(val, len(ins_code) - 1)], val)
+        return (k >> KEY_POS_SHIFT) & 0xFFFFFF, code, typ == 2
+
+    def describe(self, ordinals) -> list[tuple[int, str, str]]:
+        """(pos, typ, str(val)) of the given ordinals without building Variant objects."""
+        src = getattr(self, "_variant_src", None)
+        if src is not None:   # list-built tabulation: ordinals index the caller's variant list
+            return [(src[o].pos, src[o].typ, str(src[o].val)) for o in ordinals]
+        keys_all = getattr(self, "_keys_all", None)
+        if keys_all is None:
+            keys_all = self._keys_all = np.concatenate([self.dindex.host.key, self.novelKeys()])
+        strings = getattr(self, "ins_strings", None) or self.dindex.host.ins_strings
+        out = []
+        for k in keys_all[np.asarray(ordinals, dtype=np.int64)].tolist():
+            typ = TYPE_OF_RANK[(k >> KEY_TYP_SHIFT) & 3]
+            val = k & KEY_VAL_MASK
+            label = chr(val) if typ == "single" else (str(val) if typ == "deletion" else strings[val])
+            out.append(((k >> KEY_POS_SHIFT) & 0xFFFFFF, typ, label))
+        return out
 
     # ---- selections
     def selectGene(self, gene: int, multiple: bool = False) -> tuple[DeviceBuffer, int]:

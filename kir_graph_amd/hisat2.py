@@ -121,10 +121,24 @@ def filterRead(line: str, num_editdist: int = 4) -> bool:
 class SampleData:
     """Tabulated sample: device CSR (``Tabulation``) + variant table + gene tables."""
 
-    def __init__(self, tab: Tabulation, index: GkIndex, novel: list[Variant], pairs_text=None):
-        self.tab, self.index, self.novel = tab, index, novel
+    def __init__(self, tab: Tabulation, index: GkIndex, novel: list[Variant] | None = None, pairs_text=None,
+                 ins_strings: list[str] | None = None):
+        self.tab, self.index = tab, index
+        self._novel = novel           # built lazily from the device keys when None
+        self.ins_strings = ins_strings if ins_strings is not None else index.ins_strings
+        tab.ins_strings = self.ins_strings
         self.pairs_text = pairs_text  # [(l_sam, r_sam)] of the input pairs, when available
         self._reads = None
+
+    @property
+    def novel(self) -> list[Variant]:
+        """Novel variants of the sample (objects are only built when somebody needs them)."""
+        if self._novel is None:
+            self._novel = self.tab.novelVariants(self.ins_strings)
+        return self._novel
+
+    def novelOfGene(self, gene: str) -> list[Variant]:
+        return [v for v in self.novel if v.ref == gene]
 
     @property
     def variants(self) -> list[Variant]:
@@ -194,6 +208,7 @@ class SampleData:
         tab.n_valid, tab.n_ids = n, int(info.n_ids)
         tab.n_novel, tab.novel_base, tab._novel_keys = len(novel), 0, None
         tab._id_names = [str(v.id) for v in index.variants + novel]
+        tab._variant_src = index.variants + novel
         self = cls(tab, index, novel)
         self._reads = list(reads)
         return self
@@ -217,10 +232,9 @@ def extractVariant(pair_reads: Iterable[tuple[str, str]], index: GkIndex | list[
     rec, table = packPairs(pairs, index)
     base = Variant.novel_id
     tab = Tabulation(dindex, rec, novel_base=base)
-    novel = tab.novelVariants(table.strings)
     Variant.novel_id = base + tab.n_novel
     logger.info(f"[Graph] Filterd pairs: {tab.n_valid}")
-    return SampleData(tab, index, novel, pairs_text=pairs)
+    return SampleData(tab, index, None, pairs_text=pairs, ins_strings=table.strings)
 
 
 def writeReadsAndVariantsData(reads_data: ReadsAndVariantsData, filename: str) -> None:

@@ -79,13 +79,15 @@ class _GeneView:
             self.rows, self.n_rows = tab.dev.alloc(1, np.int32), 0
             self.vbeg = self.n_span = 0
             self.mask, self.alleles, self.variants = None, [], []
+            self.novel = lambda: []
             return
         t = idx.tables[g]
         self.rows, self.n_rows = tab.selectGene(g, multiple)
         self.vbeg, self.n_span = t.vbeg, t.vend - t.vbeg
         self.mask = tab.dindex.masks[g]
         self.alleles = t.alleles
-        self.variants = data.variantsOfGene(gene)
+        self.variants = idx.variants[t.vbeg:t.vend]          # index part; novel ones are built lazily
+        self.novel = lambda: data.novelOfGene(gene)
 
     def exonFlags(self) -> np.ndarray:
         idx, tab = self.data.index, self.data.tab
@@ -124,12 +126,13 @@ class TypingWithPosNegAllele(Typing):
             typ: AlleleTyping = AlleleTyping(
                 reads, view.variants, force_homo=force_homo, top_n=self._top_n,
                 variant_correction=self._variant_correction, logs=self._logs, _vbeg=view.vbeg,
-                _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles)
+                _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles, _novel=view.novel)
         else:
             typ = AlleleTypingExonFirst(
                 reads, view.variants, force_homo=force_homo, top_n=self._top_n, exon_only=self._exon_only,
                 candidate_set_threshold=self._exon_candidate_threshold, logs=self._logs, _vbeg=view.vbeg,
-                _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles, _exon_flags=view.exonFlags())
+                _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles, _exon_flags=view.exonFlags(),
+                _novel=view.novel)
         res = typ.typing(cn)
         self._result[gene] = typ.result
         alleles = [a if a != "fail" else f"{pure_gene}*" for a in res.selectBest()]

@@ -229,7 +229,15 @@ def packSample(sample, index: GkIndex, table: InsTable | None = None) -> tuple[n
 
     ev_cnt = (sample.ev_off[1:] - sample.ev_off[:-1])[src]
     if np.any(todo & (ev_cnt > MAX_EV)):
-        raise PackCapacityError("a filter-passing synthetic mate has more than 4 events")
+        raise PackCapacityError(f"a filter-passing synthetic mate has more than {MAX_EV} events")
+    if np.any(todo):
+        kinds_all = sample.ev_kind
+        per_mate = lambda sel: np.bincount(  # noqa: E731
+            np.repeat(np.arange(n_m), sample.ev_off[1:] - sample.ev_off[:-1])[sel], minlength=n_m)[src]
+        if (np.any(todo & (per_mate(kinds_all == EV_SINGLE) > MAX_MM))
+                or np.any(todo & (per_mate(kinds_all == EV_INS) > MAX_INS))
+                or np.any(todo & (2 * per_mate(kinds_all != EV_SINGLE) + 1 > MAX_CIG))):
+            raise PackCapacityError("a filter-passing synthetic mate does not fit gk_mate")
     # flatten the events of the records to pack
     slots = np.nonzero(todo)[0]
     cnt = ev_cnt[slots]

@@ -340,19 +340,21 @@ def makeSample(index: SynthIndex, seed: int = 1031, n_pairs: int = 2000,
         if sel.any():
             refbase[sel] = index.backbone[g][np.minimum(p[sel], len(index.backbone[g]) - 1)]
     keep &= ~(single & (v == refbase))
-    m, p, kk, v = m[keep], p[keep], kk[keep], v[keep]
+    m, p, kk, v, is_err = m[keep], p[keep], kk[keep], v[keep], is_err[keep]
 
     n_m = 2 * n_pairs
     ev_cnt = np.bincount(m, minlength=n_m)
     ev_off = np.zeros(n_m + 1, dtype=np.int64)
     np.cumsum(ev_cnt, out=ev_off[1:])
-    # edit distance
-    w = np.where(kk == EV_SINGLE, 1, 0).astype(np.int64)
-    w = np.where(kk == EV_DEL, v, w)
-    if ins_strings:
-        ins_len = np.array([len(s) for s in ins_strings], dtype=np.int64)
-        w = np.where(kk == EV_INS, ins_len[np.where(kk == EV_INS, v, 0)], w)
-    nm = np.bincount(m, weights=w, minlength=n_m).astype(np.int32)
+    # NM: HISAT2 counts only edits that are NOT variants of the graph (the reference's own example,
+    # hisat2.py:294, is a read with two graph deletions that must pass the NM <= 4 filter), so
+    # allele-carried variants cost nothing and substitution errors cost 1 unless they hit a graph SNP.
+    known = np.array(sorted((gi << 40) | (vv.pos << 8) | ord(str(vv.val))
+                            for gi, g in enumerate(genes) for vv in variants_by_gene.get(g, [])
+                            if vv.typ == "single"), dtype=np.int64)
+    ekey = (pair_gene[m // 2].astype(np.int64) << 40) | (p.astype(np.int64) << 8) | v.astype(np.int64)
+    novel = is_err & ~np.isin(ekey, known)
+    nm = np.bincount(m[novel], minlength=n_m).astype(np.int32)
 
     # flags / NH / secondary / clipping
     strand = rng.random(n_pairs) < 0.5
@@ -362,6 +364,15 @@ def makeSample(index: SynthIndex, seed: int = 1031, n_pairs: int = 2000,
     improper = rng.random(n_pairs) < frac_improper
     flag[0::2] = np.where(improper, flag[0::2] & ~np.uint16(2), flag[0::2])
     flag[1::2] = np.where(improper, flag[1::2] & ~np.uint16(2), flag[1::2])
+    # mates that would not fit the packed device record are reported as not properly paired (both
+    # the SAM and the packed route then drop the pair in filterRead)
+    n_single = np.bincount(m[kk == EV_SINGLE], minlength=n_m)
+    n_indel = np.bincount(m[kk != EV_SINGLE], minlength=n_m)
+    n_ins = np.bincount(m[kk == EV_INS], minlength=n_m)
+    too_big = (n_single > 16) | (n_ins > 6) | (2 * n_indel + 1 > 14) | (ev_cnt > 22)
+    big_pair = too_big[0::2] | too_big[1::2]
+    flag[0::2] = np.where(big_pair, flag[0::2] & ~np.uint16(2), flag[0::2])
+    flag[1::2] = np.where(big_pair, flag[1::2] & ~np.uint16(2), flag[1::2])
     pair_nh = np.where(rng.random(n_pairs) < frac_multi, 2, 1).astype(np.uint8)
     clip = np.zeros((n_m, 2), dtype=np.int32)
     clipped = np.nonzero(rng.random(n_m) < frac_clip)[0]

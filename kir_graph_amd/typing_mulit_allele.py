@@ -161,8 +161,14 @@ def rankScore(value: np.ndarray, value_sum_indv: np.ndarray, fraction: np.ndarra
 
 def firstOccurrence(ids: np.ndarray, n_allele: int) -> np.ndarray:
     """Mask of the first occurrence of every allele multiset (uniqueAllele 456-476), vectorised."""
-    srt = np.sort(ids, axis=1).astype(np.int64)
+    ids = np.asarray(ids, dtype=np.int64)
     bits = max(1, int(n_allele - 1).bit_length())
+    if ids.shape[1] == 2:
+        # two alleles per set: order them with min / max and test duplicates by hashing
+        import pandas as pd
+        key = (np.minimum(ids[:, 0], ids[:, 1]) << bits) | np.maximum(ids[:, 0], ids[:, 1])
+        return ~pd.Series(key).duplicated(keep="first").to_numpy()
+    srt = np.sort(ids, axis=1)
     if bits * ids.shape[1] > 62:
         seen, keep = set(), np.zeros(len(ids), dtype=bool)
         for i, row in enumerate(map(tuple, srt)):
@@ -172,10 +178,8 @@ def firstOccurrence(ids: np.ndarray, n_allele: int) -> np.ndarray:
     key = np.zeros(len(ids), dtype=np.int64)
     for j in range(ids.shape[1]):
         key = (key << bits) | srt[:, j]
-    _, first = np.unique(key, return_index=True)
-    keep = np.zeros(len(ids), dtype=bool)
-    keep[first] = True
-    return keep
+    import pandas as pd
+    return ~pd.Series(key).duplicated(keep="first").to_numpy()
 
 
 # ---------------------------------------------------------------- device read set
@@ -215,6 +219,7 @@ class ReadSet:
         tab.info, tab.n_valid, tab.n_ids = info, n, int(info.n_ids)
         tab.n_novel, tab.novel_base, tab._novel_keys = 0, 0, None
         tab._id_names = [str(v.id) for v in variants] or ["-"]
+        tab._variant_src = list(variants)
         rows = dev.put(np.arange(max(n, 1), dtype=np.int32))
         return cls(tab, rows, n), ordinal
 
@@ -257,13 +262,16 @@ class AlleleTyping:
     def __init__(self, reads, variants: list[Variant], force_homo: bool | None = None, top_n: int = 300,
                  no_empty: bool = True, variant_correction: bool = True, *, device: Device | None = None,
                  logs: LogTable | None = None, _vbeg: int = 0, _n_span: int | None = None,
-                 _mask: DeviceBuffer | None = None, _alleles: list[str] | None = None, _defer_log: bool = False):
+                 _mask: DeviceBuffer | None = None, _alleles: list[str] | None = None, _defer_log: bool = False,
+                 _novel=None):
         self.top_n = top_n
         self._no_empty = no_empty
         self.force_homo = force_homo
         if not no_empty:
             raise NotImplementedError("no_empty=False is not used by the pipeline and not implemented on the device")
-        self.variants: dict[str, Variant] = {str(v.id): v for v in variants}
+        self._variant_list = variants
+        self._novel_provider = _novel    # callable -> novel variants of the gene (built on demand)
+        self._variants_map: dict[str, Variant] | None = None
         names = _alleles if _alleles is not None else sorted(self.collectAlleleNames(variants))
         self.id_to_allele: dict[int, str] = dict(enumerate(names))
         self.allele_to_id: dict[str, int] = {a: i for i, a in self.id_to_allele.items()}
@@ -303,6 +311,14 @@ class AlleleTyping:
         self._model.finishLog()
 
     # ---- reference attribute surface (lazy)
+    @property
+    def variants(self) -> dict[str, Variant]:
+        """variant id -> Variant (index variants of the gene + the sample's novel ones)."""
+        if self._variants_map is None:
+            extra = self._novel_provider() if self._novel_provider is not None else []
+            self._variants_map = {str(v.id): v for v in chain(self._variant_list, extra)}
+        return self._variants_map
+
     @property
     def probs(self) -> np.ndarray:
         return self._model.hostProbs()
@@ -410,17 +426,27 @@ class AlleleTyping:
         ids, score = ids[first], score[first]
         top = np.argsort(score)[::-1][:max(self.top_n, score.shape[0] // 5)]
         top_ids = ids[top]
-        res = TypingResult(
-            n=prev.n + 1, value=score[top],
-            value_sum_indv=self._colsums()[top_ids],            # = log_probs[:, ids].sum(axis=0)
-            allele_id=top_ids, allele_name=[], allele_prob=LazyAlleleProb([(m, top_ids)]),
-            fraction=m.fraction(top_ids), fraction_uniq=np.ones(top_ids.shape))
-        order = rankScore(res.value, res.value_sum_indv, res.fraction)[:self.top_n]
+        value = score[top]
+        sum_indv = self._colsums()[top_ids]                     # = log_probs[:, ids].sum(axis=0)
+        key1, key2 = -value, -sum_indv.sum(axis=1)
+        # The reference computes abundance fractions for all K = max(top_n, N//5) kept sets and then
+        # keeps the first top_n under the stable order (-value, -sum, unevenness).  Unevenness is the
+        # last key, so only rows not worse than the top_n-th row on the first two keys can make the
+        # cut: fractions are evaluated for those contenders only (same final rows, same order).
+        if len(top_ids) > self.top_n:
+            b = np.lexsort((key2, key1))[self.top_n - 1]
+            contend = np.nonzero((key1 < key1[b]) | ((key1 == key1[b]) & (key2 <= key2[b])))[0]
+        else:
+            contend = np.arange(len(top_ids))
+        frac = m.fraction(top_ids[contend])
+        uneven = np.abs(frac - frac.mean(axis=1, keepdims=True)).sum(axis=1)
+        sub = np.lexsort((uneven, key2[contend], key1[contend]))[:self.top_n]
+        order = contend[sub]
         kept = top_ids[order]
         res = TypingResult(
-            n=res.n, value=res.value[order], value_sum_indv=res.value_sum_indv[order], allele_id=kept,
+            n=prev.n + 1, value=value[order], value_sum_indv=sum_indv[order], allele_id=kept,
             allele_name=self.mapAlleleIDs(kept), allele_prob=LazyAlleleProb([(m, kept)]),
-            fraction=res.fraction[order], fraction_uniq=res.fraction_uniq[order])
+            fraction=frac[sub], fraction_uniq=np.ones(kept.shape))
         self.result.append(res)
         return res
 
@@ -439,16 +465,37 @@ class AlleleTyping:
         if cn <= 1:
             return False
         pos, neg = self._variantCounts()
-        names = self._readset.tab.idNames()
-        site: dict[int, dict[str, int]] = defaultdict(lambda: defaultdict(int))
-        for o in np.nonzero(pos + neg)[0]:
-            v = self.variants.get(names[o])
-            if v is None or v.typ == "deletion":
-                continue
-            if pos[o]:
-                site[v.pos][str(v.val)] += int(pos[o])
-            if neg[o]:
-                site[v.pos][f"*{v.val}"] += int(neg[o])
+        seen = np.nonzero(pos + neg)[0]
+        tab = self._readset.tab
+        fields = tab.labelCodes(seen)
+        if fields is not None:
+            # vectorised screen: only positions with >= 2 distinct observations, one of them positive,
+            # can change the verdict (lines 835-840 skip the rest)
+            vpos, code, is_del = fields
+            keep = ~is_del
+            o, vpos, code = seen[keep], vpos[keep], code[keep]
+            ent_pos = np.concatenate([vpos[pos[o] > 0], vpos[neg[o] > 0]])
+            ent_code = np.concatenate([code[pos[o] > 0], code[neg[o] > 0]])
+            ent_neg = np.concatenate([np.zeros(int((pos[o] > 0).sum()), bool), np.ones(int((neg[o] > 0).sum()), bool)])
+            ent_cnt = np.concatenate([pos[o][pos[o] > 0], neg[o][neg[o] > 0]]).astype(np.int64)
+            upos, inv_site = np.unique(ent_pos, return_inverse=True)
+            n_keys = np.bincount(inv_site, minlength=len(upos))          # upper bound on distinct keys
+            n_posk = np.bincount(inv_site[~ent_neg], minlength=len(upos))
+            cand = np.nonzero((n_keys >= 2) & (n_posk >= 1))[0]
+            site: dict[int, dict[str, int]] = defaultdict(lambda: defaultdict(int))
+            sel = np.isin(inv_site, cand)
+            for p_, c_, ng, ct in zip(ent_pos[sel].tolist(), ent_code[sel].tolist(), ent_neg[sel].tolist(),
+                                      ent_cnt[sel].tolist()):
+                site[p_][f"*{c_}" if ng else f"{c_}"] += ct
+        else:
+            site = defaultdict(lambda: defaultdict(int))
+            for o, (vpos, typ, label) in zip(seen, tab.describe(seen)):
+                if typ == "deletion":
+                    continue
+                if pos[o]:
+                    site[vpos][label] += int(pos[o])
+                if neg[o]:
+                    site[vpos][f"*{label}"] += int(neg[o])
         hits = 0
         for obs in site.values():
             if len(obs) <= 1 or all("*" in k for k in obs):
@@ -472,7 +519,7 @@ class AlleleTypingExonFirst(AlleleTyping):
                  candidate_set_threshold: float = 1.0, variant_correction: bool = True,
                  force_homo: bool | None = None, *, device: Device | None = None, logs: LogTable | None = None,
                  _vbeg: int = 0, _n_span: int | None = None, _mask: DeviceBuffer | None = None,
-                 _alleles: list[str] | None = None, _exon_flags: np.ndarray | None = None):
+                 _alleles: list[str] | None = None, _exon_flags: np.ndarray | None = None, _novel=None):
         if isinstance(reads, ReadSet):
             base = reads
             template = None
@@ -505,7 +552,7 @@ class AlleleTypingExonFirst(AlleleTyping):
         exon_mask = dev.put(buildMask(grouped[:n_span], group_names))
         # the base class runs errorCorrection once more on the exon lists (line 664: default True)
         super().__init__(exon_set, grouped, force_homo=force_homo, top_n=top_n, logs=logs,
-                         _vbeg=_vbeg, _n_span=n_span, _mask=exon_mask, _alleles=group_names, _defer_log=True)
+                         _vbeg=_vbeg, _n_span=n_span, _mask=exon_mask, _alleles=group_names, _defer_log=True, _novel=_novel)
         self._template = template
         self.candidate_set_threshold = candidate_set_threshold
         if not exon_only:
@@ -513,7 +560,7 @@ class AlleleTypingExonFirst(AlleleTyping):
             self.full_model: AlleleTyping | None = AlleleTyping(
                 full_set, variants, force_homo=force_homo, top_n=top_n // 5,
                 variant_correction=variant_correction, logs=logs, _vbeg=_vbeg, _n_span=n_span, _mask=_mask,
-                _alleles=_alleles, _defer_log=True)
+                _alleles=_alleles, _defer_log=True, _novel=_novel)
             self.full_model._template = template
         else:
             self.full_model = None
