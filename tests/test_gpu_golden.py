@@ -1,0 +1,91 @@
+"""GPU parity against fixtures produced by the reference itself (tests/golden): SAM text in,
+the reference's lists / calls out, through the product's text decoder and the HIP path."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from kir_graph_amd.hisat2 import extractVariant, pairLines
+from kir_graph_amd.index import GkIndex
+from kir_graph_amd.kir_typing import selectKirTypingModel
+from kir_graph_amd.msa2hisat import Variant
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with gzip.open(os.path.join(GOLD, name), "rt") as f:
+        return json.load(f)
+
+
+def index_from(text, tmp_path):
+    for ext, body in text.items():
+        (tmp_path / f"ix.{ext}").write_text(body)
+    return GkIndex.load(str(tmp_path / "ix"))
+
+
+def unhex(xs):
+    return np.array([float.fromhex(x) for x in xs])
+
+
+def test_hand_built_records(device, tmp_path):
+    t1 = load("t1_tabulation.json.gz")
+    gidx = index_from(t1["index"], tmp_path)
+    Variant.novel_id = 0
+    data = extractVariant(pairLines(t1["lines"]), gidx, dev=device)
+    reads = data.reads()
+    assert len(reads) == t1["n_kept"]
+    for got, want in zip(reads, t1["reads"]):
+        assert (got.lpv, got.lnv, got.rpv, got.rnv) == (want["lpv"], want["lnv"], want["rpv"], want["rnv"])
+        assert got.multiple == want["multiple"] and got.backbone == want["backbone"]
+    assert [[v.id, v.typ, v.pos, v.val, v.length, v.allele, v.in_exon] for v in data.variants] == t1["variants"]
+    assert Variant.novel_id == sum(1 for v in t1["variants"] if v[0].startswith("nv"))
+
+
+@pytest.fixture(scope="module")
+def typed_case(device, tmp_path_factory):
+    case = load("typing_case.json.gz")
+    gidx = index_from(case["index"], tmp_path_factory.mktemp("ix"))
+    Variant.novel_id = 0
+    data = extractVariant(pairLines(case["lines"]), gidx, dev=device)
+    return case, data
+
+
+def test_synthetic_sample_lists(typed_case):
+    case, data = typed_case
+    reads = data.reads()
+    assert len(reads) == len(case["reads"])
+    for got, want in zip(reads, case["reads"]):
+        assert (got.lpv, got.lnv, got.rpv, got.rnv) == (want["lpv"], want["lnv"], want["rpv"], want["rnv"])
+    assert [[v.id, v.typ, v.pos, v.val, v.length, v.ref] for v in data.novel] == case["novel"]
+
+
+@pytest.mark.parametrize("method", ["full", "exonfirst_1", "exonfirst_0.9"])
+def test_allele_calls_and_likelihoods(typed_case, method):
+    case, data = typed_case
+    want = case["methods"][method]
+    typer = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
+    calls, warn = typer.typing(case["gene_cn"])
+    assert calls == want["calls"]
+    assert warn == want["warnings"]
+    for gene, w in want["genes"].items():
+        last = typer._result[gene][-1]
+        assert len(typer._result[gene]) == w["steps"]
+        assert np.allclose(last.value[:50], unhex(w["value"]), rtol=1e-9, atol=0)       # north_star: 1e-5
+        assert np.allclose(np.asarray(last.value_sum_indv[:50]).ravel(), unhex(w["value_sum_indv"]), rtol=1e-9, atol=0)
+        assert np.allclose(np.asarray(last.fraction[:50]).ravel(), unhex(w["fraction"]), rtol=1e-9, atol=0)
+
+
+def test_em_abundances(typed_case):
+    case, data = typed_case
+    want = case["methods"]["em"]
+    typer = selectKirTypingModel("em", data)
+    calls, warn = typer.typing(case["gene_cn"])
+    assert sorted(calls) == sorted(want["calls"])
+    for gene, rows in want["genes"].items():
+        got = sorted([[r.allele, r.count, r.prob] for r in typer._result[gene]])
+        assert [g[:2] for g in got] == [r[:2] for r in rows]
+        assert np.allclose([g[2] for g in got], unhex([r[2] for r in rows]), rtol=1e-5, atol=1e-9)

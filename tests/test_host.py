@@ -1,0 +1,135 @@
+"""CPU-side tests of the product's host logic (no GPU): decoding, pairing, packing, ranking helpers."""
+import gzip
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from kir_graph_amd import _lib, packed, synth
+from kir_graph_amd.hisat2 import pairLines, filterRead
+from kir_graph_amd.index import GkIndex, getVariants, packKey
+from kir_graph_amd.typing_mulit_allele import firstOccurrence, rankScore
+from oracle import tabulate as ot
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with gzip.open(os.path.join(GOLD, name), "rt") as f:
+        return json.load(f)
+
+
+def test_abi_library_exports_every_declared_symbol():
+    """The C-ABI library loads on a machine without a GPU and exports all of include/graphkir_hip.h."""
+    header = open(os.path.join(os.path.dirname(GOLD), "..", "include", "graphkir_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(gk_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared <= set(_lib.EXPORTED) | {"gk_abi_version"}, declared - set(_lib.EXPORTED)
+    assert lib.gk_abi_version() == 1
+
+
+def test_no_device_is_a_loud_error():
+    """Without a HIP device the typing path must raise, not fall back."""
+    if _lib.deviceCount() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.GkNoDevice):
+        _lib.Device(0)
+
+
+def test_mate_record_layout():
+    assert _lib.MATE_DTYPE.itemsize == 128
+    off = {k: v[1] for k, v in _lib.MATE_DTYPE.fields.items()}
+    assert (off["pos0"], off["flag"], off["ref"], off["nh"], off["nm"], off["n_cig"], off["n_mm"], off["n_ins"],
+            off["cig"], off["mm"], off["ins"]) == (0, 4, 6, 7, 8, 9, 10, 11, 12, 40, 104)
+
+
+def test_pairing_matches_reference_fixture():
+    t2 = load("t2_pairing.json.gz")
+    lines = t2["lines"]
+    got = [[lines.index(a), lines.index(b)] for a, b in pairLines(lines)]
+    assert got == t2["pairs"]
+
+
+def test_filter_read_matches_oracle():
+    t1 = load("t1_tabulation.json.gz")
+    for line in t1["lines"]:
+        assert filterRead(line) == ot.passesFilter(line)
+
+
+def _index_from(text, tmp_path):
+    for ext, body in text.items():
+        (tmp_path / f"ix.{ext}").write_text(body)
+    return GkIndex.load(str(tmp_path / "ix"))
+
+
+def test_decoder_raises_like_the_reference(tmp_path):
+    """CIGAR/MD/Zs consistency errors of recordToRawVariant surface from packPairs."""
+    t1 = load("t1_tabulation.json.gz")
+    gidx = _index_from(t1["index"], tmp_path)
+    good = t1["lines"][1]
+    for rec in t1["records"]:
+        if "error" not in rec:
+            continue
+        exc = {"AssertionError": AssertionError, "NotImplementedError": NotImplementedError}[rec["error"]]
+        with pytest.raises(exc):
+            packed.packPairs([(rec["line"], good)], gidx)
+
+
+def test_key_order_equals_variant_order(tmp_path):
+    t1 = load("t1_tabulation.json.gz")
+    gidx = _index_from(t1["index"], tmp_path)
+    assert list(gidx.key) == sorted(gidx.key)
+    assert [v.id for v in gidx.variants] == [v[0] for v in t1["variants"] if not v[0].startswith("nv")]
+    # window keys of getVariantsBoundary: single 'A' sorts after insertions, 'T' after A/C/G
+    k = lambda pos, typ, val: packKey(0, pos, typ, val)  # noqa: E731
+    assert k(100, 0, 5) < k(100, 1, ord("A")) < k(100, 1, ord("C")) < k(100, 1, ord("T")) < k(100, 2, 1)
+
+
+def test_packers_agree_on_synthetic_sample():
+    sidx = synth.makeIndex(seed=5, n_genes=3, var_range=(200, 300), allele_range=(10, 20))
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    sample = synth.makeSample(sidx, seed=9, n_pairs=1500)
+    lines = synth.toSamLines(sample)
+    a, _ = packed.packPairs(list(pairLines(lines)), gidx)
+    b, _ = packed.packSample(sample, gidx)
+    assert a.tobytes() == b.tobytes()
+    # a fair share of pairs must survive the filter, and events of all three kinds must occur
+    assert 0.7 * sample.n_pairs < sum(ot.passesFilter(l) for l in lines) / 2
+    assert set(np.unique(sample.ev_kind)) == {0, 1, 2}
+
+
+def test_index_files_round_trip(tmp_path):
+    sidx = synth.makeIndex(seed=3, n_genes=2, var_range=(100, 150), allele_range=(8, 12))
+    sidx.write(str(tmp_path / "ix"))
+    back = getVariants(str(tmp_path / "ix"))
+    assert [(v.id, v.pos, v.typ, v.val, v.allele, v.in_exon) for v in back] == \
+           [(v.id, v.pos, v.typ, v.val, v.allele, v.in_exon) for v in sidx.variants]
+
+
+def test_rank_equals_python_sorted():
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        n, c = int(rng.integers(1, 300)), int(rng.integers(1, 5))
+        value = -np.round(rng.random(n) * 5, 1)           # many ties
+        sums = -np.round(rng.random((n, c)) * 3, 1)
+        frac = rng.integers(0, 4, (n, c)) / 4
+        keys = np.array([-value, -sums.sum(axis=1), np.abs(frac - frac.mean(axis=1, keepdims=True)).sum(axis=1)]).T
+        want = sorted(range(n), key=lambda i: tuple(keys[i]))
+        assert list(rankScore(value, sums, frac)) == want
+
+
+def test_first_occurrence_equals_set_walk():
+    rng = np.random.default_rng(2)
+    for c in (1, 2, 3, 4):
+        ids = rng.integers(0, 12, (500, c))
+        seen, want = set(), []
+        for row in ids:
+            k = tuple(sorted(row))
+            want.append(k not in seen)
+            seen.add(k)
+        assert list(firstOccurrence(ids, 12)) == want
