@@ -130,6 +130,7 @@ def main():
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
     dev.profEnable(True)
     dev.profCollect()
+    dev.call_log = []
     barrier()
     t0 = time.perf_counter()
     n_valid = 0
@@ -156,7 +157,7 @@ def main():
             for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
                 log(f"[bench] {k:18s} launches {n:6d}  total {ms:9.3f} ms  avg {ms / n:8.4f} ms")
             log(f"[bench] kernel time {total_kernel_ms / args.steps:.2f} ms of {ms_per_step:.2f} ms per step")
-        roof = roofline(dom, typer, args)
+        roof = roofline(dom, dev.call_log or [])
         out = {
             "metric": "typed 150 bp PE reads/s (pileup+EM) per GPU; achieved HBM GB/s vs roofline",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,20 +179,11 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(dom, typer, args):
+def roofline(dom, call_log):
     """Roofline entry of the dominant kernel (algorithmic bytes stated in DESIGN.md)."""
+    from kir_graph_amd import roofmodel
     name, (launches, total_ms) = dom
-    avg_s = total_ms / max(launches, 1) / 1e3
-    bytes_per_launch = None
-    try:
-        from kir_graph_amd import roofmodel
-        bytes_per_launch = roofmodel.algorithmicBytes(name, typer)
-    except Exception as e:  # noqa: BLE001
-        log(f"[bench] roofline model unavailable: {e}")
-    achieved = (bytes_per_launch / avg_s / 1e9) if (bytes_per_launch and avg_s > 0) else None
-    return {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-            "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
-            "launches": launches, "avg_launch_ms": total_ms / max(launches, 1)}
+    return roofmodel.summarise(call_log, name, total_ms, launches)
 
 
 if __name__ == "__main__":

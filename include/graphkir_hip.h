@@ -144,7 +144,15 @@ int gk_select_nonempty(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows,
  * positives then negatives); gk_variant_correct applies the <3 / <20 % thresholds to d_vflag. */
 int gk_variant_count(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag,
                      gk_dptr d_cnt);
+/* Same tally with a hint: the rows' index variants lie in [vbeg, vend) (one gene), so their counters
+ * are privatised in LDS and flushed once per workgroup. */
+int gk_variant_count_range(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag,
+                           gk_dptr d_cnt, int32_t vbeg, int32_t vend);
 int gk_variant_correct(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag);
+/* Ordinals and (positive, negative) tallies of the variants that survive d_vflag, compacted on the
+ * device: input of isHomozygous (typing_mulit_allele.py:807-857).  Host arrays hold max_out entries. */
+int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag, int64_t max_out,
+                         int32_t* ord_out, uint32_t* pos_out, uint32_t* neg_out, int64_t* n_out);
 
 /* ---- compatibility: reads2AlleleProb (typing_mulit_allele.py:340-381).
  * d_mask uint32 [vend-vbeg][words]: allele bit rows of the gene's index variants.

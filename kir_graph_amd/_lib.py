@@ -81,6 +81,10 @@ _SIGS = {
     "gk_select_nonempty": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint64,
                                      C.POINTER(C.c_int64)]),
     "gk_variant_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint64]),
+    "gk_variant_count_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint64,
+                                         C.c_int32, C.c_int32]),
+    "gk_variant_surviving": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "gk_variant_correct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "gk_compat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_int32, C.c_int32,
                             C.c_uint64, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]),
@@ -198,6 +202,7 @@ class Device:
         check(lib().gk_ctx_create(ordinal, C.byref(ctx)))
         self.ctx = ctx
         self.ordinal = ordinal
+        self.call_log: list[tuple] | None = None   # set to [] to record launch geometry (bench roofline)
 
     def alloc(self, shape, dtype) -> DeviceBuffer:
         return DeviceBuffer(self, shape, dtype)

@@ -61,29 +61,35 @@ __device__ inline double group_sum8(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(kThreads) void maxsum_chunks(const double* __restrict__ L, int64_t ld,
-                                                          const int32_t* __restrict__ ids, int n_sets, int c_prev,
+__global__ __launch_bounds__(kThreads, 3) void maxsum_chunks(const double* __restrict__ L, int64_t ld,
+                                                          const double* __restrict__ Pbase, int64_t ldp,
+                                                          const int32_t* __restrict__ pcol, int n_sets,
                                                           const int32_t* __restrict__ cols, int n_cols,
                                                           const Span* __restrict__ spans,
-                                                          const Leaf* __restrict__ leaves,
+                                                          const Leaf* __restrict__ leaves, int n_tiles,
                                                           double* __restrict__ partial) {
   __shared__ double Pt[kTileT * kLD];
   __shared__ double Lt[kTileA * kLD];
-  __shared__ int32_t p_col[kTileT * kMaxC];
+  __shared__ int32_t p_col[kTileT];
   __shared__ int32_t l_col[kTileA];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int j = lane & 7, g = lane >> 3, gt = g >> 2, ga = g & 3;
   const int tiles_a = (n_cols + kTileA - 1) / kTileA;
-  const int tile_t = blockIdx.x / tiles_a, tile_a = blockIdx.x % tiles_a;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+  // contiguous range of (span, tile) pairs with the tile index fastest -- all tiles of a span
+  // re-read the same <= 1024 rows of L from that XCD's L2 instead of from MALL / HBM.
+  const unsigned nb = gridDim.x, b = blockIdx.x;
+  const unsigned xcd = b & 7u, kq = b >> 3, q8 = nb >> 3, r8 = nb & 7u;
+  const unsigned logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kq;
+  const int span_idx = (int)(logical / (unsigned)n_tiles);
+  const int tile = (int)(logical % (unsigned)n_tiles);
+  const int tile_t = tile / tiles_a, tile_a = tile % tiles_a;
   const int t0 = tile_t * kTileT, a0 = tile_a * kTileA;
-  const Span span = spans[blockIdx.y];
+  const Span span = spans[span_idx];
 
-  for (int i = tid; i < kTileT * kMaxC; i += kThreads) {
-    const int t = t0 + i / kMaxC, k = i % kMaxC;
-    p_col[i] = (t < n_sets && k < c_prev) ? ids[t * c_prev + k] : -1;
-  }
-  if (tid < kTileA) l_col[tid] = (a0 + tid < n_cols) ? cols[a0 + tid] : -1;
+  if (tid < kTileT) p_col[tid] = (pcol && t0 + tid < n_sets) ? pcol[t0 + tid] : -1;
+  if (tid >= 64 && tid < 64 + kTileA) l_col[tid - 64] = (a0 + tid - 64 < n_cols) ? cols[a0 + tid - 64] : -1;
   __syncthreads();
 
   const int srow = tid & (kBlockRows - 1);   // staged row of this thread
@@ -91,24 +97,21 @@ __global__ __launch_bounds__(kThreads) void maxsum_chunks(const double* __restri
   double pre_l[kLPer], pre_p[kPPer];
 
   auto prefetch = [&](const Leaf& lf) {
-    const int64_t r = span.row0 + lf.start + srow;
-    const bool in = srow < lf.len;
+    // rows / columns past the edge are clamped to a valid address and their values never stored
+    // as results, so every load is unconditional (no exec-masked branch per load)
+    const int64_t r = span.row0 + lf.start + (srow < lf.len ? srow : 0);
 #pragma unroll
     for (int q = 0; q < kLPer; ++q) {
       const int cidx = l_col[scol + 2 * q];
-      pre_l[q] = (in && cidx >= 0) ? L[(int64_t)cidx * ld + r] : 0.0;
+      pre_l[q] = L[(int64_t)(cidx >= 0 ? cidx : 0) * ld + r];
     }
+    // the previous set's likelihood is ONE column (a column of L for single-allele sets, a column
+    // of the row-wise-max buffer otherwise): plain loads that stay in flight during the reduction
 #pragma unroll
     for (int q = 0; q < kPPer; ++q) {
-      double v = -__builtin_huge_val();
-      if (in) {
-        const int t = scol + 2 * q;
-        for (int k = 0; k < c_prev; ++k) {
-          const int cidx = p_col[t * kMaxC + k];
-          if (cidx >= 0) v = vmax(v, L[(int64_t)cidx * ld + r]);
-        }
-      }
-      pre_p[q] = v;
+      const int cidx = p_col[scol + 2 * q];
+      const double v = Pbase[(int64_t)(cidx >= 0 ? cidx : 0) * ldp + r];
+      pre_p[q] = cidx >= 0 ? v : -__builtin_huge_val();
     }
   };
 
@@ -163,16 +166,41 @@ __global__ __launch_bounds__(kThreads) void maxsum_chunks(const double* __restri
 #pragma unroll
           for (int y = 0; y < TA; ++y) acc[x][y] = vmax(p[x], l[y]);
       }
-      for (int r = 8 + j; r < n8; r += 8) {
-        double p[TT], l[TA];
+      // rows j+8, j+16, ...: two row-steps per trip; all 16 LDS reads are issued before the 64
+      // max/add so one LDS latency is paid per trip (the scheduler would otherwise sink each read
+      // next to its use and wait 8 times per row-step)
+      const int n_it = n8 >> 3;
+      const double* pl = Pt + t_loc * kLD + j;
+      const double* ll = Lt + ga * kLD + j;
+      int it = 1;
+      for (; it + 1 < n_it; it += 2) {
+        double p0[TT], p1[TT], l0[TA], l1[TA];
 #pragma unroll
-        for (int x = 0; x < TT; ++x) p[x] = Pt[(t_loc + x) * kLD + r];
+        for (int x = 0; x < TT; ++x) { p0[x] = pl[x * kLD + it * 8]; p1[x] = pl[x * kLD + it * 8 + 8]; }
 #pragma unroll
-        for (int y = 0; y < TA; ++y) l[y] = Lt[(ga + 4 * y) * kLD + r];
+        for (int y = 0; y < TA; ++y) { l0[y] = ll[4 * y * kLD + it * 8]; l1[y] = ll[4 * y * kLD + it * 8 + 8]; }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int x = 0; x < TT; ++x)
 #pragma unroll
-          for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p[x], l[y]);
+          for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p0[x], l0[y]);
+#pragma unroll
+        for (int x = 0; x < TT; ++x)
+#pragma unroll
+          for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p1[x], l1[y]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (it < n_it) {
+        double p0[TT], l0[TA];
+#pragma unroll
+        for (int x = 0; x < TT; ++x) p0[x] = pl[x * kLD + it * 8];
+#pragma unroll
+        for (int y = 0; y < TA; ++y) l0[y] = ll[4 * y * kLD + it * 8];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int x = 0; x < TT; ++x)
+#pragma unroll
+          for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p0[x], l0[y]);
       }
 #pragma unroll
       for (int x = 0; x < TT; ++x)
@@ -215,7 +243,7 @@ __global__ __launch_bounds__(kThreads) void maxsum_chunks(const double* __restri
 #pragma unroll
       for (int y = 0; y < TA; ++y) {
         const int a = a0 + ga + 4 * y;
-        if (t < n_sets && a < n_cols) partial[((int64_t)blockIdx.y * n_sets + t) * n_cols + a] = st[x][y];
+        if (t < n_sets && a < n_cols) partial[((int64_t)span_idx * n_sets + t) * n_cols + a] = st[x][y];
       }
     }
   }
@@ -451,24 +479,40 @@ int upload_program(gk_ctx* ctx, int64_t n_rows, const int32_t* ids, size_t n_ids
 
 extern "C" {
 
+int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
+              gk_dptr d_P);
+
 int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c_prev,
               const int32_t* cols, int32_t n_cols, double* out) {
   GK_REQUIRE(ctx && cols && out && n_rows > 0 && ld >= n_rows && n_cols > 0, "bad maxsum arguments");
   GK_REQUIRE(c_prev >= 0 && c_prev <= kMaxC, "copy number beyond supported set size");
   GK_REQUIRE(n_sets >= 1 && (c_prev == 0 || ids), "missing previous sets");
-  DeviceProgram dp;
-  int rc = upload_program(ctx, n_rows, ids, (size_t)n_sets * c_prev, cols, (size_t)n_cols, dp);
-  if (rc) return rc;
+  // previous sets as single columns: c_prev == 1 -> columns of L itself; c_prev >= 2 -> their
+  // row-wise max is materialised once (HBM-bound, typing_mulit_allele.py:569) and used as columns
   hipStream_t st = ctx->stream;
+  std::vector<int32_t> pcol_host((size_t)n_sets);
+  double* d_P = nullptr;
+  if (c_prev == 1) {
+    for (int t = 0; t < n_sets; ++t) pcol_host[t] = ids[t];
+  } else if (c_prev >= 2) {
+    for (int t = 0; t < n_sets; ++t) pcol_host[t] = t;
+    GK_HIP(gk_pool_malloc(ctx, (void**)&d_P, (size_t)n_sets * ld * sizeof(double)));
+    int rc0 = gk_setmax(ctx, d_L, n_rows, ld, ids, n_sets, c_prev, gk_addr(d_P));
+    if (rc0) return rc0;
+  }
+  DeviceProgram dp;
+  int rc = upload_program(ctx, n_rows, pcol_host.data(), c_prev ? (size_t)n_sets : 0, cols, (size_t)n_cols, dp);
+  if (rc) return rc;
   double *d_partial = nullptr, *d_out = nullptr;
   const int64_t n_out = (int64_t)n_sets * n_cols;
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * dp.n_spans * sizeof(double)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_out * sizeof(double)));
   const int tiles_t = (n_sets + kTileT - 1) / kTileT, tiles_a = (n_cols + kTileA - 1) / kTileA;
   GK_PROF(ctx, GK_K_MAXSUM,
-          hipLaunchKernelGGL(maxsum_chunks, dim3((unsigned)(tiles_t * tiles_a), (unsigned)dp.n_spans), dim3(kThreads),
-                             0, st, gk_ptr<double>(d_L), ld, dp.ids, n_sets, c_prev, dp.cols, n_cols, dp.spans,
-                             dp.leaves, d_partial));
+          hipLaunchKernelGGL(maxsum_chunks, dim3((unsigned)(tiles_t * tiles_a * dp.n_spans)), dim3(kThreads),
+                             0, st, gk_ptr<double>(d_L), ld, c_prev >= 2 ? d_P : gk_ptr<double>(d_L), ld,
+                             c_prev ? dp.ids : nullptr, n_sets, dp.cols, n_cols, dp.spans, dp.leaves,
+                             tiles_t * tiles_a, d_partial));
   GK_PROF(ctx, GK_K_COMBINE,
           hipLaunchKernelGGL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
                              d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, 0.0, d_out));
@@ -478,6 +522,7 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   gk_pool_free(ctx, d_partial);
   gk_pool_free(ctx, d_out);
   gk_pool_free(ctx, dp.base);
+  gk_pool_free(ctx, d_P);
   return GK_OK;
 }
 

@@ -25,20 +25,35 @@ __global__ __launch_bounds__(kThreads) void flag_gene(const uint8_t* gene, const
 }
 
 // one thread per list (4 lists per row): tally surviving ids
+// One thread per list (4 lists per row), grid-stride over rows.  Counters of the gene's index
+// variants [vbeg, vend) are privatised in LDS (positive / negative halves) and flushed once per
+// workgroup; ordinals outside that range (novel variants, other genes) go straight to global atomics.
 __global__ __launch_bounds__(kThreads) void count_ids(const int32_t* rows, int64_t n_rows, const uint32_t* off,
                                                       const uint32_t* ids, const uint8_t* vflag, uint32_t* cnt_pos,
-                                                      uint32_t* cnt_neg) {
-  const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (t >= 4 * n_rows) return;
-  const int64_t row = rows[t >> 2];
-  const int list = (int)(t & 3);
-  const uint32_t b = off[4 * row + list], e = off[4 * row + list + 1];
-  const bool positive = list < 2;
-  const uint8_t bit = positive ? 1 : 2;
-  uint32_t* cnt = positive ? cnt_pos : cnt_neg;
-  for (uint32_t k = b; k < e; ++k) {
-    const uint32_t v = ids[k];
-    if (!(vflag[v] & bit)) atomicAdd(&cnt[v], 1u);
+                                                      uint32_t* cnt_neg, int vbeg, int n_local) {
+  extern __shared__ uint32_t hist[];   // [2][n_local]
+  for (int i = threadIdx.x; i < 2 * n_local; i += kThreads) hist[i] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < 4 * n_rows; t += stride) {
+    const int64_t row = rows[t >> 2];
+    const int list = (int)(t & 3);
+    const uint32_t b = off[4 * row + list], e = off[4 * row + list + 1];
+    const bool positive = list < 2;
+    const uint8_t bit = positive ? 1 : 2;
+    uint32_t* cnt = positive ? cnt_pos : cnt_neg;
+    uint32_t* local = hist + (positive ? 0 : n_local);
+    for (uint32_t k = b; k < e; ++k) {
+      const uint32_t v = ids[k];
+      if (vflag[v] & bit) continue;
+      const uint32_t l = v - (uint32_t)vbeg;
+      if (l < (uint32_t)n_local) atomicAdd(&local[l], 1u); else atomicAdd(&cnt[v], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * n_local; i += kThreads) {
+    const uint32_t c = hist[i];
+    if (c) atomicAdd(i < n_local ? &cnt_pos[vbeg + i] : &cnt_neg[vbeg + i - n_local], c);
   }
 }
 
@@ -80,7 +95,8 @@ __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, i
                                                           int lds_rows, double* probs, uint8_t* miss_out,
                                                           uint16_t* nvar_out) {
   extern __shared__ uint32_t lds_mask[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   // stage the gene's bit rows (all words) when they fit
   const int n_stage = lds_rows * words;
   for (int i = tid; i < n_stage; i += kThreads) lds_mask[i] = mask[i];
@@ -97,34 +113,44 @@ __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, i
   const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;
   for (int64_t i = wave_global; i < n_rows; i += wave_stride) {
     const int64_t row = rows[i];
-    const uint32_t b = off[4 * row], mid = off[4 * row + 2], e = off[4 * row + 4];
+    const uint32_t b = __builtin_amdgcn_readfirstlane(off[4 * row]);
+    const uint32_t mid = __builtin_amdgcn_readfirstlane(off[4 * row + 2]);
+    const uint32_t e = __builtin_amdgcn_readfirstlane(off[4 * row + 4]);
     double p[kSlots];
     uint32_t miss[kSlots];
     uint32_t nvar = 0;
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) { p[s] = 1.0; miss[s] = 0; }
-    bool first = true;
-    for (uint32_t k = b; k < e; ++k) {
-      const uint32_t v = ids[k];
-      const bool positive = k < mid;
-      if (vflag[v] & (positive ? 1 : 2)) continue;   // wave-uniform
-      const int local = (int)v - vbeg;
-      const bool indexed = (int)v < vend && local >= 0;   // novel variants carry no allele
-#pragma unroll
-      for (int s = 0; s < kSlots; ++s) {
-        uint32_t w = 0;
-        if (indexed && live[s]) {
-          const int wi = local * words + (a[s] >> 5);
-          w = local < lds_rows ? lds_mask[wi] : mask[wi];
-        }
-        const bool has = (w >> (a[s] & 31)) & 1u;
-        const bool hit = positive ? has : !has;
-        const double f = hit ? 0.999 : 0.001;
-        p[s] = first ? f : p[s] * f;
-        miss[s] += hit ? 0u : 1u;
+    // the pair's ordinals are fetched 64 at a time (one coalesced load + one gather of the drop
+    // flags), then broadcast lane by lane: no dependent global load inside the factor loop
+    for (uint32_t base = b; base < e; base += 64) {
+      const uint32_t k = base + lane;
+      uint32_t my_v = 0, my_keep = 0;
+      if (k < e) {
+        my_v = ids[k];
+        my_keep = (vflag[my_v] & (k < mid ? 1 : 2)) ? 0u : 1u;
       }
-      first = false;
-      ++nvar;
+      const int cnt = (int)min(64u, e - base);
+      for (int t = 0; t < cnt; ++t) {
+        if (!__builtin_amdgcn_readlane(my_keep, t)) continue;   // wave-uniform
+        const uint32_t v = __builtin_amdgcn_readlane(my_v, t);
+        const bool positive = base + t < mid;
+        const int local = (int)v - vbeg;
+        const bool indexed = (int)v < vend && local >= 0;   // novel variants carry no allele
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+          uint32_t w = 0;
+          if (indexed && live[s]) {
+            const int wi = local * words + (a[s] >> 5);
+            w = local < lds_rows ? lds_mask[wi] : mask[wi];
+          }
+          const bool has = (w >> (a[s] & 31)) & 1u;
+          const bool hit = positive ? has : !has;
+          p[s] *= hit ? 0.999 : 0.001;   // 1.0 * f == f: same bits as numpy's multiply.reduce
+          miss[s] += hit ? 0u : 1u;
+        }
+        ++nvar;
+      }
     }
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
@@ -168,14 +194,29 @@ int gk_select_nonempty(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows,
   return rc;
 }
 
+int gk_variant_count_range(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, gk_dptr d_cnt,
+                            int32_t vbeg, int32_t vend);
+
 int gk_variant_count(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, gk_dptr d_cnt) {
-  GK_REQUIRE(ctx && tab, "null pointer");
+  return gk_variant_count_range(ctx, tab, d_rows, n_rows, d_vflag, d_cnt, 0, 0);
+}
+
+int gk_variant_count_range(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, gk_dptr d_cnt,
+                            int32_t vbeg, int32_t vend) {
+  GK_REQUIRE(ctx && tab && vend >= vbeg, "bad arguments");
+  int n_local = vend - vbeg;
+  if ((size_t)n_local * 8 > 60 * 1024) n_local = 60 * 1024 / 8;   // LDS budget per workgroup
   const int64_t nv = (int64_t)tab->n_var + tab->n_novel;
   uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
   GK_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * nv) * sizeof(uint32_t), ctx->stream));
-  if (n_rows)
-    GK_PROF(ctx, GK_K_COUNT_IDS, hipLaunchKernelGGL(count_ids, dim3(nblk(4 * n_rows)), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
-                       n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), cnt, cnt + nv));
+  if (n_rows) {
+    unsigned blocks = nblk(4 * n_rows);
+    if (blocks > 1024) blocks = 1024;   // grid-stride: many rows per workgroup before the LDS flush
+    GK_PROF(ctx, GK_K_COUNT_IDS,
+            hipLaunchKernelGGL(count_ids, dim3(blocks), dim3(kThreads), (size_t)n_local * 8, ctx->stream,
+                               gk_ptr<int32_t>(d_rows), n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), cnt,
+                               cnt + nv, vbeg, n_local));
+  }
   GK_HIP(hipGetLastError());
   return GK_OK;
 }
@@ -191,6 +232,63 @@ int gk_variant_correct(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag)
   return GK_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(kThreads) void flag_surviving(const uint32_t* cnt_pos, const uint32_t* cnt_neg,
+                                                           const uint8_t* vflag, int64_t n, uint32_t* flag) {
+  const int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (v >= n) return;
+  const uint8_t f = vflag[v];
+  flag[v] = ((!(f & 1) && cnt_pos[v]) || (!(f & 2) && cnt_neg[v])) ? 1u : 0u;
+}
+__global__ __launch_bounds__(kThreads) void gather_surviving(const int32_t* ord, int64_t n, const uint32_t* cnt_pos,
+                                                             const uint32_t* cnt_neg, const uint8_t* vflag,
+                                                             uint32_t* out /*[2][n]*/) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const int32_t v = ord[i];
+  const uint8_t f = vflag[v];
+  out[i] = (f & 1) ? 0u : cnt_pos[v];
+  out[n + i] = (f & 2) ? 0u : cnt_neg[v];
+}
+}  // namespace
+
+/* Variants whose tally survives the drop flags: ordinals + (positive, negative) counts, compacted on
+ * the device (feeds isHomozygous, typing_mulit_allele.py:807-857).  Host arrays must hold max_out. */
+int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag, int64_t max_out, int32_t* ord_out,
+                         uint32_t* pos_out, uint32_t* neg_out, int64_t* n_out) {
+  GK_REQUIRE(ctx && tab && ord_out && pos_out && neg_out && n_out, "null pointer");
+  const int64_t nv = (int64_t)tab->n_var + tab->n_novel;
+  *n_out = 0;
+  if (!nv) return GK_OK;
+  uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
+  uint32_t *flag = nullptr, *vals = nullptr;
+  int32_t* ord = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)nv * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&ord, (size_t)nv * sizeof(int32_t)));
+  hipLaunchKernelGGL(flag_surviving, dim3(nblk(nv)), dim3(kThreads), 0, ctx->stream, cnt, cnt + nv,
+                     gk_ptr<uint8_t>(d_vflag), nv, flag);
+  int64_t n = 0;
+  int rc = gk_compact(ctx, flag, nullptr, nv, ord, &n);
+  if (rc == GK_OK && n > max_out) {
+    gk_set_error("surviving-variant buffer too small (%lld > %lld)", (long long)n, (long long)max_out);
+    rc = GK_ERR_CAPACITY;
+  }
+  if (rc == GK_OK && n) {
+    GK_HIP(gk_pool_malloc(ctx, (void**)&vals, (size_t)(2 * n) * sizeof(uint32_t)));
+    hipLaunchKernelGGL(gather_surviving, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream, ord, n, cnt, cnt + nv,
+                       gk_ptr<uint8_t>(d_vflag), vals);
+    GK_HIP(hipMemcpyAsync(ord_out, ord, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(hipMemcpyAsync(pos_out, vals, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(hipMemcpyAsync(neg_out, vals + n, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(hipStreamSynchronize(ctx->stream));
+    gk_pool_free(ctx, vals);
+  }
+  gk_pool_free(ctx, flag);
+  gk_pool_free(ctx, ord);
+  if (rc == GK_OK) *n_out = n;
+  return rc;
+}
+
 int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg, int32_t vend,
               gk_dptr d_mask, int32_t words, int32_t n_allele, gk_dptr d_probs, gk_dptr d_miss, gk_dptr d_nvar) {
   GK_REQUIRE(ctx && tab, "null pointer");
@@ -203,7 +301,7 @@ int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr 
   if ((size_t)lds_rows * words * 4 > budget) lds_rows = (int)(budget / ((size_t)words * 4));
   const size_t lds_bytes = (size_t)lds_rows * words * 4;
   int64_t want = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
-  unsigned blocks = (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
+  unsigned blocks = (unsigned)(want < 512 ? (want < 1 ? 1 : want) : 512);   // each stages the bit rows once
   for (int a_base = 0; a_base < n_allele; a_base += 64 * kSlots) {
     GK_PROF(ctx, GK_K_COMPAT, hipLaunchKernelGGL(compat_kernel, dim3(blocks), dim3(kThreads), lds_bytes, ctx->stream, gk_ptr<int32_t>(d_rows),
                        n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, gk_ptr<uint32_t>(d_mask),

@@ -187,18 +187,44 @@ class Tabulation:
         check(lib().gk_select_nonempty(self.dev.ctx, self.handle, rows.ptr, n_rows, vflag.ptr, out.ptr, C.byref(n)))
         return out, int(n.value)
 
-    def countVariants(self, rows: DeviceBuffer, n_rows: int, vflag: DeviceBuffer, cnt: DeviceBuffer) -> None:
-        check(lib().gk_variant_count(self.dev.ctx, self.handle, rows.ptr, n_rows, vflag.ptr, cnt.ptr))
+    def countVariants(self, rows: DeviceBuffer, n_rows: int, vflag: DeviceBuffer, cnt: DeviceBuffer,
+                      span: tuple[int, int] = (0, 0)) -> None:
+        check(lib().gk_variant_count_range(self.dev.ctx, self.handle, rows.ptr, n_rows, vflag.ptr, cnt.ptr,
+                                           span[0], span[1]))
 
     def correctVariants(self, cnt: DeviceBuffer, vflag: DeviceBuffer) -> None:
         check(lib().gk_variant_correct(self.dev.ctx, self.handle, cnt.ptr, vflag.ptr))
 
-    def errorCorrection(self, rows: DeviceBuffer, n_rows: int, vflag: DeviceBuffer) -> None:
-        """One pass of ``AlleleTyping.errorCorrection`` on the lists as filtered by ``vflag``."""
+    def errorCorrection(self, rows: DeviceBuffer, n_rows: int, vflag: DeviceBuffer,
+                        span: tuple[int, int] = (0, 0), keep: bool = False) -> DeviceBuffer | None:
+        """One pass of ``AlleleTyping.errorCorrection`` on the lists as filtered by ``vflag``.
+
+        ``span`` = index-variant ordinal range of the rows' gene (LDS-privatised counters).
+        With ``keep`` the tally buffer is returned (its counts masked by the updated ``vflag`` are
+        the tallies of the corrected lists)."""
         cnt = self.dev.alloc(2 * self.n_var_total, np.uint32)
-        self.countVariants(rows, n_rows, vflag, cnt)
+        self.countVariants(rows, n_rows, vflag, cnt, span)
         self.correctVariants(cnt, vflag)
+        if keep:
+            return cnt
         cnt.free()
+        return None
+
+    def survivingCounts(self, cnt: DeviceBuffer, vflag: DeviceBuffer) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(ordinals, positive tally, negative tally) of variants with a surviving observation."""
+        cap = 1 << 16
+        while True:
+            o = np.empty(cap, dtype=np.int32)
+            p = np.empty(cap, dtype=np.uint32)
+            q = np.empty(cap, dtype=np.uint32)
+            n = C.c_int64()
+            rc = lib().gk_variant_surviving(self.dev.ctx, self.handle, cnt.ptr, vflag.ptr, cap, o.ctypes.data,
+                                            p.ctypes.data, q.ctypes.data, C.byref(n))
+            if rc == -5 and cap < self.n_var_total:
+                cap = min(cap * 8, max(self.n_var_total, 1))
+                continue
+            check(rc)
+            return o[:n.value], p[:n.value], q[:n.value]
 
 
 class LogTable:
@@ -276,6 +302,9 @@ class DeviceModel:
             n_sets, c_prev = prev_ids.shape
             ids_p = prev_ids.ctypes.data
         out = np.empty((n_sets, len(cols)), dtype=np.float64)
+        if self.dev.call_log is not None:
+            n_prev_cols = 0 if ids_p is None else len(np.unique(prev_ids))
+            self.dev.call_log.append(("maxsum_chunks", self.n_rows, n_sets, c_prev, len(cols), n_prev_cols))
         check(lib().gk_maxsum(self.dev.ctx, self.L.ptr, self.n_rows, self.n_rows, ids_p, n_sets, c_prev,
                               cols.ctypes.data, len(cols), out.ctypes.data))
         return out

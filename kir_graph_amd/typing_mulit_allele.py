@@ -287,13 +287,15 @@ class AlleleTyping:
         self._dev = rs.tab.dev
         self._logs = logs or sharedLogTable(self._dev)
         tab = rs.tab
+        n_span = len(variants) if _n_span is None else _n_span
+        self._span = (_vbeg, _vbeg + n_span)
+        self._tally = None
         if variant_correction:
-            tab.errorCorrection(rs.rows, rs.n_rows, rs.vflag)
+            self._tally = tab.errorCorrection(rs.rows, rs.n_rows, rs.vflag, span=self._span, keep=True)
         rows, n_rows = tab.selectNonEmpty(rs.rows, rs.n_rows, rs.vflag)
         self._readset = ReadSet(tab, rows, n_rows, rs.vflag)
         n_allele = len(names)
         words = max(1, (n_allele + 31) // 32)
-        n_span = len(variants) if _n_span is None else _n_span
         if _mask is None:
             _mask = self._dev.put(buildMask(variants[:n_span], names))
         self._model = DeviceModel(tab, rows, n_rows, rs.vflag, _vbeg, _vbeg + n_span, _mask, words, n_allele,
@@ -451,21 +453,25 @@ class AlleleTyping:
         return res
 
     # ---- homozygosity test on device counts
-    def _variantCounts(self) -> tuple[np.ndarray, np.ndarray]:
+    def _variantCounts(self) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(ordinals, positive tally, negative tally) of the corrected lists, nonzero entries only."""
         rs = self._readset
         tab = rs.tab
-        cnt = self._dev.alloc(2 * tab.n_var_total, np.uint32)
-        tab.countVariants(rs.rows, rs.n_rows, rs.vflag, cnt)
-        c = cnt.download()
-        cnt.free()
-        return c[:tab.n_var_total], c[tab.n_var_total:]
+        cnt = self._tally
+        if cnt is None:   # no correction pass ran: tally now
+            cnt = self._dev.alloc(2 * tab.n_var_total, np.uint32)
+            tab.countVariants(rs.rows, rs.n_rows, rs.vflag, cnt, self._span)
+        out = tab.survivingCounts(cnt, rs.vflag)
+        if cnt is not self._tally:
+            cnt.free()
+        return out
 
     def _isHomozygous(self, cn: int) -> bool:
         """isHomozygous (807-857) from per-variant positive / negative tallies of the kept reads."""
         if cn <= 1:
             return False
-        pos, neg = self._variantCounts()
-        seen = np.nonzero(pos + neg)[0]
+        seen, pos, neg = self._variantCounts()       # surviving variants only, compacted on the device
+        pos, neg = pos.astype(np.int64), neg.astype(np.int64)
         tab = self._readset.tab
         fields = tab.labelCodes(seen)
         if fields is not None:
@@ -473,11 +479,12 @@ class AlleleTyping:
             # can change the verdict (lines 835-840 skip the rest)
             vpos, code, is_del = fields
             keep = ~is_del
-            o, vpos, code = seen[keep], vpos[keep], code[keep]
-            ent_pos = np.concatenate([vpos[pos[o] > 0], vpos[neg[o] > 0]])
-            ent_code = np.concatenate([code[pos[o] > 0], code[neg[o] > 0]])
-            ent_neg = np.concatenate([np.zeros(int((pos[o] > 0).sum()), bool), np.ones(int((neg[o] > 0).sum()), bool)])
-            ent_cnt = np.concatenate([pos[o][pos[o] > 0], neg[o][neg[o] > 0]]).astype(np.int64)
+            vpos, code, pos, neg = vpos[keep], code[keep], pos[keep], neg[keep]
+            hp, hn = pos > 0, neg > 0
+            ent_pos = np.concatenate([vpos[hp], vpos[hn]])
+            ent_code = np.concatenate([code[hp], code[hn]])
+            ent_neg = np.concatenate([np.zeros(int(hp.sum()), bool), np.ones(int(hn.sum()), bool)])
+            ent_cnt = np.concatenate([pos[hp], neg[hn]])
             upos, inv_site = np.unique(ent_pos, return_inverse=True)
             n_keys = np.bincount(inv_site, minlength=len(upos))          # upper bound on distinct keys
             n_posk = np.bincount(inv_site[~ent_neg], minlength=len(upos))
@@ -489,13 +496,13 @@ class AlleleTyping:
                 site[p_][f"*{c_}" if ng else f"{c_}"] += ct
         else:
             site = defaultdict(lambda: defaultdict(int))
-            for o, (vpos, typ, label) in zip(seen, tab.describe(seen)):
+            for (vpos, typ, label), np_, nn_ in zip(tab.describe(seen), pos.tolist(), neg.tolist()):
                 if typ == "deletion":
                     continue
-                if pos[o]:
-                    site[vpos][label] += int(pos[o])
-                if neg[o]:
-                    site[vpos][f"*{label}"] += int(neg[o])
+                if np_:
+                    site[vpos][label] += np_
+                if nn_:
+                    site[vpos][f"*{label}"] += nn_
         hits = 0
         for obs in site.values():
             if len(obs) <= 1 or all("*" in k for k in obs):
@@ -536,7 +543,7 @@ class AlleleTypingExonFirst(AlleleTyping):
             _exon_flags = np.array([0 if n in in_exon else 3 for n in tab.idNames()], dtype=np.uint8)
         exon_flags = dev.put(_exon_flags)
         if variant_correction:
-            tab.errorCorrection(base.rows, base.n_rows, exon_flags)
+            tab.errorCorrection(base.rows, base.n_rows, exon_flags, span=(_vbeg, _vbeg + n_span))
         exon_set = ReadSet(tab, base.rows, base.n_rows, exon_flags)
 
         # alleles sharing one exon-variant set become one group (649-659)
