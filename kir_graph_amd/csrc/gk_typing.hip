@@ -88,19 +88,28 @@ __global__ __launch_bounds__(kThreads) void flag_nonempty(const int32_t* rows, i
 
 constexpr int kSlots = 3;   // alleles per lane and pass: 192 alleles per pass
 constexpr int kWavesPerBlock = 4;
+constexpr int kTileRows = 16;            // rows per output tile (4 per wave)
+constexpr int kTileLd = kTileRows + 1;   // padded LDS stride (doubles) of the transposed tile
+constexpr int kPassAlleles = 64 * kSlots;
 
+constexpr int kPassWords = kPassAlleles / 32;   // 6 bit-row words cover one pass
+
+// One wavefront per read pair, lanes = alleles (3 allele slots per lane).  Per chunk of 64 variant
+// ordinals, lane k loads ordinal k, its drop flag and the 6 bit-row words of that variant that this
+// pass needs (windows are runs of consecutive ordinals, so these are coalesced row reads of the
+// L2-resident bit matrix).  The factor loop then only uses v_readlane broadcasts -- no memory
+// access and no LDS lookup per factor -- and multiplies 0.999 / 0.001 in the reference's order.
+// Results of a 16-row tile are transposed through LDS so that the column-major [allele][row]
+// output is written as 128-byte runs instead of one 8-byte store per (allele, row).
 __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, int64_t n_rows, const uint32_t* off,
                                                           const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
                                                           const uint32_t* mask, int words, int n_allele, int a_base,
-                                                          int lds_rows, double* probs, uint8_t* miss_out,
-                                                          uint16_t* nvar_out) {
-  extern __shared__ uint32_t lds_mask[];
+                                                          double* probs, uint8_t* miss_out, uint16_t* nvar_out) {
+  __shared__ double tile[kPassAlleles * kTileLd];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // stage the gene's bit rows (all words) when they fit
-  const int n_stage = lds_rows * words;
-  for (int i = tid; i < n_stage; i += kThreads) lds_mask[i] = mask[i];
-  __syncthreads();
+  const bool upper = lane >= 32;
+  const int w_base = a_base >> 5;   // a_base is a multiple of 192 = 6 words
 
   int a[kSlots];
   bool live[kSlots];
@@ -109,58 +118,75 @@ __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, i
     a[s] = a_base + lane + 64 * s;
     live[s] = a[s] < n_allele;
   }
-  const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wid;
-  const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;
-  for (int64_t i = wave_global; i < n_rows; i += wave_stride) {
-    const int64_t row = rows[i];
-    const uint32_t b = __builtin_amdgcn_readfirstlane(off[4 * row]);
-    const uint32_t mid = __builtin_amdgcn_readfirstlane(off[4 * row + 2]);
-    const uint32_t e = __builtin_amdgcn_readfirstlane(off[4 * row + 4]);
-    double p[kSlots];
-    uint32_t miss[kSlots];
-    uint32_t nvar = 0;
+  const uint32_t my_bit = 1u << (lane & 31);
+  const int n_pass = min(kPassAlleles, n_allele - a_base);
+  const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+  for (int64_t tile_i = blockIdx.x; tile_i < n_tiles; tile_i += gridDim.x) {
+    const int64_t row0 = tile_i * kTileRows;
+    for (int q = 0; q < kTileRows / kWavesPerBlock; ++q) {
+      const int rt = wid * (kTileRows / kWavesPerBlock) + q;   // row inside the tile
+      const int64_t i = row0 + rt;
+      if (i >= n_rows) break;                                   // wave-uniform
+      const int64_t row = rows[i];
+      const uint32_t b = __builtin_amdgcn_readfirstlane(off[4 * row]);
+      const uint32_t mid = __builtin_amdgcn_readfirstlane(off[4 * row + 2]);
+      const uint32_t e = __builtin_amdgcn_readfirstlane(off[4 * row + 4]);
+      double p[kSlots];
+      uint32_t miss[kSlots];
+      uint32_t nvar = 0;
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) { p[s] = 1.0; miss[s] = 0; }
-    // the pair's ordinals are fetched 64 at a time (one coalesced load + one gather of the drop
-    // flags), then broadcast lane by lane: no dependent global load inside the factor loop
-    for (uint32_t base = b; base < e; base += 64) {
-      const uint32_t k = base + lane;
-      uint32_t my_v = 0, my_keep = 0;
-      if (k < e) {
-        my_v = ids[k];
-        my_keep = (vflag[my_v] & (k < mid ? 1 : 2)) ? 0u : 1u;
-      }
-      const int cnt = (int)min(64u, e - base);
-      for (int t = 0; t < cnt; ++t) {
-        if (!__builtin_amdgcn_readlane(my_keep, t)) continue;   // wave-uniform
-        const uint32_t v = __builtin_amdgcn_readlane(my_v, t);
-        const bool positive = base + t < mid;
-        const int local = (int)v - vbeg;
-        const bool indexed = (int)v < vend && local >= 0;   // novel variants carry no allele
+      for (int s = 0; s < kSlots; ++s) { p[s] = 1.0; miss[s] = 0; }
+      for (uint32_t base = b; base < e; base += 64) {
+        const uint32_t k = base + lane;
+        uint32_t my_keep = 0;
+        uint32_t mrow[kPassWords];
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) {
-          uint32_t w = 0;
-          if (indexed && live[s]) {
-            const int wi = local * words + (a[s] >> 5);
-            w = local < lds_rows ? lds_mask[wi] : mask[wi];
+        for (int w = 0; w < kPassWords; ++w) mrow[w] = 0;
+        if (k < e) {
+          const uint32_t v = ids[k];
+          my_keep = (vflag[v] & (k < mid ? 1 : 2)) ? 0u : 1u;
+          const int local = (int)v - vbeg;
+          if (my_keep && (int)v < vend && local >= 0) {   // novel variants carry no allele: all-zero row
+            const uint32_t* src = mask + (int64_t)local * words + w_base;
+#pragma unroll
+            for (int w = 0; w < kPassWords; ++w)
+              if (w_base + w < words) mrow[w] = src[w];
           }
-          const bool has = (w >> (a[s] & 31)) & 1u;
-          const bool hit = positive ? has : !has;
-          p[s] *= hit ? 0.999 : 0.001;   // 1.0 * f == f: same bits as numpy's multiply.reduce
-          miss[s] += hit ? 0u : 1u;
         }
-        ++nvar;
-      }
-    }
+        const int cnt = (int)min(64u, e - base);
+        for (int t = 0; t < cnt; ++t) {
+          if (!__builtin_amdgcn_readlane(my_keep, t)) continue;   // wave-uniform
+          const bool positive = base + t < mid;
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
-      if (live[s]) {
-        const int64_t o = (int64_t)a[s] * n_rows + i;
-        if (probs) probs[o] = p[s];
-        if (miss_out) miss_out[o] = (uint8_t)min(miss[s], 255u);
+          for (int s = 0; s < kSlots; ++s) {
+            const uint32_t lo = __builtin_amdgcn_readlane(mrow[2 * s], t);
+            const uint32_t hi = __builtin_amdgcn_readlane(mrow[2 * s + 1], t);
+            const bool has = ((upper ? hi : lo) & my_bit) != 0;
+            const bool hit = positive ? has : !has;
+            p[s] *= hit ? 0.999 : 0.001;   // 1.0 * f == f: same bits as numpy's multiply.reduce
+            miss[s] += hit ? 0u : 1u;
+          }
+          ++nvar;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < kSlots; ++s) {
+        if (live[s]) {
+          tile[(lane + 64 * s) * kTileLd + rt] = p[s];
+          if (miss_out) miss_out[(int64_t)a[s] * n_rows + i] = (uint8_t)min(miss[s], 255u);
+        }
+      }
+      if (nvar_out && lane == 0 && a_base == 0) nvar_out[i] = (uint16_t)min(nvar, 65535u);
+    }
+    __syncthreads();
+    if (probs) {
+      const int n_r = (int)min<int64_t>(kTileRows, n_rows - row0);
+      for (int idx = tid; idx < n_pass * kTileRows; idx += kThreads) {
+        const int al = idx / kTileRows, r = idx % kTileRows;
+        if (r < n_r) probs[(int64_t)(a_base + al) * n_rows + row0 + r] = tile[al * kTileLd + r];
       }
     }
-    if (nvar_out && lane == 0 && a_base == 0) nvar_out[i] = (uint16_t)min(nvar, 65535u);
+    __syncthreads();
   }
 }
 
@@ -294,19 +320,14 @@ int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr 
   GK_REQUIRE(ctx && tab, "null pointer");
   GK_REQUIRE(words >= 1 && n_allele >= 0 && n_allele <= words * 32 && vend >= vbeg, "bad mask geometry");
   if (n_rows == 0 || n_allele == 0) return GK_OK;
-  const int n_v = vend - vbeg;
-  // LDS budget: 64 KiB of bit rows per workgroup keeps two workgroups per CU
-  int lds_rows = n_v;
-  const size_t budget = 64 * 1024;
-  if ((size_t)lds_rows * words * 4 > budget) lds_rows = (int)(budget / ((size_t)words * 4));
-  const size_t lds_bytes = (size_t)lds_rows * words * 4;
-  int64_t want = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
-  unsigned blocks = (unsigned)(want < 512 ? (want < 1 ? 1 : want) : 512);   // each stages the bit rows once
-  for (int a_base = 0; a_base < n_allele; a_base += 64 * kSlots) {
-    GK_PROF(ctx, GK_K_COMPAT, hipLaunchKernelGGL(compat_kernel, dim3(blocks), dim3(kThreads), lds_bytes, ctx->stream, gk_ptr<int32_t>(d_rows),
-                       n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, gk_ptr<uint32_t>(d_mask),
-                       words, n_allele, a_base, lds_rows, gk_ptr<double>(d_probs), gk_ptr<uint8_t>(d_miss),
-                       gk_ptr<uint16_t>(d_nvar)));
+  int64_t want = (n_rows + kTileRows - 1) / kTileRows;
+  unsigned blocks = (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
+  for (int a_base = 0; a_base < n_allele; a_base += kPassAlleles) {
+    GK_PROF(ctx, GK_K_COMPAT,
+            hipLaunchKernelGGL(compat_kernel, dim3(blocks), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
+                               n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend,
+                               gk_ptr<uint32_t>(d_mask), words, n_allele, a_base, gk_ptr<double>(d_probs),
+                               gk_ptr<uint8_t>(d_miss), gk_ptr<uint16_t>(d_nvar)));
   }
   GK_HIP(hipGetLastError());
   return GK_OK;
