@@ -128,9 +128,13 @@ def main():
         one_step(dev, dindex, gidx, mates, table, gene_cn, args.method)
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
-    dev.profEnable(True)
-    dev.profCollect()
-    dev.call_log = []
+    def all_devices():
+        return list(_lib.Device.instances)
+
+    for d in all_devices():
+        d.profEnable(True)
+        d.profCollect()
+        d.call_log = []
     barrier()
     t0 = time.perf_counter()
     n_valid = 0
@@ -138,8 +142,13 @@ def main():
         calls, warn, n_valid, typer = one_step(dev, dindex, gidx, mates, table, gene_cn, args.method)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = dev.profCollect()
-    dev.profEnable(False)
+    prof, call_log = {}, []
+    for d in all_devices():
+        for k, (n, ms) in d.profCollect().items():
+            n0, ms0 = prof.get(k, (0, 0.0))
+            prof[k] = (n0 + n, ms0 + ms)
+        call_log += d.call_log or []
+        d.profEnable(False)
 
     if dist is not None:
         import torch
@@ -157,7 +166,7 @@ def main():
             for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
                 log(f"[bench] {k:18s} launches {n:6d}  total {ms:9.3f} ms  avg {ms / n:8.4f} ms")
             log(f"[bench] kernel time {total_kernel_ms / args.steps:.2f} ms of {ms_per_step:.2f} ms per step")
-        roof = roofline(dom, dev.call_log or [])
+        roof = roofline(dom, call_log)
         out = {
             "metric": "typed 150 bp PE reads/s (pileup+EM) per GPU; achieved HBM GB/s vs roofline",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

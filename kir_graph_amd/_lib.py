@@ -203,6 +203,16 @@ class Device:
         self.ctx = ctx
         self.ordinal = ordinal
         self.call_log: list[tuple] | None = None   # set to [] to record launch geometry (bench roofline)
+        self._workers: list["Device"] = []
+        Device.instances.append(self)
+
+    instances: list["Device"] = []
+
+    def worker(self, k: int) -> "Device":
+        """k-th extra context (own stream + allocator) on the same GPU, for per-gene host threads."""
+        while len(self._workers) <= k:
+            self._workers.append(Device(self.ordinal))
+        return self._workers[k]
 
     def alloc(self, shape, dtype) -> DeviceBuffer:
         return DeviceBuffer(self, shape, dtype)

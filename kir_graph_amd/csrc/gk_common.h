@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -42,6 +43,7 @@ struct gk_ctx {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   // caching allocator state (gk_pool_*)
+  std::mutex pool_mutex;   // frees may come from another host thread (Python GC)
   std::multimap<size_t, void*> pool_free;
   std::unordered_map<void*, size_t> pool_live;
   size_t pool_cached_bytes = 0;

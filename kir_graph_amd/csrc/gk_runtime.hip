@@ -141,6 +141,7 @@ static size_t pool_class(size_t bytes) {
 }
 
 hipError_t gk_pool_malloc(gk_ctx* ctx, void** out, size_t bytes) {
+  std::lock_guard<std::mutex> lock(ctx->pool_mutex);
   const size_t cls = pool_class(bytes);
   auto it = ctx->pool_free.find(cls);
   if (it != ctx->pool_free.end()) {
@@ -164,6 +165,7 @@ hipError_t gk_pool_malloc(gk_ctx* ctx, void** out, size_t bytes) {
 
 void gk_pool_free(gk_ctx* ctx, void* p) {
   if (!p) return;
+  std::lock_guard<std::mutex> lock(ctx->pool_mutex);
   auto it = ctx->pool_live.find(p);
   if (it == ctx->pool_live.end()) {   // not ours
     hipFree(p);

@@ -80,9 +80,22 @@ class Tabulation:
         return self.dindex.host.n_variant + self.n_novel
 
     def close(self) -> None:
-        if self.handle:
+        if self.handle and not getattr(self, "_borrowed", False):
             lib().gk_tab_destroy(self.handle)
-            self.handle = None
+        self.handle = None
+
+    def on(self, dev: Device) -> "Tabulation":
+        """The same tabulation driven from another context (stream) of the same GPU.
+
+        The CSR is read-only after ``gk_tabulate`` returned (it synchronises), so per-gene work can
+        run on independent streams."""
+        if dev is self.dev:
+            return self
+        import copy
+        other = copy.copy(self)
+        other.dev = dev
+        other._borrowed = True
+        return other
 
     # ---- host views (outputs / tests)
     def offsets(self) -> np.ndarray:

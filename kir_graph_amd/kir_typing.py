@@ -10,6 +10,8 @@ reference CLI forwards ``report`` to a factory that does not know it, main.py:19
 from __future__ import annotations
 
 import json
+import threading
+from concurrent.futures import ThreadPoolExecutor
 from typing import Any
 
 import numpy as np
@@ -66,15 +68,22 @@ class Typing:
         raise NotImplementedError
 
 
+def hostThreads() -> int:
+    """Host threads that type genes concurrently (each with its own HIP stream); GK_THREADS overrides."""
+    import os
+    return max(1, int(os.environ.get("GK_THREADS", "4")))
+
+
 class _GeneView:
     """Per-gene handles into a tabulated sample."""
 
-    def __init__(self, data: SampleData, gene: str, multiple: bool):
+    def __init__(self, data: SampleData, gene: str, multiple: bool, tab=None):
         self.data, self.gene = data, gene
         idx = data.index
         g = idx.gene_id.get(gene)
         self.g = g
-        tab = data.tab
+        tab = tab or data.tab
+        self.tab = tab
         if g is None:
             self.rows, self.n_rows = tab.dev.alloc(1, np.int32), 0
             self.vbeg = self.n_span = 0
@@ -109,28 +118,73 @@ class TypingWithPosNegAllele(Typing):
         self._exon_first, self._exon_only = exon_first, exon_only
         self._exon_candidate_threshold = exon_candidate_threshold
         self._variant_correction = variant_correction
-        self._logs = sharedLogTable(self._data.tab.dev)
+        self._local = threading.local()
+
+    def _context(self):
+        """(tabulation bound to this thread's context, its log table)."""
+        tab = getattr(self._local, "tab", None)
+        if tab is None:
+            base = self._data.tab
+            k = getattr(self._local, "slot", None)
+            dev = base.dev if k is None else base.dev.worker(k)
+            tab = self._local.tab = base.on(dev)
+            self._local.logs = sharedLogTable(dev)
+        return tab, self._local.logs
+
+    def typing(self, gene_cn: dict[str, int], min_reads_num: int = 100) -> tuple[list[str], list[str]]:
+        """Genes are independent: type them on a few host threads, each with its own HIP stream, so the
+        ranking work of one gene (numpy, host) overlaps the reductions of another (device).  Results
+        are assembled in CN-table order, exactly like the sequential loop (kir_typing.py:42-62)."""
+        todo = [(gene, int(cn)) for gene, cn in gene_cn.items() if cn]
+        n_threads = min(hostThreads(), len(todo))
+        if n_threads <= 1:
+            return super().typing(gene_cn, min_reads_num)
+        slots = iter(range(n_threads))
+        lock = threading.Lock()
+
+        def init():
+            with lock:
+                self._local.slot = next(slots)
+                self._data.tab.dev.worker(self._local.slot)   # create the context under the lock
+
+        with ThreadPoolExecutor(max_workers=n_threads, initializer=init) as pool:
+            # largest genes first (they dominate the makespan); order of results is restored below
+            order = sorted(range(len(todo)), key=lambda i: -self._geneWeight(todo[i][0]))
+            futures = {i: pool.submit(self.typingPerGene, *todo[i]) for i in order}
+            results = [futures[i].result() for i in range(len(todo))]
+        self._result = {gene: self._result[gene] for gene, _ in todo if gene in self._result}
+        predict_alleles, warning_genes = [], []
+        for (gene, _), (alleles, reads_num) in zip(todo, results):
+            predict_alleles.extend(alleles)
+            if reads_num < min_reads_num:
+                warning_genes.append(gene)
+        return predict_alleles, warning_genes
+
+    def _geneWeight(self, gene: str) -> int:
+        g = self._data.index.gene_id.get(gene)
+        return 0 if g is None else self._data.index.tables[g].n_allele ** 2
 
     def typingPerGene(self, gene: str, cn: int) -> tuple[list[str], int]:
         logger.debug(f"[Allele] {gene=} {cn=}")
         force_homo = False if isHetrozygous(gene) else None
-        view = _GeneView(self._data, gene, self._multiple)
+        tab, logs = self._context()
+        view = _GeneView(self._data, gene, self._multiple, tab=tab)
         pure_gene = gene.split("*")[0]
         if view.g is None or not view.alleles:
             # gene absent from the sample's variants: the reference yields "fail" calls (or crashes
             # in createHomoResult for cn >= 2 with automatic zygosity; soft-fail here, SURVEY 8b)
             self._result[gene] = []
             return [f"{pure_gene}*"] * cn, 0
-        reads = ReadSet(self._data.tab, view.rows, view.n_rows)
+        reads = ReadSet(tab, view.rows, view.n_rows)
         if not self._exon_first and not self._exon_only:
             typ: AlleleTyping = AlleleTyping(
                 reads, view.variants, force_homo=force_homo, top_n=self._top_n,
-                variant_correction=self._variant_correction, logs=self._logs, _vbeg=view.vbeg,
+                variant_correction=self._variant_correction, logs=logs, _vbeg=view.vbeg,
                 _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles, _novel=view.novel)
         else:
             typ = AlleleTypingExonFirst(
                 reads, view.variants, force_homo=force_homo, top_n=self._top_n, exon_only=self._exon_only,
-                candidate_set_threshold=self._exon_candidate_threshold, logs=self._logs, _vbeg=view.vbeg,
+                candidate_set_threshold=self._exon_candidate_threshold, logs=logs, _vbeg=view.vbeg,
                 _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles, _exon_flags=view.exonFlags(),
                 _novel=view.novel)
         res = typ.typing(cn)
