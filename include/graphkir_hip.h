@@ -199,6 +199,23 @@ int gk_em_run(gk_ctx* ctx, const uint32_t* sets, const double* weight, int32_t n
               int32_t n_allele, int32_t iter_max, double diff_threshold, double* prob_out,
               int32_t* iters_out);
 
+/* ---- read depth: replaces `samtools depth -aa {name}.no_multi.bam` (samtools_utils.py:9-14).
+ * Depth of every backbone position from the M runs of the filter-passing pairs of a tabulation made
+ * by gk_tabulate (NH == 1 only unless `multiple`).  gene_off[g] = start of backbone g in the
+ * concatenated position space, gene_off[n_gene] = total; depth_out holds gene_off[n_gene] values. */
+int gk_depth(gk_ctx* ctx, gk_tab* tab, gk_dptr d_mates, int32_t multiple, const int64_t* gene_off,
+             int32_t n_gene, uint32_t* depth_out);
+
+/* ---- copy-number model (LCND / "CNgroup"): cn_model.py:124-204.
+ * gk_cn_fit:    loglik_out[j] = sum_x log(max_n N(x; bases[j]*n, dev[n]) * space + 1e-9) * density[x]
+ *               for n = first_cn .. first_cn + n_cn - 1 (CNgroup.fit 153-164, calcCNGroupProb 179-204)
+ * gk_cn_assign: cn_of_bin_out[x] = argmax_n of the same table at `base` (assignCN 171-177). */
+int gk_cn_fit(gk_ctx* ctx, const double* x, const double* density, int32_t bins, const double* bases,
+              int32_t n_bases, const double* dev, int32_t n_cn, int32_t first_cn, double space,
+              double* loglik_out);
+int gk_cn_assign(gk_ctx* ctx, const double* x, int32_t bins, double base, const double* dev, int32_t n_cn,
+                 int32_t first_cn, double space, int32_t* cn_of_bin_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,11 @@ _SIGS = {
                               C.c_void_p]),
     "gk_setmax": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                             C.c_uint64]),
+    "gk_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "gk_cn_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                            C.c_int32, C.c_int32, C.c_double, C.c_void_p]),
+    "gk_cn_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_int32,
+                               C.c_double, C.c_void_p]),
     "gk_em_sets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_uint64,
                              C.c_int32, C.c_uint64]),
     "gk_em_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

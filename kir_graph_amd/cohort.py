@@ -1,0 +1,89 @@
+"""
+Cohort sharding over the GPUs of one node.
+
+Samples are independent in the reference (sequential loops, main.py:139-167, 178-220), so a cohort
+shards embarrassingly: one process per GPU, every rank tabulates and types its own samples, rank 0
+merges the per-sample TSVs.  The only exchange is ``--cn-cohort``: the reference pools the raw gene
+depths of all samples into one list before fitting ONE copy-number model (kir_cn.py:61, 167-186).
+Here every rank contributes the depths of its samples through a single all-gather
+(``torch.distributed``: backend ``nccl`` = RCCL over xGMI on the GPUs, ``gloo`` in CPU tests); the
+payload is 8 x (genes + 1) bytes per sample, so the collective is latency bound.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def shardSamples(n_samples: int, world: int) -> list[list[int]]:
+    """Round-robin assignment of sample indices to ranks (deterministic, known to every rank)."""
+    return [list(range(r, n_samples, world)) for r in range(world)]
+
+
+class Comm:
+    """Thin wrapper over an initialised ``torch.distributed`` process group."""
+
+    def __init__(self, n_samples: int, device: str | None = None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.n_samples = n_samples
+        self.shards = shardSamples(n_samples, self.world)
+        self.device = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
+
+    @property
+    def mine(self) -> list[int]:
+        return self.shards[self.rank]
+
+    def allgatherDepths(self, local_depths: list[dict[str, float]]) -> list[float]:
+        """Pool the gene depths of the whole cohort, in cohort sample order then gene order.
+
+        ``local_depths[i]`` belongs to cohort sample ``self.mine[i]``.  One all-gather of a
+        ``[max_local, 1 + genes]`` float64 tensor per rank."""
+        import torch
+        assert len(local_depths) == len(self.mine)
+        genes = sorted(set().union(*[d.keys() for d in local_depths])) if local_depths else []
+        n_gene = torch.tensor([len(genes)], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(n_gene, op=self.dist.ReduceOp.MAX)
+        G = int(n_gene.item())
+        max_local = max(len(s) for s in self.shards)
+        buf = np.full((max_local, 1 + G), np.nan, dtype=np.float64)
+        buf[:, 0] = -1
+        for i, (gi, d) in enumerate(zip(self.mine, local_depths)):
+            if len(d) != G:
+                raise ValueError("all samples of a cohort must report the same genes (samtools depth -aa)")
+            buf[i, 0] = gi
+            buf[i, 1:] = [d[g] for g in d]          # the sample's own (sorted-gene) order
+        mine = torch.from_numpy(buf).to(self.device)
+        out = torch.empty((self.world * max_local, 1 + G), dtype=mine.dtype, device=self.device)
+        self.dist.all_gather_into_tensor(out, mine)   # ranks concatenated along dim 0
+        rows = out.reshape(-1, 1 + G).cpu().numpy()
+        rows = rows[rows[:, 0] >= 0]
+        rows = rows[np.argsort(rows[:, 0], kind="stable")]
+        if len(rows) != self.n_samples:
+            raise RuntimeError(f"cohort all-gather returned {len(rows)} of {self.n_samples} samples")
+        return [float(v) for v in rows[:, 1:].reshape(-1)]
+
+    def barrier(self) -> None:
+        self.dist.barrier()
+
+
+def initFromEnv(backend: str | None = None):
+    """Initialise ``torch.distributed`` from RANK / WORLD_SIZE / MASTER_* (torchrun); None if single."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    return dist

@@ -25,7 +25,7 @@ import numpy as np
 from . import _lib
 from ._lib import Device, check, lib
 from .engine import DeviceIndex, Tabulation
-from .index import GkIndex, getVariants  # noqa: F401  (re-export: reference name)
+from .index import GkIndex, getVariants, readExons  # noqa: F401  (re-export: reference names)
 from .msa2hisat import Variant
 from .packed import InsTable, packPairs
 from .utils import logger

@@ -1,0 +1,284 @@
+"""
+``graphkir`` command line -- drop-in for the typing stages of ``graphkir/main.py``.
+
+Same flags, defaults, file naming and TSV schemas (createParser 258-420, main 423-606,
+readMapping 124-168, alleleTyping 171-220, getCommonName 223-250).  What differs:
+
+* tabulation, read depth, copy-number fit and allele typing run on the GPU; a sample's tabulation
+  is handed to typing in memory (the ``.variant.json`` is still written unless
+  ``--no-variant-json``);
+* additive flags: ``--alignment`` (use existing name-collated SAM/BAM instead of running hisat2),
+  ``--no-variant-json``; ``--allele-strategy`` also accepts ``pv`` (= full) and maps ``report`` to
+  the EM strategy (the reference forwards ``report`` to a factory that rejects it, main.py:192);
+* launched under ``torchrun`` the samples are sharded over the ranks (one GPU each); ``--cn-cohort``
+  then pools the gene depths with one all-gather (``cohort.Comm``), rank 0 merges the outputs;
+* index building, WGS extraction and plotting are outside this build: the index files must exist.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+from pathlib import Path
+
+import pandas as pd
+
+from . import cohort
+from .external_tools import setEngine
+from .hisat2 import SampleData, extractVariant, readExons, readPair, writeReadsAndVariantsData  # noqa: F401
+from .index import GkIndex
+from .kir_cn import filterDepth, loadCN, predictSamplesCN
+from .kir_typing import defaultDevice, selectKirTypingModel
+from .samtools_utils import depthOfSample, readLocusLengths
+from .utils import getThreads, logger, mergeAllele, mergeCN, setThreads
+
+
+def getCommonName(r1: str, r2: str) -> str:
+    """Longest common dot-separated prefix of the two read file names (main.py:223-250)."""
+    name = ""
+    for s1, s2 in zip(r1.split("."), r2.split(".")):
+        if s1 != s2:
+            return name
+        name = name + "." + s1 if name else s1
+    return name
+
+
+def replaceParentFolder(filename: str, new_folder: str) -> str:
+    return str(Path(new_folder) / Path(filename).name)
+
+
+def hisatMap(index: str, f1: str, f2: str, output_file: str, threads: int = 1) -> None:
+    """External aligner, unchanged from the reference (hisat2.py:68-92); needs hisat2 + samtools."""
+    from .external_tools import runTool
+    assert output_file.endswith(".bam")
+    name = output_file.rsplit(".", 1)[0]
+    runTool("hisat", ["hisat2", "--threads", str(threads), "-x", index, "-1", f1, "-2", f2,
+                      "--no-spliced-alignment", "--max-altstried", "64", "--haplotype", "-S", f"{name}.sam"])
+    runTool("samtools", ["samtools", "sort", f"-@{threads}", f"{name}.sam", "-o", f"{name}.bam"])
+    runTool("samtools", ["samtools", "index", f"-@{threads}", f"{name}.bam"])
+
+
+def readMapping(names, reads, index, index_ref, exon_region_only=False, alignments=None, write_json=True):
+    """Graph mapping (external) -> tabulation (GPU) -> depth (GPU), per sample (main.py:124-168)."""
+    gk = GkIndex.load(index_ref)
+    gene_len = readLocusLengths(index_ref)
+    dev = defaultDevice()
+    from .engine import DeviceIndex
+    dindex = DeviceIndex(dev, gk)
+    bam_files, processed, depth_files = [], [], []
+    for k, (name, (fq1, fq2)) in enumerate(zip(names, reads)):
+        suffix = "." + index.replace(".", "_").replace("/", "_")
+        name += suffix
+        if alignments:
+            source = alignments[k]
+        else:
+            logger.info(f"[Graph] Run graph mapping on index {index} ({name})")
+            hisatMap(index, fq1, fq2, name + ".bam", threads=getThreads())
+            source = name + ".bam"
+        bam_files.append(source)
+        name += ".variant"
+        logger.info(f"[Graph] Filter mapping ({name})")
+        data = extractVariant(readPair(source), gk, dev=dev, dindex=dindex)
+        if write_json:
+            writeReadsAndVariantsData(data.asDict(), name + ".json")
+        processed.append((name, data))
+        name += ".no_multi"
+        logger.info(f"[Graph] Calculate read depth to {name}.depth.tsv")
+        depthOfSample(data, gene_len, name + ".depth.tsv")
+        name += ".depth"
+        if exon_region_only:
+            logger.info(f"[Graph] Filter exon read to {name}.exon.tsv")
+            filterDepth(name + ".tsv", name + ".exon.tsv", readExons(index_ref))
+            name += ".exon"
+        depth_files.append(name + ".tsv")
+    return bam_files, processed, depth_files
+
+
+def alleleTyping(processed_bam, cn_files: list[str], method: str = "full") -> list[str]:
+    """Allele typing of every sample; writes ``{name}{suffix}.tsv`` and ``.possible.tsv`` (171-220).
+
+    ``processed_bam`` entries are names (the ``.json`` next to them is loaded) or (name, SampleData)."""
+    allele_files = []
+    for entry, cn_file in zip(processed_bam, cn_files):
+        name, source = entry if isinstance(entry, tuple) else (entry, entry + ".json")
+        logger.debug(f"[Allele] Allele typing ({method}) with CN {cn_file} ({name})")
+        suffix = ".cn" + cn_file[len(getCommonName(name, cn_file)):].replace("/", "_").replace(".", "_") + "."
+        if method == "exonfirst":
+            method += "_1"
+        suffix += method
+        t = selectKirTypingModel(method, source, top_n=600, variant_correction=True)
+        cn = loadCN(cn_file)
+        called_alleles, warning_genes = t.typing(cn)
+        logger.info(f"[Allele] {called_alleles} ({name})")
+        name += suffix
+        pd.DataFrame({"name": [name], "alleles": ["_".join(called_alleles)],
+                      "warnings": ["_".join(warning_genes)]}).to_csv(name + ".tsv", sep="\t", index=False)
+        allele_files.append(name + ".tsv")
+        try:
+            possible = t.getAllPossibleTyping()
+        except NotImplementedError:      # EM strategy has no possible-set table (kir_typing.py:63-68)
+            possible = []
+        pd.DataFrame(possible).fillna("").to_csv(name + ".possible.tsv", index=False, sep="\t")
+    return allele_files
+
+
+def createParser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Run Graph-KIR (MI355X typing path)",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--thread", default=1, help="Number of threads")
+    p.add_argument("--engine", default="local", choices=["podman", "docker", "singularity", "local"],
+                   help="How external tools (hisat2 / samtools) are run; only 'local' is supported here.")
+    p.add_argument("--log-level", default="INFO", choices=logging._nameToLevel.keys(), help="Set the log level")
+    p.add_argument("--r1", action="append", help="Paths to paired-end Read 1 FASTQ files")
+    p.add_argument("--r2", action="append", help="Paths to paired-end Read 2 FASTQ files (in order)")
+    p.add_argument("--input-csv", help="CSV with columns name, r1, r2 [, cnfile]")
+    p.add_argument("--output-folder", help="Output folder (default: same folder as input reads)")
+    p.add_argument("--output-cohort-name", help="Output prefix of the cohort files (default {output-folder}/cohort)")
+    p.add_argument("--plot", action="store_true", help="(not supported in this build)")
+    p.add_argument("--ipd-version", default="2100", help="IPD*KIR version")
+    p.add_argument("--msa-type", default="ab_2dl1s1", choices=["merge", "split", "ab", "ab_2dl1s1"],
+                   help="Type of MSA setup of the index")
+    p.add_argument("--msa-no-exon-only-allele", action="store_true", help="Index without exon-only alleles")
+    p.add_argument("--index-folder", default="index", help="Folder of the HISAT2-indexed KIR reference")
+    p.add_argument("--index-wgs", help="(WGS extraction is outside this build)")
+    p.add_argument("--ref-genome", default="hg19", choices=["hg19", "hg38"], help="(WGS extraction only)")
+    p.add_argument("--cn-diploid-gene", choices=["", "VDR", "RYR1", "EGFR"], default="", help="(WGS extraction only)")
+    p.add_argument("--cn-exon", action="store_true", help="Use exon-only depths for CN prediction")
+    p.add_argument("--cn-cohort", action="store_true", help="Predict CN cohort-wise instead of sample-wise")
+    p.add_argument("--cn-select", default="p75", choices=["p75", "mean", "median"], help="Gene depth statistic")
+    p.add_argument("--cn-algorithm", default="LCND", choices=["LCND", "KDE"], help="CN prediction model")
+    p.add_argument("--cn-dist-dev", default=0.08, help="Deviation of distributions in LCND")
+    p.add_argument("--cn-3dl3-not-diploid", action="store_true", help="Do not assume KIR3DL3 is diploid")
+    p.add_argument("--cn-provided", nargs="*", help="Provided CN TSVs (one per sample, in order)")
+    p.add_argument("--allele-strategy", default="full", choices=["full", "pv", "exonfirst", "report", "em"],
+                   help="full (alias pv): likelihood over all variants; exonfirst: exon variants first; "
+                        "report (alias em): EM abundance typing")
+    p.add_argument("--step-skip-extraction", action="store_true", help="Skip extracting KIR reads from WGS")
+    p.add_argument("--step-skip-typing", action="store_true", help="Skip allele typing")
+    # additive
+    p.add_argument("--alignment", action="append",
+                   help="Existing name-collated alignments (SAM / SAM.gz / BAM), one per sample: skips hisat2")
+    p.add_argument("--no-variant-json", action="store_true", help="Do not write {name}.variant.json")
+    return p
+
+
+def main(args: argparse.Namespace) -> None:
+    setThreads(args.thread)
+    setEngine(args.engine)
+    logger.setLevel(args.log_level)
+    logger.debug(f"[Main] {args}")
+    if not args.step_skip_extraction and not args.alignment:
+        raise NotImplementedError("WGS extraction (bwa) is outside this build: pass --step-skip-extraction")
+    if args.plot:
+        raise NotImplementedError("--plot is outside this build")
+
+    if not args.input_csv:
+        if not args.r1 and not args.alignment:
+            raise ValueError("At least one paired-end read 1 FASTQ file must be provided")
+        if args.r1:
+            if len(args.r1) != len(args.r2 or []):
+                raise ValueError("The number of paired-end read 1 and read 2 FASTQ files must be equal")
+            reads = list(zip(args.r1, args.r2))
+            names = [getCommonName(a, b) for a, b in reads]
+        else:
+            reads = [("", "")] * len(args.alignment)
+            names = [a.rsplit(".", 2 if a.endswith(".gz") else 1)[0] for a in args.alignment]
+        cn_files = list(args.cn_provided) if args.cn_provided else [""] * len(names)
+    else:
+        df = pd.read_csv(args.input_csv)
+        names = list(df["name"])
+        reads = list(zip(df["r1"], df["r2"]))
+        cn_files = list(df["cnfile"].fillna("")) if "cnfile" in df.columns else [""] * len(names)
+    if not names:
+        raise ValueError("No samples found in input")
+    if len(cn_files) != len(names):
+        raise ValueError("Mismatch between number of samples and copy number files")
+    if args.alignment and len(args.alignment) != len(names):
+        raise ValueError("--alignment must be given once per sample")
+    logger.info(f"[Main] Samples: {names}")
+
+    if args.output_folder:
+        Path(args.output_folder).mkdir(exist_ok=True)
+        names = [replaceParentFolder(n, args.output_folder) for n in names]
+        output_folder = args.output_folder
+    else:
+        output_folder = str(Path(names[0]).parent)
+    cohort_name = args.output_cohort_name or str(Path(output_folder) / "cohort")
+    Path(cohort_name).parent.mkdir(exist_ok=True)
+
+    # index (must exist: building it needs the network, pyhlamsa and muscle -- out of scope)
+    if args.msa_no_exon_only_allele:
+        index_msa = f"{args.index_folder}/kir_{args.ipd_version}_{args.msa_type}.leftalign"
+    else:
+        index_msa = f"{args.index_folder}/kir_{args.ipd_version}_withexon_{args.msa_type}.leftalign"
+    index_ref = index_msa + ".mut01"
+    index = index_ref + ".graph"
+    if not Path(index_ref + ".snp").exists():
+        raise FileNotFoundError(f"{index_ref}.snp/.link/.locus not found: building the index is outside this build")
+
+    # shard the cohort over ranks (one GPU per process)
+    dist = cohort.initFromEnv()
+    comm = cohort.Comm(len(names)) if dist is not None else None
+    mine = comm.mine if comm else list(range(len(names)))
+    pick = lambda xs: [xs[i] for i in mine]   # noqa: E731
+
+    bam_files, processed, depth_files = readMapping(
+        pick(names), pick(reads), index, index_ref, exon_region_only=args.cn_exon,
+        alignments=pick(args.alignment) if args.alignment else None, write_json=not args.no_variant_json)
+    my_cn = pick(cn_files)
+
+    kwargs = {"base_dev": float(args.cn_dist_dev), "start_base": 2}
+    if all(cn_files):
+        pass
+    elif not args.cn_cohort:
+        for i, depth_file in enumerate(depth_files):
+            if my_cn[i]:
+                continue
+            name = str(Path(depth_file).with_suffix(f".{args.cn_select}.{args.cn_algorithm}"))
+            logger.info(f"[CN] Copy number estimation per sample ({name})")
+            predictSamplesCN([depth_file], [name + ".tsv"], "", cluster_method=args.cn_algorithm,
+                             cluster_method_kwargs=kwargs, assume_3DL3_diploid=not args.cn_3dl3_not_diploid,
+                             save_cn_model_path=name + ".json", select_mode=args.cn_select)
+            my_cn[i] = name + ".tsv"
+    else:
+        suffix = f".{args.cn_select}.cohort.{args.cn_algorithm}"
+        my_cn = [str(Path(p).with_suffix(suffix + ".tsv")) for p in depth_files]
+        logger.info(f"[CN] Copy number estimation by cohort ({cohort_name + suffix})")
+        predictSamplesCN(depth_files, my_cn, cluster_method=args.cn_algorithm, cluster_method_kwargs=kwargs,
+                         save_cn_model_path=cohort_name + suffix + ".json", select_mode=args.cn_select, comm=comm)
+
+    allele_files: list[str] = []
+    if not args.step_skip_typing:
+        method = {"pv": "full", "report": "em"}.get(args.allele_strategy, args.allele_strategy)
+        allele_files = alleleTyping(processed, my_cn, method=method)
+
+    # merge on rank 0, in cohort order
+    if comm is not None:
+        all_cn, all_al = [None] * comm.world, [None] * comm.world
+        dist.all_gather_object(all_cn, my_cn)
+        dist.all_gather_object(all_al, allele_files)
+        if comm.rank == 0:
+            cn_sorted, al_sorted = [""] * len(names), [""] * len(names)
+            for r, idxs in enumerate(comm.shards):
+                for k, gi in enumerate(idxs):
+                    cn_sorted[gi] = all_cn[r][k]
+                    if all_al[r]:
+                        al_sorted[gi] = all_al[r][k]
+            my_cn, allele_files = cn_sorted, [a for a in al_sorted if a]
+    if comm is None or comm.rank == 0:
+        logger.info(f"[CN] Saved copy number in {cohort_name}.cn.tsv")
+        mergeCN(my_cn, cohort_name + ".cn.tsv")
+        if allele_files:
+            logger.info(f"[Allele] Saved in {cohort_name}.allele.tsv")
+            mergeAllele(allele_files, cohort_name + ".allele.tsv")
+    if comm is not None:
+        comm.barrier()
+        dist.destroy_process_group()
+    logger.info("[Main] Success")
+
+
+def entrypoint() -> None:
+    main(createParser().parse_args())
+
+
+if __name__ == "__main__":
+    entrypoint()

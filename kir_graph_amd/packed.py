@@ -176,8 +176,15 @@ def packPairs(pairs, index: GkIndex, table: InsTable | None = None) -> tuple[np.
                 continue
             ops, mms, ins, clipped = _walkText(int(cols[3]) - 1, cols[5], cols[9], md, zs, table)
             if clipped:
-                r["n_cig"] = 1
-                r["cig"][0] = CIG_S
+                # a soft-clipped mate yields no variants (hisat2.py:682-683) but still counts for read
+                # depth: keep its CIGAR when it fits (S ops included), else just the clip marker
+                full = [(CIG_S if o == "S" else {"M": CIG_M, "I": CIG_I, "D": CIG_D}[o], int(n))
+                        for n, o in _CIGAR.findall(cols[5])]
+                if len(full) > MAX_CIG or any(n > MAX_OPLEN for _, n in full):
+                    full = [(CIG_S, 0)]
+                r["n_cig"] = len(full)
+                for i, (o, n) in enumerate(full):
+                    r["cig"][i] = (n << 4) | o
                 continue
             n_ev = len(mms) + sum(1 for o, _ in ops if o in (CIG_I, CIG_D))
             if (len(ops) > MAX_CIG or len(mms) > MAX_MM or len(ins) > MAX_INS or n_ev > MAX_EV
@@ -221,10 +228,27 @@ def packSample(sample, index: GkIndex, table: InsTable | None = None) -> tuple[n
     ok = ((flag & 2) != 0) & (nm >= 0) & (nm <= 4)
     ok_pair = ok[0::2] & ok[1::2]
     walk = np.repeat(ok_pair, 2)
-    clipped = (sample.clip[src].sum(axis=1) > 0) & walk
-    rec["n_cig"][clipped] = 1
+    clip = sample.clip[src]
+    clipped = (clip.sum(axis=1) > 0) & walk
     cig = rec["cig"]
-    cig[clipped, 0] = CIG_S
+    # synthetic clipped mates carry no events: CIGAR = [head S] span M [tail S]
+    span_all = sample.span[src].astype(np.int64)
+    for side_mask, head, tail in ((clipped & (clip[:, 0] > 0) & (clip[:, 1] == 0), True, False),
+                                  (clipped & (clip[:, 0] == 0) & (clip[:, 1] > 0), False, True),
+                                  (clipped & (clip[:, 0] > 0) & (clip[:, 1] > 0), True, True)):
+        idx = np.nonzero(side_mask)[0]
+        if not len(idx):
+            continue
+        k = 0
+        if head:
+            cig[idx, k] = ((clip[idx, 0].astype(np.int64) << 4) | CIG_S).astype(np.uint16)
+            k += 1
+        cig[idx, k] = ((span_all[idx] << 4) | CIG_M).astype(np.uint16)
+        k += 1
+        if tail:
+            cig[idx, k] = ((clip[idx, 1].astype(np.int64) << 4) | CIG_S).astype(np.uint16)
+            k += 1
+        rec["n_cig"][idx] = k
     todo = walk & ~clipped
 
     ev_cnt = (sample.ev_off[1:] - sample.ev_off[:-1])[src]

@@ -1,0 +1,107 @@
+"""GPU parity: read depth, copy-number model and the command line end to end vs the CPU oracle."""
+import copy
+import gzip
+import io
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from kir_graph_amd import synth
+from kir_graph_amd.hisat2 import extractVariant, pairLines
+from kir_graph_amd.index import GkIndex
+from kir_graph_amd.kir_cn import depthToCN, predictSamplesCN, loadCN
+from kir_graph_amd.samtools_utils import depthOfSample
+from oracle import cn as ocn, depth as odepth, tabulate as ot, typing as oty
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_depth_matches_oracle(device, small_case):
+    sidx, gidx, sample = small_case
+    lines = synth.toSamLines(sample)
+    data = extractVariant(pairLines(lines), gidx, dev=device)
+    gene_len = {g: len(sidx.backbone[g]) for g in sidx.genes}
+    df = depthOfSample(data, gene_len)
+    kept = [(l, r, ot.nhOf(l)) for l, r in ot.pairMates(lines) if ot.passesFilter(l) and ot.passesFilter(r)]
+    want = odepth.depthFromPairs(kept, gene_len)
+    for g in sidx.genes:
+        got = df[df["gene"] == g]["depth"].to_numpy()
+        assert np.array_equal(got, want[g]), g
+    assert list(df[df["gene"] == sidx.genes[0]]["pos"][:3]) == [1, 2, 3]
+
+
+def test_copy_number_matches_reference_fixture(device):
+    with gzip.open(os.path.join(GOLD, "t8_cn.json.gz"), "rt") as f:
+        t8 = json.load(f)
+    tables = [pd.DataFrame(rows, columns=["gene", "pos", "depth"]) for rows in t8["depth_tables"]]
+    kw = {"base_dev": 0.08, "start_base": 2}
+    for mode, res in t8["per_sample"].items():
+        for df, want in zip(tables, res):
+            depths = ocn.geneDepths(df, mode)
+            cns, model = depthToCN([depths], cluster_method="LCND", cluster_method_kwargs=kw,
+                                   assume_3DL3_diploid=True)
+            ref = pd.read_csv(io.StringIO(want["tsv"]), sep="\t")
+            assert {k: int(v) for k, v in cns[0].items()} == dict(zip(ref["gene"], ref["cn"]))   # integer CN: exact
+            assert model.base == pytest.approx(float.fromhex(want["base"]), rel=1e-12)
+            assert model.bin_num == want["bin_num"]
+    for method, files in t8["cohort"].items():
+        depths = [ocn.geneDepths(df, "p75") for df in tables]
+        cns, _ = depthToCN(depths, cluster_method=method, cluster_method_kwargs=kw if method == "LCND" else {})
+        for got, want in zip(cns, files):
+            ref = pd.read_csv(io.StringIO(want), sep="\t")
+            assert {k: int(v) for k, v in got.items()} == dict(zip(ref["gene"], ref["cn"]))
+
+
+def test_likelihood_curve_close_to_scipy(device):
+    rng = np.random.default_rng(3)
+    values = list(np.concatenate([rng.normal(30 * k, 2 + k, 6) for k in (1, 2, 2, 3)]).clip(0))
+    _, dev_model = depthToCN([dict(enumerate(values))], cluster_method="LCND",
+                             cluster_method_kwargs={"base_dev": 0.08, "start_base": 2})
+    _, cpu_model = ocn.depthsToCN([dict(enumerate(values))], "LCND", {"base_dev": 0.08, "start_base": 2})
+    assert np.allclose(dev_model.likelihood, cpu_model.likelihood, rtol=1e-10, atol=1e-9)
+    assert dev_model.base == cpu_model.base
+
+
+def test_command_line_two_samples(device, tmp_path):
+    """graphkir CLI on two synthetic samples: same files, same allele calls as the oracle pipeline."""
+    from kir_graph_amd import main as cli
+    sidx = synth.makeIndex(seed=11, n_genes=3, var_range=(200, 300), allele_range=(12, 20))
+    folder = tmp_path / "index"
+    folder.mkdir()
+    prefix = str(folder / "kir_2100_withexon_ab_2dl1s1.leftalign.mut01")
+    sidx.write(prefix)
+    gidx = GkIndex.load(prefix)
+    # 3DL3 must be present for the per-sample CN model: rename the last backbone is not needed in cohort mode
+    sams, cns, samples = [], [], []
+    for k in range(2):
+        s = synth.makeSample(sidx, seed=50 + k, n_pairs=2500)
+        path = tmp_path / f"s{k}.sam.gz"
+        with gzip.open(path, "wt") as f:
+            f.write("@HD\tVN:1.0\tSO:queryname\n" + "\n".join(synth.toSamLines(s)) + "\n")
+        cn_path = tmp_path / f"s{k}.cn.tsv"
+        cn_path.write_text("gene\tcn\n" + "".join(f"{g}\t{c}\n" for g, c in s.gene_cn.items()))
+        sams.append(str(path)); cns.append(str(cn_path)); samples.append(s)
+    args = cli.createParser().parse_args(
+        ["--step-skip-extraction", "--index-folder", str(folder), "--output-folder", str(tmp_path / "out"),
+         "--allele-strategy", "pv", "--cn-provided", *cns, "--alignment", sams[0], "--alignment", sams[1]])
+    cli.main(args)
+    out = pd.read_csv(tmp_path / "out" / "cohort.allele.tsv", sep="\t")
+    assert list(out.columns) == ["name", "alleles", "warnings"]
+    assert len(out) == 2
+    for k, s in enumerate(samples):
+        ref = ot.tabulateLines(synth.toSamLines(s), gidx.variants)
+        calls, warn = oty.makeTyper("full", copy.deepcopy(ref), top_n=600, variant_correction=True).typing(s.gene_cn)
+        assert out["alleles"][k] == "_".join(calls)
+        assert (out["warnings"][k] if isinstance(out["warnings"][k], str) else "") == "_".join(warn)
+        assert out["name"][k].endswith(".full")
+    cn = pd.read_csv(tmp_path / "out" / "cohort.cn.tsv", sep="\t", index_col=0)
+    assert list(cn.columns) == cns
+    # the per-sample artefacts of the reference's naming chain exist
+    produced = sorted(p.name for p in (tmp_path / "out").iterdir())
+    assert any(n.endswith(".variant.json") for n in produced)
+    assert any(n.endswith(".variant.no_multi.depth.tsv") for n in produced)
+    assert any(n.endswith(".full.possible.tsv") for n in produced)
