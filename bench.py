@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per sample (config 2: 1e6)")
     ap.add_argument("--method", default="pv")
-    ap.add_argument("--cpu-pairs", type=int, default=6000, help="pairs for the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs for the CPU baseline sample (0 = skip)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--profile-host", action="store_true", help="cProfile one extra step to stderr")
     args = ap.parse_args()
