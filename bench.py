@@ -94,16 +94,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = os.environ.get("GK_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N > 1 path on one GPU
     if world > 1:
         import torch
         import torch.distributed as dist_
-        torch.cuda.set_device(local_rank)
-        dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_.init_process_group(backend)
         dist = dist_
 
     from kir_graph_amd import _lib
     from kir_graph_amd.engine import DeviceIndex
-    dev = _lib.Device(local_rank if world > 1 else 0)
+    n_dev = max(1, _lib.deviceCount())
+    dev = _lib.Device(local_rank % n_dev if world > 1 else 0)
     sidx, gidx, sample, rec, table = build_inputs(seed=1031 + rank, n_pairs=args.pairs)
     gene_cn = sample.gene_cn
     dindex = DeviceIndex(dev, gidx)
@@ -114,9 +119,11 @@ def main():
         dev.sync()
         if dist is not None:
             import torch
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         one_step(dev, dindex, gidx, mates, table, gene_cn, args.method)
@@ -152,7 +159,7 @@ def main():
 
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

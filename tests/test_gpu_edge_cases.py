@@ -1,0 +1,94 @@
+"""GPU parity on edge cases: row counts around numpy's summation block sizes, small top_n, copy numbers
+1-4, forced / automatic zygosity, duplicated alleles (tie heavy), empty genes -- through the list-based
+drop-in constructors (``AlleleTyping(reads, variants, ...)``) vs the CPU oracle."""
+import copy
+
+import numpy as np
+import pytest
+
+from kir_graph_amd import synth
+from kir_graph_amd.hisat2 import PairRead
+from kir_graph_amd.typing_mulit_allele import AlleleTyping, AlleleTypingExonFirst
+from oracle import tabulate as ot, typing as oty
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def one_gene():
+    sidx = synth.makeIndex(seed=77, n_genes=1, var_range=(260, 320), allele_range=(22, 28), len_range=(5000, 6000))
+    g = sidx.genes[0]
+    # duplicate one allele under a second name: every set containing either ties exactly
+    twin_of, twin = sidx.alleles[g][0], sidx.alleles[g][0] + "X"
+    for v in sidx.variants:
+        if twin_of in v.allele:
+            v.allele = sorted(v.allele + [twin])
+    sidx.alleles[g].append(twin)
+    sample = synth.makeSample(sidx, seed=5, n_pairs=21000, gene_cn={g: 2}, frac_multi=0.0)
+    data = ot.tabulateLines(synth.toSamLines(sample), sidx.variants)
+    variants = data["variants"]
+    return g, variants, data["reads"]
+
+
+def to_pairs(reads):
+    return [PairRead(lpv=list(r["lpv"]), lnv=list(r["lnv"]), rpv=list(r["rpv"]), rnv=list(r["rnv"]),
+                     multiple=r["multiple"], backbone=r["backbone"]) for r in reads]
+
+
+def same(a, b):
+    assert a.n == b.n
+    for f in ("value", "value_sum_indv", "allele_id", "fraction"):
+        x, y = np.asarray(getattr(a, f)), np.asarray(getattr(b, f))
+        assert x.shape == y.shape, (f, x.shape, y.shape)
+        assert np.array_equal(x, y), f
+    assert list(map(list, a.allele_name)) == b.allele_name
+
+
+@pytest.mark.parametrize("n_rows", [1, 7, 8, 9, 127, 128, 129, 1000, 8191, 8192, 8193, 20000])
+def test_row_counts_around_block_sizes(device, one_gene, n_rows):
+    g, variants, reads = one_gene
+    sub = reads[:n_rows]
+    cpu = oty.GeneModel(copy.deepcopy(sub), variants, force_homo=False, top_n=600, variant_correction=False)
+    gpu = AlleleTyping(to_pairs(sub), variants, force_homo=False, top_n=600, variant_correction=False, device=device)
+    assert gpu.getReadsNum() == cpu.readsNum()
+    want = cpu.typing(2)
+    got = gpu.typing(2)
+    if cpu.readsNum():
+        assert np.array_equal(gpu.log_probs, cpu.log_probs)
+    same(got, want)
+    assert got.selectBest() == oty.selectBest(want)
+
+
+@pytest.mark.parametrize("cn,top_n,force", [(1, 600, None), (2, 5, False), (3, 600, False), (4, 40, False),
+                                            (2, 600, None), (3, 600, None), (2, 600, True)])
+def test_copy_numbers_topn_zygosity(device, one_gene, cn, top_n, force):
+    g, variants, reads = one_gene
+    sub = reads[:3000]
+    cpu = oty.GeneModel(copy.deepcopy(sub), variants, force_homo=force, top_n=top_n, variant_correction=True)
+    gpu = AlleleTyping(to_pairs(sub), variants, force_homo=force, top_n=top_n, variant_correction=True, device=device)
+    want, got = cpu.typing(cn), gpu.typing(cn)
+    assert len(gpu.result) == len(cpu.result)
+    for a, b in zip(gpu.result, cpu.result):
+        same(a, b)
+    assert got.selectBest() == oty.selectBest(want)
+    # the kept reads (after error correction / empty removal) are exposed like the reference's .reads
+    assert [(r.lpv, r.rpv, r.lnv, r.rnv) for r in gpu.reads[:50]] == \
+           [(r["lpv"], r["rpv"], r["lnv"], r["rnv"]) for r in cpu.reads[:50]]
+
+
+def test_exon_first_from_lists(device, one_gene):
+    g, variants, reads = one_gene
+    sub = reads[:4000]
+    cpu = oty.ExonFirstModel(copy.deepcopy(sub), variants, top_n=600, candidate_set_threshold=1.0)
+    gpu = AlleleTypingExonFirst(to_pairs(sub), variants, top_n=600, candidate_set_threshold=1.0, device=device)
+    want, got = cpu.typing(2), gpu.typing(2)
+    same(got, want)
+    assert gpu.allele_group == cpu.allele_group
+
+
+def test_gene_without_reads_fails_softly(device, one_gene):
+    g, variants, _ = one_gene
+    gpu = AlleleTyping([], variants, force_homo=False, top_n=600, device=device)
+    res = gpu.typing(2)
+    assert res.isFail() and res.selectBest() == ["fail", "fail"]
+    assert gpu.getReadsNum() == 0
