@@ -199,6 +199,22 @@ int gk_em_run(gk_ctx* ctx, const uint32_t* sets, const double* weight, int32_t n
               int32_t n_allele, int32_t iter_max, double diff_threshold, double* prob_out,
               int32_t* iters_out);
 
+/* ---- host ingest (no GPU): name-collated SAM text -> gk_mate records.
+ * Native form of readPair (hisat2.py:228-276), of the field reads of filterRead / getNH (551-569,
+ * 95-100) and of the CIGAR / MD / Zs consistency checks of recordToRawVariant (279-515).  Text is fed
+ * in chunks; on a reference `assert` / NotImplementedError the feed stops and gk_packer_error tells
+ * kind (1 AssertionError, 2 NotImplementedError, 3 record capacity, 4 ValueError) and input line. */
+typedef struct gk_packer gk_packer;
+int gk_packer_create(const char* const* gene_names, int32_t n_genes, const char* const* ins_strings,
+                     int32_t n_ins, gk_packer** out);
+int gk_packer_destroy(gk_packer* pk);
+int gk_packer_feed(gk_packer* pk, const char* text, size_t n_bytes, int32_t final);
+int gk_packer_counts(gk_packer* pk, int64_t* n_lines, int64_t* n_reads, int64_t* n_pairs, int64_t* n_strange,
+                     int64_t* n_strings);
+int gk_packer_error(gk_packer* pk, int32_t* kind, int64_t* line_index);
+int gk_packer_records(gk_packer* pk, gk_mate* mates_out, int64_t* pair_lines_out);
+const char* gk_packer_string(gk_packer* pk, int64_t i);
+
 /* ---- read depth: replaces `samtools depth -aa {name}.no_multi.bam` (samtools_utils.py:9-14).
  * Depth of every backbone position from the M runs of the filter-passing pairs of a tabulation made
  * by gk_tabulate (NH == 1 only unless `multiple`).  gene_off[g] = start of backbone g in the

@@ -101,6 +101,14 @@ _SIGS = {
                               C.c_void_p]),
     "gk_setmax": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                             C.c_uint64]),
+    "gk_packer_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "gk_packer_destroy": (C.c_int, [C.c_void_p]),
+    "gk_packer_feed": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int32]),
+    "gk_packer_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gk_packer_error": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "gk_packer_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gk_packer_string": (C.c_char_p, [C.c_void_p, C.c_int64]),
     "gk_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "gk_cn_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                             C.c_int32, C.c_int32, C.c_double, C.c_void_p]),

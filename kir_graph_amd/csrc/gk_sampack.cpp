@@ -1,0 +1,465 @@
+// Host-side ingest: name-collated SAM text -> packed gk_mate records (no GPU work here).
+//
+// Native counterpart of kir_graph_amd/packed.py::packPairs + hisat2.pairLines, i.e. of the text side
+// of the reference: readPair (hisat2.py:228-276), the field reads of filterRead (551-569), getNH
+// (95-100) and the CIGAR / MD / Zs co-walk CHECKS of recordToRawVariant (279-515: asserts at 416-417,
+// 461, 512-514; NotImplementedError for N and unknown ops at 499-502).  The variant walk itself runs on
+// the device from the records produced here.  Errors are reported with the reference's exception kind
+// and the 0-based index of the offending input line; the Python wrapper re-raises them.
+#include <cctype>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "graphkir_hip.h"
+
+void gk_set_error(const char* fmt, ...);
+
+namespace {
+
+using sv = std::string_view;
+
+struct LineRef { int64_t begin, len, index; };   // byte range in the stream and line number
+
+struct Pending { std::string line; int64_t index; int flag; };
+
+struct MdTok { int kind; long num; char ch; };   // kind 0 = number, 1 = character
+
+}  // namespace
+
+struct gk_packer {
+  std::vector<std::string> genes;
+  std::unordered_map<std::string, int> gene_id;
+  std::unordered_map<std::string, uint32_t> ins_id;
+  std::vector<std::string> ins_strings;
+  uint32_t n_index_ins = 0;
+  std::unordered_map<std::string, Pending> waiting;
+  std::vector<gk_mate> mates;
+  std::vector<int64_t> pair_lines;   // 2 per pair: line index of left (later) and right (earlier) record
+  std::string carry;                 // partial last line of the previous chunk
+  int64_t n_lines = 0, n_reads = 0, n_pairs = 0, n_strange = 0;
+  int err_kind = 0;                  // 0 none, 1 AssertionError, 2 NotImplementedError, 3 capacity, 4 ValueError
+  int64_t err_line = -1;
+  std::string err_msg;
+};
+
+namespace {
+
+sv strip(sv s) {
+  size_t a = 0, b = s.size();
+  while (a < b && isspace((unsigned char)s[a])) ++a;
+  while (b > a && isspace((unsigned char)s[b - 1])) --b;
+  return s.substr(a, b - a);
+}
+
+void split_tabs(sv s, std::vector<sv>& out) {
+  out.clear();
+  size_t a = 0;
+  for (;;) {
+    size_t t = s.find('\t', a);
+    if (t == sv::npos) { out.push_back(s.substr(a)); return; }
+    out.push_back(s.substr(a, t - a));
+    a = t + 1;
+  }
+}
+
+bool to_long(sv s, long& v) {   // Python int(): optional sign, digits, surrounding blanks
+  s = strip(s);
+  if (s.empty()) return false;
+  size_t i = 0;
+  bool neg = false;
+  if (s[0] == '+' || s[0] == '-') { neg = s[0] == '-'; i = 1; }
+  if (i >= s.size()) return false;
+  long x = 0;
+  for (; i < s.size(); ++i) {
+    if (!isdigit((unsigned char)s[i])) return false;
+    x = x * 10 + (s[i] - '0');
+  }
+  v = neg ? -x : x;
+  return true;
+}
+
+struct Fail { int kind; std::string msg; };
+
+struct Walked {
+  std::vector<std::pair<int, long>> ops;        // (GK_CIG_*, length)
+  std::vector<std::pair<long, int>> mms;        // (ref offset, read base)
+  std::vector<uint32_t> ins;
+  bool clipped = false;
+};
+
+bool is_acgt(const MdTok& t) { return t.kind == 1 && (t.ch == 'A' || t.ch == 'C' || t.ch == 'G' || t.ch == 'T'); }
+
+// CIGAR / MD / Zs co-walk with the reference's consumption checks (see packed.py::_walkText)
+bool walk_text(gk_packer* pk, sv cigar, sv seq, bool has_md, sv md_s, bool has_zs, sv zs_s, Walked& w, Fail& f) {
+  std::vector<MdTok> md;
+  if (has_md) {
+    for (size_t i = 0; i < md_s.size();) {
+      if (isdigit((unsigned char)md_s[i])) {
+        long x = 0;
+        while (i < md_s.size() && isdigit((unsigned char)md_s[i])) x = x * 10 + (md_s[i++] - '0');
+        md.push_back({0, x, 0});
+      } else {
+        md.push_back({1, 0, md_s[i++]});
+      }
+    }
+  }
+  struct Zs { long gap; char kind; };
+  std::vector<Zs> zs;
+  if (has_zs && !zs_s.empty()) {
+    size_t a = 0;
+    for (;;) {
+      size_t c = zs_s.find(',', a);
+      sv ent = zs_s.substr(a, c == sv::npos ? sv::npos : c - a);
+      size_t p1 = ent.find('|');
+      size_t p2 = p1 == sv::npos ? sv::npos : ent.find('|', p1 + 1);
+      long gap = 0;
+      if (p1 == sv::npos || p2 == sv::npos || !to_long(ent.substr(0, p1), gap)) {
+        f = {4, "malformed Zs entry"};
+        return false;
+      }
+      sv kind = ent.substr(p1 + 1, p2 - p1 - 1);
+      zs.push_back({gap, kind.size() == 1 ? kind[0] : '?'});
+      if (c == sv::npos) break;
+      a = c + 1;
+    }
+  }
+  long ref = 0, ri = 0, owed = 0, zpos = 0;
+  size_t mi = 0, zi = 0;
+  auto take_zs = [&](char kind) {
+    if (zi < zs.size() && zs[zi].kind == kind && ri + owed == zpos + zs[zi].gap) {
+      zpos += zs[zi].gap + (kind == 'S' ? 1 : 0);
+      ++zi;
+    }
+  };
+  auto md_is_zero = [&](size_t i) { return i < md.size() && md[i].kind == 0 && md[i].num == 0; };
+  // re.findall(r"(\d+)(\w)"): digit runs followed by one word character; anything else is skipped
+  for (size_t i = 0; i < cigar.size();) {
+    if (!isdigit((unsigned char)cigar[i])) { ++i; continue; }
+    long n = 0;
+    size_t j = i;
+    while (j < cigar.size() && isdigit((unsigned char)cigar[j])) n = n * 10 + (cigar[j++] - '0');
+    char op;
+    if (j >= cigar.size() || !(isalnum((unsigned char)cigar[j]) || cigar[j] == '_')) {
+      // regex backtracking: with no word character after the digits, "\d+" gives its last digit to "\w"
+      if (j - i < 2) { i = j; continue; }
+      n /= 10;
+      op = cigar[j - 1];
+      i = j;
+    } else {
+      op = cigar[j];
+      i = j + 1;
+    }
+    if (md_is_zero(mi)) ++mi;
+    if (op == 'M') {
+      w.ops.push_back({GK_CIG_M, n});
+      long done = 0;
+      for (;;) {
+        if (owed <= done && mi < md.size() && md[mi].kind == 0) { owed += md[mi].num; ++mi; }
+        if (owed >= n) { owed -= n; break; }
+        if (ri + owed >= (long)seq.size() || mi >= md.size()) { f = {1, "MD / SEQ exhausted inside an M op"}; return false; }
+        const char base = seq[ri + owed];
+        if (md_is_zero(mi)) ++mi;
+        if (mi >= md.size()) { f = {1, "MD exhausted inside an M op"}; return false; }
+        if (!is_acgt(md[mi])) { f = {1, "MD mismatch token is not a base"}; return false; }
+        if (md[mi].ch == base) { f = {1, "MD reference base equals the read base"}; return false; }
+        ++mi;
+        take_zs('S');
+        w.mms.push_back({ref + owed, (unsigned char)base});
+        owed += 1;
+        done = owed;
+        if (owed == n) { owed = 0; break; }
+      }
+      ref += n;
+      ri += n;
+    } else if (op == 'I') {
+      w.ops.push_back({GK_CIG_I, n});
+      take_zs('I');
+      std::string s(seq.substr((size_t)std::min<long>(ri, (long)seq.size()),
+                               (size_t)std::max<long>(0, std::min<long>(n, (long)seq.size() - ri))));
+      auto it = pk->ins_id.find(s);
+      uint32_t id;
+      if (it == pk->ins_id.end()) {
+        id = (uint32_t)pk->ins_strings.size();
+        pk->ins_id.emplace(s, id);
+        pk->ins_strings.push_back(s);
+      } else {
+        id = it->second;
+      }
+      w.ins.push_back(id);
+      ri += n;
+    } else if (op == 'D') {
+      w.ops.push_back({GK_CIG_D, n});
+      if (mi >= md.size() || !(md[mi].kind == 1 && md[mi].ch == '^')) { f = {1, "MD has no deletion at a D op"}; return false; }
+      ++mi;
+      while (mi < md.size() && is_acgt(md[mi])) ++mi;
+      take_zs('D');
+      ref += n;
+    } else if (op == 'S') {
+      w.clipped = true;
+      zpos += n;
+      ri += n;
+    } else if (op == 'N') {
+      f = {2, "Cannot typing with splicing"};
+      return false;
+    } else {
+      f = {2, "unsupported CIGAR operation"};
+      return false;
+    }
+  }
+  if (md_is_zero(mi)) ++mi;
+  if (zi != zs.size()) { f = {1, "Zs entries do not line up with the alignment"}; return false; }
+  if (mi != md.size()) { f = {1, "MD not fully consumed"}; return false; }
+  if (ri != (long)seq.size()) { f = {1, "CIGAR does not cover the read"}; return false; }
+  return true;
+}
+
+struct Parsed {
+  std::vector<sv> cols;
+  long flag = 0, pos = 0;
+  bool has_nm = false, has_md = false, has_zs = false;
+  long nm = 0;
+  sv md, zs;
+  long nh = 1;
+};
+
+bool parse_record(sv line, Parsed& p, Fail& f) {
+  split_tabs(strip(line), p.cols);
+  if (p.cols.size() < 11 || !to_long(p.cols[1], p.flag) || !to_long(p.cols[3], p.pos)) {
+    f = {4, "malformed SAM record"};
+    return false;
+  }
+  for (size_t i = 11; i < p.cols.size(); ++i) {
+    sv c = p.cols[i];
+    if (c.substr(0, 2) == "NM") {
+      long v;
+      if (!to_long(c.size() >= 5 ? c.substr(5) : sv(), v)) { f = {4, "malformed NM tag"}; return false; }
+      p.has_nm = true; p.nm = v;
+    } else if (!p.has_md && c.substr(0, 2) == "MD") {
+      p.has_md = true; p.md = c.size() >= 5 ? c.substr(5) : sv();
+    } else if (!p.has_zs && c.substr(0, 2) == "Zs") {
+      p.has_zs = true; p.zs = c.size() >= 5 ? c.substr(5) : sv();
+    }
+  }
+  // getNH: first "NH:i:<digits>" anywhere in the line
+  p.nh = 1;
+  size_t at = line.find("NH:i:");
+  while (at != sv::npos) {
+    size_t d = at + 5;
+    if (d < line.size() && isdigit((unsigned char)line[d])) {
+      long x = 0;
+      while (d < line.size() && isdigit((unsigned char)line[d])) x = x * 10 + (line[d++] - '0');
+      p.nh = x;
+      break;
+    }
+    at = line.find("NH:i:", at + 1);
+  }
+  return true;
+}
+
+bool passes(const Parsed& p) { return (p.flag & 2) && p.has_nm && p.nm <= 4; }
+
+bool fail(gk_packer* pk, const Fail& f, int64_t line_index) {
+  pk->err_kind = f.kind;
+  pk->err_line = line_index;
+  pk->err_msg = f.msg;
+  return false;
+}
+
+// one emitted pair: left = the later line, right = the earlier one (readPair yields (line, next_line))
+bool emit_pair(gk_packer* pk, sv left, int64_t left_idx, sv right, int64_t right_idx) {
+  Parsed pr[2];
+  Fail f{0, ""};
+  sv lines[2] = {left, right};
+  int64_t idx[2] = {left_idx, right_idx};
+  for (int s = 0; s < 2; ++s)
+    if (!parse_record(lines[s], pr[s], f)) return fail(pk, f, idx[s]);
+  const bool both = passes(pr[0]) && passes(pr[1]);
+  gk_mate rec[2];
+  memset(rec, 0, sizeof(rec));
+  for (int s = 0; s < 2; ++s) {
+    const Parsed& p = pr[s];
+    gk_mate& r = rec[s];
+    auto g = pk->gene_id.find(std::string(p.cols[2]));
+    if (g == pk->gene_id.end()) return fail(pk, {4, "reference is not a backbone of the index"}, idx[s]);
+    r.pos0 = (uint32_t)(p.pos - 1);
+    r.flag = (uint16_t)(p.flag & 0xFFFF);
+    r.ref = (uint8_t)g->second;
+    r.nh = (uint8_t)std::min<long>(p.nh, 255);
+    r.nm = p.has_nm ? (uint8_t)std::min<long>(std::max<long>(p.nm, 0), 254) : (uint8_t)GK_NM_ABSENT;
+    if (!both) continue;
+    Walked w;
+    if (!walk_text(pk, p.cols[5], p.cols[9], p.has_md, p.md, p.has_zs, p.zs, w, f)) return fail(pk, f, idx[s]);
+    if (w.clipped) {
+      // keep the CIGAR (S ops included) for read depth when it fits, else only the clip marker
+      std::vector<std::pair<int, long>> full;
+      sv cg = p.cols[5];
+      for (size_t i = 0; i < cg.size();) {
+        if (!isdigit((unsigned char)cg[i])) { ++i; continue; }
+        long n = 0;
+        while (i < cg.size() && isdigit((unsigned char)cg[i])) n = n * 10 + (cg[i++] - '0');
+        if (i >= cg.size()) break;
+        const char op = cg[i++];
+        full.push_back({op == 'S' ? GK_CIG_S : op == 'M' ? GK_CIG_M : op == 'I' ? GK_CIG_I : GK_CIG_D, n});
+      }
+      bool fits = full.size() <= GK_MAX_CIG;
+      for (auto& o : full) fits = fits && o.second <= 4095;
+      if (!fits) { full.clear(); full.push_back({GK_CIG_S, 0}); }
+      r.n_cig = (uint8_t)full.size();
+      for (size_t i = 0; i < full.size(); ++i) r.cig[i] = (uint16_t)((full[i].second << 4) | full[i].first);
+      continue;
+    }
+    size_t n_ev = w.mms.size();
+    for (auto& o : w.ops) n_ev += (o.first == GK_CIG_I || o.first == GK_CIG_D) ? 1 : 0;
+    bool fits = w.ops.size() <= GK_MAX_CIG && w.mms.size() <= GK_MAX_MM && w.ins.size() <= GK_MAX_INS &&
+                n_ev <= GK_MAX_EVENTS;
+    for (auto& o : w.ops) fits = fits && o.second <= 4095;
+    for (auto& m : w.mms) fits = fits && m.first <= 0xFFFF;
+    if (!fits) return fail(pk, {3, "record does not fit gk_mate"}, idx[s]);
+    r.n_cig = (uint8_t)w.ops.size(); r.n_mm = (uint8_t)w.mms.size(); r.n_ins = (uint8_t)w.ins.size();
+    for (size_t i = 0; i < w.ops.size(); ++i) r.cig[i] = (uint16_t)((w.ops[i].second << 4) | w.ops[i].first);
+    for (size_t i = 0; i < w.mms.size(); ++i) { r.mm[i].ref_off = (uint16_t)w.mms[i].first; r.mm[i].base = (uint8_t)w.mms[i].second; }
+    for (size_t i = 0; i < w.ins.size(); ++i) r.ins[i] = w.ins[i];
+  }
+  pk->mates.push_back(rec[0]);
+  pk->mates.push_back(rec[1]);
+  pk->pair_lines.push_back(left_idx);
+  pk->pair_lines.push_back(right_idx);
+  return true;
+}
+
+bool feed_line(gk_packer* pk, sv line, int64_t index) {
+  if (line.empty() || line[0] == '@' || line.substr(0, 15) == "[bam_sort_core]") return true;
+  // the first 8 tab fields (readPair: qname, flag, ref, pos, _, _, rnext, pnext)
+  sv f[8];
+  size_t a = 0;
+  for (int k = 0; k < 8; ++k) {
+    size_t t = line.find('\t', a);
+    if (t == sv::npos) {
+      if (k < 7) return fail(pk, {4, "SAM line has fewer than 8 fields"}, index);
+      f[k] = line.substr(a);
+      a = line.size();
+    } else {
+      f[k] = line.substr(a, t - a);
+      a = t + 1;
+    }
+  }
+  if (f[6] != "=") return true;
+  pk->n_reads += 1;
+  long flag;
+  if (!to_long(f[1], flag)) return fail(pk, {4, "malformed FLAG"}, index);
+  const char sec = (flag & 256) ? '1' : '0';
+  auto key = [&](sv pos) {
+    std::string k;
+    k.reserve(f[0].size() + f[2].size() + pos.size() + 4);
+    k.append(f[0]); k.push_back('\t'); k.append(f[2]); k.push_back('\t'); k.append(pos); k.push_back('\t'); k.push_back(sec);
+    return k;
+  };
+  auto it = pk->waiting.find(key(f[7]));
+  if (it == pk->waiting.end()) {
+    pk->waiting[key(f[3])] = Pending{std::string(line), index, (int)flag};
+    return true;
+  }
+  if (((it->second.flag | flag) & 192) != 192) {   // READ1 and READ2 must both be present
+    pk->n_strange += 1;
+    return true;
+  }
+  Pending mate = std::move(it->second);
+  pk->waiting.erase(it);
+  pk->n_pairs += 1;
+  return emit_pair(pk, line, index, mate.line, mate.index);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gk_packer_create(const char* const* gene_names, int32_t n_genes, const char* const* ins_strings, int32_t n_ins,
+                     gk_packer** out) {
+  if (!out || n_genes < 0 || n_ins < 0) { gk_set_error("bad packer arguments"); return GK_ERR_ARG; }
+  gk_packer* pk = new gk_packer();
+  for (int i = 0; i < n_genes; ++i) { pk->genes.emplace_back(gene_names[i]); pk->gene_id[gene_names[i]] = i; }
+  for (int i = 0; i < n_ins; ++i) { pk->ins_strings.emplace_back(ins_strings[i]); pk->ins_id[ins_strings[i]] = (uint32_t)i; }
+  pk->n_index_ins = (uint32_t)n_ins;
+  *out = pk;
+  return GK_OK;
+}
+
+int gk_packer_destroy(gk_packer* pk) {
+  delete pk;
+  return GK_OK;
+}
+
+// Feed a chunk of SAM text (lines may straddle chunks; pass final != 0 with the last chunk).
+// Returns GK_OK, or GK_ERR_ASSERT / GK_ERR_ARG with the details available from gk_packer_error.
+int gk_packer_feed(gk_packer* pk, const char* text, size_t n_bytes, int32_t final) {
+  if (!pk || (!text && n_bytes)) { gk_set_error("bad packer arguments"); return GK_ERR_ARG; }
+  if (pk->err_kind) return GK_ERR_ASSERT;
+  std::string owned;
+  sv data;
+  if (!pk->carry.empty()) {
+    owned = std::move(pk->carry);
+    pk->carry.clear();
+    owned.append(text, n_bytes);
+    data = owned;
+  } else {
+    data = sv(text, n_bytes);
+  }
+  size_t a = 0;
+  while (a < data.size()) {
+    size_t nl = data.find('\n', a);
+    if (nl == sv::npos) {
+      if (!final) { pk->carry.assign(data.substr(a)); return GK_OK; }
+      nl = data.size();
+    }
+    sv line = data.substr(a, nl - a);
+    if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+    const int64_t index = pk->n_lines++;
+    if (!feed_line(pk, line, index)) {
+      gk_set_error("SAM line %lld: %s", (long long)pk->err_line, pk->err_msg.c_str());
+      return GK_ERR_ASSERT;
+    }
+    a = nl + 1;
+  }
+  return GK_OK;
+}
+
+int gk_packer_counts(gk_packer* pk, int64_t* n_lines, int64_t* n_reads, int64_t* n_pairs, int64_t* n_strange,
+                     int64_t* n_strings) {
+  if (!pk) return GK_ERR_ARG;
+  if (n_lines) *n_lines = pk->n_lines;
+  if (n_reads) *n_reads = pk->n_reads;
+  if (n_pairs) *n_pairs = (int64_t)pk->mates.size() / 2;
+  if (n_strange) *n_strange = pk->n_strange;
+  if (n_strings) *n_strings = (int64_t)pk->ins_strings.size();
+  return GK_OK;
+}
+
+// kind: 0 none, 1 AssertionError, 2 NotImplementedError, 3 record capacity, 4 ValueError
+int gk_packer_error(gk_packer* pk, int32_t* kind, int64_t* line_index) {
+  if (!pk) return GK_ERR_ARG;
+  if (kind) *kind = pk->err_kind;
+  if (line_index) *line_index = pk->err_line;
+  return GK_OK;
+}
+
+// Copy out the records (2 per pair) and the line indices (left, right) of every pair.
+int gk_packer_records(gk_packer* pk, gk_mate* mates_out, int64_t* pair_lines_out) {
+  if (!pk) return GK_ERR_ARG;
+  if (mates_out && !pk->mates.empty()) memcpy(mates_out, pk->mates.data(), pk->mates.size() * sizeof(gk_mate));
+  if (pair_lines_out && !pk->pair_lines.empty())
+    memcpy(pair_lines_out, pk->pair_lines.data(), pk->pair_lines.size() * sizeof(int64_t));
+  return GK_OK;
+}
+
+// The i-th interned inserted string (index strings first, then novel ones in first-seen order).
+const char* gk_packer_string(gk_packer* pk, int64_t i) {
+  if (!pk || i < 0 || i >= (int64_t)pk->ins_strings.size()) return "";
+  return pk->ins_strings[(size_t)i].c_str();
+}
+
+}  // extern "C"

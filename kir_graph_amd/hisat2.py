@@ -237,6 +237,32 @@ def extractVariant(pair_reads: Iterable[tuple[str, str]], index: GkIndex | list[
     return SampleData(tab, index, None, pairs_text=pairs, ins_strings=table.strings)
 
 
+def extractVariantFromText(source, index: GkIndex, dev: Device | None = None, dindex: DeviceIndex | None = None,
+                           keep_text: bool = True) -> SampleData:
+    """Name-collated SAM file (or iterable of byte chunks) -> tabulated sample.
+
+    Same result as ``extractVariant(readPair(path), ...)`` with the pairing and text decoding done
+    natively (``gk_packer_*``).  ``keep_text``: keep the SAM lines of the emitted pairs (needed only
+    for the ``l_sam`` / ``r_sam`` fields of ``.variant.json``)."""
+    from .packed import packText, readChunks
+    dev = dev or Device()
+    dindex = dindex or DeviceIndex(dev, index)
+    chunks = readChunks(source) if isinstance(source, str) else source
+    if keep_text:
+        chunks = list(chunks)
+    rec, table, pair_lines, counts = packText(chunks, index)
+    logger.info(f"[Graph] Reads: {counts['reads']} Pairs: {counts['pairs']}")
+    pairs_text = None
+    if keep_text:
+        lines = b"".join(chunks).decode().split("\n")
+        pairs_text = [(lines[a].rstrip("\r"), lines[b].rstrip("\r")) for a, b in pair_lines.tolist()]
+    base = Variant.novel_id
+    tab = Tabulation(dindex, rec, novel_base=base)
+    Variant.novel_id = base + tab.n_novel
+    logger.info(f"[Graph] Filterd pairs: {tab.n_valid}")
+    return SampleData(tab, index, None, pairs_text=pairs_text, ins_strings=table.strings)
+
+
 def writeReadsAndVariantsData(reads_data: ReadsAndVariantsData, filename: str) -> None:
     with open(filename, "w") as f:
         json.dump({"variants": [asdict(v) for v in reads_data["variants"]],

@@ -24,7 +24,8 @@ import pandas as pd
 
 from . import cohort
 from .external_tools import setEngine
-from .hisat2 import SampleData, extractVariant, readExons, readPair, writeReadsAndVariantsData  # noqa: F401
+from .hisat2 import (SampleData, extractVariant, extractVariantFromText, readExons, readPair,  # noqa: F401
+                     writeReadsAndVariantsData)
 from .index import GkIndex
 from .kir_cn import filterDepth, loadCN, predictSamplesCN
 from .kir_typing import defaultDevice, selectKirTypingModel
@@ -77,7 +78,10 @@ def readMapping(names, reads, index, index_ref, exon_region_only=False, alignmen
         bam_files.append(source)
         name += ".variant"
         logger.info(f"[Graph] Filter mapping ({name})")
-        data = extractVariant(readPair(source), gk, dev=dev, dindex=dindex)
+        if source.endswith((".sam", ".sam.gz")):
+            data = extractVariantFromText(source, gk, dev=dev, dindex=dindex, keep_text=write_json)
+        else:   # BAM: name-collate through samtools like the reference (hisat2.readBam)
+            data = extractVariant(readPair(source), gk, dev=dev, dindex=dindex)
         if write_json:
             writeReadsAndVariantsData(data.asDict(), name + ".json")
         processed.append((name, data))

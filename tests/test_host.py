@@ -133,3 +133,44 @@ def test_first_occurrence_equals_set_walk():
             want.append(k not in seen)
             seen.add(k)
         assert list(firstOccurrence(ids, 12)) == want
+
+
+def test_native_packer_equals_python_decoder(tmp_path):
+    """csrc/gk_sampack.cpp == hisat2.pairLines + packed.packPairs: records, pairing order, string table."""
+    sidx = synth.makeIndex(seed=5, n_genes=3, var_range=(200, 300), allele_range=(10, 20))
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    sample = synth.makeSample(sidx, seed=9, n_pairs=1500)
+    lines = ["@HD\tVN:1.0\tSO:queryname", "[bam_sort_core] merging from 1 files"] + synth.toSamLines(sample)
+    want, table_py = packed.packPairs(list(pairLines(lines)), gidx)
+    text = ("\n".join(lines) + "\n").encode()
+    for chunk in (len(text), 4096, 997):           # lines straddling chunk boundaries
+        chunks = [text[i:i + chunk] for i in range(0, len(text), chunk)]
+        got, table, pair_lines, counts = packed.packText(chunks, gidx)
+        assert got.tobytes() == want.tobytes()
+        assert table.strings == table_py.strings
+        assert counts["pairs"] == len(want) // 2
+        expect_pairs = [[lines.index(a), lines.index(b)] for a, b in pairLines(lines)]
+        assert pair_lines.tolist() == expect_pairs
+    # no trailing newline
+    got, *_ = packed.packText([text.rstrip(b"\n")], gidx)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_native_packer_raises_like_the_reference(tmp_path):
+    t1 = load("t1_tabulation.json.gz")
+    gidx = _index_from(t1["index"], tmp_path)
+    good = t1["lines"][:2]
+    got, _, pair_lines, _ = packed.packText([("\n".join(t1["lines"]) + "\n").encode()], gidx)
+    want, _ = packed.packPairs(list(pairLines(t1["lines"])), gidx)
+    assert got.tobytes() == want.tobytes()
+    for rec in t1["records"]:
+        if "error" not in rec:
+            continue
+        exc = {"AssertionError": AssertionError, "NotImplementedError": NotImplementedError}[rec["error"]]
+        # make the bad record the first mate of a pair with a good second mate
+        c = rec["line"].split("\t")
+        mate = good[1].split("\t")
+        c[0] = mate[0]; c[7] = mate[3]
+        mate[7] = c[3]
+        with pytest.raises(exc):
+            packed.packText([("\t".join(c) + "\n" + "\t".join(mate) + "\n").encode()], gidx)
