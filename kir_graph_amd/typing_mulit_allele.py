@@ -62,9 +62,9 @@ class TypingResult:
 
     def selectBest(self, filter_fraction: bool = True, filter_minor: bool = False) -> list[str]:
         ids: Iterable[int] = range(len(self.fraction))
-        if filter_fraction:
+        if filter_fraction and len(self.fraction):
             floor = (1 / self.n) / 2
-            ids = [i for i in ids if all(f >= floor for f in self.fraction[i])]
+            ids = np.flatnonzero((np.asarray(self.fraction) >= floor).all(axis=1)).tolist()
         if filter_minor:
             ids = [i for i in ids
                    if np.abs(self.value_sum_indv[i]).min() / np.abs(self.value_sum_indv[i]).max() > 0.8]
@@ -180,6 +180,54 @@ def firstOccurrence(ids: np.ndarray, n_allele: int) -> np.ndarray:
         key = (key << bits) | srt[:, j]
     import pandas as pd
     return ~pd.Series(key).duplicated(keep="first").to_numpy()
+
+
+def firstOfSets(prev_ids: np.ndarray, cols: np.ndarray, n_allele: int) -> np.ndarray:
+    """First-occurrence mask over the candidates ``prev_ids[t] + [cols[a]]`` in (t-major, a-minor) order.
+
+    Same result as ``firstOccurrence`` on the stacked id table; the sorted-multiset key of every
+    candidate is formed by broadcasting the (already sorted) previous set against the new allele."""
+    import pandas as pd
+    T, k = prev_ids.shape
+    bits = max(1, int(n_allele - 1).bit_length())
+    if bits * (k + 1) > 62 or k > 2:
+        ids = np.hstack([np.repeat(prev_ids, len(cols), axis=0), np.tile(cols, T)[:, None]])
+        return firstOccurrence(ids, n_allele)
+    a = cols[None, :]
+    if k == 1:
+        p = prev_ids[:, :1]
+        key = (np.minimum(p, a) << bits) | np.maximum(p, a)
+    else:
+        ps = np.sort(prev_ids, axis=1)
+        p0, p1 = ps[:, :1], ps[:, 1:2]
+        lo, hi = np.minimum(p0, a), np.maximum(p1, a)
+        mid = p0 + p1 + a - lo - hi
+        key = (((lo << bits) | mid) << bits) | hi
+    return ~pd.Series(key.ravel()).duplicated(keep="first").to_numpy()
+
+
+class LazyNames:
+    """``allele_name`` (list of name lists) built from the id table only for the rows that are read."""
+
+    def __init__(self, ids: np.ndarray, id_to_allele: dict[int, str]):
+        self._ids, self._map = ids, id_to_allele
+
+    def __len__(self) -> int:
+        return len(self._ids)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        return [self._map[int(x)] for x in self._ids[i]]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __eq__(self, other) -> bool:
+        return list(self) == list(other)
+
+    def __repr__(self) -> str:
+        return f"LazyNames({len(self)} sets)"
 
 
 # ---------------------------------------------------------------- device read set
@@ -415,19 +463,22 @@ class AlleleTyping:
             top_ids = cols[:, None][top]
             res = TypingResult(
                 n=1, value=score[top], value_sum_indv=score[top][:, None], allele_id=top_ids,
-                allele_name=self.mapAlleleIDs(top_ids), allele_prob=LazyAlleleProb([(m, top_ids)]),
+                allele_name=LazyNames(top_ids, self.id_to_allele), allele_prob=LazyAlleleProb([(m, top_ids)]),
                 fraction=np.ones(top_ids.shape), fraction_uniq=np.ones(top_ids.shape))
             self.result.append(res)
             return res
 
         prev = self.result[-1]
-        prev_ids = np.asarray(prev.allele_id)
-        score = m.maxsum(prev_ids, cols).flatten()
-        ids = np.hstack([np.repeat(prev_ids, len(cols), axis=0), np.tile(cols, len(prev_ids))[:, None]])
-        first = firstOccurrence(ids, m.n_allele)
-        ids, score = ids[first], score[first]
-        top = np.argsort(score)[::-1][:max(self.top_n, score.shape[0] // 5)]
-        top_ids = ids[top]
+        prev_ids = np.asarray(prev.allele_id, dtype=np.int64)
+        score = m.maxsum(prev_ids, cols).ravel()            # candidate (t, a) at flat index t * len(cols) + a
+        # first occurrence of every allele multiset in (t-major, a-minor) order (uniqueAllele 456-476),
+        # from keys built by broadcasting -- the (T*A) x CN id table is never materialised
+        first = np.flatnonzero(firstOfSets(prev_ids, np.asarray(cols, dtype=np.int64), m.n_allele))
+        score_u = score[first]
+        top = np.argsort(score_u)[::-1][:max(self.top_n, score_u.shape[0] // 5)]
+        t_idx, a_idx = np.divmod(first[top], len(cols))
+        top_ids = np.concatenate([prev_ids[t_idx], np.asarray(cols, dtype=np.int64)[a_idx][:, None]], axis=1)
+        score = score_u
         value = score[top]
         sum_indv = self._colsums()[top_ids]                     # = log_probs[:, ids].sum(axis=0)
         key1, key2 = -value, -sum_indv.sum(axis=1)
@@ -447,7 +498,7 @@ class AlleleTyping:
         kept = top_ids[order]
         res = TypingResult(
             n=prev.n + 1, value=value[order], value_sum_indv=sum_indv[order], allele_id=kept,
-            allele_name=self.mapAlleleIDs(kept), allele_prob=LazyAlleleProb([(m, kept)]),
+            allele_name=LazyNames(kept, self.id_to_allele), allele_prob=LazyAlleleProb([(m, kept)]),
             fraction=frac[sub], fraction_uniq=np.ones(kept.shape))
         self.result.append(res)
         return res

@@ -174,3 +174,13 @@ def test_native_packer_raises_like_the_reference(tmp_path):
         mate[7] = c[3]
         with pytest.raises(exc):
             packed.packText([("\t".join(c) + "\n" + "\t".join(mate) + "\n").encode()], gidx)
+
+
+def test_first_of_sets_equals_stacked_table():
+    from kir_graph_amd.typing_mulit_allele import firstOfSets
+    rng = np.random.default_rng(4)
+    for k in (1, 2, 3):
+        prev = rng.integers(0, 20, (37, k))
+        cols = rng.permutation(20)[:13]
+        ids = np.hstack([np.repeat(prev, len(cols), axis=0), np.tile(cols, len(prev))[:, None]])
+        assert list(firstOfSets(prev, cols, 20)) == list(firstOccurrence(ids, 20))
