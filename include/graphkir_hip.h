@@ -174,6 +174,13 @@ int gk_lut_pending(gk_lut* lut, int32_t* n_total, int32_t* n_known);     /* sync
 int gk_lut_export(gk_lut* lut, int32_t first, int32_t count, double* keys_out);
 int gk_lut_define(gk_lut* lut, int32_t first, int32_t count, const double* log_vals);
 int gk_lut_apply(gk_lut* lut, gk_dptr d_in, gk_dptr d_out, int64_t n);
+/* reads2AlleleProb and np.log10 in one pass (typing_mulit_allele.py:257-263): gk_compat's product,
+ * mapped through the value table as it is written; d_log is column-major double [allele][row].
+ * A product whose log10 is not defined yet is inserted into the table and stored as NaN: when
+ * gk_lut_pending reports n_total > n_known afterwards, export/define the new values and call again. */
+int gk_compat_log(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag,
+                  int32_t vbeg, int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele,
+                  gk_lut* lut, gk_dptr d_log);
 
 /* ---- likelihood search: AlleleTyping.addCandidate (typing_mulit_allele.py:478-598).
  * L is column-major double [n_allele][ld] (ld >= n_rows).  Reductions over rows follow

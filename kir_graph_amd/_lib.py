@@ -95,6 +95,8 @@ _SIGS = {
     "gk_lut_export": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gk_lut_define": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gk_lut_apply": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64]),
+    "gk_compat_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_int32, C.c_int32,
+                                C.c_uint64, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64]),
     "gk_maxsum": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                             C.c_void_p, C.c_int32, C.c_void_p]),
     "gk_fraction": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,

@@ -1,0 +1,79 @@
+// Device value table shared by gk_lut.hip (collect / apply passes) and the compatibility kernel
+// (direct lookup): probability bit pattern -> numpy.log10 of it, evaluated on the host.
+#pragma once
+#include "gk_common.h"
+
+struct gk_lut {
+  gk_ctx* ctx = nullptr;
+  uint32_t log2cap = 0;
+  uint64_t* d_keys = nullptr;      // slot -> bit pattern (kLutEmptyKey when free)
+  uint32_t* d_slot_idx = nullptr;  // slot -> dense index
+  uint64_t* d_list = nullptr;      // dense index -> bit pattern (insertion order)
+  double* d_vals = nullptr;        // dense index -> log10 (defined for index < n_known)
+  uint32_t* d_count = nullptr;     // number of dense entries
+  int32_t n_known = 0;             // entries with a defined value
+};
+
+// a NaN payload no product of 0.999 / 0.001 can produce
+constexpr uint64_t kLutEmptyKey = 0x7FF8DEADBEEF0001ull;
+
+struct LutView {
+  uint64_t* keys;
+  uint32_t* slot_idx;
+  uint64_t* list;
+  uint32_t* count;
+  const double* vals;
+  uint32_t mask;
+  uint32_t n_known;
+};
+
+static inline LutView gk_lut_view(const gk_lut* l) {
+  return LutView{l->d_keys, l->d_slot_idx, l->d_list, l->d_count, l->d_vals,
+                 (uint32_t)((1ull << l->log2cap) - 1), (uint32_t)l->n_known};
+}
+
+__device__ inline uint32_t gk_hash64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+// insert `k` if absent (open addressing, first writer assigns the dense index)
+__device__ inline void gk_lut_insert(const LutView& t, uint64_t k) {
+  uint32_t s = gk_hash64(k) & t.mask;
+  for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+    const uint64_t cur = t.keys[s];
+    if (cur == k) return;
+    if (cur == kLutEmptyKey) {
+      const unsigned long long prev =
+          atomicCAS((unsigned long long*)&t.keys[s], (unsigned long long)kLutEmptyKey, (unsigned long long)k);
+      if (prev == kLutEmptyKey) {
+        const uint32_t idx = atomicAdd(t.count, 1u);
+        t.slot_idx[s] = idx;
+        if (idx <= t.mask) t.list[idx] = k;
+        return;
+      }
+      if (prev == k) return;
+    }
+    s = (s + 1) & t.mask;
+  }
+}
+
+// value of `k` if its log is already defined; otherwise *found = false
+__device__ inline double gk_lut_lookup(const LutView& t, uint64_t k, bool* found) {
+  uint32_t s = gk_hash64(k) & t.mask;
+  for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+    const uint64_t cur = t.keys[s];
+    if (cur == k) {
+      const uint32_t idx = t.slot_idx[s];
+      if (idx < t.n_known) {
+        *found = true;
+        return t.vals[idx];
+      }
+      break;
+    }
+    if (cur == kLutEmptyKey) break;
+    s = (s + 1) & t.mask;
+  }
+  *found = false;
+  return __longlong_as_double(0x7FF8000000000000ll);
+}

@@ -4,29 +4,14 @@
 // handful of orders).  The device collects the distinct patterns in a hash set, the host evaluates
 // numpy.log10 on them -- so the result bits are the reference's on the same machine, whatever
 // libm / SVML numpy dispatches to -- and the device maps every element through the table.
-#include "gk_common.h"
-
-struct gk_lut {
-  gk_ctx* ctx = nullptr;
-  uint32_t log2cap = 0;
-  uint64_t* d_keys = nullptr;   // slot -> bit pattern (kEmptyKey when free)
-  uint32_t* d_slot_idx = nullptr;  // slot -> dense index
-  uint64_t* d_list = nullptr;   // dense index -> bit pattern (insertion order, racy but stable after the kernel)
-  double* d_vals = nullptr;     // dense index -> log10
-  uint32_t* d_count = nullptr;  // number of dense entries
-  int32_t n_known = 0;          // entries with a defined value
-};
+#include "gk_lut.h"
 
 namespace {
 
 constexpr int kThreads = 256;
-// 0x7FF8dead... is a NaN payload no product of 0.999 / 0.001 can produce
-constexpr uint64_t kEmptyKey = 0x7FF8DEADBEEF0001ull;
+constexpr uint64_t kEmptyKey = kLutEmptyKey;
 
-__device__ inline uint32_t hash64(uint64_t k) {
-  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-  return (uint32_t)k;
-}
+__device__ inline uint32_t hash64(uint64_t k) { return gk_hash64(k); }
 
 __global__ __launch_bounds__(kThreads) void lut_collect(const uint64_t* vals, int64_t n, uint64_t* keys,
                                                         uint32_t* slot_idx, uint64_t* list, uint32_t* count,

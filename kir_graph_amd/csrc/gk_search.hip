@@ -53,14 +53,32 @@ __device__ inline double vmax(double a, double b) {
   return r;
 }
 
+// cross-lane move inside a 16-lane row as two v_mov_b32_dpp (no LDS round trip like ds_bpermute)
+constexpr int kDppSwap1 = 0xB1;        // quad_perm:[1,0,3,2]  lane ^ 1
+constexpr int kDppSwap2 = 0x4E;        // quad_perm:[2,3,0,1]  lane ^ 2
+constexpr int kDppHalfMirror = 0x141;  // row_half_mirror      lane -> 7 - lane inside its group of 8
+constexpr int kDppShl1 = 0x101;        // row_shl:1            lane reads lane + 1
+
+template <int kCtrl>
+__device__ inline double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  // bound_ctrl: a lane whose source lies outside the row reads 0 (only row_shl's last lane, never used)
+  lo = __builtin_amdgcn_update_dpp(0, lo, kCtrl, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, kCtrl, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ inline double group_sum8(double v) {
-  // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) over the 8 lanes of a group; every lane gets the result
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
+  // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) over the 8 lanes of a group; every lane gets the result.
+  // After two steps lanes 0-3 hold the left half-sum and lanes 4-7 the right one, so the mirror
+  // partner (7 - lane) supplies the other half; a + b == b + a bit for bit.
+  v += dpp_f64<kDppSwap1>(v);
+  v += dpp_f64<kDppSwap2>(v);
+  v += dpp_f64<kDppHalfMirror>(v);
   return v;
 }
 
+template <bool kPrev>
 __global__ __launch_bounds__(kThreads, 3) void maxsum_chunks(const double* __restrict__ L, int64_t ld,
                                                           const double* __restrict__ Pbase, int64_t ldp,
                                                           const int32_t* __restrict__ pcol, int n_sets,
@@ -93,26 +111,35 @@ __global__ __launch_bounds__(kThreads, 3) void maxsum_chunks(const double* __res
   __syncthreads();
 
   const int srow = tid & (kBlockRows - 1);   // staged row of this thread
-  const int scol = tid >> 7;                 // first staged column (0/1), then +2 per step
+  const int scol = __builtin_amdgcn_readfirstlane(tid >> 7);   // first staged column (0/1), then +2 per step
   double pre_l[kLPer], pre_p[kPPer];
+  // The staged columns of a wave are wave-uniform: their base addresses live in SGPR pairs, so a
+  // prefetch is one scalar add per column and a global_load with a 32-bit lane offset -- no
+  // per-lane 64-bit address arithmetic.  Columns past the edge are clamped to a valid one and
+  // their results never stored; the previous set's likelihood is ONE column (a column of L for
+  // single-allele sets, a column of the row-wise-max buffer otherwise).
+  const double* l_base[kLPer];
+  const double* p_base[kPPer];
+#pragma unroll
+  for (int q = 0; q < kLPer; ++q) {
+    const int cidx = __builtin_amdgcn_readfirstlane(l_col[scol + 2 * q]);
+    l_base[q] = L + (int64_t)(cidx >= 0 ? cidx : 0) * ld + span.row0;
+  }
+#pragma unroll
+  for (int q = 0; q < kPPer; ++q) {
+    const int cidx = kPrev ? __builtin_amdgcn_readfirstlane(p_col[scol + 2 * q]) : 0;
+    p_base[q] = Pbase + (int64_t)(cidx >= 0 ? cidx : 0) * ldp + span.row0;
+  }
 
   auto prefetch = [&](const Leaf& lf) {
-    // rows / columns past the edge are clamped to a valid address and their values never stored
-    // as results, so every load is unconditional (no exec-masked branch per load)
-    const int64_t r = span.row0 + lf.start + (srow < lf.len ? srow : 0);
+    // rows past the end of the leaf are clamped too, so every load is unconditional
+    const uint32_t voff = (uint32_t)(srow < lf.len ? srow : 0) * (uint32_t)sizeof(double);
 #pragma unroll
-    for (int q = 0; q < kLPer; ++q) {
-      const int cidx = l_col[scol + 2 * q];
-      pre_l[q] = L[(int64_t)(cidx >= 0 ? cidx : 0) * ld + r];
-    }
-    // the previous set's likelihood is ONE column (a column of L for single-allele sets, a column
-    // of the row-wise-max buffer otherwise): plain loads that stay in flight during the reduction
+    for (int q = 0; q < kLPer; ++q)
+      pre_l[q] = *(const double*)((const char*)(l_base[q] + lf.start) + voff);
 #pragma unroll
-    for (int q = 0; q < kPPer; ++q) {
-      const int cidx = p_col[scol + 2 * q];
-      const double v = Pbase[(int64_t)(cidx >= 0 ? cidx : 0) * ldp + r];
-      pre_p[q] = cidx >= 0 ? v : -__builtin_huge_val();
-    }
+    for (int q = 0; q < kPPer; ++q)
+      pre_p[q] = kPrev ? *(const double*)((const char*)(p_base[q] + lf.start) + voff) : -__builtin_huge_val();
   };
 
   const int t_loc = (wid * 2 + gt) * TT;   // first of TT consecutive sets of this lane
@@ -224,14 +251,13 @@ __global__ __launch_bounds__(kThreads, 3) void maxsum_chunks(const double* __res
         for (int y = 0; y < TA; ++y) st[x][y] = mine ? acc[x][y] : st[x][y];
     }
     for (int k = 0; k < cur.n_add; ++k) {
-      const int s = cur.slot - k;          // slot (s-1) += slot s
-      const int src = (lane & ~7) | s;
+      const int s = cur.slot - k;          // slot (s-1) += slot s: lane s-1 reads its right neighbour
       const bool mine = (j == s - 1);
 #pragma unroll
       for (int x = 0; x < TT; ++x)
 #pragma unroll
         for (int y = 0; y < TA; ++y) {
-          const double other = __shfl(st[x][y], src, 64);
+          const double other = dpp_f64<kDppShl1>(st[x][y]);
           st[x][y] = mine ? st[x][y] + other : st[x][y];
         }
     }
@@ -508,11 +534,18 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * dp.n_spans * sizeof(double)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_out * sizeof(double)));
   const int tiles_t = (n_sets + kTileT - 1) / kTileT, tiles_a = (n_cols + kTileA - 1) / kTileA;
-  GK_PROF(ctx, GK_K_MAXSUM,
-          hipLaunchKernelGGL(maxsum_chunks, dim3((unsigned)(tiles_t * tiles_a * dp.n_spans)), dim3(kThreads),
-                             0, st, gk_ptr<double>(d_L), ld, c_prev >= 2 ? d_P : gk_ptr<double>(d_L), ld,
-                             c_prev ? dp.ids : nullptr, n_sets, dp.cols, n_cols, dp.spans, dp.leaves,
-                             tiles_t * tiles_a, d_partial));
+  const dim3 grid((unsigned)(tiles_t * tiles_a * dp.n_spans));
+  if (c_prev) {
+    GK_PROF(ctx, GK_K_MAXSUM,
+            hipLaunchKernelGGL(maxsum_chunks<true>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
+                               c_prev >= 2 ? d_P : gk_ptr<double>(d_L), ld, dp.ids, n_sets, dp.cols, n_cols, dp.spans,
+                               dp.leaves, tiles_t * tiles_a, d_partial));
+  } else {
+    GK_PROF(ctx, GK_K_MAXSUM,
+            hipLaunchKernelGGL(maxsum_chunks<false>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
+                               gk_ptr<double>(d_L), ld, (const int32_t*)nullptr, n_sets, dp.cols, n_cols, dp.spans,
+                               dp.leaves, tiles_t * tiles_a, d_partial));
+  }
   GK_PROF(ctx, GK_K_COMBINE,
           hipLaunchKernelGGL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
                              d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, 0.0, d_out));

@@ -12,6 +12,7 @@
 // order (lpv, rpv, lnv, rnv), so the double product is bit-identical to numpy's sequential
 // multiply.reduce.  Bit rows of the gene are staged in LDS when they fit.
 #include "gk_common.h"
+#include "gk_lut.h"
 
 namespace {
 
@@ -101,10 +102,17 @@ constexpr int kPassWords = kPassAlleles / 32;   // 6 bit-row words cover one pas
 // access and no LDS lookup per factor -- and multiplies 0.999 / 0.001 in the reference's order.
 // Results of a 16-row tile are transposed through LDS so that the column-major [allele][row]
 // output is written as 128-byte runs instead of one 8-byte store per (allele, row).
+//
+// kLog: the tile is mapped through the log10 value table on its way out (typing_mulit_allele.py:263),
+// so the table of log-probabilities is the only thing written.  A value whose log10 the host has not
+// evaluated yet is inserted into the table and stored as NaN; the host sees the table grow, evaluates
+// numpy.log10 for the new values and runs the kernel once more.
+template <bool kLog>
 __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, int64_t n_rows, const uint32_t* off,
                                                           const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
                                                           const uint32_t* mask, int words, int n_allele, int a_base,
-                                                          double* probs, uint8_t* miss_out, uint16_t* nvar_out) {
+                                                          double* probs, uint8_t* miss_out, uint16_t* nvar_out,
+                                                          LutView lut) {
   __shared__ double tile[kPassAlleles * kTileLd];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,9 +189,23 @@ __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, i
     __syncthreads();
     if (probs) {
       const int n_r = (int)min<int64_t>(kTileRows, n_rows - row0);
+      uint64_t last_key = kLutEmptyKey;
+      double last_val = 0.0;
       for (int idx = tid; idx < n_pass * kTileRows; idx += kThreads) {
         const int al = idx / kTileRows, r = idx % kTileRows;
-        if (r < n_r) probs[(int64_t)(a_base + al) * n_rows + row0 + r] = tile[al * kTileLd + r];
+        if (r >= n_r) continue;
+        double v = tile[al * kTileLd + r];
+        if (kLog) {
+          const uint64_t key = (uint64_t)__double_as_longlong(v);
+          if (key != last_key) {   // one read's alleles mostly share a handful of values
+            bool found;
+            last_val = gk_lut_lookup(lut, key, &found);
+            if (!found) gk_lut_insert(lut, key);
+            last_key = key;
+          }
+          v = last_val;
+        }
+        probs[(int64_t)(a_base + al) * n_rows + row0 + r] = v;
       }
     }
     __syncthreads();
@@ -324,10 +346,30 @@ int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr 
   unsigned blocks = (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
   for (int a_base = 0; a_base < n_allele; a_base += kPassAlleles) {
     GK_PROF(ctx, GK_K_COMPAT,
-            hipLaunchKernelGGL(compat_kernel, dim3(blocks), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
-                               n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend,
-                               gk_ptr<uint32_t>(d_mask), words, n_allele, a_base, gk_ptr<double>(d_probs),
-                               gk_ptr<uint8_t>(d_miss), gk_ptr<uint16_t>(d_nvar)));
+            hipLaunchKernelGGL(compat_kernel<false>, dim3(blocks), dim3(kThreads), 0, ctx->stream,
+                               gk_ptr<int32_t>(d_rows), n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg,
+                               vend, gk_ptr<uint32_t>(d_mask), words, n_allele, a_base, gk_ptr<double>(d_probs),
+                               gk_ptr<uint8_t>(d_miss), gk_ptr<uint16_t>(d_nvar), LutView{}));
+  }
+  GK_HIP(hipGetLastError());
+  return GK_OK;
+}
+
+int gk_compat_log(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg,
+                  int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, gk_lut* lut, gk_dptr d_log) {
+  GK_REQUIRE(ctx && tab && lut && lut->ctx == ctx, "null pointer or value table of another context");
+  GK_REQUIRE(words >= 1 && n_allele >= 0 && n_allele <= words * 32 && vend >= vbeg, "bad mask geometry");
+  if (n_rows == 0 || n_allele == 0) return GK_OK;
+  GK_REQUIRE(d_log, "null output");
+  int64_t want = (n_rows + kTileRows - 1) / kTileRows;
+  unsigned blocks = (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
+  const LutView view = gk_lut_view(lut);
+  for (int a_base = 0; a_base < n_allele; a_base += kPassAlleles) {
+    GK_PROF(ctx, GK_K_COMPAT,
+            hipLaunchKernelGGL(compat_kernel<true>, dim3(blocks), dim3(kThreads), 0, ctx->stream,
+                               gk_ptr<int32_t>(d_rows), n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg,
+                               vend, gk_ptr<uint32_t>(d_mask), words, n_allele, a_base, gk_ptr<double>(d_log),
+                               (uint8_t*)nullptr, (uint16_t*)nullptr, view));
   }
   GK_HIP(hipGetLastError());
   return GK_OK;

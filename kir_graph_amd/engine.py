@@ -249,6 +249,7 @@ class LogTable:
         check(lib().gk_lut_create(dev.ctx, log2_capacity, C.byref(h)))
         self.handle = h
         self.n_host_evals = 0
+        self.n_known = 0          # values with a defined log10 (== the library's count)
 
     def collect(self, buf: DeviceBuffer, n: int) -> None:
         check(lib().gk_lut_collect(self.handle, buf.ptr, n))
@@ -265,6 +266,7 @@ class LogTable:
                 vals = np.log10(keys)
             check(lib().gk_lut_define(self.handle, known.value, new, vals.ctypes.data))
             self.n_host_evals += new
+            self.n_known = tot.value
         return max(new, 0)
 
     def apply(self, src: DeviceBuffer, dst: DeviceBuffer, n: int) -> None:
@@ -285,25 +287,51 @@ class DeviceModel:
         self.tab, self.dev = tab, tab.dev
         self.rows, self.n_rows, self.n_allele = rows, n_rows, n_allele
         self.vflag = vflag
-        self.probs = self.L = self.miss = self.nvar = None
+        self.L = self.miss = self.nvar = None
+        self._probs = None
+        self._logs = logs
+        self._geom = (vbeg, vend, mask, words)
+        self._want_miss = want_miss
+        self._known_at_launch = -1
         if n_rows == 0 or n_allele == 0:
             return
-        self.probs = self.dev.alloc((n_allele, n_rows), np.float64)
+        self.L = self.dev.alloc((n_allele, n_rows), np.float64)
+        self._launchLog()
         if want_miss:
-            self.miss = self.dev.alloc((n_allele, n_rows), np.uint8)
-            self.nvar = self.dev.alloc(n_rows, np.uint16)
-        check(lib().gk_compat(self.dev.ctx, tab.handle, rows.ptr, n_rows, vflag.ptr, vbeg, vend, mask.ptr, words,
-                              n_allele, self.probs.ptr, self.miss.ptr if self.miss else 0,
+            self._launchProbs()
+
+    def _launchLog(self) -> None:
+        vbeg, vend, mask, words = self._geom
+        self._known_at_launch = self._logs.n_known
+        check(lib().gk_compat_log(self.dev.ctx, self.tab.handle, self.rows.ptr, self.n_rows, self.vflag.ptr, vbeg, vend,
+                                  mask.ptr, words, self.n_allele, self._logs.handle, self.L.ptr))
+
+    def _launchProbs(self) -> None:
+        """The un-logged products (and the mismatch counts): only built when somebody asks for them."""
+        vbeg, vend, mask, words = self._geom
+        self._probs = self.dev.alloc((self.n_allele, self.n_rows), np.float64)
+        if self._want_miss:
+            self.miss = self.dev.alloc((self.n_allele, self.n_rows), np.uint8)
+            self.nvar = self.dev.alloc(self.n_rows, np.uint16)
+        check(lib().gk_compat(self.dev.ctx, self.tab.handle, self.rows.ptr, self.n_rows, self.vflag.ptr, vbeg, vend,
+                              mask.ptr, words, self.n_allele, self._probs.ptr, self.miss.ptr if self.miss else 0,
                               self.nvar.ptr if self.nvar else 0))
-        logs.collect(self.probs, n_allele * n_rows)
-        self._logs = logs
+
+    @property
+    def probs(self) -> DeviceBuffer | None:
+        if self._probs is None and self.L is not None:
+            self._launchProbs()
+        return self._probs
 
     def finishLog(self) -> None:
-        """Second half of construction, after ``LogTable.resolve()``."""
-        if self.probs is None or self.L is not None:
+        """Second half of construction: if the kernel met products whose log10 the table did not
+        hold yet, the host evaluates them (numpy.log10) and the table is written once more."""
+        if self.L is None or self._known_at_launch < 0:
             return
-        self.L = self.dev.alloc((self.n_allele, self.n_rows), np.float64)
-        self._logs.apply(self.probs, self.L, self.n_allele * self.n_rows)
+        self._logs.resolve()
+        if self._logs.n_known > self._known_at_launch:
+            self._launchLog()
+        self._known_at_launch = -1
 
     # ---- reductions (numpy summation tree on the device)
     def maxsum(self, prev_ids: np.ndarray | None, cols: np.ndarray) -> np.ndarray:
@@ -343,12 +371,12 @@ class DeviceModel:
         return out
 
     def hostProbs(self) -> np.ndarray:
-        return self.probs.download().reshape(self.n_allele, self.n_rows).T if self.probs else np.array([])
+        return self.probs.download().reshape(self.n_allele, self.n_rows).T if self.L else np.array([])
 
     def hostLogProbs(self) -> np.ndarray:
         return self.L.download().reshape(self.n_allele, self.n_rows).T if self.L else np.array([])
 
     def free(self) -> None:
-        for b in (self.probs, self.L, self.miss, self.nvar):
+        for b in (self._probs, self.L, self.miss, self.nvar):
             if b is not None:
                 b.free()
