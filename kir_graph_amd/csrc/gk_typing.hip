@@ -11,6 +11,8 @@
 // allele bit in the variant's bit row and multiplies 0.999 / 0.001 in the reference's factor
 // order (lpv, rpv, lnv, rnv), so the double product is bit-identical to numpy's sequential
 // multiply.reduce.  Bit rows of the gene are staged in LDS when they fit.
+#include <algorithm>
+
 #include "gk_common.h"
 #include "gk_lut.h"
 
@@ -87,17 +89,15 @@ __global__ __launch_bounds__(kThreads) void flag_nonempty(const int32_t* rows, i
   flag[i] = alive;
 }
 
-constexpr int kSlots = 3;   // alleles per lane and pass: 192 alleles per pass
+constexpr int kMaxSlots = 4;   // alleles per lane and pass: up to 256 alleles per pass
 constexpr int kWavesPerBlock = 4;
 constexpr int kTileRows = 16;            // rows per output tile (4 per wave)
 constexpr int kTileLd = kTileRows + 1;   // padded LDS stride (doubles) of the transposed tile
-constexpr int kPassAlleles = 64 * kSlots;
 
-constexpr int kPassWords = kPassAlleles / 32;   // 6 bit-row words cover one pass
-
-// One wavefront per read pair, lanes = alleles (3 allele slots per lane).  Per chunk of 64 variant
-// ordinals, lane k loads ordinal k, its drop flag and the 6 bit-row words of that variant that this
-// pass needs (windows are runs of consecutive ordinals, so these are coalesced row reads of the
+// One wavefront per read pair, lanes = alleles (kSlots allele slots per lane; a gene of <= 256
+// alleles is one pass, and the last pass of a wider gene only carries the slots it needs).  Per chunk
+// of 64 variant ordinals, lane k loads ordinal k, its drop flag and the 2*kSlots bit-row words of
+// that variant that this pass needs (windows are runs of consecutive ordinals, so these are coalesced row reads of the
 // L2-resident bit matrix).  The factor loop then only uses v_readlane broadcasts -- no memory
 // access and no LDS lookup per factor -- and multiplies 0.999 / 0.001 in the reference's order.
 // Results of a 16-row tile are transposed through LDS so that the column-major [allele][row]
@@ -107,17 +107,19 @@ constexpr int kPassWords = kPassAlleles / 32;   // 6 bit-row words cover one pas
 // so the table of log-probabilities is the only thing written.  A value whose log10 the host has not
 // evaluated yet is inserted into the table and stored as NaN; the host sees the table grow, evaluates
 // numpy.log10 for the new values and runs the kernel once more.
-template <bool kLog>
+template <bool kLog, int kSlots>
 __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, int64_t n_rows, const uint32_t* off,
                                                           const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
                                                           const uint32_t* mask, int words, int n_allele, int a_base,
                                                           double* probs, uint8_t* miss_out, uint16_t* nvar_out,
                                                           LutView lut) {
+  constexpr int kPassAlleles = 64 * kSlots;
+  constexpr int kPassWords = 2 * kSlots;   // bit-row words covering one pass
   __shared__ double tile[kPassAlleles * kTileLd];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool upper = lane >= 32;
-  const int w_base = a_base >> 5;   // a_base is a multiple of 192 = 6 words
+  const int w_base = a_base >> 5;   // a_base is a multiple of 256 = 8 words
 
   int a[kSlots];
   bool live[kSlots];
@@ -210,6 +212,30 @@ __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, i
     }
     __syncthreads();
   }
+}
+
+template <bool kLog>
+int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int vbeg, int vend,
+                  gk_dptr d_mask, int words, int n_allele, double* out, uint8_t* miss, uint16_t* nvar, LutView view) {
+  int64_t want = (n_rows + kTileRows - 1) / kTileRows;
+  const dim3 grid((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048)), block(kThreads);
+  for (int a_base = 0; a_base < n_allele; a_base += 64 * kMaxSlots) {
+    const int slots = std::min(kMaxSlots, (n_allele - a_base + 63) / 64);
+#define GK_COMPAT_LAUNCH(S)                                                                                        \
+  GK_PROF(ctx, GK_K_COMPAT,                                                                                        \
+          hipLaunchKernelGGL((compat_kernel<kLog, S>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows, \
+                             tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, gk_ptr<uint32_t>(d_mask),  \
+                             words, n_allele, a_base, out, miss, nvar, view))
+    switch (slots) {
+      case 1: GK_COMPAT_LAUNCH(1); break;
+      case 2: GK_COMPAT_LAUNCH(2); break;
+      case 3: GK_COMPAT_LAUNCH(3); break;
+      default: GK_COMPAT_LAUNCH(4); break;
+    }
+#undef GK_COMPAT_LAUNCH
+  }
+  GK_HIP(hipGetLastError());
+  return GK_OK;
 }
 
 }  // namespace
@@ -342,17 +368,8 @@ int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr 
   GK_REQUIRE(ctx && tab, "null pointer");
   GK_REQUIRE(words >= 1 && n_allele >= 0 && n_allele <= words * 32 && vend >= vbeg, "bad mask geometry");
   if (n_rows == 0 || n_allele == 0) return GK_OK;
-  int64_t want = (n_rows + kTileRows - 1) / kTileRows;
-  unsigned blocks = (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
-  for (int a_base = 0; a_base < n_allele; a_base += kPassAlleles) {
-    GK_PROF(ctx, GK_K_COMPAT,
-            hipLaunchKernelGGL(compat_kernel<false>, dim3(blocks), dim3(kThreads), 0, ctx->stream,
-                               gk_ptr<int32_t>(d_rows), n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg,
-                               vend, gk_ptr<uint32_t>(d_mask), words, n_allele, a_base, gk_ptr<double>(d_probs),
-                               gk_ptr<uint8_t>(d_miss), gk_ptr<uint16_t>(d_nvar), LutView{}));
-  }
-  GK_HIP(hipGetLastError());
-  return GK_OK;
+  return launch_compat<false>(ctx, tab, d_rows, n_rows, d_vflag, vbeg, vend, d_mask, words, n_allele,
+                              gk_ptr<double>(d_probs), gk_ptr<uint8_t>(d_miss), gk_ptr<uint16_t>(d_nvar), LutView{});
 }
 
 int gk_compat_log(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg,
@@ -361,18 +378,8 @@ int gk_compat_log(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
   GK_REQUIRE(words >= 1 && n_allele >= 0 && n_allele <= words * 32 && vend >= vbeg, "bad mask geometry");
   if (n_rows == 0 || n_allele == 0) return GK_OK;
   GK_REQUIRE(d_log, "null output");
-  int64_t want = (n_rows + kTileRows - 1) / kTileRows;
-  unsigned blocks = (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
-  const LutView view = gk_lut_view(lut);
-  for (int a_base = 0; a_base < n_allele; a_base += kPassAlleles) {
-    GK_PROF(ctx, GK_K_COMPAT,
-            hipLaunchKernelGGL(compat_kernel<true>, dim3(blocks), dim3(kThreads), 0, ctx->stream,
-                               gk_ptr<int32_t>(d_rows), n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg,
-                               vend, gk_ptr<uint32_t>(d_mask), words, n_allele, a_base, gk_ptr<double>(d_log),
-                               (uint8_t*)nullptr, (uint16_t*)nullptr, view));
-  }
-  GK_HIP(hipGetLastError());
-  return GK_OK;
+  return launch_compat<true>(ctx, tab, d_rows, n_rows, d_vflag, vbeg, vend, d_mask, words, n_allele,
+                             gk_ptr<double>(d_log), nullptr, nullptr, gk_lut_view(lut));
 }
 
 }  // extern "C"

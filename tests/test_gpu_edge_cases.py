@@ -92,3 +92,24 @@ def test_gene_without_reads_fails_softly(device, one_gene):
     res = gpu.typing(2)
     assert res.isFail() and res.selectBest() == ["fail", "fail"]
     assert gpu.getReadsNum() == 0
+
+
+@pytest.mark.parametrize("n_allele", [64, 65, 130, 200, 256, 257, 330])
+def test_wide_genes_cover_every_allele_slot_layout(device, n_allele):
+    """Allele counts around the 64-lane slot / 256-allele pass boundaries of the compatibility kernel and
+    the 16 / 32 wide tiles of the search kernel."""
+    sidx = synth.makeIndex(seed=400 + n_allele, n_genes=1, var_range=(250, 300), allele_range=(n_allele, n_allele),
+                           len_range=(5000, 6000))
+    g = sidx.genes[0]
+    sample = synth.makeSample(sidx, seed=6, n_pairs=700, gene_cn={g: 2}, frac_multi=0.0)
+    data = ot.tabulateLines(synth.toSamLines(sample), sidx.variants)
+    variants, reads = data["variants"], data["reads"]
+    cpu = oty.GeneModel(copy.deepcopy(reads), variants, force_homo=False, top_n=40, variant_correction=True)
+    gpu = AlleleTyping(to_pairs(reads), variants, force_homo=False, top_n=40, variant_correction=True, device=device)
+    assert len(gpu.id_to_allele) == n_allele
+    assert np.array_equal(gpu.probs, cpu.probs)
+    assert np.array_equal(gpu.log_probs, cpu.log_probs)
+    want, got = cpu.typing(3), gpu.typing(3)
+    for a, b in zip(gpu.result, cpu.result):
+        same(a, b)
+    assert got.selectBest() == oty.selectBest(want)
