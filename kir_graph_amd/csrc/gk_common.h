@@ -81,6 +81,8 @@ struct gk_index {
   gk_ctx* ctx = nullptr;
   uint64_t* d_key = nullptr;
   int32_t* d_gene_vbeg = nullptr;
+  int32_t* d_bucket = nullptr;      // 16-bp position buckets into d_key, all genes back to back
+  int32_t* d_gene_boff = nullptr;   // [n_gene + 1] first bucket of each gene
   int32_t n_var = 0, n_gene = 0;
   std::vector<int32_t> gene_vbeg;
 };

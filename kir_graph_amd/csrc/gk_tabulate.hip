@@ -8,13 +8,20 @@
 //   getPNFromVariantList  hisat2.py:716-800   (positives, negatives, novel-indel drop, N exclusion, deletion edge rule)
 //   extractVariant        hisat2.py:803-844   (pair assembly, NH, backbone)
 //
-// Data layout (HBM): mates are 64-byte records, two per pair, read once per pass with 16-byte
-// vector loads; the sorted variant key table (<= ~0.5 MB) stays L2/MALL resident; outputs are one
-// CSR (uint32 offsets, uint32 ordinals) in the factor order lpv, rpv, lnv, rnv.
+// Data layout (HBM): mates are 128-byte records, two per pair.  A workgroup stages its 256 records
+// (32 KB contiguous) into LDS with coalesced 16-byte loads; every lane then walks its own record out
+// of LDS (stride 33 dwords: conflict-free, and the CIGAR / mismatch cursors index it dynamically
+// without private memory).  The sorted variant key table (<= ~0.5 MB) stays L2 resident and is
+// entered through a 16-bp bucket table, so a lookup is two bucket reads plus a <= 3-step bisection
+// instead of a 16-step one.  Outputs are one CSR (uint32 offsets, uint32 ordinals) in the factor
+// order lpv, rpv, lnv, rnv.
 //
 // Two passes (count, emit) around one exclusive scan; novel variants are deduplicated in a device
 // hash table keyed by the packed variant key, ranked by first appearance through a bitmap over
 // (mate, event) sequence numbers, so that the numbering equals the reference's sequential counter.
+#include <algorithm>
+#include <vector>
+
 #include "gk_common.h"
 
 namespace {
@@ -23,109 +30,73 @@ constexpr int kThreads = 256;
 constexpr int kMaxEv = GK_MAX_EVENTS;
 constexpr uint64_t kEmpty = ~0ull;
 
-struct Events {
-  int n;
-  uint64_t key[kMaxEv];   // position / type / value of every non-match event (private memory)
-  uint32_t last_len;      // walker length of the last event: 1 single, k insertion / deletion
-  bool clipped;
-  bool overflow;
-  bool last_is_event;     // last walk element is events[n-1]; otherwise a match ending at ref_end
-  uint32_t ref_end;
-};
-
-__device__ inline uint4 load16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
-
 constexpr int kMateWords = sizeof(gk_mate) / 4;   // 32
 constexpr int kCigWord = 3;                         // uint16 cig[] starts at byte 12
 constexpr int kMmWord = kCigWord + GK_MAX_CIG / 2;  // 10
 constexpr int kInsWord = kMmWord + GK_MAX_MM;       // 26
 static_assert(sizeof(gk_mate) == 128 && kInsWord + GK_MAX_INS == kMateWords, "gk_mate layout");
+constexpr int kRecLd = kMateWords + 1;   // LDS stride of a staged record (dwords)
+constexpr int kEvLd = kMaxEv + 1;        // LDS stride of a lane's event words (odd: conflict-free)
 
-struct MateRegs {
-  uint32_t w[kMateWords];
+// event word: what the negative filter needs to know about one non-match event of the mate
+constexpr uint32_t kEvNovel = 1u << 31;   // not an index variant; low 24 bits = position
+constexpr uint32_t kEvIsN = 1u << 30;     // substitution to 'N'
+constexpr uint32_t kEvOrdMask = (1u << 26) - 1;
+
+// a staged record, read out of LDS
+struct MateView {
+  const uint32_t* w;
   __device__ uint32_t pos0() const { return w[0]; }
   __device__ uint32_t flag() const { return w[1] & 0xFFFFu; }
   __device__ uint32_t ref() const { return (w[1] >> 16) & 0xFFu; }
-  __device__ uint32_t nh() const { return w[1] >> 24; }
   __device__ uint32_t nm() const { return w[2] & 0xFFu; }
   __device__ uint32_t n_cig() const { return (w[2] >> 8) & 0xFFu; }
   __device__ uint32_t n_mm() const { return (w[2] >> 16) & 0xFFu; }
-  __device__ uint32_t n_ins() const { return w[2] >> 24; }
   __device__ uint32_t cig(int i) const {  // uint16 array starting at byte 12
-    uint32_t word = w[kCigWord + (i >> 1)];
+    const uint32_t word = w[kCigWord + (i >> 1)];
     return (i & 1) ? (word >> 16) : (word & 0xFFFFu);
   }
   __device__ uint32_t mm_off(int i) const { return w[kMmWord + i] & 0xFFFFu; }
   __device__ uint32_t mm_base(int i) const { return (w[kMmWord + i] >> 16) & 0xFFu; }
   __device__ uint32_t ins(int i) const { return w[kInsWord + i]; }
+  __device__ bool passes() const { return (flag() & 2u) && nm() != GK_NM_ABSENT && nm() <= 4u; }
 };
 
-__device__ inline void load_mate(const gk_mate* mates, int64_t m, MateRegs& r) {
-  const uint4* p = reinterpret_cast<const uint4*>(mates + m);
+// the workgroup's records [m0, m0 + 256) -> LDS, coalesced
+__device__ inline void stage_mates(const gk_mate* mates, int64_t m0, int64_t n_mates, uint32_t* rec) {
+  const uint4* src = reinterpret_cast<const uint4*>(mates + m0);
+  const int n_vec = (int)min<int64_t>(kThreads, n_mates - m0) * (kMateWords / 4);
 #pragma unroll
   for (int k = 0; k < kMateWords / 4; ++k) {
-    uint4 v = p[k];
-    r.w[4 * k + 0] = v.x; r.w[4 * k + 1] = v.y; r.w[4 * k + 2] = v.z; r.w[4 * k + 3] = v.w;
-  }
-}
-
-__device__ inline bool mate_passes(const MateRegs& r) {
-  return (r.flag() & 2u) && r.nm() != GK_NM_ABSENT && r.nm() <= 4u;
-}
-
-__device__ inline void push_event(Events& ev, uint32_t pos, uint32_t len, uint64_t key) {
-  (void)pos;
-  if (ev.n < kMaxEv) {
-    ev.key[ev.n] = key;
-    ev.last_len = len;
-    ev.n++;
-  } else {
-    ev.overflow = true;
-  }
-  ev.last_is_event = true;
-}
-
-// CIGAR x mismatch co-walk (recordToRawVariant): only non-match events are stored; the match
-// segments matter solely through the left edge (pos0) and the right edge (ref_end / last event).
-__device__ inline void walk(const MateRegs& r, Events& ev) {
-  ev.n = 0; ev.clipped = false; ev.overflow = false; ev.last_is_event = false;
-  uint32_t cur = r.pos0();
-  const uint32_t ref = r.ref();
-  int mi = 0, ii = 0;
-  const int n_mm = min((int)r.n_mm(), GK_MAX_MM), n_cig = min((int)r.n_cig(), GK_MAX_CIG);
-  for (int c = 0; c < n_cig; ++c) {
-    const uint32_t cg = r.cig(c);
-    const uint32_t op = cg & 15u, len = cg >> 4;
-    if (op == GK_CIG_S) {
-      ev.clipped = true;
-    } else if (op == GK_CIG_M) {
-      const uint32_t end = cur + len;
-      uint32_t seg = cur;
-      while (mi < n_mm && r.pos0() + r.mm_off(mi) < end) {
-        const uint32_t p = r.pos0() + r.mm_off(mi);
-        push_event(ev, p, 1u, gk_make_key(ref, p, GK_TYP_SINGLE, r.mm_base(mi)));
-        seg = p + 1;
-        ++mi;
-      }
-      if (seg < end) ev.last_is_event = false;  // trailing match segment
-      cur = end;
-    } else if (op == GK_CIG_I) {
-      const uint32_t sid = ii < GK_MAX_INS ? r.ins(ii) : 0u;
-      push_event(ev, cur, len, gk_make_key(ref, cur, GK_TYP_INS, sid));
-      ++ii;
-    } else if (op == GK_CIG_D) {
-      push_event(ev, cur, len, gk_make_key(ref, cur, GK_TYP_DEL, len));
-      cur += len;
+    const int idx = threadIdx.x + kThreads * k;
+    if (idx < n_vec) {
+      const uint4 v = src[idx];
+      uint32_t* d = rec + (idx >> 3) * kRecLd + (idx & 7) * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
   }
-  ev.ref_end = cur;
+  __syncthreads();
 }
 
-__device__ inline int lower_bound_key(const uint64_t* key, int n, uint64_t k) {
-  int lo = 0, hi = n;
+struct IndexView {
+  const uint64_t* key;
+  const int32_t* bucket;      // per gene: lower bound of (gene, 16 * b) for b = 0 .. n_bucket(gene) - 1
+  const int32_t* gene_boff;   // [n_gene + 1] first bucket of each gene
+  int n_var, n_gene;
+};
+
+// first ordinal whose key is >= k, where k = (ref, pos, ...)
+__device__ inline int lower_bound_key(const IndexView& ix, uint32_t ref, uint32_t pos, uint64_t k) {
+  int lo = 0, hi = ix.n_var;
+  if ((int)ref < ix.n_gene) {
+    const int b0 = ix.gene_boff[ref], last = ix.gene_boff[ref + 1] - b0 - 1;
+    const int b = min((int)(pos >> 4), last);
+    lo = ix.bucket[b0 + b];
+    hi = ix.bucket[b0 + min(b + 1, last)];
+  }
   while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (key[mid] < k) lo = mid + 1; else hi = mid;
+    const int mid = (lo + hi) >> 1;
+    if (ix.key[mid] < k) lo = mid + 1; else hi = mid;
   }
   return lo;
 }
@@ -137,7 +108,7 @@ __device__ inline uint32_t hash64(uint64_t k) {
 
 struct NovelTable {
   uint64_t* keys;   // kEmpty when free
-  uint32_t* seq;    // min (mate*4 + event) over insertions
+  uint32_t* seq;    // min (mate * kMaxEv + event) over insertions
   uint32_t* rank;   // first-appearance rank (filled by rank kernel)
   uint32_t mask;
 };
@@ -166,59 +137,113 @@ __device__ inline uint32_t novel_rank(const NovelTable& t, uint64_t key) {
   return 0xFFFFFFFFu;
 }
 
-struct Resolved {
-  int32_t ord[kMaxEv];   // >= 0 index ordinal, -1 novel
-  bool drop;             // novel insertion / deletion present -> mate yields ([], [])
-  uint32_t right;
-  int lo, hi;
-  bool bad_window;
+// One mate: the CIGAR x mismatch co-walk (recordToRawVariant), with every non-match event resolved
+// against the index as it is produced (findVariantId); only an event word per event is kept (LDS).
+// The match segments matter solely through the left edge (pos0) and the right edge.
+struct Walked {
+  int n;                 // events
+  bool clipped, overflow, drop, bad_window;
+  uint32_t right;        // right edge of the variant window
+  uint32_t any_n;        // some event is a substitution to 'N'
+  int lo, hi;            // ordinals of the window [lo, hi)
 };
 
-__device__ inline void resolve(const Events& ev, const MateRegs& r, const uint64_t* key, int n_var, Resolved& rs) {
-  rs.drop = false;
-  for (int e = 0; e < ev.n; ++e) {
-    int i = lower_bound_key(key, n_var, ev.key[e]);
-    if (i < n_var && key[i] == ev.key[e]) {
-      rs.ord[e] = i;
-    } else {
-      rs.ord[e] = -1;
-      if (gk_key_typ(ev.key[e]) != GK_TYP_SINGLE) rs.drop = true;
+template <bool kEmit>
+__device__ inline void walk_mate(const MateView& r, const IndexView& ix, const NovelTable& nt, int64_t m,
+                                 uint32_t* evw, uint32_t* ids, uint32_t o_pos, uint32_t o_pos_end, Walked& wk) {
+  wk.n = 0; wk.clipped = false; wk.overflow = false; wk.drop = false; wk.any_n = 0; wk.bad_window = false;
+  wk.lo = wk.hi = 0; wk.right = 0;
+  const int n_cig = min((int)r.n_cig(), GK_MAX_CIG);
+  // a soft-clipped read yields no variants at all and registers no novel ones (hisat2.py:681-684: returned before findVariantId)
+  for (int c = 0; c < n_cig; ++c) wk.clipped |= (r.cig(c) & 15u) == GK_CIG_S;
+  if (wk.clipped) return;
+  bool last_is_event = false, last_novel = false;
+  uint32_t last_pos = 0, last_len = 0;
+  const uint32_t ref = r.ref(), pos0 = r.pos0();
+  uint32_t cur = pos0;
+  int mi = 0, ii = 0;
+  const int n_mm = min((int)r.n_mm(), GK_MAX_MM);
+
+  auto event = [&](uint32_t pos, uint32_t len, uint32_t typ, uint32_t val) {
+    last_is_event = true;
+    if (wk.n >= kMaxEv) { wk.overflow = true; return; }
+    const uint64_t k = gk_make_key(ref, pos, typ, val);
+    const int i = lower_bound_key(ix, ref, pos, k);
+    const bool known = i < ix.n_var && ix.key[i] == k;
+    const bool is_n = typ == GK_TYP_SINGLE && val == 'N';
+    if (is_n) wk.any_n = 1;
+    evw[wk.n] = (known ? (uint32_t)i : (kEvNovel | (pos & 0xFFFFFFu))) | (is_n ? kEvIsN : 0u);
+    if (!known && typ != GK_TYP_SINGLE) wk.drop = true;   // novel insertion / deletion: mate yields ([], [])
+    if (kEmit) {
+      if (o_pos + wk.n < o_pos_end)
+        ids[o_pos + wk.n] = known ? (uint32_t)i : (uint32_t)ix.n_var + novel_rank(nt, k);
+    } else if (!known) {
+      novel_insert(nt, k, (uint32_t)(m * kMaxEv + wk.n));
+    }
+    last_pos = pos; last_len = len; last_novel = !known;
+    wk.n++;
+  };
+
+  for (int c = 0; c < n_cig; ++c) {
+    const uint32_t cg = r.cig(c);
+    const uint32_t op = cg & 15u, len = cg >> 4;
+    if (op == GK_CIG_M) {
+      const uint32_t end = cur + len;
+      uint32_t seg = cur;
+      while (mi < n_mm && pos0 + r.mm_off(mi) < end) {
+        const uint32_t p = pos0 + r.mm_off(mi);
+        event(p, 1u, GK_TYP_SINGLE, r.mm_base(mi));
+        seg = p + 1;
+        ++mi;
+      }
+      if (seg < end) last_is_event = false;  // trailing match segment
+      cur = end;
+    } else if (op == GK_CIG_I) {
+      event(cur, len, GK_TYP_INS, ii < GK_MAX_INS ? r.ins(ii) : 0u);
+      ++ii;
+    } else if (op == GK_CIG_D) {
+      event(cur, len, GK_TYP_DEL, len);
+      cur += len;
     }
   }
-  if (ev.last_is_event && ev.n > 0) {
-    const int e = ev.n - 1;
-    rs.right = gk_key_pos(ev.key[e]) + (rs.ord[e] >= 0 ? 0u : ev.last_len);  // index records carry length 0
-  } else {
-    rs.right = ev.ref_end;
-  }
-  const uint32_t ref = r.ref();
-  rs.lo = lower_bound_key(key, n_var, gk_make_key(ref, r.pos0(), GK_TYP_SINGLE, 'A'));
-  rs.hi = lower_bound_key(key, n_var, gk_make_key(ref, rs.right, GK_TYP_SINGLE, 'T'));
-  rs.bad_window = rs.lo > rs.hi;
+  // index records carry length 0, novel ones their walker length
+  wk.right = (last_is_event && wk.n > 0) ? last_pos + (last_novel ? last_len : 0u) : cur;
+  // getVariantsBoundary: [single 'A' at the left edge, single 'T' at the right edge)
+  wk.lo = lower_bound_key(ix, ref, pos0, gk_make_key(ref, pos0, GK_TYP_SINGLE, 'A'));
+  wk.hi = lower_bound_key(ix, ref, wk.right, gk_make_key(ref, wk.right, GK_TYP_SINGLE, 'T'));
+  wk.bad_window = wk.lo > wk.hi;
 }
 
-__device__ inline bool negative_kept(uint64_t k, int i, const Events& ev, const Resolved& rs) {
+__device__ inline bool negative_kept(uint64_t k, int i, const IndexView& ix, const uint32_t* evw, const Walked& wk) {
   const uint32_t typ = gk_key_typ(k), pos = gk_key_pos(k), val = gk_key_val(k);
-  for (int e = 0; e < ev.n; ++e) {
-    if (rs.ord[e] == i) return false;
-    if (gk_key_typ(ev.key[e]) == GK_TYP_SINGLE && gk_key_val(ev.key[e]) == 'N' && typ == GK_TYP_SINGLE &&
-        pos == gk_key_pos(ev.key[e]) && (val == 'A' || val == 'C' || val == 'G' || val == 'T'))
-      return false;
+  for (int e = 0; e < wk.n; ++e)
+    if ((evw[e] & ~kEvIsN) == (uint32_t)i) return false;   // a positive of this mate
+  if (wk.any_n && typ == GK_TYP_SINGLE && (val == 'A' || val == 'C' || val == 'G' || val == 'T')) {
+    for (int e = 0; e < wk.n; ++e) {
+      const uint32_t w = evw[e];
+      if (!(w & kEvIsN)) continue;
+      const uint32_t p = (w & kEvNovel) ? (w & 0xFFFFFFu) : gk_key_pos(ix.key[w & kEvOrdMask]);
+      if (p == pos) return false;                           // the read says N here
+    }
   }
-  if (typ == GK_TYP_DEL && pos + val + 10u >= rs.right) return false;
+  if (typ == GK_TYP_DEL && pos + val + 10u >= wk.right) return false;
   return true;
 }
 
-// pass 1: validity, counts, novel registration.  One thread per mate; mates of a pair sit in
+// pass 1: validity, counts, novel registration.  One lane per mate; mates of a pair sit in
 // adjacent lanes so the pair verdict is one lane shuffle.
-__global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int64_t n_mates, const uint64_t* key,
-                                                      int n_var, NovelTable nt, uint32_t* cnt /*[4*n_pairs+1]*/,
+__global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int64_t n_mates, IndexView ix,
+                                                      NovelTable nt, uint32_t* cnt /*[4*n_pairs+1]*/,
                                                       uint32_t* valid /*[n_pairs]*/, int* err_flags) {
-  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  __shared__ uint32_t rec[kThreads * kRecLd];
+  __shared__ uint32_t evs[kThreads * kEvLd];
+  const int64_t m0 = (int64_t)blockIdx.x * kThreads;
+  stage_mates(mates, m0, n_mates, rec);
+  const int64_t m = m0 + threadIdx.x;
   const bool in = m < n_mates;
-  MateRegs r;
-  if (in) load_mate(mates, m, r); else { for (int k = 0; k < kMateWords; ++k) r.w[k] = 0; }
-  const bool ok = in && mate_passes(r);
+  const MateView r{rec + threadIdx.x * kRecLd};
+  uint32_t* evw = evs + threadIdx.x * kEvLd;
+  const bool ok = in && r.passes();
   const bool ok_other = __shfl_xor((int)ok, 1, 64) != 0;
   const bool pair_ok = ok && ok_other;
   if (!in) return;
@@ -226,20 +251,15 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
   const int side = (int)(m & 1);
   uint32_t n_pos = 0, n_neg = 0;
   if (pair_ok) {
-    Events ev;
-    walk(r, ev);
-    if (ev.overflow) atomicOr(err_flags, 2);
-    if (!ev.clipped) {
-      Resolved rs;
-      resolve(ev, r, key, n_var, rs);
-      for (int e = 0; e < ev.n; ++e)
-        if (rs.ord[e] < 0) novel_insert(nt, ev.key[e], (uint32_t)(m * kMaxEv + e));
-      if (rs.bad_window) {
-        atomicOr(err_flags, 1);
-      } else if (!rs.drop) {
-        n_pos = ev.n;
-        for (int i = rs.lo; i < rs.hi; ++i) n_neg += negative_kept(key[i], i, ev, rs) ? 1u : 0u;
-      }
+    Walked wk;
+    walk_mate<false>(r, ix, nt, m, evw, nullptr, 0, 0, wk);
+    if (wk.overflow) atomicOr(err_flags, 2);
+    if (wk.clipped) {
+    } else if (wk.bad_window) {
+      atomicOr(err_flags, 1);
+    } else if (!wk.drop) {
+      n_pos = wk.n;
+      for (int i = wk.lo; i < wk.hi; ++i) n_neg += negative_kept(ix.key[i], i, ix, evw, wk) ? 1u : 0u;
     }
   }
   cnt[4 * pair + side] = n_pos;
@@ -269,10 +289,14 @@ __global__ void novel_assign(NovelTable nt, const uint32_t* bitmap, const uint32
 }
 
 // pass 2: emit ordinals at the scanned offsets
-__global__ __launch_bounds__(kThreads) void tab_emit(const gk_mate* mates, int64_t n_mates, const uint64_t* key,
-                                                     int n_var, NovelTable nt, const uint32_t* off,
-                                                     const uint32_t* valid, uint32_t* ids) {
-  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+__global__ __launch_bounds__(kThreads) void tab_emit(const gk_mate* mates, int64_t n_mates, IndexView ix,
+                                                     NovelTable nt, const uint32_t* off, const uint32_t* valid,
+                                                     uint32_t* ids) {
+  __shared__ uint32_t rec[kThreads * kRecLd];
+  __shared__ uint32_t evs[kThreads * kEvLd];
+  const int64_t m0 = (int64_t)blockIdx.x * kThreads;
+  stage_mates(mates, m0, n_mates, rec);
+  const int64_t m = m0 + threadIdx.x;
   if (m >= n_mates) return;
   const int64_t pair = m >> 1;
   const int side = (int)(m & 1);
@@ -280,17 +304,15 @@ __global__ __launch_bounds__(kThreads) void tab_emit(const gk_mate* mates, int64
   const uint32_t o_pos = off[4 * pair + side], o_pos_end = off[4 * pair + side + 1];
   const uint32_t o_neg = off[4 * pair + 2 + side], o_neg_end = off[4 * pair + 2 + side + 1];
   if (o_pos == o_pos_end && o_neg == o_neg_end) return;
-  MateRegs r;
-  load_mate(mates, m, r);
-  Events ev;
-  walk(r, ev);
-  Resolved rs;
-  resolve(ev, r, key, n_var, rs);
-  for (int e = 0; e < ev.n && o_pos + e < o_pos_end; ++e)
-    ids[o_pos + e] = rs.ord[e] >= 0 ? (uint32_t)rs.ord[e] : (uint32_t)n_var + novel_rank(nt, ev.key[e]);
+  const MateView r{rec + threadIdx.x * kRecLd};
+  uint32_t* evw = evs + threadIdx.x * kEvLd;
+  Walked wk;
+  walk_mate<true>(r, ix, nt, m, evw, ids, o_pos, o_pos_end, wk);
   uint32_t w = o_neg;
-  for (int i = rs.lo; i < rs.hi && w < o_neg_end; ++i)
-    if (negative_kept(key[i], i, ev, rs)) ids[w++] = (uint32_t)i;
+  for (int i = wk.lo; i < wk.hi && w < o_neg_end; ++i) {
+    const uint64_t k = ix.key[i];
+    if (negative_kept(k, i, ix, evw, wk)) ids[w++] = (uint32_t)i;
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void gather_pairs(const gk_mate* mates, const int32_t* pair_src, int64_t n_valid,
@@ -318,15 +340,35 @@ extern "C" {
 
 int gk_index_create(gk_ctx* ctx, const uint64_t* key, int32_t n_var, const int32_t* gene_vbeg, int32_t n_gene,
                     gk_index** out) {
-  GK_REQUIRE(ctx && out && gene_vbeg && n_gene > 0 && n_gene < 255 && n_var >= 0, "bad index arguments");
+  GK_REQUIRE(ctx && out && gene_vbeg && n_gene > 0 && n_gene < 255 && n_var >= 0 && n_var < (1 << 26),
+             "bad index arguments");
+  GK_REQUIRE(gene_vbeg[0] == 0 && gene_vbeg[n_gene] == n_var, "gene_vbeg must cover the key table");
   for (int i = 1; i < n_var; ++i) GK_REQUIRE(key[i - 1] < key[i], "index keys must be strictly increasing");
   gk_index* idx = new gk_index();
   idx->ctx = ctx; idx->n_var = n_var; idx->n_gene = n_gene;
   idx->gene_vbeg.assign(gene_vbeg, gene_vbeg + n_gene + 1);
+  // 16-bp bucket table per gene: bucket b holds the first ordinal at or after (gene, 16 * b); one
+  // extra bucket past the last variant position closes the last interval
+  std::vector<int32_t> boff((size_t)n_gene + 1, 0), bucket;
+  for (int g = 0; g < n_gene; ++g) {
+    const uint64_t* first = key + gene_vbeg[g];
+    const uint64_t* last = key + gene_vbeg[g + 1];
+    for (const uint64_t* k = first; k < last; ++k)
+      GK_REQUIRE((uint32_t)(*k >> GK_KEY_REF_SHIFT) == (uint32_t)g, "gene_vbeg does not match the key table");
+    const uint32_t max_pos = first < last ? gk_key_pos(*(last - 1)) : 0u;
+    const int nb = (int)(max_pos >> 4) + 2;
+    for (int b = 0; b < nb; ++b)
+      bucket.push_back((int32_t)(std::lower_bound(key, key + n_var, gk_make_key((uint32_t)g, (uint32_t)b << 4, 0, 0)) - key));
+    boff[g + 1] = (int32_t)bucket.size();
+  }
   GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_key, (size_t)(n_var + 1) * sizeof(uint64_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_gene_vbeg, (size_t)(n_gene + 1) * sizeof(int32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_bucket, bucket.size() * sizeof(int32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_gene_boff, boff.size() * sizeof(int32_t)));
   GK_HIP(hipMemcpyAsync(idx->d_key, key, (size_t)n_var * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   GK_HIP(hipMemcpyAsync(idx->d_gene_vbeg, gene_vbeg, (size_t)(n_gene + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  GK_HIP(hipMemcpyAsync(idx->d_bucket, bucket.data(), bucket.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  GK_HIP(hipMemcpyAsync(idx->d_gene_boff, boff.data(), boff.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   GK_HIP(hipStreamSynchronize(ctx->stream));
   *out = idx;
   return GK_OK;
@@ -337,6 +379,8 @@ int gk_index_destroy(gk_index* idx) {
   gk_ctx* ctx = idx->ctx;
   gk_pool_free(ctx,idx->d_key);
   gk_pool_free(ctx,idx->d_gene_vbeg);
+  gk_pool_free(ctx,idx->d_bucket);
+  gk_pool_free(ctx,idx->d_gene_boff);
   delete idx;
   return GK_OK;
 }
@@ -371,9 +415,10 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_err, sizeof(int)));
   GK_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
 
+  const IndexView ix{idx->d_key, idx->d_bucket, idx->d_gene_boff, idx->n_var, idx->n_gene};
   if (n_mates) {
-    GK_PROF(ctx, GK_K_TAB_COUNT, hipLaunchKernelGGL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, idx->d_key,
-                       idx->n_var, nt, cnt, valid, d_err));
+    GK_PROF(ctx, GK_K_TAB_COUNT, hipLaunchKernelGGL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
+                       nt, cnt, valid, d_err));
   }
   // offsets over input pairs (invalid pairs contribute zeros)
   int rc = gk_scan_u32(ctx, cnt, 4 * n_pairs, cnt + 4 * n_pairs);
@@ -411,8 +456,8 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
 
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_ids, (size_t)(tab->n_ids + 1) * sizeof(uint32_t)));
   if (n_mates) {
-    GK_PROF(ctx, GK_K_TAB_EMIT, hipLaunchKernelGGL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, idx->d_key, idx->n_var,
-                       nt, cnt, valid, tab->d_ids));
+    GK_PROF(ctx, GK_K_TAB_EMIT, hipLaunchKernelGGL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix, nt, cnt,
+                       valid, tab->d_ids));
   }
   // compact valid pairs (order preserving)
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_pair_src, (size_t)(n_pairs + 1) * sizeof(int32_t)));
