@@ -99,6 +99,14 @@ struct gk_tab {
   uint8_t* d_pair_gene = nullptr;
   uint8_t* d_pair_nh = nullptr;
   uint64_t* d_novel_key = nullptr;
+  // rows grouped by backbone in row order, built once per (multiple) flavour on first use:
+  // [0] reads mapped to one backbone only, [1] every read
+  struct GenePartition {
+    gk_ctx* owner = nullptr;          // context whose pool holds d_rows
+    int32_t* d_rows = nullptr;
+    std::vector<int64_t> gene_off;    // [n_bins + 1]
+  } part[2];
+  std::mutex part_mutex;
 };
 
 template <typename T>

@@ -521,6 +521,8 @@ int gk_tab_destroy(gk_tab* tab) {
   gk_ctx* ctx = tab->ctx;
   gk_pool_free(ctx,tab->d_pair_src); gk_pool_free(ctx,tab->d_off); gk_pool_free(ctx,tab->d_ids);
   gk_pool_free(ctx,tab->d_pair_gene); gk_pool_free(ctx,tab->d_pair_nh); gk_pool_free(ctx,tab->d_novel_key);
+  for (auto& part : tab->part)
+    if (part.d_rows) gk_pool_free(part.owner, part.d_rows);
   delete tab;
   return GK_OK;
 }

@@ -21,10 +21,39 @@ namespace {
 constexpr int kThreads = 256;
 inline unsigned nblk(int64_t n, int t = kThreads) { return (unsigned)((n + t - 1) / t); }
 
-__global__ __launch_bounds__(kThreads) void flag_gene(const uint8_t* gene, const uint8_t* nh, int64_t n, int g,
-                                                      int multiple, uint32_t* flag) {
+// Rows grouped by backbone, row order kept (a stable counting sort with one tile per wavefront):
+// part_count writes, for every wave of 64 rows, how many selected rows each backbone has (bin-major,
+// so ONE exclusive scan yields every (backbone, wave) output offset); part_scatter ranks a row
+// among the lanes of its wave with the same backbone.  Replaces one flag + scan + scatter per gene.
+template <bool kScatter>
+__global__ __launch_bounds__(kThreads) void part_pass(const uint8_t* gene, const uint8_t* nh, int64_t n, int multiple,
+                                                      int n_bins, int64_t n_tiles, uint32_t* hist, int32_t* out) {
   const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i < n) flag[i] = (gene[i] == g) && (multiple || nh[i] == 1);
+  const int lane = threadIdx.x & 63;
+  const int64_t tile = i >> 6;
+  int bin = -1;
+  if (i < n && (multiple || nh[i] == 1)) {
+    bin = gene[i];
+    if (bin >= n_bins) bin = -1;
+  }
+  uint64_t todo = __ballot(bin >= 0);
+  while (todo) {
+    const int leader = __ffsll((unsigned long long)todo) - 1;
+    const int b = __shfl(bin, leader, 64);
+    const uint64_t same = __ballot(bin == b);
+    if (kScatter) {
+      if (bin == b) out[hist[(int64_t)b * n_tiles + tile] + __popcll(same & ((1ull << lane) - 1ull))] = (int32_t)i;
+    } else if (lane == leader) {
+      hist[(int64_t)b * n_tiles + tile] = (uint32_t)__popcll(same);
+    }
+    todo &= ~same;
+  }
+}
+
+__global__ void part_offsets(const uint32_t* hist, const uint32_t* total, int n_bins, int64_t n_tiles, uint32_t* goff) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n_bins) goff[b] = hist[(int64_t)b * n_tiles];
+  if (b == n_bins) goff[b] = *total;
 }
 
 // one thread per list (4 lists per row): tally surviving ids
@@ -107,7 +136,7 @@ constexpr int kTileLd = kTileRows + 1;   // padded LDS stride (doubles) of the t
 // so the table of log-probabilities is the only thing written.  A value whose log10 the host has not
 // evaluated yet is inserted into the table and stored as NaN; the host sees the table grow, evaluates
 // numpy.log10 for the new values and runs the kernel once more.
-template <bool kLog, int kSlots>
+template <bool kLog, int kSlots, bool kMiss>
 __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, int64_t n_rows, const uint32_t* off,
                                                           const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
                                                           const uint32_t* mask, int words, int n_allele, int a_base,
@@ -118,7 +147,6 @@ __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, i
   __shared__ double tile[kPassAlleles * kTileLd];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool upper = lane >= 32;
   const int w_base = a_base >> 5;   // a_base is a multiple of 256 = 8 words
 
   int a[kSlots];
@@ -128,7 +156,6 @@ __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, i
     a[s] = a_base + lane + 64 * s;
     live[s] = a[s] < n_allele;
   }
-  const uint32_t my_bit = 1u << (lane & 31);
   const int n_pass = min(kPassAlleles, n_allele - a_base);
   const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   for (int64_t tile_i = blockIdx.x; tile_i < n_tiles; tile_i += gridDim.x) {
@@ -166,15 +193,28 @@ __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, i
         const int cnt = (int)min(64u, e - base);
         for (int t = 0; t < cnt; ++t) {
           if (!__builtin_amdgcn_readlane(my_keep, t)) continue;   // wave-uniform
-          const bool positive = base + t < mid;
+          const bool positive = base + t < mid;   // wave-uniform: two straight-line bodies
+          // The two bit-row words of a slot, read back from lane t, ARE the slot's 64 per-lane
+          // "allele has the variant" bits: as an SGPR pair they condition v_cndmask directly
+          // (no per-lane bit test).
+          if (positive) {
 #pragma unroll
-          for (int s = 0; s < kSlots; ++s) {
-            const uint32_t lo = __builtin_amdgcn_readlane(mrow[2 * s], t);
-            const uint32_t hi = __builtin_amdgcn_readlane(mrow[2 * s + 1], t);
-            const bool has = ((upper ? hi : lo) & my_bit) != 0;
-            const bool hit = positive ? has : !has;
-            p[s] *= hit ? 0.999 : 0.001;   // 1.0 * f == f: same bits as numpy's multiply.reduce
-            miss[s] += hit ? 0u : 1u;
+            for (int s = 0; s < kSlots; ++s) {
+              const uint32_t lo = __builtin_amdgcn_readlane(mrow[2 * s], t);
+              const uint32_t hi = __builtin_amdgcn_readlane(mrow[2 * s + 1], t);
+              const bool has = __builtin_amdgcn_inverse_ballot_w64(((uint64_t)hi << 32) | lo);
+              p[s] *= has ? 0.999 : 0.001;   // 1.0 * f == f: same bits as numpy's multiply.reduce
+              if (kMiss) miss[s] += has ? 0u : 1u;
+            }
+          } else {
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) {
+              const uint32_t lo = __builtin_amdgcn_readlane(mrow[2 * s], t);
+              const uint32_t hi = __builtin_amdgcn_readlane(mrow[2 * s + 1], t);
+              const bool has = __builtin_amdgcn_inverse_ballot_w64(((uint64_t)hi << 32) | lo);
+              p[s] *= has ? 0.001 : 0.999;
+              if (kMiss) miss[s] += has ? 1u : 0u;
+            }
           }
           ++nvar;
         }
@@ -183,10 +223,10 @@ __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, i
       for (int s = 0; s < kSlots; ++s) {
         if (live[s]) {
           tile[(lane + 64 * s) * kTileLd + rt] = p[s];
-          if (miss_out) miss_out[(int64_t)a[s] * n_rows + i] = (uint8_t)min(miss[s], 255u);
+          if (kMiss && miss_out) miss_out[(int64_t)a[s] * n_rows + i] = (uint8_t)min(miss[s], 255u);
         }
       }
-      if (nvar_out && lane == 0 && a_base == 0) nvar_out[i] = (uint16_t)min(nvar, 65535u);
+      if (kMiss && nvar_out && lane == 0 && a_base == 0) nvar_out[i] = (uint16_t)min(nvar, 65535u);
     }
     __syncthreads();
     if (probs) {
@@ -223,7 +263,7 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
     const int slots = std::min(kMaxSlots, (n_allele - a_base + 63) / 64);
 #define GK_COMPAT_LAUNCH(S)                                                                                        \
   GK_PROF(ctx, GK_K_COMPAT,                                                                                        \
-          hipLaunchKernelGGL((compat_kernel<kLog, S>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows, \
+          hipLaunchKernelGGL((compat_kernel<kLog, S, !kLog>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows, \
                              tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, gk_ptr<uint32_t>(d_mask),  \
                              words, n_allele, a_base, out, miss, nvar, view))
     switch (slots) {
@@ -242,17 +282,59 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
 
 extern "C" {
 
+static int build_partition(gk_ctx* ctx, gk_tab* tab, int multiple) {
+  gk_tab::GenePartition& part = tab->part[multiple ? 1 : 0];
+  const int64_t n = tab->n_valid;
+  const int n_bins = tab->idx ? tab->idx->n_gene : 256;
+  const int64_t n_tiles = (n + 63) / 64;
+  const size_t n_hist = (size_t)n_bins * n_tiles;
+  uint32_t *hist = nullptr, *goff = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&hist, (n_hist + 1) * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&goff, (size_t)(n_bins + 1) * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&part.d_rows, (size_t)(n + 1) * sizeof(int32_t)));
+  part.owner = ctx;
+  GK_HIP(hipMemsetAsync(hist, 0, n_hist * sizeof(uint32_t), ctx->stream));
+  GK_PROF(ctx, GK_K_SELECT, hipLaunchKernelGGL(part_pass<false>, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream,
+                                               tab->d_pair_gene, tab->d_pair_nh, n, multiple, n_bins, n_tiles, hist,
+                                               (int32_t*)nullptr));
+  int rc = gk_scan_u32(ctx, hist, (int64_t)n_hist, hist + n_hist);
+  if (rc) return rc;
+  GK_PROF(ctx, GK_K_SELECT, hipLaunchKernelGGL(part_pass<true>, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream,
+                                               tab->d_pair_gene, tab->d_pair_nh, n, multiple, n_bins, n_tiles, hist,
+                                               part.d_rows));
+  hipLaunchKernelGGL(part_offsets, dim3((unsigned)(n_bins / 256 + 1)), dim3(256), 0, ctx->stream, hist, hist + n_hist,
+                     n_bins, n_tiles, goff);
+  GK_HIP(hipGetLastError());
+  std::vector<uint32_t> host((size_t)n_bins + 1);
+  GK_HIP(hipMemcpyAsync(host.data(), goff, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  GK_HIP(hipStreamSynchronize(ctx->stream));
+  part.gene_off.assign(host.begin(), host.end());
+  gk_pool_free(ctx, hist);
+  gk_pool_free(ctx, goff);
+  return GK_OK;
+}
+
 int gk_select_gene(gk_ctx* ctx, gk_tab* tab, int gene, int multiple, gk_dptr d_rows_out, int64_t* n_out) {
   GK_REQUIRE(ctx && tab && n_out, "null pointer");
-  const int64_t n = tab->n_valid;
-  if (n == 0) { *n_out = 0; return GK_OK; }
-  uint32_t* flag = nullptr;
-  GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)n * sizeof(uint32_t)));
-  GK_PROF(ctx, GK_K_SELECT, hipLaunchKernelGGL(flag_gene, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream, tab->d_pair_gene, tab->d_pair_nh, n,
-                     gene, multiple, flag));
-  int rc = gk_compact(ctx, flag, nullptr, n, gk_ptr<int32_t>(d_rows_out), n_out);
-  gk_pool_free(ctx,flag);
-  return rc;
+  *n_out = 0;
+  if (tab->n_valid == 0 || gene < 0) return GK_OK;
+  gk_tab::GenePartition& part = tab->part[multiple ? 1 : 0];
+  {
+    std::lock_guard<std::mutex> lock(tab->part_mutex);
+    if (part.gene_off.empty()) {
+      int rc = build_partition(ctx, tab, multiple);
+      if (rc) { part.gene_off.clear(); return rc; }
+    }
+  }
+  if ((size_t)gene + 1 >= part.gene_off.size()) return GK_OK;
+  const int64_t first = part.gene_off[gene], count = part.gene_off[gene + 1] - first;
+  if (count > 0) {
+    GK_REQUIRE(d_rows_out, "null output");
+    GK_HIP(hipMemcpyAsync(gk_ptr<int32_t>(d_rows_out), part.d_rows + first, (size_t)count * sizeof(int32_t),
+                          hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  *n_out = count;
+  return GK_OK;
 }
 
 int gk_select_nonempty(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, gk_dptr d_rows_out,
