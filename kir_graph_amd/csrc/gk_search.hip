@@ -295,95 +295,114 @@ __global__ __launch_bounds__(kThreads) void combine_chunks(const double* __restr
   out[o] = scale_div != 0.0 ? total / scale_div : total;
 }
 
-// abundance share: one 8-lane group per allele set, rows read straight from L2 / HBM
+// abundance share (typing_mulit_allele.py:575-580): one 8-lane group per allele set, 32 sets per
+// workgroup.  The host orders the sets so that neighbours share alleles and hands every tile of 32
+// sets the list of its distinct columns; the workgroup stages those columns through LDS in blocks
+// of 32 rows (coalesced 256-byte runs) instead of every set reading its own columns from L2.
+constexpr int kFracSets = kThreads / 8;   // sets per workgroup
+constexpr int kFracRows = 32;             // staged rows per block (4 row-steps of the 8 lanes)
+constexpr int kFracLd = kFracRows + 9;    // + up to 7 tail rows of the leaf, odd stride
+
+template <int kC>
 __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __restrict__ L, int64_t ld,
-                                                            const int32_t* __restrict__ ids, int n_sets, int c,
+                                                            const int32_t* __restrict__ tile_col_off,
+                                                            const int32_t* __restrict__ tile_cols,
+                                                            const int32_t* __restrict__ local_idx,
+                                                            const int32_t* __restrict__ perm, int n_sets,
                                                             const Span* __restrict__ spans,
                                                             const Leaf* __restrict__ leaves,
                                                             double* __restrict__ partial) {
+  extern __shared__ double fbuf[];   // [distinct columns of the tile][kFracLd]
   const int tid = threadIdx.x, lane = tid & 63;
   const int j = lane & 7;
-  const int k = blockIdx.x * (kThreads / 8) + (tid >> 3);
+  const int k = blockIdx.x * kFracSets + (tid >> 3);   // position in the host's set order
   const Span span = spans[blockIdx.y];
   const bool live = k < n_sets;
-  const double* colp[kMaxC];
+  const int c0 = tile_col_off[blockIdx.x], n_dist = tile_col_off[blockIdx.x + 1] - c0;
+  const int32_t* cols = tile_cols + c0;
+  int loc[kC];
 #pragma unroll
-  for (int q = 0; q < kMaxC; ++q) colp[q] = L + (int64_t)((live && q < c) ? ids[k * c + q] : 0) * ld;
-  double inv[kMaxC + 1];
+  for (int q = 0; q < kC; ++q) loc[q] = live ? local_idx[k * kC + q] * kFracLd : 0;
+  double inv[kC + 1];
 #pragma unroll
-  for (int q = 1; q <= kMaxC; ++q) inv[q] = 1.0 / (double)q;   // exact IEEE quotients, as numpy's bool / int
+  for (int q = 1; q <= kC; ++q) inv[q] = 1.0 / (double)q;   // exact IEEE quotients, as numpy's bool / int
   inv[0] = 0.0;
-  double st[kMaxC];
+  double st[kC];
 #pragma unroll
-  for (int q = 0; q < kMaxC; ++q) st[q] = 0.0;
+  for (int q = 0; q < kC; ++q) st[q] = 0.0;
 
-  auto terms = [&](int64_t r, double* out_t) {
-    double v[kMaxC];
+  // acc += the row's shares; staged row index r (0..kFracLd)
+  auto add_terms = [&](int r, double* acc) {
+    double v[kC];
     double best = -__builtin_huge_val();
 #pragma unroll
-    for (int q = 0; q < kMaxC; ++q) {
-      v[q] = q < c ? colp[q][r] : -__builtin_huge_val();
-      if (q < c) best = vmax(best, v[q]);
+    for (int q = 0; q < kC; ++q) {
+      v[q] = fbuf[loc[q] + r];
+      best = vmax(best, v[q]);
     }
     int cnt = 0;
 #pragma unroll
-    for (int q = 0; q < kMaxC; ++q) cnt += (q < c && v[q] == best) ? 1 : 0;
+    for (int q = 0; q < kC; ++q) cnt += v[q] == best ? 1 : 0;
     double share = inv[1];
 #pragma unroll
-    for (int q = 2; q <= kMaxC; ++q) share = cnt == q ? inv[q] : share;
+    for (int q = 2; q <= kC; ++q) share = cnt == q ? inv[q] : share;
 #pragma unroll
-    for (int q = 0; q < kMaxC; ++q) out_t[q] = (q < c && v[q] == best) ? share : 0.0;
+    for (int q = 0; q < kC; ++q) acc[q] += v[q] == best ? share : 0.0;   // 0.0 + x == x: first term exact
   };
 
   for (int li = span.leaf_begin; li < span.leaf_end; ++li) {
     const Leaf cur = leaves[li];
     const int64_t r0 = span.row0 + cur.start;
     const int len = cur.len;
-    const int n8 = len - (len & 7);
-    double acc[kMaxC], t[kMaxC];
-    if (len < 8) {
+    const int n8 = len < 8 ? 0 : len - (len & 7);   // rows summed by the 8 strided accumulators
+    double acc[kC];
 #pragma unroll
-      for (int q = 0; q < kMaxC; ++q) acc[q] = 0.0;
-      for (int r = 0; r < len; ++r) {
-        terms(r0 + r, t);
-#pragma unroll
-        for (int q = 0; q < kMaxC; ++q) acc[q] += t[q];
+    for (int q = 0; q < kC; ++q) acc[q] = 0.0;
+    const int n_blocks = n8 ? (n8 + kFracRows - 1) / kFracRows : 1;
+    for (int sb = 0; sb < n_blocks; ++sb) {
+      const int b0 = sb * kFracRows;
+      const int rows_in = min(kFracRows, n8 - b0);          // <= 0 when the leaf is all tail
+      const bool last = sb + 1 == n_blocks;
+      __syncthreads();
+      for (int idx = tid; idx < n_dist * kFracRows; idx += kThreads) {
+        const int col = idx >> 5, r = idx & (kFracRows - 1);
+        if (r < rows_in) fbuf[col * kFracLd + r] = L[(int64_t)cols[col] * ld + r0 + b0 + r];
       }
-    } else {
-      terms(r0 + j, acc);
-      for (int r = 8 + j; r < n8; r += 8) {
-        terms(r0 + r, t);
-#pragma unroll
-        for (int q = 0; q < kMaxC; ++q) acc[q] += t[q];
+      if (last) {   // sequential tail rows n8 .. len (all rows of a leaf shorter than 8)
+        for (int idx = tid; idx < n_dist * 8; idx += kThreads) {
+          const int col = idx >> 3, r = n8 + (idx & 7);
+          if (r < len) fbuf[col * kFracLd + kFracRows + (idx & 7)] = L[(int64_t)cols[col] * ld + r0 + r];
+        }
       }
+      __syncthreads();
+      for (int r = j; r < rows_in; r += 8) add_terms(r, acc);
+      if (last) {
+        if (n8) {
 #pragma unroll
-      for (int q = 0; q < kMaxC; ++q) acc[q] = group_sum8(acc[q]);
-      for (int r = n8; r < len; ++r) {
-        terms(r0 + r, t);
-#pragma unroll
-        for (int q = 0; q < kMaxC; ++q) acc[q] += t[q];
+          for (int q = 0; q < kC; ++q) acc[q] = group_sum8(acc[q]);
+        }
+        for (int r = n8; r < len; ++r) add_terms(kFracRows + r - n8, acc);   // same in every lane
       }
     }
     {
       const bool mine = (j == cur.slot);
 #pragma unroll
-      for (int q = 0; q < kMaxC; ++q) st[q] = mine ? acc[q] : st[q];
+      for (int q = 0; q < kC; ++q) st[q] = mine ? acc[q] : st[q];
     }
     for (int a = 0; a < cur.n_add; ++a) {
       const int s = cur.slot - a;
-      const int src = (lane & ~7) | s;
       const bool mine = (j == s - 1);
 #pragma unroll
-      for (int q = 0; q < kMaxC; ++q) {
-        const double other = __shfl(st[q], src, 64);
+      for (int q = 0; q < kC; ++q) {
+        const double other = dpp_f64<kDppShl1>(st[q]);
         st[q] = mine ? st[q] + other : st[q];
       }
     }
   }
   if (j == 0 && live) {
+    const int64_t ko = perm[k];
 #pragma unroll
-    for (int q = 0; q < kMaxC; ++q)
-      if (q < c) partial[((int64_t)blockIdx.y * n_sets + k) * c + q] = st[q];
+    for (int q = 0; q < kC; ++q) partial[((int64_t)blockIdx.y * n_sets + ko) * kC + q] = st[q];
   }
 }
 
@@ -563,19 +582,83 @@ int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int3
                 double* frac_out) {
   GK_REQUIRE(ctx && ids && frac_out && n_rows > 0 && ld >= n_rows && n_sets > 0, "bad fraction arguments");
   GK_REQUIRE(c >= 1 && c <= kMaxC, "copy number beyond supported set size");
+  // Order the sets so that tiles of 32 share columns: the best sets pair a few strong alleles with
+  // many partners, so sort by each set's ids taken rarest-first (partners adjacent, hubs shared).
+  int32_t max_id = 0;
+  for (int64_t i = 0; i < (int64_t)n_sets * c; ++i) {
+    GK_REQUIRE(ids[i] >= 0, "negative allele id");
+    max_id = std::max(max_id, ids[i]);
+  }
+  std::vector<int32_t> freq((size_t)max_id + 1, 0);
+  for (int64_t i = 0; i < (int64_t)n_sets * c; ++i) freq[ids[i]]++;
+  std::vector<int32_t> key((size_t)n_sets * c), perm((size_t)n_sets);
+  for (int k = 0; k < n_sets; ++k) {
+    int32_t* kk = key.data() + (size_t)k * c;
+    std::copy(ids + (size_t)k * c, ids + (size_t)(k + 1) * c, kk);
+    std::sort(kk, kk + c, [&](int32_t x, int32_t y) { return freq[x] != freq[y] ? freq[x] < freq[y] : x < y; });
+    perm[k] = k;
+  }
+  std::sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) {
+    const int32_t *kx = key.data() + (size_t)x * c, *ky = key.data() + (size_t)y * c;
+    for (int q = 0; q < c; ++q)
+      if (kx[q] != ky[q]) return kx[q] < ky[q];
+    return x < y;
+  });
+  const int n_tiles = (n_sets + kFracSets - 1) / kFracSets;
+  std::vector<int32_t> plan;   // [tile_col_off | tile_cols | local_idx | perm]
+  std::vector<int32_t> tile_off((size_t)n_tiles + 1, 0), tile_cols, local((size_t)n_sets * c);
+  std::vector<int32_t> slot_of((size_t)max_id + 1, -1);
+  int max_dist = 1;
+  for (int t = 0; t < n_tiles; ++t) {
+    const size_t first = tile_cols.size();
+    for (int k = t * kFracSets; k < std::min(n_sets, (t + 1) * kFracSets); ++k)
+      for (int q = 0; q < c; ++q) {
+        const int32_t id = ids[(size_t)perm[k] * c + q];
+        if (slot_of[id] < 0) {
+          slot_of[id] = (int32_t)(tile_cols.size() - first);
+          tile_cols.push_back(id);
+        }
+        local[(size_t)k * c + q] = slot_of[id];
+      }
+    for (size_t i = first; i < tile_cols.size(); ++i) slot_of[tile_cols[i]] = -1;
+    tile_off[t + 1] = (int32_t)tile_cols.size();
+    max_dist = std::max(max_dist, (int)(tile_cols.size() - first));
+  }
+  plan.insert(plan.end(), tile_off.begin(), tile_off.end());
+  const size_t o_cols = plan.size();
+  plan.insert(plan.end(), tile_cols.begin(), tile_cols.end());
+  const size_t o_local = plan.size();
+  plan.insert(plan.end(), local.begin(), local.end());
+  const size_t o_perm = plan.size();
+  plan.insert(plan.end(), perm.begin(), perm.end());
+
   DeviceProgram dp;
-  int rc = upload_program(ctx, n_rows, ids, (size_t)n_sets * c, nullptr, 0, dp);
+  int rc = upload_program(ctx, n_rows, plan.data(), plan.size(), nullptr, 0, dp);
   if (rc) return rc;
   hipStream_t st = ctx->stream;
   double *d_partial = nullptr, *d_out = nullptr;
   const int64_t n_out = (int64_t)n_sets * c;
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * dp.n_spans * sizeof(double)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_out * sizeof(double)));
-  const int per_block = kThreads / 8;
-  GK_PROF(ctx, GK_K_FRACTION,
-          hipLaunchKernelGGL(fraction_chunks, dim3((unsigned)((n_sets + per_block - 1) / per_block), (unsigned)dp.n_spans),
-                             dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld, dp.ids, n_sets, c, dp.spans, dp.leaves,
-                             d_partial));
+  const dim3 grid((unsigned)n_tiles, (unsigned)dp.n_spans);
+  const size_t lds = (size_t)max_dist * kFracLd * sizeof(double);   // <= 256 columns * 41 * 8 = 84 KB
+#define GK_FRAC_LAUNCH(C)                                                                                            \
+  if (lds > 48 * 1024)                                                                                               \
+    GK_HIP(hipFuncSetAttribute((const void*)fraction_chunks<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+  GK_PROF(ctx, GK_K_FRACTION,                                                                                        \
+          hipLaunchKernelGGL(fraction_chunks<C>, grid, dim3(kThreads), lds, st, gk_ptr<double>(d_L), ld, dp.ids,     \
+                             dp.ids + o_cols, dp.ids + o_local, dp.ids + o_perm, n_sets, dp.spans, dp.leaves, d_partial))
+  switch (c) {
+    case 1: GK_FRAC_LAUNCH(1); break;
+    case 2: GK_FRAC_LAUNCH(2); break;
+    case 3: GK_FRAC_LAUNCH(3); break;
+    case 4: GK_FRAC_LAUNCH(4); break;
+    case 5: GK_FRAC_LAUNCH(5); break;
+    case 6: GK_FRAC_LAUNCH(6); break;
+    case 7: GK_FRAC_LAUNCH(7); break;
+    default: GK_FRAC_LAUNCH(8); break;
+  }
+#undef GK_FRAC_LAUNCH
   GK_PROF(ctx, GK_K_COMBINE,
           hipLaunchKernelGGL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
                              d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, (double)n_rows, d_out));

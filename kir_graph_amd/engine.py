@@ -356,6 +356,8 @@ class DeviceModel:
     def fraction(self, ids: np.ndarray) -> np.ndarray:
         ids = _i32(ids)
         out = np.empty(ids.shape, dtype=np.float64)
+        if self.dev.call_log is not None:
+            self.dev.call_log.append(("fraction_chunks", self.n_rows, ids.shape[0], ids.shape[1], len(np.unique(ids))))
         check(lib().gk_fraction(self.dev.ctx, self.L.ptr, self.n_rows, self.n_rows, ids.ctypes.data, ids.shape[0],
                                 ids.shape[1], out.ctypes.data))
         return out
