@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kThreads, 3) void maxsum_chunks(const double* __res
                                                           const int32_t* __restrict__ cols, int n_cols,
                                                           const Span* __restrict__ spans,
                                                           const Leaf* __restrict__ leaves, int n_tiles,
-                                                          double* __restrict__ partial) {
+                                                          int symmetric, double* __restrict__ partial) {
   __shared__ double Pt[kTileT * kLD];
   __shared__ double Lt[kTileA * kLD];
   __shared__ int32_t p_col[kTileT];
@@ -104,6 +104,9 @@ __global__ __launch_bounds__(kThreads, 3) void maxsum_chunks(const double* __res
   const int tile = (int)(logical % (unsigned)n_tiles);
   const int tile_t = tile / tiles_a, tile_a = tile % tiles_a;
   const int t0 = tile_t * kTileT, a0 = tile_a * kTileA;
+  // symmetric launch (set t IS column t): sum max(L_t, L_a) == sum max(L_a, L_t) term by term, so
+  // tiles entirely below the diagonal are left to the host, which mirrors them
+  if (symmetric && a0 + kTileA - 1 < t0) return;
   const Span span = spans[span_idx];
 
   if (tid < kTileT) p_col[tid] = (pcol && t0 + tid < n_sets) ? pcol[t0 + tid] : -1;
@@ -537,7 +540,30 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   hipStream_t st = ctx->stream;
   std::vector<int32_t> pcol_host((size_t)n_sets);
   double* d_P = nullptr;
-  if (c_prev == 1) {
+  // second allele of the search: the sets are the single alleles themselves, so the table is
+  // symmetric; run the sets in column order and compute the upper triangle only
+  std::vector<int32_t> row_of_set;
+  if (c_prev == 1 && n_sets == n_cols && n_sets > kTileT) {
+    int32_t max_id = 0;
+    for (int j = 0; j < n_cols; ++j) max_id = std::max(max_id, cols[j]);
+    std::vector<int32_t> pos((size_t)max_id + 1, -1);
+    bool ok = true;
+    for (int j = 0; j < n_cols && ok; ++j) {
+      ok = cols[j] >= 0 && pos[cols[j]] < 0;
+      if (ok) pos[cols[j]] = j;
+    }
+    row_of_set.resize((size_t)n_sets);
+    std::vector<char> seen((size_t)n_cols, 0);
+    for (int t = 0; t < n_sets && ok; ++t) {
+      ok = ids[t] >= 0 && ids[t] <= max_id && pos[ids[t]] >= 0 && !seen[pos[ids[t]]];
+      if (ok) { row_of_set[t] = pos[ids[t]]; seen[row_of_set[t]] = 1; }
+    }
+    if (!ok) row_of_set.clear();
+  }
+  const bool symmetric = !row_of_set.empty();
+  if (symmetric) {
+    for (int t = 0; t < n_sets; ++t) pcol_host[t] = cols[t];
+  } else if (c_prev == 1) {
     for (int t = 0; t < n_sets; ++t) pcol_host[t] = ids[t];
   } else if (c_prev >= 2) {
     for (int t = 0; t < n_sets; ++t) pcol_host[t] = t;
@@ -558,19 +584,30 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
     GK_PROF(ctx, GK_K_MAXSUM,
             hipLaunchKernelGGL(maxsum_chunks<true>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
                                c_prev >= 2 ? d_P : gk_ptr<double>(d_L), ld, dp.ids, n_sets, dp.cols, n_cols, dp.spans,
-                               dp.leaves, tiles_t * tiles_a, d_partial));
+                               dp.leaves, tiles_t * tiles_a, symmetric ? 1 : 0, d_partial));
   } else {
     GK_PROF(ctx, GK_K_MAXSUM,
             hipLaunchKernelGGL(maxsum_chunks<false>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
                                gk_ptr<double>(d_L), ld, (const int32_t*)nullptr, n_sets, dp.cols, n_cols, dp.spans,
-                               dp.leaves, tiles_t * tiles_a, d_partial));
+                               dp.leaves, tiles_t * tiles_a, 0, d_partial));
   }
   GK_PROF(ctx, GK_K_COMBINE,
           hipLaunchKernelGGL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
                              d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, 0.0, d_out));
   GK_HIP(hipGetLastError());
-  GK_HIP(hipMemcpyAsync(out, d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
-  GK_HIP(hipStreamSynchronize(st));
+  if (symmetric) {
+    std::vector<double> sq((size_t)n_out);
+    GK_HIP(hipMemcpyAsync(sq.data(), d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+    GK_HIP(hipStreamSynchronize(st));
+    for (int t = 0; t < n_sets; ++t) {
+      const int x = row_of_set[t];
+      double* dst = out + (size_t)t * n_cols;
+      for (int y = 0; y < n_cols; ++y) dst[y] = x <= y ? sq[(size_t)x * n_cols + y] : sq[(size_t)y * n_cols + x];
+    }
+  } else {
+    GK_HIP(hipMemcpyAsync(out, d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+    GK_HIP(hipStreamSynchronize(st));
+  }
   gk_pool_free(ctx, d_partial);
   gk_pool_free(ctx, d_out);
   gk_pool_free(ctx, dp.base);

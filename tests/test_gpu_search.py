@@ -60,3 +60,22 @@ def test_maxsum_and_setmax_match_numpy(device, n_rows, n_allele, n_sets, c_prev)
         assert np.array_equal(buf.download().reshape(n_sets, n_rows).T, prev)
         buf.free()
     dL.free()
+
+
+@pytest.mark.parametrize("n_allele", [33, 70, 200])
+def test_second_allele_table_is_mirrored_exactly(device, n_allele):
+    """Sets = every single allele in rank order, columns = every allele: the library computes the upper
+    triangle in column order and mirrors it; the result must still be numpy's, bit for bit."""
+    n_rows = 3000
+    rng = np.random.default_rng(n_allele)
+    L = table(rng, n_rows, n_allele)
+    dL = device.put(np.ascontiguousarray(L.T))
+    cols = np.arange(n_allele, dtype=np.int32)
+    ids = np.ascontiguousarray(rng.permutation(n_allele)[:, None], dtype=np.int32)
+    out = np.empty((n_allele, n_allele))
+    check(lib().gk_maxsum(device.ctx, dL.ptr, n_rows, n_rows, ids.ctypes.data, n_allele, 1, cols.ctypes.data,
+                          n_allele, out.ctypes.data))
+    prev = L[:, ids.flatten()]
+    want = np.maximum(L[:, cols], prev.T[:, :, None]).sum(axis=1)
+    assert np.array_equal(out, want)
+    dL.free()
