@@ -185,25 +185,44 @@ def firstOccurrence(ids: np.ndarray, n_allele: int) -> np.ndarray:
 def firstOfSets(prev_ids: np.ndarray, cols: np.ndarray, n_allele: int) -> np.ndarray:
     """First-occurrence mask over the candidates ``prev_ids[t] + [cols[a]]`` in (t-major, a-minor) order.
 
-    Same result as ``firstOccurrence`` on the stacked id table; the sorted-multiset key of every
-    candidate is formed by broadcasting the (already sorted) previous set against the new allele."""
-    import pandas as pd
+    Same result as ``firstOccurrence`` on the stacked id table (uniqueAllele 456-476), without hashing
+    T x A keys: candidate (t, a) repeats an earlier one exactly when swapping the new allele with a
+    member e of the previous set gives a previous set that sits earlier in the list -- the multiset
+    ``prev[t] - {e} + {a}`` at a position < t, with e itself among the offered alleles -- or when
+    ``prev[t]`` already occurred earlier.  One- and two-allele previous sets are looked up in
+    position tables; larger ones fall back to the hashed table."""
+    prev_ids = np.asarray(prev_ids, dtype=np.int64)
+    cols = np.asarray(cols, dtype=np.int64)
     T, k = prev_ids.shape
-    bits = max(1, int(n_allele - 1).bit_length())
-    if bits * (k + 1) > 62 or k > 2:
-        ids = np.hstack([np.repeat(prev_ids, len(cols), axis=0), np.tile(cols, T)[:, None]])
+    A = len(cols)
+    if k > 2 or n_allele > 2048 or len(np.unique(cols)) != A:
+        ids = np.hstack([np.repeat(prev_ids, A, axis=0), np.tile(cols, T)[:, None]])
         return firstOccurrence(ids, n_allele)
-    a = cols[None, :]
+    never = np.int64(T)
+    offered = np.zeros(n_allele, dtype=bool)
+    offered[cols] = True
+    rank = np.arange(T, dtype=np.int64)
     if k == 1:
-        p = prev_ids[:, :1]
-        key = (np.minimum(p, a) << bits) | np.maximum(p, a)
-    else:
-        ps = np.sort(prev_ids, axis=1)
-        p0, p1 = ps[:, :1], ps[:, 1:2]
-        lo, hi = np.minimum(p0, a), np.maximum(p1, a)
-        mid = p0 + p1 + a - lo - hi
-        key = (((lo << bits) | mid) << bits) | hi
-    return ~pd.Series(key.ravel()).duplicated(keep="first").to_numpy()
+        p = prev_ids[:, 0]
+        pos = np.full(n_allele, never)
+        np.minimum.at(pos, p[::-1], rank[::-1])              # first position of every single-allele set
+        first = (pos[cols][None, :] >= rank[:, None]) | ~offered[p][:, None]
+        first &= (pos[p] == rank)[:, None]                   # prev[t] itself must be a first occurrence
+        return first.ravel()
+    lo, hi = prev_ids.min(axis=1), prev_ids.max(axis=1)
+    pos = np.full(n_allele * n_allele, never)
+    np.minimum.at(pos, (lo * n_allele + hi)[::-1], rank[::-1])
+    pos = pos.reshape(n_allele, n_allele)
+    a = cols[None, :]
+
+    def earlier(keep: np.ndarray, gone: np.ndarray) -> np.ndarray:
+        """candidate repeats (keep[t], a) + gone[t] found at an earlier position"""
+        k_ = keep[:, None]
+        return (pos[np.minimum(k_, a), np.maximum(k_, a)] < rank[:, None]) & offered[gone][:, None]
+
+    first = ~(earlier(hi, lo) | earlier(lo, hi))
+    first &= (pos[lo, hi] == rank)[:, None]
+    return first.ravel()
 
 
 class LazyNames:
@@ -473,24 +492,31 @@ class AlleleTyping:
         score = m.maxsum(prev_ids, cols).ravel()            # candidate (t, a) at flat index t * len(cols) + a
         # first occurrence of every allele multiset in (t-major, a-minor) order (uniqueAllele 456-476),
         # from keys built by broadcasting -- the (T*A) x CN id table is never materialised
-        first = np.flatnonzero(firstOfSets(prev_ids, np.asarray(cols, dtype=np.int64), m.n_allele))
-        score_u = score[first]
-        top = np.argsort(score_u)[::-1][:max(self.top_n, score_u.shape[0] // 5)]
-        t_idx, a_idx = np.divmod(first[top], len(cols))
-        top_ids = np.concatenate([prev_ids[t_idx], np.asarray(cols, dtype=np.int64)[a_idx][:, None]], axis=1)
-        score = score_u
+        cols = np.asarray(cols, dtype=np.int64)
+        first = np.flatnonzero(firstOfSets(prev_ids, cols, m.n_allele))
+        score = score[first]
+        n_keep = max(self.top_n, score.shape[0] // 5)
+        top = np.argsort(score)[::-1][:n_keep]                  # numpy's own order among tied scores
         value = score[top]
+        # The reference keeps these K = max(top_n, N // 5) sets, computes their abundance fractions and
+        # then keeps the first top_n under the stable order (-value, -sum of per-allele sums,
+        # unevenness).  Unevenness is the last key, so only rows not worse than the top_n-th row on the
+        # first two keys can make the cut: per-allele sums are formed for the rows that reach the
+        # top_n-th value, fractions for the contenders among them (same final rows, same order).
+        if len(top) > self.top_n:
+            head = int(np.count_nonzero(value >= value[self.top_n - 1]))     # value is descending
+        else:
+            head = len(top)
+        top, value = top[:head], value[:head]
+        t_idx, a_idx = np.divmod(first[top], len(cols))
+        top_ids = np.concatenate([prev_ids[t_idx], cols[a_idx][:, None]], axis=1)
         sum_indv = self._colsums()[top_ids]                     # = log_probs[:, ids].sum(axis=0)
         key1, key2 = -value, -sum_indv.sum(axis=1)
-        # The reference computes abundance fractions for all K = max(top_n, N//5) kept sets and then
-        # keeps the first top_n under the stable order (-value, -sum, unevenness).  Unevenness is the
-        # last key, so only rows not worse than the top_n-th row on the first two keys can make the
-        # cut: fractions are evaluated for those contenders only (same final rows, same order).
-        if len(top_ids) > self.top_n:
+        if head > self.top_n:
             b = np.lexsort((key2, key1))[self.top_n - 1]
             contend = np.nonzero((key1 < key1[b]) | ((key1 == key1[b]) & (key2 <= key2[b])))[0]
         else:
-            contend = np.arange(len(top_ids))
+            contend = np.arange(head)
         frac = m.fraction(top_ids[contend])
         uneven = np.abs(frac - frac.mean(axis=1, keepdims=True)).sum(axis=1)
         sub = np.lexsort((uneven, key2[contend], key1[contend]))[:self.top_n]
@@ -517,6 +543,41 @@ class AlleleTyping:
             cnt.free()
         return out
 
+    @staticmethod
+    def _siteVerdict(ent_pos: np.ndarray, ent_code: np.ndarray, ent_neg: np.ndarray, ent_cnt: np.ndarray,
+                     cn: int) -> bool:
+        """Lines 835-857 on flat (position, label code, negative?, count) observations, vectorised.
+
+        Per position the reference sums counts per label, skips positions with one label or only
+        negative labels, keeps counts > 3, needs their total >= 20, and calls the position
+        heterozygous when the second largest share is > 0.1 and > 1 / (2 cn)."""
+        if not len(ent_pos):
+            return True
+        upos, site = np.unique(ent_pos, return_inverse=True)
+        key = (site.astype(np.int64) << 32) | (ent_code.astype(np.int64) << 1) | ent_neg.astype(np.int64)
+        ukey, inv = np.unique(key, return_inverse=True)
+        count = np.bincount(inv, weights=ent_cnt.astype(np.float64), minlength=len(ukey)).astype(np.int64)
+        usite = ukey >> 32
+        n_site = len(upos)
+        n_label = np.bincount(usite, minlength=n_site)
+        n_positive = np.bincount(usite[(ukey & 1) == 0], minlength=n_site)
+        big = count > 3
+        total = np.bincount(usite[big], weights=count[big].astype(np.float64), minlength=n_site)
+        # second largest kept count of every position: order labels by (position, -count)
+        order = np.lexsort((-count, usite))
+        so_site, so_count, so_big = usite[order], count[order], big[order]
+        first = np.r_[True, so_site[1:] != so_site[:-1]]
+        second_idx = np.flatnonzero(first) + 1
+        second_idx = second_idx[second_idx < len(order)]
+        ok = (so_site[second_idx] == so_site[second_idx - 1]) & so_big[second_idx]
+        second = np.zeros(n_site)
+        second[so_site[second_idx[ok]]] = so_count[second_idx[ok]]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            share = second / total                      # the reference's c / total in float64
+        het = (n_label >= 2) & (n_positive >= 1) & (total >= 20) & (second > 0) & (share > 0.1) & \
+              (share > (1 / (cn * 2)))
+        return not bool(het.any())
+
     def _isHomozygous(self, cn: int) -> bool:
         """isHomozygous (807-857) from per-variant positive / negative tallies of the kept reads."""
         if cn <= 1:
@@ -536,15 +597,7 @@ class AlleleTyping:
             ent_code = np.concatenate([code[hp], code[hn]])
             ent_neg = np.concatenate([np.zeros(int(hp.sum()), bool), np.ones(int(hn.sum()), bool)])
             ent_cnt = np.concatenate([pos[hp], neg[hn]])
-            upos, inv_site = np.unique(ent_pos, return_inverse=True)
-            n_keys = np.bincount(inv_site, minlength=len(upos))          # upper bound on distinct keys
-            n_posk = np.bincount(inv_site[~ent_neg], minlength=len(upos))
-            cand = np.nonzero((n_keys >= 2) & (n_posk >= 1))[0]
-            site: dict[int, dict[str, int]] = defaultdict(lambda: defaultdict(int))
-            sel = np.isin(inv_site, cand)
-            for p_, c_, ng, ct in zip(ent_pos[sel].tolist(), ent_code[sel].tolist(), ent_neg[sel].tolist(),
-                                      ent_cnt[sel].tolist()):
-                site[p_][f"*{c_}" if ng else f"{c_}"] += ct
+            return self._siteVerdict(ent_pos, ent_code, ent_neg, ent_cnt, cn)
         else:
             site = defaultdict(lambda: defaultdict(int))
             for (vpos, typ, label), np_, nn_ in zip(tab.describe(seen), pos.tolist(), neg.tolist()):

@@ -184,3 +184,38 @@ def test_first_of_sets_equals_stacked_table():
         cols = rng.permutation(20)[:13]
         ids = np.hstack([np.repeat(prev, len(cols), axis=0), np.tile(cols, len(prev))[:, None]])
         assert list(firstOfSets(prev, cols, 20)) == list(firstOccurrence(ids, 20))
+
+
+def test_site_verdict_equals_reference_loop():
+    """Vectorised isHomozygous tail (typing_mulit_allele.py:835-857) vs the reference's per-position loop."""
+    from collections import defaultdict
+    from kir_graph_amd.typing_mulit_allele import AlleleTyping
+    rng = np.random.default_rng(7)
+    verdicts = set()
+    for trial in range(300):
+        n = int(rng.integers(1, 60))
+        pos = rng.integers(0, 12, n)
+        code = rng.integers(65, 70, n)
+        neg = rng.integers(0, 2, n).astype(bool)
+        cnt = np.where(rng.random(n) < 0.3, rng.integers(1, 5, n), rng.integers(1, 60, n))
+        cn = int(rng.integers(2, 5))
+        site = defaultdict(lambda: defaultdict(int))
+        for p_, c_, ng, ct in zip(pos.tolist(), code.tolist(), neg.tolist(), cnt.tolist()):
+            site[p_][f"*{c_}" if ng else f"{c_}"] += ct
+        hits = 0
+        for obs in site.values():
+            if len(obs) <= 1 or all("*" in k for k in obs):
+                continue
+            counts = [c for c in sorted(obs.values(), reverse=True) if c > 3]
+            total = sum(counts)
+            if total < 20:
+                continue
+            major = [c / total for c in counts if c / total > 0.1]
+            if len(major) == 1:
+                continue
+            if major[1] > (1 / (cn * 2)):
+                hits += 1
+        got = AlleleTyping._siteVerdict(pos, code, neg, cnt, cn)
+        assert got == (hits == 0), trial
+        verdicts.add(got)
+    assert verdicts == {True, False}
