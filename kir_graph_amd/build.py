@@ -23,23 +23,43 @@ def outOfDate(lib: Path) -> bool:
     if not lib.exists():
         return True
     t = lib.stat().st_mtime
-    deps = [PKG / "csrc" / s for s in SOURCES] + [PKG / "csrc" / "gk_common.h", ROOT / "include" / "graphkir_hip.h"]
+    deps = [PKG / "csrc" / s for s in SOURCES] + list((PKG / "csrc").glob("*.h")) + [ROOT / "include" / "graphkir_hip.h"]
     return any(d.stat().st_mtime > t for d in deps)
 
 
+# Per-source extra flags (none needed at present).
+EXTRA_FLAGS: dict[str, list[str]] = {}
+
+
 def buildNative(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every source to an object (in parallel) under ``csrc/build/`` and link the library."""
     lib = PKG / "libgraphkir_hip.so"
     if not force and not outOfDate(lib):
         return lib
-    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", "-Wno-unused-result",
-           f"-I{ROOT / 'include'}", f"-I{PKG / 'csrc'}", "-o", str(lib)]
-    cmd += [str(PKG / "csrc" / s) for s in SOURCES]
+    objdir = PKG / "csrc" / "build"
+    objdir.mkdir(exist_ok=True)
+    base = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value",
+            "-Wno-unused-result", f"-I{ROOT / 'include'}", f"-I{PKG / 'csrc'}"]
+    jobs = []
+    for src in SOURCES:
+        obj = objdir / (src.rsplit(".", 1)[0] + ".o")
+        cmd = base + EXTRA_FLAGS.get(src, []) + ["-c", str(PKG / "csrc" / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    failed = []
+    for src, obj, proc in jobs:
+        out, err = proc.communicate()
+        if proc.returncode != 0:
+            failed.append(f"{src}:\n{out}\n{err}")
+    if failed:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib)] + [str(o) for _, o, _ in jobs]
     if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
+        print(" ".join(link))
+    res = subprocess.run(link, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+        raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
     return lib
 
 

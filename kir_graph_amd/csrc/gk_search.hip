@@ -33,10 +33,15 @@ constexpr int kBlockRows = 128;   // numpy PW_BLOCKSIZE
 constexpr int kChunkRows = 8192;  // numpy buffer size for add.reduce
 constexpr int kSpanRows = 1024;   // rows of the recursion sub-tree owned by one workgroup
 constexpr int kMaxSpans = 16;     // sub-trees per chunk (span sizes are in (512, 1024])
-constexpr int kLD = kBlockRows + 8;  // LDS column stride (doubles): +64 B de-phases the 4 allele groups
+constexpr int kHalfRows = 512;    // a span above this is run as its two child sub-trees (lane stack depth)
+constexpr int kMaxSlot = 3;       // deepest stack slot of a leaf program (4 lanes of a quad)
+constexpr int kLeafHold = 1 << 8;     // Leaf::n_add flag: park slot 0 (left child of the span is complete)
+constexpr int kLeafAddHold = 1 << 9;  // Leaf::n_add flag: slot 0 = parked + slot 0 (right child complete)
 constexpr int TT = 4, TA = 4;
 constexpr int kTileT = 8 * TT;    // 32 sets per workgroup
-constexpr int kTileA = 4 * TA;    // 16 candidate columns per workgroup
+constexpr int kTileA = 8 * TA;    // 32 candidate columns per workgroup
+constexpr int kPairs = kBlockRows / 2;   // row pairs of a staged leaf
+constexpr int kCP = 33;           // LDS columns per row pair (32 + 1 pad)
 constexpr int kMaxC = 8;          // alleles per set (copy number) supported
 constexpr int kLPer = kTileA * kBlockRows / kThreads;   // 8 staged L values per thread
 constexpr int kPPer = kTileT * kBlockRows / kThreads;   // 16 staged P values per thread
@@ -78,49 +83,61 @@ __device__ inline double group_sum8(double v) {
   return v;
 }
 
+// cross-lane moves inside a quad
+constexpr int kDppQuadNext = 0xF9;     // quad_perm:[1,2,3,3]  lane reads lane + 1 of its quad
+
+// The (max,+) contraction.  Workgroup = 32 previous sets x 32 candidate columns x one row span.
+// A quad of lanes owns a 4 x 4 block of outputs; lane k of the quad carries numpy's strided
+// accumulators 2k and 2k+1 (rows 8i+2k, 8i+2k+1 of the leaf), so its operands are the two
+// adjacent rows of a column = one ds_read_b128, the pair sum r[2k] + r[2k+1] of numpy's
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) is an in-lane add and two quad DPP steps finish it.  The
+// recursion stack of a sub-tree of <= 512 rows (depth <= 4) lives in the quad too: lane s holds slot s.
+// LDS tiles are [row pair][column][parity] with 33 columns per row pair: the b128 reads of a
+// 16-lane group then fall on 16 different bank quads (33 = 1 mod 16, column = 4 * group + y).
 template <bool kPrev>
-__global__ __launch_bounds__(kThreads, 3) void maxsum_chunks(const double* __restrict__ L, int64_t ld,
+__global__ __launch_bounds__(kThreads, 2) void maxsum_chunks(const double* __restrict__ L, int64_t ld,
                                                           const double* __restrict__ Pbase, int64_t ldp,
                                                           const int32_t* __restrict__ pcol, int n_sets,
                                                           const int32_t* __restrict__ cols, int n_cols,
                                                           const Span* __restrict__ spans,
                                                           const Leaf* __restrict__ leaves, int n_tiles,
                                                           int symmetric, double* __restrict__ partial) {
-  __shared__ double Pt[kTileT * kLD];
-  __shared__ double Lt[kTileA * kLD];
+  __shared__ double2 Pt[kPairs * kCP];
+  __shared__ double2 Lt[kPairs * kCP];
+  __shared__ double hold[(kThreads / 4) * TT * TA];   // parked left-child sums, one quad's 16 outputs each
   __shared__ int32_t p_col[kTileT];
   __shared__ int32_t l_col[kTileA];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int j = lane & 7, g = lane >> 3, gt = g >> 2, ga = g & 3;
+  const int k = lane & 3, g = lane >> 2, gt = g >> 3, ga = g & 7;
   const int tiles_a = (n_cols + kTileA - 1) / kTileA;
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
   // contiguous range of (span, tile) pairs with the tile index fastest -- all tiles of a span
-  // re-read the same <= 1024 rows of L from that XCD's L2 instead of from MALL / HBM.
+  // re-read the same <= 512 rows of L from that XCD's L2 instead of from MALL / HBM.
   const unsigned nb = gridDim.x, b = blockIdx.x;
   const unsigned xcd = b & 7u, kq = b >> 3, q8 = nb >> 3, r8 = nb & 7u;
   const unsigned logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kq;
   const int span_idx = (int)(logical / (unsigned)n_tiles);
   const int tile = (int)(logical % (unsigned)n_tiles);
   const int tile_t = tile / tiles_a, tile_a = tile % tiles_a;
-  const int t0 = tile_t * kTileT, a0 = tile_a * kTileA;
+  const int t0 = tile_t * kTileT, c0 = tile_a * kTileA;
   // symmetric launch (set t IS column t): sum max(L_t, L_a) == sum max(L_a, L_t) term by term, so
   // tiles entirely below the diagonal are left to the host, which mirrors them
-  if (symmetric && a0 + kTileA - 1 < t0) return;
+  if (symmetric && c0 + kTileA - 1 < t0) return;
   const Span span = spans[span_idx];
 
   if (tid < kTileT) p_col[tid] = (pcol && t0 + tid < n_sets) ? pcol[t0 + tid] : -1;
-  if (tid >= 64 && tid < 64 + kTileA) l_col[tid - 64] = (a0 + tid - 64 < n_cols) ? cols[a0 + tid - 64] : -1;
+  if (tid >= 64 && tid < 64 + kTileA) l_col[tid - 64] = (c0 + tid - 64 < n_cols) ? cols[c0 + tid - 64] : -1;
   __syncthreads();
 
   const int srow = tid & (kBlockRows - 1);   // staged row of this thread
   const int scol = __builtin_amdgcn_readfirstlane(tid >> 7);   // first staged column (0/1), then +2 per step
   double pre_l[kLPer], pre_p[kPPer];
-  // The staged columns of a wave are wave-uniform: their base addresses live in SGPR pairs, so a
-  // prefetch is one scalar add per column and a global_load with a 32-bit lane offset -- no
-  // per-lane 64-bit address arithmetic.  Columns past the edge are clamped to a valid one and
-  // their results never stored; the previous set's likelihood is ONE column (a column of L for
-  // single-allele sets, a column of the row-wise-max buffer otherwise).
+  // The staged columns of a wave are wave-uniform: their base addresses are scalar, so a prefetch
+  // is a scalar add per column and a global_load with a 32-bit lane offset -- no per-lane 64-bit
+  // address arithmetic.  Columns past the edge are clamped to a valid one and their results never
+  // stored; the previous set's likelihood is ONE column (a column of L for single-allele sets, a
+  // column of the row-wise-max buffer otherwise).
   const double* l_base[kLPer];
   const double* p_base[kPPer];
 #pragma unroll
@@ -145,12 +162,17 @@ __global__ __launch_bounds__(kThreads, 3) void maxsum_chunks(const double* __res
       pre_p[q] = kPrev ? *(const double*)((const char*)(p_base[q] + lf.start) + voff) : -__builtin_huge_val();
   };
 
-  const int t_loc = (wid * 2 + gt) * TT;   // first of TT consecutive sets of this lane
+  const int pc = (wid * 2 + gt) * TT;   // first of TT consecutive sets of this quad
+  const int lc = ga * TA;               // first of TA consecutive columns of this quad
   double st[TT][TA];
 #pragma unroll
   for (int x = 0; x < TT; ++x)
 #pragma unroll
     for (int y = 0; y < TA; ++y) st[x][y] = 0.0;
+  double* const my_hold = hold + (tid >> 2) * (TT * TA);   // written and read by lane 0 of the quad only
+  double* const Pd = reinterpret_cast<double*>(Pt);
+  double* const Ld = reinterpret_cast<double*>(Lt);
+  const int sdst = ((srow >> 1) * kCP + scol) * 2 + (srow & 1);   // staging slot of column scol
 
   Leaf lf = leaves[span.leaf_begin];
   prefetch(lf);
@@ -158,9 +180,9 @@ __global__ __launch_bounds__(kThreads, 3) void maxsum_chunks(const double* __res
     // ---- publish the prefetched rows, start fetching the next leaf
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < kLPer; ++q) Lt[(scol + 2 * q) * kLD + srow] = pre_l[q];
+    for (int q = 0; q < kLPer; ++q) Ld[sdst + 4 * q] = pre_l[q];
 #pragma unroll
-    for (int q = 0; q < kPPer; ++q) Pt[(scol + 2 * q) * kLD + srow] = pre_p[q];
+    for (int q = 0; q < kPPer; ++q) Pd[sdst + 4 * q] = pre_p[q];
     __syncthreads();
     const Leaf cur = lf;
     if (li + 1 < span.leaf_end) {
@@ -168,111 +190,121 @@ __global__ __launch_bounds__(kThreads, 3) void maxsum_chunks(const double* __res
       prefetch(lf);
     }
     const int len = cur.len;
-    // ---- numpy pairwise block: 8 strided accumulators = 8 lanes
-    double acc[TT][TA];
-    const int n8 = len - (len & 7);
-    if (len < 8) {
-#pragma unroll
-      for (int x = 0; x < TT; ++x)
-#pragma unroll
-        for (int y = 0; y < TA; ++y) acc[x][y] = 0.0;
-      for (int r = 0; r < len; ++r) {
-#pragma unroll
-        for (int x = 0; x < TT; ++x) {
-          const double p = Pt[(t_loc + x) * kLD + r];
-#pragma unroll
-          for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p, Lt[(ga + 4 * y) * kLD + r]);
-        }
-      }
-    } else {
+    const int n8 = len < 8 ? 0 : len - (len & 7);
+    double a[TT][TA];
+    if (n8) {
+      // ---- numpy pairwise block: accumulators 2k (x of the double2) and 2k+1 (y) in this lane
+      double a0[TT][TA], a1[TT][TA];
+      const double2* pp = Pt + k * kCP + pc;
+      const double2* lp = Lt + k * kCP + lc;
       {
-        double p[TT], l[TA];
+        double2 p[TT], l[TA];
 #pragma unroll
-        for (int x = 0; x < TT; ++x) p[x] = Pt[(t_loc + x) * kLD + j];
+        for (int x = 0; x < TT; ++x) p[x] = pp[x];
 #pragma unroll
-        for (int y = 0; y < TA; ++y) l[y] = Lt[(ga + 4 * y) * kLD + j];
+        for (int y = 0; y < TA; ++y) l[y] = lp[y];
 #pragma unroll
         for (int x = 0; x < TT; ++x)
 #pragma unroll
-          for (int y = 0; y < TA; ++y) acc[x][y] = vmax(p[x], l[y]);
+          for (int y = 0; y < TA; ++y) {
+            a0[x][y] = vmax(p[x].x, l[y].x);
+            a1[x][y] = vmax(p[x].y, l[y].y);
+          }
       }
-      // rows j+8, j+16, ...: two row-steps per trip; all 16 LDS reads are issued before the 64
-      // max/add so one LDS latency is paid per trip (the scheduler would otherwise sink each read
-      // next to its use and wait 8 times per row-step)
       const int n_it = n8 >> 3;
-      const double* pl = Pt + t_loc * kLD + j;
-      const double* ll = Lt + ga * kLD + j;
-      int it = 1;
-      for (; it + 1 < n_it; it += 2) {
-        double p0[TT], p1[TT], l0[TA], l1[TA];
+      for (int it = 1; it < n_it; ++it) {
+        double2 p[TT], l[TA];
 #pragma unroll
-        for (int x = 0; x < TT; ++x) { p0[x] = pl[x * kLD + it * 8]; p1[x] = pl[x * kLD + it * 8 + 8]; }
+        for (int x = 0; x < TT; ++x) p[x] = pp[it * 4 * kCP + x];
 #pragma unroll
-        for (int y = 0; y < TA; ++y) { l0[y] = ll[4 * y * kLD + it * 8]; l1[y] = ll[4 * y * kLD + it * 8 + 8]; }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int y = 0; y < TA; ++y) l[y] = lp[it * 4 * kCP + y];
+        __builtin_amdgcn_sched_barrier(0);   // all 8 reads in flight before the 64 max / add
+        // Software pipeline, order pinned: the add of term i is issued kLag max instructions after
+        // the max that feeds it, so no instruction waits on the f64 pipeline latency of its
+        // predecessor (the allocator otherwise pairs every max with its add through one register).
+        constexpr int kTerms = 2 * TT * TA, kLag = 2;
+        double t[kLag + 1];
 #pragma unroll
-        for (int x = 0; x < TT; ++x)
-#pragma unroll
-          for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p0[x], l0[y]);
-#pragma unroll
-        for (int x = 0; x < TT; ++x)
-#pragma unroll
-          for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p1[x], l1[y]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (it < n_it) {
-        double p0[TT], l0[TA];
-#pragma unroll
-        for (int x = 0; x < TT; ++x) p0[x] = pl[x * kLD + it * 8];
-#pragma unroll
-        for (int y = 0; y < TA; ++y) l0[y] = ll[4 * y * kLD + it * 8];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int x = 0; x < TT; ++x)
-#pragma unroll
-          for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p0[x], l0[y]);
-      }
-#pragma unroll
-      for (int x = 0; x < TT; ++x)
-#pragma unroll
-        for (int y = 0; y < TA; ++y) acc[x][y] = group_sum8(acc[x][y]);
-      for (int r = n8; r < len; ++r) {   // sequential tail, same in every lane
-#pragma unroll
-        for (int x = 0; x < TT; ++x) {
-          const double p = Pt[(t_loc + x) * kLD + r];
-#pragma unroll
-          for (int y = 0; y < TA; ++y) acc[x][y] += vmax(p, Lt[(ga + 4 * y) * kLD + r]);
+        for (int i = 0; i < kTerms + kLag; ++i) {
+          if (i < kTerms) {
+            const int x = (i >> 1) / TA, y = (i >> 1) % TA;
+            t[i % (kLag + 1)] = (i & 1) ? vmax(p[x].y, l[y].y) : vmax(p[x].x, l[y].x);
+          }
+          if (i >= kLag) {
+            const int jx = ((i - kLag) >> 1) / TA, jy = ((i - kLag) >> 1) % TA;
+            if ((i - kLag) & 1) a1[jx][jy] += t[(i - kLag) % (kLag + 1)];
+            else a0[jx][jy] += t[(i - kLag) % (kLag + 1)];
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-    }
-    // ---- push on the lane stack, then fold finished sub-trees
-    {
-      const bool mine = (j == cur.slot);
-#pragma unroll
-      for (int x = 0; x < TT; ++x)
-#pragma unroll
-        for (int y = 0; y < TA; ++y) st[x][y] = mine ? acc[x][y] : st[x][y];
-    }
-    for (int k = 0; k < cur.n_add; ++k) {
-      const int s = cur.slot - k;          // slot (s-1) += slot s: lane s-1 reads its right neighbour
-      const bool mine = (j == s - 1);
 #pragma unroll
       for (int x = 0; x < TT; ++x)
 #pragma unroll
         for (int y = 0; y < TA; ++y) {
-          const double other = dpp_f64<kDppShl1>(st[x][y]);
+          double v = a0[x][y] + a1[x][y];            // r[2k] + r[2k+1]
+          v += dpp_f64<kDppSwap1>(v);                // (r0+r1)+(r2+r3) | (r4+r5)+(r6+r7)
+          v += dpp_f64<kDppSwap2>(v);                // both halves; a + b == b + a bit for bit
+          a[x][y] = v;
+        }
+    } else {
+#pragma unroll
+      for (int x = 0; x < TT; ++x)
+#pragma unroll
+        for (int y = 0; y < TA; ++y) a[x][y] = 0.0;
+    }
+    for (int r = n8; r < len; ++r) {   // sequential tail (the whole leaf when it is shorter than 8), same in every lane
+      const int o = (r >> 1) * kCP * 2 + (r & 1);
+#pragma unroll
+      for (int x = 0; x < TT; ++x) {
+        const double p = Pd[o + (pc + x) * 2];
+#pragma unroll
+        for (int y = 0; y < TA; ++y) a[x][y] += vmax(p, Ld[o + (lc + y) * 2]);
+      }
+    }
+    // ---- push on the lane stack, then fold finished sub-trees
+    {
+      const bool mine = (k == cur.slot);
+#pragma unroll
+      for (int x = 0; x < TT; ++x)
+#pragma unroll
+        for (int y = 0; y < TA; ++y) st[x][y] = mine ? a[x][y] : st[x][y];
+    }
+    const int n_fold = cur.n_add & 0xFF;
+    for (int f = 0; f < n_fold; ++f) {
+      const int s = cur.slot - f;          // slot (s-1) += slot s: lane s-1 reads its right neighbour
+      const bool mine = (k == s - 1);
+#pragma unroll
+      for (int x = 0; x < TT; ++x)
+#pragma unroll
+        for (int y = 0; y < TA; ++y) {
+          const double other = dpp_f64<kDppQuadNext>(st[x][y]);
           st[x][y] = mine ? st[x][y] + other : st[x][y];
         }
     }
+    // a span of more than 512 rows is its two children run one after the other on the same four
+    // slots: the left child's sum (slot 0 = lane 0 of the quad) is parked, then added in-lane
+    if ((cur.n_add & kLeafHold) && k == 0) {
+#pragma unroll
+      for (int x = 0; x < TT; ++x)
+#pragma unroll
+        for (int y = 0; y < TA; ++y) my_hold[x * TA + y] = st[x][y];
+    }
+    if ((cur.n_add & kLeafAddHold) && k == 0) {
+#pragma unroll
+      for (int x = 0; x < TT; ++x)
+#pragma unroll
+        for (int y = 0; y < TA; ++y) st[x][y] = my_hold[x * TA + y] + st[x][y];
+    }
   }
-  if (j == 0) {
+  if (k == 0) {
 #pragma unroll
     for (int x = 0; x < TT; ++x) {
-      const int t = t0 + t_loc + x;
+      const int t = t0 + pc + x;
 #pragma unroll
       for (int y = 0; y < TA; ++y) {
-        const int a = a0 + ga + 4 * y;
-        if (t < n_sets && a < n_cols) partial[((int64_t)span_idx * n_sets + t) * n_cols + a] = st[x][y];
+        const int c = c0 + lc + y;
+        if (t < n_sets && c < n_cols) partial[((int64_t)span_idx * n_sets + t) * n_cols + c] = st[x][y];
       }
     }
   }
@@ -330,9 +362,9 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
 #pragma unroll
   for (int q = 1; q <= kC; ++q) inv[q] = 1.0 / (double)q;   // exact IEEE quotients, as numpy's bool / int
   inv[0] = 0.0;
-  double st[kC];
+  double st[kC], hold[kC];
 #pragma unroll
-  for (int q = 0; q < kC; ++q) st[q] = 0.0;
+  for (int q = 0; q < kC; ++q) st[q] = hold[q] = 0.0;
 
   // acc += the row's shares; staged row index r (0..kFracLd)
   auto add_terms = [&](int r, double* acc) {
@@ -392,7 +424,8 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
 #pragma unroll
       for (int q = 0; q < kC; ++q) st[q] = mine ? acc[q] : st[q];
     }
-    for (int a = 0; a < cur.n_add; ++a) {
+    const int n_fold = cur.n_add & 0xFF;
+    for (int a = 0; a < n_fold; ++a) {
       const int s = cur.slot - a;
       const bool mine = (j == s - 1);
 #pragma unroll
@@ -400,6 +433,14 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
         const double other = dpp_f64<kDppShl1>(st[q]);
         st[q] = mine ? st[q] + other : st[q];
       }
+    }
+    if (cur.n_add & kLeafHold) {      // left child of the span complete: park its sum (lane 0)
+#pragma unroll
+      for (int q = 0; q < kC; ++q) hold[q] = st[q];
+    }
+    if (cur.n_add & kLeafAddHold) {   // right child complete
+#pragma unroll
+      for (int q = 0; q < kC; ++q) st[q] = hold[q] + st[q];
     }
   }
   if (j == 0 && live) {
@@ -448,7 +489,16 @@ int chunk_nodes(Program& p, int chunk, int64_t chunk_row0, int start, int n, int
     Span s;
     s.row0 = chunk_row0 + start;
     s.leaf_begin = (int32_t)p.leaves.size();
-    span_leaves(0, n, 0, p.leaves);
+    if (n <= kHalfRows) {
+      span_leaves(0, n, 0, p.leaves);
+    } else {   // two children on the same slots: park the left sum, add it to the right one
+      int n2 = n / 2;
+      n2 -= n2 % 8;
+      span_leaves(0, n2, 0, p.leaves);
+      p.leaves.back().n_add |= kLeafHold;
+      span_leaves(n2, n - n2, 0, p.leaves);
+      p.leaves.back().n_add |= kLeafAddHold;
+    }
     s.leaf_end = (int32_t)p.leaves.size();
     s.chunk = chunk;
     s.pad = 0;
@@ -500,6 +550,7 @@ int upload_program(gk_ctx* ctx, int64_t n_rows, const int32_t* ids, size_t n_ids
   build_program(n_rows, p);
   for (size_t q = 0; q + 1 < p.chunk_span0.size(); ++q)
     GK_REQUIRE(p.chunk_span0[q + 1] - p.chunk_span0[q] <= kMaxSpans, "too many spans in a chunk");
+  for (const Leaf& lf : p.leaves) GK_REQUIRE(lf.slot <= kMaxSlot, "leaf program deeper than the lane stack");
   std::vector<char> buf;
   const size_t o_leaf = put(buf, p.leaves.data(), p.leaves.size());
   const size_t o_span = put(buf, p.spans.data(), p.spans.size());
