@@ -47,18 +47,26 @@ def build_inputs(seed: int, n_pairs: int, index_seed: int = 2022):
     return sidx, gidx, sample, rec, table
 
 
-def one_step(dev, dindex, gidx, mates_buf, table, gene_cn, method):
-    """Tabulation + typing of one sample whose records are resident in HBM."""
+def run_steps(n_steps, dev, dindex, gidx, mates_buf, table, gene_cn, method):
+    """``n_steps`` samples: tabulation + typing of records resident in HBM.
+
+    Like a cohort run, the samples go through ``cohort.prefetched``: the tabulation of sample k+1
+    (device stream of ``dev``) is issued while sample k is typed (worker streams).  Every
+    tabulation and every typing of the ``n_steps`` samples starts and ends inside this call."""
+    from kir_graph_amd.cohort import prefetched
     from kir_graph_amd.engine import Tabulation
     from kir_graph_amd.hisat2 import SampleData
-    from kir_graph_amd.kir_typing import selectKirTypingModel
-    tab = Tabulation(dindex, mates_buf)
-    data = SampleData(tab, gidx, None, ins_strings=table.strings)
-    typer = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
-    calls, warn = typer.typing(gene_cn)
-    n_valid = tab.n_valid
-    tab.close()
-    return calls, warn, n_valid, typer
+    from kir_graph_amd.kir_typing import hostThreads, selectKirTypingModel
+    out = None
+    depth = int(os.environ.get("GK_PREFETCH", "1"))
+    ingest = dev.worker(hostThreads())      # a context of its own: the typing threads use workers 0..n-1
+    for tab in prefetched(range(n_steps), lambda _: Tabulation(dindex, mates_buf, dev=ingest), depth=depth):
+        data = SampleData(tab, gidx, None, ins_strings=table.strings)
+        typer = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
+        calls, warn = typer.typing(gene_cn)
+        out = (calls, warn, tab.n_valid, typer)
+        tab.close()
+    return out
 
 
 def cpu_baseline(sidx, gidx, gene_cn, method, n_pairs, seed):
@@ -125,14 +133,14 @@ def main():
             if backend == "nccl":
                 torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step(dev, dindex, gidx, mates, table, gene_cn, args.method)
+    if args.warmup:
+        run_steps(args.warmup, dev, dindex, gidx, mates, table, gene_cn, args.method)
     if args.profile_host:
         import cProfile
         import pstats
         pr = cProfile.Profile()
         pr.enable()
-        one_step(dev, dindex, gidx, mates, table, gene_cn, args.method)
+        run_steps(1, dev, dindex, gidx, mates, table, gene_cn, args.method)
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
     def all_devices():
@@ -144,9 +152,7 @@ def main():
         d.call_log = []
     barrier()
     t0 = time.perf_counter()
-    n_valid = 0
-    for _ in range(args.steps):
-        calls, warn, n_valid, typer = one_step(dev, dindex, gidx, mates, table, gene_cn, args.method)
+    calls, warn, n_valid, typer = run_steps(args.steps, dev, dindex, gidx, mates, table, gene_cn, args.method)
     barrier()
     elapsed = time.perf_counter() - t0
     prof, call_log = {}, []

@@ -16,6 +16,26 @@ import os
 import numpy as np
 
 
+def prefetched(items, prepare, depth: int = 1):
+    """Yield ``prepare(item)`` for every item, in order, preparing up to ``depth`` items ahead on a
+    helper thread while the caller works on the current one.
+
+    Samples of a cohort are independent, so the ingest + tabulation of the next sample (native code:
+    the GIL is released, its kernels run on the device's own stream) overlaps the typing of the
+    current one, which runs on the worker streams.  An exception in ``prepare`` is re-raised at the
+    matching ``next()``."""
+    from concurrent.futures import ThreadPoolExecutor
+    items = iter(items)
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="gk-prefetch") as pool:
+        pending = []
+        for item in items:
+            pending.append(pool.submit(prepare, item))
+            if len(pending) > depth:
+                yield pending.pop(0).result()
+        while pending:
+            yield pending.pop(0).result()
+
+
 def shardSamples(n_samples: int, world: int) -> list[list[int]]:
     """Round-robin assignment of sample indices to ranks (deterministic, known to every rank)."""
     return [list(range(r, n_samples, world)) for r in range(world)]

@@ -52,8 +52,9 @@ class DeviceIndex:
 class Tabulation:
     """Result of ``gk_tabulate`` for one sample (replaces the ``.variant.json`` hand-off)."""
 
-    def __init__(self, dindex: DeviceIndex, mates, novel_base: int = 0):
-        self.dev, self.dindex = dindex.dev, dindex
+    def __init__(self, dindex: DeviceIndex, mates, novel_base: int = 0, dev: Device | None = None):
+        """``dev``: context (stream) that runs the tabulation; defaults to the index's own."""
+        self.dev, self.dindex = dev or dindex.dev, dindex
         if isinstance(mates, np.ndarray):
             assert mates.dtype == _lib.MATE_DTYPE
             self.mates = self.dev.put(mates)

@@ -126,7 +126,9 @@ class TypingWithPosNegAllele(Typing):
         if tab is None:
             base = self._data.tab
             k = getattr(self._local, "slot", None)
-            dev = base.dev if k is None else base.dev.worker(k)
+            # never the tabulation's own context: a cohort run may already be tabulating the next
+            # sample there (cohort.prefetched), and a context serves one host thread at a time
+            dev = base.dev.worker(0 if k is None else k)
             tab = self._local.tab = base.on(dev)
             self._local.logs = sharedLogTable(dev)
         return tab, self._local.logs
