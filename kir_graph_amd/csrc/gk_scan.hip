@@ -66,6 +66,57 @@ __global__ __launch_bounds__(kThreads) void scatter_selected(const uint32_t* fla
   if (i < n && flag[i]) out[pos[i]] = values ? values[i] : (int32_t)i;
 }
 
+// ---- two-launch stable compaction for up to kCompactMaxBlocks * kCompactTile items: per-block
+// counts, then every block sums the counts before it (<= 4096 loads) and scatters its own items.
+constexpr int kCompactItems = 4;
+constexpr int kCompactTile = kThreads * kCompactItems;   // 1024 items per block
+constexpr int kCompactMaxBlocks = 4096;
+
+__global__ __launch_bounds__(kThreads) void compact_count(const uint32_t* __restrict__ flag, int64_t n,
+                                                          uint32_t* __restrict__ block_count) {
+  __shared__ uint32_t wave_tot[kThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)tid * kCompactItems;
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < kCompactItems; ++k) c += (base + k < n && flag[base + k]) ? 1u : 0u;
+  const uint32_t incl = wave_incl_scan(c, lane);
+  if (lane == 63) wave_tot[wid] = incl;
+  __syncthreads();
+  if (tid == 0) block_count[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+__global__ __launch_bounds__(kThreads) void compact_scatter(const uint32_t* __restrict__ flag,
+                                                            const int32_t* __restrict__ values, int64_t n,
+                                                            const uint32_t* __restrict__ block_count,
+                                                            int32_t* __restrict__ out, uint32_t* __restrict__ total) {
+  __shared__ uint32_t wave_tot[kThreads / 64];
+  __shared__ uint32_t wave_pre[kThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // items kept by the blocks before this one
+  uint32_t before = 0;
+  for (int b = tid; b < (int)blockIdx.x; b += kThreads) before += block_count[b];
+  before = wave_incl_scan(before, lane);
+  if (lane == 63) wave_pre[wid] = before;
+  const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)tid * kCompactItems;
+  bool keep[kCompactItems];
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < kCompactItems; ++k) {
+    keep[k] = base + k < n && flag[base + k];
+    c += keep[k] ? 1u : 0u;
+  }
+  const uint32_t incl = wave_incl_scan(c, lane);
+  if (lane == 63) wave_tot[wid] = incl;
+  __syncthreads();
+  uint32_t pos = wave_pre[0] + wave_pre[1] + wave_pre[2] + wave_pre[3] + incl - c;
+  for (int w = 0; w < wid; ++w) pos += wave_tot[w];
+#pragma unroll
+  for (int k = 0; k < kCompactItems; ++k)
+    if (keep[k]) out[pos++] = values ? values[base + k] : (int32_t)(base + k);
+  if (blockIdx.x == gridDim.x - 1 && tid == kThreads - 1) *total = pos;
+}
+
 }  // namespace
 
 static int scan_rec(gk_ctx* ctx, uint32_t* d, int64_t n, uint32_t* sums_area, uint32_t* d_total) {
@@ -102,6 +153,22 @@ int gk_compact(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int
                int64_t* n_out) {
   if (n <= 0) {
     if (n_out) *n_out = 0;
+    return GK_OK;
+  }
+  const int64_t blocks2 = (n + kCompactTile - 1) / kCompactTile;
+  if (blocks2 <= kCompactMaxBlocks) {
+    uint32_t* cnt = nullptr;
+    GK_HIP(gk_pool_malloc(ctx, (void**)&cnt, (size_t)(blocks2 + 1) * sizeof(uint32_t)));
+    GK_PROF(ctx, GK_K_SCAN, hipLaunchKernelGGL(compact_count, dim3((unsigned)blocks2), dim3(kThreads), 0, ctx->stream,
+                                             d_flag, n, cnt));
+    GK_PROF(ctx, GK_K_SCAN, hipLaunchKernelGGL(compact_scatter, dim3((unsigned)blocks2), dim3(kThreads), 0, ctx->stream,
+                                             d_flag, d_values, n, cnt, d_out, cnt + blocks2));
+    GK_HIP(hipGetLastError());
+    uint32_t total = 0;
+    GK_HIP(hipMemcpyAsync(&total, cnt + blocks2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(hipStreamSynchronize(ctx->stream));
+    gk_pool_free(ctx, cnt);
+    if (n_out) *n_out = total;
     return GK_OK;
   }
   uint32_t* pos = nullptr;
