@@ -222,6 +222,17 @@ int gk_packer_error(gk_packer* pk, int32_t* kind, int64_t* line_index);
 int gk_packer_records(gk_packer* pk, gk_mate* mates_out, int64_t* pair_lines_out);
 const char* gk_packer_string(gk_packer* pk, int64_t i);
 
+/* ---- host ingest (no GPU, no samtools): BGZF / BAM -> SAM text lines, replacing the
+ * `samtools sort -n bam -O SAM` of readBam (hisat2.py:103-110).  name_sorted != 0 orders the records
+ * by query name (digit runs as numbers), READ1 before READ2, ties in file order; 0 keeps file order.
+ * gk_bam_next fills the buffer with whole '\n'-terminated lines; *n_written == 0 marks the end. */
+typedef struct gk_bam gk_bam;
+int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out);
+int gk_bam_close(gk_bam* bam);
+int gk_bam_info(gk_bam* bam, int64_t* n_records, int64_t* header_bytes, int32_t* n_ref);
+int gk_bam_header(gk_bam* bam, char* text_out, int64_t capacity);
+int gk_bam_next(gk_bam* bam, char* text_out, int64_t capacity, int64_t* n_written);
+
 /* ---- read depth: replaces `samtools depth -aa {name}.no_multi.bam` (samtools_utils.py:9-14).
  * Depth of every backbone position from the M runs of the filter-passing pairs of a tabulation made
  * by gk_tabulate (NH == 1 only unless `multiple`).  gene_off[g] = start of backbone g in the

@@ -9,7 +9,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 SOURCES = ["gk_runtime.hip", "gk_scan.hip", "gk_tabulate.hip", "gk_typing.hip", "gk_lut.hip",
-           "gk_search.hip", "gk_em.hip", "gk_cn.hip", "gk_depth.hip", "gk_sampack.cpp"]
+           "gk_search.hip", "gk_em.hip", "gk_cn.hip", "gk_depth.hip", "gk_sampack.cpp", "gk_bamread.cpp"]
 
 
 def hipcc() -> str:
@@ -54,7 +54,7 @@ def buildNative(force: bool = False, verbose: bool = False) -> Path:
             failed.append(f"{src}:\n{out}\n{err}")
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
-    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib)] + [str(o) for _, o, _ in jobs]
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib)] + [str(o) for _, o, _ in jobs] + ["-lz"]
     if verbose:
         print(" ".join(link))
     res = subprocess.run(link, capture_output=True, text=True)

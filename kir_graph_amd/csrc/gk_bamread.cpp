@@ -1,0 +1,343 @@
+// Host-side ingest: BGZF / BAM -> name-collated SAM text (no GPU work, no samtools).
+//
+// Native counterpart of hisat2.readBam (hisat2.py:103-110), which shells out to
+// `samtools sort -n bam -O SAM` and splits its stdout into lines: the file is inflated with zlib,
+// the alignment records are ordered the way a query-name sort orders them (natural order of the read
+// names -- digit runs compare as numbers --, READ1 before READ2, ties in input order) and rendered
+// as SAM text lines, which then flow through the same packer as a `.sam` input (gk_sampack.cpp).
+// Format: SAM/BAM specification v1 sections 4.1 (BGZF) and 4.2 (BAM records).
+//
+// samtools is not part of this image, so the rendering and the order are checked against BAM files
+// written by the test suite's own encoder, not against samtools output ("parity unpinned").
+#include <zlib.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "graphkir_hip.h"
+
+void gk_set_error(const char* fmt, ...);
+
+struct gk_bam {
+  std::vector<uint8_t> data;            // inflated BAM stream
+  std::string header;                   // SAM header text ('@' lines)
+  std::vector<std::string> ref_names;
+  struct Rec { uint64_t off; uint32_t size; };
+  std::vector<Rec> recs;                // in output order after sorting
+  size_t next = 0;                      // next record to render
+  std::string line;                     // rendered line that did not fit the caller's buffer yet
+};
+
+namespace {
+
+inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+inline int32_t rds32(const uint8_t* p) { return (int32_t)rd32(p); }
+inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | p[1] << 8); }
+
+// Every gzip member of the BGZF file, inflated back to back.
+bool inflate_members(const std::vector<uint8_t>& in, std::vector<uint8_t>& out) {
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
+  out.clear();
+  out.reserve(in.size() * 4);
+  std::vector<uint8_t> buf(1 << 20);
+  zs.next_in = const_cast<Bytef*>(in.data());
+  zs.avail_in = 0;
+  size_t consumed = 0;
+  bool ok = true;
+  while (consumed < in.size() || zs.avail_in) {
+    if (zs.avail_in == 0) {
+      const size_t take = std::min<size_t>(in.size() - consumed, 1u << 30);
+      zs.next_in = const_cast<Bytef*>(in.data() + consumed);
+      zs.avail_in = (uInt)take;
+      consumed += take;
+    }
+    zs.next_out = buf.data();
+    zs.avail_out = (uInt)buf.size();
+    const int rc = inflate(&zs, Z_NO_FLUSH);
+    out.insert(out.end(), buf.data(), buf.data() + (buf.size() - zs.avail_out));
+    if (rc == Z_STREAM_END) {
+      if (zs.avail_in == 0 && consumed >= in.size()) break;
+      if (inflateReset(&zs) != Z_OK) { ok = false; break; }   // next member
+    } else if (rc != Z_OK) {
+      ok = false;
+      break;
+    }
+  }
+  inflateEnd(&zs);
+  return ok;
+}
+
+// Query-name order: characters compare by code, except that where both names have a digit the two
+// digit runs compare as numbers (leading zeros skipped, more digits = larger); equal numbers written
+// with a different count of leading zeros order the shorter spelling last.
+int name_order(const char* a0, const char* b0) {
+  const unsigned char *a = (const unsigned char*)a0, *b = (const unsigned char*)b0;
+  const unsigned char *pa = a, *pb = b;
+  while (*pa && *pb) {
+    if (isdigit(*pa) && isdigit(*pb)) {
+      while (*pa == '0') ++pa;
+      while (*pb == '0') ++pb;
+      const unsigned char *ea = pa, *eb = pb;
+      while (isdigit(*ea)) ++ea;
+      while (isdigit(*eb)) ++eb;
+      const long la = ea - pa, lb = eb - pb;
+      if (la != lb) return la > lb ? 1 : -1;
+      for (long i = 0; i < la; ++i)
+        if (pa[i] != pb[i]) return (int)pa[i] - (int)pb[i];
+      pa = ea;
+      pb = eb;
+      if (pa - a != pb - b) return (pa - a) < (pb - b) ? 1 : -1;
+    } else {
+      if (*pa != *pb) return (int)*pa - (int)*pb;
+      ++pa;
+      ++pb;
+    }
+  }
+  return *pa ? 1 : *pb ? -1 : 0;
+}
+
+void append_int(std::string& s, long long v) {
+  char tmp[24];
+  const int n = snprintf(tmp, sizeof(tmp), "%lld", v);
+  s.append(tmp, (size_t)n);
+}
+
+// one optional field "TAG:TYPE:VALUE"; returns the bytes consumed or 0 on a malformed field
+size_t render_tag(const uint8_t* p, size_t left, std::string& s) {
+  if (left < 3) return 0;
+  s.push_back((char)p[0]); s.push_back((char)p[1]); s.push_back(':');
+  const char type = (char)p[2];
+  const uint8_t* v = p + 3;
+  left -= 3;
+  auto need = [&](size_t n) { return left >= n; };
+  switch (type) {
+    case 'A': if (!need(1)) return 0; s += "A:"; s.push_back((char)v[0]); return 4;
+    case 'c': if (!need(1)) return 0; s += "i:"; append_int(s, (int8_t)v[0]); return 4;
+    case 'C': if (!need(1)) return 0; s += "i:"; append_int(s, v[0]); return 4;
+    case 's': if (!need(2)) return 0; s += "i:"; append_int(s, (int16_t)rd16(v)); return 5;
+    case 'S': if (!need(2)) return 0; s += "i:"; append_int(s, rd16(v)); return 5;
+    case 'i': if (!need(4)) return 0; s += "i:"; append_int(s, rds32(v)); return 7;
+    case 'I': if (!need(4)) return 0; s += "i:"; append_int(s, rd32(v)); return 7;
+    case 'f': {
+      if (!need(4)) return 0;
+      float f; const uint32_t u = rd32(v); memcpy(&f, &u, 4);
+      char tmp[32]; const int n = snprintf(tmp, sizeof(tmp), "%g", f);
+      s += "f:"; s.append(tmp, (size_t)n);
+      return 7;
+    }
+    case 'Z': case 'H': {
+      const void* z = memchr(v, 0, left);
+      if (!z) return 0;
+      const size_t n = (const uint8_t*)z - v;
+      s.push_back(type); s.push_back(':'); s.append((const char*)v, n);
+      return 3 + n + 1;
+    }
+    case 'B': {
+      if (!need(5)) return 0;
+      const char sub = (char)v[0];
+      const uint32_t count = rd32(v + 1);
+      const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0;
+      if (!w || !need(5 + (size_t)count * w)) return 0;
+      s += "B:"; s.push_back(sub);
+      const uint8_t* e = v + 5;
+      for (uint32_t i = 0; i < count; ++i, e += w) {
+        s.push_back(',');
+        switch (sub) {
+          case 'c': append_int(s, (int8_t)e[0]); break;
+          case 'C': append_int(s, e[0]); break;
+          case 's': append_int(s, (int16_t)rd16(e)); break;
+          case 'S': append_int(s, rd16(e)); break;
+          case 'i': append_int(s, rds32(e)); break;
+          case 'I': append_int(s, rd32(e)); break;
+          default: {
+            float f; const uint32_t u = rd32(e); memcpy(&f, &u, 4);
+            char tmp[32]; const int n = snprintf(tmp, sizeof(tmp), "%g", f);
+            s.append(tmp, (size_t)n);
+          }
+        }
+      }
+      return 3 + 5 + (size_t)count * w;
+    }
+    default: return 0;
+  }
+}
+
+// SAM text of one alignment record (without the trailing newline)
+bool render(const gk_bam& b, const gk_bam::Rec& r, std::string& s) {
+  const uint8_t* p = b.data.data() + r.off;   // first byte after block_size
+  if (r.size < 32) return false;
+  const int32_t ref_id = rds32(p), pos = rds32(p + 4);
+  const uint32_t l_name = p[8], mapq = p[9], n_cig = rd16(p + 12), flag = rd16(p + 14);
+  const uint32_t l_seq = rd32(p + 16);
+  const int32_t next_ref = rds32(p + 20), next_pos = rds32(p + 24), tlen = rds32(p + 28);
+  const size_t fixed = 32, need = fixed + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
+  if (need > r.size || l_name == 0) return false;
+  const uint8_t* name = p + fixed;
+  const uint8_t* cig = name + l_name;
+  const uint8_t* seq = cig + 4ull * n_cig;
+  const uint8_t* qual = seq + (l_seq + 1) / 2;
+  const uint8_t* tags = qual + l_seq;
+  const uint8_t* end = p + r.size;
+  auto ref_name = [&](int32_t id) -> const char* {
+    return (id >= 0 && (size_t)id < b.ref_names.size()) ? b.ref_names[(size_t)id].c_str() : "*";
+  };
+  s.clear();
+  s.append((const char*)name, strnlen((const char*)name, l_name));
+  s.push_back('\t'); append_int(s, flag);
+  s.push_back('\t'); s += ref_name(ref_id);
+  s.push_back('\t'); append_int(s, (long long)pos + 1);
+  s.push_back('\t'); append_int(s, mapq);
+  s.push_back('\t');
+  if (n_cig == 0) {
+    s.push_back('*');
+  } else {
+    for (uint32_t i = 0; i < n_cig; ++i) {
+      const uint32_t c = rd32(cig + 4ull * i), op = c & 15u;
+      append_int(s, c >> 4);
+      s.push_back(op < 9 ? "MIDNSHP=X"[op] : '?');
+    }
+  }
+  s.push_back('\t');
+  if (next_ref < 0) s.push_back('*');
+  else if (next_ref == ref_id) s.push_back('=');
+  else s += ref_name(next_ref);
+  s.push_back('\t'); append_int(s, (long long)next_pos + 1);
+  s.push_back('\t'); append_int(s, tlen);
+  s.push_back('\t');
+  if (l_seq == 0) {
+    s.push_back('*');
+  } else {
+    static const char kBase[] = "=ACMGRSVTWYHKDBN";
+    for (uint32_t i = 0; i < l_seq; ++i) s.push_back(kBase[(seq[i >> 1] >> ((~i & 1u) << 2)) & 15u]);
+  }
+  s.push_back('\t');
+  if (l_seq == 0 || qual[0] == 0xFF) {
+    s.push_back('*');
+  } else {
+    for (uint32_t i = 0; i < l_seq; ++i) s.push_back((char)(qual[i] + 33));
+  }
+  while (tags < end) {
+    s.push_back('\t');
+    const size_t used = render_tag(tags, (size_t)(end - tags), s);
+    if (!used) return false;
+    tags += used;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
+  if (!path || !out) { gk_set_error("null argument"); return GK_ERR_ARG; }
+  FILE* f = fopen(path, "rb");
+  if (!f) { gk_set_error("cannot open %s", path); return GK_ERR_ARG; }
+  std::vector<uint8_t> raw;
+  {
+    std::vector<uint8_t> buf(1 << 22);
+    size_t n;
+    while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) raw.insert(raw.end(), buf.data(), buf.data() + n);
+    fclose(f);
+  }
+  gk_bam* b = new gk_bam();
+  if (!inflate_members(raw, b->data)) {
+    delete b;
+    gk_set_error("%s is not a BGZF / gzip stream or is truncated", path);
+    return GK_ERR_ARG;
+  }
+  raw.clear(); raw.shrink_to_fit();
+  const std::vector<uint8_t>& d = b->data;
+  auto bad = [&](const char* what) {
+    gk_set_error("%s: malformed BAM (%s)", path, what);
+    delete b;
+    return GK_ERR_ARG;
+  };
+  if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) return bad("magic");
+  size_t o = 4;
+  const uint32_t l_text = rd32(d.data() + o); o += 4;
+  if (o + l_text + 4 > d.size()) return bad("header text");
+  b->header.assign((const char*)d.data() + o, strnlen((const char*)d.data() + o, l_text));
+  o += l_text;
+  const uint32_t n_ref = rd32(d.data() + o); o += 4;
+  for (uint32_t i = 0; i < n_ref; ++i) {
+    if (o + 4 > d.size()) return bad("reference list");
+    const uint32_t l_name = rd32(d.data() + o); o += 4;
+    if (o + l_name + 4 > d.size() || l_name == 0) return bad("reference name");
+    b->ref_names.emplace_back((const char*)d.data() + o, strnlen((const char*)d.data() + o, l_name));
+    o += l_name + 4;   // name, l_ref
+  }
+  while (o + 4 <= d.size()) {
+    const uint32_t size = rd32(d.data() + o);
+    o += 4;
+    if (size < 32 || o + size > d.size()) return bad("alignment block");
+    b->recs.push_back({(uint64_t)o, size});
+    o += size;
+  }
+  if (o != d.size()) return bad("trailing bytes");
+  if (name_sorted) {
+    const uint8_t* base = d.data();
+    std::stable_sort(b->recs.begin(), b->recs.end(), [base](const gk_bam::Rec& x, const gk_bam::Rec& y) {
+      const uint8_t *px = base + x.off, *py = base + y.off;
+      const int t = name_order((const char*)px + 32, (const char*)py + 32);
+      if (t) return t < 0;
+      return (rd16(px + 14) & 0xC0u) < (rd16(py + 14) & 0xC0u);   // READ1 (0x40) before READ2 (0x80)
+    });
+  }
+  *out = b;
+  return GK_OK;
+}
+
+int gk_bam_close(gk_bam* b) {
+  delete b;
+  return GK_OK;
+}
+
+int gk_bam_info(gk_bam* b, int64_t* n_records, int64_t* header_bytes, int32_t* n_ref) {
+  if (!b) { gk_set_error("null handle"); return GK_ERR_ARG; }
+  if (n_records) *n_records = (int64_t)b->recs.size();
+  if (header_bytes) *header_bytes = (int64_t)b->header.size();
+  if (n_ref) *n_ref = (int32_t)b->ref_names.size();
+  return GK_OK;
+}
+
+int gk_bam_header(gk_bam* b, char* text_out, int64_t capacity) {
+  if (!b || !text_out || capacity < (int64_t)b->header.size()) { gk_set_error("header buffer too small"); return GK_ERR_ARG; }
+  memcpy(text_out, b->header.data(), b->header.size());
+  return GK_OK;
+}
+
+// Whole lines ('\n' terminated) in output order until the buffer is full; *n_written == 0 at the end.
+int gk_bam_next(gk_bam* b, char* text_out, int64_t capacity, int64_t* n_written) {
+  if (!b || !text_out || !n_written || capacity < 1) { gk_set_error("bad arguments"); return GK_ERR_ARG; }
+  int64_t w = 0;
+  while (true) {
+    if (b->line.empty()) {
+      if (b->next >= b->recs.size()) break;
+      if (!render(*b, b->recs[b->next], b->line)) {
+        gk_set_error("malformed alignment record %zu", b->next);
+        return GK_ERR_ARG;
+      }
+      b->line.push_back('\n');
+      ++b->next;
+    }
+    if ((int64_t)b->line.size() > capacity - w) {
+      if (w == 0) { gk_set_error("line of %zu bytes does not fit the buffer", b->line.size()); return GK_ERR_CAPACITY; }
+      break;
+    }
+    memcpy(text_out + w, b->line.data(), b->line.size());
+    w += (int64_t)b->line.size();
+    b->line.clear();
+  }
+  *n_written = w;
+  return GK_OK;
+}
+
+}  // extern "C"

@@ -66,12 +66,20 @@ def readSamLines(sam_file: str) -> Iterator[str]:
 
 
 def readBam(bam_file: str) -> Iterable[str]:
-    """``.sam`` / ``.sam.gz`` are read directly; ``.bam`` goes through samtools like the reference."""
+    """Name-collated SAM lines of an alignment file (hisat2.py:103-110).
+
+    ``.sam`` / ``.sam.gz`` are read directly (they must already be name-collated); ``.bam`` is
+    decoded and name-sorted natively (``packed.bamChunks``).  ``GK_BAM_READER=samtools`` runs
+    ``samtools sort -n`` like the reference instead."""
     if bam_file.endswith((".sam", ".sam.gz")):
         return readSamLines(bam_file)
-    from .external_tools import runTool
-    proc = runTool("samtools", ["samtools", "sort", "-n", bam_file, "-O", "SAM"], capture_output=True)
-    return str(proc.stdout).split("\n")
+    import os
+    if os.environ.get("GK_BAM_READER", "native") == "samtools":
+        from .external_tools import runTool
+        proc = runTool("samtools", ["samtools", "sort", "-n", bam_file, "-O", "SAM"], capture_output=True)
+        return str(proc.stdout).split("\n")
+    from .packed import bamChunks
+    return (line for chunk in bamChunks(bam_file) for line in chunk.decode().split("\n") if line)
 
 
 def pairLines(lines: Iterable[str]) -> Iterator[tuple[str, str]]:

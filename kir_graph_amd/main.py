@@ -17,6 +17,7 @@ readMapping 124-168, alleleTyping 171-220, getCommonName 223-250).  What differs
 from __future__ import annotations
 
 import argparse
+import os
 import logging
 from pathlib import Path
 
@@ -78,9 +79,10 @@ def readMapping(names, reads, index, index_ref, exon_region_only=False, alignmen
         bam_files.append(source)
         name += ".variant"
         logger.info(f"[Graph] Filter mapping ({name})")
-        if source.endswith((".sam", ".sam.gz")):
+        if source.endswith((".sam", ".sam.gz")) or os.environ.get("GK_BAM_READER", "native") != "samtools":
+            # SAM text, or BAM decoded + name-collated natively (packed.bamChunks), packed natively
             data = extractVariantFromText(source, gk, dev=dev, dindex=dindex, keep_text=write_json)
-        else:   # BAM: name-collate through samtools like the reference (hisat2.readBam)
+        else:   # BAM name-collated through samtools like the reference (hisat2.readBam)
             data = extractVariant(readPair(source), gk, dev=dev, dindex=dindex)
         if write_json:
             writeReadsAndVariantsData(data.asDict(), name + ".json")

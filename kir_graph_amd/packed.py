@@ -245,8 +245,48 @@ def packText(chunks, index: GkIndex, table: InsTable | None = None):
         lib().gk_packer_destroy(pk)
 
 
+def bamChunks(path: str, chunk_bytes: int = 1 << 24, name_sorted: bool = True):
+    """SAM text of a ``.bam`` file in query-name order, as byte chunks of whole lines.
+
+    Native replacement of ``samtools sort -n bam -O SAM`` (hisat2.py:103-110): BGZF inflate, BAM
+    decode and name collation happen in ``csrc/gk_bamread.cpp``; no external tool is started."""
+    import ctypes as C
+    from ._lib import check, lib
+    h = C.c_void_p()
+    check(lib().gk_bam_open(path.encode(), int(name_sorted), C.byref(h)))
+    try:
+        buf = C.create_string_buffer(chunk_bytes)
+        n = C.c_int64()
+        while True:
+            check(lib().gk_bam_next(h, buf, chunk_bytes, C.byref(n)))
+            if n.value == 0:
+                return
+            yield buf.raw[:n.value]
+    finally:
+        lib().gk_bam_close(h)
+
+
+def bamHeader(path: str) -> str:
+    """``@`` header lines of a BAM file (``samtools view -H``, hisat2.py:113-118)."""
+    import ctypes as C
+    from ._lib import check, lib
+    h = C.c_void_p()
+    check(lib().gk_bam_open(path.encode(), 0, C.byref(h)))
+    try:
+        n = C.c_int64()
+        check(lib().gk_bam_info(h, None, C.byref(n), None))
+        buf = C.create_string_buffer(max(int(n.value), 1))
+        check(lib().gk_bam_header(h, buf, n.value))
+        return buf.raw[:n.value].decode()
+    finally:
+        lib().gk_bam_close(h)
+
+
 def readChunks(path: str, chunk_bytes: int = 1 << 24):
-    """Byte chunks of a ``.sam`` / ``.sam.gz`` file."""
+    """Byte chunks of a ``.sam`` / ``.sam.gz`` file, or of the name-collated text of a ``.bam``."""
+    if path.endswith(".bam"):
+        yield from bamChunks(path, chunk_bytes)
+        return
     import gzip
     opener = gzip.open if path.endswith(".gz") else open
     with opener(path, "rb") as f:

@@ -105,3 +105,34 @@ def test_command_line_two_samples(device, tmp_path):
     assert any(n.endswith(".variant.json") for n in produced)
     assert any(n.endswith(".variant.no_multi.depth.tsv") for n in produced)
     assert any(n.endswith(".full.possible.tsv") for n in produced)
+
+
+def test_command_line_reads_coordinate_sorted_bam(device, tmp_path):
+    """A coordinate-sorted BAM goes through the native reader (no samtools) and gives the calls of the SAM text."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from bamwriter import samToBam
+    from kir_graph_amd import main as cli
+    sidx = synth.makeIndex(seed=11, n_genes=3, var_range=(200, 300), allele_range=(12, 20))
+    folder = tmp_path / "index"
+    folder.mkdir()
+    prefix = str(folder / "kir_2100_withexon_ab_2dl1s1.leftalign.mut01")
+    sidx.write(prefix)
+    s = synth.makeSample(sidx, seed=50, n_pairs=2500)
+    lines = synth.toSamLines(s)
+    header = ["@HD\tVN:1.0\tSO:coordinate"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+    by_coord = sorted(lines, key=lambda l: (l.split("\t")[2], int(l.split("\t")[3])))
+    samToBam(header + by_coord, str(tmp_path / "s.bam"))
+    with gzip.open(tmp_path / "s.sam.gz", "wt") as f:
+        f.write("\n".join(lines) + "\n")
+    cn_path = tmp_path / "s.cn.tsv"
+    cn_path.write_text("gene\tcn\n" + "".join(f"{g}\t{c}\n" for g, c in s.gene_cn.items()))
+    calls = []
+    for k, aln in enumerate(("s.bam", "s.sam.gz")):
+        out = tmp_path / f"out{k}"
+        args = cli.createParser().parse_args(
+            ["--step-skip-extraction", "--index-folder", str(folder), "--output-folder", str(out),
+             "--allele-strategy", "pv", "--cn-provided", str(cn_path), "--alignment", str(tmp_path / aln)])
+        cli.main(args)
+        calls.append(pd.read_csv(out / "cohort.allele.tsv", sep="\t")["alleles"][0])
+    assert calls[0] == calls[1] and "*" in calls[0]

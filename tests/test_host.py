@@ -219,3 +219,84 @@ def test_site_verdict_equals_reference_loop():
         assert got == (hits == 0), trial
         verdicts.add(got)
     assert verdicts == {True, False}
+
+
+def _name_order(a: str, b: str) -> int:
+    """Query-name order restated in Python: digit runs compare as numbers, everything else by code."""
+    i = j = 0
+    while i < len(a) and j < len(b):
+        if a[i].isdigit() and b[j].isdigit():
+            while i < len(a) and a[i] == "0":
+                i += 1
+            while j < len(b) and b[j] == "0":
+                j += 1
+            ea, eb = i, j
+            while ea < len(a) and a[ea].isdigit():
+                ea += 1
+            while eb < len(b) and b[eb].isdigit():
+                eb += 1
+            if ea - i != eb - j:
+                return 1 if ea - i > eb - j else -1
+            if a[i:ea] != b[j:eb]:
+                return 1 if a[i:ea] > b[j:eb] else -1
+            i, j = ea, eb
+            if i != j:
+                return 1 if i < j else -1
+        else:
+            if a[i] != b[j]:
+                return 1 if a[i] > b[j] else -1
+            i += 1
+            j += 1
+    return 1 if i < len(a) else -1 if j < len(b) else 0
+
+
+def test_native_bam_reader_collates_and_renders_like_sam_text(tmp_path):
+    """csrc/gk_bamread.cpp: BGZF inflate + BAM decode + query-name collation == the SAM text it was made of."""
+    import functools
+    from bamwriter import samToBam
+    sidx = synth.makeIndex(seed=5, n_genes=3, var_range=(200, 300), allele_range=(10, 20))
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    sample = synth.makeSample(sidx, seed=9, n_pairs=1500)
+    records = synth.toSamLines(sample)
+    # rename some reads so that the order depends on the numeric rule, add tags of every type
+    tricky = ["r2", "r10", "r1", "r01", "a", "r1a", "r1b10", "r1b9", "x007y3", "x7y12"]
+    for k, name in enumerate(tricky):
+        for m in (0, 1):
+            f = records[2 * k + m].split("\t")
+            f[0] = name
+            records[2 * k + m] = "\t".join(f) + "\tXA:A:q\tXf:f:0.5\tXB:B:s,-3,7\tXH:H:1AE3\tXI:i:3000000000\tXS:i:-70000"
+    header = ["@HD\tVN:1.0\tSO:coordinate"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+    by_coord = sorted(records, key=lambda l: (l.split("\t")[2], int(l.split("\t")[3])))   # a coordinate-sorted BAM
+    path = str(tmp_path / "s.bam")
+    samToBam(header + by_coord, path, block=30000)
+
+    assert packed.bamHeader(path) == "\n".join(header) + "\n"
+    got = b"".join(packed.bamChunks(path, chunk_bytes=1 << 16)).decode().split("\n")
+    assert got[-1] == ""
+    got = got[:-1]
+
+    def order(x, y):
+        fx, fy = x.split("\t", 2), y.split("\t", 2)
+        return _name_order(fx[0], fy[0]) or (int(fx[1]) & 192) - (int(fy[1]) & 192)
+    want = sorted(by_coord, key=functools.cmp_to_key(order))          # Python's sort is stable, like the reader's
+    assert got == want
+    names = [l.split("\t", 1)[0] for l in got]
+    firsts = [n for i, n in enumerate(names) if (i == 0 or names[i - 1] != n) and n in tricky]
+    assert firsts == ["a", "r01", "r1", "r1a", "r1b9", "r1b10", "r2", "r10", "x007y3", "x7y12"]
+    # file order without collation
+    raw = b"".join(packed.bamChunks(path, name_sorted=False)).decode().split("\n")[:-1]
+    assert raw == by_coord
+    # the packer sees the same stream either way
+    a, _, pa, _ = packed.packText(packed.readChunks(path), gidx)
+    b, _, pb, _ = packed.packText([("\n".join(want) + "\n").encode()], gidx)
+    assert a.tobytes() == b.tobytes() and pa.tolist() == pb.tolist()
+    # hisat2.readBam yields the same lines
+    from kir_graph_amd.hisat2 import readBam
+    assert list(readBam(path)) == want
+
+
+def test_native_bam_reader_rejects_garbage(tmp_path):
+    p = tmp_path / "bad.bam"
+    p.write_bytes(b"not a bam file at all")
+    with pytest.raises(_lib.GkError):
+        list(packed.bamChunks(str(p)))
