@@ -222,6 +222,73 @@ class SampleData:
         return self
 
 
+COMPACT_FORMAT = "graphkir-variant-csr-1"
+
+
+def indexFingerprint(index: GkIndex) -> np.ndarray:
+    """(number of variants, wrap-around sum and xor of the packed keys): ties a compact file to its index."""
+    key = index.key.astype(np.uint64)
+    return np.array([len(key), int(key.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(key)) if len(key) else 0],
+                    dtype=np.uint64)
+
+
+def writeCompact(data: SampleData, filename: str, index_ref: str = "") -> None:
+    """Binary side-format of the ``.variant.json`` hand-off (hisat2.py:847-866): the tabulation's CSR
+    (offsets + variant ordinals in list order lpv, rpv, lnv, rnv), backbone and NH per pair, the keys
+    of the novel variants and the inserted-string table -- ~4 bytes per variant hit instead of JSON
+    with embedded SAM text.  Index variants are not stored: ``index_ref`` names the index files and
+    a fingerprint of the packed keys is checked on load."""
+    tab = data.tab
+    if getattr(tab, "_variant_src", None) is not None:
+        raise ValueError("compact files are written from tabulations made against an index")
+    np.savez(filename if filename.endswith(".npz") else filename + ".npz",
+             format=np.array(COMPACT_FORMAT), index_ref=np.array(index_ref), fingerprint=indexFingerprint(data.index),
+             genes=np.array(data.index.genes), off=tab.offsets(), ids=tab.ids(), pair_gene=tab.pairGene(),
+             pair_nh=tab.pairNH(), novel_key=tab.novelKeys(), novel_base=np.array(tab.novel_base),
+             ins_strings=np.array(data.ins_strings if data.ins_strings else [""]),
+             n_ins=np.array(len(data.ins_strings or [])))
+
+
+_index_cache: dict[str, GkIndex] = {}
+
+
+def loadCompact(filename: str, dev: Device | None = None, index: GkIndex | None = None,
+                dindex: DeviceIndex | None = None) -> SampleData:
+    """Load ``writeCompact`` output as a device CSR (no re-tabulation, no Variant objects built)."""
+    z = np.load(filename, allow_pickle=False)
+    if str(z["format"]) != COMPACT_FORMAT:
+        raise ValueError(f"{filename}: unknown format {z['format']!r}")
+    if index is None:
+        ref = str(z["index_ref"])
+        if not ref:
+            raise ValueError(f"{filename} does not name its index; pass index=")
+        index = _index_cache.get(ref)
+        if index is None:
+            index = _index_cache[ref] = GkIndex.load(ref)
+    if not np.array_equal(z["fingerprint"], indexFingerprint(index)) or list(z["genes"]) != list(index.genes):
+        raise ValueError(f"{filename} was tabulated against a different index")
+    dev = dev or Device()
+    dindex = dindex or DeviceIndex(dev, index)
+    off, ids = np.ascontiguousarray(z["off"], np.uint32), np.ascontiguousarray(z["ids"], np.uint32)
+    gene, nh = np.ascontiguousarray(z["pair_gene"], np.uint8), np.ascontiguousarray(z["pair_nh"], np.uint8)
+    novel_key = np.ascontiguousarray(z["novel_key"], np.uint64)
+    n = len(gene)
+    tab = Tabulation.__new__(Tabulation)
+    tab.dev, tab.dindex, tab.mates, tab.n_pairs = dev, dindex, None, n
+    h = C.c_void_p()
+    check(lib().gk_tab_from_csr(dev.ctx, index.n_variant + len(novel_key), n, off.ctypes.data,
+                                ids.ctypes.data if len(ids) else None, gene.ctypes.data if n else None,
+                                nh.ctypes.data if n else None, C.byref(h)))
+    tab.handle = h
+    info = _lib.TabInfo()
+    check(lib().gk_tab_get_info(h, C.byref(info)))
+    tab.info = info
+    tab.n_valid, tab.n_ids = n, int(info.n_ids)
+    tab.n_novel, tab.novel_base, tab._novel_keys = len(novel_key), int(z["novel_base"]), novel_key
+    strings = [str(x) for x in z["ins_strings"][:int(z["n_ins"])]]
+    return SampleData(tab, index, None, ins_strings=strings)
+
+
 def extractVariant(pair_reads: Iterable[tuple[str, str]], index: GkIndex | list[Variant], dev: Device | None = None,
                    dindex: DeviceIndex | None = None, pileup=None) -> SampleData:
     """SAM pairs -> tabulated sample on the device (extractVariant, hisat2.py:803-844).

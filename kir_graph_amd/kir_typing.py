@@ -37,6 +37,9 @@ def defaultDevice() -> Device:
 def _sample(source, dev: Device | None) -> SampleData:
     if isinstance(source, SampleData):
         return source
+    if str(source).endswith(".npz"):     # compact side-format (hisat2.writeCompact)
+        from .hisat2 import loadCompact
+        return loadCompact(str(source), dev or defaultDevice())
     return SampleData.fromHost(dev or defaultDevice(), loadReadsAndVariantsData(source))
 
 

@@ -136,3 +136,32 @@ def test_command_line_reads_coordinate_sorted_bam(device, tmp_path):
         cli.main(args)
         calls.append(pd.read_csv(out / "cohort.allele.tsv", sep="\t")["alleles"][0])
     assert calls[0] == calls[1] and "*" in calls[0]
+
+
+def test_compact_side_format_round_trip(device, tmp_path):
+    """hisat2.writeCompact / loadCompact: the CSR hand-off types like the in-memory tabulation."""
+    from kir_graph_amd.hisat2 import extractVariantFromText, loadCompact, writeCompact
+    from kir_graph_amd.kir_typing import selectKirTypingModel
+    sidx = synth.makeIndex(seed=12, n_genes=3, var_range=(200, 300), allele_range=(12, 20))
+    prefix = str(tmp_path / "idx")
+    sidx.write(prefix)
+    gidx = GkIndex.load(prefix)
+    s = synth.makeSample(sidx, seed=8, n_pairs=3000)
+    text = ("\n".join(synth.toSamLines(s)) + "\n").encode()
+    data = extractVariantFromText([text], gidx, dev=device, keep_text=False)
+    want = selectKirTypingModel("pv", data, top_n=600, variant_correction=True).typing(s.gene_cn)
+    path = str(tmp_path / "s.variant.npz")
+    writeCompact(data, path, index_ref=prefix)
+    back = loadCompact(path, device)
+    assert back.tab.n_valid == data.tab.n_valid and back.tab.n_novel == data.tab.n_novel
+    assert np.array_equal(back.tab.ids(), data.tab.ids()) and np.array_equal(back.tab.offsets(), data.tab.offsets())
+    assert [str(v.id) for v in back.novel] == [str(v.id) for v in data.novel]
+    assert selectKirTypingModel("pv", path, top_n=600, variant_correction=True).typing(s.gene_cn) == want
+    for strategy in ("exonfirst_1", "em"):
+        a = selectKirTypingModel(strategy, data, top_n=600, variant_correction=True).typing(s.gene_cn)
+        b = selectKirTypingModel(strategy, back, top_n=600, variant_correction=True).typing(s.gene_cn)
+        assert a == b, strategy
+    # a file made against another index is refused
+    other = synth.makeIndex(seed=13, n_genes=3, var_range=(200, 300), allele_range=(12, 20))
+    with pytest.raises(ValueError):
+        loadCompact(path, device, index=GkIndex.fromVariants(other.variants, genes=other.genes, exons=other.exons))
