@@ -80,7 +80,11 @@ int gk_lut_create(gk_ctx* ctx, int32_t log2_capacity, gk_lut** out) {
   GK_HIP(hipMalloc((void**)&l->d_count, sizeof(uint32_t)));
   GK_HIP(hipMemsetAsync(l->d_count, 0, sizeof(uint32_t), ctx->stream));
   hipLaunchKernelGGL(fill_keys, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, l->d_keys, (uint64_t)cap);
+  // unwritten list entries are recognisable: a table shared by several streams may be read while a
+  // kernel of another stream has claimed an index but not stored its key yet
+  hipLaunchKernelGGL(fill_keys, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, l->d_list, (uint64_t)cap);
   GK_HIP(hipGetLastError());
+  GK_HIP(hipStreamSynchronize(ctx->stream));   // kernels of other contexts may use the table right away
   *out = l;
   return GK_OK;
 }
@@ -110,6 +114,12 @@ int gk_lut_pending(gk_lut* l, int32_t* n_total, int32_t* n_known) {
   uint32_t c = 0;
   GK_HIP(hipMemcpyAsync(&c, l->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, l->ctx->stream));
   GK_HIP(hipStreamSynchronize(l->ctx->stream));
+  if ((int64_t)c > (int64_t)l->n_known) {
+    // new values: let every stream of the device finish, so that all claimed entries are written
+    GK_HIP(hipDeviceSynchronize());
+    GK_HIP(hipMemcpyAsync(&c, l->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, l->ctx->stream));
+    GK_HIP(hipStreamSynchronize(l->ctx->stream));
+  }
   if ((uint64_t)c * 2 > (1ull << l->log2cap)) {
     gk_set_error("probability value table overflow (%u distinct values)", c);
     return GK_ERR_CAPACITY;

@@ -456,7 +456,7 @@ int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr 
 
 int gk_compat_log(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg,
                   int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, gk_lut* lut, gk_dptr d_log) {
-  GK_REQUIRE(ctx && tab && lut && lut->ctx == ctx, "null pointer or value table of another context");
+  GK_REQUIRE(ctx && tab && lut, "null pointer");   // the table may belong to another context of the same device
   GK_REQUIRE(words >= 1 && n_allele >= 0 && n_allele <= words * 32 && vend >= vbeg, "bad mask geometry");
   if (n_rows == 0 || n_allele == 0) return GK_OK;
   GK_REQUIRE(d_log, "null output");

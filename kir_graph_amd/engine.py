@@ -242,33 +242,56 @@ class Tabulation:
 
 
 class LogTable:
-    """``numpy.log10`` applied through a device value table (see ``csrc/gk_lut.hip``)."""
+    """``numpy.log10`` applied through a device value table (see ``csrc/gk_lut.hip``).
 
-    def __init__(self, dev: Device, log2_capacity: int = 20):
-        self.dev = dev
+    One table serves every context (stream) of a GPU: kernels of any stream look values up and
+    insert unknown ones; ``resolve`` (serialised by a lock, on the table's own context) evaluates
+    ``numpy.log10`` for the new ones."""
+
+    _EMPTY = np.uint64(0x7FF8DEADBEEF0001)   # kLutEmptyKey: a claimed list entry whose key is not stored yet
+
+    def __init__(self, dev: Device, log2_capacity: int = 20, private_context: bool = False):
+        self.dev = Device(dev.ordinal) if private_context else dev
         h = C.c_void_p()
-        check(lib().gk_lut_create(dev.ctx, log2_capacity, C.byref(h)))
+        check(lib().gk_lut_create(self.dev.ctx, log2_capacity, C.byref(h)))
         self.handle = h
         self.n_host_evals = 0
         self.n_known = 0          # values with a defined log10 (== the library's count)
+        self.n_undefined = 0      # entries seen by the last resolve() that could not be defined yet
+        import threading
+        self._lock = threading.Lock()
 
     def collect(self, buf: DeviceBuffer, n: int) -> None:
         check(lib().gk_lut_collect(self.handle, buf.ptr, n))
 
     def resolve(self) -> int:
-        """Evaluate numpy.log10 for values first seen since the last call; returns how many."""
-        tot, known = C.c_int32(), C.c_int32()
-        check(lib().gk_lut_pending(self.handle, C.byref(tot), C.byref(known)))
-        new = tot.value - known.value
-        if new > 0:
+        """Evaluate numpy.log10 for values first seen since the last call; returns how many.
+
+        The caller's own kernels must have completed (``Device.sync``).  Kernels of other streams
+        may still be inserting: ``gk_lut_pending`` waits for the device when the table grew, and an
+        entry that is claimed but not stored yet (possible only for kernels launched meanwhile) ends
+        the batch -- whoever launched that kernel resolves it."""
+        with self._lock:
+            tot, known = C.c_int32(), C.c_int32()
+            check(lib().gk_lut_pending(self.handle, C.byref(tot), C.byref(known)))
+            new = tot.value - known.value
+            if new <= 0:
+                self.n_undefined = 0
+                return 0
             keys = np.empty(new, dtype=np.float64)
             check(lib().gk_lut_export(self.handle, known.value, new, keys.ctypes.data))
-            with np.errstate(divide="ignore"):
-                vals = np.log10(keys)
-            check(lib().gk_lut_define(self.handle, known.value, new, vals.ctypes.data))
-            self.n_host_evals += new
-            self.n_known = tot.value
-        return max(new, 0)
+            unset = np.flatnonzero(keys.view(np.uint64) == self._EMPTY)
+            if len(unset):
+                new = int(unset[0])
+                keys = keys[:new]
+            if new:
+                with np.errstate(divide="ignore"):
+                    vals = np.log10(keys)
+                check(lib().gk_lut_define(self.handle, known.value, new, vals.ctypes.data))
+                self.n_host_evals += new
+                self.n_known = known.value + new
+            self.n_undefined = tot.value - self.n_known    # claimed by kernels still running elsewhere
+            return new
 
     def apply(self, src: DeviceBuffer, dst: DeviceBuffer, n: int) -> None:
         check(lib().gk_lut_apply(self.handle, src.ptr, dst.ptr, n))
@@ -329,9 +352,15 @@ class DeviceModel:
         hold yet, the host evaluates them (numpy.log10) and the table is written once more."""
         if self.L is None or self._known_at_launch < 0:
             return
-        self._logs.resolve()
-        if self._logs.n_known > self._known_at_launch:
-            self._launchLog()
+        for _ in range(64):
+            self.dev.sync()                     # this model's kernel has stored every key it claimed
+            self._logs.resolve()
+            if self._logs.n_known > self._known_at_launch:
+                self._launchLog()               # some values were undefined at launch: write the table again
+            elif self._logs.n_undefined == 0:
+                break                           # every value this launch met had its log10 in the table
+        else:
+            raise _lib.GkError("log10 value table did not settle")
         self._known_at_launch = -1
 
     # ---- reductions (numpy summation tree on the device)

@@ -24,6 +24,8 @@ from dataclasses import dataclass, field
 from itertools import chain
 from typing import Iterable, Optional
 
+import threading
+
 import numpy as np
 
 from ._lib import Device, DeviceBuffer
@@ -33,13 +35,16 @@ from .msa2hisat import Variant
 from .utils import logger
 
 _default_logs: dict[int, LogTable] = {}
+_default_logs_lock = threading.Lock()
 
 
 def sharedLogTable(dev: Device) -> LogTable:
-    """One log10 value table per device context (values recur across genes and samples)."""
-    t = _default_logs.get(id(dev))
-    if t is None:
-        t = _default_logs[id(dev)] = LogTable(dev)
+    """One log10 value table per GPU, shared by all its contexts (values recur across genes, samples
+    and host threads, so every value is evaluated by numpy once per process)."""
+    with _default_logs_lock:
+        t = _default_logs.get(dev.ordinal)
+        if t is None:
+            t = _default_logs[dev.ordinal] = LogTable(dev, private_context=True)
     return t
 
 
