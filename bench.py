@@ -201,11 +201,28 @@ def main():
         dist.destroy_process_group()
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the committed PMC passes over this same command
+    (profiles/r01_bench_traffic.json, made by tools/collect_profiles.sh), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return float(t["traffic_bytes_per_launch"]) if t.get("kernel") == kernel else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def roofline(dom, call_log):
     """Roofline entry of the dominant kernel (algorithmic bytes stated in DESIGN.md)."""
     from kir_graph_amd import roofmodel
     name, (launches, total_ms) = dom
-    return roofmodel.summarise(call_log, name, total_ms, launches)
+    out = roofmodel.summarise(call_log, name, total_ms, launches)
+    traffic = measured_traffic(name)
+    if traffic is not None:
+        out["traffic"] = traffic
+        out["traffic_source"] = "profiles/r01_bench_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+    return out
 
 
 if __name__ == "__main__":

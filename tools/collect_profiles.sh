@@ -14,3 +14,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/cal_fetch -o p --output-format c
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/cal_write -o p --output-format csv -- $R/tools/fetch_calib.bin > /dev/null 2>&1
 ls $O $O/stats
 cat $O/bench.json
+# HBM traffic of the dominant kernel over the bench's own launch mix (two more passes, as the guide prescribes)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/bench_fetch -o p --output-format csv -- python3 $R/bench.py --cpu-pairs 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/bench_write -o p --output-format csv -- python3 $R/bench.py --cpu-pairs 0 > /dev/null 2>&1
+python3 $R/tools/pmc_traffic.py $O/bench_fetch/p_counter_collection.csv $O/bench_write/p_counter_collection.csv maxsum_chunks > $O/bench_traffic.json
+cat $O/bench_traffic.json
