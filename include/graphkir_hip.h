@@ -202,6 +202,10 @@ int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
  * gk_em_run:  SQUAREM EM on weighted distinct sets (hisatEMnp 107-188), one workgroup. */
 int gk_em_sets(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, int32_t vbeg, int32_t vend,
                gk_dptr d_mask, int32_t words, gk_dptr d_sets_out /* uint32 [n_rows][words] */);
+/* distinct rows of d_sets (uint32 [n_rows][words], as written by gk_em_sets) with their multiplicities,
+ * in no particular order; GK_ERR_CAPACITY when there are more than max_out (n_out then holds the count). */
+int gk_em_distinct(gk_ctx* ctx, gk_dptr d_sets, int64_t n_rows, int32_t words, int32_t max_out,
+                   uint32_t* sets_out, uint32_t* count_out, int32_t* n_out);
 int gk_em_run(gk_ctx* ctx, const uint32_t* sets, const double* weight, int32_t n_sets, int32_t words,
               int32_t n_allele, int32_t iter_max, double diff_threshold, double* prob_out,
               int32_t* iters_out);

@@ -123,6 +123,8 @@ _SIGS = {
                                C.c_double, C.c_void_p]),
     "gk_em_sets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_uint64,
                              C.c_int32, C.c_uint64]),
+    "gk_em_distinct": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                 C.POINTER(C.c_int32)]),
     "gk_em_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                             C.c_double, C.c_void_p, C.POINTER(C.c_int32)]),
 }

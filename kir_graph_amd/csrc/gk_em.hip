@@ -59,6 +59,55 @@ __global__ __launch_bounds__(kThreads) void em_sets_kernel(const int32_t* rows, 
     if (w < words) out[i * words + w] = both ? (side[0][w] & side[1][w]) : (side[0][w] | side[1][w]);
 }
 
+// Distinct candidate sets and their multiplicities (the EM only needs those): open addressing on a
+// 64-bit mix of the row; a slot is owned by the first row that claims it, later rows compare their
+// words with the owner's and either add 1 to its count or probe on.
+__device__ inline uint64_t mix_row(const uint32_t* r, int words) {
+  uint64_t h = 0x9E3779B97F4A7C15ull;
+  for (int w = 0; w < words; ++w) {
+    h ^= r[w];
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 29;
+  }
+  return h;
+}
+
+__global__ __launch_bounds__(kThreads) void em_distinct_kernel(const uint32_t* __restrict__ sets, int64_t n_rows, int words,
+                                                               int32_t* owner, uint32_t* count, uint32_t mask) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n_rows) return;
+  const uint32_t* mine = sets + i * words;
+  uint32_t s = (uint32_t)mix_row(mine, words) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    int32_t o = owner[s];
+    if (o < 0) {
+      const int32_t prev = atomicCAS(&owner[s], -1, (int32_t)i);
+      o = prev < 0 ? (int32_t)i : prev;
+    }
+    const uint32_t* other = sets + (int64_t)o * words;
+    bool same = true;
+    for (int w = 0; w < words; ++w) same &= other[w] == mine[w];
+    if (same) {
+      atomicAdd(&count[s], 1u);
+      return;
+    }
+    s = (s + 1) & mask;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void em_distinct_emit(const uint32_t* __restrict__ sets, int words,
+                                                             const int32_t* __restrict__ owner,
+                                                             const uint32_t* __restrict__ count, uint32_t n_slots,
+                                                             uint32_t max_out, uint32_t* n_out, uint32_t* sets_out,
+                                                             uint32_t* count_out) {
+  const uint32_t s = blockIdx.x * kThreads + threadIdx.x;
+  if (s >= n_slots || owner[s] < 0) return;
+  const uint32_t k = atomicAdd(n_out, 1u);
+  if (k >= max_out) return;
+  for (int w = 0; w < words; ++w) sets_out[(int64_t)k * words + w] = sets[(int64_t)owner[s] * words + w];
+  count_out[k] = count[s];
+}
+
 struct EmShared {
   double p[kMaxAllele], p1[kMaxAllele], p2[kMaxAllele], p3[kMaxAllele];
   double scalar[4];
@@ -166,6 +215,52 @@ int gk_em_sets(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, int32_t
                      gk_ptr<uint32_t>(d_mask), words, gk_ptr<uint32_t>(d_sets_out)));
   GK_HIP(hipGetLastError());
   return GK_OK;
+}
+
+int gk_em_distinct(gk_ctx* ctx, gk_dptr d_sets, int64_t n_rows, int32_t words, int32_t max_out, uint32_t* sets_out,
+                   uint32_t* count_out, int32_t* n_out) {
+  GK_REQUIRE(ctx && sets_out && count_out && n_out && max_out > 0, "null pointer");
+  GK_REQUIRE(words >= 1 && words <= kMaxWords && n_rows >= 0 && n_rows < (1ll << 31), "bad set geometry");
+  *n_out = 0;
+  if (!n_rows) return GK_OK;
+  hipStream_t st = ctx->stream;
+  uint32_t log2 = 10;
+  while ((1ull << log2) < (uint64_t)n_rows * 2 && log2 < 28) ++log2;   // load factor <= 0.5 even if all rows differ
+  const uint32_t n_slots = 1u << log2;
+  int32_t* owner = nullptr;
+  uint32_t *count = nullptr, *d_n = nullptr, *d_out_sets = nullptr, *d_out_count = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&owner, (size_t)n_slots * sizeof(int32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&count, (size_t)n_slots * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_n, sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_out_sets, (size_t)max_out * words * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_out_count, (size_t)max_out * sizeof(uint32_t)));
+  GK_HIP(hipMemsetAsync(owner, 0xFF, (size_t)n_slots * sizeof(int32_t), st));
+  GK_HIP(hipMemsetAsync(count, 0, (size_t)n_slots * sizeof(uint32_t), st));
+  GK_HIP(hipMemsetAsync(d_n, 0, sizeof(uint32_t), st));
+  GK_PROF(ctx, GK_K_EM_SETS,
+          hipLaunchKernelGGL(em_distinct_kernel, dim3((unsigned)((n_rows + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                             gk_ptr<uint32_t>(d_sets), n_rows, words, owner, count, n_slots - 1));
+  GK_PROF(ctx, GK_K_EM_SETS,
+          hipLaunchKernelGGL(em_distinct_emit, dim3((n_slots + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
+                             gk_ptr<uint32_t>(d_sets), words, owner, count, n_slots, (uint32_t)max_out, d_n, d_out_sets,
+                             d_out_count));
+  GK_HIP(hipGetLastError());
+  uint32_t n = 0;
+  GK_HIP(hipMemcpyAsync(&n, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  GK_HIP(hipStreamSynchronize(st));
+  int rc = GK_OK;
+  if (n > (uint32_t)max_out) {
+    gk_set_error("%u distinct candidate sets exceed the output capacity %d", n, max_out);
+    rc = GK_ERR_CAPACITY;
+  } else if (n) {
+    GK_HIP(hipMemcpyAsync(sets_out, d_out_sets, (size_t)n * words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    GK_HIP(hipMemcpyAsync(count_out, d_out_count, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    GK_HIP(hipStreamSynchronize(st));
+  }
+  *n_out = (int32_t)n;
+  gk_pool_free(ctx, owner); gk_pool_free(ctx, count); gk_pool_free(ctx, d_n);
+  gk_pool_free(ctx, d_out_sets); gk_pool_free(ctx, d_out_count);
+  return rc;
 }
 
 int gk_em_run(gk_ctx* ctx, const uint32_t* sets, const double* weight, int32_t n_sets, int32_t words, int32_t n_allele,

@@ -66,6 +66,23 @@ def test_em_strategy(tabulated):
     assert got[1] == want[1]
 
 
+def test_em_distinct_sets_equal_numpy_unique(tabulated):
+    """gk_em_distinct (device grouping of the candidate bit sets) == np.unique(axis=0) of the per-read sets."""
+    from kir_graph_amd.kir_typing import _GeneView
+    from kir_graph_amd.typing_em import candidateSets, candidateSetsDistinct, distinctSets
+    data, ref, sample = tabulated
+    for gene in data.index.genes:
+        view = _GeneView(data, gene, multiple=False)
+        t = data.index.tables[view.g]
+        args = (data.tab, view.rows, view.n_rows, view.vbeg, view.vbeg + view.n_span, view.mask, t.words)
+        per_read = candidateSets(*args)
+        want_sets, want_count = np.unique(per_read, axis=0, return_counts=True)
+        got_sets, got_count = candidateSetsDistinct(*args)
+        assert np.array_equal(got_sets, want_sets) and np.array_equal(got_count, want_count), gene
+        host_sets, host_count = distinctSets(per_read)
+        assert np.array_equal(host_sets, want_sets) and np.array_equal(host_count, want_count), gene
+
+
 def test_json_roundtrip_path(device, tabulated, tmp_path):
     """selectKirTypingModel(method, '<file>.json') -- the reference's calling convention."""
     from kir_graph_amd.hisat2 import writeReadsAndVariantsData
