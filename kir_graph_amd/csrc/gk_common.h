@@ -42,6 +42,10 @@ struct gk_ctx {
   // pinned host staging for small parameter arrays
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  // reduction-tree programs of gk_search.hip, one device block per row count (they depend on nothing else)
+  std::map<int64_t, void*> tree_programs;
+  struct TreeHead { size_t o_leaf, o_span, o_cs, o_co, o_top; int n_spans, n_chunks; };
+  std::map<int64_t, TreeHead> tree_heads;
   // caching allocator state (gk_pool_*)
   std::mutex pool_mutex;   // frees may come from another host thread (Python GC)
   std::multimap<size_t, void*> pool_free;

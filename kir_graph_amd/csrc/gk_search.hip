@@ -544,33 +544,67 @@ size_t put(std::vector<char>& buf, const T* src, size_t n) {
   return off;
 }
 
+// The span / leaf / top program depends on the row count only: it is built and uploaded once per
+// (context, row count) and kept (a search makes dozens of calls on the same table).  The per-call
+// id / column arrays go through the context's pinned staging buffer, so a call costs one truly
+// asynchronous copy and no synchronisation before its kernels.
+using CachedProgram = gk_ctx::TreeHead;
+constexpr size_t kMaxCachedPrograms = 64;
+
 int upload_program(gk_ctx* ctx, int64_t n_rows, const int32_t* ids, size_t n_ids, const int32_t* cols, size_t n_cols,
                    DeviceProgram& d) {
-  Program p;
-  build_program(n_rows, p);
-  for (size_t q = 0; q + 1 < p.chunk_span0.size(); ++q)
-    GK_REQUIRE(p.chunk_span0[q + 1] - p.chunk_span0[q] <= kMaxSpans, "too many spans in a chunk");
-  for (const Leaf& lf : p.leaves) GK_REQUIRE(lf.slot <= kMaxSlot, "leaf program deeper than the lane stack");
-  std::vector<char> buf;
-  const size_t o_leaf = put(buf, p.leaves.data(), p.leaves.size());
-  const size_t o_span = put(buf, p.spans.data(), p.spans.size());
-  const size_t o_cs = put(buf, p.chunk_span0.data(), p.chunk_span0.size());
-  const size_t o_co = put(buf, p.chunk_op0.data(), p.chunk_op0.size());
-  const size_t o_top = put(buf, p.top.data(), p.top.size());
-  const size_t o_ids = put(buf, ids, n_ids);
-  const size_t o_cols = put(buf, cols, n_cols);
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d.base, buf.size()));
-  GK_HIP(hipMemcpyAsync(d.base, buf.data(), buf.size(), hipMemcpyHostToDevice, ctx->stream));
-  GK_HIP(hipStreamSynchronize(ctx->stream));   // buf is pageable and goes out of scope
-  d.leaves = (Leaf*)(d.base + o_leaf);
-  d.spans = (Span*)(d.base + o_span);
-  d.chunk_span0 = (int32_t*)(d.base + o_cs);
-  d.chunk_op0 = (int32_t*)(d.base + o_co);
-  d.top = (TopOp*)(d.base + o_top);
-  d.ids = (int32_t*)(d.base + o_ids);
-  d.cols = (int32_t*)(d.base + o_cols);
-  d.n_spans = (int)p.spans.size();
-  d.n_chunks = (int)p.chunk_span0.size() - 1;
+  char* prog = nullptr;
+  auto hit = ctx->tree_programs.find(n_rows);
+  if (hit != ctx->tree_programs.end()) {
+    prog = (char*)hit->second;
+  } else {
+    Program p;
+    build_program(n_rows, p);
+    for (size_t q = 0; q + 1 < p.chunk_span0.size(); ++q)
+      GK_REQUIRE(p.chunk_span0[q + 1] - p.chunk_span0[q] <= kMaxSpans, "too many spans in a chunk");
+    for (const Leaf& lf : p.leaves) GK_REQUIRE(lf.slot <= kMaxSlot, "leaf program deeper than the lane stack");
+    std::vector<char> buf;
+    CachedProgram head;
+    head.o_leaf = put(buf, p.leaves.data(), p.leaves.size());
+    head.o_span = put(buf, p.spans.data(), p.spans.size());
+    head.o_cs = put(buf, p.chunk_span0.data(), p.chunk_span0.size());
+    head.o_co = put(buf, p.chunk_op0.data(), p.chunk_op0.size());
+    head.o_top = put(buf, p.top.data(), p.top.size());
+    head.n_spans = (int)p.spans.size();
+    head.n_chunks = (int)p.chunk_span0.size() - 1;
+    if (ctx->tree_programs.size() >= kMaxCachedPrograms) {   // every earlier call has synchronised: nothing is in flight
+      for (auto& kv : ctx->tree_programs) gk_pool_free(ctx, kv.second);
+      ctx->tree_programs.clear();
+      ctx->tree_heads.clear();
+    }
+    GK_HIP(gk_pool_malloc(ctx, (void**)&prog, buf.size()));
+    GK_HIP(hipMemcpyAsync(prog, buf.data(), buf.size(), hipMemcpyHostToDevice, ctx->stream));
+    GK_HIP(hipStreamSynchronize(ctx->stream));   // buf is pageable and goes out of scope
+    ctx->tree_programs[n_rows] = prog;
+    ctx->tree_heads[n_rows] = head;
+  }
+  const CachedProgram& head = ctx->tree_heads[n_rows];
+  d.leaves = (Leaf*)(prog + head.o_leaf);
+  d.spans = (Span*)(prog + head.o_span);
+  d.chunk_span0 = (int32_t*)(prog + head.o_cs);
+  d.chunk_op0 = (int32_t*)(prog + head.o_co);
+  d.top = (TopOp*)(prog + head.o_top);
+  d.n_spans = head.n_spans;
+  d.n_chunks = head.n_chunks;
+  // per-call parameters
+  const size_t n_par = std::max<size_t>(n_ids + n_cols, 1);
+  if (ctx->pinned_bytes < n_par * sizeof(int32_t)) {
+    if (ctx->pinned) GK_HIP(hipHostFree(ctx->pinned));
+    ctx->pinned_bytes = std::max<size_t>(n_par * sizeof(int32_t) * 2, 1 << 16);
+    GK_HIP(hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+  }
+  int32_t* stage = (int32_t*)ctx->pinned;
+  if (n_ids) memcpy(stage, ids, n_ids * sizeof(int32_t));
+  if (n_cols) memcpy(stage + n_ids, cols, n_cols * sizeof(int32_t));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d.base, n_par * sizeof(int32_t)));
+  GK_HIP(hipMemcpyAsync(d.base, stage, n_par * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  d.ids = (int32_t*)d.base;
+  d.cols = (int32_t*)d.base + n_ids;
   return GK_OK;
 }
 

@@ -101,6 +101,11 @@ class _GeneView:
         self.variants = idx.variants[t.vbeg:t.vend]          # index part; novel ones are built lazily
         self.novel = lambda: data.novelOfGene(gene)
 
+    def groupCache(self) -> dict:
+        """Per-gene store of the exon allele groups (index-only data, computed on first use)."""
+        store = self.data.index.__dict__.setdefault("_exon_group_cache", {})
+        return store.setdefault(self.gene, {})
+
     def exonFlags(self) -> np.ndarray:
         idx, tab = self.data.index, self.data.tab
         flags = np.full(tab.n_var_total, 3, dtype=np.uint8)
@@ -191,7 +196,7 @@ class TypingWithPosNegAllele(Typing):
                 reads, view.variants, force_homo=force_homo, top_n=self._top_n, exon_only=self._exon_only,
                 candidate_set_threshold=self._exon_candidate_threshold, logs=logs, _vbeg=view.vbeg,
                 _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles, _exon_flags=view.exonFlags(),
-                _novel=view.novel)
+                _novel=view.novel, _group_cache=view.groupCache())
         res = typ.typing(cn)
         self._result[gene] = typ.result
         alleles = [a if a != "fail" else f"{pure_gene}*" for a in res.selectBest()]

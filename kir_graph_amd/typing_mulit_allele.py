@@ -635,7 +635,10 @@ class AlleleTypingExonFirst(AlleleTyping):
                  candidate_set_threshold: float = 1.0, variant_correction: bool = True,
                  force_homo: bool | None = None, *, device: Device | None = None, logs: LogTable | None = None,
                  _vbeg: int = 0, _n_span: int | None = None, _mask: DeviceBuffer | None = None,
-                 _alleles: list[str] | None = None, _exon_flags: np.ndarray | None = None, _novel=None):
+                 _alleles: list[str] | None = None, _exon_flags: np.ndarray | None = None, _novel=None,
+                 _group_cache: dict | None = None):
+        """``_group_cache``: a dict owned by the caller (one per gene of an index); the exon allele
+        groups, the regrouped variants and their bit rows depend on the index only and are kept there."""
         if isinstance(reads, ReadSet):
             base = reads
             template = None
@@ -656,16 +659,24 @@ class AlleleTypingExonFirst(AlleleTyping):
         exon_set = ReadSet(tab, base.rows, base.n_rows, exon_flags)
 
         # alleles sharing one exon-variant set become one group (649-659)
-        exon_variants = [v for v in variants if v.in_exon]
-        groups = self.aggrVariantsByAllele(exon_variants)
-        rest = self.collectAlleleNames(variants) - self.collectAlleleNames(exon_variants)
-        if rest:
-            groups[tuple()] = sorted(rest)
-        self.allele_group = {"|".join(a): a for a in groups.values()}
-        inverse = self.createInverseMapping(self.allele_group)
-        grouped = self.removeDuplicateAllele(variants, inverse)
-        group_names = sorted(self.collectAlleleNames(grouped))
-        exon_mask = dev.put(buildMask(grouped[:n_span], group_names))
+        cache = _group_cache if _group_cache is not None else {}
+        if "grouped" not in cache:
+            exon_variants = [v for v in variants if v.in_exon]
+            groups = self.aggrVariantsByAllele(exon_variants)
+            rest = self.collectAlleleNames(variants) - self.collectAlleleNames(exon_variants)
+            if rest:
+                groups[tuple()] = sorted(rest)
+            cache["allele_group"] = {"|".join(a): a for a in groups.values()}
+            inverse = self.createInverseMapping(cache["allele_group"])
+            cache["grouped"] = self.removeDuplicateAllele(variants, inverse)
+            cache["group_names"] = sorted(self.collectAlleleNames(cache["grouped"]))
+            cache["mask"] = buildMask(cache["grouped"][:n_span], cache["group_names"])
+            cache["device_mask"] = {}
+        self.allele_group = cache["allele_group"]
+        grouped, group_names = cache["grouped"], cache["group_names"]
+        exon_mask = cache["device_mask"].get(dev.ordinal)
+        if exon_mask is None:
+            exon_mask = cache["device_mask"][dev.ordinal] = dev.put(cache["mask"])
         # the base class runs errorCorrection once more on the exon lists (line 664: default True)
         super().__init__(exon_set, grouped, force_homo=force_homo, top_n=top_n, logs=logs,
                          _vbeg=_vbeg, _n_span=n_span, _mask=exon_mask, _alleles=group_names, _defer_log=True, _novel=_novel)

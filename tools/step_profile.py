@@ -17,7 +17,7 @@ mates = dev.put(rec)
 def step():
     tab = Tabulation(dindex, mates)
     data = SampleData(tab, gidx, None, ins_strings=table.strings)
-    typer = kir_typing.selectKirTypingModel("pv", data, top_n=600, variant_correction=True)
+    typer = kir_typing.selectKirTypingModel(os.environ.get("GK_METHOD", "pv"), data, top_n=600, variant_correction=True)
     typer.typing(sample.gene_cn)
     tab.close()
 
