@@ -470,6 +470,82 @@ class AlleleTyping:
         return self._colsum_all
 
     def addCandidate(self, candidate_allele: Optional[list[str]] = None) -> TypingResult:
+        """One copy-number step (478-598).  The step is written as a generator that yields its device
+        requests (``_candidateSteps``); here they are served one by one, ``runLockstep`` serves the
+        same requests of many independent searches with one launch each."""
+        steps = self._candidateSteps(candidate_allele)
+        try:
+            request = next(steps)
+            while True:
+                request = steps.send(self._serve([request])[0])
+        except StopIteration as done:
+            return done.value
+
+    def _serve(self, requests: list[tuple]) -> list[np.ndarray]:
+        """Answer device requests of one kind -- ("maxsum", prev_ids, cols) or ("fraction", ids) -- that
+        all refer to this model's table, with ONE launch: the sets are stacked (and the columns united),
+        every requester gets its own block back.  Each value depends on its set, its column and the
+        read order only, so the blocks hold the same bits as separate launches would."""
+        m = self._model
+        kind = requests[0][0]
+        assert all(r[0] == kind for r in requests)
+        if kind == "fraction":
+            ids = [np.asarray(r[1], dtype=np.int64) for r in requests]
+            if len(ids) == 1:
+                return [m.fraction(ids[0])]
+            uniq, back = np.unique(np.concatenate(ids), axis=0, return_inverse=True)   # searches share sets
+            out = m.fraction(uniq)[back.ravel()]
+            cuts = np.cumsum([len(x) for x in ids])[:-1]
+            return np.split(out, cuts)
+        prev = [np.asarray(r[1], dtype=np.int64) for r in requests]
+        cols = [np.asarray(r[2], dtype=np.int64) for r in requests]
+        if len(requests) == 1:
+            return [m.maxsum(prev[0], cols[0])]
+        union = np.unique(np.concatenate(cols))
+        uniq, back = np.unique(np.concatenate(prev), axis=0, return_inverse=True)       # searches share sets
+        out = m.maxsum(uniq, union)
+        back = back.ravel()
+        blocks, row = [], 0
+        for p_, c_ in zip(prev, cols):
+            blocks.append(out[back[row:row + len(p_)]][:, np.searchsorted(union, c_)])
+            row += len(p_)
+        return blocks
+
+    @staticmethod
+    def runLockstep(searches: list[tuple["AlleleTyping", list]]) -> None:
+        """Run ``model.addCandidate(c)`` for every c of every (model, [c, ...]) entry, where all models
+        are forks of one table: searches advance together, and the device requests they make at the
+        same point are served by one launch (``_serve``).  Same results as running them one by one."""
+        if not searches:
+            return
+        if len(searches) > 64:       # bound the stacked launches (their partial sums scale with the sets)
+            for i in range(0, len(searches), 64):
+                AlleleTyping.runLockstep(searches[i:i + 64])
+            return
+        owner = searches[0][0]
+        n_round = max(len(c) for _, c in searches)
+        for k in range(n_round):
+            active = [(model, model._candidateSteps(cands[k])) for model, cands in searches if k < len(cands)]
+            pending = []
+            for model, gen in active:
+                try:
+                    pending.append((gen, next(gen)))
+                except StopIteration:
+                    pass
+            while pending:
+                kinds = sorted({req[0] for _, req in pending})
+                nxt = []
+                for kind in kinds:
+                    group = [(g, r) for g, r in pending if r[0] == kind]
+                    answers = owner._serve([r for _, r in group])
+                    for (g, _), ans in zip(group, answers):
+                        try:
+                            nxt.append((g, g.send(ans)))
+                        except StopIteration:
+                            pass
+                pending = nxt
+
+    def _candidateSteps(self, candidate_allele: Optional[list[str]] = None):
         m = self._model
         if not m.n_rows:
             logger.warning("[Allele] Empty reads for typing. Skip")
@@ -494,7 +570,7 @@ class AlleleTyping:
 
         prev = self.result[-1]
         prev_ids = np.asarray(prev.allele_id, dtype=np.int64)
-        score = m.maxsum(prev_ids, cols).ravel()            # candidate (t, a) at flat index t * len(cols) + a
+        score = (yield ("maxsum", prev_ids, cols)).ravel()  # candidate (t, a) at flat index t * len(cols) + a
         # first occurrence of every allele multiset in (t-major, a-minor) order (uniqueAllele 456-476),
         # from keys built by broadcasting -- the (T*A) x CN id table is never materialised
         cols = np.asarray(cols, dtype=np.int64)
@@ -522,7 +598,7 @@ class AlleleTyping:
             contend = np.nonzero((key1 < key1[b]) | ((key1 == key1[b]) & (key2 <= key2[b])))[0]
         else:
             contend = np.arange(head)
-        frac = m.fraction(top_ids[contend])
+        frac = yield ("fraction", top_ids[contend])
         uneven = np.abs(frac - frac.mean(axis=1, keepdims=True)).sum(axis=1)
         sub = np.lexsort((uneven, key2[contend], key1[contend]))[:self.top_n]
         order = contend[sub]
@@ -737,10 +813,16 @@ class AlleleTypingExonFirst(AlleleTyping):
         if not result.value.shape[0]:
             logger.warning("[Allele] Cannot typing with exon-only reads. Typing with exon+intron")
             return self.full_model.typing(cn)
+        # every exon candidate is refined by an independent search on the full model (741-747):
+        # the searches run in lock-step so that their device requests share launches
         finals = []
-        for i in result.topRank(threshold=self.candidate_set_threshold):
-            logger.debug(f"[Allele] Exon-first: Typing Intron of candidate {i}")
-            model = self.typingIntron(result.allele_name_group[i])
+        assert self.full_model
+        if self.full_model._model.n_rows:
+            self.full_model._colsums()      # column sums are shared by the forks, not recomputed per search
+        searches = [(self.full_model.fork(), result.allele_name_group[i])
+                    for i in result.topRank(threshold=self.candidate_set_threshold)]
+        AlleleTyping.runLockstep(searches)
+        for model, _ in searches:
             self.result.extend(model.result)
             finals.append(model.result[-1])
         logger.debug(f"[Allele] Intron Candidate {len(finals)} Done")

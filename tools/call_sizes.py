@@ -16,7 +16,8 @@ mates = dev.put(rec)
 tab = Tabulation(dindex, mates)
 data = SampleData(tab, gidx, None, ins_strings=table.strings)
 dev.call_log = []
-typer = kir_typing.selectKirTypingModel("pv", data, top_n=600, variant_correction=True)
+dev.worker(0).call_log = []      # single-threaded typing runs on worker 0
+typer = kir_typing.selectKirTypingModel(os.environ.get("GK_METHOD", "pv"), data, top_n=600, variant_correction=True)
 typer.typing(sample.gene_cn)
 for d in _lib.Device.instances:
     for c in d.call_log or []:
