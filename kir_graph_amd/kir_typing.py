@@ -113,19 +113,11 @@ class _GeneView:
         return flags
 
 
-class TypingWithPosNegAllele(Typing):
-    """Likelihood typing with positive / negative variants (77-150)."""
+class _GenesInParallel(Typing):
+    """Gene loop on a few host threads, each with its own HIP stream (needs ``self._data``)."""
 
-    def __init__(self, filename_variant_json, top_n: int = 300, multiple: bool = False, exon_first: bool = False,
-                 exon_only: bool = False, exon_candidate_threshold: float = .9, variant_correction: bool = False,
-                 device: Device | None = None):
+    def __init__(self) -> None:
         super().__init__()
-        self._data = _sample(filename_variant_json, device)
-        self._multiple = multiple
-        self._top_n = top_n
-        self._exon_first, self._exon_only = exon_first, exon_only
-        self._exon_candidate_threshold = exon_candidate_threshold
-        self._variant_correction = variant_correction
         self._local = threading.local()
 
     def _context(self):
@@ -174,6 +166,21 @@ class TypingWithPosNegAllele(Typing):
         g = self._data.index.gene_id.get(gene)
         return 0 if g is None else self._data.index.tables[g].n_allele ** 2
 
+
+class TypingWithPosNegAllele(_GenesInParallel):
+    """Likelihood typing with positive / negative variants (77-150)."""
+
+    def __init__(self, filename_variant_json, top_n: int = 300, multiple: bool = False, exon_first: bool = False,
+                 exon_only: bool = False, exon_candidate_threshold: float = .9, variant_correction: bool = False,
+                 device: Device | None = None):
+        super().__init__()
+        self._data = _sample(filename_variant_json, device)
+        self._multiple = multiple
+        self._top_n = top_n
+        self._exon_first, self._exon_only = exon_first, exon_only
+        self._exon_candidate_threshold = exon_candidate_threshold
+        self._variant_correction = variant_correction
+
     def typingPerGene(self, gene: str, cn: int) -> tuple[list[str], int]:
         logger.debug(f"[Allele] {gene=} {cn=}")
         force_homo = False if isHetrozygous(gene) else None
@@ -215,7 +222,7 @@ class TypingWithPosNegAllele(Typing):
         return rows
 
 
-class TypingWithReport(Typing):
+class TypingWithReport(_GenesInParallel):
     """Abundance typing by the HISAT-genotype EM (153-204)."""
 
     def __init__(self, filename_variant_json, device: Device | None = None):
@@ -223,12 +230,13 @@ class TypingWithReport(Typing):
         self._data = _sample(filename_variant_json, device)
 
     def typingPerGene(self, gene: str, cn: int) -> tuple[list[str], int]:
-        view = _GeneView(self._data, gene, multiple=False)
+        tab, _ = self._context()
+        view = _GeneView(self._data, gene, multiple=False, tab=tab)
         pure_gene = gene.split("*")[0]
         report: list[Hisat2AlleleResult] = []
         if view.g is not None and view.alleles and view.n_rows:
             t = self._data.index.tables[view.g]
-            report = hisat2TypingPerGene(self._data.tab, view.rows, view.n_rows, view.vbeg, view.vbeg + view.n_span,
+            report = hisat2TypingPerGene(tab, view.rows, view.n_rows, view.vbeg, view.vbeg + view.n_span,
                                          view.mask, t.words, view.alleles)
         # descending abundance; ties by allele name (the reference leaves them to set order)
         report.sort(key=lambda r: (-r.prob, r.allele))
