@@ -1,0 +1,113 @@
+"""GPU checks at BASELINE.json's full size (configs[1]: 1 M read pairs, the bench workload), where the
+oracle is too slow: size-independent properties of the tabulation and of the typing results, recovery
+of the planted genotype, determinism, and the compact hand-off round trip."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (input generator of the bench workload)
+from kir_graph_amd.engine import DeviceIndex, Tabulation  # noqa: E402
+from kir_graph_amd.hisat2 import SampleData, loadCompact, writeCompact  # noqa: E402
+from kir_graph_amd.kir_typing import selectKirTypingModel  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+N_PAIRS = 1_000_000
+
+
+@pytest.fixture(scope="module")
+def full(device):
+    sidx, gidx, sample, rec, table = bench.build_inputs(1031, N_PAIRS)
+    dindex = DeviceIndex(device, gidx)
+    tab = Tabulation(dindex, device.put(rec))
+    data = SampleData(tab, gidx, None, ins_strings=table.strings)
+    yield sidx, gidx, sample, rec, data
+    tab.close()
+
+
+def test_tabulation_invariants(full):
+    sidx, gidx, sample, rec, data = full
+    tab = data.tab
+    # filterRead on both mates (hisat2.py:541-578), recomputed with numpy from the packed records
+    ok = ((rec["flag"] & 2) != 0) & (rec["nm"] != 255) & (rec["nm"] <= 4)
+    pair_ok = ok[0::2] & ok[1::2]
+    assert tab.n_valid == int(pair_ok.sum())
+    src = tab.pairSrc()
+    assert np.array_equal(src, np.flatnonzero(pair_ok))                     # input order kept
+    assert np.array_equal(tab.pairGene(), rec["ref"][0::2][src])
+    off, ids = tab.offsets().astype(np.int64), tab.ids()
+    assert off[0] == 0 and off[-1] == len(ids) == tab.n_ids and np.all(np.diff(off) >= 0)
+    assert ids.max() < tab.n_var_total
+    # every index ordinal of a pair belongs to the pair's own gene
+    vbeg = np.array([t.vbeg for t in gidx.tables]); vend = np.array([t.vend for t in gidx.tables])
+    owner = np.repeat(np.repeat(tab.pairGene().astype(np.int64), 4), np.diff(off))
+    known = ids < gidx.n_variant
+    assert np.all((ids[known] >= vbeg[owner[known]]) & (ids[known] < vend[owner[known]]))
+    # novel variants are numbered by first appearance (hisat2.py:597-602)
+    novel = ids[~known].astype(np.int64) - gidx.n_variant
+    _, first = np.unique(novel, return_index=True)
+    assert np.all(np.diff(first) > 0)
+    # a variant is never both positive and negative in one mate
+    lists = np.repeat(np.arange(len(off) - 1), np.diff(off))
+    mate = (lists >> 2) * 2 + (lists & 1)                                    # lpv,rpv,lnv,rnv -> left/right
+    key = mate.astype(np.int64) * (tab.n_var_total + 1) + ids
+    assert len(np.unique(key)) == len(key)
+
+
+def _type(data, sample, method="pv"):
+    typer = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
+    calls, warn = typer.typing(sample.gene_cn)
+    return typer, calls, warn
+
+
+def test_typing_recovers_the_planted_genotype_and_is_deterministic(full):
+    sidx, gidx, sample, rec, data = full
+    typer, calls, warn = _type(data, sample)
+    want = [a for g in sample.gene_cn for a in sorted(sample.truth[g])]
+    got = []
+    for g, cn in sample.gene_cn.items():
+        if cn:
+            got += sorted(c for c in calls if c.split("*")[0] == g.split("*")[0])
+    assert got == want
+    assert warn == []
+    # results of the last copy-number step of every gene: ranked, consistent
+    for gene, steps in typer._result.items():
+        last = steps[-1]
+        assert np.all(np.diff(last.value) <= 0)                               # best first
+        frac = np.asarray(last.fraction)
+        assert np.allclose(frac.sum(axis=1), 1.0, rtol=0, atol=1e-12)          # shares of a set sum to 1
+        ids = np.sort(np.asarray(last.allele_id), axis=1)
+        assert len(np.unique(ids, axis=0)) == len(ids)                        # no allele multiset twice
+        assert np.all(np.asarray(last.value_sum_indv) <= 0)
+    # a second run -- other thread interleaving, other stream assignment -- gives the same bits
+    typer2, calls2, _ = _type(data, sample)
+    assert calls2 == calls
+    for gene in typer._result:
+        a, b = typer._result[gene][-1], typer2._result[gene][-1]
+        assert np.array_equal(a.value, b.value) and np.array_equal(a.allele_id, b.allele_id)
+        assert np.array_equal(a.fraction, b.fraction)
+
+
+def test_other_strategies_agree_on_the_planted_genotype(full):
+    sidx, gidx, sample, rec, data = full
+    want = sorted(a for g in sample.gene_cn for a in sample.truth[g])
+    for method in ("exonfirst_1", "em"):
+        _, calls, _ = _type(data, sample, method)
+        if method == "em":      # abundance rounding may merge near-identical copies; the alleles named must be planted ones
+            assert set(calls) <= set(want)
+        else:                   # a copy planted twice may come back as another member of its exon group
+            assert set(want) <= set(calls) and len(calls) == len(want)
+
+
+def test_compact_round_trip_at_full_size(full, device, tmp_path):
+    sidx, gidx, sample, rec, data = full
+    _, calls, _ = _type(data, sample)
+    path = str(tmp_path / "s.variant.npz")
+    writeCompact(data, path)
+    back = loadCompact(path, device, index=gidx)
+    assert os.path.getsize(path) < 6 * data.tab.n_ids                          # ~4 B per variant hit + offsets
+    _, calls2, _ = _type(back, sample)
+    assert calls2 == calls
+    back.tab.close()
