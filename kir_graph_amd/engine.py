@@ -380,6 +380,12 @@ class DeviceModel:
                               cols.ctypes.data, len(cols), out.ctypes.data))
         return out
 
+    def pairTable(self) -> np.ndarray:
+        """``sum_r max(L[r, a], L[r, b])`` for every allele pair (a, b): the second search step's scores.
+        The library computes the upper triangle and mirrors it; the diagonal is the column sum."""
+        every = np.arange(self.n_allele)
+        return self.maxsum(every[:, None], every)
+
     def colsum(self, cols: np.ndarray) -> np.ndarray:
         return self.maxsum(None, cols)[0]
 

@@ -373,6 +373,7 @@ class AlleleTyping:
         self._model = DeviceModel(tab, rows, n_rows, rs.vflag, _vbeg, _vbeg + n_span, _mask, words, n_allele,
                                   self._logs)
         self._colsum_all: np.ndarray | None = None
+        self._pair_table: np.ndarray | None = None    # scores of all allele pairs (second step), when formed
         self._reads_cache = None
         if not _defer_log:
             self.finish()
@@ -434,6 +435,13 @@ class AlleleTyping:
             self.addCandidate()
             self.addHomoResultForCn(cn)
         else:
+            if cn >= 2 and 32 < self._model.n_allele <= self.top_n and self._model.n_rows:
+                # Every allele survives the first step, so the second step scores all allele pairs:
+                # the symmetric table is computed first -- its diagonal sum max(L_a, L_a) = sum L_a IS
+                # the first step's column sum (same terms, same summation tree), so no separate
+                # column-sum launch is needed and the second step reads its scores out of the table.
+                self._pair_table = self._model.pairTable()
+                self._colsum_all = np.ascontiguousarray(np.diagonal(self._pair_table))
             for _ in range(cn):
                 self.addCandidate()
         self.result[-1].print()
@@ -570,7 +578,12 @@ class AlleleTyping:
 
         prev = self.result[-1]
         prev_ids = np.asarray(prev.allele_id, dtype=np.int64)
-        score = (yield ("maxsum", prev_ids, cols)).ravel()  # candidate (t, a) at flat index t * len(cols) + a
+        table = getattr(self, "_pair_table", None)
+        if table is not None and prev_ids.shape[1] == 1:
+            score = table[prev_ids[:, 0]][:, np.asarray(cols, dtype=np.int64)].ravel()
+        else:
+            score = (yield ("maxsum", prev_ids, cols)).ravel()
+        # candidate (t, a) sits at flat index t * len(cols) + a
         # first occurrence of every allele multiset in (t-major, a-minor) order (uniqueAllele 456-476),
         # from keys built by broadcasting -- the (T*A) x CN id table is never materialised
         cols = np.asarray(cols, dtype=np.int64)
