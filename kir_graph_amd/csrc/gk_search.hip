@@ -317,15 +317,18 @@ __global__ __launch_bounds__(kThreads) void combine_chunks(const double* __restr
                                                            const int32_t* __restrict__ chunk_op0,
                                                            const TopOp* __restrict__ top, double scale_div,
                                                            double* __restrict__ out) {
+  // the span sums of a chunk sit in LDS ([span][thread]: conflict-free, and the program's dst / src
+  // indices need no private-memory array)
+  __shared__ double sp[kMaxSpans][kThreads];
   const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (o >= n_out) return;
+  const int t = threadIdx.x;
   double total = 0.0;
   for (int q = 0; q < n_chunks; ++q) {
     const int s0 = chunk_span0[q], s1 = chunk_span0[q + 1];
-    double p[kMaxSpans];
-    for (int s = s0; s < s1; ++s) p[s - s0] = partial[(int64_t)s * n_out + o];
-    for (int k = chunk_op0[q]; k < chunk_op0[q + 1]; ++k) p[top[k].dst] += p[top[k].src];
-    total = q == 0 ? p[0] : total + p[0];
+    for (int s = s0; s < s1; ++s) sp[s - s0][t] = partial[(int64_t)s * n_out + o];
+    for (int k = chunk_op0[q]; k < chunk_op0[q + 1]; ++k) sp[top[k].dst][t] += sp[top[k].src][t];
+    total = q == 0 ? sp[0][t] : total + sp[0][t];
   }
   out[o] = scale_div != 0.0 ? total / scale_div : total;
 }
