@@ -6,12 +6,19 @@
 // 461, 512-514; NotImplementedError for N and unknown ops at 499-502).  The variant walk itself runs on
 // the device from the records produced here.  Errors are reported with the reference's exception kind
 // and the 0-based index of the offending input line; the Python wrapper re-raises them.
+//
+// A chunk is processed in three steps: (1) the mate pairing, sequential and cheap (it decides the
+// emission order, which numbers the novel variants downstream); (2) the record decoding of the
+// emitted pairs, on several threads (GK_PACK_THREADS, default 8), each pair independent; (3) a
+// sequential merge in emission order that interns the inserted strings -- same ids as a one-by-one
+// walk -- and stops at the first pair the reference would have raised on.
 #include <cctype>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -40,6 +47,8 @@ struct gk_packer {
   std::unordered_map<std::string, Pending> waiting;
   std::vector<gk_mate> mates;
   std::vector<int64_t> pair_lines;   // 2 per pair: line index of left (later) and right (earlier) record
+  struct Job { sv left; std::string right; int64_t left_idx, right_idx; };
+  std::vector<Job> jobs;             // pairs emitted by the pairing pass of the current chunk
   std::string carry;                 // partial last line of the previous chunk
   int64_t n_lines = 0, n_reads = 0, n_pairs = 0, n_strange = 0;
   int err_kind = 0;                  // 0 none, 1 AssertionError, 2 NotImplementedError, 3 capacity, 4 ValueError
@@ -88,14 +97,14 @@ struct Fail { int kind; std::string msg; };
 struct Walked {
   std::vector<std::pair<int, long>> ops;        // (GK_CIG_*, length)
   std::vector<std::pair<long, int>> mms;        // (ref offset, read base)
-  std::vector<uint32_t> ins;
+  std::vector<std::string> ins;                 // inserted strings in I-op order (interned at merge time)
   bool clipped = false;
 };
 
 bool is_acgt(const MdTok& t) { return t.kind == 1 && (t.ch == 'A' || t.ch == 'C' || t.ch == 'G' || t.ch == 'T'); }
 
 // CIGAR / MD / Zs co-walk with the reference's consumption checks (see packed.py::_walkText)
-bool walk_text(gk_packer* pk, sv cigar, sv seq, bool has_md, sv md_s, bool has_zs, sv zs_s, Walked& w, Fail& f) {
+bool walk_text(sv cigar, sv seq, bool has_md, sv md_s, bool has_zs, sv zs_s, Walked& w, Fail& f) {
   std::vector<MdTok> md;
   if (has_md) {
     for (size_t i = 0; i < md_s.size();) {
@@ -179,18 +188,8 @@ bool walk_text(gk_packer* pk, sv cigar, sv seq, bool has_md, sv md_s, bool has_z
     } else if (op == 'I') {
       w.ops.push_back({GK_CIG_I, n});
       take_zs('I');
-      std::string s(seq.substr((size_t)std::min<long>(ri, (long)seq.size()),
-                               (size_t)std::max<long>(0, std::min<long>(n, (long)seq.size() - ri))));
-      auto it = pk->ins_id.find(s);
-      uint32_t id;
-      if (it == pk->ins_id.end()) {
-        id = (uint32_t)pk->ins_strings.size();
-        pk->ins_id.emplace(s, id);
-        pk->ins_strings.push_back(s);
-      } else {
-        id = it->second;
-      }
-      w.ins.push_back(id);
+      w.ins.emplace_back(seq.substr((size_t)std::min<long>(ri, (long)seq.size()),
+                                    (size_t)std::max<long>(0, std::min<long>(n, (long)seq.size() - ri))));
       ri += n;
     } else if (op == 'D') {
       w.ops.push_back({GK_CIG_D, n});
@@ -270,22 +269,31 @@ bool fail(gk_packer* pk, const Fail& f, int64_t line_index) {
   return false;
 }
 
-// one emitted pair: left = the later line, right = the earlier one (readPair yields (line, next_line))
-bool emit_pair(gk_packer* pk, sv left, int64_t left_idx, sv right, int64_t right_idx) {
+// one emitted pair: left = the later line, right = the earlier one (readPair yields (line, next_line)).
+// Pure function of the two lines and the gene table: safe to run for many pairs at once.
+struct Decoded {
+  gk_mate rec[2];
+  std::vector<std::string> ins[2];   // inserted strings met by the walk of each mate, in order
+  bool store_ins[2] = {false, false};   // ... and whether the record keeps their ids (not for clipped mates)
+  Fail fail{0, ""};
+  int64_t fail_line = -1;
+};
+
+void decode_pair(const gk_packer* pk, sv left, int64_t left_idx, sv right, int64_t right_idx, Decoded& out) {
   Parsed pr[2];
   Fail f{0, ""};
   sv lines[2] = {left, right};
   int64_t idx[2] = {left_idx, right_idx};
+  auto failed = [&](const Fail& why, int64_t line) { out.fail = why; out.fail_line = line; };
+  memset(out.rec, 0, sizeof(out.rec));
   for (int s = 0; s < 2; ++s)
-    if (!parse_record(lines[s], pr[s], f)) return fail(pk, f, idx[s]);
+    if (!parse_record(lines[s], pr[s], f)) return failed(f, idx[s]);
   const bool both = passes(pr[0]) && passes(pr[1]);
-  gk_mate rec[2];
-  memset(rec, 0, sizeof(rec));
   for (int s = 0; s < 2; ++s) {
     const Parsed& p = pr[s];
-    gk_mate& r = rec[s];
+    gk_mate& r = out.rec[s];
     auto g = pk->gene_id.find(std::string(p.cols[2]));
-    if (g == pk->gene_id.end()) return fail(pk, {4, "reference is not a backbone of the index"}, idx[s]);
+    if (g == pk->gene_id.end()) return failed({4, "reference is not a backbone of the index"}, idx[s]);
     r.pos0 = (uint32_t)(p.pos - 1);
     r.flag = (uint16_t)(p.flag & 0xFFFF);
     r.ref = (uint8_t)g->second;
@@ -293,8 +301,10 @@ bool emit_pair(gk_packer* pk, sv left, int64_t left_idx, sv right, int64_t right
     r.nm = p.has_nm ? (uint8_t)std::min<long>(std::max<long>(p.nm, 0), 254) : (uint8_t)GK_NM_ABSENT;
     if (!both) continue;
     Walked w;
-    if (!walk_text(pk, p.cols[5], p.cols[9], p.has_md, p.md, p.has_zs, p.zs, w, f)) return fail(pk, f, idx[s]);
-    if (w.clipped) {
+    const bool walked = walk_text(p.cols[5], p.cols[9], p.has_md, p.md, p.has_zs, p.zs, w, f);
+    out.ins[s] = std::move(w.ins);   // strings met before a failure are interned too, like a one-by-one walk
+    if (!walked) return failed(f, idx[s]);
+    if (w.clipped) {   // its strings are still interned at merge time, the record keeps none of them
       // keep the CIGAR (S ops included) for read depth when it fits, else only the clip marker
       std::vector<std::pair<int, long>> full;
       sv cg = p.cols[5];
@@ -315,21 +325,73 @@ bool emit_pair(gk_packer* pk, sv left, int64_t left_idx, sv right, int64_t right
     }
     size_t n_ev = w.mms.size();
     for (auto& o : w.ops) n_ev += (o.first == GK_CIG_I || o.first == GK_CIG_D) ? 1 : 0;
-    bool fits = w.ops.size() <= GK_MAX_CIG && w.mms.size() <= GK_MAX_MM && w.ins.size() <= GK_MAX_INS &&
+    bool fits = w.ops.size() <= GK_MAX_CIG && w.mms.size() <= GK_MAX_MM && out.ins[s].size() <= GK_MAX_INS &&
                 n_ev <= GK_MAX_EVENTS;
     for (auto& o : w.ops) fits = fits && o.second <= 4095;
     for (auto& m : w.mms) fits = fits && m.first <= 0xFFFF;
-    if (!fits) return fail(pk, {3, "record does not fit gk_mate"}, idx[s]);
-    r.n_cig = (uint8_t)w.ops.size(); r.n_mm = (uint8_t)w.mms.size(); r.n_ins = (uint8_t)w.ins.size();
+    if (!fits) return failed({3, "record does not fit gk_mate"}, idx[s]);
+    r.n_cig = (uint8_t)w.ops.size(); r.n_mm = (uint8_t)w.mms.size(); r.n_ins = (uint8_t)out.ins[s].size();
+    out.store_ins[s] = true;
     for (size_t i = 0; i < w.ops.size(); ++i) r.cig[i] = (uint16_t)((w.ops[i].second << 4) | w.ops[i].first);
     for (size_t i = 0; i < w.mms.size(); ++i) { r.mm[i].ref_off = (uint16_t)w.mms[i].first; r.mm[i].base = (uint8_t)w.mms[i].second; }
-    for (size_t i = 0; i < w.ins.size(); ++i) r.ins[i] = w.ins[i];
   }
-  pk->mates.push_back(rec[0]);
-  pk->mates.push_back(rec[1]);
-  pk->pair_lines.push_back(left_idx);
-  pk->pair_lines.push_back(right_idx);
-  return true;
+}
+
+int pack_threads() {
+  const char* e = getenv("GK_PACK_THREADS");
+  long n = e ? atol(e) : 8;
+  const long hw = (long)std::thread::hardware_concurrency();
+  if (hw > 0) n = std::min(n, hw);
+  return (int)std::max<long>(1, std::min<long>(n, 64));
+}
+
+// steps (2) and (3) for the pairs queued by the pairing pass
+bool run_jobs(gk_packer* pk) {
+  const size_t n = pk->jobs.size();
+  if (!n) return true;
+  std::vector<Decoded> dec(n);
+  const int n_thr = (int)std::min<size_t>((size_t)pack_threads(), (n + 255) / 256);
+  auto work = [&](size_t a, size_t b) {
+    for (size_t i = a; i < b; ++i) {
+      const gk_packer::Job& j = pk->jobs[i];
+      decode_pair(pk, j.left, j.left_idx, j.right, j.right_idx, dec[i]);
+    }
+  };
+  if (n_thr <= 1) {
+    work(0, n);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_thr; ++t) pool.emplace_back(work, n * t / n_thr, n * (t + 1) / n_thr);
+    for (auto& th : pool) th.join();
+  }
+  bool ok = true;
+  for (size_t i = 0; i < n && ok; ++i) {
+    Decoded& d = dec[i];
+    for (int s = 0; s < 2; ++s) {
+      for (size_t q = 0; q < d.ins[s].size(); ++q) {
+        auto it = pk->ins_id.find(d.ins[s][q]);
+        uint32_t id;
+        if (it == pk->ins_id.end()) {
+          id = (uint32_t)pk->ins_strings.size();
+          pk->ins_id.emplace(d.ins[s][q], id);
+          pk->ins_strings.push_back(d.ins[s][q]);
+        } else {
+          id = it->second;
+        }
+        if (d.store_ins[s] && q < GK_MAX_INS) d.rec[s].ins[q] = id;
+      }
+    }
+    if (d.fail.kind) {
+      ok = fail(pk, d.fail, d.fail_line);
+      break;
+    }
+    pk->mates.push_back(d.rec[0]);
+    pk->mates.push_back(d.rec[1]);
+    pk->pair_lines.push_back(pk->jobs[i].left_idx);
+    pk->pair_lines.push_back(pk->jobs[i].right_idx);
+  }
+  pk->jobs.clear();
+  return ok;
 }
 
 bool feed_line(gk_packer* pk, sv line, int64_t index) {
@@ -371,7 +433,8 @@ bool feed_line(gk_packer* pk, sv line, int64_t index) {
   Pending mate = std::move(it->second);
   pk->waiting.erase(it);
   pk->n_pairs += 1;
-  return emit_pair(pk, line, index, mate.line, mate.index);
+  pk->jobs.push_back({line, std::move(mate.line), index, mate.index});
+  return true;
 }
 
 }  // namespace
@@ -410,20 +473,30 @@ int gk_packer_feed(gk_packer* pk, const char* text, size_t n_bytes, int32_t fina
     data = sv(text, n_bytes);
   }
   size_t a = 0;
-  while (a < data.size()) {
+  bool ok = true;
+  while (a < data.size() && ok) {
     size_t nl = data.find('\n', a);
     if (nl == sv::npos) {
-      if (!final) { pk->carry.assign(data.substr(a)); return GK_OK; }
+      if (!final) { pk->carry.assign(data.substr(a)); break; }
       nl = data.size();
     }
     sv line = data.substr(a, nl - a);
     if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
     const int64_t index = pk->n_lines++;
-    if (!feed_line(pk, line, index)) {
-      gk_set_error("SAM line %lld: %s", (long long)pk->err_line, pk->err_msg.c_str());
-      return GK_ERR_ASSERT;
-    }
+    ok = feed_line(pk, line, index);    // pairing only: emitted pairs are queued
     a = nl + 1;
+  }
+  // decode the queued pairs (their left lines point into `data`, so before this call returns).  A
+  // pairing error comes from a later line than every queued pair: the queued pairs still decide
+  // whether an earlier one fails first.
+  const Fail pairing{pk->err_kind, pk->err_msg};
+  const int64_t pairing_line = pk->err_line;
+  if (!ok) { pk->err_kind = 0; pk->err_line = -1; pk->err_msg.clear(); }
+  bool decoded = run_jobs(pk);
+  if (decoded && !ok) fail(pk, pairing, pairing_line);
+  if (!decoded || !ok) {
+    gk_set_error("SAM line %lld: %s", (long long)pk->err_line, pk->err_msg.c_str());
+    return GK_ERR_ASSERT;
   }
   return GK_OK;
 }
