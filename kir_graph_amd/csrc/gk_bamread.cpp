@@ -16,7 +16,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "graphkir_hip.h"
@@ -72,6 +74,71 @@ bool inflate_members(const std::vector<uint8_t>& in, std::vector<uint8_t>& out) 
   }
   inflateEnd(&zs);
   return ok;
+}
+
+// BGZF members carry their own compressed size (extra field 'BC') and end with the uncompressed size,
+// so the file splits into independent blocks that inflate in parallel, each straight into its place.
+// Returns false when the stream is not made of such blocks (the caller then inflates sequentially).
+bool inflate_bgzf_parallel(const std::vector<uint8_t>& in, std::vector<uint8_t>& out, int n_threads) {
+  struct Block { size_t in_off, in_len, out_off, out_len; };
+  std::vector<Block> blocks;
+  size_t o = 0, total = 0;
+  while (o < in.size()) {
+    if (o + 18 > in.size()) return false;
+    const uint8_t* h = in.data() + o;
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+    const size_t xlen = rd16(h + 10);
+    if (o + 12 + xlen > in.size()) return false;
+    size_t bsize = 0;
+    for (size_t x = 0; x + 4 <= xlen;) {
+      const uint8_t* sub = h + 12 + x;
+      const size_t slen = rd16(sub + 2);
+      if (sub[0] == 'B' && sub[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (size_t)rd16(sub + 4) + 1;
+      x += 4 + slen;
+    }
+    if (!bsize || bsize < 12 + xlen + 8 || o + bsize > in.size()) return false;
+    const size_t isize = rd32(h + bsize - 4);
+    blocks.push_back({o + 12 + xlen, bsize - 12 - xlen - 8, total, isize});
+    total += isize;
+    o += bsize;
+  }
+  out.resize(total);
+  std::vector<char> bad((size_t)std::max(n_threads, 1), 0);
+  auto work = [&](int t, size_t a, size_t b) {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) { bad[(size_t)t] = 1; return; }
+    for (size_t i = a; i < b; ++i) {
+      const Block& bl = blocks[i];
+      if (!bl.out_len) continue;
+      inflateReset(&zs);
+      zs.next_in = const_cast<Bytef*>(in.data() + bl.in_off);
+      zs.avail_in = (uInt)bl.in_len;
+      zs.next_out = out.data() + bl.out_off;
+      zs.avail_out = (uInt)bl.out_len;
+      if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) { bad[(size_t)t] = 1; break; }
+    }
+    inflateEnd(&zs);
+  };
+  const size_t n = blocks.size();
+  n_threads = (int)std::min<size_t>((size_t)std::max(n_threads, 1), std::max<size_t>(n / 8, 1));
+  if (n_threads <= 1) {
+    work(0, 0, n);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; ++t) pool.emplace_back(work, t, n * t / n_threads, n * (t + 1) / n_threads);
+    for (auto& th : pool) th.join();
+  }
+  for (char b : bad) if (b) return false;
+  return true;
+}
+
+int ingest_threads() {
+  const char* e = getenv("GK_PACK_THREADS");
+  long n = e ? atol(e) : 8;
+  const long hw = (long)std::thread::hardware_concurrency();
+  if (hw > 0) n = std::min(n, hw);
+  return (int)std::max<long>(1, std::min<long>(n, 64));
 }
 
 // Query-name order: characters compare by code, except that where both names have a digit the two
@@ -248,7 +315,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
     fclose(f);
   }
   gk_bam* b = new gk_bam();
-  if (!inflate_members(raw, b->data)) {
+  if (!inflate_bgzf_parallel(raw, b->data, ingest_threads()) && !inflate_members(raw, b->data)) {
     delete b;
     gk_set_error("%s is not a BGZF / gzip stream or is truncated", path);
     return GK_ERR_ARG;

@@ -66,8 +66,8 @@ def _bgzf_block(data: bytes) -> bytes:
             struct.pack("<II", zlib.crc32(data), len(data)))
 
 
-def samToBam(lines: list[str], path: str, block: int = 40000) -> None:
-    """Write header ('@' lines) and records of ``lines`` to ``path`` as BAM, in the given order."""
+def bamBytes(lines: list[str]) -> bytes:
+    """Uncompressed BAM stream of header ('@' lines) and records of ``lines``, in the given order."""
     header = [l for l in lines if l.startswith("@")]
     refs = []
     for l in header:
@@ -79,7 +79,12 @@ def samToBam(lines: list[str], path: str, block: int = 40000) -> None:
     raw = b"BAM\x01" + struct.pack("<I", len(text)) + text + struct.pack("<I", len(refs))
     for n, ln in refs:
         raw += struct.pack("<I", len(n) + 1) + n.encode() + b"\0" + struct.pack("<I", ln)
-    raw += b"".join(_record(l, ref_id) for l in lines if l and not l.startswith("@"))
+    return raw + b"".join(_record(l, ref_id) for l in lines if l and not l.startswith("@"))
+
+
+def samToBam(lines: list[str], path: str, block: int = 40000) -> None:
+    """Write ``bamBytes(lines)`` to ``path`` as BGZF blocks of ``block`` bytes plus the EOF block."""
+    raw = bamBytes(lines)
     with open(path, "wb") as f:
         for i in range(0, len(raw), block):
             f.write(_bgzf_block(raw[i:i + block]))

@@ -293,6 +293,18 @@ def test_native_bam_reader_collates_and_renders_like_sam_text(tmp_path):
     # hisat2.readBam yields the same lines
     from kir_graph_amd.hisat2 import readBam
     assert list(readBam(path)) == want
+    # a plain gzip stream without BGZF block sizes takes the sequential inflate path
+    from bamwriter import bamBytes
+    plain = str(tmp_path / "plain.bam")
+    with open(plain, "wb") as f:
+        f.write(gzip.compress(bamBytes(header + by_coord)))
+    assert b"".join(packed.bamChunks(plain)).decode().split("\n")[:-1] == want
+    # one decoding thread or many: same text
+    os.environ["GK_PACK_THREADS"] = "1"
+    try:
+        assert b"".join(packed.bamChunks(path)).decode().split("\n")[:-1] == want
+    finally:
+        del os.environ["GK_PACK_THREADS"]
 
 
 def test_native_bam_reader_rejects_garbage(tmp_path):
