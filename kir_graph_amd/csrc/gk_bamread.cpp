@@ -32,7 +32,8 @@ struct gk_bam {
   struct Rec { uint64_t off; uint32_t size; };
   std::vector<Rec> recs;                // in output order after sorting
   size_t next = 0;                      // next record to render
-  std::string line;                     // rendered line that did not fit the caller's buffer yet
+  std::string staged;                   // rendered lines not handed out yet
+  size_t staged_off = 0;
 };
 
 namespace {
@@ -172,8 +173,12 @@ int name_order(const char* a0, const char* b0) {
 
 void append_int(std::string& s, long long v) {
   char tmp[24];
-  const int n = snprintf(tmp, sizeof(tmp), "%lld", v);
-  s.append(tmp, (size_t)n);
+  char* e = tmp + sizeof(tmp);
+  char* p = e;
+  unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+  do { *--p = (char)('0' + u % 10); u /= 10; } while (u);
+  if (v < 0) *--p = '-';
+  s.append(p, (size_t)(e - p));
 }
 
 // one optional field "TAG:TYPE:VALUE"; returns the bytes consumed or 0 on a malformed field
@@ -282,13 +287,24 @@ bool render(const gk_bam& b, const gk_bam::Rec& r, std::string& s) {
     s.push_back('*');
   } else {
     static const char kBase[] = "=ACMGRSVTWYHKDBN";
-    for (uint32_t i = 0; i < l_seq; ++i) s.push_back(kBase[(seq[i >> 1] >> ((~i & 1u) << 2)) & 15u]);
+    const size_t at = s.size();
+    s.resize(at + l_seq);
+    char* d = &s[at];
+    for (uint32_t i = 0; i + 1 < l_seq; i += 2) {
+      const uint8_t b2 = seq[i >> 1];
+      d[i] = kBase[b2 >> 4];
+      d[i + 1] = kBase[b2 & 15u];
+    }
+    if (l_seq & 1u) d[l_seq - 1] = kBase[seq[(l_seq - 1) >> 1] >> 4];
   }
   s.push_back('\t');
   if (l_seq == 0 || qual[0] == 0xFF) {
     s.push_back('*');
   } else {
-    for (uint32_t i = 0; i < l_seq; ++i) s.push_back((char)(qual[i] + 33));
+    const size_t at = s.size();
+    s.resize(at + l_seq);
+    char* d = &s[at];
+    for (uint32_t i = 0; i < l_seq; ++i) d[i] = (char)(qual[i] + 33);
   }
   while (tags < end) {
     s.push_back('\t');
@@ -351,12 +367,33 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
   if (o != d.size()) return bad("trailing bytes");
   if (name_sorted) {
     const uint8_t* base = d.data();
-    std::stable_sort(b->recs.begin(), b->recs.end(), [base](const gk_bam::Rec& x, const gk_bam::Rec& y) {
+    auto before = [base](const gk_bam::Rec& x, const gk_bam::Rec& y) {
       const uint8_t *px = base + x.off, *py = base + y.off;
       const int t = name_order((const char*)px + 32, (const char*)py + 32);
       if (t) return t < 0;
       return (rd16(px + 14) & 0xC0u) < (rd16(py + 14) & 0xC0u);   // READ1 (0x40) before READ2 (0x80)
-    });
+    };
+    // stable merge sort over the ingest threads: sorted runs, then pairwise stable merges
+    auto& recs = b->recs;
+    const size_t n = recs.size();
+    int runs = 1;
+    while (runs * 2 <= ingest_threads() && (size_t)runs * 2 * 4096 <= n) runs *= 2;
+    auto bound = [&](int i) { return n * (size_t)i / (size_t)runs; };
+    {
+      std::vector<std::thread> pool;
+      for (int i = 0; i < runs; ++i)
+        pool.emplace_back([&, i] { std::stable_sort(recs.begin() + bound(i), recs.begin() + bound(i + 1), before); });
+      for (auto& th : pool) th.join();
+    }
+    for (int width = 1; width < runs; width *= 2) {
+      std::vector<std::thread> pool;
+      for (int i = 0; i + width < runs; i += 2 * width)
+        pool.emplace_back([&, i, width] {
+          std::inplace_merge(recs.begin() + bound(i), recs.begin() + bound(i + width),
+                             recs.begin() + bound(std::min(i + 2 * width, runs)), before);
+        });
+      for (auto& th : pool) th.join();
+    }
   }
   *out = b;
   return GK_OK;
@@ -382,26 +419,56 @@ int gk_bam_header(gk_bam* b, char* text_out, int64_t capacity) {
 }
 
 // Whole lines ('\n' terminated) in output order until the buffer is full; *n_written == 0 at the end.
+// Records are rendered in batches, each batch split over the ingest threads.
 int gk_bam_next(gk_bam* b, char* text_out, int64_t capacity, int64_t* n_written) {
   if (!b || !text_out || !n_written || capacity < 1) { gk_set_error("bad arguments"); return GK_ERR_ARG; }
   int64_t w = 0;
   while (true) {
-    if (b->line.empty()) {
+    if (b->staged_off >= b->staged.size()) {
+      b->staged.clear();
+      b->staged_off = 0;
       if (b->next >= b->recs.size()) break;
-      if (!render(*b, b->recs[b->next], b->line)) {
-        gk_set_error("malformed alignment record %zu", b->next);
-        return GK_ERR_ARG;
+      const size_t first = b->next, last = std::min(b->recs.size(), first + (size_t)65536);
+      const int n_thr = (int)std::min<size_t>((size_t)ingest_threads(), (last - first + 1023) / 1024);
+      std::vector<std::string> part((size_t)std::max(n_thr, 1));
+      std::vector<long long> bad((size_t)std::max(n_thr, 1), -1);
+      auto work = [&](int t, size_t a, size_t e) {
+        std::string line;
+        part[(size_t)t].reserve((e - a) * 480);
+        for (size_t i = a; i < e; ++i) {
+          if (!render(*b, b->recs[i], line)) { bad[(size_t)t] = (long long)i; return; }
+          part[(size_t)t] += line;
+          part[(size_t)t].push_back('\n');
+        }
+      };
+      const size_t n = last - first;
+      if (n_thr <= 1) {
+        work(0, first, last);
+      } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_thr; ++t) pool.emplace_back(work, t, first + n * t / n_thr, first + n * (t + 1) / n_thr);
+        for (auto& th : pool) th.join();
       }
-      b->line.push_back('\n');
-      ++b->next;
+      for (long long i : bad)
+        if (i >= 0) { gk_set_error("malformed alignment record %lld", i); return GK_ERR_ARG; }
+      for (auto& p : part) b->staged += p;
+      b->next = last;
     }
-    if ((int64_t)b->line.size() > capacity - w) {
-      if (w == 0) { gk_set_error("line of %zu bytes does not fit the buffer", b->line.size()); return GK_ERR_CAPACITY; }
+    // hand out whole lines
+    const size_t avail = b->staged.size() - b->staged_off;
+    size_t take = std::min<size_t>(avail, (size_t)(capacity - w));
+    if (take < avail) {   // cut at the last newline that fits
+      const size_t nl = b->staged.rfind('\n', b->staged_off + take - 1);
+      take = (nl == std::string::npos || nl < b->staged_off) ? 0 : nl + 1 - b->staged_off;
+    }
+    if (take == 0) {
+      if (w == 0) { gk_set_error("a line does not fit the buffer of %lld bytes", (long long)capacity); return GK_ERR_CAPACITY; }
       break;
     }
-    memcpy(text_out + w, b->line.data(), b->line.size());
-    w += (int64_t)b->line.size();
-    b->line.clear();
+    memcpy(text_out + w, b->staged.data() + b->staged_off, take);
+    w += (int64_t)take;
+    b->staged_off += take;
+    if (w == capacity) break;
   }
   *n_written = w;
   return GK_OK;

@@ -32,7 +32,14 @@ using sv = std::string_view;
 
 struct LineRef { int64_t begin, len, index; };   // byte range in the stream and line number
 
-struct Pending { std::string line; int64_t index; int flag; };
+// a record waiting for its mate: a view into the chunk being fed, turned into an owned copy only if the
+// mate has not arrived by the end of the chunk
+struct Pending {
+  sv view;
+  std::string owned;
+  int64_t index;
+  int flag;
+};
 
 struct MdTok { int kind; long num; char ch; };   // kind 0 = number, 1 = character
 
@@ -47,7 +54,7 @@ struct gk_packer {
   std::unordered_map<std::string, Pending> waiting;
   std::vector<gk_mate> mates;
   std::vector<int64_t> pair_lines;   // 2 per pair: line index of left (later) and right (earlier) record
-  struct Job { sv left; std::string right; int64_t left_idx, right_idx; };
+  struct Job { sv left, right; std::string right_owned; int64_t left_idx, right_idx; };
   std::vector<Job> jobs;             // pairs emitted by the pairing pass of the current chunk
   std::string carry;                 // partial last line of the previous chunk
   int64_t n_lines = 0, n_reads = 0, n_pairs = 0, n_strange = 0;
@@ -354,7 +361,7 @@ bool run_jobs(gk_packer* pk) {
   auto work = [&](size_t a, size_t b) {
     for (size_t i = a; i < b; ++i) {
       const gk_packer::Job& j = pk->jobs[i];
-      decode_pair(pk, j.left, j.left_idx, j.right, j.right_idx, dec[i]);
+      decode_pair(pk, j.left, j.left_idx, j.right_owned.empty() ? j.right : sv(j.right_owned), j.right_idx, dec[i]);
     }
   };
   if (n_thr <= 1) {
@@ -415,15 +422,15 @@ bool feed_line(gk_packer* pk, sv line, int64_t index) {
   long flag;
   if (!to_long(f[1], flag)) return fail(pk, {4, "malformed FLAG"}, index);
   const char sec = (flag & 256) ? '1' : '0';
-  auto key = [&](sv pos) {
-    std::string k;
-    k.reserve(f[0].size() + f[2].size() + pos.size() + 4);
-    k.append(f[0]); k.push_back('\t'); k.append(f[2]); k.push_back('\t'); k.append(pos); k.push_back('\t'); k.push_back(sec);
-    return k;
+  static thread_local std::string kbuf;
+  auto key = [&](sv pos) -> std::string& {
+    kbuf.clear();
+    kbuf.append(f[0]); kbuf.push_back('\t'); kbuf.append(f[2]); kbuf.push_back('\t'); kbuf.append(pos); kbuf.push_back('\t'); kbuf.push_back(sec);
+    return kbuf;
   };
   auto it = pk->waiting.find(key(f[7]));
   if (it == pk->waiting.end()) {
-    pk->waiting[key(f[3])] = Pending{std::string(line), index, (int)flag};
+    pk->waiting[key(f[3])] = Pending{line, std::string(), index, (int)flag};
     return true;
   }
   if (((it->second.flag | flag) & 192) != 192) {   // READ1 and READ2 must both be present
@@ -433,7 +440,7 @@ bool feed_line(gk_packer* pk, sv line, int64_t index) {
   Pending mate = std::move(it->second);
   pk->waiting.erase(it);
   pk->n_pairs += 1;
-  pk->jobs.push_back({line, std::move(mate.line), index, mate.index});
+  pk->jobs.push_back({line, mate.view, std::move(mate.owned), index, mate.index});
   return true;
 }
 
@@ -493,6 +500,8 @@ int gk_packer_feed(gk_packer* pk, const char* text, size_t n_bytes, int32_t fina
   const int64_t pairing_line = pk->err_line;
   if (!ok) { pk->err_kind = 0; pk->err_line = -1; pk->err_msg.clear(); }
   bool decoded = run_jobs(pk);
+  for (auto& kv : pk->waiting)      // records still waiting outlive this chunk: keep their text
+    if (kv.second.owned.empty()) { kv.second.owned.assign(kv.second.view); kv.second.view = sv(); }
   if (decoded && !ok) fail(pk, pairing, pairing_line);
   if (!decoded || !ok) {
     gk_set_error("SAM line %lld: %s", (long long)pk->err_line, pk->err_msg.c_str());
