@@ -236,6 +236,9 @@ int gk_bam_close(gk_bam* bam);
 int gk_bam_info(gk_bam* bam, int64_t* n_records, int64_t* header_bytes, int32_t* n_ref);
 int gk_bam_header(gk_bam* bam, char* text_out, int64_t capacity);
 int gk_bam_next(gk_bam* bam, char* text_out, int64_t capacity, int64_t* n_written);
+/* every record, in output order, straight into a packer (created with gk_packer_create): the same pairs
+ * and gk_mate records as feeding the rendered text to gk_packer_feed, without producing the text. */
+int gk_bam_pack(gk_bam* bam, struct gk_packer* packer);
 
 /* ---- read depth: replaces `samtools depth -aa {name}.no_multi.bam` (samtools_utils.py:9-14).
  * Depth of every backbone position from the M runs of the filter-passing pairs of a tabulation made

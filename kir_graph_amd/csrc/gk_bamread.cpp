@@ -21,6 +21,7 @@
 #include <thread>
 #include <vector>
 
+#include "gk_ingest.h"
 #include "graphkir_hip.h"
 
 void gk_set_error(const char* fmt, ...);
@@ -397,6 +398,94 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
   }
   *out = b;
   return GK_OK;
+}
+
+// The records, in output order, straight into a packer: same pairing, checks and records as feeding
+// the rendered text to gk_packer_feed, without rendering or re-parsing it.  Only what the packer reads
+// is converted (CIGAR and SEQ to text; NM / MD / Zs / NH from the optional fields).
+int gk_bam_pack(gk_bam* b, gk_packer* pk) {
+  if (!b || !pk) { gk_set_error("null handle"); return GK_ERR_ARG; }
+  const uint8_t* base = b->data.data();
+  auto ref_name = [&](int32_t id) -> std::string_view {
+    return (id >= 0 && (size_t)id < b->ref_names.size()) ? std::string_view(b->ref_names[(size_t)id]) : std::string_view("*");
+  };
+  auto key = [&](int64_t i, GkAlnKey& k) {
+    const uint8_t* p = base + b->recs[(size_t)i].off;
+    const int32_t ref_id = rds32(p), next_ref = rds32(p + 20);
+    k.name = std::string_view((const char*)p + 32, strnlen((const char*)p + 32, p[8]));
+    k.ref = ref_name(ref_id);
+    k.flag = rd16(p + 14);
+    k.pos = (long)rds32(p + 4) + 1;
+    k.next_pos = (long)rds32(p + 24) + 1;
+    k.mate_same_ref = next_ref >= 0 && next_ref == ref_id;
+  };
+  auto full = [&](int64_t i, GkAlnRecord& r) {
+    const gk_bam::Rec& rec = b->recs[(size_t)i];
+    const uint8_t* p = base + rec.off;
+    const uint32_t l_name = p[8], n_cig = rd16(p + 12), l_seq = rd32(p + 16);
+    r.ref = ref_name(rds32(p));
+    r.flag = rd16(p + 14);
+    r.pos = (long)rds32(p + 4) + 1;
+    const uint8_t* cig = p + 32 + l_name;
+    const uint8_t* seq = cig + 4ull * n_cig;
+    const uint8_t* tags = seq + (l_seq + 1) / 2 + l_seq;
+    const uint8_t* end = p + rec.size;
+    r.cigar_text.clear();
+    if (n_cig == 0) r.cigar_text.push_back('*');
+    for (uint32_t c = 0; c < n_cig; ++c) {
+      const uint32_t v = rd32(cig + 4ull * c);
+      append_int(r.cigar_text, v >> 4);
+      r.cigar_text.push_back((v & 15u) < 9 ? "MIDNSHP=X"[v & 15u] : '?');
+    }
+    static const char kBase[] = "=ACMGRSVTWYHKDBN";
+    r.seq_text.resize(l_seq ? l_seq : 1);
+    if (!l_seq) r.seq_text[0] = '*';
+    for (uint32_t q = 0; q < l_seq; ++q) r.seq_text[q] = kBase[(seq[q >> 1] >> ((~q & 1u) << 2)) & 15u];
+    r.cigar = r.cigar_text;
+    r.seq = r.seq_text;
+    r.has_nm = r.has_md = r.has_zs = false;
+    r.nh = 1;
+    bool has_nh = false;
+    while (tags + 3 <= end) {
+      const char t0 = (char)tags[0], t1 = (char)tags[1], type = (char)tags[2];
+      const uint8_t* v = tags + 3;
+      size_t used = 0;
+      long ival = 0;
+      bool is_int = true;
+      switch (type) {
+        case 'A': used = 1; is_int = false; break;
+        case 'c': used = 1; ival = (int8_t)v[0]; break;
+        case 'C': used = 1; ival = v[0]; break;
+        case 's': used = 2; ival = (int16_t)rd16(v); break;
+        case 'S': used = 2; ival = rd16(v); break;
+        case 'i': used = 4; ival = rds32(v); break;
+        case 'I': used = 4; ival = (long)rd32(v); break;
+        case 'f': used = 4; is_int = false; break;
+        case 'Z': case 'H': {
+          const void* z = memchr(v, 0, (size_t)(end - v));
+          if (!z) return;
+          const size_t n = (const uint8_t*)z - v;
+          if (type == 'Z' && t0 == 'M' && t1 == 'D' && !r.has_md) { r.has_md = true; r.md = std::string_view((const char*)v, n); }
+          if (type == 'Z' && t0 == 'Z' && t1 == 's' && !r.has_zs) { r.has_zs = true; r.zs = std::string_view((const char*)v, n); }
+          used = n + 1; is_int = false;
+          break;
+        }
+        case 'B': {
+          if (v + 5 > end) return;
+          const char sub = (char)v[0];
+          const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+          used = 5 + (size_t)rd32(v + 1) * w; is_int = false;
+          break;
+        }
+        default: return;
+      }
+      if (v + used > end) return;
+      if (is_int && t0 == 'N' && t1 == 'M') { r.has_nm = true; r.nm = ival; }            // the last NM counts (hisat2.py:564-567)
+      if (is_int && t0 == 'N' && t1 == 'H' && !has_nh && ival >= 0) { has_nh = true; r.nh = ival; }   // getNH: the first
+      tags = v + used;
+    }
+  };
+  return gk_packer_feed_records(pk, (int64_t)b->recs.size(), key, full);
 }
 
 int gk_bam_close(gk_bam* b) {

@@ -1,0 +1,29 @@
+// Internal interface between the alignment readers and the packer (gk_sampack.cpp): what the packer
+// needs to know about one alignment record, whatever it was read from.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <string_view>
+
+struct gk_packer;
+
+struct GkAlnKey {            // fields of readPair's pairing rule (hisat2.py:248-258)
+  std::string_view name, ref;
+  long flag = 0, pos = 0, next_pos = 0;   // positions 1-based like the SAM text
+  bool mate_same_ref = false;             // RNEXT is "="
+};
+
+struct GkAlnRecord {         // fields of filterRead / getNH / recordToRawVariant
+  std::string_view ref, cigar, seq, md, zs;
+  std::string cigar_text, seq_text;       // storage when the source is not text (views above point here)
+  long flag = 0, pos = 0, nm = 0, nh = 1;
+  bool has_nm = false, has_md = false, has_zs = false;
+};
+
+// Pair n records in stream order like readPair and pack the emitted pairs (decoding on several
+// threads).  key(i, k) and full(i, r) fill the fields of record i; both must be thread-safe and the
+// views must stay valid until the call returns.  Line numbers reported for errors / pairs are
+// first_line + i.  Returns GK_OK or the packer's error code.
+int gk_packer_feed_records(gk_packer* pk, int64_t n, const std::function<void(int64_t, GkAlnKey&)>& key,
+                           const std::function<void(int64_t, GkAlnRecord&)>& full);

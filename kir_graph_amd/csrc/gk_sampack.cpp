@@ -22,6 +22,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "gk_ingest.h"
 #include "graphkir_hip.h"
 
 void gk_set_error(const char* fmt, ...);
@@ -224,23 +225,17 @@ bool walk_text(sv cigar, sv seq, bool has_md, sv md_s, bool has_zs, sv zs_s, Wal
   return true;
 }
 
-struct Parsed {
+// SAM text line -> record fields (views into the line)
+bool parse_record(sv line, GkAlnRecord& p, Fail& f) {
   std::vector<sv> cols;
-  long flag = 0, pos = 0;
-  bool has_nm = false, has_md = false, has_zs = false;
-  long nm = 0;
-  sv md, zs;
-  long nh = 1;
-};
-
-bool parse_record(sv line, Parsed& p, Fail& f) {
-  split_tabs(strip(line), p.cols);
-  if (p.cols.size() < 11 || !to_long(p.cols[1], p.flag) || !to_long(p.cols[3], p.pos)) {
+  split_tabs(strip(line), cols);
+  if (cols.size() < 11 || !to_long(cols[1], p.flag) || !to_long(cols[3], p.pos)) {
     f = {4, "malformed SAM record"};
     return false;
   }
-  for (size_t i = 11; i < p.cols.size(); ++i) {
-    sv c = p.cols[i];
+  p.ref = cols[2]; p.cigar = cols[5]; p.seq = cols[9];
+  for (size_t i = 11; i < cols.size(); ++i) {
+    sv c = cols[i];
     if (c.substr(0, 2) == "NM") {
       long v;
       if (!to_long(c.size() >= 5 ? c.substr(5) : sv(), v)) { f = {4, "malformed NM tag"}; return false; }
@@ -267,7 +262,7 @@ bool parse_record(sv line, Parsed& p, Fail& f) {
   return true;
 }
 
-bool passes(const Parsed& p) { return (p.flag & 2) && p.has_nm && p.nm <= 4; }
+bool passes(const GkAlnRecord& p) { return (p.flag & 2) && p.has_nm && p.nm <= 4; }
 
 bool fail(gk_packer* pk, const Fail& f, int64_t line_index) {
   pk->err_kind = f.kind;
@@ -286,20 +281,29 @@ struct Decoded {
   int64_t fail_line = -1;
 };
 
+void decode_records(const gk_packer* pk, const GkAlnRecord* pr, const int64_t* idx, Decoded& out);
+
 void decode_pair(const gk_packer* pk, sv left, int64_t left_idx, sv right, int64_t right_idx, Decoded& out) {
-  Parsed pr[2];
+  GkAlnRecord pr[2];
   Fail f{0, ""};
   sv lines[2] = {left, right};
   int64_t idx[2] = {left_idx, right_idx};
-  auto failed = [&](const Fail& why, int64_t line) { out.fail = why; out.fail_line = line; };
   memset(out.rec, 0, sizeof(out.rec));
   for (int s = 0; s < 2; ++s)
-    if (!parse_record(lines[s], pr[s], f)) return failed(f, idx[s]);
+    if (!parse_record(lines[s], pr[s], f)) { out.fail = f; out.fail_line = idx[s]; return; }
+  decode_records(pk, pr, idx, out);
+}
+
+// the pair (left, right) as record fields -> two gk_mate records + the strings to intern
+void decode_records(const gk_packer* pk, const GkAlnRecord* pr, const int64_t* idx, Decoded& out) {
+  Fail f{0, ""};
+  auto failed = [&](const Fail& why, int64_t line) { out.fail = why; out.fail_line = line; };
+  memset(out.rec, 0, sizeof(out.rec));
   const bool both = passes(pr[0]) && passes(pr[1]);
   for (int s = 0; s < 2; ++s) {
-    const Parsed& p = pr[s];
+    const GkAlnRecord& p = pr[s];
     gk_mate& r = out.rec[s];
-    auto g = pk->gene_id.find(std::string(p.cols[2]));
+    auto g = pk->gene_id.find(std::string(p.ref));
     if (g == pk->gene_id.end()) return failed({4, "reference is not a backbone of the index"}, idx[s]);
     r.pos0 = (uint32_t)(p.pos - 1);
     r.flag = (uint16_t)(p.flag & 0xFFFF);
@@ -308,13 +312,13 @@ void decode_pair(const gk_packer* pk, sv left, int64_t left_idx, sv right, int64
     r.nm = p.has_nm ? (uint8_t)std::min<long>(std::max<long>(p.nm, 0), 254) : (uint8_t)GK_NM_ABSENT;
     if (!both) continue;
     Walked w;
-    const bool walked = walk_text(p.cols[5], p.cols[9], p.has_md, p.md, p.has_zs, p.zs, w, f);
+    const bool walked = walk_text(p.cigar, p.seq, p.has_md, p.md, p.has_zs, p.zs, w, f);
     out.ins[s] = std::move(w.ins);   // strings met before a failure are interned too, like a one-by-one walk
     if (!walked) return failed(f, idx[s]);
     if (w.clipped) {   // its strings are still interned at merge time, the record keeps none of them
       // keep the CIGAR (S ops included) for read depth when it fits, else only the clip marker
       std::vector<std::pair<int, long>> full;
-      sv cg = p.cols[5];
+      sv cg = p.cigar;
       for (size_t i = 0; i < cg.size();) {
         if (!isdigit((unsigned char)cg[i])) { ++i; continue; }
         long n = 0;
@@ -352,27 +356,9 @@ int pack_threads() {
   return (int)std::max<long>(1, std::min<long>(n, 64));
 }
 
-// steps (2) and (3) for the pairs queued by the pairing pass
-bool run_jobs(gk_packer* pk) {
-  const size_t n = pk->jobs.size();
-  if (!n) return true;
-  std::vector<Decoded> dec(n);
-  const int n_thr = (int)std::min<size_t>((size_t)pack_threads(), (n + 255) / 256);
-  auto work = [&](size_t a, size_t b) {
-    for (size_t i = a; i < b; ++i) {
-      const gk_packer::Job& j = pk->jobs[i];
-      decode_pair(pk, j.left, j.left_idx, j.right_owned.empty() ? j.right : sv(j.right_owned), j.right_idx, dec[i]);
-    }
-  };
-  if (n_thr <= 1) {
-    work(0, n);
-  } else {
-    std::vector<std::thread> pool;
-    for (int t = 0; t < n_thr; ++t) pool.emplace_back(work, n * t / n_thr, n * (t + 1) / n_thr);
-    for (auto& th : pool) th.join();
-  }
-  bool ok = true;
-  for (size_t i = 0; i < n && ok; ++i) {
+// step (3): in emission order, intern the inserted strings, stop at the first failed pair
+bool merge_decoded(gk_packer* pk, std::vector<Decoded>& dec, const std::vector<int64_t>& lines) {
+  for (size_t i = 0; i < dec.size(); ++i) {
     Decoded& d = dec[i];
     for (int s = 0; s < 2; ++s) {
       for (size_t q = 0; q < d.ins[s].size(); ++q) {
@@ -388,15 +374,41 @@ bool run_jobs(gk_packer* pk) {
         if (d.store_ins[s] && q < GK_MAX_INS) d.rec[s].ins[q] = id;
       }
     }
-    if (d.fail.kind) {
-      ok = fail(pk, d.fail, d.fail_line);
-      break;
-    }
+    if (d.fail.kind) return fail(pk, d.fail, d.fail_line);
     pk->mates.push_back(d.rec[0]);
     pk->mates.push_back(d.rec[1]);
-    pk->pair_lines.push_back(pk->jobs[i].left_idx);
-    pk->pair_lines.push_back(pk->jobs[i].right_idx);
+    pk->pair_lines.push_back(lines[2 * i]);
+    pk->pair_lines.push_back(lines[2 * i + 1]);
   }
+  return true;
+}
+
+template <typename Work>
+void on_threads(size_t n, const Work& work) {
+  const int n_thr = (int)std::min<size_t>((size_t)pack_threads(), (n + 255) / 256);
+  if (n_thr <= 1) {
+    work(0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < n_thr; ++t) pool.emplace_back(work, n * t / n_thr, n * (t + 1) / n_thr);
+  for (auto& th : pool) th.join();
+}
+
+// steps (2) and (3) for the pairs queued by the pairing pass
+bool run_jobs(gk_packer* pk) {
+  const size_t n = pk->jobs.size();
+  if (!n) return true;
+  std::vector<Decoded> dec(n);
+  on_threads(n, [&](size_t a, size_t b) {
+    for (size_t i = a; i < b; ++i) {
+      const gk_packer::Job& j = pk->jobs[i];
+      decode_pair(pk, j.left, j.left_idx, j.right_owned.empty() ? j.right : sv(j.right_owned), j.right_idx, dec[i]);
+    }
+  });
+  std::vector<int64_t> lines(2 * n);
+  for (size_t i = 0; i < n; ++i) { lines[2 * i] = pk->jobs[i].left_idx; lines[2 * i + 1] = pk->jobs[i].right_idx; }
+  const bool ok = merge_decoded(pk, dec, lines);
   pk->jobs.clear();
   return ok;
 }
@@ -445,6 +457,61 @@ bool feed_line(gk_packer* pk, sv line, int64_t index) {
 }
 
 }  // namespace
+
+// Records of another source (BAM) through the same pairing rule, decoder and merge as SAM text.
+int gk_packer_feed_records(gk_packer* pk, int64_t n, const std::function<void(int64_t, GkAlnKey&)>& key,
+                           const std::function<void(int64_t, GkAlnRecord&)>& full) {
+  if (!pk || n < 0) { gk_set_error("bad packer arguments"); return GK_ERR_ARG; }
+  if (pk->err_kind) return GK_ERR_ASSERT;
+  if (!pk->waiting.empty() || !pk->carry.empty()) { gk_set_error("text and record input cannot be mixed"); return GK_ERR_ARG; }
+  const int64_t base = pk->n_lines;
+  pk->n_lines += n;
+  // (1) pairing in stream order (hisat2.py:248-270)
+  struct Wait { int64_t index; long flag; };
+  std::unordered_map<std::string, Wait> waiting;
+  std::vector<int64_t> pairs;   // left (later) and right (earlier) record of every emitted pair
+  std::string kbuf;
+  for (int64_t i = 0; i < n; ++i) {
+    GkAlnKey k;
+    key(i, k);
+    if (!k.mate_same_ref) continue;
+    pk->n_reads += 1;
+    auto make = [&](long pos) -> std::string& {
+      kbuf.assign(k.name); kbuf.push_back('\t'); kbuf.append(k.ref); kbuf.push_back('\t');
+      kbuf.append(std::to_string(pos)); kbuf.push_back('\t'); kbuf.push_back((k.flag & 256) ? '1' : '0');
+      return kbuf;
+    };
+    auto it = waiting.find(make(k.next_pos));
+    if (it == waiting.end()) {
+      waiting[make(k.pos)] = Wait{i, k.flag};
+      continue;
+    }
+    if (((it->second.flag | k.flag) & 192) != 192) { pk->n_strange += 1; continue; }
+    pairs.push_back(i);
+    pairs.push_back(it->second.index);
+    waiting.erase(it);
+    pk->n_pairs += 1;
+  }
+  // (2) decode on threads, (3) ordered merge
+  const size_t n_pair = pairs.size() / 2;
+  std::vector<Decoded> dec(n_pair);
+  on_threads(n_pair, [&](size_t a, size_t b) {
+    for (size_t i = a; i < b; ++i) {
+      GkAlnRecord pr[2];
+      const int64_t idx[2] = {base + pairs[2 * i], base + pairs[2 * i + 1]};
+      full(pairs[2 * i], pr[0]);
+      full(pairs[2 * i + 1], pr[1]);
+      decode_records(pk, pr, idx, dec[i]);
+    }
+  });
+  std::vector<int64_t> lines(pairs.size());
+  for (size_t i = 0; i < pairs.size(); ++i) lines[i] = base + pairs[i];
+  if (!merge_decoded(pk, dec, lines)) {
+    gk_set_error("alignment record %lld: %s", (long long)pk->err_line, pk->err_msg.c_str());
+    return GK_ERR_ASSERT;
+  }
+  return GK_OK;
+}
 
 extern "C" {
 

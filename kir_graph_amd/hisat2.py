@@ -319,13 +319,18 @@ def extractVariantFromText(source, index: GkIndex, dev: Device | None = None, di
     Same result as ``extractVariant(readPair(path), ...)`` with the pairing and text decoding done
     natively (``gk_packer_*``).  ``keep_text``: keep the SAM lines of the emitted pairs (needed only
     for the ``l_sam`` / ``r_sam`` fields of ``.variant.json``)."""
-    from .packed import packText, readChunks
+    from .packed import packBam, packText, readChunks
     dev = dev or Device()
     dindex = dindex or DeviceIndex(dev, index)
-    chunks = readChunks(source) if isinstance(source, str) else source
-    if keep_text:
-        chunks = list(chunks)
-    rec, table, pair_lines, counts = packText(chunks, index)
+    if isinstance(source, str) and source.endswith(".bam") and not keep_text:
+        # nobody needs the SAM text: the BAM records go to the packer in binary form
+        chunks = None
+        rec, table, pair_lines, counts = packBam(source, index)
+    else:
+        chunks = readChunks(source) if isinstance(source, str) else source
+        if keep_text:
+            chunks = list(chunks)
+        rec, table, pair_lines, counts = packText(chunks, index)
     logger.info(f"[Graph] Reads: {counts['reads']} Pairs: {counts['pairs']}")
     pairs_text = None
     if keep_text:

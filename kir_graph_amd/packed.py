@@ -204,12 +204,8 @@ def packPairs(pairs, index: GkIndex, table: InsTable | None = None) -> tuple[np.
 _ERR_KINDS = {1: AssertionError, 2: NotImplementedError, 3: PackCapacityError, 4: ValueError}
 
 
-def packText(chunks, index: GkIndex, table: InsTable | None = None):
-    """Name-collated SAM text (iterable of ``bytes`` chunks) -> (records, table, pair_lines, counts).
-
-    Native pairing + decoding (``csrc/gk_sampack.cpp``): same records, same pairing order and the same
-    exceptions as ``hisat2.pairLines`` + ``packPairs``, at a few million lines per second.
-    ``pair_lines[p] = (line index of left, line index of right)`` for the emitted pairs."""
+def _withPacker(index: GkIndex, table: InsTable | None, feed):
+    """Create a native packer, let ``feed(handle)`` push alignments into it, collect the result."""
     import ctypes as C
     from ._lib import check, lib
     table = table or InsTable(index)
@@ -218,13 +214,7 @@ def packText(chunks, index: GkIndex, table: InsTable | None = None):
     pk = C.c_void_p()
     check(lib().gk_packer_create(genes, len(index.genes), strings, len(table.strings), C.byref(pk)))
     try:
-        rc = 0
-        for chunk in chunks:
-            rc = lib().gk_packer_feed(pk, chunk, len(chunk), 0)
-            if rc:
-                break
-        if not rc:
-            lib().gk_packer_feed(pk, b"", 0, 1)   # flush the last (unterminated) line
+        feed(pk)
         kind, line = C.c_int32(), C.c_int64()
         check(lib().gk_packer_error(pk, C.byref(kind), C.byref(line)))
         if kind.value:
@@ -243,6 +233,38 @@ def packText(chunks, index: GkIndex, table: InsTable | None = None):
         return rec, table, pair_lines, counts
     finally:
         lib().gk_packer_destroy(pk)
+
+
+def packText(chunks, index: GkIndex, table: InsTable | None = None):
+    """Name-collated SAM text (iterable of ``bytes`` chunks) -> (records, table, pair_lines, counts).
+
+    Native pairing + decoding (``csrc/gk_sampack.cpp``): same records, same pairing order and the same
+    exceptions as ``hisat2.pairLines`` + ``packPairs``, at about a million lines per second.
+    ``pair_lines[p] = (line index of left, line index of right)`` for the emitted pairs."""
+    from ._lib import lib
+
+    def feed(pk):
+        for chunk in chunks:
+            if lib().gk_packer_feed(pk, chunk, len(chunk), 0):
+                return
+        lib().gk_packer_feed(pk, b"", 0, 1)   # flush the last (unterminated) line
+
+    return _withPacker(index, table, feed)
+
+
+def packBam(path: str, index: GkIndex, table: InsTable | None = None, name_sorted: bool = True):
+    """``.bam`` file -> (records, table, pair_lines, counts) without going through SAM text.
+
+    Same result as ``packText(bamChunks(path), ...)``: the records are inflated, name-collated and handed
+    to the packer in binary form (``gk_bam_pack``); ``pair_lines`` index the collated record stream."""
+    import ctypes as C
+    from ._lib import check, lib
+    h = C.c_void_p()
+    check(lib().gk_bam_open(path.encode(), int(name_sorted), C.byref(h)))
+    try:
+        return _withPacker(index, table, lambda pk: lib().gk_bam_pack(h, pk))
+    finally:
+        lib().gk_bam_close(h)
 
 
 def bamChunks(path: str, chunk_bytes: int = 1 << 24, name_sorted: bool = True):

@@ -128,14 +128,18 @@ def test_command_line_reads_coordinate_sorted_bam(device, tmp_path):
     cn_path = tmp_path / "s.cn.tsv"
     cn_path.write_text("gene\tcn\n" + "".join(f"{g}\t{c}\n" for g, c in s.gene_cn.items()))
     calls = []
-    for k, aln in enumerate(("s.bam", "s.sam.gz")):
+    # BAM through the rendered text (JSON wanted), BAM in binary form (no JSON: compact hand-off), SAM text
+    for k, (aln, extra) in enumerate((("s.bam", []), ("s.bam", ["--no-variant-json"]), ("s.sam.gz", []))):
         out = tmp_path / f"out{k}"
         args = cli.createParser().parse_args(
             ["--step-skip-extraction", "--index-folder", str(folder), "--output-folder", str(out),
-             "--allele-strategy", "pv", "--cn-provided", str(cn_path), "--alignment", str(tmp_path / aln)])
+             "--allele-strategy", "pv", "--cn-provided", str(cn_path), "--alignment", str(tmp_path / aln)] + extra)
         cli.main(args)
         calls.append(pd.read_csv(out / "cohort.allele.tsv", sep="\t")["alleles"][0])
-    assert calls[0] == calls[1] and "*" in calls[0]
+        produced = [p.name for p in out.iterdir()]
+        assert any(n.endswith(".variant.npz") for n in produced) == bool(extra)
+        assert any(n.endswith(".variant.json") for n in produced) != bool(extra)
+    assert calls[0] == calls[1] == calls[2] and "*" in calls[0]
 
 
 def test_compact_side_format_round_trip(device, tmp_path):

@@ -290,6 +290,11 @@ def test_native_bam_reader_collates_and_renders_like_sam_text(tmp_path):
     a, _, pa, _ = packed.packText(packed.readChunks(path), gidx)
     b, _, pb, _ = packed.packText([("\n".join(want) + "\n").encode()], gidx)
     assert a.tobytes() == b.tobytes() and pa.tolist() == pb.tolist()
+    # ... and so does the binary hand-over that skips the text
+    c, table_c, pc, counts_c = packed.packBam(path, gidx)
+    assert c.tobytes() == b.tobytes() and pc.tolist() == pb.tolist()
+    assert table_c.strings == packed.packText([("\n".join(want) + "\n").encode()], gidx)[1].strings
+    assert counts_c["pairs"] == len(b) // 2 and counts_c["lines"] == len(want)
     # hisat2.readBam yields the same lines
     from kir_graph_amd.hisat2 import readBam
     assert list(readBam(path)) == want

@@ -25,3 +25,6 @@ print(f"BAM -> collated text     {len(lines) / dt1 / 1e6:.2f} M lines/s")
 t = time.time(); rec2, *_ = packed.packText(chunks, gidx); dt2 = time.time() - t
 print(f"BAM -> records (total)   {len(lines) / (dt1 + dt2) / 1e6:.2f} M lines/s")
 assert rec.tobytes() == rec2.tobytes()
+t = time.time(); rec3, *_ = packed.packBam(bam, gidx); dt3 = time.time() - t
+print(f"BAM -> records (binary)  {len(lines) / dt3 / 1e6:.2f} M lines/s")
+assert rec.tobytes() == rec3.tobytes()
