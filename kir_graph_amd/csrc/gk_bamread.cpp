@@ -32,6 +32,7 @@ struct gk_bam {
   std::vector<std::string> ref_names;
   struct Rec { uint64_t off; uint32_t size; };
   std::vector<Rec> recs;                // in output order after sorting
+  bool name_sorted = false;             // recs are in query-name order
   size_t next = 0;                      // next record to render
   std::string staged;                   // rendered lines not handed out yet
   size_t staged_off = 0;
@@ -366,6 +367,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
     o += size;
   }
   if (o != d.size()) return bad("trailing bytes");
+  b->name_sorted = name_sorted != 0;
   if (name_sorted) {
     const uint8_t* base = d.data();
     auto before = [base](const gk_bam::Rec& x, const gk_bam::Rec& y) {
@@ -485,7 +487,7 @@ int gk_bam_pack(gk_bam* b, gk_packer* pk) {
       tags = v + used;
     }
   };
-  return gk_packer_feed_records(pk, (int64_t)b->recs.size(), key, full);
+  return gk_packer_feed_records(pk, (int64_t)b->recs.size(), b->name_sorted, key, full);
 }
 
 int gk_bam_close(gk_bam* b) {

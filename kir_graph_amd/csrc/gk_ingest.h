@@ -24,6 +24,8 @@ struct GkAlnRecord {         // fields of filterRead / getNH / recordToRawVarian
 // Pair n records in stream order like readPair and pack the emitted pairs (decoding on several
 // threads).  key(i, k) and full(i, r) fill the fields of record i; both must be thread-safe and the
 // views must stay valid until the call returns.  Line numbers reported for errors / pairs are
-// first_line + i.  Returns GK_OK or the packer's error code.
-int gk_packer_feed_records(gk_packer* pk, int64_t n, const std::function<void(int64_t, GkAlnKey&)>& key,
+// first_line + i.  names_contiguous: records of one name are adjacent (a name-collated stream), which
+// lets the pairing run on several threads.  Returns GK_OK or the packer's error code.
+int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
+                           const std::function<void(int64_t, GkAlnKey&)>& key,
                            const std::function<void(int64_t, GkAlnRecord&)>& full);

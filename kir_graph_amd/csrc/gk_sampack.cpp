@@ -459,38 +459,72 @@ bool feed_line(gk_packer* pk, sv line, int64_t index) {
 }  // namespace
 
 // Records of another source (BAM) through the same pairing rule, decoder and merge as SAM text.
-int gk_packer_feed_records(gk_packer* pk, int64_t n, const std::function<void(int64_t, GkAlnKey&)>& key,
+int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
+                           const std::function<void(int64_t, GkAlnKey&)>& key,
                            const std::function<void(int64_t, GkAlnRecord&)>& full) {
   if (!pk || n < 0) { gk_set_error("bad packer arguments"); return GK_ERR_ARG; }
   if (pk->err_kind) return GK_ERR_ASSERT;
   if (!pk->waiting.empty() || !pk->carry.empty()) { gk_set_error("text and record input cannot be mixed"); return GK_ERR_ARG; }
   const int64_t base = pk->n_lines;
   pk->n_lines += n;
-  // (1) pairing in stream order (hisat2.py:248-270)
+  // (1) pairing in stream order (hisat2.py:248-270).  Only records with the same name can pair, so
+  // when equal names are contiguous (a name-collated stream) the stream is cut at name changes and
+  // the pieces are paired independently; their emission lists, concatenated, are the sequential one.
   struct Wait { int64_t index; long flag; };
-  std::unordered_map<std::string, Wait> waiting;
-  std::vector<int64_t> pairs;   // left (later) and right (earlier) record of every emitted pair
-  std::string kbuf;
-  for (int64_t i = 0; i < n; ++i) {
-    GkAlnKey k;
-    key(i, k);
-    if (!k.mate_same_ref) continue;
-    pk->n_reads += 1;
-    auto make = [&](long pos) -> std::string& {
-      kbuf.assign(k.name); kbuf.push_back('\t'); kbuf.append(k.ref); kbuf.push_back('\t');
-      kbuf.append(std::to_string(pos)); kbuf.push_back('\t'); kbuf.push_back((k.flag & 256) ? '1' : '0');
-      return kbuf;
-    };
-    auto it = waiting.find(make(k.next_pos));
-    if (it == waiting.end()) {
-      waiting[make(k.pos)] = Wait{i, k.flag};
-      continue;
+  struct Piece { std::vector<int64_t> pairs; int64_t n_reads = 0, n_strange = 0; };
+  auto pair_range = [&](int64_t a, int64_t b, Piece& out) {
+    std::unordered_map<std::string, Wait> waiting;
+    std::string kbuf;
+    for (int64_t i = a; i < b; ++i) {
+      GkAlnKey k;
+      key(i, k);
+      if (!k.mate_same_ref) continue;
+      out.n_reads += 1;
+      auto make = [&](long pos) -> std::string& {
+        kbuf.assign(k.name); kbuf.push_back('\t'); kbuf.append(k.ref); kbuf.push_back('\t');
+        kbuf.append(std::to_string(pos)); kbuf.push_back('\t'); kbuf.push_back((k.flag & 256) ? '1' : '0');
+        return kbuf;
+      };
+      auto it = waiting.find(make(k.next_pos));
+      if (it == waiting.end()) {
+        waiting[make(k.pos)] = Wait{i, k.flag};
+        continue;
+      }
+      if (((it->second.flag | k.flag) & 192) != 192) { out.n_strange += 1; continue; }
+      out.pairs.push_back(i);                    // left = the later record
+      out.pairs.push_back(it->second.index);     // right = the earlier one
+      waiting.erase(it);
     }
-    if (((it->second.flag | k.flag) & 192) != 192) { pk->n_strange += 1; continue; }
-    pairs.push_back(i);
-    pairs.push_back(it->second.index);
-    waiting.erase(it);
-    pk->n_pairs += 1;
+  };
+  std::vector<int64_t> cuts{0};
+  if (names_contiguous) {
+    const int want = (int)std::min<int64_t>(pack_threads(), std::max<int64_t>(n / 4096, 1));
+    for (int t = 1; t < want; ++t) {
+      int64_t c = std::max(cuts.back(), n * t / want);
+      GkAlnKey prev, cur;
+      while (c > cuts.back() && c < n) {
+        key(c - 1, prev); key(c, cur);
+        if (prev.name != cur.name) break;
+        ++c;
+      }
+      if (c > cuts.back() && c < n) cuts.push_back(c);
+    }
+  }
+  cuts.push_back(n);
+  std::vector<Piece> pieces(cuts.size() - 1);
+  if (pieces.size() == 1) {
+    pair_range(0, n, pieces[0]);
+  } else {
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < pieces.size(); ++t) pool.emplace_back([&, t] { pair_range(cuts[t], cuts[t + 1], pieces[t]); });
+    for (auto& th : pool) th.join();
+  }
+  std::vector<int64_t> pairs;   // left (later) and right (earlier) record of every emitted pair
+  for (auto& pc : pieces) {
+    pairs.insert(pairs.end(), pc.pairs.begin(), pc.pairs.end());
+    pk->n_reads += pc.n_reads;
+    pk->n_strange += pc.n_strange;
+    pk->n_pairs += (int64_t)pc.pairs.size() / 2;
   }
   // (2) decode on threads, (3) ordered merge
   const size_t n_pair = pairs.size() / 2;
