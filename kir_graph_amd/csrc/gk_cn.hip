@@ -66,6 +66,7 @@ extern "C" {
 // loglik_out[j] for bases[j]; cn_of_bin_out (may be null) = argmax CN row per bin at best_base.
 int gk_cn_fit(gk_ctx* ctx, const double* x, const double* density, int32_t bins, const double* bases, int32_t n_bases,
               const double* dev, int32_t n_cn, int32_t first_cn, double space, double* loglik_out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && x && density && bases && dev && loglik_out, "null pointer");
   GK_REQUIRE(bins > 0 && n_bases > 0 && n_cn > 0 && n_cn <= kMaxCN, "bad CN fit geometry");
   hipStream_t st = ctx->stream;
@@ -88,6 +89,7 @@ int gk_cn_fit(gk_ctx* ctx, const double* x, const double* density, int32_t bins,
 
 int gk_cn_assign(gk_ctx* ctx, const double* x, int32_t bins, double base, const double* dev, int32_t n_cn,
                  int32_t first_cn, double space, int32_t* cn_of_bin_out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && x && dev && cn_of_bin_out && bins > 0 && n_cn > 0 && n_cn <= kMaxCN, "bad CN assign arguments");
   hipStream_t st = ctx->stream;
   double* d = nullptr;

@@ -75,6 +75,13 @@ void gk_prof_end(gk_ctx* ctx);
 
 int gk_ctx_scratch(gk_ctx* ctx, size_t bytes, void** out);
 
+// Make the context's GPU the current HIP device of the calling host thread.  Every entry point of
+// the C ABI starts with it: contexts are driven from pool threads (gene workers, sample prefetch)
+// that never chose a device themselves, and on a multi-GPU node the default device is not theirs.
+static inline void gk_bind(gk_ctx* ctx) {
+  if (ctx) (void)hipSetDevice(ctx->device);   // per-thread state in the runtime: cheap, and never stale
+}
+
 // Stream-ordered caching allocator: freed blocks are kept per size class and handed out again
 // without hipMalloc / hipFree (both synchronise the device).  Safe because every kernel and copy
 // of a context runs on its single stream.

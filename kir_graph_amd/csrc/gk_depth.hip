@@ -51,6 +51,7 @@ __global__ __launch_bounds__(kThreads) void depth_finish(const uint32_t* excl, c
 
 extern "C" int gk_depth(gk_ctx* ctx, gk_tab* tab, gk_dptr d_mates, int32_t multiple, const int64_t* gene_off,
                         int32_t n_gene, uint32_t* depth_out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && tab && gene_off && depth_out && n_gene > 0, "bad depth arguments");
   GK_REQUIRE(tab->d_pair_src, "depth needs a tabulation made from packed records");
   const int64_t total = gene_off[n_gene];

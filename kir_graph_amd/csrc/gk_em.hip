@@ -207,6 +207,7 @@ extern "C" {
 
 int gk_em_sets(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, int32_t vbeg, int32_t vend, gk_dptr d_mask,
                int32_t words, gk_dptr d_sets_out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && tab, "null pointer");
   GK_REQUIRE(words >= 1 && words <= kMaxWords, "more than 512 alleles per gene are not supported by the EM kernel");
   if (!n_rows) return GK_OK;
@@ -219,6 +220,7 @@ int gk_em_sets(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, int32_t
 
 int gk_em_distinct(gk_ctx* ctx, gk_dptr d_sets, int64_t n_rows, int32_t words, int32_t max_out, uint32_t* sets_out,
                    uint32_t* count_out, int32_t* n_out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && sets_out && count_out && n_out && max_out > 0, "null pointer");
   GK_REQUIRE(words >= 1 && words <= kMaxWords && n_rows >= 0 && n_rows < (1ll << 31), "bad set geometry");
   *n_out = 0;
@@ -265,6 +267,7 @@ int gk_em_distinct(gk_ctx* ctx, gk_dptr d_sets, int64_t n_rows, int32_t words, i
 
 int gk_em_run(gk_ctx* ctx, const uint32_t* sets, const double* weight, int32_t n_sets, int32_t words, int32_t n_allele,
               int32_t iter_max, double diff_threshold, double* prob_out, int32_t* iters_out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && sets && weight && prob_out && iters_out, "null pointer");
   GK_REQUIRE(n_sets > 0 && words >= 1 && words <= kMaxWords && n_allele >= 1 && n_allele <= words * 32,
              "bad EM geometry");

@@ -69,6 +69,7 @@ __global__ void fill_keys(uint64_t* keys, uint64_t n) {
 extern "C" {
 
 int gk_lut_create(gk_ctx* ctx, int32_t log2_capacity, gk_lut** out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && out && log2_capacity >= 10 && log2_capacity <= 26, "bad table capacity");
   gk_lut* l = new gk_lut();
   l->ctx = ctx; l->log2cap = (uint32_t)log2_capacity;
@@ -90,6 +91,7 @@ int gk_lut_create(gk_ctx* ctx, int32_t log2_capacity, gk_lut** out) {
 }
 
 int gk_lut_destroy(gk_lut* l) {
+  gk_bind(l ? l->ctx : nullptr);
   if (!l) return GK_OK;
   hipStreamSynchronize(l->ctx->stream);
   hipFree(l->d_keys); hipFree(l->d_slot_idx); hipFree(l->d_list); hipFree(l->d_vals); hipFree(l->d_count);
@@ -98,6 +100,7 @@ int gk_lut_destroy(gk_lut* l) {
 }
 
 int gk_lut_collect(gk_lut* l, gk_dptr d_vals, int64_t n) {
+  gk_bind(l ? l->ctx : nullptr);
   GK_REQUIRE(l, "null table");
   if (n <= 0) return GK_OK;
   int64_t want = (n + kThreads - 1) / kThreads;
@@ -110,6 +113,7 @@ int gk_lut_collect(gk_lut* l, gk_dptr d_vals, int64_t n) {
 }
 
 int gk_lut_pending(gk_lut* l, int32_t* n_total, int32_t* n_known) {
+  gk_bind(l ? l->ctx : nullptr);
   GK_REQUIRE(l && n_total && n_known, "null pointer");
   uint32_t c = 0;
   GK_HIP(hipMemcpyAsync(&c, l->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, l->ctx->stream));
@@ -130,6 +134,7 @@ int gk_lut_pending(gk_lut* l, int32_t* n_total, int32_t* n_known) {
 }
 
 int gk_lut_export(gk_lut* l, int32_t first, int32_t count, double* keys_out) {
+  gk_bind(l ? l->ctx : nullptr);
   GK_REQUIRE(l && keys_out && first >= 0 && count >= 0, "bad arguments");
   if (!count) return GK_OK;
   GK_HIP(hipMemcpyAsync(keys_out, l->d_list + first, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost,
@@ -139,6 +144,7 @@ int gk_lut_export(gk_lut* l, int32_t first, int32_t count, double* keys_out) {
 }
 
 int gk_lut_define(gk_lut* l, int32_t first, int32_t count, const double* log_vals) {
+  gk_bind(l ? l->ctx : nullptr);
   GK_REQUIRE(l && log_vals && first == l->n_known && count >= 0, "values must be defined in order");
   if (!count) return GK_OK;
   GK_HIP(hipMemcpyAsync(l->d_vals + first, log_vals, (size_t)count * sizeof(double), hipMemcpyHostToDevice,
@@ -149,6 +155,7 @@ int gk_lut_define(gk_lut* l, int32_t first, int32_t count, const double* log_val
 }
 
 int gk_lut_apply(gk_lut* l, gk_dptr d_in, gk_dptr d_out, int64_t n) {
+  gk_bind(l ? l->ctx : nullptr);
   GK_REQUIRE(l, "null table");
   if (n <= 0) return GK_OK;
   int64_t want = (n + kThreads - 1) / kThreads;

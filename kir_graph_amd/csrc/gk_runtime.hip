@@ -47,6 +47,7 @@ int gk_ctx_create(int device, gk_ctx** out) {
 }
 
 int gk_ctx_destroy(gk_ctx* ctx) {
+  gk_bind(ctx);
   if (!ctx) return GK_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
@@ -62,12 +63,14 @@ int gk_ctx_destroy(gk_ctx* ctx) {
 }
 
 int gk_sync(gk_ctx* ctx) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   GK_HIP(hipStreamSynchronize(ctx->stream));
   return GK_OK;
 }
 
 int gk_malloc(gk_ctx* ctx, size_t bytes, gk_dptr* out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && out, "null pointer");
   GK_HIP(hipSetDevice(ctx->device));
   void* p = nullptr;
@@ -77,6 +80,7 @@ int gk_malloc(gk_ctx* ctx, size_t bytes, gk_dptr* out) {
 }
 
 int gk_free(gk_ctx* ctx, gk_dptr p) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   if (!p) return GK_OK;
   gk_pool_free(ctx, gk_ptr<void>(p));
@@ -84,6 +88,7 @@ int gk_free(gk_ctx* ctx, gk_dptr p) {
 }
 
 int gk_memset(gk_ctx* ctx, gk_dptr p, int value, size_t bytes) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   if (!bytes) return GK_OK;
   GK_HIP(hipMemsetAsync(gk_ptr<void>(p), value, bytes, ctx->stream));
@@ -91,6 +96,7 @@ int gk_memset(gk_ctx* ctx, gk_dptr p, int value, size_t bytes) {
 }
 
 int gk_h2d(gk_ctx* ctx, gk_dptr dst, const void* src, size_t bytes) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   if (!bytes) return GK_OK;
   GK_HIP(hipMemcpyAsync(gk_ptr<void>(dst), src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -99,6 +105,7 @@ int gk_h2d(gk_ctx* ctx, gk_dptr dst, const void* src, size_t bytes) {
 }
 
 int gk_d2h(gk_ctx* ctx, void* dst, gk_dptr src, size_t bytes) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   if (!bytes) return GK_OK;
   GK_HIP(hipMemcpyAsync(dst, gk_ptr<void>(src), bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -107,6 +114,7 @@ int gk_d2h(gk_ctx* ctx, void* dst, gk_dptr src, size_t bytes) {
 }
 
 int gk_d2d(gk_ctx* ctx, gk_dptr dst, gk_dptr src, size_t bytes) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   if (!bytes) return GK_OK;
   GK_HIP(hipMemcpyAsync(gk_ptr<void>(dst), gk_ptr<void>(src), bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -114,12 +122,14 @@ int gk_d2d(gk_ctx* ctx, gk_dptr dst, gk_dptr src, size_t bytes) {
 }
 
 int gk_timer_start(gk_ctx* ctx) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   GK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
   return GK_OK;
 }
 
 int gk_timer_stop_ms(gk_ctx* ctx, float* ms) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && ms, "null pointer");
   GK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
   GK_HIP(hipEventSynchronize(ctx->ev1));
@@ -203,6 +213,7 @@ static const char* kKernelNames[GK_K_N] = {
     "lut_apply", "maxsum_chunks", "combine_chunks", "fraction_chunks", "setmax_kernel", "em_sets_kernel", "em_kernel"};
 
 extern "C" int gk_prof_enable(gk_ctx* ctx, int on) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   ctx->prof_on = on != 0;
   return GK_OK;
@@ -213,6 +224,7 @@ extern "C" const char* gk_prof_kernel_name(int id) { return id >= 0 && id < GK_K
 
 // launches[id], total_ms[id] for id < GK_K_N; clears the recorded spans
 extern "C" int gk_prof_collect(gk_ctx* ctx, int64_t* launches, double* total_ms) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && launches && total_ms, "null pointer");
   GK_HIP(hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < GK_K_N; ++i) { launches[i] = 0; total_ms[i] = 0.0; }
@@ -230,6 +242,7 @@ extern "C" int gk_prof_collect(gk_ctx* ctx, int64_t* launches, double* total_ms)
 }
 
 int gk_ctx_scratch(gk_ctx* ctx, size_t bytes, void** out) {
+  gk_bind(ctx);
   if (bytes > ctx->scratch_bytes) {
     GK_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->scratch) GK_HIP(hipFree(ctx->scratch));

@@ -139,6 +139,7 @@ static int scan_rec(gk_ctx* ctx, uint32_t* d, int64_t n, uint32_t* sums_area, ui
 }
 
 int gk_scan_u32(gk_ctx* ctx, uint32_t* d_data, int64_t n, uint32_t* d_total) {
+  gk_bind(ctx);
   // scratch for tile sums of every level: tiles + tiles/kTile + ... <= tiles + tiles/1024 + 64
   int64_t tiles = (n + kTile - 1) / kTile;
   size_t need = (size_t)(tiles + tiles / 1024 + 4096) * sizeof(uint32_t);
@@ -151,6 +152,7 @@ int gk_scan_u32(gk_ctx* ctx, uint32_t* d_data, int64_t n, uint32_t* d_total) {
 
 int gk_compact(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int64_t n, int32_t* d_out,
                int64_t* n_out) {
+  gk_bind(ctx);
   if (n <= 0) {
     if (n_out) *n_out = 0;
     return GK_OK;

@@ -620,6 +620,7 @@ int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
 
 int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c_prev,
               const int32_t* cols, int32_t n_cols, double* out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && cols && out && n_rows > 0 && ld >= n_rows && n_cols > 0, "bad maxsum arguments");
   GK_REQUIRE(c_prev >= 0 && c_prev <= kMaxC, "copy number beyond supported set size");
   GK_REQUIRE(n_sets >= 1 && (c_prev == 0 || ids), "missing previous sets");
@@ -705,6 +706,7 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
 
 int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
                 double* frac_out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && ids && frac_out && n_rows > 0 && ld >= n_rows && n_sets > 0, "bad fraction arguments");
   GK_REQUIRE(c >= 1 && c <= kMaxC, "copy number beyond supported set size");
   // Order the sets so that tiles of 32 share columns: the best sets pair a few strong alleles with
@@ -798,6 +800,7 @@ int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int3
 
 int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
               gk_dptr d_P) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && ids && n_rows > 0 && ld >= n_rows && n_sets > 0 && c >= 1 && c <= kMaxC, "bad setmax arguments");
   hipStream_t st = ctx->stream;
   int32_t* d_ids = nullptr;

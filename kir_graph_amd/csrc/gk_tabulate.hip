@@ -340,6 +340,7 @@ extern "C" {
 
 int gk_index_create(gk_ctx* ctx, const uint64_t* key, int32_t n_var, const int32_t* gene_vbeg, int32_t n_gene,
                     gk_index** out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && out && gene_vbeg && n_gene > 0 && n_gene < 255 && n_var >= 0 && n_var < (1 << 26),
              "bad index arguments");
   GK_REQUIRE(gene_vbeg[0] == 0 && gene_vbeg[n_gene] == n_var, "gene_vbeg must cover the key table");
@@ -375,6 +376,7 @@ int gk_index_create(gk_ctx* ctx, const uint64_t* key, int32_t n_var, const int32
 }
 
 int gk_index_destroy(gk_index* idx) {
+  gk_bind(idx ? idx->ctx : nullptr);
   if (!idx) return GK_OK;
   gk_ctx* ctx = idx->ctx;
   gk_pool_free(ctx,idx->d_key);
@@ -386,6 +388,7 @@ int gk_index_destroy(gk_index* idx) {
 }
 
 int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, gk_tab** out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && idx && out && n_pairs >= 0, "bad tabulate arguments");
   GK_REQUIRE(n_pairs < (1ll << 26), "more than 2^26 pairs per call");
   const gk_mate* mates = gk_ptr<const gk_mate>(d_mates_p);
@@ -483,6 +486,7 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
 
 int gk_tab_from_csr(gk_ctx* ctx, int32_t n_var_total, int64_t n_valid, const uint32_t* off, const uint32_t* ids,
                     const uint8_t* pair_gene, const uint8_t* pair_nh, gk_tab** out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && out && off && pair_gene && pair_nh && n_valid >= 0 && n_var_total >= 0, "bad CSR arguments");
   const int64_t n_ids = off[4 * n_valid];
   for (int64_t i = 0; i < 4 * n_valid; ++i) GK_REQUIRE(off[i] <= off[i + 1], "CSR offsets must be non-decreasing");
@@ -507,6 +511,7 @@ int gk_tab_from_csr(gk_ctx* ctx, int32_t n_var_total, int64_t n_valid, const uin
 }
 
 int gk_tab_get_info(gk_tab* tab, gk_tab_info* info) {
+  gk_bind(tab ? tab->ctx : nullptr);
   GK_REQUIRE(tab && info, "null pointer");
   info->n_pairs = tab->n_pairs; info->n_valid = tab->n_valid; info->n_ids = tab->n_ids;
   info->n_novel = tab->n_novel; info->err_flags = tab->err_flags;
@@ -517,6 +522,7 @@ int gk_tab_get_info(gk_tab* tab, gk_tab_info* info) {
 }
 
 int gk_tab_destroy(gk_tab* tab) {
+  gk_bind(tab ? tab->ctx : nullptr);
   if (!tab) return GK_OK;
   gk_ctx* ctx = tab->ctx;
   gk_pool_free(ctx,tab->d_pair_src); gk_pool_free(ctx,tab->d_off); gk_pool_free(ctx,tab->d_ids);

@@ -315,6 +315,7 @@ static int build_partition(gk_ctx* ctx, gk_tab* tab, int multiple) {
 }
 
 int gk_select_gene(gk_ctx* ctx, gk_tab* tab, int gene, int multiple, gk_dptr d_rows_out, int64_t* n_out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && tab && n_out, "null pointer");
   *n_out = 0;
   if (tab->n_valid == 0 || gene < 0) return GK_OK;
@@ -339,6 +340,7 @@ int gk_select_gene(gk_ctx* ctx, gk_tab* tab, int gene, int multiple, gk_dptr d_r
 
 int gk_select_nonempty(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, gk_dptr d_rows_out,
                        int64_t* n_out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && tab && n_out, "null pointer");
   if (n_rows == 0) { *n_out = 0; return GK_OK; }
   uint32_t* flag = nullptr;
@@ -354,11 +356,13 @@ int gk_variant_count_range(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_r
                             int32_t vbeg, int32_t vend);
 
 int gk_variant_count(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, gk_dptr d_cnt) {
+  gk_bind(ctx);
   return gk_variant_count_range(ctx, tab, d_rows, n_rows, d_vflag, d_cnt, 0, 0);
 }
 
 int gk_variant_count_range(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, gk_dptr d_cnt,
                             int32_t vbeg, int32_t vend) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && tab && vend >= vbeg, "bad arguments");
   int n_local = vend - vbeg;
   if ((size_t)n_local * 8 > 60 * 1024) n_local = 60 * 1024 / 8;   // LDS budget per workgroup
@@ -378,6 +382,7 @@ int gk_variant_count_range(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_r
 }
 
 int gk_variant_correct(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && tab, "null pointer");
   const int64_t nv = (int64_t)tab->n_var + tab->n_novel;
   uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
@@ -412,6 +417,7 @@ __global__ __launch_bounds__(kThreads) void gather_surviving(const int32_t* ord,
  * the device (feeds isHomozygous, typing_mulit_allele.py:807-857).  Host arrays must hold max_out. */
 int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag, int64_t max_out, int32_t* ord_out,
                          uint32_t* pos_out, uint32_t* neg_out, int64_t* n_out) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && tab && ord_out && pos_out && neg_out && n_out, "null pointer");
   const int64_t nv = (int64_t)tab->n_var + tab->n_novel;
   *n_out = 0;
@@ -447,6 +453,7 @@ int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vfla
 
 int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg, int32_t vend,
               gk_dptr d_mask, int32_t words, int32_t n_allele, gk_dptr d_probs, gk_dptr d_miss, gk_dptr d_nvar) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && tab, "null pointer");
   GK_REQUIRE(words >= 1 && n_allele >= 0 && n_allele <= words * 32 && vend >= vbeg, "bad mask geometry");
   if (n_rows == 0 || n_allele == 0) return GK_OK;
@@ -456,6 +463,7 @@ int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr 
 
 int gk_compat_log(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg,
                   int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, gk_lut* lut, gk_dptr d_log) {
+  gk_bind(ctx);
   GK_REQUIRE(ctx && tab && lut, "null pointer");   // the table may belong to another context of the same device
   GK_REQUIRE(words >= 1 && n_allele >= 0 && n_allele <= words * 32 && vend >= vbeg, "bad mask geometry");
   if (n_rows == 0 || n_allele == 0) return GK_OK;
