@@ -193,7 +193,7 @@ def main():
             "roofline": roof,
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
         }
-        if args.cpu_pairs:
+        if args.cpu_pairs and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(sidx, gidx, gene_cn, args.method, args.cpu_pairs, seed=99)
         print(json.dumps(out), flush=True)
     if dist is not None:
