@@ -1,5 +1,5 @@
 """
-Packed alignment records: the device's input format (``gk_mate``, 64 bytes).
+Packed alignment records: the device's input format (``gk_mate``, 128 bytes).
 
 Two producers, one format (``include/graphkir_hip.h``):
 

@@ -12,7 +12,7 @@ environment, so tests and ``bench.py`` type synthetic samples:
   errors) drawn from the sample's true alleles and expressed the way HISAT2
   reports them: 0-based start, CIGAR, mismatch list, inserted strings, NM, NH.
   The sample is held as flat event arrays from which both SAM text lines
-  (small cases, reference/oracle input) and packed 64-byte mate records
+  (small cases, reference/oracle input) and packed 128-byte mate records
   (device input, any size) are derived, so both routes see the same
   alignments.
 
