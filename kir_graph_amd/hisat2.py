@@ -27,7 +27,7 @@ from ._lib import Device, check, lib
 from .engine import DeviceIndex, Tabulation
 from .index import GkIndex, getVariants, readExons  # noqa: F401  (re-export: reference names)
 from .msa2hisat import Variant
-from .packed import InsTable, packPairs
+from .packed import packPairs
 from .utils import logger
 
 

@@ -17,11 +17,10 @@ import json
 from itertools import chain
 from typing import Any
 
-import numpy as np
 import pandas as pd
 
 from .cn_model import CNgroup, Dist, KDEcut
-from .utils import NumpyEncoder, logger
+from .utils import logger
 
 
 def readSamtoolsDepth(depth_filename: str) -> pd.DataFrame:
