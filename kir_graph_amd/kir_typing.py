@@ -74,7 +74,7 @@ class Typing:
 def hostThreads() -> int:
     """Host threads that type genes concurrently (each with its own HIP stream); GK_THREADS overrides."""
     import os
-    return max(1, int(os.environ.get("GK_THREADS", "4")))
+    return max(1, int(os.environ.get("GK_THREADS", "6")))
 
 
 class _GeneView:
