@@ -78,7 +78,7 @@ int gk_cn_fit(gk_ctx* ctx, const double* x, const double* density, int32_t bins,
   GK_HIP(hipMemcpyAsync(d_den, density, (size_t)bins * sizeof(double), hipMemcpyHostToDevice, st));
   GK_HIP(hipMemcpyAsync(d_bases, bases, (size_t)n_bases * sizeof(double), hipMemcpyHostToDevice, st));
   GK_HIP(hipMemcpyAsync(d_dev, dev, (size_t)n_cn * sizeof(double), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(cn_fit_kernel, dim3((unsigned)n_bases), dim3(kThreads), 0, st, d_x, d_den, bins, d_bases, d_dev,
+  GK_KERNEL(cn_fit_kernel, dim3((unsigned)n_bases), dim3(kThreads), 0, st, d_x, d_den, bins, d_bases, d_dev,
                      n_cn, first_cn, space, d_ll);
   GK_HIP(hipGetLastError());
   GK_HIP(hipMemcpyAsync(loglik_out, d_ll, (size_t)n_bases * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -98,7 +98,7 @@ int gk_cn_assign(gk_ctx* ctx, const double* x, int32_t bins, double base, const 
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_cn, (size_t)bins * sizeof(int32_t)));
   GK_HIP(hipMemcpyAsync(d, x, (size_t)bins * sizeof(double), hipMemcpyHostToDevice, st));
   GK_HIP(hipMemcpyAsync(d + bins, dev, (size_t)n_cn * sizeof(double), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(cn_assign_kernel, dim3((unsigned)((bins + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, d,
+  GK_KERNEL(cn_assign_kernel, dim3((unsigned)((bins + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, d,
                      bins, base, d + bins, n_cn, first_cn, space, d_cn);
   GK_HIP(hipGetLastError());
   GK_HIP(hipMemcpyAsync(cn_of_bin_out, d_cn, (size_t)bins * sizeof(int32_t), hipMemcpyDeviceToHost, st));

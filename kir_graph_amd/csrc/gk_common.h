@@ -1,6 +1,7 @@
 // Internal helpers shared by the HIP translation units of libgraphkir_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -64,14 +65,29 @@ enum {
   GK_K_LUT_COLLECT, GK_K_LUT_APPLY, GK_K_MAXSUM, GK_K_COMBINE, GK_K_FRACTION, GK_K_SETMAX, GK_K_EM_SETS,
   GK_K_EM_RUN, GK_K_N
 };
-void gk_prof_begin(gk_ctx* ctx, int id);
+// Per-kernel timing.  GK_PROF brackets a launch with two events recorded on the stream (cheap; under
+// multi-stream load the span also counts the time the kernel waits for CUs that other streams are using).
+// GK_PROF_EXACT hands the events to hipExtLaunchKernelGGL, which binds them to the kernel's own begin
+// and end on the GPU -- what rocprofv3 reports; such dispatches carry a profiling signal and cost some
+// cross-stream overlap, so only the kernel the roofline is reported for is timed this way.
+void gk_prof_begin(gk_ctx* ctx, int id, int exact);
 void gk_prof_end(gk_ctx* ctx);
-#define GK_PROF(ctx, id, launch) \
-  do {                           \
-    gk_prof_begin((ctx), (id));  \
-    launch;                      \
-    gk_prof_end((ctx));          \
+hipEvent_t gk_prof_start_event();   // events of the exact span opened on this thread, else nullptr
+hipEvent_t gk_prof_stop_event();
+#define GK_PROF(ctx, id, launch)   \
+  do {                             \
+    gk_prof_begin((ctx), (id), 0); \
+    launch;                        \
+    gk_prof_end((ctx));            \
   } while (0)
+#define GK_PROF_EXACT(ctx, id, launch) \
+  do {                                 \
+    gk_prof_begin((ctx), (id), 1);     \
+    launch;                            \
+    gk_prof_end((ctx));                \
+  } while (0)
+#define GK_KERNEL(kernel, grid, block, lds, stream, ...) \
+  hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, gk_prof_start_event(), gk_prof_stop_event(), 0, __VA_ARGS__)
 
 int gk_ctx_scratch(gk_ctx* ctx, size_t bytes, void** out);
 

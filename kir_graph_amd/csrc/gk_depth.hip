@@ -64,13 +64,13 @@ extern "C" int gk_depth(gk_ctx* ctx, gk_tab* tab, gk_dptr d_mates, int32_t multi
   GK_HIP(hipMemsetAsync(diff, 0, (size_t)(total + 1) * sizeof(uint32_t), st));
   GK_HIP(hipMemcpyAsync(d_off, gene_off, (size_t)(n_gene + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
   if (tab->n_valid)
-    hipLaunchKernelGGL(depth_mark, dim3((unsigned)((2 * tab->n_valid + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+    GK_KERNEL(depth_mark, dim3((unsigned)((2 * tab->n_valid + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
                        gk_ptr<const gk_mate>(d_mates), tab->d_pair_src, tab->d_pair_nh, tab->n_valid, multiple, d_off,
                        n_gene, diff);
   GK_HIP(hipMemcpyAsync(scan, diff, (size_t)(total + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   int rc = gk_scan_u32(ctx, scan, total + 1, nullptr);
   if (rc) return rc;
-  hipLaunchKernelGGL(depth_finish, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, scan, diff,
+  GK_KERNEL(depth_finish, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, scan, diff,
                      total, diff);
   GK_HIP(hipGetLastError());
   GK_HIP(hipMemcpyAsync(depth_out, diff, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

@@ -211,7 +211,7 @@ int gk_em_sets(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, int32_t
   GK_REQUIRE(ctx && tab, "null pointer");
   GK_REQUIRE(words >= 1 && words <= kMaxWords, "more than 512 alleles per gene are not supported by the EM kernel");
   if (!n_rows) return GK_OK;
-  GK_PROF(ctx, GK_K_EM_SETS, hipLaunchKernelGGL(em_sets_kernel, dim3((unsigned)((n_rows + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+  GK_PROF(ctx, GK_K_EM_SETS, GK_KERNEL(em_sets_kernel, dim3((unsigned)((n_rows + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                      ctx->stream, gk_ptr<int32_t>(d_rows), n_rows, tab->d_off, tab->d_ids, vbeg, vend,
                      gk_ptr<uint32_t>(d_mask), words, gk_ptr<uint32_t>(d_sets_out)));
   GK_HIP(hipGetLastError());
@@ -240,10 +240,10 @@ int gk_em_distinct(gk_ctx* ctx, gk_dptr d_sets, int64_t n_rows, int32_t words, i
   GK_HIP(hipMemsetAsync(count, 0, (size_t)n_slots * sizeof(uint32_t), st));
   GK_HIP(hipMemsetAsync(d_n, 0, sizeof(uint32_t), st));
   GK_PROF(ctx, GK_K_EM_SETS,
-          hipLaunchKernelGGL(em_distinct_kernel, dim3((unsigned)((n_rows + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+          GK_KERNEL(em_distinct_kernel, dim3((unsigned)((n_rows + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
                              gk_ptr<uint32_t>(d_sets), n_rows, words, owner, count, n_slots - 1));
   GK_PROF(ctx, GK_K_EM_SETS,
-          hipLaunchKernelGGL(em_distinct_emit, dim3((n_slots + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
+          GK_KERNEL(em_distinct_emit, dim3((n_slots + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
                              gk_ptr<uint32_t>(d_sets), words, owner, count, n_slots, (uint32_t)max_out, d_n, d_out_sets,
                              d_out_count));
   GK_HIP(hipGetLastError());
@@ -282,7 +282,7 @@ int gk_em_run(gk_ctx* ctx, const uint32_t* sets, const double* weight, int32_t n
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_it, sizeof(int)));
   GK_HIP(hipMemcpyAsync(d_sets, sets, (size_t)n_sets * words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   GK_HIP(hipMemcpyAsync(d_w, weight, (size_t)n_sets * sizeof(double), hipMemcpyHostToDevice, st));
-  GK_PROF(ctx, GK_K_EM_RUN, hipLaunchKernelGGL(em_kernel, dim3(1), dim3(kThreads), 0, st, d_sets, d_w, d_scale, n_sets, words, n_allele, iter_max,
+  GK_PROF(ctx, GK_K_EM_RUN, GK_KERNEL(em_kernel, dim3(1), dim3(kThreads), 0, st, d_sets, d_w, d_scale, n_sets, words, n_allele, iter_max,
                      diff_threshold, d_prob, d_it));
   GK_HIP(hipGetLastError());
   GK_HIP(hipMemcpyAsync(prob_out, d_prob, (size_t)n_allele * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -80,10 +80,10 @@ int gk_lut_create(gk_ctx* ctx, int32_t log2_capacity, gk_lut** out) {
   GK_HIP(hipMalloc((void**)&l->d_vals, cap * sizeof(double)));
   GK_HIP(hipMalloc((void**)&l->d_count, sizeof(uint32_t)));
   GK_HIP(hipMemsetAsync(l->d_count, 0, sizeof(uint32_t), ctx->stream));
-  hipLaunchKernelGGL(fill_keys, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, l->d_keys, (uint64_t)cap);
+  GK_KERNEL(fill_keys, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, l->d_keys, (uint64_t)cap);
   // unwritten list entries are recognisable: a table shared by several streams may be read while a
   // kernel of another stream has claimed an index but not stored its key yet
-  hipLaunchKernelGGL(fill_keys, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, l->d_list, (uint64_t)cap);
+  GK_KERNEL(fill_keys, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, l->d_list, (uint64_t)cap);
   GK_HIP(hipGetLastError());
   GK_HIP(hipStreamSynchronize(ctx->stream));   // kernels of other contexts may use the table right away
   *out = l;
@@ -106,7 +106,7 @@ int gk_lut_collect(gk_lut* l, gk_dptr d_vals, int64_t n) {
   int64_t want = (n + kThreads - 1) / kThreads;
   unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
   gk_ctx* ctx = l->ctx;
-  GK_PROF(ctx, GK_K_LUT_COLLECT, hipLaunchKernelGGL(lut_collect, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_vals), n,
+  GK_PROF(ctx, GK_K_LUT_COLLECT, GK_KERNEL(lut_collect, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_vals), n,
                      l->d_keys, l->d_slot_idx, l->d_list, l->d_count, (uint32_t)((1ull << l->log2cap) - 1)));
   GK_HIP(hipGetLastError());
   return GK_OK;
@@ -161,7 +161,7 @@ int gk_lut_apply(gk_lut* l, gk_dptr d_in, gk_dptr d_out, int64_t n) {
   int64_t want = (n + kThreads - 1) / kThreads;
   unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
   gk_ctx* ctx = l->ctx;
-  GK_PROF(ctx, GK_K_LUT_APPLY, hipLaunchKernelGGL(lut_apply, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_in),
+  GK_PROF(ctx, GK_K_LUT_APPLY, GK_KERNEL(lut_apply, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_in),
                      gk_ptr<double>(d_out), n, l->d_keys, l->d_slot_idx, l->d_vals,
                      (uint32_t)((1ull << l->log2cap) - 1)));
   GK_HIP(hipGetLastError());

@@ -187,7 +187,15 @@ void gk_pool_free(gk_ctx* ctx, void* p) {
   ctx->pool_cached_bytes += cls;
 }
 
-void gk_prof_begin(gk_ctx* ctx, int id) {
+static thread_local gk_ctx::ProfSpan* t_span = nullptr;   // span whose events the next GK_KERNEL launch takes
+
+hipEvent_t gk_prof_start_event() { return t_span ? t_span->a : nullptr; }
+hipEvent_t gk_prof_stop_event() { return t_span ? t_span->b : nullptr; }
+
+// exact != 0: the events are bound to the kernel itself (GK_KERNEL hands them to
+// hipExtLaunchKernelGGL); otherwise they are recorded on the stream before and after the launch.
+void gk_prof_begin(gk_ctx* ctx, int id, int exact) {
+  t_span = nullptr;
   if (!ctx->prof_on) return;
   gk_ctx::ProfSpan sp;
   sp.id = id;
@@ -199,11 +207,13 @@ void gk_prof_begin(gk_ctx* ctx, int id) {
       hipEventCreate(e);
     }
   }
-  hipEventRecord(sp.a, ctx->stream);
   ctx->prof_spans.push_back(sp);
+  if (exact) t_span = &ctx->prof_spans.back();
+  else hipEventRecord(sp.a, ctx->stream);
 }
 
 void gk_prof_end(gk_ctx* ctx) {
+  if (t_span) { t_span = nullptr; return; }
   if (!ctx->prof_on || ctx->prof_spans.empty()) return;
   hipEventRecord(ctx->prof_spans.back().b, ctx->stream);
 }
@@ -238,6 +248,7 @@ extern "C" int gk_prof_collect(gk_ctx* ctx, int64_t* launches, double* total_ms)
     ctx->prof_pool.push_back(sp.b);
   }
   ctx->prof_spans.clear();
+  (void)hipGetLastError();   // a span whose kernel never ran leaves an error behind; it is not the caller's
   return GK_OK;
 }
 

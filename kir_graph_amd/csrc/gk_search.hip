@@ -670,18 +670,18 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   const int tiles_t = (n_sets + kTileT - 1) / kTileT, tiles_a = (n_cols + kTileA - 1) / kTileA;
   const dim3 grid((unsigned)(tiles_t * tiles_a * dp.n_spans));
   if (c_prev) {
-    GK_PROF(ctx, GK_K_MAXSUM,
-            hipLaunchKernelGGL(maxsum_chunks<true>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
+    GK_PROF_EXACT(ctx, GK_K_MAXSUM,
+            GK_KERNEL(maxsum_chunks<true>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
                                c_prev >= 2 ? d_P : gk_ptr<double>(d_L), ld, dp.ids, n_sets, dp.cols, n_cols, dp.spans,
                                dp.leaves, tiles_t * tiles_a, symmetric ? 1 : 0, d_partial));
   } else {
-    GK_PROF(ctx, GK_K_MAXSUM,
-            hipLaunchKernelGGL(maxsum_chunks<false>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
+    GK_PROF_EXACT(ctx, GK_K_MAXSUM,
+            GK_KERNEL(maxsum_chunks<false>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
                                gk_ptr<double>(d_L), ld, (const int32_t*)nullptr, n_sets, dp.cols, n_cols, dp.spans,
                                dp.leaves, tiles_t * tiles_a, 0, d_partial));
   }
   GK_PROF(ctx, GK_K_COMBINE,
-          hipLaunchKernelGGL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+          GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
                              d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, 0.0, d_out));
   GK_HIP(hipGetLastError());
   if (symmetric) {
@@ -773,7 +773,7 @@ int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int3
   if (lds > 48 * 1024)                                                                                               \
     GK_HIP(hipFuncSetAttribute((const void*)fraction_chunks<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
   GK_PROF(ctx, GK_K_FRACTION,                                                                                        \
-          hipLaunchKernelGGL(fraction_chunks<C>, grid, dim3(kThreads), lds, st, gk_ptr<double>(d_L), ld, dp.ids,     \
+          GK_KERNEL(fraction_chunks<C>, grid, dim3(kThreads), lds, st, gk_ptr<double>(d_L), ld, dp.ids,     \
                              dp.ids + o_cols, dp.ids + o_local, dp.ids + o_perm, n_sets, dp.spans, dp.leaves, d_partial))
   switch (c) {
     case 1: GK_FRAC_LAUNCH(1); break;
@@ -787,7 +787,7 @@ int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int3
   }
 #undef GK_FRAC_LAUNCH
   GK_PROF(ctx, GK_K_COMBINE,
-          hipLaunchKernelGGL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+          GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
                              d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, (double)n_rows, d_out));
   GK_HIP(hipGetLastError());
   GK_HIP(hipMemcpyAsync(frac_out, d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -809,7 +809,7 @@ int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   int64_t want = (n_rows + kThreads - 1) / kThreads;
   unsigned bx = (unsigned)(want < 1024 ? want : 1024);
   GK_PROF(ctx, GK_K_SETMAX,
-          hipLaunchKernelGGL(setmax_kernel, dim3(bx, (unsigned)n_sets), dim3(kThreads), 0, st, gk_ptr<double>(d_L), n_rows,
+          GK_KERNEL(setmax_kernel, dim3(bx, (unsigned)n_sets), dim3(kThreads), 0, st, gk_ptr<double>(d_L), n_rows,
                              ld, d_ids, n_sets, c, gk_ptr<double>(d_P)));
   GK_HIP(hipGetLastError());
   GK_HIP(hipStreamSynchronize(st));

@@ -420,7 +420,7 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
 
   const IndexView ix{idx->d_key, idx->d_bucket, idx->d_gene_boff, idx->n_var, idx->n_gene};
   if (n_mates) {
-    GK_PROF(ctx, GK_K_TAB_COUNT, hipLaunchKernelGGL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
+    GK_PROF(ctx, GK_K_TAB_COUNT, GK_KERNEL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
                        nt, cnt, valid, d_err));
   }
   // offsets over input pairs (invalid pairs contribute zeros)
@@ -434,8 +434,8 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
   GK_HIP(gk_pool_malloc(ctx, (void**)&bitmap, (size_t)n_words * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&prefix, (size_t)(n_words + 1) * sizeof(uint32_t)));
   GK_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_words * sizeof(uint32_t), st));
-  GK_PROF(ctx, GK_K_NOVEL, hipLaunchKernelGGL(novel_mark, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap));
-  GK_PROF(ctx, GK_K_NOVEL, hipLaunchKernelGGL(bitmap_popc, dim3(nblk(n_words)), dim3(kThreads), 0, st, bitmap, prefix, n_words));
+  GK_PROF(ctx, GK_K_NOVEL, GK_KERNEL(novel_mark, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap));
+  GK_PROF(ctx, GK_K_NOVEL, GK_KERNEL(bitmap_popc, dim3(nblk(n_words)), dim3(kThreads), 0, st, bitmap, prefix, n_words));
   rc = gk_scan_u32(ctx, prefix, n_words, prefix + n_words);
   if (rc) return rc;
 
@@ -454,12 +454,12 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
   }
 
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_novel_key, (size_t)(tab->n_novel + 1) * sizeof(uint64_t)));
-  GK_PROF(ctx, GK_K_NOVEL, hipLaunchKernelGGL(novel_assign, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap, prefix,
+  GK_PROF(ctx, GK_K_NOVEL, GK_KERNEL(novel_assign, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap, prefix,
                      tab->d_novel_key));
 
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_ids, (size_t)(tab->n_ids + 1) * sizeof(uint32_t)));
   if (n_mates) {
-    GK_PROF(ctx, GK_K_TAB_EMIT, hipLaunchKernelGGL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix, nt, cnt,
+    GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix, nt, cnt,
                        valid, tab->d_ids));
   }
   // compact valid pairs (order preserving)
@@ -469,7 +469,7 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_off, (size_t)(4 * tab->n_valid + 1) * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_pair_gene, (size_t)tab->n_valid + 1));
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_pair_nh, (size_t)tab->n_valid + 1));
-  GK_PROF(ctx, GK_K_SELECT, hipLaunchKernelGGL(gather_pairs, dim3(nblk(tab->n_valid + 1)), dim3(kThreads), 0, st, mates, tab->d_pair_src,
+  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(gather_pairs, dim3(nblk(tab->n_valid + 1)), dim3(kThreads), 0, st, mates, tab->d_pair_src,
                      tab->n_valid, cnt, tab->d_off, tab->d_pair_gene, tab->d_pair_nh, (uint32_t)tab->n_ids));
   GK_HIP(hipGetLastError());
   GK_HIP(hipStreamSynchronize(st));

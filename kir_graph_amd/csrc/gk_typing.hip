@@ -263,7 +263,7 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
     const int slots = std::min(kMaxSlots, (n_allele - a_base + 63) / 64);
 #define GK_COMPAT_LAUNCH(S)                                                                                        \
   GK_PROF(ctx, GK_K_COMPAT,                                                                                        \
-          hipLaunchKernelGGL((compat_kernel<kLog, S, !kLog>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows, \
+          GK_KERNEL((compat_kernel<kLog, S, !kLog>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows, \
                              tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, gk_ptr<uint32_t>(d_mask),  \
                              words, n_allele, a_base, out, miss, nvar, view))
     switch (slots) {
@@ -294,15 +294,15 @@ static int build_partition(gk_ctx* ctx, gk_tab* tab, int multiple) {
   GK_HIP(gk_pool_malloc(ctx, (void**)&part.d_rows, (size_t)(n + 1) * sizeof(int32_t)));
   part.owner = ctx;
   GK_HIP(hipMemsetAsync(hist, 0, n_hist * sizeof(uint32_t), ctx->stream));
-  GK_PROF(ctx, GK_K_SELECT, hipLaunchKernelGGL(part_pass<false>, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream,
+  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(part_pass<false>, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream,
                                                tab->d_pair_gene, tab->d_pair_nh, n, multiple, n_bins, n_tiles, hist,
                                                (int32_t*)nullptr));
   int rc = gk_scan_u32(ctx, hist, (int64_t)n_hist, hist + n_hist);
   if (rc) return rc;
-  GK_PROF(ctx, GK_K_SELECT, hipLaunchKernelGGL(part_pass<true>, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream,
+  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(part_pass<true>, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream,
                                                tab->d_pair_gene, tab->d_pair_nh, n, multiple, n_bins, n_tiles, hist,
                                                part.d_rows));
-  hipLaunchKernelGGL(part_offsets, dim3((unsigned)(n_bins / 256 + 1)), dim3(256), 0, ctx->stream, hist, hist + n_hist,
+  GK_KERNEL(part_offsets, dim3((unsigned)(n_bins / 256 + 1)), dim3(256), 0, ctx->stream, hist, hist + n_hist,
                      n_bins, n_tiles, goff);
   GK_HIP(hipGetLastError());
   std::vector<uint32_t> host((size_t)n_bins + 1);
@@ -345,7 +345,7 @@ int gk_select_nonempty(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows,
   if (n_rows == 0) { *n_out = 0; return GK_OK; }
   uint32_t* flag = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)n_rows * sizeof(uint32_t)));
-  GK_PROF(ctx, GK_K_SELECT, hipLaunchKernelGGL(flag_nonempty, dim3(nblk(n_rows)), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
+  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(flag_nonempty, dim3(nblk(n_rows)), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
                      n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), flag));
   int rc = gk_compact(ctx, flag, gk_ptr<int32_t>(d_rows), n_rows, gk_ptr<int32_t>(d_rows_out), n_out);
   gk_pool_free(ctx,flag);
@@ -373,7 +373,7 @@ int gk_variant_count_range(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_r
     unsigned blocks = nblk(4 * n_rows);
     if (blocks > 1024) blocks = 1024;   // grid-stride: many rows per workgroup before the LDS flush
     GK_PROF(ctx, GK_K_COUNT_IDS,
-            hipLaunchKernelGGL(count_ids, dim3(blocks), dim3(kThreads), (size_t)n_local * 8, ctx->stream,
+            GK_KERNEL(count_ids, dim3(blocks), dim3(kThreads), (size_t)n_local * 8, ctx->stream,
                                gk_ptr<int32_t>(d_rows), n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), cnt,
                                cnt + nv, vbeg, n_local));
   }
@@ -387,7 +387,7 @@ int gk_variant_correct(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag)
   const int64_t nv = (int64_t)tab->n_var + tab->n_novel;
   uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
   if (nv)
-    GK_PROF(ctx, GK_K_COUNT_IDS, hipLaunchKernelGGL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, ctx->stream, cnt, cnt + nv, nv,
+    GK_PROF(ctx, GK_K_COUNT_IDS, GK_KERNEL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, ctx->stream, cnt, cnt + nv, nv,
                        gk_ptr<uint8_t>(d_vflag)));
   GK_HIP(hipGetLastError());
   return GK_OK;
@@ -427,7 +427,7 @@ int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vfla
   int32_t* ord = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)nv * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&ord, (size_t)nv * sizeof(int32_t)));
-  hipLaunchKernelGGL(flag_surviving, dim3(nblk(nv)), dim3(kThreads), 0, ctx->stream, cnt, cnt + nv,
+  GK_KERNEL(flag_surviving, dim3(nblk(nv)), dim3(kThreads), 0, ctx->stream, cnt, cnt + nv,
                      gk_ptr<uint8_t>(d_vflag), nv, flag);
   int64_t n = 0;
   int rc = gk_compact(ctx, flag, nullptr, nv, ord, &n);
@@ -437,7 +437,7 @@ int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vfla
   }
   if (rc == GK_OK && n) {
     GK_HIP(gk_pool_malloc(ctx, (void**)&vals, (size_t)(2 * n) * sizeof(uint32_t)));
-    hipLaunchKernelGGL(gather_surviving, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream, ord, n, cnt, cnt + nv,
+    GK_KERNEL(gather_surviving, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream, ord, n, cnt, cnt + nv,
                        gk_ptr<uint8_t>(d_vflag), vals);
     GK_HIP(hipMemcpyAsync(ord_out, ord, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP(hipMemcpyAsync(pos_out, vals, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
