@@ -56,30 +56,33 @@ __global__ void part_offsets(const uint32_t* hist, const uint32_t* total, int n_
   if (b == n_bins) goff[b] = *total;
 }
 
-// one thread per list (4 lists per row): tally surviving ids
-// One thread per list (4 lists per row), grid-stride over rows.  Counters of the gene's index
-// variants [vbeg, vend) are privatised in LDS (positive / negative halves) and flushed once per
-// workgroup; ordinals outside that range (novel variants, other genes) go straight to global atomics.
-__global__ __launch_bounds__(kThreads) void count_ids(const int32_t* rows, int64_t n_rows, const uint32_t* off,
-                                                      const uint32_t* ids, const uint8_t* vflag, uint32_t* cnt_pos,
+// Tally of the surviving ids (AlleleTyping.errorCorrection 302-338 counts them per variant).  One
+// wavefront per row, grid-stride: the row's ids (lpv, rpv, lnv, rnv are contiguous in the CSR) are read
+// 64 at a time, coalesced; positives are the ids before the row's mid offset.  Counters of the gene's
+// index variants [vbeg, vend) are privatised in LDS (positive / negative halves) -- the ids of one row
+// are distinct, so the 64 atomics of a wave instruction hit different counters -- and flushed once per
+// workgroup; ordinals outside that range (novel variants) go straight to global atomics.
+__global__ __launch_bounds__(kThreads) void count_ids(const int32_t* __restrict__ rows, int64_t n_rows,
+                                                      const uint32_t* __restrict__ off,
+                                                      const uint32_t* __restrict__ ids,
+                                                      const uint8_t* __restrict__ vflag, uint32_t* cnt_pos,
                                                       uint32_t* cnt_neg, int vbeg, int n_local) {
   extern __shared__ uint32_t hist[];   // [2][n_local]
   for (int i = threadIdx.x; i < 2 * n_local; i += kThreads) hist[i] = 0;
   __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < 4 * n_rows; t += stride) {
-    const int64_t row = rows[t >> 2];
-    const int list = (int)(t & 3);
-    const uint32_t b = off[4 * row + list], e = off[4 * row + list + 1];
-    const bool positive = list < 2;
-    const uint8_t bit = positive ? 1 : 2;
-    uint32_t* cnt = positive ? cnt_pos : cnt_neg;
-    uint32_t* local = hist + (positive ? 0 : n_local);
-    for (uint32_t k = b; k < e; ++k) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * kThreads) >> 6;
+  for (int64_t i = wave; i < n_rows; i += n_waves) {
+    const int64_t row = rows[i];
+    const uint32_t b = off[4 * row], mid = off[4 * row + 2], e = off[4 * row + 4];
+    for (uint32_t k = b + lane; k < e; k += 64) {
       const uint32_t v = ids[k];
-      if (vflag[v] & bit) continue;
+      const bool positive = k < mid;
+      if (vflag[v] & (positive ? 1 : 2)) continue;
       const uint32_t l = v - (uint32_t)vbeg;
-      if (l < (uint32_t)n_local) atomicAdd(&local[l], 1u); else atomicAdd(&cnt[v], 1u);
+      if (l < (uint32_t)n_local) atomicAdd(&hist[(positive ? 0 : n_local) + l], 1u);
+      else atomicAdd(positive ? &cnt_pos[v] : &cnt_neg[v], 1u);
     }
   }
   __syncthreads();
@@ -370,8 +373,8 @@ int gk_variant_count_range(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_r
   uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
   GK_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * nv) * sizeof(uint32_t), ctx->stream));
   if (n_rows) {
-    unsigned blocks = nblk(4 * n_rows);
-    if (blocks > 1024) blocks = 1024;   // grid-stride: many rows per workgroup before the LDS flush
+    unsigned blocks = nblk(64 * n_rows);   // a wavefront per row
+    if (blocks > 1024) blocks = 1024;      // grid-stride: many rows per workgroup before the LDS flush (measured optimum)
     GK_PROF(ctx, GK_K_COUNT_IDS,
             GK_KERNEL(count_ids, dim3(blocks), dim3(kThreads), (size_t)n_local * 8, ctx->stream,
                                gk_ptr<int32_t>(d_rows), n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), cnt,
