@@ -214,20 +214,83 @@ __device__ inline void walk_mate(const MateView& r, const IndexView& ix, const N
   wk.bad_window = wk.lo > wk.hi;
 }
 
-__device__ inline bool negative_kept(uint64_t k, int i, const IndexView& ix, const uint32_t* evw, const Walked& wk) {
+__device__ inline bool negative_kept(uint64_t k, int i, const IndexView& ix, const uint32_t* evw, int n_ev,
+                                     uint32_t any_n, uint32_t right) {
   const uint32_t typ = gk_key_typ(k), pos = gk_key_pos(k), val = gk_key_val(k);
-  for (int e = 0; e < wk.n; ++e)
+  for (int e = 0; e < n_ev; ++e)
     if ((evw[e] & ~kEvIsN) == (uint32_t)i) return false;   // a positive of this mate
-  if (wk.any_n && typ == GK_TYP_SINGLE && (val == 'A' || val == 'C' || val == 'G' || val == 'T')) {
-    for (int e = 0; e < wk.n; ++e) {
+  if (any_n && typ == GK_TYP_SINGLE && (val == 'A' || val == 'C' || val == 'G' || val == 'T')) {
+    for (int e = 0; e < n_ev; ++e) {
       const uint32_t w = evw[e];
       if (!(w & kEvIsN)) continue;
       const uint32_t p = (w & kEvNovel) ? (w & 0xFFFFFFu) : gk_key_pos(ix.key[w & kEvOrdMask]);
       if (p == pos) return false;                           // the read says N here
     }
   }
-  if (typ == GK_TYP_DEL && pos + val + 10u >= wk.right) return false;
+  if (typ == GK_TYP_DEL && pos + val + 10u >= right) return false;
   return true;
+}
+
+// The negative lists of the 64 mates of a wavefront, enumerated TOGETHER: the windows [lo, hi) of the
+// lanes are laid end to end (wave prefix sum) and the wave walks that sequence 64 candidates at a
+// time, every lane taking one candidate of whichever mate owns it -- window lengths differ a lot
+// between mates (0 .. ~100 variants), so a loop per lane would run every lane for the longest one.
+// A candidate's owner is found by bisecting the prefix sums; the owner's event words, right edge and
+// N flag are read from LDS.  kEmit: kept candidates are written to the owner's negative list in
+// ascending ordinal order (rank inside the wave step + the owner's running count); otherwise they are
+// only counted.  Returns the calling lane's own count.
+struct WaveNeg {            // per wave, in LDS
+  uint32_t incl[64];        // inclusive prefix sums of the window lengths
+  uint32_t lo[64], right[64], n_ev[64], any_n[64];
+  uint32_t kept[64];        // running count of kept candidates per owner lane
+  uint32_t out0[64];        // kEmit: first slot of the owner's negative list
+};
+
+template <bool kEmit>
+__device__ inline uint32_t cooperative_negatives(WaveNeg& wv, const IndexView& ix, const uint32_t* evs_wave,
+                                                 uint32_t my_len, uint32_t my_lo, uint32_t my_right, uint32_t my_n,
+                                                 uint32_t my_any_n, uint32_t my_out0, uint32_t* ids) {
+  const int lane = threadIdx.x & 63;
+  uint32_t incl = my_len;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  wv.incl[lane] = incl; wv.lo[lane] = my_lo; wv.right[lane] = my_right; wv.n_ev[lane] = my_n;
+  wv.any_n[lane] = my_any_n; wv.kept[lane] = 0; wv.out0[lane] = my_out0;
+  const uint32_t total = __shfl(incl, 63, 64);
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t j = 0; j < total; j += 64) {
+    const uint32_t c = j + lane;
+    const bool active = c < total;
+    // owner = first lane whose inclusive sum exceeds c
+    int owner = 0;
+    if (active) {
+#pragma unroll
+      for (int step = 32; step; step >>= 1)
+        if (wv.incl[owner + step - 1] <= c) owner += step;
+    }
+    const uint32_t start = owner ? wv.incl[owner - 1] : 0u;
+    bool keep = false;
+    uint32_t i = 0;
+    if (active) {
+      i = wv.lo[owner] + (c - start);
+      keep = negative_kept(ix.key[i], (int)i, ix, evs_wave + owner * kEvLd, (int)wv.n_ev[owner], wv.any_n[owner],
+                           wv.right[owner]);
+    }
+    // candidates of one owner are a run of consecutive lanes
+    const uint64_t kept_mask = __ballot(keep);
+    const uint32_t first_lane = start > j ? start - j : 0u;          // first lane of my owner's run in this step
+    const uint32_t end = wv.incl[owner] - j;                          // one past its last lane (may exceed 64)
+    const uint64_t run = (end >= 64 ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << first_lane) - 1ull);
+    const uint32_t before = wv.kept[owner];                           // read by every lane of the run ...
+    __builtin_amdgcn_wave_barrier();
+    if (kEmit && keep) ids[wv.out0[owner] + before + (uint32_t)__popcll(kept_mask & run & ((1ull << lane) - 1ull))] = i;
+    if (active && (uint32_t)lane == first_lane) wv.kept[owner] = before + (uint32_t)__popcll(kept_mask & run);   // ... written by its first
+    __builtin_amdgcn_wave_barrier();
+  }
+  return wv.kept[lane];
 }
 
 // pass 1: validity, counts, novel registration.  One lane per mate; mates of a pair sit in
@@ -237,6 +300,7 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
                                                       uint32_t* valid /*[n_pairs]*/, int* err_flags) {
   __shared__ uint32_t rec[kThreads * kRecLd];
   __shared__ uint32_t evs[kThreads * kEvLd];
+  __shared__ WaveNeg wneg[kThreads / 64];
   const int64_t m0 = (int64_t)blockIdx.x * kThreads;
   stage_mates(mates, m0, n_mates, rec);
   const int64_t m = m0 + threadIdx.x;
@@ -246,12 +310,13 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
   const bool ok = in && r.passes();
   const bool ok_other = __shfl_xor((int)ok, 1, 64) != 0;
   const bool pair_ok = ok && ok_other;
-  if (!in) return;
   const int64_t pair = m >> 1;
   const int side = (int)(m & 1);
-  uint32_t n_pos = 0, n_neg = 0;
+  uint32_t n_pos = 0;
+  Walked wk;
+  wk.n = 0; wk.lo = wk.hi = 0; wk.right = 0; wk.any_n = 0;
+  bool enumerate = false;
   if (pair_ok) {
-    Walked wk;
     walk_mate<false>(r, ix, nt, m, evw, nullptr, 0, 0, wk);
     if (wk.overflow) atomicOr(err_flags, 2);
     if (wk.clipped) {
@@ -259,9 +324,14 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
       atomicOr(err_flags, 1);
     } else if (!wk.drop) {
       n_pos = wk.n;
-      for (int i = wk.lo; i < wk.hi; ++i) n_neg += negative_kept(ix.key[i], i, ix, evw, wk) ? 1u : 0u;
+      enumerate = true;
     }
   }
+  const int wid = threadIdx.x >> 6;
+  const uint32_t n_neg = cooperative_negatives<false>(wneg[wid], ix, evs + wid * 64 * kEvLd,
+                                                      enumerate ? (uint32_t)(wk.hi - wk.lo) : 0u, (uint32_t)wk.lo, wk.right,
+                                                      (uint32_t)wk.n, wk.any_n, 0u, nullptr);
+  if (!in) return;
   cnt[4 * pair + side] = n_pos;
   cnt[4 * pair + 2 + side] = n_neg;
   if (side == 0) valid[pair] = pair_ok ? 1u : 0u;
@@ -294,25 +364,26 @@ __global__ __launch_bounds__(kThreads) void tab_emit(const gk_mate* mates, int64
                                                      uint32_t* ids) {
   __shared__ uint32_t rec[kThreads * kRecLd];
   __shared__ uint32_t evs[kThreads * kEvLd];
+  __shared__ WaveNeg wneg[kThreads / 64];
   const int64_t m0 = (int64_t)blockIdx.x * kThreads;
   stage_mates(mates, m0, n_mates, rec);
   const int64_t m = m0 + threadIdx.x;
-  if (m >= n_mates) return;
   const int64_t pair = m >> 1;
   const int side = (int)(m & 1);
-  if (!valid[pair]) return;
-  const uint32_t o_pos = off[4 * pair + side], o_pos_end = off[4 * pair + side + 1];
-  const uint32_t o_neg = off[4 * pair + 2 + side], o_neg_end = off[4 * pair + 2 + side + 1];
-  if (o_pos == o_pos_end && o_neg == o_neg_end) return;
+  uint32_t o_pos = 0, o_pos_end = 0, o_neg = 0, o_neg_end = 0;
+  if (m < n_mates && valid[pair]) {
+    o_pos = off[4 * pair + side]; o_pos_end = off[4 * pair + side + 1];
+    o_neg = off[4 * pair + 2 + side]; o_neg_end = off[4 * pair + 2 + side + 1];
+  }
   const MateView r{rec + threadIdx.x * kRecLd};
   uint32_t* evw = evs + threadIdx.x * kEvLd;
   Walked wk;
-  walk_mate<true>(r, ix, nt, m, evw, ids, o_pos, o_pos_end, wk);
-  uint32_t w = o_neg;
-  for (int i = wk.lo; i < wk.hi && w < o_neg_end; ++i) {
-    const uint64_t k = ix.key[i];
-    if (negative_kept(k, i, ix, evw, wk)) ids[w++] = (uint32_t)i;
-  }
+  wk.n = 0; wk.lo = wk.hi = 0; wk.right = 0; wk.any_n = 0;
+  if (o_pos != o_pos_end || o_neg != o_neg_end) walk_mate<true>(r, ix, nt, m, evw, ids, o_pos, o_pos_end, wk);
+  const int wid = threadIdx.x >> 6;
+  // a mate with an empty negative list has nothing to enumerate (its window may still be non-empty)
+  cooperative_negatives<true>(wneg[wid], ix, evs + wid * 64 * kEvLd, o_neg != o_neg_end ? (uint32_t)(wk.hi - wk.lo) : 0u,
+                              (uint32_t)wk.lo, wk.right, (uint32_t)wk.n, wk.any_n, o_neg, ids);
 }
 
 __global__ __launch_bounds__(kThreads) void gather_pairs(const gk_mate* mates, const int32_t* pair_src, int64_t n_valid,
