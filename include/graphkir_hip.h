@@ -239,6 +239,10 @@ int gk_bam_next(gk_bam* bam, char* text_out, int64_t capacity, int64_t* n_writte
 /* every record, in output order, straight into a packer (created with gk_packer_create): the same pairs
  * and gk_mate records as feeding the rendered text to gk_packer_feed, without producing the text. */
 int gk_bam_pack(gk_bam* bam, struct gk_packer* packer);
+/* SAM text (header lines + alignment lines) -> BGZF-compressed BAM at `path`: the native form of
+ * saveReadsToBam / samtobam (hisat2.py:869-901, `samtools sort`).  coordinate_sort != 0 orders the
+ * records by (reference, position), stable, unmapped last; no .bai index is written. */
+int gk_bam_write(const char* path, const char* sam_text, int64_t n_bytes, int32_t coordinate_sort);
 
 /* ---- read depth: replaces `samtools depth -aa {name}.no_multi.bam` (samtools_utils.py:9-14).
  * Depth of every backbone position from the M runs of the filter-passing pairs of a tabulation made

@@ -566,3 +566,289 @@ int gk_bam_next(gk_bam* b, char* text_out, int64_t capacity, int64_t* n_written)
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// BAM writer: SAM text (header lines + alignment lines) -> BGZF-compressed BAM, the native form of
+// utils.samtobam / hisat2.saveReadsToBam (`samtools sort` of the rewritten SAM, hisat2.py:869-901).
+// Records are optionally ordered by (reference, position) like `samtools sort` (stable; unmapped
+// last); BGZF blocks are deflated in parallel.  No .bai index is written.
+namespace {
+
+struct SamHeaderRefs {
+  std::vector<std::string> names;
+  std::vector<uint32_t> lengths;
+};
+
+void put32(std::string& s, uint32_t v) { char b[4] = {(char)v, (char)(v >> 8), (char)(v >> 16), (char)(v >> 24)}; s.append(b, 4); }
+void put16(std::string& s, uint32_t v) { char b[2] = {(char)v, (char)(v >> 8)}; s.append(b, 2); }
+
+// UCSC binning scheme (SAM specification section 5.3) for the 0-based half-open interval [beg, end)
+uint32_t reg2bin(int64_t beg, int64_t end) {
+  --end;
+  if (beg >> 14 == end >> 14) return (uint32_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+  if (beg >> 17 == end >> 17) return (uint32_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+  if (beg >> 20 == end >> 20) return (uint32_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+  if (beg >> 23 == end >> 23) return (uint32_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+  if (beg >> 26 == end >> 26) return (uint32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+  return 0;
+}
+
+bool parse_ll(std::string_view s, long long& v) {
+  if (s.empty()) return false;
+  size_t i = 0;
+  bool neg = false;
+  if (s[0] == '-' || s[0] == '+') { neg = s[0] == '-'; i = 1; }
+  if (i >= s.size()) return false;
+  long long x = 0;
+  for (; i < s.size(); ++i) {
+    if (!isdigit((unsigned char)s[i])) return false;
+    x = x * 10 + (s[i] - '0');
+  }
+  v = neg ? -x : x;
+  return true;
+}
+
+bool encode_tag(std::string_view f, std::string& out) {
+  if (f.size() < 5 || f[2] != ':' || f[4] != ':') return false;
+  out.append(f.data(), 2);
+  const char type = f[3];
+  std::string_view val = f.substr(5);
+  long long v;
+  switch (type) {
+    case 'i':
+      if (!parse_ll(val, v)) return false;
+      if (v >= -128 && v <= 127) { out.push_back('c'); out.push_back((char)v); }
+      else if (v >= 0 && v <= 255) { out.push_back('C'); out.push_back((char)v); }
+      else if (v >= -32768 && v <= 32767) { out.push_back('s'); put16(out, (uint32_t)v); }
+      else if (v >= 0 && v <= 65535) { out.push_back('S'); put16(out, (uint32_t)v); }
+      else if (v >= -2147483648LL && v <= 2147483647LL) { out.push_back('i'); put32(out, (uint32_t)v); }
+      else if (v >= 0 && v <= 4294967295LL) { out.push_back('I'); put32(out, (uint32_t)v); }
+      else return false;
+      return true;
+    case 'A':
+      if (val.size() != 1) return false;
+      out.push_back('A'); out.push_back(val[0]);
+      return true;
+    case 'f': {
+      const float fl = strtof(std::string(val).c_str(), nullptr);
+      uint32_t u; memcpy(&u, &fl, 4);
+      out.push_back('f'); put32(out, u);
+      return true;
+    }
+    case 'Z': case 'H':
+      out.push_back(type); out.append(val); out.push_back('\0');
+      return true;
+    case 'B': {
+      if (val.empty()) return false;
+      const char sub = val[0];
+      std::vector<std::string_view> items;
+      size_t a = 1;
+      while (a < val.size()) {
+        if (val[a] != ',') return false;
+        const size_t c = val.find(',', a + 1);
+        items.push_back(val.substr(a + 1, c == std::string_view::npos ? std::string_view::npos : c - a - 1));
+        a = c == std::string_view::npos ? val.size() : c;
+      }
+      out.push_back('B'); out.push_back(sub); put32(out, (uint32_t)items.size());
+      for (auto it : items) {
+        if (sub == 'f') { const float fl = strtof(std::string(it).c_str(), nullptr); uint32_t u; memcpy(&u, &fl, 4); put32(out, u); continue; }
+        if (!parse_ll(it, v)) return false;
+        if (sub == 'c' || sub == 'C') out.push_back((char)v);
+        else if (sub == 's' || sub == 'S') put16(out, (uint32_t)v);
+        else if (sub == 'i' || sub == 'I') put32(out, (uint32_t)v);
+        else return false;
+      }
+      return true;
+    }
+    default: return false;
+  }
+}
+
+// one alignment line -> BAM record (with its leading block_size); ref_id / pos returned for sorting
+bool encode_record(std::string_view line, const std::vector<std::string>& ref_names, std::string& out, int32_t& ref_id,
+                   int32_t& pos0) {
+  std::vector<std::string_view> f;
+  size_t a = 0;
+  for (;;) {
+    const size_t t = line.find('\t', a);
+    f.push_back(line.substr(a, t == std::string_view::npos ? std::string_view::npos : t - a));
+    if (t == std::string_view::npos) break;
+    a = t + 1;
+  }
+  if (f.size() < 11) return false;
+  long long flag, pos, mapq, pnext, tlen;
+  if (!parse_ll(f[1], flag) || !parse_ll(f[3], pos) || !parse_ll(f[4], mapq) || !parse_ll(f[7], pnext) || !parse_ll(f[8], tlen))
+    return false;
+  auto find_ref = [&](std::string_view n) -> int32_t {
+    for (size_t i = 0; i < ref_names.size(); ++i) if (ref_names[i] == n) return (int32_t)i;
+    return -1;
+  };
+  ref_id = f[2] == "*" ? -1 : find_ref(f[2]);
+  const int32_t next_id = f[6] == "=" ? ref_id : (f[6] == "*" ? -1 : find_ref(f[6]));
+  pos0 = (int32_t)pos - 1;
+  std::vector<uint32_t> cig;
+  int64_t ref_len = 0;
+  if (f[5] != "*") {
+    long long n = 0;
+    bool have = false;
+    for (char c : f[5]) {
+      if (isdigit((unsigned char)c)) { n = n * 10 + (c - '0'); have = true; continue; }
+      const char* ops = "MIDNSHP=X";
+      const char* at = strchr(ops, c);
+      if (!at || !have) return false;
+      const uint32_t op = (uint32_t)(at - ops);
+      cig.push_back((uint32_t)n << 4 | op);
+      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += n;
+      n = 0; have = false;
+    }
+  }
+  const std::string_view seq = f[9], qual = f[10];
+  const uint32_t l_seq = seq == "*" ? 0u : (uint32_t)seq.size();
+  std::string body;
+  put32(body, (uint32_t)ref_id);
+  put32(body, (uint32_t)pos0);
+  body.push_back((char)(f[0].size() + 1));
+  body.push_back((char)mapq);
+  put16(body, reg2bin(pos0, pos0 + (ref_len ? ref_len : 1)));
+  put16(body, (uint32_t)cig.size());
+  put16(body, (uint32_t)flag);
+  put32(body, l_seq);
+  put32(body, (uint32_t)next_id);
+  put32(body, (uint32_t)((int32_t)pnext - 1));
+  put32(body, (uint32_t)(int32_t)tlen);
+  body.append(f[0]); body.push_back('\0');
+  for (uint32_t c : cig) put32(body, c);
+  static const char kBase[] = "=ACMGRSVTWYHKDBN";
+  for (uint32_t i = 0; i < l_seq; i += 2) {
+    auto code = [&](char c) -> uint32_t { const char* at = strchr(kBase, toupper((unsigned char)c)); return at ? (uint32_t)(at - kBase) : 15u; };
+    body.push_back((char)(code(seq[i]) << 4 | (i + 1 < l_seq ? code(seq[i + 1]) : 0u)));
+  }
+  if (qual == "*" || qual.size() != l_seq) body.append(l_seq, (char)0xFF);
+  else for (char c : qual) body.push_back((char)(c - 33));
+  for (size_t i = 11; i < f.size(); ++i)
+    if (!encode_tag(f[i], body)) return false;
+  put32(out, (uint32_t)body.size());
+  out += body;
+  return true;
+}
+
+bool deflate_block(const uint8_t* data, size_t n, std::string& out) {
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+  std::vector<uint8_t> buf(compressBound((uLong)n) + 64);
+  zs.next_in = const_cast<Bytef*>(data);
+  zs.avail_in = (uInt)n;
+  zs.next_out = buf.data();
+  zs.avail_out = (uInt)buf.size();
+  const int rc = deflate(&zs, Z_FINISH);
+  const size_t clen = buf.size() - zs.avail_out;
+  deflateEnd(&zs);
+  if (rc != Z_STREAM_END || clen + 26 > 65536) return false;
+  static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+  out.append((const char*)head, 16);
+  put16(out, (uint32_t)(clen + 25));   // BSIZE = total block size - 1
+  out.append((const char*)buf.data(), clen);
+  put32(out, (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n));
+  put32(out, (uint32_t)n);
+  return true;
+}
+
+}  // namespace
+
+extern "C" int gk_bam_write(const char* path, const char* sam_text, int64_t n_bytes, int32_t coordinate_sort) {
+  if (!path || (!sam_text && n_bytes)) { gk_set_error("null argument"); return GK_ERR_ARG; }
+  std::string_view text(sam_text, (size_t)n_bytes);
+  std::string header;
+  SamHeaderRefs refs;
+  std::vector<std::string_view> lines;
+  for (size_t a = 0; a < text.size();) {
+    size_t nl = text.find('\n', a);
+    if (nl == std::string_view::npos) nl = text.size();
+    std::string_view line = text.substr(a, nl - a);
+    if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+    a = nl + 1;
+    if (line.empty()) continue;
+    if (line[0] == '@') {
+      header.append(line); header.push_back('\n');
+      if (line.substr(0, 3) == "@SQ") {
+        std::string name; long long len = 0;
+        for (size_t p = 0; p < line.size();) {
+          size_t t = line.find('\t', p);
+          std::string_view fld = line.substr(p, t == std::string_view::npos ? std::string_view::npos : t - p);
+          if (fld.substr(0, 3) == "SN:") name = std::string(fld.substr(3));
+          if (fld.substr(0, 3) == "LN:") parse_ll(fld.substr(3), len);
+          if (t == std::string_view::npos) break;
+          p = t + 1;
+        }
+        refs.names.push_back(name); refs.lengths.push_back((uint32_t)len);
+      }
+    } else {
+      lines.push_back(line);
+    }
+  }
+  struct Enc { std::string rec; int32_t ref_id, pos0; };
+  std::vector<Enc> enc(lines.size());
+  std::vector<char> bad((size_t)std::max(ingest_threads(), 1), 0);
+  {
+    const size_t n = lines.size();
+    const int n_thr = (int)std::min<size_t>((size_t)ingest_threads(), std::max<size_t>(n / 1024, 1));
+    auto work = [&](int t, size_t a, size_t b) {
+      for (size_t i = a; i < b; ++i)
+        if (!encode_record(lines[i], refs.names, enc[i].rec, enc[i].ref_id, enc[i].pos0)) { bad[(size_t)t] = 1; return; }
+    };
+    if (n_thr <= 1) work(0, 0, n);
+    else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < n_thr; ++t) pool.emplace_back(work, t, n * t / n_thr, n * (t + 1) / n_thr);
+      for (auto& th : pool) th.join();
+    }
+  }
+  for (char b : bad) if (b) { gk_set_error("malformed SAM line"); return GK_ERR_ARG; }
+  std::vector<uint32_t> order(enc.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
+  if (coordinate_sort)
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+      const uint32_t rx = (uint32_t)enc[x].ref_id, ry = (uint32_t)enc[y].ref_id;   // -1 (unmapped) sorts last
+      if (rx != ry) return rx < ry;
+      return enc[x].pos0 < enc[y].pos0;
+    });
+  std::string raw("BAM\1", 4);
+  put32(raw, (uint32_t)header.size());
+  raw += header;
+  put32(raw, (uint32_t)refs.names.size());
+  for (size_t i = 0; i < refs.names.size(); ++i) {
+    put32(raw, (uint32_t)refs.names[i].size() + 1);
+    raw += refs.names[i]; raw.push_back('\0');
+    put32(raw, refs.lengths[i]);
+  }
+  for (uint32_t i : order) raw += enc[i].rec;
+  // BGZF blocks of <= 0xff00 input bytes, deflated in parallel, written in order, then the EOF block
+  const size_t kBlock = 0xff00, n_blocks = (raw.size() + kBlock - 1) / kBlock;
+  std::vector<std::string> comp(n_blocks + 1);
+  std::vector<char> bad2(n_blocks + 1, 0);
+  {
+    const int n_thr = (int)std::min<size_t>((size_t)ingest_threads(), std::max<size_t>(n_blocks / 4, 1));
+    auto work = [&](size_t a, size_t b) {
+      for (size_t i = a; i < b; ++i) {
+        const size_t off = i * kBlock, len = std::min(kBlock, raw.size() - off);
+        if (!deflate_block((const uint8_t*)raw.data() + off, len, comp[i])) bad2[i] = 1;
+      }
+    };
+    if (n_thr <= 1) work(0, n_blocks);
+    else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < n_thr; ++t) pool.emplace_back(work, n_blocks * t / n_thr, n_blocks * (t + 1) / n_thr);
+      for (auto& th : pool) th.join();
+    }
+  }
+  if (!deflate_block((const uint8_t*)"", 0, comp[n_blocks])) bad2[n_blocks] = 1;
+  for (char b : bad2) if (b) { gk_set_error("deflate failed"); return GK_ERR_ARG; }
+  FILE* f = fopen(path, "wb");
+  if (!f) { gk_set_error("cannot write %s", path); return GK_ERR_ARG; }
+  bool ok = true;
+  for (auto& c : comp) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
+  ok = fclose(f) == 0 && ok;
+  if (!ok) { gk_set_error("short write to %s", path); return GK_ERR_ARG; }
+  return GK_OK;
+}

@@ -361,17 +361,47 @@ def removeMultipleMapped(reads_data: ReadsAndVariantsData) -> ReadsAndVariantsDa
             "reads": [r for r in reads_data["reads"] if r.multiple == 1]}
 
 
+def alignmentHeader(path: str) -> str:
+    """``@`` header lines of a ``.bam`` / ``.sam`` / ``.sam.gz`` file (readBamHeader, hisat2.py:113-118)."""
+    if path.endswith(".bam"):
+        from .packed import bamHeader
+        return bamHeader(path)
+    import gzip
+    opener = gzip.open if path.endswith(".gz") else open
+    out = []
+    with opener(path, "rt") as f:
+        for line in f:
+            if not line.startswith("@"):
+                break
+            out.append(line)
+    return "".join(out)
+
+
+def saveReadsToBam(data: "SampleData", filename_prefix: str, bam_file: str, filter_multi_mapped: bool = False) -> None:
+    """Write the filter-passing pairs (optionally only NH == 1) as ``{filename_prefix}.bam``
+    (hisat2.py:880-901: saveSam + samtobam), coordinate-sorted like ``samtools sort``, with the header
+    of ``bam_file``.  Encoded and compressed natively (``packed.writeBam``)."""
+    from .packed import writeBam
+    if data.pairs_text is None:
+        raise ValueError("the SAM text of the pairs was not kept (keep_text=False)")
+    tab = data.tab
+    src = tab.pairSrc() if tab.info.d_pair_src else np.arange(tab.n_valid)
+    keep = src[tab.pairNH() == 1] if filter_multi_mapped else src
+    body = "".join(f"{data.pairs_text[int(i)][0]}\n{data.pairs_text[int(i)][1]}\n" for i in keep)
+    writeBam(filename_prefix + ".bam", alignmentHeader(bam_file) + body)
+
+
 def extractVariantFromBam(index: str, bam_file: str, output_prefix: str, error_correction: bool = True,
                           dev: Device | None = None) -> SampleData:
-    """index + name-sorted alignments -> ``{output_prefix}.json`` (hisat2.py:904-940).
-
-    The filtered ``.bam`` / ``.no_multi.bam`` rewrites of the reference need samtools; when the
-    input is SAM text they are written as ``.sam`` / ``.no_multi.sam`` instead.
-    """
+    """index + alignments -> ``{output_prefix}.json``, ``.bam`` and ``.no_multi.bam`` (hisat2.py:904-940)."""
     if error_correction:
         raise NotImplementedError("error_correction=True (pileup) is not implemented; the CLI passes False")
     gk = GkIndex.load(index)
-    data = extractVariant(readPair(bam_file), gk, dev=dev)
+    data = extractVariantFromText(bam_file, gk, dev=dev, keep_text=True)
     logger.debug(f"[Graph] Save allele per reads in {output_prefix}.json")
     writeReadsAndVariantsData(data.asDict(), f"{output_prefix}.json")
+    logger.debug(f"[Graph] Save filtered reads in {output_prefix}.bam")
+    saveReadsToBam(data, output_prefix, bam_file)
+    logger.debug(f"[Graph] Save filtered and unique reads in {output_prefix}.no_multi.bam")
+    saveReadsToBam(data, output_prefix + ".no_multi", bam_file, filter_multi_mapped=True)
     return data

@@ -26,7 +26,7 @@ import pandas as pd
 from . import cohort
 from .external_tools import setEngine
 from .hisat2 import (SampleData, extractVariant, extractVariantFromText, readExons, readPair,  # noqa: F401
-                     writeCompact,
+                     saveReadsToBam, writeCompact,
                      writeReadsAndVariantsData)
 from .index import GkIndex
 from .kir_cn import filterDepth, loadCN, predictSamplesCN
@@ -87,6 +87,9 @@ def readMapping(names, reads, index, index_ref, exon_region_only=False, alignmen
             data = extractVariant(readPair(source), gk, dev=dev, dindex=dindex)
         if write_json:
             writeReadsAndVariantsData(data.asDict(), name + ".json")
+            # the reference also rewrites the filtered pairs as BAM (hisat2.py:936-940)
+            saveReadsToBam(data, name, source)
+            saveReadsToBam(data, name + ".no_multi", source, filter_multi_mapped=True)
         else:   # compact hand-off instead: CSR + string table, no SAM text (hisat2.writeCompact)
             writeCompact(data, name + ".npz", index_ref=index_ref)
         processed.append((name, data))

@@ -304,6 +304,15 @@ def bamHeader(path: str) -> str:
         lib().gk_bam_close(h)
 
 
+def writeBam(path: str, sam_text: bytes | str, coordinate_sort: bool = True) -> None:
+    """SAM text (header + alignment lines) -> BGZF BAM, natively (``gk_bam_write``): what
+    ``samtools sort`` of the SAM does for ``utils.samtobam`` (hisat2.py:869-901); no ``.bai``."""
+    from ._lib import check, lib
+    if isinstance(sam_text, str):
+        sam_text = sam_text.encode()
+    check(lib().gk_bam_write(path.encode(), sam_text, len(sam_text), int(coordinate_sort)))
+
+
 def readChunks(path: str, chunk_bytes: int = 1 << 24):
     """Byte chunks of a ``.sam`` / ``.sam.gz`` file, or of the name-collated text of a ``.bam``."""
     if path.endswith(".bam"):

@@ -32,6 +32,15 @@ def _tag(field: str) -> bytes:
     raise ValueError(field)
 
 
+def _reg2bin(beg: int, end: int) -> int:
+    """UCSC bin of the 0-based half-open interval (SAM specification, section 5.3)."""
+    end -= 1
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return base + (beg >> shift)
+    return 0
+
+
 def _record(line: str, ref_id: dict[str, int]) -> bytes:
     f = line.split("\t")
     name, flag, rname, pos, mapq, cigar, rnext, pnext, tlen, seq, qual = f[:11]
@@ -51,7 +60,9 @@ def _record(line: str, ref_id: dict[str, int]) -> bytes:
     for i in range(l_seq):
         packed[i >> 1] |= _BASES[seq[i]] << (4 if i % 2 == 0 else 0)
     quals = b"\xff" * l_seq if qual == "*" else bytes(ord(c) - 33 for c in qual)
-    body = struct.pack("<iiBBHHHIiii", rid, int(pos) - 1, len(name) + 1, int(mapq), 4680, len(ops), int(flag), l_seq,
+    ref_len = sum(o >> 4 for o in ops if (o & 15) in (0, 2, 3, 7, 8)) or 1
+    body = struct.pack("<iiBBHHHIiii", rid, int(pos) - 1, len(name) + 1, int(mapq),
+                       _reg2bin(int(pos) - 1, int(pos) - 1 + ref_len), len(ops), int(flag), l_seq,
                        nid, int(pnext) - 1, int(tlen))
     body += name.encode() + b"\0" + b"".join(struct.pack("<I", o) for o in ops) + bytes(packed) + quals
     body += b"".join(_tag(t) for t in f[11:])

@@ -81,7 +81,9 @@ def test_command_line_two_samples(device, tmp_path):
         s = synth.makeSample(sidx, seed=50 + k, n_pairs=2500)
         path = tmp_path / f"s{k}.sam.gz"
         with gzip.open(path, "wt") as f:
-            f.write("@HD\tVN:1.0\tSO:queryname\n" + "\n".join(synth.toSamLines(s)) + "\n")
+            f.write("@HD\tVN:1.0\tSO:queryname\n" +
+                    "".join(f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}\n" for g in sidx.genes) +
+                    "\n".join(synth.toSamLines(s)) + "\n")
         cn_path = tmp_path / f"s{k}.cn.tsv"
         cn_path.write_text("gene\tcn\n" + "".join(f"{g}\t{c}\n" for g, c in s.gene_cn.items()))
         sams.append(str(path)); cns.append(str(cn_path)); samples.append(s)
@@ -105,6 +107,19 @@ def test_command_line_two_samples(device, tmp_path):
     assert any(n.endswith(".variant.json") for n in produced)
     assert any(n.endswith(".variant.no_multi.depth.tsv") for n in produced)
     assert any(n.endswith(".full.possible.tsv") for n in produced)
+    # the filtered alignments are rewritten as BAM like extractVariantFromBam does (hisat2.py:936-940)
+    from kir_graph_amd import packed
+    bams = sorted(n for n in produced if n.endswith(".variant.bam"))
+    uniq = sorted(n for n in produced if n.endswith(".variant.no_multi.bam"))
+    assert len(bams) == 2 and len(uniq) == 2
+    for k, s in enumerate(samples):
+        ref = ot.tabulateLines(synth.toSamLines(s), gidx.variants)
+        got = b"".join(packed.bamChunks(str(tmp_path / "out" / bams[k]), name_sorted=False)).decode().split("\n")[:-1]
+        assert len(got) == 2 * len(ref["reads"])
+        pos = [(l.split("\t")[2], int(l.split("\t")[3])) for l in got]
+        assert pos == sorted(pos, key=lambda x: (sidx.genes.index(x[0]), x[1]))      # coordinate-sorted
+        only = b"".join(packed.bamChunks(str(tmp_path / "out" / uniq[k]), name_sorted=False)).decode().split("\n")[:-1]
+        assert len(only) == 2 * sum(r["multiple"] == 1 for r in ref["reads"])
 
 
 def test_command_line_reads_coordinate_sorted_bam(device, tmp_path):

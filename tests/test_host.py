@@ -317,3 +317,30 @@ def test_native_bam_reader_rejects_garbage(tmp_path):
     p.write_bytes(b"not a bam file at all")
     with pytest.raises(_lib.GkError):
         list(packed.bamChunks(str(p)))
+
+
+def test_native_bam_writer_matches_the_test_encoder_and_round_trips(tmp_path):
+    """gk_bam_write: same bytes as the suite's Python encoder for the same record order; coordinate sort;
+    what it writes is read back unchanged by the native reader."""
+    from bamwriter import bamBytes
+    sidx = synth.makeIndex(seed=5, n_genes=3, var_range=(200, 300), allele_range=(10, 20))
+    sample = synth.makeSample(sidx, seed=9, n_pairs=800)
+    records = synth.toSamLines(sample)
+    records[0] += "\tXA:A:q\tXf:f:0.5\tXB:B:s,-3,7\tXH:H:1AE3\tXI:i:3000000000\tXS:i:-70000\tXC:i:200\tXc:i:-5"
+    header = ["@HD\tVN:1.0\tSO:unsorted"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+    text = "\n".join(header + records) + "\n"
+    # file order kept: byte-identical BAM stream to the independent Python encoder
+    path = str(tmp_path / "a.bam")
+    packed.writeBam(path, text, coordinate_sort=False)
+    inflated = b"".join(gzip.decompress(b) for b in [open(path, "rb").read()])
+    assert inflated == bamBytes(header + records)
+    assert b"".join(packed.bamChunks(path, name_sorted=False)).decode().split("\n")[:-1] == records
+    assert packed.bamHeader(path) == "\n".join(header) + "\n"
+    # coordinate sort = stable sort by (reference order of the header, position)
+    path2 = str(tmp_path / "b.bam")
+    packed.writeBam(path2, text, coordinate_sort=True)
+    order = {g: i for i, g in enumerate(sidx.genes)}
+    want = sorted(records, key=lambda l: (order[l.split("\t")[2]], int(l.split("\t")[3])))
+    assert b"".join(packed.bamChunks(path2, name_sorted=False)).decode().split("\n")[:-1] == want
+    with pytest.raises(_lib.GkError):
+        packed.writeBam(str(tmp_path / "c.bam"), "@HD\tVN:1.0\nbroken line\n")
