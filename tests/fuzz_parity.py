@@ -20,10 +20,13 @@ from kir_graph_amd.kir_typing import selectKirTypingModel  # noqa: E402
 from oracle import em as oem, tabulate as ot, typing as oty  # noqa: E402
 
 
+WIDE = os.environ.get("GK_FUZZ_WIDE") == "1"     # wide genes: several allele slots / tiles per gene, fewer cases
+
+
 def one(seed: int, dev) -> str:
     rng = np.random.default_rng(seed)
-    n_genes = int(rng.integers(1, 4))
-    a_lo = int(rng.choice([3, 12, 40, 70]))
+    n_genes = int(rng.integers(1, 4)) if not WIDE else 1
+    a_lo = int(rng.choice([3, 12, 40, 70])) if not WIDE else int(rng.choice([120, 190, 250, 320]))
     sidx = synth.makeIndex(seed=seed, n_genes=n_genes, var_range=(60, 400), allele_range=(a_lo, a_lo + int(rng.integers(1, 30))),
                            len_range=(2500, 6000), frac_del=float(rng.choice([0.0, 0.09, 0.2])),
                            frac_ins=float(rng.choice([0.0, 0.03, 0.1])))
@@ -31,7 +34,8 @@ def one(seed: int, dev) -> str:
     gene_cn = {g: int(rng.choice([0, 1, 2, 2, 3, 4])) for g in sidx.genes}
     if not any(gene_cn.values()):
         gene_cn[sidx.genes[0]] = 2
-    sample = synth.makeSample(sidx, seed=seed + 1, n_pairs=int(rng.choice([40, 300, 1500, 4000])), gene_cn=gene_cn,
+    sample = synth.makeSample(sidx, seed=seed + 1, n_pairs=int(rng.choice([40, 300, 1500, 4000] if not WIDE else [2500, 9000])),
+                              gene_cn=gene_cn,
                               err_rate=float(rng.choice([0.0, 0.001, 0.01])), frac_multi=float(rng.choice([0.0, 0.05, 0.3])))
     lines = synth.toSamLines(sample)
     ref = ot.tabulateLines(lines, sidx.variants)
@@ -43,7 +47,7 @@ def one(seed: int, dev) -> str:
     for a, b in zip(got_reads, ref["reads"]):
         assert (a.lpv, a.rpv, a.lnv, a.rnv, a.multiple, a.backbone) == \
                (b["lpv"], b["rpv"], b["lnv"], b["rnv"], b["multiple"], b["backbone"]), "lists"
-    top_n = int(rng.choice([5, 60, 600]))
+    top_n = int(rng.choice([5, 60, 600] if not WIDE else [10, 40]))
     corr = bool(rng.integers(0, 2))
     for method, omethod in (("full", "full"), ("exonfirst_1", "exonfirst_1"), ("exonfirst_0.9", "exonfirst_0.9")):
         gpu = selectKirTypingModel(method, data, top_n=top_n, variant_correction=corr)
