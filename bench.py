@@ -49,22 +49,31 @@ def build_inputs(seed: int, n_pairs: int, index_seed: int = 2022):
 def run_steps(n_steps, dev, dindex, gidx, mates_buf, table, gene_cn, method):
     """``n_steps`` samples: tabulation + typing of records resident in HBM.
 
-    Like a cohort run, the samples go through ``cohort.prefetched``: the tabulation of sample k+1
-    (device stream of ``dev``) is issued while sample k is typed (worker streams).  Every
-    tabulation and every typing of the ``n_steps`` samples starts and ends inside this call."""
-    from kir_graph_amd.cohort import prefetched
+    Like a cohort run, the samples go through ``cohort.prefetched`` and ``cohort.overlapped``: the
+    tabulation of the next sample is issued while the current one is typed; with GK_SAMPLE_LANES=2
+    two samples are typed at a time (each on its own block of worker streams).  Every tabulation and
+    typing of the ``n_steps`` samples starts and ends inside this call."""
+    from kir_graph_amd.cohort import overlapped, prefetched
     from kir_graph_amd.engine import Tabulation
     from kir_graph_amd.hisat2 import SampleData
     from kir_graph_amd.kir_typing import hostThreads, selectKirTypingModel
-    out = None
     depth = int(os.environ.get("GK_PREFETCH", "1"))
-    ingest = dev.worker(hostThreads())      # a context of its own: the typing threads use workers 0..n-1
-    for tab in prefetched(range(n_steps), lambda _: Tabulation(dindex, mates_buf, dev=ingest), depth=depth):
+    lanes = int(os.environ.get("GK_SAMPLE_LANES", "1"))   # 2: two samples typed at a time (gain varies from box to box)
+    ingest = dev.worker(lanes * hostThreads())   # a context of its own: the typing lanes use workers 0..lanes*n-1
+
+    def type_one(tab, lane):
         data = SampleData(tab, gidx, None, ins_strings=table.strings)
         typer = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
+        typer.slot_base = lane * hostThreads()
         calls, warn = typer.typing(gene_cn)
-        out = (calls, warn, tab.n_valid, typer)
+        n_valid = tab.n_valid
         tab.close()
+        return calls, warn, n_valid, typer
+
+    out = None
+    tabs = prefetched(range(n_steps), lambda _: Tabulation(dindex, mates_buf, dev=ingest), depth=depth)
+    for out in overlapped(tabs, type_one, lanes=lanes):
+        pass
     return out
 
 

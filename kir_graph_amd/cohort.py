@@ -36,6 +36,39 @@ def prefetched(items, prepare, depth: int = 1):
             yield pending.pop(0).result()
 
 
+def overlapped(items, work, lanes: int = 2):
+    """Yield ``work(item, lane)`` for every item, in order, with up to ``lanes`` items in flight on
+    helper threads (``lane`` = 0 .. lanes-1 tells ``work`` which set of device contexts is its own).
+
+    Typing one sample ends with a tail -- the last, largest gene finishes alone -- and starts with
+    a ramp; with two samples in flight the GPU and the host threads of one fill the other's gaps."""
+    from concurrent.futures import ThreadPoolExecutor
+    import queue
+    if lanes <= 1:
+        for item in items:
+            yield work(item, 0)
+        return
+    free = queue.SimpleQueue()
+    for lane in range(lanes):
+        free.put(lane)
+
+    def run(item):
+        lane = free.get()
+        try:
+            return work(item, lane)
+        finally:
+            free.put(lane)
+
+    with ThreadPoolExecutor(max_workers=lanes, thread_name_prefix="gk-sample") as pool:
+        pending = []
+        for item in items:
+            pending.append(pool.submit(run, item))
+            if len(pending) >= lanes:
+                yield pending.pop(0).result()
+        while pending:
+            yield pending.pop(0).result()
+
+
 def shardSamples(n_samples: int, world: int) -> list[list[int]]:
     """Round-robin assignment of sample indices to ranks (deterministic, known to every rank)."""
     return [list(range(r, n_samples, world)) for r in range(world)]

@@ -119,6 +119,7 @@ class _GenesInParallel(Typing):
     def __init__(self) -> None:
         super().__init__()
         self._local = threading.local()
+        self.slot_base = 0     # first worker context of this typer (cohort.overlapped gives every lane its own block)
 
     def _context(self):
         """(tabulation bound to this thread's context, its log table)."""
@@ -128,7 +129,7 @@ class _GenesInParallel(Typing):
             k = getattr(self._local, "slot", None)
             # never the tabulation's own context: a cohort run may already be tabulating the next
             # sample there (cohort.prefetched), and a context serves one host thread at a time
-            dev = base.dev.worker(0 if k is None else k)
+            dev = base.dev.worker(self.slot_base + (0 if k is None else k))
             tab = self._local.tab = base.on(dev)
             self._local.logs = sharedLogTable(dev)
         return tab, self._local.logs
@@ -147,7 +148,7 @@ class _GenesInParallel(Typing):
         def init():
             with lock:
                 self._local.slot = next(slots)
-                self._data.tab.dev.worker(self._local.slot)   # create the context under the lock
+                self._data.tab.dev.worker(self.slot_base + self._local.slot)   # create the context under the lock
 
         with ThreadPoolExecutor(max_workers=n_threads, initializer=init) as pool:
             # largest genes first (they dominate the makespan); order of results is restored below
