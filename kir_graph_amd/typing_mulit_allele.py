@@ -218,12 +218,12 @@ def firstOfSets(prev_ids: np.ndarray, cols: np.ndarray, n_allele: int) -> np.nda
     pos = np.full(n_allele * n_allele, never)
     np.minimum.at(pos, (lo * n_allele + hi)[::-1], rank[::-1])
     pos = pos.reshape(n_allele, n_allele)
-    a = cols[None, :]
+    pos = np.minimum(pos, pos.T)            # symmetric: pos[x, y] = first position of the pair {x, y}
+    by_col = pos[:, cols]                   # [allele][offered column]
 
     def earlier(keep: np.ndarray, gone: np.ndarray) -> np.ndarray:
         """candidate repeats (keep[t], a) + gone[t] found at an earlier position"""
-        k_ = keep[:, None]
-        return (pos[np.minimum(k_, a), np.maximum(k_, a)] < rank[:, None]) & offered[gone][:, None]
+        return (by_col[keep] < rank[:, None]) & offered[gone][:, None]
 
     first = ~(earlier(hi, lo) | earlier(lo, hi))
     first &= (pos[lo, hi] == rank)[:, None]
