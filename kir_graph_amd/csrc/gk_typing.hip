@@ -4,13 +4,14 @@
 //   gk_variant_count /
 //   gk_variant_correct  AlleleTyping.errorCorrection            typing_mulit_allele.py:302-338
 //   gk_select_nonempty  AlleleTyping.removeEmptyReads           typing_mulit_allele.py:274-281
-//   gk_compat           reads2AlleleProb / read2Onehot / onehot2Prob   typing_mulit_allele.py:287-300, 340-381
+//   gk_compat(_log)     reads2AlleleProb / read2Onehot / onehot2Prob   typing_mulit_allele.py:287-300, 340-381
+//                       (_log: with np.log10 of line 263 applied through the value table)
 //
-// Compatibility kernel: one wavefront per read pair, lanes = alleles (3 allele slots per lane up
-// to 192 alleles per pass).  The pair's variant ordinals are wave-uniform, every lane tests its
-// allele bit in the variant's bit row and multiplies 0.999 / 0.001 in the reference's factor
-// order (lpv, rpv, lnv, rnv), so the double product is bit-identical to numpy's sequential
-// multiply.reduce.  Bit rows of the gene are staged in LDS when they fit.
+// Compatibility kernel: one wavefront per read pair, lanes = alleles (1-4 allele slots per lane,
+// up to 256 alleles per pass).  The pair's variant ordinals are wave-uniform; the two bit-row words of
+// a slot, read back through v_readlane into an SGPR pair, are the slot's 64 per-lane "allele has the
+// variant" bits and select 0.999 / 0.001, multiplied in the reference's factor order (lpv, rpv, lnv,
+// rnv), so the double product is bit-identical to numpy's sequential multiply.reduce.
 #include <algorithm>
 
 #include "gk_common.h"
