@@ -13,15 +13,17 @@
 // accumulated sequentially.
 //
 // Mapping to CDNA4: a (max,+) contraction has no multiply, so MFMA does not apply; the kernel is
-// f64-VALU bound.  The 8 strided accumulators of numpy's block loop are spread over 8 LANES
-// (lane j owns rows == j mod 8), which leaves one accumulator register per output and lets every
-// lane carry a TT x TA register tile.  The recursion stack lives in the same 8 lanes (lane s holds
-// stack slot s), so the whole tree runs without dynamically indexed registers.  L is column-major
-// [allele][row]: row blocks are staged through LDS with coalesced 512-byte wave loads (next block
-// prefetched into registers while the current one is reduced), the previous set's row-wise max is
-// formed while staging (no R x T temporary in HBM; the reference materialises T x R x A).
-// Work is split over workgroups by output tile AND by row span: every workgroup owns one sub-tree
-// of <= 1024 rows of the numpy recursion, a second small kernel finishes the tree per chunk.
+// f64-VALU bound.  The 8 strided accumulators of numpy's block loop are spread over a QUAD of lanes,
+// two per lane (lane k owns rows == 2k, 2k+1 mod 8: adjacent rows, one ds_read_b128 per operand), and
+// every lane carries a TT x TA register tile of outputs.  The recursion stack of a sub-tree of
+// <= 512 rows lives in the same four lanes (lane s holds stack slot s), so the whole tree runs
+// without dynamically indexed registers; the fraction kernel uses the older 8-lane form of the same
+// scheme.  L is column-major [allele][row]: row blocks are staged through LDS with coalesced 512-byte
+// wave loads (next block prefetched into registers while the current one is reduced); previous sets
+// of two or more alleles are first reduced to one column each (gk_setmax), so nothing of size
+// T x R x A (the reference's temporary) is ever formed.  Work is split over workgroups by output tile
+// AND by row span: every workgroup owns one sub-tree of <= 1024 rows of the numpy recursion, a second
+// small kernel finishes the tree per chunk.
 #include <algorithm>
 
 #include "gk_common.h"
