@@ -198,7 +198,7 @@ class TypingWithPosNegAllele(_GenesInParallel):
             typ: AlleleTyping = AlleleTyping(
                 reads, view.variants, force_homo=force_homo, top_n=self._top_n,
                 variant_correction=self._variant_correction, logs=logs, _vbeg=view.vbeg,
-                _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles, _novel=view.novel)
+                _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles, _novel=view.novel, _defer_log=True)
         else:
             typ = AlleleTypingExonFirst(
                 reads, view.variants, force_homo=force_homo, top_n=self._top_n, exon_only=self._exon_only,

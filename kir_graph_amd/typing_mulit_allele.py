@@ -381,8 +381,9 @@ class AlleleTyping:
             logger.warning("[Allele] Error: Empty reads for typing (or Maybe read depth is too low)")
 
     def finish(self) -> None:
-        """Complete construction after the shared log table has been resolved."""
-        self._logs.resolve()
+        """Make sure the log-likelihood table is final (every product had its log10 in the value table);
+        cheap when it already is.  Called before the table is read -- not right after its launch, so
+        that the host can do other work (the zygosity test) while the compatibility kernel runs."""
         self._model.finishLog()
 
     # ---- reference attribute surface (lazy)
@@ -400,6 +401,7 @@ class AlleleTyping:
 
     @property
     def log_probs(self) -> np.ndarray:
+        self.finish()
         return self._model.hostLogProbs()
 
     @property
@@ -430,6 +432,7 @@ class AlleleTyping:
         if cn < 1:
             raise ValueError(f"CN should be >= 1, got {cn}")
         homo = self._isHomozygous(cn) if self.force_homo is None else self.force_homo
+        self.finish()
         self.result = []
         if homo:
             self.addCandidate()
@@ -474,6 +477,7 @@ class AlleleTyping:
 
     def _colsums(self) -> np.ndarray:
         if self._colsum_all is None:
+            self.finish()
             self._colsum_all = self._model.colsum(np.arange(self._model.n_allele))
         return self._colsum_all
 
