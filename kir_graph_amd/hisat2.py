@@ -312,16 +312,12 @@ def extractVariant(pair_reads: Iterable[tuple[str, str]], index: GkIndex | list[
     return SampleData(tab, index, None, pairs_text=pairs, ins_strings=table.strings)
 
 
-def extractVariantFromText(source, index: GkIndex, dev: Device | None = None, dindex: DeviceIndex | None = None,
-                           keep_text: bool = True) -> SampleData:
-    """Name-collated SAM file (or iterable of byte chunks) -> tabulated sample.
+def packAlignments(source, index: GkIndex, keep_text: bool = True) -> dict:
+    """Host half of ``extractVariantFromText``: alignment file (or byte chunks) -> packed records.
 
-    Same result as ``extractVariant(readPair(path), ...)`` with the pairing and text decoding done
-    natively (``gk_packer_*``).  ``keep_text``: keep the SAM lines of the emitted pairs (needed only
-    for the ``l_sam`` / ``r_sam`` fields of ``.variant.json``)."""
+    Native code with the GIL released (``gk_bam_*`` / ``gk_packer_*``), so a cohort run can pack the
+    next sample on a helper thread (``cohort.prefetched``) while the current one is on the GPU."""
     from .packed import packBam, packText, readChunks
-    dev = dev or Device()
-    dindex = dindex or DeviceIndex(dev, index)
     if isinstance(source, str) and source.endswith(".bam") and not keep_text:
         # nobody needs the SAM text: the BAM records go to the packer in binary form
         chunks = None
@@ -331,16 +327,35 @@ def extractVariantFromText(source, index: GkIndex, dev: Device | None = None, di
         if keep_text:
             chunks = list(chunks)
         rec, table, pair_lines, counts = packText(chunks, index)
-    logger.info(f"[Graph] Reads: {counts['reads']} Pairs: {counts['pairs']}")
     pairs_text = None
     if keep_text:
         lines = b"".join(chunks).decode().split("\n")
         pairs_text = [(lines[a].rstrip("\r"), lines[b].rstrip("\r")) for a, b in pair_lines.tolist()]
+    return {"records": rec, "strings": table.strings, "pairs_text": pairs_text, "counts": counts}
+
+
+def extractVariantFromPacked(pack: dict, index: GkIndex, dev: Device | None = None,
+                             dindex: DeviceIndex | None = None) -> SampleData:
+    """Device half: packed records -> tabulated sample (novel ids continue the process-wide counter)."""
+    dev = dev or Device()
+    dindex = dindex or DeviceIndex(dev, index)
+    logger.info(f"[Graph] Reads: {pack['counts']['reads']} Pairs: {pack['counts']['pairs']}")
     base = Variant.novel_id
-    tab = Tabulation(dindex, rec, novel_base=base)
+    tab = Tabulation(dindex, pack["records"], novel_base=base)
     Variant.novel_id = base + tab.n_novel
     logger.info(f"[Graph] Filterd pairs: {tab.n_valid}")
-    return SampleData(tab, index, None, pairs_text=pairs_text, ins_strings=table.strings)
+    return SampleData(tab, index, None, pairs_text=pack["pairs_text"], ins_strings=pack["strings"])
+
+
+def extractVariantFromText(source, index: GkIndex, dev: Device | None = None, dindex: DeviceIndex | None = None,
+                           keep_text: bool = True) -> SampleData:
+    """Alignment file (``.sam`` / ``.sam.gz`` name-collated, or ``.bam``) or iterable of byte chunks ->
+    tabulated sample.
+
+    Same result as ``extractVariant(readPair(path), ...)`` with the pairing and decoding done natively
+    (``packAlignments``).  ``keep_text``: keep the SAM lines of the emitted pairs (needed only for the
+    ``l_sam`` / ``r_sam`` fields of ``.variant.json`` and the BAM rewrites)."""
+    return extractVariantFromPacked(packAlignments(source, index, keep_text), index, dev, dindex)
 
 
 def writeReadsAndVariantsData(reads_data: ReadsAndVariantsData, filename: str) -> None:

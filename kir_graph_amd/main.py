@@ -25,7 +25,8 @@ import pandas as pd
 
 from . import cohort
 from .external_tools import setEngine
-from .hisat2 import (SampleData, extractVariant, extractVariantFromText, readExons, readPair,  # noqa: F401
+from .hisat2 import (SampleData, extractVariant, extractVariantFromPacked, extractVariantFromText,  # noqa: F401
+                     packAlignments, readExons, readPair,
                      saveReadsToBam, writeCompact,
                      writeReadsAndVariantsData)
 from .index import GkIndex
@@ -68,21 +69,29 @@ def readMapping(names, reads, index, index_ref, exon_region_only=False, alignmen
     from .engine import DeviceIndex
     dindex = DeviceIndex(dev, gk)
     bam_files, processed, depth_files = [], [], []
-    for k, (name, (fq1, fq2)) in enumerate(zip(names, reads)):
-        suffix = "." + index.replace(".", "_").replace("/", "_")
-        name += suffix
+
+    def prepare(k: int):
+        """External mapping (when needed) + native packing of sample k: host work, off the GPU's path."""
+        name = names[k] + "." + index.replace(".", "_").replace("/", "_")
         if alignments:
             source = alignments[k]
         else:
             logger.info(f"[Graph] Run graph mapping on index {index} ({name})")
-            hisatMap(index, fq1, fq2, name + ".bam", threads=getThreads())
+            hisatMap(index, reads[k][0], reads[k][1], name + ".bam", threads=getThreads())
             source = name + ".bam"
+        pack = None
+        if source.endswith((".sam", ".sam.gz")) or os.environ.get("GK_BAM_READER", "native") != "samtools":
+            # SAM text, or BAM decoded + name-collated natively (packed.bamChunks / packBam), packed natively
+            pack = packAlignments(source, gk, keep_text=write_json)
+        return name, source, pack
+
+    # the next sample is mapped / packed on a helper thread while this one is tabulated and written out
+    for name, source, pack in cohort.prefetched(range(len(names)), prepare):
         bam_files.append(source)
         name += ".variant"
         logger.info(f"[Graph] Filter mapping ({name})")
-        if source.endswith((".sam", ".sam.gz")) or os.environ.get("GK_BAM_READER", "native") != "samtools":
-            # SAM text, or BAM decoded + name-collated natively (packed.bamChunks), packed natively
-            data = extractVariantFromText(source, gk, dev=dev, dindex=dindex, keep_text=write_json)
+        if pack is not None:
+            data = extractVariantFromPacked(pack, gk, dev=dev, dindex=dindex)
         else:   # BAM name-collated through samtools like the reference (hisat2.readBam)
             data = extractVariant(readPair(source), gk, dev=dev, dindex=dindex)
         if write_json:
