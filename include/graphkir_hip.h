@@ -124,6 +124,12 @@ typedef struct gk_tab_info {
   gk_dptr d_novel_key;  /* uint64 [n_novel] */
 } gk_tab_info;
 int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates, int64_t n_pairs, gk_tab** out);
+/* Same with the optional pileup correction of mismatches (hisat2.errorCorrection 609-654, applied in
+ * recordToVariants 684-685 before the id lookup): d_corr uint8 [total positions][5] holds, per reference
+ * position and read base (A, C, G, T, N), the base to use instead (0 = keep the read's);
+ * d_gene_pos0 int64 [n_gene + 1] = first position of every backbone in that table. */
+int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates, int64_t n_pairs, gk_dptr d_corr,
+                          gk_dptr d_gene_pos0, gk_tab** out);
 /* Same handle from host CSR lists (the `.variant.json` hand-off of hisat2.py:847-866 loaded by
  * loadReadsAndVariantsData): off[4*n_valid+1] in list order lpv, rpv, lnv, rnv; ordinals < n_var_total. */
 int gk_tab_from_csr(gk_ctx* ctx, int32_t n_var_total, int64_t n_valid, const uint32_t* off, const uint32_t* ids,
@@ -243,6 +249,11 @@ int gk_bam_pack(gk_bam* bam, struct gk_packer* packer);
  * saveReadsToBam / samtobam (hisat2.py:869-901, `samtools sort`).  coordinate_sort != 0 orders the
  * records by (reference, position), stable, unmapped last; no .bai index is written. */
 int gk_bam_write(const char* path, const char* sam_text, int64_t n_bytes, int32_t coordinate_sort);
+/* base counts per reference position, replacing pileup.getPileupBaseRatio (pileup.py:57-81: parse of
+ * `samtools mpileup -a`; the defaults modelled are listed in csrc/gk_bamread.cpp).  gene_off[g] = first
+ * position of reference g (header order) in the concatenated position space, gene_off[n_gene] = total;
+ * counts_out uint32 [total][6] = A, C, G, T, N, '*'. */
+int gk_bam_pileup(gk_bam* bam, const int64_t* gene_off, int32_t n_gene, uint32_t* counts_out);
 
 /* ---- read depth: replaces `samtools depth -aa {name}.no_multi.bam` (samtools_utils.py:9-14).
  * Depth of every backbone position from the M runs of the filter-passing pairs of a tabulation made

@@ -73,6 +73,8 @@ _SIGS = {
     "gk_index_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "gk_index_destroy": (C.c_int, [C.c_void_p]),
     "gk_tabulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_void_p)]),
+    "gk_tabulate_corrected": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint64,
+                                        C.POINTER(C.c_void_p)]),
     "gk_tab_from_csr": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_void_p)]),
     "gk_tab_get_info": (C.c_int, [C.c_void_p, C.POINTER(TabInfo)]),
@@ -99,6 +101,7 @@ _SIGS = {
     "gk_bam_close": (C.c_int, [C.c_void_p]),
     "gk_bam_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "gk_bam_header": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "gk_bam_pileup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gk_bam_write": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int64, C.c_int32]),
     "gk_bam_pack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gk_bam_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),

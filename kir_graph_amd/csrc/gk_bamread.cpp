@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "gk_ingest.h"
@@ -850,5 +851,99 @@ extern "C" int gk_bam_write(const char* path, const char* sam_text, int64_t n_by
   for (auto& c : comp) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
   ok = fclose(f) == 0 && ok;
   if (!ok) { gk_set_error("short write to %s", path); return GK_ERR_ARG; }
+  return GK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Base counts per reference position: the native form of pileup.getPileupBaseRatio (pileup.py:57-81),
+// which parses `samtools mpileup -a bam`.  The model of mpileup's defaults, from its manual page:
+// records flagged UNMAP / SECONDARY / QCFAIL / DUP are skipped, so are paired reads that are not in a
+// proper pair ("anomalous"); bases of quality < 13 are not counted; where the two mates of a pair
+// overlap, equal bases count once (the later mate's quality becomes 0), unequal ones keep only the
+// better base at 0.8 of its quality; a deleted position counts as '*'; no BAQ (no reference given).
+// Not modelled: the 8000-read depth cap.  Counts are [position][A, C, G, T, N, *]; gene_off[g] is
+// the first position of reference g (header order) in the concatenated position space.
+extern "C" int gk_bam_pileup(gk_bam* b, const int64_t* gene_off, int32_t n_gene, uint32_t* counts_out) {
+  if (!b || !gene_off || !counts_out || n_gene <= 0) { gk_set_error("bad pileup arguments"); return GK_ERR_ARG; }
+  const int64_t total = gene_off[n_gene];
+  memset(counts_out, 0, (size_t)total * 6 * sizeof(uint32_t));
+  const uint8_t* base = b->data.data();
+  struct Cov { int32_t pos; uint8_t code; uint8_t qual; bool is_del; };
+  auto code_of = [](uint8_t nib) -> uint8_t {   // BAM nibble -> A C G T N
+    switch (nib) { case 1: return 0; case 2: return 1; case 4: return 2; case 8: return 3; default: return 4; }
+  };
+  auto usable = [&](const uint8_t* p) {
+    const uint32_t flag = rd16(p + 14);
+    if (flag & (4u | 256u | 512u | 1024u)) return false;
+    if ((flag & 1u) && !(flag & 2u)) return false;
+    return rds32(p) >= 0 && rds32(p) < n_gene;
+  };
+  auto cover = [&](const uint8_t* p, std::vector<Cov>& out) {
+    out.clear();
+    const uint32_t l_name = p[8], n_cig = rd16(p + 12), l_seq = rd32(p + 16);
+    const uint8_t* cig = p + 32 + l_name;
+    const uint8_t* seq = cig + 4ull * n_cig;
+    const uint8_t* qual = seq + (l_seq + 1) / 2;
+    int32_t pos = rds32(p + 4);
+    uint32_t ri = 0;
+    for (uint32_t c = 0; c < n_cig; ++c) {
+      const uint32_t v = rd32(cig + 4ull * c), op = v & 15u, len = v >> 4;
+      if (op == 0 || op == 7 || op == 8) {
+        for (uint32_t k = 0; k < len && ri < l_seq; ++k, ++ri, ++pos)
+          out.push_back({pos, code_of((seq[ri >> 1] >> ((~ri & 1u) << 2)) & 15u), qual[ri] == 0xFF ? (uint8_t)255 : qual[ri], false});
+      } else if (op == 2) {
+        const uint8_t q = ri ? (qual[ri - 1] == 0xFF ? (uint8_t)255 : qual[ri - 1]) : (uint8_t)255;
+        for (uint32_t k = 0; k < len; ++k, ++pos) out.push_back({pos, 5, q, true});
+      } else if (op == 1 || op == 4) {
+        ri += len;
+      } else if (op == 3) {
+        pos += (int32_t)len;
+      }
+    }
+  };
+  // mates of proper pairs by name
+  std::unordered_map<std::string, int64_t> first_of;
+  std::vector<int64_t> mate((size_t)b->recs.size(), -1);
+  for (size_t i = 0; i < b->recs.size(); ++i) {
+    const uint8_t* p = base + b->recs[i].off;
+    if (!usable(p) || !(rd16(p + 14) & 1u)) continue;
+    std::string name((const char*)p + 32, strnlen((const char*)p + 32, p[8]));
+    auto it = first_of.find(name);
+    if (it == first_of.end()) first_of.emplace(std::move(name), (int64_t)i);
+    else { mate[i] = it->second; mate[(size_t)it->second] = (int64_t)i; first_of.erase(it); }
+  }
+  std::vector<Cov> mine, other;
+  for (size_t i = 0; i < b->recs.size(); ++i) {
+    const uint8_t* p = base + b->recs[i].off;
+    if (!usable(p)) continue;
+    cover(p, mine);
+    if (mate[i] >= 0) {
+      const uint8_t* q = base + b->recs[(size_t)mate[i]].off;
+      if (rds32(q) == rds32(p)) {
+        cover(q, other);
+        // "first" = the mate that starts earlier (file order on a tie)
+        const bool i_first = rds32(p + 4) < rds32(q + 4) || (rds32(p + 4) == rds32(q + 4) && (int64_t)i < mate[i]);
+        size_t a = 0, c = 0;
+        while (a < mine.size() && c < other.size()) {
+          if (mine[a].pos < other[c].pos) { ++a; continue; }
+          if (mine[a].pos > other[c].pos) { ++c; continue; }
+          Cov& x = mine[a];
+          const Cov& y = other[c];
+          if (!x.is_del && !y.is_del) {
+            if (x.code == y.code) {
+              x.qual = i_first ? (uint8_t)std::min<int>(200, (int)x.qual + (int)y.qual) : (uint8_t)0;
+            } else {
+              const bool x_wins = i_first ? x.qual >= y.qual : x.qual > y.qual;
+              x.qual = x_wins ? (uint8_t)(0.8 * x.qual) : (uint8_t)0;
+            }
+          }
+          ++a; ++c;
+        }
+      }
+    }
+    const int64_t off = gene_off[rds32(p)], len = gene_off[rds32(p) + 1] - off;
+    for (const Cov& x : mine)
+      if (x.qual >= 13 && x.pos >= 0 && x.pos < len) counts_out[(off + x.pos) * 6 + x.code] += 1;
+  }
   return GK_OK;
 }

@@ -83,6 +83,10 @@ struct IndexView {
   const int32_t* bucket;      // per gene: lower bound of (gene, 16 * b) for b = 0 .. n_bucket(gene) - 1
   const int32_t* gene_boff;   // [n_gene + 1] first bucket of each gene
   int n_var, n_gene;
+  // optional pileup correction of mismatches (hisat2.errorCorrection 609-654): corr[(gene_pos0[ref] + pos) * 5
+  // + code(read base)] = the base to use instead (0 = keep), codes A C G T N; null = no correction
+  const uint8_t* corr;
+  const int64_t* gene_pos0;   // [n_gene + 1]
 };
 
 // first ordinal whose key is >= k, where k = (ref, pos, ...)
@@ -167,6 +171,14 @@ __device__ inline void walk_mate(const MateView& r, const IndexView& ix, const N
   auto event = [&](uint32_t pos, uint32_t len, uint32_t typ, uint32_t val) {
     last_is_event = true;
     if (wk.n >= kMaxEv) { wk.overflow = true; return; }
+    if (ix.corr && typ == GK_TYP_SINGLE && (int)ref < ix.n_gene) {
+      const int code = val == 'A' ? 0 : val == 'C' ? 1 : val == 'G' ? 2 : val == 'T' ? 3 : val == 'N' ? 4 : -1;
+      const int64_t at = ix.gene_pos0[ref] + pos;
+      if (code >= 0 && at < ix.gene_pos0[ref + 1]) {
+        const uint8_t c = ix.corr[at * 5 + code];
+        if (c) val = c;
+      }
+    }
     const uint64_t k = gk_make_key(ref, pos, typ, val);
     const int i = lower_bound_key(ix, ref, pos, k);
     const bool known = i < ix.n_var && ix.key[i] == k;
@@ -459,8 +471,14 @@ int gk_index_destroy(gk_index* idx) {
 }
 
 int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, gk_tab** out) {
+  return gk_tabulate_corrected(ctx, idx, d_mates_p, n_pairs, 0, 0, out);
+}
+
+int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, gk_dptr d_corr,
+                          gk_dptr d_gene_pos0, gk_tab** out) {
   gk_bind(ctx);
   GK_REQUIRE(ctx && idx && out && n_pairs >= 0, "bad tabulate arguments");
+  GK_REQUIRE((d_corr == 0) == (d_gene_pos0 == 0), "correction table and position offsets come together");
   GK_REQUIRE(n_pairs < (1ll << 26), "more than 2^26 pairs per call");
   const gk_mate* mates = gk_ptr<const gk_mate>(d_mates_p);
   const int64_t n_mates = 2 * n_pairs;
@@ -489,7 +507,8 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_err, sizeof(int)));
   GK_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
 
-  const IndexView ix{idx->d_key, idx->d_bucket, idx->d_gene_boff, idx->n_var, idx->n_gene};
+  const IndexView ix{idx->d_key, idx->d_bucket, idx->d_gene_boff, idx->n_var, idx->n_gene,
+                     gk_ptr<uint8_t>(d_corr), gk_ptr<int64_t>(d_gene_pos0)};
   if (n_mates) {
     GK_PROF(ctx, GK_K_TAB_COUNT, GK_KERNEL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
                        nt, cnt, valid, d_err));

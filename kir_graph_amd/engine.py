@@ -52,8 +52,11 @@ class DeviceIndex:
 class Tabulation:
     """Result of ``gk_tabulate`` for one sample (replaces the ``.variant.json`` hand-off)."""
 
-    def __init__(self, dindex: DeviceIndex, mates, novel_base: int = 0, dev: Device | None = None):
-        """``dev``: context (stream) that runs the tabulation; defaults to the index's own."""
+    def __init__(self, dindex: DeviceIndex, mates, novel_base: int = 0, dev: Device | None = None,
+                 correction: tuple[np.ndarray, np.ndarray] | None = None):
+        """``dev``: context (stream) that runs the tabulation; defaults to the index's own.
+        ``correction``: (``pileup.correctionTable`` uint8 [positions][5], first position of every backbone
+        int64 [genes + 1]) -- the pileup error correction of mismatches, off when None."""
         self.dev, self.dindex = dev or dindex.dev, dindex
         if isinstance(mates, np.ndarray):
             assert mates.dtype == _lib.MATE_DTYPE
@@ -62,7 +65,15 @@ class Tabulation:
             self.mates = mates
         self.n_pairs = self.mates.size // 2
         h = C.c_void_p()
-        check(lib().gk_tabulate(self.dev.ctx, dindex.handle, self.mates.ptr, self.n_pairs, C.byref(h)))
+        if correction is None:
+            check(lib().gk_tabulate(self.dev.ctx, dindex.handle, self.mates.ptr, self.n_pairs, C.byref(h)))
+        else:
+            table, pos0 = correction
+            assert table.dtype == np.uint8 and table.shape == (int(pos0[-1]), 5) and len(pos0) == len(dindex.host.genes) + 1
+            d_table = self.dev.put(np.ascontiguousarray(table).reshape(-1) if table.size else np.zeros(1, np.uint8))
+            d_pos0 = self.dev.put(np.ascontiguousarray(pos0, dtype=np.int64))
+            check(lib().gk_tabulate_corrected(self.dev.ctx, dindex.handle, self.mates.ptr, self.n_pairs,
+                                              d_table.ptr, d_pos0.ptr, C.byref(h)))
         self.handle = h
         info = TabInfo()
         check(lib().gk_tab_get_info(h, C.byref(info)))

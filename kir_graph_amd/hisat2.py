@@ -335,27 +335,28 @@ def packAlignments(source, index: GkIndex, keep_text: bool = True) -> dict:
 
 
 def extractVariantFromPacked(pack: dict, index: GkIndex, dev: Device | None = None,
-                             dindex: DeviceIndex | None = None) -> SampleData:
-    """Device half: packed records -> tabulated sample (novel ids continue the process-wide counter)."""
+                             dindex: DeviceIndex | None = None, correction=None) -> SampleData:
+    """Device half: packed records -> tabulated sample (novel ids continue the process-wide counter).
+    ``correction``: see ``Tabulation`` (pileup error correction, hisat2.py:609-654)."""
     dev = dev or Device()
     dindex = dindex or DeviceIndex(dev, index)
     logger.info(f"[Graph] Reads: {pack['counts']['reads']} Pairs: {pack['counts']['pairs']}")
     base = Variant.novel_id
-    tab = Tabulation(dindex, pack["records"], novel_base=base)
+    tab = Tabulation(dindex, pack["records"], novel_base=base, correction=correction)
     Variant.novel_id = base + tab.n_novel
     logger.info(f"[Graph] Filterd pairs: {tab.n_valid}")
     return SampleData(tab, index, None, pairs_text=pack["pairs_text"], ins_strings=pack["strings"])
 
 
 def extractVariantFromText(source, index: GkIndex, dev: Device | None = None, dindex: DeviceIndex | None = None,
-                           keep_text: bool = True) -> SampleData:
+                           keep_text: bool = True, correction=None) -> SampleData:
     """Alignment file (``.sam`` / ``.sam.gz`` name-collated, or ``.bam``) or iterable of byte chunks ->
     tabulated sample.
 
     Same result as ``extractVariant(readPair(path), ...)`` with the pairing and decoding done natively
     (``packAlignments``).  ``keep_text``: keep the SAM lines of the emitted pairs (needed only for the
     ``l_sam`` / ``r_sam`` fields of ``.variant.json`` and the BAM rewrites)."""
-    return extractVariantFromPacked(packAlignments(source, index, keep_text), index, dev, dindex)
+    return extractVariantFromPacked(packAlignments(source, index, keep_text), index, dev, dindex, correction)
 
 
 def writeReadsAndVariantsData(reads_data: ReadsAndVariantsData, filename: str) -> None:
@@ -409,10 +410,13 @@ def saveReadsToBam(data: "SampleData", filename_prefix: str, bam_file: str, filt
 def extractVariantFromBam(index: str, bam_file: str, output_prefix: str, error_correction: bool = True,
                           dev: Device | None = None) -> SampleData:
     """index + alignments -> ``{output_prefix}.json``, ``.bam`` and ``.no_multi.bam`` (hisat2.py:904-940)."""
-    if error_correction:
-        raise NotImplementedError("error_correction=True (pileup) is not implemented; the CLI passes False")
     gk = GkIndex.load(index)
-    data = extractVariantFromText(bam_file, gk, dev=dev, keep_text=True)
+    correction = None
+    if error_correction:   # hisat2.py:925-928: pileup of the same BAM decides which mismatches are read errors
+        from .pileup import correctionTable, pileupCounts
+        counts, pos0 = pileupCounts(bam_file, gk)
+        correction = (correctionTable(counts), pos0)
+    data = extractVariantFromText(bam_file, gk, dev=dev, keep_text=True, correction=correction)
     logger.debug(f"[Graph] Save allele per reads in {output_prefix}.json")
     writeReadsAndVariantsData(data.asDict(), f"{output_prefix}.json")
     logger.debug(f"[Graph] Save filtered reads in {output_prefix}.bam")

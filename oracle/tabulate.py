@@ -299,7 +299,7 @@ def tabulate(pairs: Iterable[tuple[str, str]], index_vars: list[Variant],
 
 
 def tabulateLines(lines: Iterable[str], index_vars: list[Variant],
-                  novel: NovelCounter | None = None) -> dict:
+                  novel: NovelCounter | None = None, pileup: dict | None = None) -> dict:
     """readPair + filterRead + extractVariant in one call (extractVariantFromBam 923-932)."""
     pairs = (p for p in pairMates(lines) if passesFilter(p[0]) and passesFilter(p[1]))
-    return tabulate(pairs, index_vars, novel)
+    return tabulate(pairs, index_vars, novel, pileup)

@@ -94,3 +94,62 @@ def test_model_and_reductions_match_oracle(device, small_case):
     logs.close()
     tab.close()
     dindex.close()
+
+
+def test_pileup_error_correction_matches_oracle(device, tmp_path):
+    """error_correction=True (hisat2.py:925-928): mismatches that the pileup calls read errors are rewritten
+    before the variant lookup; product (native pileup + corrected tabulation) vs oracle, ids and novel variants."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from bamwriter import samToBam
+    from kir_graph_amd import pileup
+    from kir_graph_amd.hisat2 import extractVariantFromText
+    from kir_graph_amd.index import GkIndex
+    from oracle import pileup as opile
+    sidx = synth.makeIndex(seed=21, n_genes=3, len_range=(4200, 6000), var_range=(200, 300), allele_range=(10, 20))
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    sample = synth.makeSample(sidx, seed=77, n_pairs=3000, err_rate=0.01)
+    lines = synth.toSamLines(sample)
+    header = ["@HD\tVN:1.0\tSO:coordinate"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+    by_coord = sorted(lines, key=lambda l: (l.split("\t")[2], int(l.split("\t")[3])))
+    path = str(tmp_path / "s.bam")
+    samToBam(header + by_coord, path)
+
+    counts, pos0 = pileup.pileupCounts(path, gidx)
+    table = pileup.correctionTable(counts)
+    assert table.any()
+    dindex = DeviceIndex(device, gidx)
+    results = {}
+    from kir_graph_amd.msa2hisat import Variant
+    for name, corr in (("off", None), ("on", (table, pos0))):
+        Variant.novel_id = 0
+        data = extractVariantFromText(path, gidx, dev=device, dindex=dindex, correction=corr)
+        results[name] = (device_lists(data.tab), data.tab.novelVariants(data.ins_strings))
+        data.tab.close()
+    from kir_graph_amd.hisat2 import readBam
+    collated = list(readBam(path))
+    for name, pile in (("off", None), ("on", opile.pileupOfLines(by_coord))):
+        ref = ot.tabulateLines(collated, gidx.variants, pileup=pile)
+        got, nov = results[name]
+        assert len(got) == len(ref["reads"])
+        for i, (g, r) in enumerate(zip(got, ref["reads"])):
+            for k in ("lpv", "rpv", "lnv", "rnv"):
+                assert g[k] == r[k], (name, i, k)
+        ref_nov = [v for v in ref["variants"] if str(v.id).startswith("nv")]
+        assert [(v.id, v.pos, v.typ, v.ref, v.val, v.length) for v in nov] == \
+               [(v.id, v.pos, v.typ, v.ref, v.val, v.length) for v in ref_nov]
+    # the correction did something: distinct read errors at one site collapse onto the majority base
+    assert len(results["on"][1]) < len(results["off"][1])
+    assert results["on"][0] != results["off"][0]
+    dindex.close()
+    # the reference's entry point with its default error_correction=True writes the corrected lists
+    import json
+    from kir_graph_amd.hisat2 import extractVariantFromBam
+    prefix = str(tmp_path / "idx")
+    sidx.write(prefix)
+    Variant.novel_id = 0
+    extractVariantFromBam(prefix, path, str(tmp_path / "out"), error_correction=True, dev=device).tab.close()
+    with open(tmp_path / "out.json") as f:
+        saved = json.load(f)
+    assert [{k: r[k] for k in ("lpv", "rpv", "lnv", "rnv")} for r in saved["reads"]] == results["on"][0]

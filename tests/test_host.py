@@ -344,3 +344,72 @@ def test_native_bam_writer_matches_the_test_encoder_and_round_trips(tmp_path):
     assert b"".join(packed.bamChunks(path2, name_sorted=False)).decode().split("\n")[:-1] == want
     with pytest.raises(_lib.GkError):
         packed.writeBam(str(tmp_path / "c.bam"), "@HD\tVN:1.0\nbroken line\n")
+
+
+def _pileup_case(tmp_path, seed=9, n_pairs=1500):
+    """A coordinate-sorted BAM with varied base qualities, flags of every skipped kind and overlapping mates."""
+    from bamwriter import samToBam
+    sidx = synth.makeIndex(seed=5, n_genes=3, var_range=(200, 300), allele_range=(10, 20))
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    sample = synth.makeSample(sidx, seed=seed, n_pairs=n_pairs)
+    records = synth.toSamLines(sample)
+    rng = np.random.default_rng(3)
+    for k in range(len(records)):
+        f = records[k].split("\t")
+        q = rng.integers(2, 41, size=len(f[9]))
+        q[rng.random(len(q)) < 0.05] = 5                         # below mpileup's default --min-BQ
+        f[10] = "".join(chr(33 + x) for x in q)
+        pair = k // 2
+        if pair % 97 == 0:
+            f[1] = str(int(f[1]) | 256)                          # secondary: skipped
+        elif pair % 89 == 0:
+            f[1] = str(int(f[1]) | 1024)                         # duplicate: skipped
+        elif pair % 83 == 0:
+            f[1] = str(int(f[1]) & ~2)                           # not a proper pair: skipped
+        elif pair % 7 == 0 and k % 2 == 1:                       # move the second mate onto the first one
+            left = records[k - 1].split("\t")
+            f[3] = str(int(left[3]) + int(rng.integers(0, 60)))
+        records[k] = "\t".join(f)
+    g0 = sidx.genes[0]
+    hand = [   # equal and unequal overlapping bases, a deletion over a base, quality ties
+        f"h1\t99\t{g0}\t101\t60\t6M\t=\t103\t8\tACGTAC\t" + "".join(chr(33 + q) for q in (30, 9, 9, 20, 20, 12)),
+        f"h1\t147\t{g0}\t103\t60\t2M2D4M\t=\t101\t-8\tGAACTT\t" + "".join(chr(33 + q) for q in (30, 8, 20, 20, 20, 40)),
+        f"h2\t99\t{g0}\t101\t60\t4M\t=\t101\t4\tAAAA\t" + "".join(chr(33 + q) for q in (20, 20, 10, 30)),
+        f"h2\t147\t{g0}\t101\t60\t4M\t=\t101\t-4\tACAC\t" + "".join(chr(33 + q) for q in (20, 20, 10, 31)),
+        f"h3\t0\t{g0}\t100\t60\t3M\t*\t0\t0\tNNA\t*",
+    ]
+    records += hand
+    header = ["@HD\tVN:1.0\tSO:coordinate"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+    by_coord = sorted(records, key=lambda l: (l.split("\t")[2], int(l.split("\t")[3])))
+    path = str(tmp_path / "p.bam")
+    samToBam(header + by_coord, path, block=30000)
+    return sidx, gidx, by_coord, path
+
+
+def test_native_pileup_matches_the_restatement(tmp_path):
+    """gk_bam_pileup + pileup.ratiosOf vs oracle/pileup.py on the same alignments (pileup.py:57-81)."""
+    from kir_graph_amd import pileup
+    from oracle import pileup as opile, tabulate as ot
+    from kir_graph_amd.msa2hisat import Variant
+    sidx, gidx, lines, path = _pileup_case(tmp_path)
+    counts, pos0 = pileup.pileupCounts(path, gidx)
+    got = pileup.ratiosOf(counts, pos0, gidx.genes)
+    want = opile.pileupOfLines(lines)
+    assert got.keys() == want.keys()
+    for key in want:
+        assert got[key] == want[key], key            # same integer counts -> the same float64 quotients
+    g0 = sidx.genes[0]
+    assert want[(g0, 99)]["all"] >= 1 and "N" in want[(g0, 99)]
+    # the device table = hisat2.errorCorrection on every (position, read base)
+    table = pileup.correctionTable(counts)
+    assert table.shape == (int(pos0[-1]), 5)
+    changed = 0
+    for (ref, pos), p in want.items():
+        at = int(pos0[gidx.gene_id[ref]]) + pos
+        for j, b in enumerate("ACGTN"):
+            v = ot.pileupCorrect(Variant(typ="single", ref=ref, pos=pos, val=b), want)
+            expect = 0 if v.val == b else ord(v.val)
+            assert table[at, j] == expect, (ref, pos, b, p)
+            changed += expect != 0
+    assert changed > 100
+    assert not table[counts.sum(axis=1) == 0].any()
