@@ -123,9 +123,59 @@ __global__ __launch_bounds__(kThreads) void flag_nonempty(const int32_t* rows, i
 }
 
 constexpr int kMaxSlots = 4;   // alleles per lane and pass: up to 256 alleles per pass
-constexpr int kWavesPerBlock = 4;
-constexpr int kTileRows = 16;            // rows per output tile (4 per wave)
+constexpr int kCompatWaves = 8;          // 8 waves share one 16-row tile: 32 waves per CU at 34 KB of LDS per block
+constexpr int kCompatThreads = 64 * kCompatWaves;
+constexpr int kTileRows = 16;            // rows per output tile (2 per wave)
 constexpr int kTileLd = kTileRows + 1;   // padded LDS stride (doubles) of the transposed tile
+
+// bit matrix [variant][words] -> [word][variant]: in the compatibility kernel lane k reads word w of the
+// k-th variant of a window, and windows are runs of consecutive ordinals, so the word-major copy turns
+// 64 strided row reads into one coalesced 256-byte read per word
+__global__ __launch_bounds__(kThreads) void transpose_mask(const uint32_t* mask, int n_span, int words, uint32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= (int64_t)n_span * words) return;
+  const int w = (int)(i / n_span), v = (int)(i % n_span);
+  out[i] = mask[(int64_t)v * words + w];
+}
+
+// p[s] *= (lane's bit of m[s]) ? f_set : f_clear for the kSlots slots of a lane, as two multiplies per slot
+// under complementary EXEC masks: the uniform 64-bit word IS the lane mask, so no per-lane select is
+// needed (2 VALU ops per slot instead of 2 x v_cndmask + v_mul) and EXEC is restored once at the end.
+// Every lane of the wave is active here (the factor loop is wave-uniform).
+#define GK_MUL_SLOT(P, M)           \
+  "s_mov_b64 exec, " M "\n\t"       \
+  "v_mul_f64 " P ", " P ", %[fs]\n\t" \
+  "s_not_b64 exec, exec\n\t"       \
+  "v_mul_f64 " P ", " P ", %[fc]\n\t"
+template <int kSlots>
+__device__ __forceinline__ void mul_by_bits(double (&p)[kSlots], const uint64_t (&m)[kSlots], double f_set, double f_clear) {
+  if constexpr (kSlots == 1) {
+    asm volatile(GK_MUL_SLOT("%[p0]", "%[m0]") "s_mov_b64 exec, -1"
+                 : [p0] "+v"(p[0]) : [m0] "s"(m[0]), [fs] "s"(f_set), [fc] "s"(f_clear) : "scc");
+  } else if constexpr (kSlots == 2) {
+    asm volatile(GK_MUL_SLOT("%[p0]", "%[m0]") GK_MUL_SLOT("%[p1]", "%[m1]") "s_mov_b64 exec, -1"
+                 : [p0] "+v"(p[0]), [p1] "+v"(p[1])
+                 : [m0] "s"(m[0]), [m1] "s"(m[1]), [fs] "s"(f_set), [fc] "s"(f_clear) : "scc");
+  } else if constexpr (kSlots == 3) {
+    asm volatile(GK_MUL_SLOT("%[p0]", "%[m0]") GK_MUL_SLOT("%[p1]", "%[m1]") GK_MUL_SLOT("%[p2]", "%[m2]") "s_mov_b64 exec, -1"
+                 : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2])
+                 : [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [fs] "s"(f_set), [fc] "s"(f_clear) : "scc");
+  } else {
+    static_assert(kSlots == 4, "1 to 4 slots");
+    asm volatile(GK_MUL_SLOT("%[p0]", "%[m0]") GK_MUL_SLOT("%[p1]", "%[m1]") GK_MUL_SLOT("%[p2]", "%[m2]")
+                 GK_MUL_SLOT("%[p3]", "%[m3]") "s_mov_b64 exec, -1"
+                 : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3])
+                 : [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[3]), [fs] "s"(f_set), [fc] "s"(f_clear)
+                 : "scc");
+  }
+}
+#undef GK_MUL_SLOT
+
+// clear bit `t` of a wave-uniform bit set (one s_bitset0_b64 instead of the add / addc / and of x &= x - 1)
+__device__ __forceinline__ uint64_t clear_bit(uint64_t set, int t) {
+  asm("s_bitset0_b64 %0, %1" : "+s"(set) : "s"(t));
+  return set;
+}
 
 // One wavefront per read pair, lanes = alleles (kSlots allele slots per lane; a gene of <= 256
 // alleles is one pass, and the last pass of a wider gene only carries the slots it needs).  Per chunk
@@ -141,11 +191,12 @@ constexpr int kTileLd = kTileRows + 1;   // padded LDS stride (doubles) of the t
 // evaluated yet is inserted into the table and stored as NaN; the host sees the table grow, evaluates
 // numpy.log10 for the new values and runs the kernel once more.
 template <bool kLog, int kSlots, bool kMiss>
-__global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, int64_t n_rows, const uint32_t* off,
-                                                          const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
-                                                          const uint32_t* mask, int words, int n_allele, int a_base,
-                                                          double* probs, uint8_t* miss_out, uint16_t* nvar_out,
-                                                          LutView lut) {
+__global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* rows, int64_t n_rows, const uint32_t* off,
+                                                                const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
+                                                                const uint32_t* mask_t, int words, int n_allele, int a_base,
+                                                                double* probs, uint8_t* miss_out, uint16_t* nvar_out,
+                                                                LutView lut) {
+  const int n_span = vend - vbeg;   // mask_t: [words][n_span], see transpose_mask
   constexpr int kPassAlleles = 64 * kSlots;
   constexpr int kPassWords = 2 * kSlots;   // bit-row words covering one pass
   __shared__ double tile[kPassAlleles * kTileLd];
@@ -164,8 +215,8 @@ __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, i
   const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   for (int64_t tile_i = blockIdx.x; tile_i < n_tiles; tile_i += gridDim.x) {
     const int64_t row0 = tile_i * kTileRows;
-    for (int q = 0; q < kTileRows / kWavesPerBlock; ++q) {
-      const int rt = wid * (kTileRows / kWavesPerBlock) + q;   // row inside the tile
+    for (int q = 0; q < kTileRows / kCompatWaves; ++q) {
+      const int rt = wid * (kTileRows / kCompatWaves) + q;   // row inside the tile
       const int64_t i = row0 + rt;
       if (i >= n_rows) break;                                   // wave-uniform
       const int64_t row = rows[i];
@@ -179,48 +230,54 @@ __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, i
       for (int s = 0; s < kSlots; ++s) { p[s] = 1.0; miss[s] = 0; }
       for (uint32_t base = b; base < e; base += 64) {
         const uint32_t k = base + lane;
-        uint32_t my_keep = 0;
+        bool my_keep = false;
         uint32_t mrow[kPassWords];
 #pragma unroll
         for (int w = 0; w < kPassWords; ++w) mrow[w] = 0;
         if (k < e) {
           const uint32_t v = ids[k];
-          my_keep = (vflag[v] & (k < mid ? 1 : 2)) ? 0u : 1u;
           const int local = (int)v - vbeg;
-          if (my_keep && (int)v < vend && local >= 0) {   // novel variants carry no allele: all-zero row
-            const uint32_t* src = mask + (int64_t)local * words + w_base;
+          if ((int)v < vend && local >= 0) {   // novel variants carry no allele: all-zero row
+            const uint32_t* src = mask_t + (int64_t)w_base * n_span + local;
 #pragma unroll
             for (int w = 0; w < kPassWords; ++w)
-              if (w_base + w < words) mrow[w] = src[w];
+              if (w_base + w < words) mrow[w] = src[(int64_t)w * n_span];
           }
+          my_keep = !(vflag[v] & (k < mid ? 1 : 2));
         }
-        const int cnt = (int)min(64u, e - base);
-        for (int t = 0; t < cnt; ++t) {
-          if (!__builtin_amdgcn_readlane(my_keep, t)) continue;   // wave-uniform
-          const bool positive = base + t < mid;   // wave-uniform: two straight-line bodies
-          // The two bit-row words of a slot, read back from lane t, ARE the slot's 64 per-lane
-          // "allele has the variant" bits: as an SGPR pair they condition v_cndmask directly
-          // (no per-lane bit test).
-          if (positive) {
+        // kept variants of the chunk as scalar bit sets, walked in order: the positive ones (ordinals
+        // below `mid`) come first, then the negative ones, whose factors are swapped
+        const uint64_t kept = __ballot(my_keep);
+        nvar += (uint32_t)__builtin_popcountll(kept);
+        const uint32_t n_pos = mid > base ? min(mid - base, 64u) : 0u;
+        const uint64_t pos_lanes = n_pos >= 64 ? ~0ull : ((1ull << n_pos) - 1ull);
+        // The two bit-row words of a slot, read back from lane t, ARE the slot's 64 per-lane
+        // "allele has the variant" bits.
+        for (uint64_t todo = kept & pos_lanes; todo;) {
+          const int t = __builtin_ctzll(todo);
+          todo = clear_bit(todo, t);
+          uint64_t has[kSlots];
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) {
-              const uint32_t lo = __builtin_amdgcn_readlane(mrow[2 * s], t);
-              const uint32_t hi = __builtin_amdgcn_readlane(mrow[2 * s + 1], t);
-              const bool has = __builtin_amdgcn_inverse_ballot_w64(((uint64_t)hi << 32) | lo);
-              p[s] *= has ? 0.999 : 0.001;   // 1.0 * f == f: same bits as numpy's multiply.reduce
-              if (kMiss) miss[s] += has ? 0u : 1u;
-            }
-          } else {
-#pragma unroll
-            for (int s = 0; s < kSlots; ++s) {
-              const uint32_t lo = __builtin_amdgcn_readlane(mrow[2 * s], t);
-              const uint32_t hi = __builtin_amdgcn_readlane(mrow[2 * s + 1], t);
-              const bool has = __builtin_amdgcn_inverse_ballot_w64(((uint64_t)hi << 32) | lo);
-              p[s] *= has ? 0.001 : 0.999;
-              if (kMiss) miss[s] += has ? 1u : 0u;
-            }
+          for (int s = 0; s < kSlots; ++s) {
+            const uint32_t lo = __builtin_amdgcn_readlane(mrow[2 * s], t);
+            const uint32_t hi = __builtin_amdgcn_readlane(mrow[2 * s + 1], t);
+            has[s] = (((uint64_t)hi) << 32) | lo;
+            if (kMiss) miss[s] += __builtin_amdgcn_inverse_ballot_w64(has[s]) ? 0u : 1u;
           }
-          ++nvar;
+          mul_by_bits<kSlots>(p, has, 0.999, 0.001);   // 1.0 * f == f: same bits as numpy's multiply.reduce
+        }
+        for (uint64_t todo = kept & ~pos_lanes; todo;) {
+          const int t = __builtin_ctzll(todo);
+          todo = clear_bit(todo, t);
+          uint64_t has[kSlots];
+#pragma unroll
+          for (int s = 0; s < kSlots; ++s) {
+            const uint32_t lo = __builtin_amdgcn_readlane(mrow[2 * s], t);
+            const uint32_t hi = __builtin_amdgcn_readlane(mrow[2 * s + 1], t);
+            has[s] = (((uint64_t)hi) << 32) | lo;
+            if (kMiss) miss[s] += __builtin_amdgcn_inverse_ballot_w64(has[s]) ? 1u : 0u;
+          }
+          mul_by_bits<kSlots>(p, has, 0.001, 0.999);
         }
       }
 #pragma unroll
@@ -235,21 +292,28 @@ __global__ __launch_bounds__(kThreads) void compat_kernel(const int32_t* rows, i
     __syncthreads();
     if (probs) {
       const int n_r = (int)min<int64_t>(kTileRows, n_rows - row0);
-      uint64_t last_key = kLutEmptyKey;
-      double last_val = 0.0;
-      for (int idx = tid; idx < n_pass * kTileRows; idx += kThreads) {
+      uint64_t key0 = kLutEmptyKey, key1 = kLutEmptyKey;   // the two most recent values of this thread's read
+      double val0 = 0.0, val1 = 0.0;
+      for (int idx = tid; idx < n_pass * kTileRows; idx += kCompatThreads) {
         const int al = idx / kTileRows, r = idx % kTileRows;
         if (r >= n_r) continue;
         double v = tile[al * kTileLd + r];
         if (kLog) {
+          // one read's alleles share a handful of values: most lookups end in these two registers
           const uint64_t key = (uint64_t)__double_as_longlong(v);
-          if (key != last_key) {   // one read's alleles mostly share a handful of values
-            bool found;
-            last_val = gk_lut_lookup(lut, key, &found);
-            if (!found) gk_lut_insert(lut, key);
-            last_key = key;
+          if (key != key0) {
+            double val;
+            if (key == key1) {
+              val = val1;
+            } else {
+              bool found;
+              val = gk_lut_lookup(lut, key, &found);
+              if (!found) gk_lut_insert(lut, key);
+            }
+            key1 = key0; val1 = val0;
+            key0 = key; val0 = val;
           }
-          v = last_val;
+          v = val0;
         }
         probs[(int64_t)(a_base + al) * n_rows + row0 + r] = v;
       }
@@ -262,13 +326,19 @@ template <bool kLog>
 int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int vbeg, int vend,
                   gk_dptr d_mask, int words, int n_allele, double* out, uint8_t* miss, uint16_t* nvar, LutView view) {
   int64_t want = (n_rows + kTileRows - 1) / kTileRows;
-  const dim3 grid((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048)), block(kThreads);
+  const dim3 grid((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048)), block(kCompatThreads);
+  const int64_t n_mask = (int64_t)(vend - vbeg) * words;
+  uint32_t* mask_t = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&mask_t, (size_t)std::max<int64_t>(n_mask, 1) * sizeof(uint32_t)));
+  if (n_mask > 0)
+    GK_KERNEL(transpose_mask, dim3((unsigned)((n_mask + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
+              gk_ptr<uint32_t>(d_mask), vend - vbeg, words, mask_t);
   for (int a_base = 0; a_base < n_allele; a_base += 64 * kMaxSlots) {
     const int slots = std::min(kMaxSlots, (n_allele - a_base + 63) / 64);
 #define GK_COMPAT_LAUNCH(S)                                                                                        \
   GK_PROF(ctx, GK_K_COMPAT,                                                                                        \
           GK_KERNEL((compat_kernel<kLog, S, !kLog>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows, \
-                             tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, gk_ptr<uint32_t>(d_mask),  \
+                             tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, mask_t,  \
                              words, n_allele, a_base, out, miss, nvar, view))
     switch (slots) {
       case 1: GK_COMPAT_LAUNCH(1); break;
@@ -278,6 +348,7 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
     }
 #undef GK_COMPAT_LAUNCH
   }
+  gk_pool_free(ctx, mask_t);   // stream-ordered reuse: the next user of the block runs after these launches
   GK_HIP(hipGetLastError());
   return GK_OK;
 }

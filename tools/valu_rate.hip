@@ -1,0 +1,78 @@
+// Dev tool: issue rate of a few VALU instructions on gfx950 (cycles per wave64 instruction per SIMD).
+//   hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o tools/valu_rate.bin && tools/valu_rate.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+constexpr int kIter = 4096;
+
+#define BODY8(OP) OP(a0) OP(a1) OP(a2) OP(a3) OP(a4) OP(a5) OP(a6) OP(a7)
+
+template <int kKind>
+__global__ __launch_bounds__(256) void rate(double* out, double c, uint32_t sel) {
+  double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  uint32_t r = threadIdx.x, acc = 0;
+  for (int i = 0; i < kIter; ++i) {
+    if (kKind == 0) {
+#define OP(x) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x) : "s"(c));
+      BODY8(OP)
+#undef OP
+    } else if (kKind == 1) {
+#define OP(x) asm volatile("v_add_f64 %0, %0, %1" : "+v"(x) : "s"(c));
+      BODY8(OP)
+#undef OP
+    } else if (kKind == 2) {
+#define OP(x) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(x) : "s"(c));
+      BODY8(OP)
+#undef OP
+    } else if (kKind == 3) {
+#define OP(x) { uint32_t s; asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(s) : "v"(r)); acc += s; }
+      BODY8(OP)
+#undef OP
+    } else if (kKind == 4) {
+#define OP(x) asm volatile("v_max_f64 %0, %0, %1" : "+v"(x) : "s"(c));
+      BODY8(OP)
+#undef OP
+    } else if (kKind == 5) {   // the masked pair of the compatibility kernel
+#define OP(x) asm volatile("s_mov_b64 exec, %1\n v_mul_f64 %0, %0, %2\n s_not_b64 exec, exec\n v_mul_f64 %0, %0, %2\n s_mov_b64 exec, -1" : "+v"(x) : "s"((uint64_t)sel * 0x100000001ull), "s"(c) : "scc");
+      BODY8(OP)
+#undef OP
+    } else if (kKind == 6) {
+#define OP(x) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r) : "s"(sel));
+      BODY8(OP)
+#undef OP
+    }
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + acc + r;
+}
+
+template <int kKind>
+void run(const char* name, int ops_per_body) {
+  double* out;
+  hipMalloc(&out, 256 * 4 * 8 * 256 * sizeof(double));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int blocks = 256 * 8;   // 8 blocks of 4 waves per CU: 8 waves per SIMD
+  rate<kKind><<<blocks, 256>>>(out, 1.0000001, 0x0F0F0F0F);
+  hipEventRecord(e0);
+  rate<kKind><<<blocks, 256>>>(out, 1.0000001, 0x0F0F0F0F);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  // per SIMD: 8 waves x kIter x ops instructions
+  const double instr_per_simd = 8.0 * kIter * ops_per_body;
+  printf("%-28s %8.3f ms  %6.2f cycles per wave instruction (at 2.4 GHz)\n", name, ms, ms * 1e-3 * 2.4e9 / instr_per_simd);
+  hipFree(out);
+}
+
+int main() {
+  run<0>("v_mul_f64", 8);
+  run<1>("v_add_f64", 8);
+  run<2>("v_fma_f64", 8);
+  run<4>("v_max_f64", 8);
+  run<3>("v_readlane_b32", 8);
+  run<6>("v_mul_f32", 8);
+  run<5>("masked v_mul_f64 pair", 16);
+  return 0;
+}
