@@ -326,6 +326,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
   if (!path || !out) { gk_set_error("null argument"); return GK_ERR_ARG; }
   FILE* f = fopen(path, "rb");
   if (!f) { gk_set_error("cannot open %s", path); return GK_ERR_ARG; }
+  GkPhaseClock clock("bam_open");
   std::vector<uint8_t> raw;
   {
     std::vector<uint8_t> buf(1 << 22);
@@ -333,6 +334,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
     while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) raw.insert(raw.end(), buf.data(), buf.data() + n);
     fclose(f);
   }
+  clock.lap("read");
   gk_bam* b = new gk_bam();
   if (!inflate_bgzf_parallel(raw, b->data, ingest_threads()) && !inflate_members(raw, b->data)) {
     delete b;
@@ -340,6 +342,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
     return GK_ERR_ARG;
   }
   raw.clear(); raw.shrink_to_fit();
+  clock.lap("inflate");
   const std::vector<uint8_t>& d = b->data;
   auto bad = [&](const char* what) {
     gk_set_error("%s: malformed BAM (%s)", path, what);
@@ -369,6 +372,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
   }
   if (o != d.size()) return bad("trailing bytes");
   b->name_sorted = name_sorted != 0;
+  clock.lap("index");
   if (name_sorted) {
     const uint8_t* base = d.data();
     auto before = [base](const gk_bam::Rec& x, const gk_bam::Rec& y) {
@@ -377,7 +381,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
       if (t) return t < 0;
       return (rd16(px + 14) & 0xC0u) < (rd16(py + 14) & 0xC0u);   // READ1 (0x40) before READ2 (0x80)
     };
-    // stable merge sort over the ingest threads: sorted runs, then pairwise stable merges
+    // stable merge sort over the ingest threads: sorted runs, then one parallel multiway merge
     auto& recs = b->recs;
     const size_t n = recs.size();
     int runs = 1;
@@ -389,16 +393,52 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
         pool.emplace_back([&, i] { std::stable_sort(recs.begin() + bound(i), recs.begin() + bound(i + 1), before); });
       for (auto& th : pool) th.join();
     }
-    for (int width = 1; width < runs; width *= 2) {
+    if (runs > 1) {
+      // Parallel stable multiway merge.  Splitters cut every run at lower_bound, so records equivalent to
+      // a splitter land in the same part whatever run they come from; inside a part the runs are merged
+      // in run order with std::merge (left range first on ties): the concatenated parts are the stable order.
+      std::vector<gk_bam::Rec> sample;
+      for (int r = 0; r < runs; ++r)
+        for (int k = 1; k < runs; ++k) sample.push_back(recs[bound(r) + (bound(r + 1) - bound(r)) * (size_t)k / (size_t)runs]);
+      std::sort(sample.begin(), sample.end(), before);
+      std::vector<std::vector<size_t>> cut((size_t)runs, std::vector<size_t>((size_t)runs + 1));
+      for (int r = 0; r < runs; ++r) {
+        cut[(size_t)r][0] = bound(r);
+        cut[(size_t)r][(size_t)runs] = bound(r + 1);
+        for (int k = 1; k < runs; ++k)
+          cut[(size_t)r][(size_t)k] = (size_t)(std::lower_bound(recs.begin() + bound(r), recs.begin() + bound(r + 1),
+                                                                sample[(size_t)k * sample.size() / (size_t)runs], before) - recs.begin());
+      }
+      std::vector<gk_bam::Rec> merged(n);
+      std::vector<size_t> part_off((size_t)runs + 1, 0);
+      for (int k = 0; k < runs; ++k) {
+        size_t len = 0;
+        for (int r = 0; r < runs; ++r) len += cut[(size_t)r][(size_t)k + 1] - cut[(size_t)r][(size_t)k];
+        part_off[(size_t)k + 1] = part_off[(size_t)k] + len;
+      }
       std::vector<std::thread> pool;
-      for (int i = 0; i + width < runs; i += 2 * width)
-        pool.emplace_back([&, i, width] {
-          std::inplace_merge(recs.begin() + bound(i), recs.begin() + bound(i + width),
-                             recs.begin() + bound(std::min(i + 2 * width, runs)), before);
+      for (int k = 0; k < runs; ++k)
+        pool.emplace_back([&, k] {
+          std::vector<std::vector<gk_bam::Rec>> level;
+          for (int r = 0; r < runs; ++r)
+            level.emplace_back(recs.begin() + cut[(size_t)r][(size_t)k], recs.begin() + cut[(size_t)r][(size_t)k + 1]);
+          while (level.size() > 1) {
+            std::vector<std::vector<gk_bam::Rec>> next;
+            for (size_t i = 0; i < level.size(); i += 2) {
+              if (i + 1 == level.size()) { next.push_back(std::move(level[i])); break; }
+              std::vector<gk_bam::Rec> both(level[i].size() + level[i + 1].size());
+              std::merge(level[i].begin(), level[i].end(), level[i + 1].begin(), level[i + 1].end(), both.begin(), before);
+              next.push_back(std::move(both));
+            }
+            level = std::move(next);
+          }
+          std::copy(level[0].begin(), level[0].end(), merged.begin() + part_off[(size_t)k]);
         });
       for (auto& th : pool) th.join();
+      recs.swap(merged);
     }
   }
+  clock.lap("name sort");
   *out = b;
   return GK_OK;
 }

@@ -6,7 +6,25 @@
 #include <string>
 #include <string_view>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 struct gk_packer;
+
+// GK_INGEST_TIMING=1: phase times of the host ingest on stderr (development aid)
+struct GkPhaseClock {
+  const char* what;
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  explicit GkPhaseClock(const char* w) : what(w), on(getenv("GK_INGEST_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* phase) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[ingest] %s %s %.1f ms\n", what, phase, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
 
 struct GkAlnKey {            // fields of readPair's pairing rule (hisat2.py:248-258)
   std::string_view name, ref;

@@ -357,58 +357,87 @@ int pack_threads() {
 }
 
 // step (3): in emission order, intern the inserted strings, stop at the first failed pair
-bool merge_decoded(gk_packer* pk, std::vector<Decoded>& dec, const std::vector<int64_t>& lines) {
-  for (size_t i = 0; i < dec.size(); ++i) {
-    Decoded& d = dec[i];
-    for (int s = 0; s < 2; ++s) {
-      for (size_t q = 0; q < d.ins[s].size(); ++q) {
-        auto it = pk->ins_id.find(d.ins[s][q]);
-        uint32_t id;
-        if (it == pk->ins_id.end()) {
-          id = (uint32_t)pk->ins_strings.size();
-          pk->ins_id.emplace(d.ins[s][q], id);
-          pk->ins_strings.push_back(d.ins[s][q]);
-        } else {
-          id = it->second;
-        }
-        if (d.store_ins[s] && q < GK_MAX_INS) d.rec[s].ins[q] = id;
-      }
-    }
-    if (d.fail.kind) return fail(pk, d.fail, d.fail_line);
-    pk->mates.push_back(d.rec[0]);
-    pk->mates.push_back(d.rec[1]);
-    pk->pair_lines.push_back(lines[2 * i]);
-    pk->pair_lines.push_back(lines[2 * i + 1]);
-  }
-  return true;
-}
-
 template <typename Work>
 void on_threads(size_t n, const Work& work) {
   const int n_thr = (int)std::min<size_t>((size_t)pack_threads(), (n + 255) / 256);
   if (n_thr <= 1) {
-    work(0, n);
+    work(0, 0, n);
     return;
   }
   std::vector<std::thread> pool;
-  for (int t = 0; t < n_thr; ++t) pool.emplace_back(work, n * t / n_thr, n * (t + 1) / n_thr);
+  for (int t = 0; t < n_thr; ++t) pool.emplace_back(work, t, n * t / n_thr, n * (t + 1) / n_thr);
   for (auto& th : pool) th.join();
 }
 
-// steps (2) and (3) for the pairs queued by the pairing pass
-bool run_jobs(gk_packer* pk) {
-  const size_t n = pk->jobs.size();
+// Steps (2) and (3) for n emitted pairs: decode(i, out) fills the records of pair i; lines(i, s) is the
+// stream index of its left (s = 0) / right (s = 1) record.  The records are written straight into their
+// final place by the decoding threads.  What depends on the order of the pairs -- ids of inserted
+// strings (first seen, first numbered) and "stop at the first failing pair" -- is settled afterwards
+// in one pass over the few pairs that met an inserted string or failed.
+struct Special {
+  size_t pair;
+  Decoded d;
+};
+
+template <typename DecodeOne, typename LineOf>
+bool decode_all(gk_packer* pk, size_t n, const DecodeOne& decode, const LineOf& line_of) {
   if (!n) return true;
-  std::vector<Decoded> dec(n);
-  on_threads(n, [&](size_t a, size_t b) {
+  const size_t first = pk->mates.size() / 2;
+  pk->mates.resize(2 * (first + n));
+  pk->pair_lines.resize(2 * (first + n));
+  std::vector<std::vector<Special>> special((size_t)pack_threads() + 1);
+  on_threads(n, [&](int t, size_t a, size_t b) {
+    Decoded d;
     for (size_t i = a; i < b; ++i) {
-      const gk_packer::Job& j = pk->jobs[i];
-      decode_pair(pk, j.left, j.left_idx, j.right_owned.empty() ? j.right : sv(j.right_owned), j.right_idx, dec[i]);
+      d.ins[0].clear(); d.ins[1].clear();
+      d.store_ins[0] = d.store_ins[1] = false;
+      d.fail = Fail{0, ""};
+      d.fail_line = -1;
+      decode(i, d);
+      gk_mate* dst = pk->mates.data() + 2 * (first + i);
+      dst[0] = d.rec[0];
+      dst[1] = d.rec[1];
+      pk->pair_lines[2 * (first + i)] = line_of(i, 0);
+      pk->pair_lines[2 * (first + i) + 1] = line_of(i, 1);
+      if (d.fail.kind || !d.ins[0].empty() || !d.ins[1].empty()) special[(size_t)t].push_back(Special{i, d});
     }
   });
-  std::vector<int64_t> lines(2 * n);
-  for (size_t i = 0; i < n; ++i) { lines[2 * i] = pk->jobs[i].left_idx; lines[2 * i + 1] = pk->jobs[i].right_idx; }
-  const bool ok = merge_decoded(pk, dec, lines);
+  for (auto& list : special) {   // threads own ascending ranges: this walks the pairs in order
+    for (Special& sp : list) {
+      gk_mate* dst = pk->mates.data() + 2 * (first + sp.pair);
+      for (int s = 0; s < 2; ++s) {
+        for (size_t q = 0; q < sp.d.ins[s].size(); ++q) {
+          auto it = pk->ins_id.find(sp.d.ins[s][q]);
+          uint32_t id;
+          if (it == pk->ins_id.end()) {
+            id = (uint32_t)pk->ins_strings.size();
+            pk->ins_id.emplace(sp.d.ins[s][q], id);
+            pk->ins_strings.push_back(sp.d.ins[s][q]);
+          } else {
+            id = it->second;
+          }
+          if (sp.d.store_ins[s] && q < GK_MAX_INS) dst[s].ins[q] = id;
+        }
+      }
+      if (sp.d.fail.kind) {   // the pairs before it stay, like a one-by-one walk
+        pk->mates.resize(2 * (first + sp.pair));
+        pk->pair_lines.resize(2 * (first + sp.pair));
+        return fail(pk, sp.d.fail, sp.d.fail_line);
+      }
+    }
+  }
+  return true;
+}
+
+// the pairs queued by the pairing pass of the text reader
+bool run_jobs(gk_packer* pk) {
+  const bool ok = decode_all(
+      pk, pk->jobs.size(),
+      [&](size_t i, Decoded& out) {
+        const gk_packer::Job& j = pk->jobs[i];
+        decode_pair(pk, j.left, j.left_idx, j.right_owned.empty() ? j.right : sv(j.right_owned), j.right_idx, out);
+      },
+      [&](size_t i, int s) { return s ? pk->jobs[i].right_idx : pk->jobs[i].left_idx; });
   pk->jobs.clear();
   return ok;
 }
@@ -467,6 +496,7 @@ int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
   if (!pk->waiting.empty() || !pk->carry.empty()) { gk_set_error("text and record input cannot be mixed"); return GK_ERR_ARG; }
   const int64_t base = pk->n_lines;
   pk->n_lines += n;
+  GkPhaseClock clock("feed_records");
   // (1) pairing in stream order (hisat2.py:248-270).  Only records with the same name can pair, so
   // when equal names are contiguous (a name-collated stream) the stream is cut at name changes and
   // the pieces are paired independently; their emission lists, concatenated, are the sequential one.
@@ -475,25 +505,56 @@ int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
   auto pair_range = [&](int64_t a, int64_t b, Piece& out) {
     std::unordered_map<std::string, Wait> waiting;
     std::string kbuf;
-    for (int64_t i = a; i < b; ++i) {
-      GkAlnKey k;
-      key(i, k);
-      if (!k.mate_same_ref) continue;
+    GkAlnKey k;
+    auto make = [&](long pos) -> std::string& {
+      kbuf.assign(k.name); kbuf.push_back('\t'); kbuf.append(k.ref); kbuf.push_back('\t');
+      kbuf.append(std::to_string(pos)); kbuf.push_back('\t'); kbuf.push_back((k.flag & 256) ? '1' : '0');
+      return kbuf;
+    };
+    auto general = [&](int64_t i) {   // k holds record i
+      if (!k.mate_same_ref) return;
       out.n_reads += 1;
-      auto make = [&](long pos) -> std::string& {
-        kbuf.assign(k.name); kbuf.push_back('\t'); kbuf.append(k.ref); kbuf.push_back('\t');
-        kbuf.append(std::to_string(pos)); kbuf.push_back('\t'); kbuf.push_back((k.flag & 256) ? '1' : '0');
-        return kbuf;
-      };
       auto it = waiting.find(make(k.next_pos));
       if (it == waiting.end()) {
         waiting[make(k.pos)] = Wait{i, k.flag};
-        continue;
+        return;
       }
-      if (((it->second.flag | k.flag) & 192) != 192) { out.n_strange += 1; continue; }
+      if (((it->second.flag | k.flag) & 192) != 192) { out.n_strange += 1; return; }
       out.pairs.push_back(i);                    // left = the later record
       out.pairs.push_back(it->second.index);     // right = the earlier one
       waiting.erase(it);
+    };
+    if (!names_contiguous) {
+      for (int64_t i = a; i < b; ++i) { key(i, k); general(i); }
+      return;
+    }
+    // Only records of one name can pair and they are adjacent: the table is per name, and the usual
+    // group -- exactly two records -- is settled by comparing the two keys directly.
+    GkAlnKey first, second, third;
+    for (int64_t i = a; i < b;) {
+      key(i, first);
+      int64_t e = i + 1;
+      if (e < b) { key(e, second); if (second.name == first.name) ++e; }
+      if (e == i + 2 && (e == b || (key(e, third), third.name != first.name))) {
+        if (first.mate_same_ref) out.n_reads += 1;
+        if (second.mate_same_ref) out.n_reads += 1;
+        // the second record finds the waiting first one iff (ref, its mate position, secondary flag) agree
+        if (first.mate_same_ref && second.mate_same_ref && second.ref == first.ref && second.next_pos == first.pos &&
+            ((second.flag ^ first.flag) & 256) == 0) {
+          if (((first.flag | second.flag) & 192) != 192) {
+            out.n_strange += 1;
+          } else {
+            out.pairs.push_back(i + 1);
+            out.pairs.push_back(i);
+          }
+        }
+        i = e;
+        continue;
+      }
+      while (e < b && (key(e, second), second.name == first.name)) ++e;
+      waiting.clear();
+      for (int64_t j = i; j < e; ++j) { key(j, k); general(j); }
+      i = e;
     }
   };
   std::vector<int64_t> cuts{0};
@@ -526,21 +587,20 @@ int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
     pk->n_strange += pc.n_strange;
     pk->n_pairs += (int64_t)pc.pairs.size() / 2;
   }
-  // (2) decode on threads, (3) ordered merge
-  const size_t n_pair = pairs.size() / 2;
-  std::vector<Decoded> dec(n_pair);
-  on_threads(n_pair, [&](size_t a, size_t b) {
-    for (size_t i = a; i < b; ++i) {
-      GkAlnRecord pr[2];
-      const int64_t idx[2] = {base + pairs[2 * i], base + pairs[2 * i + 1]};
-      full(pairs[2 * i], pr[0]);
-      full(pairs[2 * i + 1], pr[1]);
-      decode_records(pk, pr, idx, dec[i]);
-    }
-  });
-  std::vector<int64_t> lines(pairs.size());
-  for (size_t i = 0; i < pairs.size(); ++i) lines[i] = base + pairs[i];
-  if (!merge_decoded(pk, dec, lines)) {
+  clock.lap("pairing");
+  // (2) decode on threads, (3) ordered pass over the pairs with inserted strings
+  const bool merged = decode_all(
+      pk, pairs.size() / 2,
+      [&](size_t i, Decoded& out) {
+        GkAlnRecord pr[2];
+        const int64_t idx[2] = {base + pairs[2 * i], base + pairs[2 * i + 1]};
+        full(pairs[2 * i], pr[0]);
+        full(pairs[2 * i + 1], pr[1]);
+        decode_records(pk, pr, idx, out);
+      },
+      [&](size_t i, int s) { return base + pairs[2 * i + s]; });
+  clock.lap("decode + merge");
+  if (!merged) {
     gk_set_error("alignment record %lld: %s", (long long)pk->err_line, pk->err_msg.c_str());
     return GK_ERR_ASSERT;
   }
@@ -633,7 +693,13 @@ int gk_packer_error(gk_packer* pk, int32_t* kind, int64_t* line_index) {
 // Copy out the records (2 per pair) and the line indices (left, right) of every pair.
 int gk_packer_records(gk_packer* pk, gk_mate* mates_out, int64_t* pair_lines_out) {
   if (!pk) return GK_ERR_ARG;
-  if (mates_out && !pk->mates.empty()) memcpy(mates_out, pk->mates.data(), pk->mates.size() * sizeof(gk_mate));
+  if (mates_out && !pk->mates.empty()) {   // first touch of the caller's pages: worth spreading over the threads
+    const size_t bytes = pk->mates.size() * sizeof(gk_mate), piece = 1u << 22;
+    on_threads((bytes + piece - 1) / piece, [&](int, size_t a, size_t b) {
+      const size_t lo = a * piece, hi = std::min(bytes, b * piece);
+      if (hi > lo) memcpy((char*)mates_out + lo, (const char*)pk->mates.data() + lo, hi - lo);
+    });
+  }
   if (pair_lines_out && !pk->pair_lines.empty())
     memcpy(pair_lines_out, pk->pair_lines.data(), pk->pair_lines.size() * sizeof(int64_t));
   return GK_OK;

@@ -413,3 +413,59 @@ def test_native_pileup_matches_the_restatement(tmp_path):
             changed += expect != 0
     assert changed > 100
     assert not table[counts.sum(axis=1) == 0].any()
+
+
+def test_bam_pairing_of_name_groups_matches_python(tmp_path):
+    """gk_bam_pack's per-name pairing (2-record fast path, larger groups through the table) emits the pairs
+    of hisat2.pairLines (readPair 248-270) on the collated stream: secondary copies, singletons, mates whose
+    PNEXT does not point at each other, two READ1 records, groups cut at thread boundaries."""
+    from bamwriter import samToBam
+    from kir_graph_amd.hisat2 import readBam
+    sidx = synth.makeIndex(seed=5, n_genes=3, var_range=(200, 300), allele_range=(10, 20))
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    sample = synth.makeSample(sidx, seed=12, n_pairs=6000)
+    base = synth.toSamLines(sample)
+    rng = np.random.default_rng(8)
+    records = []
+    for p in range(len(base) // 2):
+        l, r = base[2 * p].split("\t"), base[2 * p + 1].split("\t")
+        kind = int(rng.integers(0, 12))
+        if kind == 0:        # a secondary copy of the pair elsewhere (its own key: flag 256)
+            records += ["\t".join(l), "\t".join(r)]
+            l2, r2 = list(l), list(r)
+            shift = int(rng.integers(1, 40))
+            l2[1], r2[1] = str(int(l[1]) | 256), str(int(r[1]) | 256)
+            l2[3], r2[7] = str(int(l[3]) + shift), str(int(r[7]) + shift)
+            records += ["\t".join(l2), "\t".join(r2)]
+        elif kind == 1:      # mate lost
+            records += ["\t".join(l)]
+        elif kind == 2:      # PNEXT of the second mate points elsewhere: both keep waiting
+            r[7] = str(int(r[7]) + 3)
+            records += ["\t".join(l), "\t".join(r)]
+        elif kind == 3:      # two READ1 records
+            r[1] = str((int(r[1]) & ~128) | 64)
+            records += ["\t".join(l), "\t".join(r)]
+        elif kind == 4:      # mate on another reference
+            r[6] = sidx.genes[0] if r[2] != sidx.genes[0] else sidx.genes[1]
+            records += ["\t".join(l), "\t".join(r)]
+        elif kind == 5:      # three copies of the same mate pair (same keys): the third record waits again
+            records += ["\t".join(l), "\t".join(r), "\t".join(l)]
+        else:
+            records += ["\t".join(l), "\t".join(r)]
+    header = ["@HD\tVN:1.0\tSO:coordinate"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+    by_coord = sorted(records, key=lambda x: (x.split("\t")[2], int(x.split("\t")[3])))
+    path = str(tmp_path / "g.bam")
+    samToBam(header + by_coord, path)
+    collated = list(readBam(path))
+    pairs = list(pairLines(collated))
+    want, table_py = packed.packPairs(pairs, gidx)
+    got, table_c, pair_lines, counts = packed.packBam(path, gidx)
+    assert counts["pairs"] == len(pairs) and counts["lines"] == len(collated)
+    assert got.tobytes() == want.tobytes()
+    assert table_c.strings == table_py.strings
+    where = {id(x): i for i, x in enumerate(collated)}
+    assert pair_lines.tolist() == [[where[id(a)], where[id(b)]] for a, b in pairs]
+    # the text packer agrees as well (its pairing runs over the whole stream)
+    txt, _, pl_txt, counts_txt = packed.packText([("\n".join(collated) + "\n").encode()], gidx)
+    assert txt.tobytes() == want.tobytes() and pl_txt.tolist() == pair_lines.tolist()
+    assert counts_txt["strange"] == counts["strange"] > 0 and counts_txt["reads"] == counts["reads"]
