@@ -54,7 +54,7 @@ def buildNative(force: bool = False, verbose: bool = False) -> Path:
             failed.append(f"{src}:\n{out}\n{err}")
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
-    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib)] + [str(o) for _, o, _ in jobs] + ["-lz"]
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib)] + [str(o) for _, o, _ in jobs] + ["-lz", "-ldl"]
     if verbose:
         print(" ".join(link))
     res = subprocess.run(link, capture_output=True, text=True)

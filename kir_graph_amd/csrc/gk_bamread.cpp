@@ -9,6 +9,8 @@
 //
 // samtools is not part of this image, so the rendering and the order are checked against BAM files
 // written by the test suite's own encoder, not against samtools output ("parity unpinned").
+#include <dlfcn.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -17,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <memory>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -27,8 +30,18 @@
 
 void gk_set_error(const char* fmt, ...);
 
+// byte buffer whose resize() leaves new bytes uninitialised: the inflated stream is hundreds of megabytes
+// that the inflating threads are about to overwrite (and first-touch in parallel)
+template <typename T>
+struct RawInit : std::allocator<T> {
+  template <typename U> struct rebind { using other = RawInit<U>; };
+  template <typename U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+  template <typename U, typename... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+using Bytes = std::vector<uint8_t, RawInit<uint8_t>>;
+
 struct gk_bam {
-  std::vector<uint8_t> data;            // inflated BAM stream
+  Bytes data;                           // inflated BAM stream
   std::string header;                   // SAM header text ('@' lines)
   std::vector<std::string> ref_names;
   struct Rec { uint64_t off; uint32_t size; };
@@ -46,7 +59,7 @@ inline int32_t rds32(const uint8_t* p) { return (int32_t)rd32(p); }
 inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | p[1] << 8); }
 
 // Every gzip member of the BGZF file, inflated back to back.
-bool inflate_members(const std::vector<uint8_t>& in, std::vector<uint8_t>& out) {
+bool inflate_members(const Bytes& in, Bytes& out) {
   z_stream zs;
   memset(&zs, 0, sizeof(zs));
   if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
@@ -80,10 +93,33 @@ bool inflate_members(const std::vector<uint8_t>& in, std::vector<uint8_t>& out) 
   return ok;
 }
 
+// libdeflate inflates BGZF blocks 2-3 times faster than zlib.  The image ships its runtime library without
+// the header, so the three entry points used are bound by name at first use (signatures of libdeflate.h,
+// stable since 1.0); without the library, or with GK_NO_LIBDEFLATE set, zlib does the work.
+struct FastInflate {
+  void* (*alloc)() = nullptr;
+  int (*run)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;   // 0 = LIBDEFLATE_SUCCESS
+  void (*release)(void*) = nullptr;
+};
+
+const FastInflate* fast_inflate() {
+  static const FastInflate* found = []() -> const FastInflate* {
+    if (getenv("GK_NO_LIBDEFLATE")) return nullptr;
+    void* lib = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return nullptr;
+    static FastInflate f;
+    f.alloc = (void* (*)())dlsym(lib, "libdeflate_alloc_decompressor");
+    f.run = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(lib, "libdeflate_deflate_decompress");
+    f.release = (void (*)(void*))dlsym(lib, "libdeflate_free_decompressor");
+    return (f.alloc && f.run && f.release) ? &f : nullptr;
+  }();
+  return found;
+}
+
 // BGZF members carry their own compressed size (extra field 'BC') and end with the uncompressed size,
 // so the file splits into independent blocks that inflate in parallel, each straight into its place.
 // Returns false when the stream is not made of such blocks (the caller then inflates sequentially).
-bool inflate_bgzf_parallel(const std::vector<uint8_t>& in, std::vector<uint8_t>& out, int n_threads) {
+bool inflate_bgzf_parallel(const Bytes& in, Bytes& out, int n_threads) {
   struct Block { size_t in_off, in_len, out_off, out_len; };
   std::vector<Block> blocks;
   size_t o = 0, total = 0;
@@ -108,7 +144,23 @@ bool inflate_bgzf_parallel(const std::vector<uint8_t>& in, std::vector<uint8_t>&
   }
   out.resize(total);
   std::vector<char> bad((size_t)std::max(n_threads, 1), 0);
+  const FastInflate* fast = fast_inflate();
   auto work = [&](int t, size_t a, size_t b) {
+    if (fast) {
+      void* d = fast->alloc();
+      if (!d) { bad[(size_t)t] = 1; return; }
+      for (size_t i = a; i < b; ++i) {
+        const Block& bl = blocks[i];
+        if (!bl.out_len) continue;
+        size_t made = 0;
+        if (fast->run(d, in.data() + bl.in_off, bl.in_len, out.data() + bl.out_off, bl.out_len, &made) != 0 || made != bl.out_len) {
+          bad[(size_t)t] = 1;
+          break;
+        }
+      }
+      fast->release(d);
+      return;
+    }
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, -15) != Z_OK) { bad[(size_t)t] = 1; return; }
@@ -172,6 +224,47 @@ int name_order(const char* a0, const char* b0) {
     }
   }
   return *pa ? 1 : *pb ? -1 : 0;
+}
+
+// Sort key of a query name: a byte string whose memcmp order is name_order's.  Characters stand for
+// themselves; a digit run becomes '0' + its count of significant digits, those digits, then 255 - its count
+// of leading zeros (more zeros order first); the name ends with a 0 byte.  Only the first kNameKey bytes
+// are kept: keys that agree over the shorter of the two kept lengths decide nothing (the names themselves
+// are compared then), unless both are whole -- then the names are equal.
+constexpr int kNameKey = 16;
+struct SortRec {
+  uint8_t key[kNameKey];
+  uint64_t off;
+  uint32_t size;
+  uint8_t kept;      // key bytes that are meaningful
+  uint8_t whole;     // the key covers the whole name (terminator included)
+  uint8_t mate;      // FLAG & 0xC0: READ1 before READ2 among equal names
+};
+
+void name_key(const char* name, SortRec& r) {
+  const unsigned char* p = (const unsigned char*)name;
+  int n = 0;
+  bool room = true;
+  auto put = [&](unsigned v) { if (n < kNameKey) r.key[n++] = (uint8_t)v; else room = false; };
+  while (*p && room) {
+    if (isdigit(*p)) {
+      const unsigned char* z = p;
+      while (*p == '0') ++p;
+      const unsigned zeros = (unsigned)(p - z);
+      const unsigned char* e = p;
+      while (isdigit(*e)) ++e;
+      if (e - p > 9 || zeros > 200) { room = false; break; }   // not expressible: the key stops before the run
+      put('0' + (unsigned)(e - p));
+      for (; p < e; ++p) put(*p);
+      put(255u - zeros);
+    } else {
+      put(*p++);
+    }
+  }
+  if (room) put(0);
+  r.kept = (uint8_t)n;
+  r.whole = room ? 1 : 0;
+  for (int i = n; i < kNameKey; ++i) r.key[i] = 0;
 }
 
 void append_int(std::string& s, long long v) {
@@ -327,11 +420,18 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
   FILE* f = fopen(path, "rb");
   if (!f) { gk_set_error("cannot open %s", path); return GK_ERR_ARG; }
   GkPhaseClock clock("bam_open");
-  std::vector<uint8_t> raw;
+  Bytes raw;
   {
-    std::vector<uint8_t> buf(1 << 22);
-    size_t n;
-    while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) raw.insert(raw.end(), buf.data(), buf.data() + n);
+    struct stat st;
+    size_t have = 0;
+    raw.resize(fstat(fileno(f), &st) == 0 && st.st_size > 0 ? (size_t)st.st_size : (size_t)1 << 22);
+    for (;;) {   // whole file, whatever fstat said
+      if (have == raw.size()) raw.resize(raw.size() * 2);
+      const size_t n = fread(raw.data() + have, 1, raw.size() - have, f);
+      if (!n) break;
+      have += n;
+    }
+    raw.resize(have);
     fclose(f);
   }
   clock.lap("read");
@@ -343,7 +443,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
   }
   raw.clear(); raw.shrink_to_fit();
   clock.lap("inflate");
-  const std::vector<uint8_t>& d = b->data;
+  const Bytes& d = b->data;
   auto bad = [&](const char* what) {
     gk_set_error("%s: malformed BAM (%s)", path, what);
     delete b;
@@ -375,29 +475,41 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
   clock.lap("index");
   if (name_sorted) {
     const uint8_t* base = d.data();
-    auto before = [base](const gk_bam::Rec& x, const gk_bam::Rec& y) {
-      const uint8_t *px = base + x.off, *py = base + y.off;
-      const int t = name_order((const char*)px + 32, (const char*)py + 32);
-      if (t) return t < 0;
-      return (rd16(px + 14) & 0xC0u) < (rd16(py + 14) & 0xC0u);   // READ1 (0x40) before READ2 (0x80)
+    auto before = [base](const SortRec& x, const SortRec& y) {
+      const int c = memcmp(x.key, y.key, std::min(x.kept, y.kept));   // the keys usually decide without touching the records
+      if (c) return c < 0;
+      if (!(x.whole && y.whole)) {
+        const int t = name_order((const char*)base + x.off + 32, (const char*)base + y.off + 32);
+        if (t) return t < 0;
+      }
+      return x.mate < y.mate;   // READ1 (0x40) before READ2 (0x80)
     };
-    // stable merge sort over the ingest threads: sorted runs, then one parallel multiway merge
-    auto& recs = b->recs;
-    const size_t n = recs.size();
+    // stable merge sort over the ingest threads: keyed records, sorted runs, then one parallel multiway merge
+    const size_t n = b->recs.size();
+    std::vector<SortRec> recs(n);
     int runs = 1;
     while (runs * 2 <= ingest_threads() && (size_t)runs * 2 * 4096 <= n) runs *= 2;
     auto bound = [&](int i) { return n * (size_t)i / (size_t)runs; };
     {
       std::vector<std::thread> pool;
       for (int i = 0; i < runs; ++i)
-        pool.emplace_back([&, i] { std::stable_sort(recs.begin() + bound(i), recs.begin() + bound(i + 1), before); });
+        pool.emplace_back([&, i] {
+          for (size_t k = bound(i); k < bound(i + 1); ++k) {
+            SortRec& r = recs[k];
+            r.off = b->recs[k].off;
+            r.size = b->recs[k].size;
+            r.mate = (uint8_t)(rd16(base + r.off + 14) & 0xC0u);
+            name_key((const char*)base + r.off + 32, r);
+          }
+          std::stable_sort(recs.begin() + bound(i), recs.begin() + bound(i + 1), before);
+        });
       for (auto& th : pool) th.join();
     }
     if (runs > 1) {
       // Parallel stable multiway merge.  Splitters cut every run at lower_bound, so records equivalent to
       // a splitter land in the same part whatever run they come from; inside a part the runs are merged
       // in run order with std::merge (left range first on ties): the concatenated parts are the stable order.
-      std::vector<gk_bam::Rec> sample;
+      std::vector<SortRec> sample;
       for (int r = 0; r < runs; ++r)
         for (int k = 1; k < runs; ++k) sample.push_back(recs[bound(r) + (bound(r + 1) - bound(r)) * (size_t)k / (size_t)runs]);
       std::sort(sample.begin(), sample.end(), before);
@@ -409,7 +521,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
           cut[(size_t)r][(size_t)k] = (size_t)(std::lower_bound(recs.begin() + bound(r), recs.begin() + bound(r + 1),
                                                                 sample[(size_t)k * sample.size() / (size_t)runs], before) - recs.begin());
       }
-      std::vector<gk_bam::Rec> merged(n);
+      std::vector<SortRec> merged(n);
       std::vector<size_t> part_off((size_t)runs + 1, 0);
       for (int k = 0; k < runs; ++k) {
         size_t len = 0;
@@ -419,14 +531,14 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
       std::vector<std::thread> pool;
       for (int k = 0; k < runs; ++k)
         pool.emplace_back([&, k] {
-          std::vector<std::vector<gk_bam::Rec>> level;
+          std::vector<std::vector<SortRec>> level;
           for (int r = 0; r < runs; ++r)
             level.emplace_back(recs.begin() + cut[(size_t)r][(size_t)k], recs.begin() + cut[(size_t)r][(size_t)k + 1]);
           while (level.size() > 1) {
-            std::vector<std::vector<gk_bam::Rec>> next;
+            std::vector<std::vector<SortRec>> next;
             for (size_t i = 0; i < level.size(); i += 2) {
               if (i + 1 == level.size()) { next.push_back(std::move(level[i])); break; }
-              std::vector<gk_bam::Rec> both(level[i].size() + level[i + 1].size());
+              std::vector<SortRec> both(level[i].size() + level[i + 1].size());
               std::merge(level[i].begin(), level[i].end(), level[i + 1].begin(), level[i + 1].end(), both.begin(), before);
               next.push_back(std::move(both));
             }
@@ -437,6 +549,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
       for (auto& th : pool) th.join();
       recs.swap(merged);
     }
+    for (size_t k = 0; k < n; ++k) b->recs[k] = {recs[k].off, recs[k].size};
   }
   clock.lap("name sort");
   *out = b;

@@ -469,3 +469,40 @@ def test_bam_pairing_of_name_groups_matches_python(tmp_path):
     txt, _, pl_txt, counts_txt = packed.packText([("\n".join(collated) + "\n").encode()], gidx)
     assert txt.tobytes() == want.tobytes() and pl_txt.tolist() == pair_lines.tolist()
     assert counts_txt["strange"] == counts["strange"] > 0 and counts_txt["reads"] == counts["reads"]
+
+
+def test_name_collation_on_random_name_shapes(tmp_path):
+    """The keyed name sort (16-byte prefix keys, full comparison when they do not decide) orders any mix of
+    name shapes like the plain comparator: long names, equal prefixes beyond the key, digit runs of more
+    than 9 digits, leading zeros, digits against letters, names that are prefixes of others."""
+    import functools
+    from bamwriter import samToBam
+    rng = np.random.default_rng(17)
+    stems = ["r", "read", "A00123:45:HXXXXXXXX:1:", "x", "", "r0", "sample_long_prefix_over_sixteen_bytes/", "7", "00"]
+    pieces = ["", "a", "b", ":", "_", "-", "0", "00", "000", "1", "9", "10", "007", "12345678901", "123456789", "99999999999999"]
+    names = set()
+    while len(names) < 17000:     # 34 k records: all eight sorted runs and the multiway merge take part
+        k = int(rng.integers(1, 6))
+        name = stems[int(rng.integers(len(stems)))] + "".join(
+            pieces[int(rng.integers(len(pieces)))] if rng.random() < 0.5 else str(int(rng.integers(0, 3000))).zfill(int(rng.integers(0, 7)))
+            for _ in range(k))
+        if name and len(name) < 200:
+            names.add(name)
+    names = sorted(names)
+    rng.shuffle(names)
+    g = "KIR_TEST*BACKBONE"
+    lines = []
+    for i, name in enumerate(names):
+        pos = 100 + i
+        lines.append(f"{name}\t147\t{g}\t{pos + 200}\t60\t10M\t=\t{pos}\t-210\tACGTACGTAC\tIIIIIIIIII\tNM:i:0")   # READ2 first in the file
+        lines.append(f"{name}\t99\t{g}\t{pos}\t60\t10M\t=\t{pos + 200}\t210\tACGTACGTAC\tIIIIIIIIII\tNM:i:0")
+    header = ["@HD\tVN:1.0\tSO:unsorted", f"@SQ\tSN:{g}\tLN:100000"]
+    path = str(tmp_path / "n.bam")
+    samToBam(header + lines, path, block=20000)
+    got = b"".join(packed.bamChunks(path, chunk_bytes=1 << 15)).decode().split("\n")[:-1]
+
+    def order(x, y):
+        fx, fy = x.split("\t", 2), y.split("\t", 2)
+        return _name_order(fx[0], fy[0]) or (int(fx[1]) & 192) - (int(fy[1]) & 192)
+    want = sorted(lines, key=functools.cmp_to_key(order))
+    assert got == want
