@@ -164,9 +164,11 @@ int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vfla
  * d_mask uint32 [vend-vbeg][words]: allele bit rows of the gene's index variants.
  * Outputs are column-major [allele][row] with leading dimension n_rows:
  *   d_probs double (ordered product lpv, rpv, lnv, rnv of 0.999 / 0.001), may be 0;
- *   d_miss uint8 (#mismatching ids, saturated 255), may be 0;  d_nvar uint16 [n_rows], may be 0. */
+ *   d_miss uint8 (#mismatching ids, saturated 255), may be 0;  d_nvar uint16 [n_rows], may be 0.
+ * keep_empty != 0: a row without any kept id scores 0.999 for every allele (no_empty=False, 372-374;
+ * the caller then passes all rows instead of gk_select_nonempty's); otherwise such a row scores 1.0. */
 int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag,
-              int32_t vbeg, int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele,
+              int32_t vbeg, int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty,
               gk_dptr d_probs, gk_dptr d_miss, gk_dptr d_nvar);
 
 /* ---- log10 through a value table: log_probs = np.log10(probs) (typing_mulit_allele.py:263).
@@ -185,7 +187,7 @@ int gk_lut_apply(gk_lut* lut, gk_dptr d_in, gk_dptr d_out, int64_t n);
  * A product whose log10 is not defined yet is inserted into the table and stored as NaN: when
  * gk_lut_pending reports n_total > n_known afterwards, export/define the new values and call again. */
 int gk_compat_log(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag,
-                  int32_t vbeg, int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele,
+                  int32_t vbeg, int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty,
                   gk_lut* lut, gk_dptr d_log);
 
 /* ---- likelihood search: AlleleTyping.addCandidate (typing_mulit_allele.py:478-598).

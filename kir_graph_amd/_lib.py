@@ -89,7 +89,7 @@ _SIGS = {
                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "gk_variant_correct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "gk_compat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_int32, C.c_int32,
-                            C.c_uint64, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]),
+                            C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]),
     "gk_lut_create": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "gk_lut_destroy": (C.c_int, [C.c_void_p]),
     "gk_lut_collect": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64]),
@@ -106,7 +106,7 @@ _SIGS = {
     "gk_bam_pack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gk_bam_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "gk_compat_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_int32, C.c_int32,
-                                C.c_uint64, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64]),
+                                C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64]),
     "gk_maxsum": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                             C.c_void_p, C.c_int32, C.c_void_p]),
     "gk_fraction": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
                                                                 const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
                                                                 const uint32_t* mask_t, int words, int n_allele, int a_base,
                                                                 double* probs, uint8_t* miss_out, uint16_t* nvar_out,
-                                                                LutView lut) {
+                                                                LutView lut, double empty_p) {
   const int n_span = vend - vbeg;   // mask_t: [words][n_span], see transpose_mask
   constexpr int kPassAlleles = 64 * kSlots;
   constexpr int kPassWords = 2 * kSlots;   // bit-row words covering one pass
@@ -283,7 +283,9 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
 #pragma unroll
       for (int s = 0; s < kSlots; ++s) {
         if (live[s]) {
-          tile[(lane + 64 * s) * kTileLd + rt] = p[s];
+          // a read without any kept variant: 1.0, or 0.999 for every allele when such reads stay in the
+          // model (no_empty=False, typing_mulit_allele.py:372-374)
+          tile[(lane + 64 * s) * kTileLd + rt] = nvar ? p[s] : empty_p;
           if (kMiss && miss_out) miss_out[(int64_t)a[s] * n_rows + i] = (uint8_t)min(miss[s], 255u);
         }
       }
@@ -324,7 +326,9 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
 
 template <bool kLog>
 int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int vbeg, int vend,
-                  gk_dptr d_mask, int words, int n_allele, double* out, uint8_t* miss, uint16_t* nvar, LutView view) {
+                  gk_dptr d_mask, int words, int n_allele, double* out, uint8_t* miss, uint16_t* nvar, LutView view,
+                  int keep_empty) {
+  const double empty_p = keep_empty ? 0.999 : 1.0;
   int64_t want = (n_rows + kTileRows - 1) / kTileRows;
   const dim3 grid((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048)), block(kCompatThreads);
   const int64_t n_mask = (int64_t)(vend - vbeg) * words;
@@ -339,7 +343,7 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
   GK_PROF(ctx, GK_K_COMPAT,                                                                                        \
           GK_KERNEL((compat_kernel<kLog, S, !kLog>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows, \
                              tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, mask_t,  \
-                             words, n_allele, a_base, out, miss, nvar, view))
+                             words, n_allele, a_base, out, miss, nvar, view, empty_p))
     switch (slots) {
       case 1: GK_COMPAT_LAUNCH(1); break;
       case 2: GK_COMPAT_LAUNCH(2); break;
@@ -527,24 +531,26 @@ int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vfla
 }
 
 int gk_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg, int32_t vend,
-              gk_dptr d_mask, int32_t words, int32_t n_allele, gk_dptr d_probs, gk_dptr d_miss, gk_dptr d_nvar) {
+              gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty, gk_dptr d_probs, gk_dptr d_miss,
+              gk_dptr d_nvar) {
   gk_bind(ctx);
   GK_REQUIRE(ctx && tab, "null pointer");
   GK_REQUIRE(words >= 1 && n_allele >= 0 && n_allele <= words * 32 && vend >= vbeg, "bad mask geometry");
   if (n_rows == 0 || n_allele == 0) return GK_OK;
   return launch_compat<false>(ctx, tab, d_rows, n_rows, d_vflag, vbeg, vend, d_mask, words, n_allele,
-                              gk_ptr<double>(d_probs), gk_ptr<uint8_t>(d_miss), gk_ptr<uint16_t>(d_nvar), LutView{});
+                              gk_ptr<double>(d_probs), gk_ptr<uint8_t>(d_miss), gk_ptr<uint16_t>(d_nvar), LutView{}, keep_empty);
 }
 
 int gk_compat_log(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg,
-                  int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, gk_lut* lut, gk_dptr d_log) {
+                  int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty, gk_lut* lut,
+                  gk_dptr d_log) {
   gk_bind(ctx);
   GK_REQUIRE(ctx && tab && lut, "null pointer");   // the table may belong to another context of the same device
   GK_REQUIRE(words >= 1 && n_allele >= 0 && n_allele <= words * 32 && vend >= vbeg, "bad mask geometry");
   if (n_rows == 0 || n_allele == 0) return GK_OK;
   GK_REQUIRE(d_log, "null output");
   return launch_compat<true>(ctx, tab, d_rows, n_rows, d_vflag, vbeg, vend, d_mask, words, n_allele,
-                             gk_ptr<double>(d_log), nullptr, nullptr, gk_lut_view(lut));
+                             gk_ptr<double>(d_log), nullptr, nullptr, gk_lut_view(lut), keep_empty);
 }
 
 }  // extern "C"

@@ -318,8 +318,11 @@ class DeviceModel:
 
     def __init__(self, tab: Tabulation, rows: DeviceBuffer, n_rows: int, vflag: DeviceBuffer,
                  vbeg: int, vend: int, mask: DeviceBuffer, words: int, n_allele: int, logs: LogTable,
-                 want_miss: bool = False):
+                 want_miss: bool = False, keep_empty: bool = False):
+        """``keep_empty``: rows without any kept variant are part of the model and score 0.999 for every
+        allele (``no_empty=False``, typing_mulit_allele.py:372-374)."""
         self.tab, self.dev = tab, tab.dev
+        self._keep_empty = int(bool(keep_empty))
         self.rows, self.n_rows, self.n_allele = rows, n_rows, n_allele
         self.vflag = vflag
         self.L = self.miss = self.nvar = None
@@ -339,7 +342,7 @@ class DeviceModel:
         vbeg, vend, mask, words = self._geom
         self._known_at_launch = self._logs.n_known
         check(lib().gk_compat_log(self.dev.ctx, self.tab.handle, self.rows.ptr, self.n_rows, self.vflag.ptr, vbeg, vend,
-                                  mask.ptr, words, self.n_allele, self._logs.handle, self.L.ptr))
+                                  mask.ptr, words, self.n_allele, self._keep_empty, self._logs.handle, self.L.ptr))
 
     def _launchProbs(self) -> None:
         """The un-logged products (and the mismatch counts): only built when somebody asks for them."""
@@ -349,7 +352,8 @@ class DeviceModel:
             self.miss = self.dev.alloc((self.n_allele, self.n_rows), np.uint8)
             self.nvar = self.dev.alloc(self.n_rows, np.uint16)
         check(lib().gk_compat(self.dev.ctx, self.tab.handle, self.rows.ptr, self.n_rows, self.vflag.ptr, vbeg, vend,
-                              mask.ptr, words, self.n_allele, self._probs.ptr, self.miss.ptr if self.miss else 0,
+                              mask.ptr, words, self.n_allele, self._keep_empty, self._probs.ptr,
+                              self.miss.ptr if self.miss else 0,
                               self.nvar.ptr if self.nvar else 0))
 
     @property

@@ -339,8 +339,6 @@ class AlleleTyping:
         self.top_n = top_n
         self._no_empty = no_empty
         self.force_homo = force_homo
-        if not no_empty:
-            raise NotImplementedError("no_empty=False is not used by the pipeline and not implemented on the device")
         self._variant_list = variants
         self._novel_provider = _novel    # callable -> novel variants of the gene (built on demand)
         self._variants_map: dict[str, Variant] | None = None
@@ -364,14 +362,17 @@ class AlleleTyping:
         self._tally = None
         if variant_correction:
             self._tally = tab.errorCorrection(rs.rows, rs.n_rows, rs.vflag, span=self._span, keep=True)
-        rows, n_rows = tab.selectNonEmpty(rs.rows, rs.n_rows, rs.vflag)
+        if no_empty:
+            rows, n_rows = tab.selectNonEmpty(rs.rows, rs.n_rows, rs.vflag)
+        else:   # reads without information stay and score 0.999 for every allele (372-374)
+            rows, n_rows = rs.rows, rs.n_rows
         self._readset = ReadSet(tab, rows, n_rows, rs.vflag)
         n_allele = len(names)
         words = max(1, (n_allele + 31) // 32)
         if _mask is None:
             _mask = self._dev.put(buildMask(variants[:n_span], names))
         self._model = DeviceModel(tab, rows, n_rows, rs.vflag, _vbeg, _vbeg + n_span, _mask, words, n_allele,
-                                  self._logs)
+                                  self._logs, keep_empty=not no_empty)
         self._colsum_all: np.ndarray | None = None
         self._pair_table: np.ndarray | None = None    # scores of all allele pairs (second step), when formed
         self._reads_cache = None

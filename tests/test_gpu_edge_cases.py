@@ -113,3 +113,27 @@ def test_wide_genes_cover_every_allele_slot_layout(device, n_allele):
     for a, b in zip(gpu.result, cpu.result):
         same(a, b)
     assert got.selectBest() == oty.selectBest(want)
+
+
+@pytest.mark.parametrize("correction", [False, True])
+def test_reads_without_information_stay_when_asked(device, one_gene, correction):
+    """no_empty=False (the way novel_discover.py:273 builds its model): reads without any variant -- from the
+    start, or once error correction dropped theirs -- stay in the model and score 0.999 for every allele
+    (typing_mulit_allele.py:259-260, 372-374)."""
+    g, variants, reads = one_gene
+    sub = copy.deepcopy(reads[:2500])
+    for i in range(0, len(sub), 9):
+        for k in ("lpv", "lnv", "rpv", "rnv"):
+            sub[i][k] = []
+    cpu = oty.GeneModel(copy.deepcopy(sub), variants, force_homo=False, top_n=600, no_empty=False,
+                        variant_correction=correction)
+    gpu = AlleleTyping(to_pairs(sub), variants, force_homo=False, top_n=600, no_empty=False,
+                       variant_correction=correction, device=device)
+    assert gpu.getReadsNum() == cpu.readsNum() == len(sub)
+    assert np.array_equal(gpu.probs, cpu.probs)
+    assert (gpu.probs[0] == 0.999).all()
+    assert np.array_equal(gpu.log_probs, cpu.log_probs)
+    want, got = cpu.typing(2), gpu.typing(2)
+    for a, b in zip(gpu.result, cpu.result):
+        same(a, b)
+    assert got.selectBest() == oty.selectBest(want)
