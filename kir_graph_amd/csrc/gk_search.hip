@@ -313,7 +313,12 @@ __global__ __launch_bounds__(kThreads, 2) void maxsum_chunks(const double* __res
 }
 
 // finish the tree: fold the spans of each chunk with that chunk's program, then accumulate the
-// chunk sums sequentially (numpy's outer reduce loop)
+// chunk sums sequentially (numpy's outer reduce loop).  A workgroup owns 64 outputs; its four waves
+// fold four chunks at a time (the span sums of a chunk are read with all loads in flight), wave 0
+// then adds the four chunk sums in chunk order.
+constexpr int kCombOut = 64;
+constexpr int kCombLanes = kThreads / kCombOut;
+
 __global__ __launch_bounds__(kThreads) void combine_chunks(const double* __restrict__ partial, int64_t n_out,
                                                            int n_chunks, const int32_t* __restrict__ chunk_span0,
                                                            const int32_t* __restrict__ chunk_op0,
@@ -322,17 +327,33 @@ __global__ __launch_bounds__(kThreads) void combine_chunks(const double* __restr
   // the span sums of a chunk sit in LDS ([span][thread]: conflict-free, and the program's dst / src
   // indices need no private-memory array)
   __shared__ double sp[kMaxSpans][kThreads];
-  const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (o >= n_out) return;
-  const int t = threadIdx.x;
+  __shared__ double csum[kCombLanes][kCombOut];
+  const int t = threadIdx.x, j = t & (kCombOut - 1);
+  const int c = __builtin_amdgcn_readfirstlane(t / kCombOut);
+  const int64_t o = (int64_t)blockIdx.x * kCombOut + j;
+  const bool live = o < n_out;
   double total = 0.0;
-  for (int q = 0; q < n_chunks; ++q) {
-    const int s0 = chunk_span0[q], s1 = chunk_span0[q + 1];
-    for (int s = s0; s < s1; ++s) sp[s - s0][t] = partial[(int64_t)s * n_out + o];
-    for (int k = chunk_op0[q]; k < chunk_op0[q + 1]; ++k) sp[top[k].dst][t] += sp[top[k].src][t];
-    total = q == 0 ? sp[0][t] : total + sp[0][t];
+  for (int q0 = 0; q0 < n_chunks; q0 += kCombLanes) {
+    const int q = q0 + c;   // wave-uniform
+    if (q < n_chunks) {
+      const int s0 = chunk_span0[q], n_s = chunk_span0[q + 1] - s0;
+      double v[kMaxSpans];
+#pragma unroll
+      for (int s = 0; s < kMaxSpans; ++s) v[s] = (s < n_s && live) ? partial[(int64_t)(s0 + s) * n_out + o] : 0.0;
+#pragma unroll
+      for (int s = 0; s < kMaxSpans; ++s)
+        if (s < n_s) sp[s][t] = v[s];
+      for (int k = chunk_op0[q]; k < chunk_op0[q + 1]; ++k) sp[top[k].dst][t] += sp[top[k].src][t];
+      csum[c][j] = sp[0][t];
+    }
+    __syncthreads();
+    if (c == 0) {
+      const int n_here = min(kCombLanes, n_chunks - q0);
+      for (int i = 0; i < n_here; ++i) total = (q0 + i == 0) ? csum[i][j] : total + csum[i][j];
+    }
+    __syncthreads();
   }
-  out[o] = scale_div != 0.0 ? total / scale_div : total;
+  if (c == 0 && live) out[o] = scale_div != 0.0 ? total / scale_div : total;
 }
 
 // abundance share (typing_mulit_allele.py:575-580): one 8-lane group per allele set, 32 sets per
@@ -683,7 +704,7 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
                                dp.leaves, tiles_t * tiles_a, 0, d_partial));
   }
   GK_PROF(ctx, GK_K_COMBINE,
-          GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+          GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st,
                              d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, 0.0, d_out));
   GK_HIP(hipGetLastError());
   if (symmetric) {
@@ -789,7 +810,7 @@ int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int3
   }
 #undef GK_FRAC_LAUNCH
   GK_PROF(ctx, GK_K_COMBINE,
-          GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+          GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st,
                              d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, (double)n_rows, d_out));
   GK_HIP(hipGetLastError());
   GK_HIP(hipMemcpyAsync(frac_out, d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -17,6 +17,9 @@ L = -rng.integers(0, 6, (A, R)).astype(np.float64) * 3.0 - rng.integers(20, 60, 
 dL = dev.put(L)
 ids = np.ascontiguousarray(rng.integers(0, A, (T, C)), dtype=np.int32)
 cols = np.arange(A, dtype=np.int32)
+if os.environ.get("GK_BENCH_SAMECOL"):   # every tile reads the same column: cache-resident operands (latency experiment)
+    cols[:] = 0
+    ids[:] = 0
 out = np.empty((T, A))
 dev.profEnable(True)
 for _ in range(2):
