@@ -97,8 +97,8 @@ def cpu_baseline(sidx, gidx, gene_cn, method, n_pairs, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per sample (config 2: 1e6)")
     ap.add_argument("--method", default="pv")
     ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs for the CPU baseline sample (0 = skip)")

@@ -37,6 +37,7 @@ constexpr int kInsWord = kMmWord + GK_MAX_MM;       // 26
 static_assert(sizeof(gk_mate) == 128 && kInsWord + GK_MAX_INS == kMateWords, "gk_mate layout");
 constexpr int kRecLd = kMateWords + 1;   // LDS stride of a staged record (dwords)
 constexpr int kEvLd = kMaxEv + 1;        // LDS stride of a lane's event words (odd: conflict-free)
+constexpr int kMaskWords = 8;            // kept-candidate bits saved per mate by pass 1: windows of up to 256 variants
 
 // event word: what the negative filter needs to know about one non-match event of the mate
 constexpr uint32_t kEvNovel = 1u << 31;   // not an index variant; low 24 bits = position
@@ -117,17 +118,19 @@ struct NovelTable {
   uint32_t mask;
 };
 
-__device__ inline void novel_insert(const NovelTable& t, uint64_t key, uint32_t seq) {
+// returns the slot of the key (the table never fills: its capacity is checked by the host)
+__device__ inline uint32_t novel_insert(const NovelTable& t, uint64_t key, uint32_t seq) {
   uint32_t s = hash64(key) & t.mask;
   for (uint32_t probe = 0; probe <= t.mask; ++probe) {
     unsigned long long prev = atomicCAS((unsigned long long*)&t.keys[s], (unsigned long long)kEmpty,
                                         (unsigned long long)key);
     if (prev == kEmpty || prev == key) {
       atomicMin(&t.seq[s], seq);
-      return;
+      return s;
     }
     s = (s + 1) & t.mask;
   }
+  return 0;
 }
 
 __device__ inline uint32_t novel_rank(const NovelTable& t, uint64_t key) {
@@ -152,9 +155,12 @@ struct Walked {
   int lo, hi;            // ordinals of the window [lo, hi)
 };
 
+// ev_out (pass 1 only, may be null): the positive list of the mate as it will be emitted -- the ordinal of a
+// known variant, kEvNovel | slot of the novel table otherwise -- so that pass 2 need not walk again.
 template <bool kEmit>
 __device__ inline void walk_mate(const MateView& r, const IndexView& ix, const NovelTable& nt, int64_t m,
-                                 uint32_t* evw, uint32_t* ids, uint32_t o_pos, uint32_t o_pos_end, Walked& wk) {
+                                 uint32_t* evw, uint32_t* ids, uint32_t o_pos, uint32_t o_pos_end, uint32_t* ev_out,
+                                 Walked& wk) {
   wk.n = 0; wk.clipped = false; wk.overflow = false; wk.drop = false; wk.any_n = 0; wk.bad_window = false;
   wk.lo = wk.hi = 0; wk.right = 0;
   const int n_cig = min((int)r.n_cig(), GK_MAX_CIG);
@@ -189,8 +195,10 @@ __device__ inline void walk_mate(const MateView& r, const IndexView& ix, const N
     if (kEmit) {
       if (o_pos + wk.n < o_pos_end)
         ids[o_pos + wk.n] = known ? (uint32_t)i : (uint32_t)ix.n_var + novel_rank(nt, k);
-    } else if (!known) {
-      novel_insert(nt, k, (uint32_t)(m * kMaxEv + wk.n));
+    } else {
+      uint32_t saved = (uint32_t)i;
+      if (!known) saved = kEvNovel | novel_insert(nt, k, (uint32_t)(m * kMaxEv + wk.n));
+      if (ev_out) ev_out[wk.n] = saved;
     }
     last_pos = pos; last_len = len; last_novel = !known;
     wk.n++;
@@ -256,6 +264,7 @@ struct WaveNeg {            // per wave, in LDS
   uint32_t lo[64], right[64], n_ev[64], any_n[64];
   uint32_t kept[64];        // running count of kept candidates per owner lane
   uint32_t out0[64];        // kEmit: first slot of the owner's negative list
+  uint32_t mask[64][kMaskWords];   // pass 1: bit b of an owner's words = candidate lo + b is kept
 };
 
 template <bool kEmit>
@@ -271,6 +280,10 @@ __device__ inline uint32_t cooperative_negatives(WaveNeg& wv, const IndexView& i
   }
   wv.incl[lane] = incl; wv.lo[lane] = my_lo; wv.right[lane] = my_right; wv.n_ev[lane] = my_n;
   wv.any_n[lane] = my_any_n; wv.kept[lane] = 0; wv.out0[lane] = my_out0;
+  if (!kEmit) {
+#pragma unroll
+    for (int w = 0; w < kMaskWords; ++w) wv.mask[lane][w] = 0;
+  }
   const uint32_t total = __shfl(incl, 63, 64);
   __builtin_amdgcn_wave_barrier();
   for (uint32_t j = 0; j < total; j += 64) {
@@ -291,6 +304,7 @@ __device__ inline uint32_t cooperative_negatives(WaveNeg& wv, const IndexView& i
       keep = negative_kept(ix.key[i], (int)i, ix, evs_wave + owner * kEvLd, (int)wv.n_ev[owner], wv.any_n[owner],
                            wv.right[owner]);
     }
+    if (!kEmit && keep && c - start < 32u * kMaskWords) atomicOr(&wv.mask[owner][(c - start) >> 5], 1u << ((c - start) & 31u));
     // candidates of one owner are a run of consecutive lanes
     const uint64_t kept_mask = __ballot(keep);
     const uint32_t first_lane = start > j ? start - j : 0u;          // first lane of my owner's run in this step
@@ -309,7 +323,10 @@ __device__ inline uint32_t cooperative_negatives(WaveNeg& wv, const IndexView& i
 // adjacent lanes so the pair verdict is one lane shuffle.
 __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int64_t n_mates, IndexView ix,
                                                       NovelTable nt, uint32_t* cnt /*[4*n_pairs+1]*/,
-                                                      uint32_t* valid /*[n_pairs]*/, int* err_flags) {
+                                                      uint32_t* valid /*[n_pairs]*/, int* err_flags,
+                                                      uint32_t* ev_save /*[n_mates][kMaxEv]*/,
+                                                      uint32_t* lo_save /*[n_mates]*/,
+                                                      uint32_t* mask_save /*[n_mates][kMaskWords]*/) {
   __shared__ uint32_t rec[kThreads * kRecLd];
   __shared__ uint32_t evs[kThreads * kEvLd];
   __shared__ WaveNeg wneg[kThreads / 64];
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
   wk.n = 0; wk.lo = wk.hi = 0; wk.right = 0; wk.any_n = 0;
   bool enumerate = false;
   if (pair_ok) {
-    walk_mate<false>(r, ix, nt, m, evw, nullptr, 0, 0, wk);
+    walk_mate<false>(r, ix, nt, m, evw, nullptr, 0, 0, ev_save + m * kMaxEv, wk);
     if (wk.overflow) atomicOr(err_flags, 2);
     if (wk.clipped) {
     } else if (wk.bad_window) {
@@ -347,6 +364,45 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
   cnt[4 * pair + side] = n_pos;
   cnt[4 * pair + 2 + side] = n_neg;
   if (side == 0) valid[pair] = pair_ok ? 1u : 0u;
+  // what pass 2 needs to write the negative list without enumerating the window again
+  if (enumerate) {
+    const uint32_t len = (uint32_t)(wk.hi - wk.lo);
+    if (len > 32u * kMaskWords) atomicOr(err_flags, 4);   // does not fit the saved bits: the host takes the two-walk path
+    lo_save[m] = (uint32_t)wk.lo;
+    const uint32_t n_words = min((len + 31u) >> 5, (uint32_t)kMaskWords);
+    for (uint32_t w = 0; w < n_words; ++w) mask_save[m * kMaskWords + w] = wneg[wid].mask[threadIdx.x & 63][w];
+  }
+}
+
+// pass 2 without a second walk: the lists are written from what pass 1 saved -- the positive list as
+// ordinals / novel-table slots, the negative list as the window's first ordinal + the kept bits.
+__global__ __launch_bounds__(kThreads) void tab_expand(int64_t n_mates, int n_var, const uint32_t* rank,
+                                                       const uint32_t* off, const uint32_t* valid,
+                                                       const uint32_t* ev_save, const uint32_t* lo_save,
+                                                       const uint32_t* mask_save, uint32_t* ids) {
+  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (m >= n_mates) return;
+  const int64_t pair = m >> 1;
+  const int side = (int)(m & 1);
+  if (!valid[pair]) return;
+  const uint32_t o_pos = off[4 * pair + side], n_pos = off[4 * pair + side + 1] - o_pos;
+  const uint32_t o_neg = off[4 * pair + 2 + side], n_neg = off[4 * pair + 2 + side + 1] - o_neg;
+  for (uint32_t e = 0; e < n_pos; ++e) {
+    const uint32_t w = ev_save[m * kMaxEv + e];
+    ids[o_pos + e] = (w & kEvNovel) ? (uint32_t)n_var + rank[w & 0xFFFFFFu] : w;
+  }
+  if (n_neg) {
+    const uint32_t lo = lo_save[m];
+    uint32_t j = 0;
+    for (int w = 0; w < kMaskWords && j < n_neg; ++w) {
+      uint32_t bits = mask_save[m * kMaskWords + w];
+      while (bits) {
+        const int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        ids[o_neg + j++] = lo + 32u * (uint32_t)w + (uint32_t)b;
+      }
+    }
+  }
 }
 
 // novel ranking: mark first-appearance sequence numbers, prefix-popcount, assign ranks
@@ -391,7 +447,7 @@ __global__ __launch_bounds__(kThreads) void tab_emit(const gk_mate* mates, int64
   uint32_t* evw = evs + threadIdx.x * kEvLd;
   Walked wk;
   wk.n = 0; wk.lo = wk.hi = 0; wk.right = 0; wk.any_n = 0;
-  if (o_pos != o_pos_end || o_neg != o_neg_end) walk_mate<true>(r, ix, nt, m, evw, ids, o_pos, o_pos_end, wk);
+  if (o_pos != o_pos_end || o_neg != o_neg_end) walk_mate<true>(r, ix, nt, m, evw, ids, o_pos, o_pos_end, nullptr, wk);
   const int wid = threadIdx.x >> 6;
   // a mate with an empty negative list has nothing to enumerate (its window may still be non-empty)
   cooperative_negatives<true>(wneg[wid], ix, evs + wid * 64 * kEvLd, o_neg != o_neg_end ? (uint32_t)(wk.hi - wk.lo) : 0u,
@@ -500,8 +556,11 @@ int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t
   GK_HIP(hipMemsetAsync(nt.keys, 0xFF, cap * sizeof(uint64_t), st));
   GK_HIP(hipMemsetAsync(nt.seq, 0xFF, cap * sizeof(uint32_t), st));
 
-  uint32_t *cnt = nullptr, *valid = nullptr;
+  uint32_t *cnt = nullptr, *valid = nullptr, *ev_save = nullptr, *lo_save = nullptr, *mask_save = nullptr;
   int* d_err = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&ev_save, (size_t)(n_mates + 1) * kMaxEv * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&lo_save, (size_t)(n_mates + 1) * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&mask_save, (size_t)(n_mates + 1) * kMaskWords * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&cnt, (size_t)(4 * n_pairs + 2) * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&valid, (size_t)(n_pairs + 1) * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_err, sizeof(int)));
@@ -511,7 +570,7 @@ int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t
                      gk_ptr<uint8_t>(d_corr), gk_ptr<int64_t>(d_gene_pos0)};
   if (n_mates) {
     GK_PROF(ctx, GK_K_TAB_COUNT, GK_KERNEL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
-                       nt, cnt, valid, d_err));
+                       nt, cnt, valid, d_err, ev_save, lo_save, mask_save));
   }
   // offsets over input pairs (invalid pairs contribute zeros)
   int rc = gk_scan_u32(ctx, cnt, 4 * n_pairs, cnt + 4 * n_pairs);
@@ -537,7 +596,7 @@ int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t
   GK_HIP(hipStreamSynchronize(st));
   tab->n_ids = totals[0];
   tab->n_novel = (int32_t)totals[1];
-  tab->err_flags = err;
+  tab->err_flags = err & 3;   // bit 2 (a window beyond the saved bits) only selects the pass-2 kernel
   if ((uint64_t)tab->n_novel * 2 > cap) {
     gk_set_error("novel variant table overflow (%d novel variants)", tab->n_novel);
     return GK_ERR_CAPACITY;
@@ -549,8 +608,15 @@ int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t
 
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_ids, (size_t)(tab->n_ids + 1) * sizeof(uint32_t)));
   if (n_mates) {
-    GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix, nt, cnt,
-                       valid, tab->d_ids));
+    // pass 2: from what pass 1 saved; the second walk only when some window did not fit the saved bits
+    const bool two_walks = getenv("GK_TAB_TWO_WALKS") != nullptr;   // development / test switch
+    if ((err & 4) || two_walks) {
+      GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix, nt,
+                         cnt, valid, tab->d_ids));
+    } else {
+      GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_expand, dim3(nblk(n_mates)), dim3(kThreads), 0, st, n_mates, idx->n_var,
+                         nt.rank, cnt, valid, ev_save, lo_save, mask_save, tab->d_ids));
+    }
   }
   // compact valid pairs (order preserving)
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_pair_src, (size_t)(n_pairs + 1) * sizeof(int32_t)));
@@ -564,6 +630,7 @@ int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t
   GK_HIP(hipGetLastError());
   GK_HIP(hipStreamSynchronize(st));
   gk_pool_free(ctx,cnt); gk_pool_free(ctx,valid); gk_pool_free(ctx,d_err); gk_pool_free(ctx,bitmap); gk_pool_free(ctx,prefix);
+  gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save);
   gk_pool_free(ctx,nt.keys); gk_pool_free(ctx,nt.seq); gk_pool_free(ctx,nt.rank);
   if (err & 2) {
     gk_set_error("a filter-passing mate carries more than %d variant events", kMaxEv);

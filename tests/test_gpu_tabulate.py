@@ -153,3 +153,56 @@ def test_pileup_error_correction_matches_oracle(device, tmp_path):
     with open(tmp_path / "out.json") as f:
         saved = json.load(f)
     assert [{k: r[k] for k in ("lpv", "rpv", "lnv", "rnv")} for r in saved["reads"]] == results["on"][0]
+
+
+def test_both_second_passes_give_the_same_tabulation(device, small_case, monkeypatch):
+    """Pass 2 normally writes the lists from what pass 1 saved (events, window start, kept bits); windows of
+    more than 256 variants take the second walk instead.  Both must give the same CSR -- also on an index
+    dense enough to need the second walk."""
+    from kir_graph_amd.index import GkIndex
+    sidx, gidx, sample = small_case
+    # an index with ~1 variant per base: every SNP site gets its other two alternative bases, carried by an
+    # allele no sample draws, so a 300-base mate sees a window of ~300 variants but few events of its own
+    from kir_graph_amd.msa2hisat import Variant
+    dense = synth.makeIndex(seed=4, n_genes=1, len_range=(4000, 4200), var_range=(3500, 3600), allele_range=(20, 24),
+                            frac_del=0.02, frac_ins=0.01)
+    g = dense.genes[0]
+    taken = {(v.pos, v.val) for v in dense.variants if v.typ == "single"}
+    extra = []
+    for v in dense.variants:
+        if v.typ != "single":
+            continue
+        for alt in "ACGT":
+            if alt != chr(dense.backbone[g][v.pos]) and (v.pos, alt) not in taken:
+                taken.add((v.pos, alt))
+                extra.append(Variant(pos=v.pos, typ="single", ref=g, val=alt, allele=[g.split("*")[0] + "*99999"],
+                                     in_exon=v.in_exon))
+    dense.variants = sorted(dense.variants + extra)
+    for i, v in enumerate(dense.variants):
+        v.id = f"hv{i}"
+    dense_idx = GkIndex.fromVariants(dense.variants, genes=dense.genes, exons=dense.exons)
+    dense_sample = synth.makeSample(dense, seed=3, n_pairs=600, read_len=300, frag_mean=700.0, frag_sd=20.0,
+                                    err_rate=0.0005)
+    for index, smp, needs_walk in ((gidx, sample, False), (dense_idx, dense_sample, True)):
+        rec, _ = packed.packSample(smp, index)
+        dindex = DeviceIndex(device, index)
+        got = []
+        for two_walks in (False, True):
+            if two_walks:
+                monkeypatch.setenv("GK_TAB_TWO_WALKS", "1")
+            else:
+                monkeypatch.delenv("GK_TAB_TWO_WALKS", raising=False)
+            tab = Tabulation(dindex, rec)
+            got.append((tab.offsets().tobytes(), tab.ids().tobytes(), tab.n_novel))
+            longest = int(np.diff(tab.offsets()).max())
+            tab.close()
+        assert got[0] == got[1]
+        assert (longest > 256) == needs_walk
+        if needs_walk:   # ... and the dense case agrees with the oracle
+            ref = oracle_lists(smp, index)
+            tab = Tabulation(dindex, rec)
+            lists = device_lists(tab)
+            assert [tuple(map(tuple, (g["lpv"], g["rpv"], g["lnv"], g["rnv"]))) for g in lists] == \
+                   [tuple(map(tuple, (r["lpv"], r["rpv"], r["lnv"], r["rnv"]))) for r in ref["reads"]]
+            tab.close()
+        dindex.close()
