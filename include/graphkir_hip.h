@@ -249,7 +249,8 @@ int gk_bam_next(gk_bam* bam, char* text_out, int64_t capacity, int64_t* n_writte
 int gk_bam_pack(gk_bam* bam, struct gk_packer* packer);
 /* SAM text (header lines + alignment lines) -> BGZF-compressed BAM at `path`: the native form of
  * saveReadsToBam / samtobam (hisat2.py:869-901, `samtools sort`).  coordinate_sort != 0 orders the
- * records by (reference, position), stable, unmapped last; no .bai index is written. */
+ * records by (reference, position), stable, unmapped last, and writes the index `{path}.bai` next to the
+ * file (`samtools index`, utils.samtobam). */
 int gk_bam_write(const char* path, const char* sam_text, int64_t n_bytes, int32_t coordinate_sort);
 /* base counts per reference position, replacing pileup.getPileupBaseRatio (pileup.py:57-81: parse of
  * `samtools mpileup -a`; the defaults modelled are listed in csrc/gk_bamread.cpp).  gene_off[g] = first

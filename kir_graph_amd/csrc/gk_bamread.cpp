@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <map>
 #include <memory>
 #include <string>
 #include <thread>
@@ -1004,6 +1005,77 @@ extern "C" int gk_bam_write(const char* path, const char* sam_text, int64_t n_by
   for (auto& c : comp) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
   ok = fclose(f) == 0 && ok;
   if (!ok) { gk_set_error("short write to %s", path); return GK_ERR_ARG; }
+  if (!coordinate_sort) return GK_OK;
+
+  // ---- {path}.bai (SAM specification, section 5.2): what `samtools index` adds in utils.samtobam.
+  // Virtual offset of a byte of the BAM stream = file offset of its BGZF block << 16 | offset in the block.
+  std::vector<uint64_t> block_at(n_blocks + 1, 0);
+  for (size_t i = 0; i < n_blocks; ++i) block_at[i + 1] = block_at[i] + comp[i].size();
+  auto voffset = [&](size_t raw_off) { return block_at[raw_off / kBlock] << 16 | (uint64_t)(raw_off % kBlock); };
+  struct Chunk { uint64_t beg, end; };
+  struct RefIndex {
+    std::map<uint32_t, std::vector<Chunk>> bins;
+    std::vector<uint64_t> linear;
+    uint64_t first = 0, last = 0, n_mapped = 0, n_unmapped = 0;
+    bool any = false;
+  };
+  std::vector<RefIndex> index(refs.names.size());
+  uint64_t n_no_coor = 0;
+  size_t at = raw.size();
+  for (uint32_t i : order) at -= enc[i].rec.size();   // first record = end of the header part
+  for (uint32_t i : order) {
+    const std::string& rec = enc[i].rec;
+    const uint64_t v0 = voffset(at), v1 = voffset(at + rec.size());
+    at += rec.size();
+    const uint8_t* p = (const uint8_t*)rec.data() + 4;
+    const int32_t ref_id = rds32(p), pos = rds32(p + 4);
+    if (ref_id < 0 || (size_t)ref_id >= index.size() || pos < 0) { ++n_no_coor; continue; }
+    const uint32_t l_name = p[8], bin = rd16(p + 10), n_cig = rd16(p + 12), flag = rd16(p + 14);
+    int64_t span = 0;
+    for (uint32_t c = 0; c < n_cig; ++c) {
+      const uint32_t v = rd32(p + 32 + l_name + 4ull * c), op = v & 15u;
+      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += v >> 4;
+    }
+    const int64_t end = pos + (span > 0 ? span : 1);
+    RefIndex& ri = index[(size_t)ref_id];
+    auto& chunks = ri.bins[bin];
+    if (!chunks.empty() && chunks.back().end == v0) chunks.back().end = v1;   // adjacent records of one bin: one chunk
+    else chunks.push_back({v0, v1});
+    const size_t w0 = (size_t)(pos >> 14), w1 = (size_t)((end - 1) >> 14);
+    if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, 0);
+    for (size_t w = w0; w <= w1; ++w)
+      if (!ri.linear[w]) ri.linear[w] = v0;
+    if (!ri.any) { ri.first = v0; ri.any = true; }
+    ri.last = v1;
+    if (flag & 4u) ++ri.n_unmapped; else ++ri.n_mapped;
+  }
+  std::string bai("BAI\1", 4);
+  auto put64 = [&](uint64_t v) { put32(bai, (uint32_t)v); put32(bai, (uint32_t)(v >> 32)); };
+  put32(bai, (uint32_t)index.size());
+  for (RefIndex& ri : index) {
+    put32(bai, (uint32_t)(ri.bins.size() + (ri.any ? 1 : 0)));
+    for (auto& kv : ri.bins) {
+      put32(bai, kv.first);
+      put32(bai, (uint32_t)kv.second.size());
+      for (const Chunk& c : kv.second) { put64(c.beg); put64(c.end); }
+    }
+    if (ri.any) {   // the metadata pseudo-bin htslib writes: file range of the reference, mapped / unmapped counts
+      put32(bai, 37450u);
+      put32(bai, 2u);
+      put64(ri.first); put64(ri.last); put64(ri.n_mapped); put64(ri.n_unmapped);
+    }
+    for (size_t w = 1; w < ri.linear.size(); ++w)
+      if (!ri.linear[w]) ri.linear[w] = ri.linear[w - 1];   // windows nothing starts in point at the previous one
+    put32(bai, (uint32_t)ri.linear.size());
+    for (uint64_t v : ri.linear) put64(v);
+  }
+  put64(n_no_coor);
+  const std::string bai_path = std::string(path) + ".bai";
+  FILE* fi = fopen(bai_path.c_str(), "wb");
+  if (!fi) { gk_set_error("cannot write %s", bai_path.c_str()); return GK_ERR_ARG; }
+  ok = fwrite(bai.data(), 1, bai.size(), fi) == bai.size();
+  ok = fclose(fi) == 0 && ok;
+  if (!ok) { gk_set_error("short write to %s", bai_path.c_str()); return GK_ERR_ARG; }
   return GK_OK;
 }
 

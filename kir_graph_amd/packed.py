@@ -306,7 +306,7 @@ def bamHeader(path: str) -> str:
 
 def writeBam(path: str, sam_text: bytes | str, coordinate_sort: bool = True) -> None:
     """SAM text (header + alignment lines) -> BGZF BAM, natively (``gk_bam_write``): what
-    ``samtools sort`` of the SAM does for ``utils.samtobam`` (hisat2.py:869-901); no ``.bai``."""
+    ``samtools sort`` of the SAM does for ``utils.samtobam`` (hisat2.py:869-901); a coordinate-sorted file gets its ``.bai`` next to it."""
     from ._lib import check, lib
     if isinstance(sam_text, str):
         sam_text = sam_text.encode()

@@ -506,3 +506,110 @@ def test_name_collation_on_random_name_shapes(tmp_path):
         return _name_order(fx[0], fy[0]) or (int(fx[1]) & 192) - (int(fy[1]) & 192)
     want = sorted(lines, key=functools.cmp_to_key(order))
     assert got == want
+
+
+def _reg2bins(beg: int, end: int) -> list[int]:
+    """Bins that may hold records overlapping [beg, end) (SAM specification, section 5.3)."""
+    end -= 1
+    bins = [0]
+    for shift, base in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        bins += list(range(base + (beg >> shift), base + (end >> shift) + 1))
+    return bins
+
+
+def test_bam_index_finds_the_records_of_a_region(tmp_path):
+    """gk_bam_write writes {path}.bai next to a coordinate-sorted BAM (utils.samtobam: samtools sort + index).
+    The index is read back the way the specification prescribes -- candidate bins, linear-index floor, chunks
+    as virtual offsets into the BGZF file -- and must lead to exactly the records that overlap a region."""
+    import struct
+    import zlib
+    sidx = synth.makeIndex(seed=5, n_genes=3, var_range=(200, 300), allele_range=(10, 20), len_range=(30000, 40000))
+    sample = synth.makeSample(sidx, seed=4, n_pairs=4000)
+    lines = synth.toSamLines(sample)
+    header = ["@HD\tVN:1.0\tSO:unsorted"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+    path = str(tmp_path / "x.bam")
+    packed.writeBam(path, "\n".join(header + lines) + "\n")
+    raw = open(path, "rb").read()
+    bai = open(path + ".bai", "rb").read()
+
+    # ---- parse the index
+    assert bai[:4] == b"BAI\x01"
+    o = 4
+    (n_ref,) = struct.unpack_from("<i", bai, o); o += 4
+    assert n_ref == len(sidx.genes)
+    refs = []
+    for _ in range(n_ref):
+        (n_bin,) = struct.unpack_from("<i", bai, o); o += 4
+        bins, meta = {}, None
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", bai, o); o += 8
+            chunks = [struct.unpack_from("<QQ", bai, o + 16 * k) for k in range(n_chunk)]
+            o += 16 * n_chunk
+            if b == 37450:
+                meta = chunks
+            else:
+                bins[b] = chunks
+        (n_intv,) = struct.unpack_from("<i", bai, o); o += 4
+        linear = list(struct.unpack_from(f"<{n_intv}Q", bai, o)); o += 8 * n_intv
+        refs.append((bins, linear, meta))
+    (n_no_coor,) = struct.unpack_from("<Q", bai, o); o += 8
+    assert o == len(bai) and n_no_coor == 0
+
+    # ---- BGZF random access: virtual offset = file offset of a block << 16 | offset inside the inflated block
+    raw_at, stream, coff = {}, b"", 0
+    while coff < len(raw):
+        xlen = struct.unpack_from("<H", raw, coff + 10)[0]
+        bsize = struct.unpack_from("<H", raw, coff + 16)[0] + 1      # the BC subfield is the only one written
+        raw_at[coff] = len(stream)
+        stream += zlib.decompress(raw[coff + 12 + xlen:coff + bsize - 8], -15)
+        coff += bsize
+
+    def position(v):
+        return raw_at[v >> 16] + (v & 0xFFFF)
+
+    def records(beg_v, end_v):
+        at, stop = position(beg_v), position(end_v)
+        while at < stop:
+            size = struct.unpack_from("<i", stream, at)[0]
+            yield stream[at + 4:at + 4 + size]
+            at += 4 + size
+        assert at == stop
+
+    def span_of(rec):
+        ref_id, pos, l_name, _, _, n_cig = struct.unpack_from("<iiBBHH", rec, 0)
+        ops = struct.unpack_from(f"<{n_cig}I", rec, 32 + l_name)
+        ref_len = sum(v >> 4 for v in ops if (v & 15) in (0, 2, 3, 7, 8)) or 1
+        name = rec[32:32 + l_name - 1].decode()
+        return ref_id, pos, pos + ref_len, name, struct.unpack_from("<H", rec, 14)[0]
+
+    everything = {}
+    for l in lines:
+        f = l.split("\t")
+        ref_len = sum(int(n) for n, op in __import__("re").findall(r"(\d+)([MDN=X])", f[5])) or 1
+        everything.setdefault(sidx.genes.index(f[2]), []).append((int(f[3]) - 1, int(f[3]) - 1 + ref_len, f[0], int(f[1])))
+    rng = np.random.default_rng(2)
+    found = 0
+    for _ in range(40):
+        rid = int(rng.integers(0, n_ref))
+        glen = len(sidx.backbone[sidx.genes[rid]])
+        beg = int(rng.integers(0, glen - 10))
+        end = min(glen, beg + int(rng.choice([1, 50, 700, 20000])))
+        bins, linear, meta = refs[rid]
+        floor = linear[beg >> 14] if (beg >> 14) < len(linear) else (linear[-1] if linear else 0)
+        got = set()
+        for b in _reg2bins(beg, end):
+            for c_beg, c_end in bins.get(b, []):
+                if c_end <= floor:
+                    continue
+                for rec in records(c_beg, c_end):
+                    r, p0, p1, name, flag = span_of(rec)
+                    assert r == rid
+                    if p0 < end and p1 > beg:
+                        got.add((p0, p1, name, flag))
+        want = {t for t in everything.get(rid, []) if t[0] < end and t[1] > beg}
+        assert got == want, (rid, beg, end, len(got), len(want))
+        found += len(want)
+    assert found > 500
+    # metadata pseudo-bin: the counts of the reference
+    for rid, (bins, linear, meta) in enumerate(refs):
+        assert meta is not None and meta[1] == (len(everything[rid]), 0)
