@@ -200,6 +200,9 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
   constexpr int kPassAlleles = 64 * kSlots;
   constexpr int kPassWords = 2 * kSlots;   // bit-row words covering one pass
   __shared__ double tile[kPassAlleles * kTileLd];
+  __shared__ uint32_t wave_rows[kCompatWaves][64 * kPassWords];
+  // 0.999 = 0x3FEFF7CED916872B, 0.001 = 0x3F50624DD2F1A9FC
+  constexpr int32_t kHi999 = 0x3FEFF7CE, kLo999 = (int32_t)0xD916872B, kHi001 = 0x3F50624D, kLo001 = (int32_t)0xD2F1A9FC;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int w_base = a_base >> 5;   // a_base is a multiple of 256 = 8 words
@@ -251,34 +254,57 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
         nvar += (uint32_t)__builtin_popcountll(kept);
         const uint32_t n_pos = mid > base ? min(mid - base, 64u) : 0u;
         const uint64_t pos_lanes = n_pos >= 64 ? ~0ull : ((1ull << n_pos) - 1ull);
-        // The two bit-row words of a slot, read back from lane t, ARE the slot's 64 per-lane
-        // "allele has the variant" bits.
-        for (uint64_t todo = kept & pos_lanes; todo;) {
-          const int t = __builtin_ctzll(todo);
-          todo = clear_bit(todo, t);
-          uint64_t has[kSlots];
+        // The bit rows of the chunk go through LDS ([variant][word], per wave): for variant t every lane reads
+        // the word that holds its allele's bit (a two-address broadcast read), sign-extends that bit into a
+        // select mask (v_bfe_i32) and picks the factor's two halves with v_bfi_b32 -- 4 VALU operations per
+        // factor and slot, none of them cross-lane.
+        uint32_t* const wrows = &wave_rows[wid][0];
+#pragma unroll
+        for (int w = 0; w < kPassWords; ++w) wrows[lane * kPassWords + w] = mrow[w];
+        __builtin_amdgcn_wave_barrier();   // LDS operations of a wave are executed in order
+        const uint32_t* const my_words = wrows + (lane >> 5);
+        const int my_bit = lane & 31;
+        // one variant's words for the lane's slots / the factor they select; the walk reads the words of the
+        // next kept variant before it multiplies the current one in (two register sets, no copies)
+        auto fetch = [&](int t, uint32_t (&w)[kSlots]) {
+#pragma unroll
+          for (int s = 0; s < kSlots; ++s) w[s] = my_words[t * kPassWords + 2 * s];
+        };
+        auto apply = [&](const uint32_t (&w)[kSlots], bool positive) {
 #pragma unroll
           for (int s = 0; s < kSlots; ++s) {
-            const uint32_t lo = __builtin_amdgcn_readlane(mrow[2 * s], t);
-            const uint32_t hi = __builtin_amdgcn_readlane(mrow[2 * s + 1], t);
-            has[s] = (((uint64_t)hi) << 32) | lo;
-            if (kMiss) miss[s] += __builtin_amdgcn_inverse_ballot_w64(has[s]) ? 0u : 1u;
+            const int32_t m = __builtin_amdgcn_sbfe((int32_t)w[s], my_bit, 1);   // -1: the allele has the variant
+            if (positive) {
+              p[s] *= __hiloint2double((m & kHi999) | (~m & kHi001), (m & kLo999) | (~m & kLo001));   // 1.0 * f == f
+              if (kMiss) miss[s] += (uint32_t)(m + 1);
+            } else {
+              p[s] *= __hiloint2double((m & kHi001) | (~m & kHi999), (m & kLo001) | (~m & kLo999));
+              if (kMiss) miss[s] += (uint32_t)(-m);
+            }
           }
-          mul_by_bits<kSlots>(p, has, 0.999, 0.001);   // 1.0 * f == f: same bits as numpy's multiply.reduce
-        }
-        for (uint64_t todo = kept & ~pos_lanes; todo;) {
-          const int t = __builtin_ctzll(todo);
+        };
+        auto walk = [&](uint64_t todo, bool positive) {
+          if (!todo) return;
+          uint32_t wa[kSlots], wb[kSlots];
+          int t = __builtin_ctzll(todo);
           todo = clear_bit(todo, t);
-          uint64_t has[kSlots];
-#pragma unroll
-          for (int s = 0; s < kSlots; ++s) {
-            const uint32_t lo = __builtin_amdgcn_readlane(mrow[2 * s], t);
-            const uint32_t hi = __builtin_amdgcn_readlane(mrow[2 * s + 1], t);
-            has[s] = (((uint64_t)hi) << 32) | lo;
-            if (kMiss) miss[s] += __builtin_amdgcn_inverse_ballot_w64(has[s]) ? 1u : 0u;
+          fetch(t, wa);
+          for (;;) {
+            if (!todo) { apply(wa, positive); break; }
+            t = __builtin_ctzll(todo);
+            todo = clear_bit(todo, t);
+            fetch(t, wb);
+            apply(wa, positive);
+            if (!todo) { apply(wb, positive); break; }
+            t = __builtin_ctzll(todo);
+            todo = clear_bit(todo, t);
+            fetch(t, wa);
+            apply(wb, positive);
           }
-          mul_by_bits<kSlots>(p, has, 0.001, 0.999);
-        }
+        };
+        walk(kept & pos_lanes, true);
+        walk(kept & ~pos_lanes, false);
+        __builtin_amdgcn_wave_barrier();   // the next chunk overwrites the rows
       }
 #pragma unroll
       for (int s = 0; s < kSlots; ++s) {
