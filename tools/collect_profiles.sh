@@ -1,4 +1,5 @@
 set -e
+# the calibration tool is built on first use: hipcc --offload-arch=gfx950 -O3 tools/fetch_calib.hip -o tools/fetch_calib.bin
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r01
 mkdir -p $O
