@@ -1,6 +1,7 @@
 set -e
-# the calibration tool is built on first use: hipcc --offload-arch=gfx950 -O3 tools/fetch_calib.hip -o tools/fetch_calib.bin
 R=$GRAFT_REPO_ROOT
+# the calibration tool is built on first use
+[ -x $R/tools/fetch_calib.bin ] || hipcc --offload-arch=gfx950 -O3 $R/tools/fetch_calib.hip -o $R/tools/fetch_calib.bin
 O=$R/gpurun_out/r01
 mkdir -p $O
 cd $R
