@@ -57,11 +57,11 @@ __global__ void part_offsets(const uint32_t* hist, const uint32_t* total, int n_
   if (b == n_bins) goff[b] = *total;
 }
 
-// Tally of the surviving ids (AlleleTyping.errorCorrection 302-338 counts them per variant).  One
-// wavefront per row, grid-stride: the row's ids (lpv, rpv, lnv, rnv are contiguous in the CSR) are read
-// 64 at a time, coalesced; positives are the ids before the row's mid offset.  Counters of the gene's
-// index variants [vbeg, vend) are privatised in LDS (positive / negative halves) -- the ids of one row
-// are distinct, so the 64 atomics of a wave instruction hit different counters -- and flushed once per
+// Tally of the surviving ids (AlleleTyping.errorCorrection 302-338 counts them per variant).  Sixteen
+// lanes per row, grid-stride: the row's ids (lpv, rpv, lnv, rnv are contiguous in the CSR) are read
+// 16 at a time; positives are the ids before the row's mid offset.  Counters of the gene's index
+// variants [vbeg, vend) are privatised in LDS (positive / negative halves) -- the ids of one row are
+// distinct, so most atomics of a wave instruction hit different counters -- and flushed once per
 // workgroup; ordinals outside that range (novel variants) go straight to global atomics.
 __global__ __launch_bounds__(kThreads) void count_ids(const int32_t* __restrict__ rows, int64_t n_rows,
                                                       const uint32_t* __restrict__ off,
@@ -71,13 +71,16 @@ __global__ __launch_bounds__(kThreads) void count_ids(const int32_t* __restrict_
   extern __shared__ uint32_t hist[];   // [2][n_local]
   for (int i = threadIdx.x; i < 2 * n_local; i += kThreads) hist[i] = 0;
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * kThreads) >> 6;
-  for (int64_t i = wave; i < n_rows; i += n_waves) {
+  // a group of 16 lanes per row: four rows of a wavefront are in flight at a time (the loads of a row
+  // -- row number, offsets, ids, flags -- depend on each other, a list has ~75 ids)
+  constexpr int kGroup = 16;
+  const int lane = threadIdx.x & (kGroup - 1);
+  const int64_t group = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / kGroup;
+  const int64_t n_groups = ((int64_t)gridDim.x * kThreads) / kGroup;
+  for (int64_t i = group; i < n_rows; i += n_groups) {
     const int64_t row = rows[i];
     const uint32_t b = off[4 * row], mid = off[4 * row + 2], e = off[4 * row + 4];
-    for (uint32_t k = b + lane; k < e; k += 64) {
+    for (uint32_t k = b + lane; k < e; k += kGroup) {
       const uint32_t v = ids[k];
       const bool positive = k < mid;
       if (vflag[v] & (positive ? 1 : 2)) continue;
@@ -475,7 +478,7 @@ int gk_variant_count_range(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_r
   uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
   GK_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * nv) * sizeof(uint32_t), ctx->stream));
   if (n_rows) {
-    unsigned blocks = nblk(64 * n_rows);   // a wavefront per row
+    unsigned blocks = nblk(16 * n_rows);   // 16 lanes per row
     if (blocks > 1024) blocks = 1024;      // grid-stride: many rows per workgroup before the LDS flush (measured optimum)
     GK_PROF(ctx, GK_K_COUNT_IDS,
             GK_KERNEL(count_ids, dim3(blocks), dim3(kThreads), (size_t)n_local * 8, ctx->stream,
