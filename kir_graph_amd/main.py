@@ -28,7 +28,7 @@ from .external_tools import setEngine
 from .hisat2 import (SampleData, extractVariant, extractVariantFromPacked, extractVariantFromText,  # noqa: F401
                      packAlignments, readExons, readPair,
                      saveReadsToBam, writeCompact,
-                     writeReadsAndVariantsData)
+                     writeReadsAndVariantsData, writeSampleJson)
 from .index import GkIndex
 from .kir_cn import filterDepth, loadCN, predictSamplesCN
 from .kir_typing import defaultDevice, selectKirTypingModel
@@ -95,7 +95,7 @@ def readMapping(names, reads, index, index_ref, exon_region_only=False, alignmen
         else:   # BAM name-collated through samtools like the reference (hisat2.readBam)
             data = extractVariant(readPair(source), gk, dev=dev, dindex=dindex)
         if write_json:
-            writeReadsAndVariantsData(data.asDict(), name + ".json")
+            writeSampleJson(data, name + ".json")
             # the reference also rewrites the filtered pairs as BAM (hisat2.py:936-940)
             saveReadsToBam(data, name, source)
             saveReadsToBam(data, name + ".no_multi", source, filter_multi_mapped=True)

@@ -92,3 +92,25 @@ def test_json_roundtrip_path(device, tabulated, tmp_path):
     a = selectKirTypingModel("full", path, top_n=600, variant_correction=True, device=device).typing(sample.gene_cn)
     b = selectKirTypingModel("full", data, top_n=600, variant_correction=True).typing(sample.gene_cn)
     assert a == b
+
+
+def test_fast_json_writer_is_byte_identical(device, tmp_path):
+    """hisat2.writeSampleJson == writeReadsAndVariantsData(data.asDict()) (json.dump of dataclasses.asdict,
+    hisat2.py:847-856), with SAM text kept, novel variants, insertion values and empty lists in the file."""
+    from kir_graph_amd.hisat2 import extractVariantFromText, writeReadsAndVariantsData, writeSampleJson
+    from kir_graph_amd.index import GkIndex
+    from kir_graph_amd.msa2hisat import Variant
+    sidx = synth.makeIndex(seed=31, n_genes=2, var_range=(200, 300), allele_range=(10, 20))
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    for n_pairs in (9000, 3):       # more than two batches of the writer / less than one
+        sample = synth.makeSample(sidx, seed=8, n_pairs=n_pairs, err_rate=0.004)
+        lines = synth.toSamLines(sample)
+        Variant.novel_id = 0
+        data = extractVariantFromText([("\n".join(lines) + "\n").encode()], gidx, dev=device, keep_text=True)
+        a, b = str(tmp_path / f"a{n_pairs}.json"), str(tmp_path / f"b{n_pairs}.json")
+        writeReadsAndVariantsData(data.asDict(), a)
+        writeSampleJson(data, b)
+        assert open(a, "rb").read() == open(b, "rb").read()
+        if n_pairs > 100:
+            assert data.tab.n_novel > 0 and data.tab.n_valid > 8192
+        data.tab.close()

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Dev tool: wall time of the command line on a synthetic cohort of coordinate-sorted BAM files
+(native BAM ingest -> tabulation -> depth / CN -> typing -> cohort tables), per sample."""
+import os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kir_graph_amd import main as cli, packed, synth
+
+n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+n_samples = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+extra = sys.argv[3:]
+tmp = tempfile.mkdtemp()
+folder = os.path.join(tmp, "index")
+os.makedirs(folder)
+prefix = os.path.join(folder, "kir_2100_withexon_ab_2dl1s1.leftalign.mut01")
+sidx = synth.makeIndex(seed=2022)
+sidx.write(prefix)
+header = ["@HD\tVN:1.0\tSO:coordinate"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+bams, cns = [], []
+t = time.time()
+for k in range(n_samples):
+    s = synth.makeSample(sidx, seed=100 + k, n_pairs=n_pairs)
+    lines = synth.toSamLines(s)
+    path = os.path.join(tmp, f"s{k}.bam")
+    packed.writeBam(path, "\n".join(header + lines) + "\n")
+    bams.append(path)
+    cn = os.path.join(tmp, f"s{k}.cn.tsv")
+    with open(cn, "w") as f:
+        f.write("gene\tcn\n" + "".join(f"{g}\t{c}\n" for g, c in s.gene_cn.items()))
+    cns.append(cn)
+print(f"{n_samples} samples of {n_pairs} pairs written in {time.time() - t:.0f}s "
+      f"({os.path.getsize(bams[0]) / 1e6:.0f} MB each)", file=sys.stderr)
+out = os.path.join(tmp, "out")
+argv = ["--step-skip-extraction", "--index-folder", folder, "--output-folder", out, "--allele-strategy", "pv"]
+for b in bams:
+    argv += ["--alignment", b]
+argv += ["--cn-provided"] + cns
+args = cli.createParser().parse_args(argv + extra)
+t = time.time()
+cli.main(args)
+dt = time.time() - t
+print(f"command line: {dt:.2f}s for {n_samples} samples = {dt / n_samples:.2f}s per sample of {2 * n_pairs} reads "
+      f"({2 * n_pairs * n_samples / dt / 1e6:.2f} M reads/s end to end; flags {extra})")
