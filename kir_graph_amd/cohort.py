@@ -16,9 +16,9 @@ import os
 import numpy as np
 
 
-def prefetched(items, prepare, depth: int = 1):
-    """Yield ``prepare(item)`` for every item, in order, preparing up to ``depth`` items ahead on a
-    helper thread while the caller works on the current one.
+def prefetched(items, prepare, depth: int = 1, workers: int = 1):
+    """Yield ``prepare(item)`` for every item, in order, preparing up to ``depth`` items ahead on
+    ``workers`` helper threads while the caller works on the current one.
 
     Samples of a cohort are independent, so the ingest + tabulation of the next sample (native code:
     the GIL is released, its kernels run on the device's own stream) overlaps the typing of the
@@ -26,7 +26,7 @@ def prefetched(items, prepare, depth: int = 1):
     matching ``next()``."""
     from concurrent.futures import ThreadPoolExecutor
     items = iter(items)
-    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="gk-prefetch") as pool:
+    with ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="gk-prefetch") as pool:
         pending = []
         for item in items:
             pending.append(pool.submit(prepare, item))

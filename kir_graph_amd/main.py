@@ -86,7 +86,9 @@ def readMapping(names, reads, index, index_ref, exon_region_only=False, alignmen
         return name, source, pack
 
     # the next sample is mapped / packed on a helper thread while this one is tabulated and written out
-    for name, source, pack in cohort.prefetched(range(len(names)), prepare):
+    # (three samples ahead on three threads: the serial stretches of one ingest leave cores to the others)
+    ahead = max(1, int(os.environ.get("GK_INGEST_AHEAD", "3")))
+    for name, source, pack in cohort.prefetched(range(len(names)), prepare, depth=ahead, workers=ahead):
         bam_files.append(source)
         name += ".variant"
         logger.info(f"[Graph] Filter mapping ({name})")
