@@ -252,6 +252,20 @@ int gk_bam_pack(gk_bam* bam, struct gk_packer* packer);
  * records by (reference, position), stable, unmapped last, and writes the index `{path}.bai` next to the
  * file (`samtools index`, utils.samtobam). */
 int gk_bam_write(const char* path, const char* sam_text, int64_t n_bytes, int32_t coordinate_sort);
+/* the same for selected lines (0-based line numbers of `sam_text`, in the given order) under the '@'
+ * lines of `header_text`: the .bam / .no_multi.bam rewrites of the filter-passing pairs
+ * (hisat2.saveReadsToBam 880-901) without assembling their text first. */
+int gk_bam_write_lines(const char* path, const char* header_text, int64_t n_header, const char* sam_text,
+                       int64_t n_bytes, const int64_t* line_idx, int64_t n_lines, int32_t coordinate_sort);
+/* Appends the "reads" array of a .variant.json to the file at `path`, as json.dump would write
+ * [dataclasses.asdict(PairRead), ...] (hisat2.writeReadsAndVariantsData 847-856): row i < n_rows has
+ * l_sam / r_sam = lines pair_lines[2 src[i]] / pair_lines[2 src[i] + 1] of `sam_text`, multiple = nh[i],
+ * backbone = genes[gene_of[i]], and the names of ids over the row's four CSR segments off[4i .. 4i+4]
+ * (lpv, rpv, lnv, rnv). */
+int gk_json_write_reads(const char* path, const char* sam_text, int64_t n_bytes, const int64_t* pair_lines,
+                        int64_t n_pairs, const int64_t* src, int64_t n_rows, const uint32_t* off,
+                        const uint32_t* ids, const char* const* names, int64_t n_names,
+                        const char* const* genes, int32_t n_genes, const uint8_t* gene_of, const uint8_t* nh);
 /* base counts per reference position, replacing pileup.getPileupBaseRatio (pileup.py:57-81: parse of
  * `samtools mpileup -a`; the defaults modelled are listed in csrc/gk_bamread.cpp).  gene_off[g] = first
  * position of reference g (header order) in the concatenated position space, gene_off[n_gene] = total;

@@ -103,6 +103,11 @@ _SIGS = {
     "gk_bam_header": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "gk_bam_pileup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gk_bam_write": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int64, C.c_int32]),
+    "gk_bam_write_lines": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64,
+                                     C.c_int32]),
+    "gk_json_write_reads": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
+                                      C.c_void_p, C.c_void_p]),
     "gk_bam_pack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gk_bam_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "gk_compat_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_int32, C.c_int32,

@@ -911,12 +911,10 @@ bool deflate_block(const uint8_t* data, size_t n, std::string& out) {
 
 }  // namespace
 
-extern "C" int gk_bam_write(const char* path, const char* sam_text, int64_t n_bytes, int32_t coordinate_sort) {
-  if (!path || (!sam_text && n_bytes)) { gk_set_error("null argument"); return GK_ERR_ARG; }
-  std::string_view text(sam_text, (size_t)n_bytes);
-  std::string header;
-  SamHeaderRefs refs;
-  std::vector<std::string_view> lines;
+namespace {
+
+// lines of a text: '@' lines go to the header (and its @SQ records to refs), the others to `lines`
+void split_sam_text(std::string_view text, std::string& header, SamHeaderRefs& refs, std::vector<std::string_view>* lines) {
   for (size_t a = 0; a < text.size();) {
     size_t nl = text.find('\n', a);
     if (nl == std::string_view::npos) nl = text.size();
@@ -938,10 +936,51 @@ extern "C" int gk_bam_write(const char* path, const char* sam_text, int64_t n_by
         }
         refs.names.push_back(name); refs.lengths.push_back((uint32_t)len);
       }
-    } else {
-      lines.push_back(line);
+    } else if (lines) {
+      lines->push_back(line);
     }
   }
+}
+
+int write_bam_lines(const char* path, const std::string& header, const SamHeaderRefs& refs,
+                    const std::vector<std::string_view>& lines, int32_t coordinate_sort);
+
+}  // namespace
+
+extern "C" int gk_bam_write(const char* path, const char* sam_text, int64_t n_bytes, int32_t coordinate_sort) {
+  if (!path || (!sam_text && n_bytes)) { gk_set_error("null argument"); return GK_ERR_ARG; }
+  std::string header;
+  SamHeaderRefs refs;
+  std::vector<std::string_view> lines;
+  split_sam_text(std::string_view(sam_text, (size_t)n_bytes), header, refs, &lines);
+  return write_bam_lines(path, header, refs, lines, coordinate_sort);
+}
+
+// The selected lines of a SAM text (0-based line numbers, in the given order) under the given header: the
+// .bam / .no_multi.bam rewrites of the filter-passing pairs (hisat2.py:869-901) without building their text.
+extern "C" int gk_bam_write_lines(const char* path, const char* header_text, int64_t n_header, const char* sam_text,
+                                  int64_t n_bytes, const int64_t* line_idx, int64_t n_lines, int32_t coordinate_sort) {
+  if (!path || (!sam_text && n_bytes) || (!line_idx && n_lines) || (!header_text && n_header)) {
+    gk_set_error("null argument");
+    return GK_ERR_ARG;
+  }
+  std::string header;
+  SamHeaderRefs refs;
+  split_sam_text(std::string_view(header_text, (size_t)n_header), header, refs, nullptr);
+  const std::string_view text(sam_text, (size_t)n_bytes);
+  const std::vector<int64_t> starts = gk_line_starts(text);
+  std::vector<std::string_view> lines((size_t)n_lines);
+  for (int64_t i = 0; i < n_lines; ++i) {
+    if (line_idx[i] < 0 || (size_t)line_idx[i] + 1 >= starts.size()) { gk_set_error("line number out of range"); return GK_ERR_ARG; }
+    lines[(size_t)i] = gk_line_at(text, starts, line_idx[i]);
+  }
+  return write_bam_lines(path, header, refs, lines, coordinate_sort);
+}
+
+namespace {
+
+int write_bam_lines(const char* path, const std::string& header, const SamHeaderRefs& refs,
+                    const std::vector<std::string_view>& lines, int32_t coordinate_sort) {
   struct Enc { std::string rec; int32_t ref_id, pos0; };
   std::vector<Enc> enc(lines.size());
   std::vector<char> bad((size_t)std::max(ingest_threads(), 1), 0);
@@ -1078,6 +1117,8 @@ extern "C" int gk_bam_write(const char* path, const char* sam_text, int64_t n_by
   if (!ok) { gk_set_error("short write to %s", bai_path.c_str()); return GK_ERR_ARG; }
   return GK_OK;
 }
+
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // Base counts per reference position: the native form of pileup.getPileupBaseRatio (pileup.py:57-81),

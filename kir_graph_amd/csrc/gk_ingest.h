@@ -5,6 +5,9 @@
 #include <functional>
 #include <string>
 #include <string_view>
+#include <algorithm>
+#include <cstring>
+#include <vector>
 
 #include <chrono>
 #include <cstdio>
@@ -47,3 +50,30 @@ struct GkAlnRecord {         // fields of filterRead / getNH / recordToRawVarian
 int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
                            const std::function<void(int64_t, GkAlnKey&)>& key,
                            const std::function<void(int64_t, GkAlnRecord&)>& full);
+
+// start offset of every line of a text (a final line without '\n' counts), plus the end as sentinel
+inline std::vector<int64_t> gk_line_starts(std::string_view text) {
+  std::vector<int64_t> starts;
+  const char* base = text.data();
+  size_t a = 0;
+  while (a < text.size()) {
+    starts.push_back((int64_t)a);
+    const void* nl = memchr(base + a, '\n', text.size() - a);
+    if (!nl) { a = text.size(); break; }
+    a = (size_t)((const char*)nl - base) + 1;
+  }
+  starts.push_back((int64_t)text.size() + (text.empty() || text.back() == '\n' ? 0 : 1));
+  return starts;
+}
+
+// line i without its line terminator ("\n" or "\r\n")
+inline std::string_view gk_line_at(std::string_view text, const std::vector<int64_t>& starts, int64_t i) {
+  if (i < 0 || (size_t)i + 1 >= starts.size()) return std::string_view();
+  size_t a = (size_t)starts[(size_t)i], b = (size_t)starts[(size_t)i + 1];
+  if (b > a) --b;                                   // the '\n' (or the sentinel's virtual one)
+  b = std::min(b, text.size());
+  std::string_view line = text.substr(a, b - a);
+  if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+  return line;
+}
+

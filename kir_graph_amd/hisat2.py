@@ -126,6 +126,31 @@ def filterRead(line: str, num_editdist: int = 4) -> bool:
 
 
 # ---------------------------------------------------------------- device hand-off
+class PairsText:
+    """The SAM lines of the emitted pairs, kept as the collated text + (left, right) line numbers instead of
+    two Python strings per pair; ``pairs[i]`` gives ``(l_sam, r_sam)`` like the list it replaces, the
+    native writers (``gk_json_write_reads`` / ``gk_bam_write_lines``) take the text and the numbers."""
+
+    def __init__(self, blob: bytes, pair_lines: np.ndarray):
+        self.blob = blob
+        self.pair_lines = np.ascontiguousarray(pair_lines, dtype=np.int64).reshape(-1, 2)
+        self._starts: np.ndarray | None = None
+
+    def __len__(self) -> int:
+        return len(self.pair_lines)
+
+    def _line(self, k: int) -> str:
+        if self._starts is None:
+            nl = np.flatnonzero(np.frombuffer(self.blob, dtype=np.uint8) == 10)
+            self._starts = np.concatenate([[0], nl + 1, [len(self.blob) + 1]]).astype(np.int64)
+        a, b = int(self._starts[k]), int(self._starts[k + 1]) - 1
+        return self.blob[a:b].decode().rstrip("\r")
+
+    def __getitem__(self, i: int) -> tuple[str, str]:
+        a, b = self.pair_lines[i]
+        return self._line(int(a)), self._line(int(b))
+
+
 class SampleData:
     """Tabulated sample: device CSR (``Tabulation``) + variant table + gene tables."""
 
@@ -327,10 +352,7 @@ def packAlignments(source, index: GkIndex, keep_text: bool = True) -> dict:
         if keep_text:
             chunks = list(chunks)
         rec, table, pair_lines, counts = packText(chunks, index)
-    pairs_text = None
-    if keep_text:
-        lines = b"".join(chunks).decode().split("\n")
-        pairs_text = [(lines[a].rstrip("\r"), lines[b].rstrip("\r")) for a, b in pair_lines.tolist()]
+    pairs_text = PairsText(b"".join(chunks), pair_lines) if keep_text else None
     return {"records": rec, "strings": table.strings, "pairs_text": pairs_text, "counts": counts}
 
 
@@ -382,6 +404,28 @@ def writeSampleJson(data: "SampleData", filename: str) -> None:
                  "allele": v.allele, "freq": v.freq, "ignore": v.ignore, "in_exon": v.in_exon} for v in data.variants]
     assert [f.name for f in dataclass_fields(Variant)] == list(variants[0]) if variants else True
     assert [f.name for f in dataclass_fields(PairRead)] == ["l_sam", "r_sam", "multiple", "backbone", "lpv", "lnv", "rpv", "rnv"]
+    if isinstance(text, PairsText):   # the reads array is formatted natively from the collated text
+        import ctypes as C
+        with open(filename, "w") as f:
+            f.write('{"variants": ')
+            f.write(json.dumps(variants))
+            f.write(', "reads": ')
+        names = tab.idNames()
+        c_names = (C.c_char_p * max(1, len(names)))(*[n.encode() for n in names])
+        c_genes = (C.c_char_p * max(1, len(data.index.genes)))(*[g.encode() for g in data.index.genes])
+        off32 = np.ascontiguousarray(tab.offsets(), dtype=np.uint32)
+        ids32 = np.ascontiguousarray(ids, dtype=np.uint32)
+        src64 = np.ascontiguousarray(src, dtype=np.int64)
+        gene8 = np.ascontiguousarray(tab.pairGene(), dtype=np.uint8)
+        nh8 = np.ascontiguousarray(tab.pairNH(), dtype=np.uint8)
+        check(lib().gk_json_write_reads(filename.encode(), text.blob, len(text.blob), text.pair_lines.ctypes.data,
+                                        len(text.pair_lines), src64.ctypes.data, tab.n_valid, off32.ctypes.data,
+                                        ids32.ctypes.data if len(ids32) else None, c_names, len(names), c_genes,
+                                        len(data.index.genes), gene8.ctypes.data if len(gene8) else None,
+                                        nh8.ctypes.data if len(nh8) else None))
+        with open(filename, "a") as f:
+            f.write("}")
+        return
     with open(filename, "w") as f:
         f.write('{"variants": ')
         f.write(json.dumps(variants))
@@ -441,7 +485,14 @@ def saveReadsToBam(data: "SampleData", filename_prefix: str, bam_file: str, filt
     tab = data.tab
     src = tab.pairSrc() if tab.info.d_pair_src else np.arange(tab.n_valid)
     keep = src[tab.pairNH() == 1] if filter_multi_mapped else src
-    body = "".join(f"{data.pairs_text[int(i)][0]}\n{data.pairs_text[int(i)][1]}\n" for i in keep)
+    text = data.pairs_text
+    if isinstance(text, PairsText):   # the selected lines go to the encoder as line numbers
+        header = alignmentHeader(bam_file).encode()
+        picked = np.ascontiguousarray(text.pair_lines[np.asarray(keep, dtype=np.int64)].reshape(-1), dtype=np.int64)
+        check(lib().gk_bam_write_lines((filename_prefix + ".bam").encode(), header, len(header), text.blob, len(text.blob),
+                                       picked.ctypes.data if len(picked) else None, len(picked), 1))
+        return
+    body = "".join(f"{text[int(i)][0]}\n{text[int(i)][1]}\n" for i in keep)
     writeBam(filename_prefix + ".bam", alignmentHeader(bam_file) + body)
 
 

@@ -109,7 +109,10 @@ def test_fast_json_writer_is_byte_identical(device, tmp_path):
         data = extractVariantFromText([("\n".join(lines) + "\n").encode()], gidx, dev=device, keep_text=True)
         a, b = str(tmp_path / f"a{n_pairs}.json"), str(tmp_path / f"b{n_pairs}.json")
         writeReadsAndVariantsData(data.asDict(), a)
-        writeSampleJson(data, b)
+        writeSampleJson(data, b)                      # native: the collated text + line numbers (hisat2.PairsText)
+        assert open(a, "rb").read() == open(b, "rb").read()
+        data.pairs_text = [data.pairs_text[i] for i in range(len(data.pairs_text))]
+        writeSampleJson(data, b)                      # ... and from a plain list of (l_sam, r_sam)
         assert open(a, "rb").read() == open(b, "rb").read()
         if n_pairs > 100:
             assert data.tab.n_novel > 0 and data.tab.n_valid > 8192
