@@ -613,3 +613,40 @@ def test_bam_index_finds_the_records_of_a_region(tmp_path):
     # metadata pseudo-bin: the counts of the reference
     for rid, (bins, linear, meta) in enumerate(refs):
         assert meta is not None and meta[1] == (len(everything[rid]), 0)
+
+
+def test_native_json_reads_array_matches_json_dumps(tmp_path):
+    """gk_json_write_reads == json.dumps([asdict(PairRead), ...]): escapes of quotes, backslashes, control
+    characters, DEL and non-ASCII text (BMP and beyond), CRLF line ends, empty id lists, a last line
+    without a line feed."""
+    import ctypes as C
+    import json
+    from kir_graph_amd._lib import check, lib
+    lines = ['r1\t99\tg*BACKBONE\t1\t60\t4M\t=\t9\t12\tACGT\tII"I\\\tXX:Z:tab\there',
+             'r1\t147\tg*BACKBONE\t9\t60\t4M\t=\t1\t-12\tACGT\tIIII\tCO:Z:café 中 \U0001F9EC \x01\x7f',
+             "r2\t99\tg*BACKBONE\t5\t60\t4M\t=\t7\t6\tACGT\tIIII\r",
+             "r2\t147\tg*BACKBONE\t7\t60\t4M\t=\t5\t-6\tACGT\tIIII"]
+    text = "\n".join(lines).encode()                      # no final line feed
+    pair_lines = np.array([[1, 0], [3, 2]], dtype=np.int64)
+    src = np.array([1, 0, 1], dtype=np.int64)             # rows may repeat / reorder pairs
+    names = ["hv0", "hv1", 'n"v\\2', "nv3"]
+    genes = ["g*BACKBONE", "KIRé"]
+    off = np.array([0, 2, 2, 3, 4,   4, 4, 4, 4,   5, 6, 6, 8], dtype=np.uint32)   # row 1 has four empty lists
+    ids = np.array([0, 1, 2, 3, 3, 0, 1, 2], dtype=np.uint32)
+    gene_of = np.array([0, 1, 0], dtype=np.uint8)
+    nh = np.array([1, 7, 255], dtype=np.uint8)
+    path = str(tmp_path / "reads.json")
+    c_names = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    c_genes = (C.c_char_p * len(genes))(*[g.encode() for g in genes])
+    check(lib().gk_json_write_reads(path.encode(), text, len(text), pair_lines.ctypes.data, len(pair_lines),
+                                    src.ctypes.data, len(src), off.ctypes.data, ids.ctypes.data, c_names, len(names),
+                                    c_genes, len(genes), gene_of.ctypes.data, nh.ctypes.data))
+    want = []
+    for i in range(len(src)):
+        o = off[4 * i:4 * i + 5]
+        l, r = (lines[k].rstrip("\r") for k in pair_lines[src[i]])
+        want.append({"l_sam": l, "r_sam": r, "multiple": int(nh[i]), "backbone": genes[gene_of[i]],
+                     "lpv": [names[v] for v in ids[o[0]:o[1]]], "lnv": [names[v] for v in ids[o[2]:o[3]]],
+                     "rpv": [names[v] for v in ids[o[1]:o[2]]], "rnv": [names[v] for v in ids[o[3]:o[4]]]})
+    assert open(path).read() == json.dumps(want)
+    assert json.loads(open(path).read()) == want
