@@ -94,6 +94,92 @@ def cpu_baseline(sidx, gidx, gene_cn, method, n_pairs, seed):
                       f"typing {t2 - t1:.1f}s)"}
 
 
+def worker(j, procs, opts, rank, local_rank, gang, rank_barrier=None, timing=None):
+    """Worker j of `procs` on this rank's GPU: builds the inputs, warms up, then types its share of the
+    rank's `steps` samples between the common start and end.
+
+    One Python process drives the GPU through ~25 host threads at most (gene workers, prefetch) and its
+    interpreter lock serialises their host work; samples are independent, so a rank runs GK_PROCS_PER_GPU
+    processes on its GPU (default 3, with 4 gene threads each), the same way a cohort run may place
+    several ranks on one GPU.  Worker 0 is the rank's own process and keeps the clock: the timed region
+    starts when every worker (and every rank) is ready and ends when every worker's last sample is typed."""
+    from types import SimpleNamespace
+    args = SimpleNamespace(**opts)
+    from kir_graph_amd import _lib
+    from kir_graph_amd.engine import DeviceIndex
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_dev = max(1, _lib.deviceCount())
+    dev = _lib.Device(local_rank % n_dev if world > 1 else 0)
+    sidx, gidx, sample, rec, table = build_inputs(seed=1031 + rank, n_pairs=args.pairs)
+    gene_cn = sample.gene_cn
+    dindex = DeviceIndex(dev, gidx)
+    mates = dev.put(rec)
+    dev.sync()
+    my_steps = args.steps // procs + (1 if j < args.steps % procs else 0)
+
+    def all_devices():
+        return list(_lib.Device.instances)
+
+    def gang_wait(name):
+        if gang is not None:
+            gang[name].wait(timeout=300)
+
+    if args.warmup:
+        run_steps(args.warmup, dev, dindex, gidx, mates, table, gene_cn, args.method)
+    if j == 0 and getattr(args, "profile_host", False):
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        run_steps(1, dev, dindex, gidx, mates, table, gene_cn, args.method)
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
+    for d in all_devices():
+        d.profEnable(True)
+        d.profCollect()
+        d.call_log = []
+    dev.sync()
+    gang_wait("ready")
+    if rank_barrier is not None:
+        rank_barrier()
+    gang_wait("go")
+    t0 = time.perf_counter()
+    n_valid = 0
+    if my_steps:
+        calls, warn, n_valid, typer = run_steps(my_steps, dev, dindex, gidx, mates, table, gene_cn, args.method)
+    for d in all_devices():
+        d.sync()
+    gang_wait("done")
+    if rank_barrier is not None:
+        rank_barrier()
+    if timing is not None:
+        timing["elapsed"] = time.perf_counter() - t0
+    prof, call_log = {}, []
+    for d in all_devices():
+        for k, (n, ms) in d.profCollect().items():
+            n0, ms0 = prof.get(k, (0, 0.0))
+            prof[k] = (n0 + n, ms0 + ms)
+        call_log += d.call_log or []
+        d.profEnable(False)
+    if j:
+        gang["results"].put({"prof": prof, "call_log": call_log})
+        return None
+    alone = None
+    if procs > 1:   # the same launches with the GPU to this process alone (the other workers are done): untimed
+        for d in all_devices():
+            d.profEnable(True)
+            d.profCollect()
+        run_steps(2, dev, dindex, gidx, mates, table, gene_cn, args.method)
+        alone = {}
+        for d in all_devices():
+            for k, (n, ms) in d.profCollect().items():
+                n0, ms0 = alone.get(k, (0, 0.0))
+                alone[k] = (n0 + n, ms0 + ms)
+            d.profEnable(False)
+    return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "sidx": sidx, "gidx": gidx, "gene_cn": gene_cn,
+            "alone": alone}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +195,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Worker processes of this rank on its GPU (see worker()): started first, before anything touches HIP.
+    procs = max(1, int(os.environ.get("GK_PROCS_PER_GPU", "3")))
+    procs = min(procs, max(1, args.steps))
+    if procs > 1:
+        os.environ.setdefault("GK_THREADS", "4")   # gene threads per process: three processes share the host cores
+    gang = None
+    if procs > 1:
+        import multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        gang = {"ready": ctx.Barrier(procs), "go": ctx.Barrier(procs), "done": ctx.Barrier(procs), "results": ctx.Queue()}
+        helpers = [ctx.Process(target=worker, args=(j, procs, vars(args), rank, local_rank, gang), daemon=True)
+                   for j in range(1, procs)]
+        try:
+            for h in helpers:
+                h.start()
+        except OSError as e:   # no child processes here (e.g. under a profiler that forbids them): one process
+            log(f"[bench] cannot start worker processes ({e}); running in one process")
+            for h in helpers:
+                if h.is_alive():
+                    h.terminate()
+            procs, gang = 1, None
+
     dist = None
     backend = os.environ.get("GK_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N > 1 path on one GPU
     if world > 1:
@@ -121,18 +229,7 @@ def main():
             dist_.init_process_group(backend)
         dist = dist_
 
-    from kir_graph_amd import _lib
-    from kir_graph_amd.engine import DeviceIndex
-    n_dev = max(1, _lib.deviceCount())
-    dev = _lib.Device(local_rank % n_dev if world > 1 else 0)
-    sidx, gidx, sample, rec, table = build_inputs(seed=1031 + rank, n_pairs=args.pairs)
-    gene_cn = sample.gene_cn
-    dindex = DeviceIndex(dev, gidx)
-    mates = dev.put(rec)
-    dev.sync()
-
-    def barrier():
-        dev.sync()
+    def rank_barrier():
         if dist is not None:
             import torch
             if backend == "nccl":
@@ -141,35 +238,17 @@ def main():
             if backend == "nccl":
                 torch.cuda.synchronize()
 
-    if args.warmup:
-        run_steps(args.warmup, dev, dindex, gidx, mates, table, gene_cn, args.method)
-    if args.profile_host:
-        import cProfile
-        import pstats
-        pr = cProfile.Profile()
-        pr.enable()
-        run_steps(1, dev, dindex, gidx, mates, table, gene_cn, args.method)
-        pr.disable()
-        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
-    def all_devices():
-        return list(_lib.Device.instances)
-
-    for d in all_devices():
-        d.profEnable(True)
-        d.profCollect()
-        d.call_log = []
-    barrier()
-    t0 = time.perf_counter()
-    calls, warn, n_valid, typer = run_steps(args.steps, dev, dindex, gidx, mates, table, gene_cn, args.method)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof, call_log = {}, []
-    for d in all_devices():
-        for k, (n, ms) in d.profCollect().items():
+    timing = {}
+    res = worker(0, procs, vars(args), rank, local_rank, gang, rank_barrier=rank_barrier, timing=timing)
+    elapsed = timing["elapsed"]
+    prof, call_log, n_valid = res["prof"], res["call_log"], res["n_valid"]
+    sidx, gidx, gene_cn = res["sidx"], res["gidx"], res["gene_cn"]
+    for _ in range(procs - 1):
+        other = gang["results"].get(timeout=600)
+        for k, (n, ms) in other["prof"].items():
             n0, ms0 = prof.get(k, (0, 0.0))
             prof[k] = (n0 + n, ms0 + ms)
-        call_log += d.call_log or []
-        d.profEnable(False)
+        call_log += other["call_log"]
 
     if dist is not None:
         import torch
@@ -188,6 +267,16 @@ def main():
                 log(f"[bench] {k:18s} launches {n:6d}  total {ms:9.3f} ms  avg {ms / n:8.4f} ms")
             log(f"[bench] kernel time {total_kernel_ms / args.steps:.2f} ms of {ms_per_step:.2f} ms per step")
         roof = roofline(dom, call_log)
+        if res.get("alone") and dom[0] in res["alone"]:
+            # launch durations in the timed region include the time the kernel shares the GPU with the kernels of
+            # the other worker processes; the same launches right after it, one process on the GPU:
+            n1, ms1 = res["alone"][dom[0]]
+            scale = (dom[1][1] / dom[1][0]) / (ms1 / n1) if n1 and ms1 else None
+            roof["one_process"] = {"avg_launch_ms": ms1 / n1, "launches": n1,
+                                   "achieved": roof["achieved"] * scale if scale else None,
+                                   "frac": roof["frac"] * scale if scale else None,
+                                   "valu_frac": roof["valu"]["frac"] * scale if scale and "valu" in roof else None,
+                                   "note": "2 untimed steps after the timed region, no other worker on the GPU"}
         out = {
             "metric": "typed 150 bp PE reads/s (pileup+EM) per GPU; achieved HBM GB/s vs roofline",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -197,7 +286,8 @@ def main():
                                    f"synthetic example_index-shaped index ({sum(len(t.alleles) for t in gidx.tables)} "
                                    f"alleles, 15 genes), --allele-strategy {args.method}, top_n 600",
                        "pairs_per_sample": args.pairs, "pairs_passing_filter": int(n_valid),
-                       "parallelism": f"samples sharded over {world} GPU(s), no data-path collective"},
+                       "parallelism": f"samples sharded over {world} GPU(s), no data-path collective; "
+                                      f"{procs} worker process(es) per GPU, {os.environ.get('GK_THREADS', '6')} gene threads each"},
             "roofline": roof,
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
         }
