@@ -132,7 +132,11 @@ def initFromEnv(backend: str | None = None):
     import torch
     import torch.distributed as dist
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # more ranks than GPUs on this node (several processes per GPU, each with its own interpreter lock):
+        # RCCL wants one rank per device, and the only exchange is a few hundred bytes -- gloo carries it
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        one_per_gpu = torch.cuda.is_available() and local_world <= torch.cuda.device_count()
+        backend = "nccl" if one_per_gpu else "gloo"
     if backend == "nccl":
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
