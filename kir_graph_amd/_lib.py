@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -151,6 +152,14 @@ def lib():
             raise GkError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). The typing path has no CPU fallback.")
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "torch" not in sys.modules:
+            # A multi-rank run also uses torch.distributed, and PyTorch ships its own copy of the HIP runtime:
+            # when it is loaded first, this library binds to that copy and the process has ONE runtime; the
+            # other order leaves two, and the second one to initialise finds no device.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         handle = C.CDLL(str(path))
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)

@@ -8,27 +8,30 @@ from kir_graph_amd import main as cli, packed, synth
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 n_samples = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 extra = sys.argv[3:]
-tmp = tempfile.mkdtemp()
+# under torchrun every rank runs this script: rank 0 writes the inputs, the others wait for them
+rank = int(os.environ.get("RANK", "0"))
+tmp = os.path.join(tempfile.gettempdir(), f"gk_cli_{n_pairs}_{n_samples}_{os.environ.get('MASTER_PORT', os.getppid())}")
 folder = os.path.join(tmp, "index")
-os.makedirs(folder)
 prefix = os.path.join(folder, "kir_2100_withexon_ab_2dl1s1.leftalign.mut01")
-sidx = synth.makeIndex(seed=2022)
-sidx.write(prefix)
-header = ["@HD\tVN:1.0\tSO:coordinate"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
-bams, cns = [], []
-t = time.time()
-for k in range(n_samples):
-    s = synth.makeSample(sidx, seed=100 + k, n_pairs=n_pairs)
-    lines = synth.toSamLines(s)
-    path = os.path.join(tmp, f"s{k}.bam")
-    packed.writeBam(path, "\n".join(header + lines) + "\n")
-    bams.append(path)
-    cn = os.path.join(tmp, f"s{k}.cn.tsv")
-    with open(cn, "w") as f:
-        f.write("gene\tcn\n" + "".join(f"{g}\t{c}\n" for g, c in s.gene_cn.items()))
-    cns.append(cn)
-print(f"{n_samples} samples of {n_pairs} pairs written in {time.time() - t:.0f}s "
-      f"({os.path.getsize(bams[0]) / 1e6:.0f} MB each)", file=sys.stderr)
+bams = [os.path.join(tmp, f"s{k}.bam") for k in range(n_samples)]
+cns = [os.path.join(tmp, f"s{k}.cn.tsv") for k in range(n_samples)]
+if rank == 0:
+    os.makedirs(folder, exist_ok=True)
+    sidx = synth.makeIndex(seed=2022)
+    sidx.write(prefix)
+    header = ["@HD\tVN:1.0\tSO:coordinate"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+    t = time.time()
+    for k in range(n_samples):
+        s = synth.makeSample(sidx, seed=100 + k, n_pairs=n_pairs)
+        lines = synth.toSamLines(s)
+        packed.writeBam(bams[k], "\n".join(header + lines) + "\n")
+        with open(cns[k], "w") as f:
+            f.write("gene\tcn\n" + "".join(f"{g}\t{c}\n" for g, c in s.gene_cn.items()))
+    print(f"{n_samples} samples of {n_pairs} pairs written in {time.time() - t:.0f}s "
+          f"({os.path.getsize(bams[0]) / 1e6:.0f} MB each)", file=sys.stderr)
+    open(os.path.join(tmp, "ready"), "w").close()
+while not os.path.exists(os.path.join(tmp, "ready")):
+    time.sleep(0.2)
 out = os.path.join(tmp, "out")
 argv = ["--step-skip-extraction", "--index-folder", folder, "--output-folder", out, "--allele-strategy", "pv"]
 for b in bams:
@@ -38,5 +41,6 @@ args = cli.createParser().parse_args(argv + extra)
 t = time.time()
 cli.main(args)
 dt = time.time() - t
-print(f"command line: {dt:.2f}s for {n_samples} samples = {dt / n_samples:.2f}s per sample of {2 * n_pairs} reads "
+if rank == 0:
+  print(f"command line: {dt:.2f}s for {n_samples} samples = {dt / n_samples:.2f}s per sample of {2 * n_pairs} reads "
       f"({2 * n_pairs * n_samples / dt / 1e6:.2f} M reads/s end to end; flags {extra})")
