@@ -19,6 +19,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 
@@ -105,6 +106,8 @@ def worker(j, procs, opts, rank, local_rank, gang, rank_barrier=None, timing=Non
     starts when every worker (and every rank) is ready and ends when every worker's last sample is typed."""
     from types import SimpleNamespace
     args = SimpleNamespace(**opts)
+    if j and os.environ.get("GK_BENCH_KILL_WORKER") == str(j):   # test hook: this worker dies at once
+        os._exit(3)
     from kir_graph_amd import _lib
     from kir_graph_amd.engine import DeviceIndex
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -198,9 +201,10 @@ def main():
     # Worker processes of this rank on its GPU (see worker()): started first, before anything touches HIP.
     procs = max(1, int(os.environ.get("GK_PROCS_PER_GPU", "3")))
     procs = min(procs, max(1, args.steps))
-    if procs > 1:
-        os.environ.setdefault("GK_THREADS", "4")   # gene threads per process: three processes share the host cores
-    gang = None
+    own_threads = procs > 1 and "GK_THREADS" not in os.environ
+    if own_threads:
+        os.environ["GK_THREADS"] = "4"   # gene threads per process: three processes share the host cores
+    gang, helpers = None, []
     if procs > 1:
         import multiprocessing as mp
         ctx = mp.get_context("spawn")
@@ -216,6 +220,18 @@ def main():
                 if h.is_alive():
                     h.terminate()
             procs, gang = 1, None
+            if own_threads:
+                del os.environ["GK_THREADS"]
+
+    finished = threading.Event()
+    if gang is not None:
+        def watch():   # a worker that exits early breaks the barriers at once instead of after their timeout
+            while not finished.wait(0.5):
+                if any(h.exitcode not in (None, 0) for h in helpers):
+                    for name in ("ready", "go", "done"):
+                        gang[name].abort()
+                    return
+        threading.Thread(target=watch, daemon=True).start()
 
     dist = None
     backend = os.environ.get("GK_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N > 1 path on one GPU
@@ -239,7 +255,21 @@ def main():
                 torch.cuda.synchronize()
 
     timing = {}
-    res = worker(0, procs, vars(args), rank, local_rank, gang, rank_barrier=rank_barrier, timing=timing)
+    try:
+        res = worker(0, procs, vars(args), rank, local_rank, gang, rank_barrier=rank_barrier, timing=timing)
+    except threading.BrokenBarrierError:
+        # a worker process died or never came up; a single-GPU run starts over in one process, a multi-rank
+        # run cannot (the other ranks are past their barriers)
+        for h in helpers:
+            if h.is_alive():
+                h.terminate()
+        if world > 1:
+            raise
+        log("[bench] a worker process failed; running the measurement in one process")
+        procs, gang = 1, None
+        if own_threads:
+            del os.environ["GK_THREADS"]
+        res = worker(0, 1, vars(args), rank, local_rank, None, rank_barrier=rank_barrier, timing=timing)
     elapsed = timing["elapsed"]
     prof, call_log, n_valid = res["prof"], res["call_log"], res["n_valid"]
     sidx, gidx, gene_cn = res["sidx"], res["gidx"], res["gene_cn"]
@@ -249,6 +279,10 @@ def main():
             n0, ms0 = prof.get(k, (0, 0.0))
             prof[k] = (n0 + n, ms0 + ms)
         call_log += other["call_log"]
+    finished.set()
+    if gang is not None:
+        for h in helpers:
+            h.join(timeout=30)
 
     if dist is not None:
         import torch
