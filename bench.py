@@ -72,7 +72,9 @@ def run_steps(n_steps, dev, dindex, gidx, mates_buf, table, gene_cn, method):
         return calls, warn, n_valid, typer
 
     out = None
-    tabs = prefetched(range(n_steps), lambda _: Tabulation(dindex, mates_buf, dev=ingest), depth=depth)
+    # n_steps: a count, or an iterator that hands out the samples of a region shared with other workers
+    items = range(n_steps) if isinstance(n_steps, int) else n_steps
+    tabs = prefetched(items, lambda _: Tabulation(dindex, mates_buf, dev=ingest), depth=depth)
     for out in overlapped(tabs, type_one, lanes=lanes):
         pass
     return out
@@ -118,7 +120,19 @@ def worker(j, procs, opts, rank, local_rank, gang, rank_barrier=None, timing=Non
     dindex = DeviceIndex(dev, gidx)
     mates = dev.put(rec)
     dev.sync()
-    my_steps = args.steps // procs + (1 if j < args.steps % procs else 0)
+
+    def claims():
+        """Samples of the timed region for this worker: all of them, or whatever it gets from the shared counter."""
+        if gang is None:
+            yield from range(args.steps)
+            return
+        while True:
+            with gang["next"].get_lock():
+                k = gang["next"].value
+                gang["next"].value = k + 1
+            if k >= args.steps:
+                return
+            yield k
 
     def all_devices():
         return list(_lib.Device.instances)
@@ -127,8 +141,9 @@ def worker(j, procs, opts, rank, local_rank, gang, rank_barrier=None, timing=Non
         if gang is not None:
             gang[name].wait(timeout=300)
 
+    n_valid = 0
     if args.warmup:
-        run_steps(args.warmup, dev, dindex, gidx, mates, table, gene_cn, args.method)
+        n_valid = run_steps(args.warmup, dev, dindex, gidx, mates, table, gene_cn, args.method)[2]
     if j == 0 and getattr(args, "profile_host", False):
         import cProfile
         import pstats
@@ -147,9 +162,9 @@ def worker(j, procs, opts, rank, local_rank, gang, rank_barrier=None, timing=Non
         rank_barrier()
     gang_wait("go")
     t0 = time.perf_counter()
-    n_valid = 0
-    if my_steps:
-        calls, warn, n_valid, typer = run_steps(my_steps, dev, dindex, gidx, mates, table, gene_cn, args.method)
+    last = run_steps(claims(), dev, dindex, gidx, mates, table, gene_cn, args.method)
+    if last is not None:
+        n_valid = last[2]
     for d in all_devices():
         d.sync()
     gang_wait("done")
@@ -208,7 +223,8 @@ def main():
     if procs > 1:
         import multiprocessing as mp
         ctx = mp.get_context("spawn")
-        gang = {"ready": ctx.Barrier(procs), "go": ctx.Barrier(procs), "done": ctx.Barrier(procs), "results": ctx.Queue()}
+        gang = {"ready": ctx.Barrier(procs), "go": ctx.Barrier(procs), "done": ctx.Barrier(procs), "results": ctx.Queue(),
+                "next": ctx.Value("i", 0)}   # the samples of the timed region are handed out one by one
         helpers = [ctx.Process(target=worker, args=(j, procs, vars(args), rank, local_rank, gang), daemon=True)
                    for j in range(1, procs)]
         try:
