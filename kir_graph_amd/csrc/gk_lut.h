@@ -10,6 +10,8 @@ struct gk_lut {
   uint32_t* d_slot_idx = nullptr;  // slot -> dense index
   uint64_t* d_list = nullptr;      // dense index -> bit pattern (insertion order)
   double* d_vals = nullptr;        // dense index -> log10 (defined for index < n_known)
+  double* d_slot_val = nullptr;    // slot -> log10 once defined (kLutEmptyKey's bit pattern until then): lets the
+                                   // fused lookup load key and value side by side instead of key -> index -> value
   uint32_t* d_count = nullptr;     // number of dense entries
   int32_t n_known = 0;             // entries with a defined value
 };
@@ -23,12 +25,13 @@ struct LutView {
   uint64_t* list;
   uint32_t* count;
   const double* vals;
+  const double* slot_val;
   uint32_t mask;
   uint32_t n_known;
 };
 
 static inline LutView gk_lut_view(const gk_lut* l) {
-  return LutView{l->d_keys, l->d_slot_idx, l->d_list, l->d_count, l->d_vals,
+  return LutView{l->d_keys, l->d_slot_idx, l->d_list, l->d_count, l->d_vals, l->d_slot_val,
                  (uint32_t)((1ull << l->log2cap) - 1), (uint32_t)l->n_known};
 }
 
@@ -58,16 +61,18 @@ __device__ inline void gk_lut_insert(const LutView& t, uint64_t k) {
   }
 }
 
-// value of `k` if its log is already defined; otherwise *found = false
+// value of `k` if its log is already defined; otherwise *found = false.  Key and value of a slot are
+// loaded together (one memory latency per probe); a value published after this kernel's launch may be
+// seen or not -- either is right, an unseen one is simply asked for again.
 __device__ inline double gk_lut_lookup(const LutView& t, uint64_t k, bool* found) {
   uint32_t s = gk_hash64(k) & t.mask;
   for (uint32_t probe = 0; probe <= t.mask; ++probe) {
     const uint64_t cur = t.keys[s];
+    const double v = t.slot_val[s];
     if (cur == k) {
-      const uint32_t idx = t.slot_idx[s];
-      if (idx < t.n_known) {
+      if ((uint64_t)__double_as_longlong(v) != kLutEmptyKey) {
         *found = true;
-        return t.vals[idx];
+        return v;
       }
       break;
     }
