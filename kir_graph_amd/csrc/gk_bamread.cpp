@@ -464,7 +464,12 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
     b->ref_names.emplace_back((const char*)d.data() + o, strnlen((const char*)d.data() + o, l_name));
     o += l_name + 4;   // name, l_ref
   }
+  b->recs.reserve(d.size() / 200);
   while (o + 4 <= d.size()) {
+    // the walk is a pointer chase (the next record starts where this one says); the records lie back to
+    // back, so the lines a few records ahead can be requested now
+    __builtin_prefetch(d.data() + o + 768);
+    __builtin_prefetch(d.data() + o + 1536);
     const uint32_t size = rd32(d.data() + o);
     o += 4;
     if (size < 32 || o + size > d.size()) return bad("alignment block");

@@ -12,6 +12,7 @@
 // emitted pairs, on several threads (GK_PACK_THREADS, default 8), each pair independent; (3) a
 // sequential merge in emission order that interns the inserted strings -- same ids as a one-by-one
 // walk -- and stops at the first pair the reference would have raised on.
+#include <atomic>
 #include <cctype>
 #include <cstdint>
 #include <cstdlib>
@@ -46,7 +47,13 @@ struct MdTok { int kind; long num; char ch; };   // kind 0 = number, 1 = charact
 
 }  // namespace
 
+inline uint64_t next_packer_serial() {
+  static std::atomic<uint64_t> n{0};
+  return ++n;
+}
+
 struct gk_packer {
+  const uint64_t serial = next_packer_serial();   // tells packers apart even when one reuses another's address
   std::vector<std::string> genes;
   std::unordered_map<std::string, int> gene_id;
   std::unordered_map<std::string, uint32_t> ins_id;
@@ -113,7 +120,8 @@ bool is_acgt(const MdTok& t) { return t.kind == 1 && (t.ch == 'A' || t.ch == 'C'
 
 // CIGAR / MD / Zs co-walk with the reference's consumption checks (see packed.py::_walkText)
 bool walk_text(sv cigar, sv seq, bool has_md, sv md_s, bool has_zs, sv zs_s, Walked& w, Fail& f) {
-  std::vector<MdTok> md;
+  static thread_local std::vector<MdTok> md;   // scratch of the decoding thread: no allocation per mate
+  md.clear();
   if (has_md) {
     for (size_t i = 0; i < md_s.size();) {
       if (isdigit((unsigned char)md_s[i])) {
@@ -126,7 +134,8 @@ bool walk_text(sv cigar, sv seq, bool has_md, sv md_s, bool has_zs, sv zs_s, Wal
     }
   }
   struct Zs { long gap; char kind; };
-  std::vector<Zs> zs;
+  static thread_local std::vector<Zs> zs;
+  zs.clear();
   if (has_zs && !zs_s.empty()) {
     size_t a = 0;
     for (;;) {
@@ -303,15 +312,23 @@ void decode_records(const gk_packer* pk, const GkAlnRecord* pr, const int64_t* i
   for (int s = 0; s < 2; ++s) {
     const GkAlnRecord& p = pr[s];
     gk_mate& r = out.rec[s];
-    auto g = pk->gene_id.find(std::string(p.ref));
-    if (g == pk->gene_id.end()) return failed({4, "reference is not a backbone of the index"}, idx[s]);
+    // neighbouring records are mostly of one backbone: remember the last name looked up (per packer and thread)
+    static thread_local uint64_t seen_pk = 0;
+    static thread_local std::string seen_ref;
+    static thread_local int seen_id = -1;
+    if (seen_pk != pk->serial || sv(seen_ref) != p.ref) {
+      auto g = pk->gene_id.find(std::string(p.ref));
+      if (g == pk->gene_id.end()) return failed({4, "reference is not a backbone of the index"}, idx[s]);
+      seen_pk = pk->serial; seen_ref.assign(p.ref); seen_id = (int)g->second;
+    }
     r.pos0 = (uint32_t)(p.pos - 1);
     r.flag = (uint16_t)(p.flag & 0xFFFF);
-    r.ref = (uint8_t)g->second;
+    r.ref = (uint8_t)seen_id;
     r.nh = (uint8_t)std::min<long>(p.nh, 255);
     r.nm = p.has_nm ? (uint8_t)std::min<long>(std::max<long>(p.nm, 0), 254) : (uint8_t)GK_NM_ABSENT;
     if (!both) continue;
-    Walked w;
+    static thread_local Walked w;
+    w.ops.clear(); w.mms.clear(); w.ins.clear(); w.clipped = false;
     const bool walked = walk_text(p.cigar, p.seq, p.has_md, p.md, p.has_zs, p.zs, w, f);
     out.ins[s] = std::move(w.ins);   // strings met before a failure are interned too, like a one-by-one walk
     if (!walked) return failed(f, idx[s]);
@@ -592,7 +609,7 @@ int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
   const bool merged = decode_all(
       pk, pairs.size() / 2,
       [&](size_t i, Decoded& out) {
-        GkAlnRecord pr[2];
+        static thread_local GkAlnRecord pr[2];   // their text buffers keep their capacity from pair to pair
         const int64_t idx[2] = {base + pairs[2 * i], base + pairs[2 * i + 1]};
         full(pairs[2 * i], pr[0]);
         full(pairs[2 * i + 1], pr[1]);
