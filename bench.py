@@ -317,6 +317,14 @@ def main():
                 log(f"[bench] {k:18s} launches {n:6d}  total {ms:9.3f} ms  avg {ms / n:8.4f} ms")
             log(f"[bench] kernel time {total_kernel_ms / args.steps:.2f} ms of {ms_per_step:.2f} ms per step")
         roof = roofline(dom, call_log)
+        # the kernel's share of the whole timed region: work of all its launches over the elapsed time (launches of
+        # different workers overlap, so this is not bounded by the per-launch figure above)
+        n_l, t_ms = dom[1]
+        if elapsed > 0 and t_ms > 0:
+            share = (t_ms * 1e-3) / elapsed          # sum of launch durations / wall time
+            roof["region"] = {"achieved": roof["achieved"] * share, "unit": roof["unit"], "frac": roof["frac"] * share,
+                              "valu_frac": roof["valu"]["frac"] * share if "valu" in roof else None,
+                              "note": "algorithmic bytes (ops) of all launches of the kernel / elapsed time of the region"}
         if res.get("alone") and dom[0] in res["alone"]:
             # launch durations in the timed region include the time the kernel shares the GPU with the kernels of
             # the other worker processes; the same launches right after it, one process on the GPU:
