@@ -190,13 +190,7 @@ bool inflate_bgzf_parallel(const Bytes& in, Bytes& out, int n_threads) {
   return true;
 }
 
-int ingest_threads() {
-  const char* e = getenv("GK_PACK_THREADS");
-  long n = e ? atol(e) : 8;
-  const long hw = (long)std::thread::hardware_concurrency();
-  if (hw > 0) n = std::min(n, hw);
-  return (int)std::max<long>(1, std::min<long>(n, 64));
-}
+int ingest_threads() { return gk_ingest_threads(); }
 
 // Query-name order: characters compare by code, except that where both names have a digit the two
 // digit runs compare as numbers (leading zeros skipped, more digits = larger); equal numbers written

@@ -13,7 +13,18 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <thread>
+
 struct gk_packer;
+
+// threads of the native readers / packers / writers: GK_PACK_THREADS (default 8), at most the hardware's
+inline int gk_ingest_threads() {
+  const char* e = getenv("GK_PACK_THREADS");
+  long n = e ? atol(e) : 8;
+  const long hw = (long)std::thread::hardware_concurrency();
+  if (hw > 0) n = std::min(n, hw);
+  return (int)std::max<long>(1, std::min<long>(n, 64));
+}
 
 // GK_INGEST_TIMING=1: phase times of the host ingest on stderr (development aid)
 struct GkPhaseClock {

@@ -365,13 +365,7 @@ void decode_records(const gk_packer* pk, const GkAlnRecord* pr, const int64_t* i
   }
 }
 
-int pack_threads() {
-  const char* e = getenv("GK_PACK_THREADS");
-  long n = e ? atol(e) : 8;
-  const long hw = (long)std::thread::hardware_concurrency();
-  if (hw > 0) n = std::min(n, hw);
-  return (int)std::max<long>(1, std::min<long>(n, 64));
-}
+int pack_threads() { return gk_ingest_threads(); }
 
 // step (3): in emission order, intern the inserted strings, stop at the first failed pair
 template <typename Work>

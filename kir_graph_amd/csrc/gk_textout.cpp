@@ -82,7 +82,7 @@ extern "C" int gk_json_write_reads(const char* path, const char* sam_text, int64
   FILE* f = fopen(path, "ab");
   if (!f) { gk_set_error("cannot append to %s", path); return GK_ERR_ARG; }
   bool ok = fputc('[', f) != EOF;
-  const int n_thr = 8;
+  const int n_thr = gk_ingest_threads();
   const int64_t kBatch = 32768;   // rows formatted per round (a few tens of MB of text)
   std::vector<std::string> piece((size_t)n_thr);
   std::vector<char> bad((size_t)n_thr, 0);
