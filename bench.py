@@ -320,12 +320,12 @@ def main():
         # the kernel's share of the whole timed region: work of all its launches over the elapsed time (launches of
         # different workers overlap, so this is not bounded by the per-launch figure above)
         n_l, t_ms = dom[1]
-        if elapsed > 0 and t_ms > 0:
+        if elapsed > 0 and t_ms > 0 and roof.get("achieved") is not None:
             share = (t_ms * 1e-3) / elapsed          # sum of launch durations / wall time
             roof["region"] = {"achieved": roof["achieved"] * share, "unit": roof["unit"], "frac": roof["frac"] * share,
                               "valu_frac": roof["valu"]["frac"] * share if "valu" in roof else None,
                               "note": "algorithmic bytes (ops) of all launches of the kernel / elapsed time of the region"}
-        if res.get("alone") and dom[0] in res["alone"]:
+        if res.get("alone") and dom[0] in res["alone"] and roof.get("achieved") is not None:
             # launch durations in the timed region include the time the kernel shares the GPU with the kernels of
             # the other worker processes; the same launches right after it, one process on the GPU:
             n1, ms1 = res["alone"][dom[0]]
