@@ -6,9 +6,11 @@ The reference shells out to ``samtools mpileup -a`` and parses its base column; 
 image, so the pileup itself is restated from the defaults documented in samtools-mpileup(1) -- skip
 UNMAP / SECONDARY / QCFAIL / DUP records and paired reads outside a proper pair, drop bases of quality
 < 13, overlapping mates: equal bases count once, unequal ones keep the better base at 0.8 of its quality,
-deleted positions count as '*', no BAQ without a reference -- **parity unpinned**.  The ratio dictionary
-and everything downstream (``hisat2.errorCorrection``, restated in ``oracle/tabulate.pileupCorrect``)
-follow the reference line by line.
+deleted positions count as '*', no BAQ without a reference -- **parity unpinned for these counts**.  The
+parser of the mpileup base column (``basesOfColumn`` <- parsePileupBase 13-37), the ratio dictionary
+(``ratiosOfColumns`` <- getPileupBaseRatio 57-81) and everything downstream (``hisat2.errorCorrection``,
+restated in ``oracle/tabulate.pileupCorrect``) follow the reference line by line and ARE pinned: fixture
+``tests/golden/t11_pileup.json.gz`` holds the reference's own outputs on hand-written mpileup columns.
 """
 from __future__ import annotations
 
@@ -16,6 +18,44 @@ import re
 from collections import Counter, defaultdict
 
 _CIGAR = re.compile(r"(\d+)([MIDNSHP=X])")
+_NUM = re.compile(r"\d+")
+
+
+def basesOfColumn(column: str) -> str:
+    """Bases of one mpileup base column (parsePileupBase, pileup.py:13-37): ``$`` dropped, ``^x`` (read start +
+    mapping quality) dropped, ``+n...`` / ``-n...`` indel annotations skipped, ``*`` and every other
+    character kept."""
+    out, i = [], 0
+    while i < len(column):
+        c = column[i]
+        if c == "$":
+            i += 1
+        elif c in "+-":
+            n = _NUM.search(column, i + 1)
+            assert n
+            i += 1 + len(n.group()) + int(n.group())
+        elif c == "^":
+            i += 2
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def ratiosOfColumns(rows) -> dict:
+    """``rows`` = (ref, 0-based pos, depth, base column) like ``readPileup`` yields (pileup.py:40-54);
+    depth-0 rows are skipped, bases are upper-cased, shares are count / total (getPileupBaseRatio 57-81)."""
+    stat = {}
+    for ref, pos, depth, column in rows:
+        if depth == 0:
+            continue
+        bases = basesOfColumn(column)
+        assert depth == len(bases)
+        count = Counter(bases.upper())
+        s = sum(count.values())
+        stat[(ref, pos)] = {k: v / s for k, v in count.items()}
+        stat[(ref, pos)]["all"] = s
+    return stat
 
 
 def _cover(line: str):

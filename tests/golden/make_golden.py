@@ -53,6 +53,7 @@ import graphkir.kir_cn as rcn                     # noqa: E402
 import graphkir.typing_mulit_allele as rta        # noqa: E402
 import graphkir.typing_em as rem                  # noqa: E402
 import graphkir.main as rmain                     # noqa: E402
+import graphkir.pileup as rpile                   # noqa: E402
 from graphkir.msa2hisat import Variant as RV      # noqa: E402
 from graphkir.utils import mergeAllele, mergeCN   # noqa: E402
 
@@ -342,6 +343,43 @@ def t8_cn():
     return out
 
 
+# ------------------------------------------------------------------ T11: pileup error correction (a21)
+def t11_pileup():
+    """pileup.py:13-37 (parsePileupBase), 57-81 (getPileupBaseRatio) and hisat2.py:609-654 (errorCorrection)
+    run on hand-written mpileup columns / ratio dictionaries -- nothing here needs samtools: ``readPileup``
+    (the only function that shells out) is replaced by a generator over the hand-written rows."""
+    g = "KIR3DL3*BACKBONE"
+    base_cases = [
+        "^]G^]G^KG^OG^]G^]G^TG^(G^KG^VG",        # the docstring's own examples
+        "A$^]A", "*", "",
+        "AAaa", "ACGTNacgtn", "A+2AGC-1TG", "a-12ACGTACGTACGTc$", "^+A^-C", "*$*^]*", "G+10AAAAAAAAAAT",
+        "AAAAAAAAAAAAAAAAAAAC", "AAAAAAAAAAAAAAAA****", "N$n$", ">><<",
+    ]
+    parsed = [{"bases": b, "out": "".join(rpile.parsePileupBase(b))} for b in base_cases]
+    # getPileupBaseRatio on rows (ref, 0-based pos, depth, bases); depth 0 rows are skipped (71-72)
+    rows = [(g, 5, 0, "*"), (g, 10, 4, "AAaa"), (g, 11, 10, "ACGTNacgtn"), (g, 12, 3, "A+2AGC-1TG"),
+            (g, 13, 20, "AAAAAAAAAAAAAAAAAAAC"), (g, 14, 20, "AAAAAAAAAAAAAAAA****"), (g, 15, 3, "*$*^]*"),
+            (g, 16, 25, "A" * 20 + "C" * 5), (g, 17, 25, "A" * 4 + "C" * 5 + "G" * 16), (g, 18, 19, "A" * 18 + "c"),
+            (g, 19, 20, "a" * 15 + "C" * 4 + "t"), (g, 20, 30, "*" * 25 + "A" * 5), (g, 21, 40, "A" * 8 + "C" * 32),
+            (g, 22, 40, "A" * 9 + "C" * 31), (g, 23, 20, "A" * 4 + "C" * 16), (g, 24, 20, "A" * 5 + "C" * 15),
+            (g, 25, 21, "N" * 1 + "C" * 20), (g, 26, 50, "A" * 10 + "C" * 10 + "G" * 10 + "T" * 20)]
+    rpile.readPileup = lambda bam: iter(rows)
+    ratio = rpile.getPileupBaseRatio("x.bam")
+    ratio_out = [{"pos": pos, "entry": {k: (float(v).hex() if k != "all" else v) for k, v in e.items()},
+                  "order": list(e)} for (_, pos), e in ratio.items()]
+    # errorCorrection of every read base at every position (and of non-SNP / uncovered variants)
+    fixes = []
+    for (_, pos) in list(ratio) + [(g, 5), (g, 999)]:
+        for val in "ACGTN":
+            v = RV(pos=pos, typ="single", ref=g, val=val, length=1)
+            w = rh.errorCorrection(v, ratio)
+            fixes.append([pos, val, w.val])
+    for typ, val in (("deletion", 2), ("insertion", "AC"), ("match", None)):
+        v = RV(pos=13, typ=typ, ref=g, val=val, length=2)
+        fixes.append([13, f"{typ}:{val}", str(rh.errorCorrection(v, ratio).val)])
+    return {"gene": g, "parse": parsed, "rows": [list(r) for r in rows], "ratio": ratio_out, "fixes": fixes}
+
+
 def t10_sums():
     rng = np.random.default_rng(11)
     cases = []
@@ -355,8 +393,19 @@ def t10_sums():
 
 if __name__ == "__main__":
     print("numpy", np.__version__)
-    dump("t1_tabulation.json.gz", t1_tabulation())
-    dump("t2_pairing.json.gz", t2_pairing())
-    dump("typing_case.json.gz", typing_case())
-    dump("t8_cn.json.gz", t8_cn())
-    dump("t10_sums.json.gz", {"numpy": np.__version__, "cases": t10_sums()})
+    only = set(sys.argv[1:])          # e.g. `make_golden.py t11` rewrites one fixture
+
+    def want(key):
+        return not only or key in only
+    if want("t1"):
+        dump("t1_tabulation.json.gz", t1_tabulation())
+    if want("t2"):
+        dump("t2_pairing.json.gz", t2_pairing())
+    if want("typing"):
+        dump("typing_case.json.gz", typing_case())
+    if want("t8"):
+        dump("t8_cn.json.gz", t8_cn())
+    if want("t10"):
+        dump("t10_sums.json.gz", {"numpy": np.__version__, "cases": t10_sums()})
+    if want("t11"):
+        dump("t11_pileup.json.gz", t11_pileup())

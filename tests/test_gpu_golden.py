@@ -77,6 +77,21 @@ def test_allele_calls_and_likelihoods(typed_case, method):
         assert np.allclose(last.value[:50], unhex(w["value"]), rtol=1e-9, atol=0)       # north_star: 1e-5
         assert np.allclose(np.asarray(last.value_sum_indv[:50]).ravel(), unhex(w["value_sum_indv"]), rtol=1e-9, atol=0)
         assert np.allclose(np.asarray(last.fraction[:50]).ravel(), unhex(w["fraction"]), rtol=1e-9, atol=0)
+        assert last.n == w["n"]
+        # ids and names agree wherever the reference's values are not tied with a neighbour (the order inside a
+        # group of tied values is numpy's argsort tie order, which depends on the host's SIMD level)
+        v = unhex(w["value"])
+        apart = np.abs(np.diff(v)) > 1e-7 * np.abs(v[1:])      # well beyond cross-host last-bit differences
+        untied = np.ones(len(v), dtype=bool)
+        untied[1:] &= apart
+        untied[:-1] &= apart
+        got_ids, want_ids = np.asarray(last.allele_id[:50]), np.asarray(w["allele_id"])
+        assert np.array_equal(np.sort(got_ids[untied], axis=1), np.sort(want_ids[untied], axis=1)), gene
+        names = last.allele_name[:50]
+        for k in np.flatnonzero(untied):
+            assert sorted(names[k]) == sorted(w["allele_name"][k]), (gene, k)
+    got_rows, want_rows = typer.getAllPossibleTyping(), want["possible"]
+    assert [(r["gene"], r["rank"]) for r in got_rows] == [(r["gene"], r["rank"]) for r in want_rows]
 
 
 def test_em_abundances(typed_case):

@@ -1,0 +1,190 @@
+"""GPU parity of the OUTPUT FILES and of the copy-number stage driven through the product's
+own entry points (a19), against bytes the reference itself wrote (tests/golden: T9 = typing_case["outputs"],
+T8 = t8_cn), plus command-line runs without ``--cn-provided`` (per-sample fit) and with ``--cn-cohort``."""
+import gzip
+import io
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from kir_graph_amd import main as cli
+from kir_graph_amd import synth
+from kir_graph_amd.hisat2 import extractVariant, pairLines, writeSampleJson
+from kir_graph_amd.index import GkIndex
+from kir_graph_amd.kir_cn import predictSamplesCN
+from kir_graph_amd.msa2hisat import Variant
+from kir_graph_amd.utils import mergeAllele, mergeCN
+from oracle import cn as ocn
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with gzip.open(os.path.join(GOLD, name), "rt") as f:
+        return json.load(f)
+
+
+def comparePossible(got_text: str, want_text: str) -> None:
+    """``.possible.tsv``: same header, same rows; every cell equal as text except ``value``, which the
+    reference prints with repr precision -- equal text when the fixture's host and this one agree on the
+    last bits of numpy.log10 / the reduction tree, 1e-9 relative otherwise (oracle/__init__.py)."""
+    got = [line.split("\t") for line in got_text.rstrip("\n").split("\n")]
+    want = [line.split("\t") for line in want_text.rstrip("\n").split("\n")]
+    assert got[0] == want[0]
+    assert len(got) == len(want)
+    vcol = want[0].index("value")
+    for g, w in zip(got[1:], want[1:]):
+        assert len(g) == len(w)
+        for k, (a, b) in enumerate(zip(g, w)):
+            if k == vcol:
+                assert float(a) == pytest.approx(float(b), rel=1e-9, abs=0), (g, w)
+                assert repr(float(a)) == a                      # printed with repr precision like the reference
+            else:
+                assert a == b, (g, w)
+
+
+@pytest.mark.parametrize("hand_off", ["memory", "json"])
+def test_output_files_equal_the_references_bytes(device, tmp_path, hand_off):
+    """main.alleleTyping + mergeAllele + mergeCN on the typing case: the four files the reference wrote
+    (main.py:171-220, utils.py:161-179), byte for byte (value column of .possible.tsv: see above)."""
+    case = load("typing_case.json.gz")
+    want = case["outputs"]
+    for ext, body in case["index"].items():
+        (tmp_path / f"ix.{ext}").write_text(body)
+    gidx = GkIndex.load(str(tmp_path / "ix"))
+    Variant.novel_id = 0
+    data = extractVariant(pairLines(case["lines"]), gidx, dev=device)
+    d = str(tmp_path)
+    cn_file = d + "/s.depth.p75.LCND.tsv"
+    with open(cn_file, "w") as f:
+        f.write("gene\tcn\n" + "".join(f"{g}\t{c}\n" for g, c in case["gene_cn"].items()))
+    if hand_off == "json":       # through the .variant.json like the reference's own call chain
+        writeSampleJson(data, d + "/s.variant.json")
+        files = cli.alleleTyping([d + "/s.variant"], [cn_file], method="full")
+    else:                        # tabulation handed over in memory (what the pipeline does)
+        files = cli.alleleTyping([(d + "/s.variant", data)], [cn_file], method="full")
+    mergeAllele(files, d + "/cohort.allele.tsv")
+    mergeCN([cn_file], d + "/cohort.cn.tsv")
+    strip = lambda s: s.replace(d + "/", "")   # noqa: E731
+    assert strip(files[0]) == want["allele_file"]                                   # the suffix rule
+    assert strip(open(files[0]).read()) == want["allele_tsv"]
+    comparePossible(open(files[0][:-4] + ".possible.tsv").read(), want["possible_tsv"])
+    assert strip(open(d + "/cohort.allele.tsv").read()) == want["cohort_allele_tsv"]
+    assert strip(open(d + "/cohort.cn.tsv").read()) == want["cohort_cn_tsv"]
+
+
+def test_possible_rows_equal_fixture_for_every_strategy(device, tmp_path):
+    """getAllPossibleTyping (kir_typing.py:134-150) of full / exonfirst_1 / exonfirst_0.9 vs the fixture rows."""
+    from kir_graph_amd.kir_typing import selectKirTypingModel
+    case = load("typing_case.json.gz")
+    for ext, body in case["index"].items():
+        (tmp_path / f"ix.{ext}").write_text(body)
+    gidx = GkIndex.load(str(tmp_path / "ix"))
+    Variant.novel_id = 0
+    data = extractVariant(pairLines(case["lines"]), gidx, dev=device)
+    for method in ("full", "exonfirst_1", "exonfirst_0.9"):
+        typer = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
+        typer.typing(case["gene_cn"])
+        got, want = typer.getAllPossibleTyping(), case["methods"][method]["possible"]
+        assert len(got) == len(want), method
+        for a, b in zip(got, want):
+            assert set(a) == set(b)
+            for k in b:
+                if k == "value":
+                    assert a[k] == pytest.approx(float.fromhex(b[k]), rel=1e-9, abs=0)
+                else:
+                    assert a[k] == b[k], (method, a, b)
+
+
+def test_predict_samples_cn_writes_the_references_tsv(device, tmp_path):
+    """The PRODUCT's predictSamplesCN (aggrDepths -> depthToCN on the GPU -> TSV writer, kir_cn.py:146-231)
+    on the T8 depth tables: the ``gene\\tcn\\tdepth`` files equal the reference's text; model parameters too."""
+    t8 = load("t8_cn.json.gz")
+    d = str(tmp_path)
+    for si, rows in enumerate(t8["depth_tables"]):
+        pd.DataFrame(rows, columns=["gene", "pos", "depth"]).to_csv(f"{d}/s{si}.depth.tsv", sep="\t", header=False,
+                                                                    index=False)
+    kw = {"base_dev": 0.08, "start_base": 2}
+    for mode, res in t8["per_sample"].items():
+        for si, want in enumerate(res):
+            predictSamplesCN([f"{d}/s{si}.depth.tsv"], [f"{d}/s{si}.cn.tsv"], cluster_method="LCND",
+                             cluster_method_kwargs=kw, assume_3DL3_diploid=True,
+                             save_cn_model_path=f"{d}/s{si}.cn.json", select_mode=mode)
+            assert open(f"{d}/s{si}.cn.tsv").read() == want["tsv"], (mode, si)
+            m = json.load(open(f"{d}/s{si}.cn.json"))
+            assert float(m["base"]) == pytest.approx(float.fromhex(want["base"]), rel=1e-12)
+            assert float(m["x_max"]) == float.fromhex(want["x_max"])
+            assert m["bin_num"] == want["bin_num"]
+    for method, files in t8["cohort"].items():
+        predictSamplesCN([f"{d}/s{si}.depth.tsv" for si in range(3)], [f"{d}/c{si}.cn.tsv" for si in range(3)],
+                         cluster_method=method, cluster_method_kwargs=kw if method == "LCND" else {},
+                         save_cn_model_path=f"{d}/c.json", select_mode="p75")
+        for si, want in enumerate(files):
+            assert open(f"{d}/c{si}.cn.tsv").read() == want, (method, si)
+
+
+def _cohort(tmp_path, n_samples=3, n_pairs=6000):
+    """Synthetic index with all 15 genes (KIR3DL3 among them) + samples as SAM text + their truth."""
+    sidx = synth.makeIndex(seed=21, n_genes=15, var_range=(60, 120), allele_range=(6, 12), len_range=(2500, 4000))
+    folder = tmp_path / "index"
+    folder.mkdir()
+    prefix = str(folder / "kir_2100_withexon_ab_2dl1s1.leftalign.mut01")
+    sidx.write(prefix)
+    sams, samples = [], []
+    for k in range(n_samples):
+        s = synth.makeSample(sidx, seed=70 + k, n_pairs=n_pairs)
+        path = tmp_path / f"s{k}.sam.gz"
+        with gzip.open(path, "wt") as f:
+            f.write("@HD\tVN:1.0\tSO:queryname\n" +
+                    "".join(f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}\n" for g in sidx.genes) +
+                    "\n".join(synth.toSamLines(s)) + "\n")
+        sams.append(str(path))
+        samples.append(s)
+    return sidx, str(folder), sams, samples
+
+
+def _run(folder, out, sams, extra):
+    args = cli.createParser().parse_args(
+        ["--step-skip-extraction", "--index-folder", folder, "--output-folder", str(out), "--allele-strategy", "pv",
+         "--no-variant-json"] + [x for s in sams for x in ("--alignment", s)] + extra)
+    cli.main(args)
+
+
+def test_command_line_fits_copy_numbers_itself(device, tmp_path):
+    """No ``--cn-provided``: depth on the device -> per-sample LCND fit -> typing with the fitted copy numbers;
+    and ``--cn-cohort``: one pooled fit.  The CN TSVs equal the oracle's fit on the very depth files the run
+    wrote; cohort.cn.tsv holds the same cells; the allele table is typed with those copy numbers."""
+    sidx, folder, sams, samples = _cohort(tmp_path)
+    for mode, extra in (("sample", ["--cn-3dl3-not-diploid"]), ("cohort", ["--cn-cohort"])):
+        out = tmp_path / f"out_{mode}"
+        _run(folder, out, sams, extra)
+        depth_files = sorted(str(p) for p in out.iterdir() if p.name.endswith(".no_multi.depth.tsv"))
+        assert len(depth_files) == len(sams)
+        tables = [pd.read_csv(f, sep="\t", header=None, names=["gene", "pos", "depth"]) for f in depth_files]
+        kw = {"base_dev": 0.08, "start_base": 2}
+        if mode == "sample":
+            want = [ocn.predictCN([t], "p75", "LCND", kw, assume_3DL3_diploid=False)[0][0] for t in tables]
+            cn_files = [f[:-len(".tsv")] + ".p75.LCND.tsv" for f in depth_files]
+        else:
+            want = ocn.predictCN(tables, "p75", "LCND", kw, False)[0]
+            cn_files = [f[:-len(".tsv")] + ".p75.cohort.LCND.tsv" for f in depth_files]
+        merged = pd.read_csv(out / "cohort.cn.tsv", sep="\t", index_col=0)
+        assert list(merged.columns) == cn_files
+        for f, w in zip(cn_files, want):
+            got = pd.read_csv(f, sep="\t")
+            assert list(got.columns) == ["gene", "cn", "depth"]
+            assert dict(zip(got["gene"], got["cn"])) == {g: int(c) for g, c in w.items()}
+            assert {g: int(merged[f][g]) for g in merged.index} == {g: int(c) for g, c in w.items()}
+        alleles = pd.read_csv(out / "cohort.allele.tsv", sep="\t")
+        assert len(alleles) == len(sams)
+        for k, (f, w) in enumerate(zip(cn_files, want)):
+            assert alleles["name"][k].endswith(".full")
+            called = alleles["alleles"][k].split("_")
+            for g, c in w.items():      # one call per fitted copy of every gene
+                assert sum(a.split("*")[0] == g.split("*")[0] for a in called) == int(c), (mode, k, g)
+        if mode == "cohort":
+            assert (out / "cohort.p75.cohort.LCND.json").exists()

@@ -650,3 +650,41 @@ def test_native_json_reads_array_matches_json_dumps(tmp_path):
                      "rpv": [names[v] for v in ids[o[1]:o[2]]], "rnv": [names[v] for v in ids[o[3]:o[4]]]})
     assert open(path).read() == json.dumps(want)
     assert json.loads(open(path).read()) == want
+
+
+def test_pileup_ratios_and_correction_table_match_reference_fixture():
+    """Product host logic of a21 (pileup.ratiosOf / correctionTable) against the REFERENCE's outputs on
+    hand-written mpileup columns (tests/golden/t11_pileup.json.gz: getPileupBaseRatio 57-81, hisat2.errorCorrection
+    609-654).  The per-position base counts are taken from the reference's own parse of the columns."""
+    import gzip
+    import json
+    from kir_graph_amd import pileup as pp
+    with gzip.open(os.path.join(os.path.dirname(__file__), "golden", "t11_pileup.json.gz"), "rt") as f:
+        t11 = json.load(f)
+    parsed = {c["bases"]: c["out"] for c in t11["parse"]}
+    n_pos = 1000
+    counts = np.zeros((n_pos, 6), dtype=np.uint32)
+    for _, pos, depth, column in t11["rows"]:
+        if depth == 0:
+            continue
+        bases = parsed.get(column)
+        if bases is None:      # plain columns (letters only) parse to themselves
+            assert not set(column) & set("$^+-")
+            bases = column
+        for b in bases.upper():
+            counts[pos, pp.BASES.index(b)] += 1
+    pos0 = np.array([0, n_pos], dtype=np.int64)
+    got = pp.ratiosOf(counts, pos0, [t11["gene"]])
+    want = {(t11["gene"], r["pos"]): r["entry"] for r in t11["ratio"]}
+    assert set(got) == set(want)
+    for key, entry in got.items():
+        assert set(entry) == set(want[key])
+        for k, v in entry.items():
+            assert v == (want[key][k] if k == "all" else float.fromhex(want[key][k])), (key, k)   # same v / s bits
+    table = pp.correctionTable(counts)
+    for pos, val, fixed in t11["fixes"]:
+        if ":" in val:
+            continue                       # non-SNP variants never reach the table
+        j = "ACGTN".index(val)
+        shown = chr(table[pos, j]) if table[pos, j] else val
+        assert shown == fixed, (pos, val, shown, fixed)

@@ -203,3 +203,38 @@ def test_numpy_reduction_tree():
         assert float(np.add.reduce(x)) == float.fromhex(c["sum"])
         col = unhex(c["colsum"])
         assert numpySum(x) == col[0] and numpySum(x[::-1]) == col[1]
+
+
+# ---------------------------------------------------------------- T11: pileup error correction (a21)
+@pytest.fixture(scope="module")
+def t11():
+    return load("t11_pileup.json.gz")
+
+
+def test_pileup_column_parser_and_ratios(t11):
+    """oracle/pileup.py against the reference's parsePileupBase / getPileupBaseRatio (pileup.py:13-37, 57-81)."""
+    from oracle import pileup as op
+    for c in t11["parse"]:
+        assert op.basesOfColumn(c["bases"]) == c["out"], c["bases"]
+    got = op.ratiosOfColumns([tuple(r) for r in t11["rows"]])
+    want = {(t11["gene"], r["pos"]): r for r in t11["ratio"]}
+    assert set(got) == set(want)
+    for key, entry in got.items():
+        w = want[key]
+        assert list(entry) == w["order"]                      # dict order = first appearance (decides max() ties)
+        for k, v in entry.items():
+            assert v == (w["entry"][k] if k == "all" else float.fromhex(w["entry"][k])), (key, k)
+
+
+def test_pileup_correction_rule(t11):
+    """oracle/tabulate.pileupCorrect against hisat2.errorCorrection (609-654) at the depth-20 / 0.2 / 0.8 edges."""
+    from kir_graph_amd.msa2hisat import Variant
+    from oracle import pileup as op
+    ratio = op.ratiosOfColumns([tuple(r) for r in t11["rows"]])
+    for pos, val, want in t11["fixes"]:
+        if ":" in val:
+            typ, raw = val.split(":")
+            v = Variant(pos=pos, typ=typ, ref=t11["gene"], val=None if raw == "None" else raw, length=2)
+        else:
+            v = Variant(pos=pos, typ="single", ref=t11["gene"], val=val, length=1)
+        assert str(ot.pileupCorrect(v, ratio).val) == str(want), (pos, val)
