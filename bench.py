@@ -3,123 +3,237 @@
 bench.py -- typed 150 bp PE reads/s of the Graph-KIR hot path on MI355X.
 
 One "step" = one synthetic sample (BASELINE.json configs[1]: 2 M reads = 1 M pairs, ~2 k alleles in
-15 genes, --allele-strategy pv == full, top_n 600, variant correction on) taken from packed
-alignment records ALREADY RESIDENT IN HBM to per-gene allele calls on the host:
-tabulation (gk_tabulate) -> per gene: error correction, compatibility table, log table, greedy
-multi-allele likelihood search -> allele selection.  N > 1: every rank types its own sample(s)
-(cohort sharding, no data-path collective), value = reads of all ranks / max-over-ranks time.
+15 genes, --allele-strategy pv == full, top_n 600, variant correction on) taken from packed alignment
+records in PINNED HOST MEMORY to per-gene allele calls on the host: the
+host-to-device copy of the records (256 MB), the tabulation (gk_tabulate), per gene the error
+correction, compatibility table, log table and greedy multi-allele likelihood search, and the allele
+selection all lie inside the timed region.  Consecutive steps take DIFFERENT samples (three distinct
+ones per rank, in rotation) and are pipelined like the samples of a cohort: the copy + tabulation of the
+next sample runs while the current one is typed.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel, HIP-event time measured in this run (gk_prof_*), algorithmic bytes
-  cpu_baseline  the oracle (CPU restatement of the reference) on a bounded sample of the same workload
+``--gpus N``: N ranks, one per GPU, every rank types its own samples (cohort sharding: weak scaling, no
+data-path collective); value = reads of all ranks / max-over-ranks time.  Started without a launcher
+(`python bench.py --gpus N`) this process starts the N ranks itself -- as fresh processes, before
+anything here touches the GPU -- and relays rank 0's line; under `torchrun` (RANK / WORLD_SIZE set) it
+is one of the ranks.  Ranks meet through kir_graph_amd/comm.py (RCCL: barrier + max of the times).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline        the dominant kernel of the step, from a ONE-PROCESS, SERIAL pass (one gene thread, no
+                  prefetch) run right after the timed region: HIP-event time per launch, algorithmic
+                  bytes / operations per launch (kir_graph_amd/roofmodel.py)
+  kernels_serial  per-kernel launches and time per step of that pass (the basis rocprofv3 reproduces:
+                  GK_PROCS_PER_GPU=1 GK_THREADS=1 GK_PREFETCH=0, profiles/)
+  cpu_baseline    the oracle (CPU restatement of the reference) on a bounded sample of the same
+                  workload, one core and N-way over the host's cores
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import threading
 import time
 
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+N_DISTINCT = 3          # distinct samples a rank rotates through
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_inputs(seed: int, n_pairs: int, index_seed: int = 2022):
-    from kir_graph_amd import synth, packed
+# ------------------------------------------------------------------------------------------ inputs
+def build_index(index_seed: int = 2022):
+    from kir_graph_amd import synth
     from kir_graph_amd.index import GkIndex
-    t = time.time()
     sidx = synth.makeIndex(seed=index_seed)
     gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
     by_gene = {}
     for v in sidx.variants:
         by_gene.setdefault(v.ref, []).append(v)
+    return sidx, gidx, by_gene
+
+
+def build_sample(sidx, gidx, by_gene, seed: int, n_pairs: int):
+    from kir_graph_amd import synth, packed
     sample = synth.makeSample(sidx, seed=seed, n_pairs=n_pairs, variants_by_gene=by_gene)
     rec, table = packed.packSample(sample, gidx)
+    return sample, rec, table
+
+
+def build_inputs(seed: int, n_pairs: int, index_seed: int = 2022):
+    """(index, packed index, sample, records, string table) of one synthetic sample (tests use this)."""
+    t = time.time()
+    sidx, gidx, by_gene = build_index(index_seed)
+    sample, rec, table = build_sample(sidx, gidx, by_gene, seed, n_pairs)
     log(f"[bench] inputs: {len(gidx.variants)} variants, {sum(len(t.alleles) for t in gidx.tables)} alleles, "
         f"{n_pairs} pairs in {time.time() - t:.1f}s")
     return sidx, gidx, sample, rec, table
 
 
-def run_steps(n_steps, dev, dindex, gidx, mates_buf, table, gene_cn, method):
-    """``n_steps`` samples: tabulation + typing of records resident in HBM.
+class PinnedRecords:
+    """The packed records of a sample in pinned host memory (gk_host_alloc): the start of a step."""
 
-    Like a cohort run, the samples go through ``cohort.prefetched`` and ``cohort.overlapped``: the
-    tabulation of the next sample is issued while the current one is typed; with GK_SAMPLE_LANES=2
-    two samples are typed at a time (each on its own block of worker streams).  Every tabulation and
-    typing of the ``n_steps`` samples starts and ends inside this call."""
+    def __init__(self, rec):
+        import numpy as np
+        from kir_graph_amd._lib import check, lib
+        self.nbytes, self.count, self.dtype = rec.nbytes, len(rec), rec.dtype
+        p = C.c_void_p()
+        check(lib().gk_host_alloc(self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        view = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self.ptr))
+        view[:] = rec.view(np.uint8).reshape(-1)
+
+    def toDevice(self, dev):
+        """Queue the copy on ``dev``'s stream; kernels launched on that stream afterwards see the records."""
+        from kir_graph_amd._lib import check, lib
+        buf = dev.alloc(self.count, self.dtype)
+        check(lib().gk_h2d_async(dev.ctx, buf.ptr, C.c_void_p(self.ptr), self.nbytes))
+        return buf
+
+    def free(self):
+        from kir_graph_amd._lib import lib
+        if self.ptr:
+            lib().gk_host_free(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+
+# ------------------------------------------------------------------------------------------ steps
+def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None):
+    """Types the samples ``inputs[k % len(inputs)]`` for k in ``items``: pinned records -> HBM -> tabulation ->
+    typing -> calls.  Like a cohort run the samples go through ``cohort.prefetched``: copy + tabulation of
+    the next sample are issued (on their own stream) while the current one is typed.  Every copy,
+    tabulation and typing of the listed samples starts and ends inside this call."""
     from kir_graph_amd.cohort import overlapped, prefetched
     from kir_graph_amd.engine import Tabulation
     from kir_graph_amd.hisat2 import SampleData
     from kir_graph_amd.kir_typing import hostThreads, selectKirTypingModel
-    depth = int(os.environ.get("GK_PREFETCH", "1"))
+    depth = int(os.environ.get("GK_PREFETCH", "1")) if depth is None else depth
     lanes = int(os.environ.get("GK_SAMPLE_LANES", "1"))   # 2: two samples typed at a time (gain varies from box to box)
     ingest = dev.worker(lanes * hostThreads())   # a context of its own: the typing lanes use workers 0..lanes*n-1
 
-    def type_one(tab, lane):
+    def stage(k):
+        pinned, table, gene_cn = inputs[k % len(inputs)]
+        mates = pinned.toDevice(ingest)
+        return Tabulation(dindex, mates, dev=ingest), table, gene_cn
+
+    def type_one(item, lane):
+        tab, table, gene_cn = item
         data = SampleData(tab, gidx, None, ins_strings=table.strings)
         typer = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
         typer.slot_base = lane * hostThreads()
         calls, warn = typer.typing(gene_cn)
         n_valid = tab.n_valid
         tab.close()
+        tab.mates.free()
         return calls, warn, n_valid, typer
 
     out = None
-    # n_steps: a count, or an iterator that hands out the samples of a region shared with other workers
-    items = range(n_steps) if isinstance(n_steps, int) else n_steps
-    tabs = prefetched(items, lambda _: Tabulation(dindex, mates_buf, dev=ingest), depth=depth)
-    for out in overlapped(tabs, type_one, lanes=lanes):
+    items = range(items) if isinstance(items, int) else items
+    if depth <= 0:
+        for k in items:
+            out = type_one(stage(k), 0)
+        return out
+    for out in overlapped(prefetched(items, stage, depth=depth), type_one, lanes=lanes):
         pass
     return out
 
 
-def cpu_baseline(sidx, gidx, gene_cn, method, n_pairs, seed):
-    """Oracle on a bounded sample of the same workload (single core)."""
+def _oracle_leg(job):
+    """One CPU-baseline job (runs in a fresh process for the N-way leg): tabulate + type with the oracle."""
+    seed, n_pairs, method = job
+    sys.path.insert(0, ROOT)
     from kir_graph_amd import synth
     from oracle import tabulate as ot, typing as oty
-    sample = synth.makeSample(sidx, seed=seed, n_pairs=n_pairs, gene_cn=gene_cn)
+    sidx, gidx, by_gene = build_index()
+    sample = synth.makeSample(sidx, seed=seed, n_pairs=n_pairs, variants_by_gene=by_gene)
     lines = synth.toSamLines(sample, with_zs=False)
     t0 = time.time()
     data = ot.tabulateLines(lines, gidx.variants)
     t1 = time.time()
     typer = oty.makeTyper("full" if method in ("pv", "full") else method, data, top_n=600, variant_correction=True)
-    typer.typing(gene_cn)
+    typer.typing(sample.gene_cn)
     t2 = time.time()
-    return {"value": 2 * n_pairs / (t2 - t0), "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": f"{n_pairs} pairs of the same synthetic workload (oracle: tabulate {t1 - t0:.1f}s + "
-                      f"typing {t2 - t1:.1f}s)"}
+    return t1 - t0, t2 - t1
 
 
-def worker(j, procs, opts, rank, local_rank, gang, rank_barrier=None, timing=None):
+def cpu_baseline(method, n_pairs):
+    """Oracle on a bounded sample of the same workload: one core, then N-way (one sample per core, the way the
+    reference's own speed test runs it: research/test_speed.graphkir.par.sh, `parallel -j 14 --thread 1`)."""
+    import multiprocessing as mp
+    t_tab, t_typ = _oracle_leg((99, n_pairs, method))
+    single = 2 * n_pairs / (t_tab + t_typ)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    n_way = max(1, min(cores, 32))
+    out = {"value": single, "unit": "reads/s", "cores": 1, "kind": "port",
+           "sample": f"{n_pairs} pairs of the same synthetic workload (R_g <= 8 k per gene: the reference's own "
+                     f"real-depth regime); oracle: tabulate {t_tab:.1f}s + typing {t_typ:.1f}s on one core",
+           "host_cores": cores}
+    if n_way > 1:
+        ctx = mp.get_context("spawn")
+        t0 = time.time()
+        with ctx.Pool(n_way) as pool:
+            pool.map(_oracle_leg, [(100 + i, n_pairs, method) for i in range(n_way)])
+        wall = time.time() - t0
+        out["n_way"] = {"value": 2 * n_pairs * n_way / wall, "unit": "reads/s", "cores": n_way,
+                        "sample": f"{n_way} samples of {n_pairs} pairs, one process per core, wall {wall:.1f}s "
+                                  "(inputs generated inside the clock's processes: ~10 % of it)"}
+    return out
+
+
+# ------------------------------------------------------------------------------------------ one worker process
+def worker(j, procs, opts, rank, local_rank, gang, timing=None):
     """Worker j of `procs` on this rank's GPU: builds the inputs, warms up, then types its share of the
     rank's `steps` samples between the common start and end.
 
     One Python process drives the GPU through ~25 host threads at most (gene workers, prefetch) and its
-    interpreter lock serialises their host work; samples are independent, so a rank runs GK_PROCS_PER_GPU
-    processes on its GPU (default 3, with 4 gene threads each), the same way a cohort run may place
-    several ranks on one GPU.  Worker 0 is the rank's own process and keeps the clock: the timed region
-    starts when every worker (and every rank) is ready and ends when every worker's last sample is typed."""
+    interpreter lock serialises their host work; samples are independent, so a rank may run
+    GK_PROCS_PER_GPU processes on its GPU, the same way a cohort run may place several ranks on one GPU.
+    Worker 0 is the rank's own process and keeps the clock: the timed region starts when every worker
+    (and every rank) is ready and ends when every worker's last sample is typed."""
     from types import SimpleNamespace
     args = SimpleNamespace(**opts)
     if j and os.environ.get("GK_BENCH_KILL_WORKER") == str(j):   # test hook: this worker dies at once
         os._exit(3)
-    from kir_graph_amd import _lib
+    from kir_graph_amd import _lib, comm as gk_comm
     from kir_graph_amd.engine import DeviceIndex
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_dev = max(1, _lib.deviceCount())
-    dev = _lib.Device(local_rank % n_dev if world > 1 else 0)
-    sidx, gidx, sample, rec, table = build_inputs(seed=1031 + rank, n_pairs=args.pairs)
-    gene_cn = sample.gene_cn
+    n_dev = _lib.deviceCount()
+    if n_dev == 0:
+        raise RuntimeError("bench.py: no HIP device visible (the typing path has no CPU fallback)")
+    backend = {"nccl": "rccl", "gloo": "file"}.get(os.environ.get("GK_BENCH_BACKEND", "rccl"),
+                                                   os.environ.get("GK_BENCH_BACKEND", "rccl"))
+    if world > 1 and backend == "rccl" and world > n_dev:
+        raise RuntimeError(f"bench.py: {world} ranks but {n_dev} GPU(s): one rank per GPU "
+                           "(GK_BENCH_BACKEND=file rehearses the multi-rank path on fewer GPUs)")
+    dev = _lib.Device(local_rank % n_dev)
+    sidx, gidx, by_gene = build_index()
+    t_in = time.time()
+    inputs, samples = [], []
+    for i in range(max(1, min(N_DISTINCT, args.steps + args.warmup))):
+        sample, rec, table = build_sample(sidx, gidx, by_gene, 1031 + 7 * rank + i, args.pairs)
+        inputs.append((PinnedRecords(rec), table, sample.gene_cn))
+        samples.append(sample)
+        del rec
+    log(f"[bench] rank {rank} worker {j}: {len(inputs)} samples of {args.pairs} pairs in pinned memory "
+        f"({time.time() - t_in:.1f}s)")
     dindex = DeviceIndex(dev, gidx)
-    mates = dev.put(rec)
     dev.sync()
+    comm = None
+    if j == 0 and world > 1:
+        comm = gk_comm.initFromEnv(dev=dev, backend=backend)
+        if comm.world != args.gpus:
+            raise RuntimeError(f"bench.py: --gpus {args.gpus} but {comm.world} ranks joined")
 
     def claims():
         """Samples of the timed region for this worker: all of them, or whatever it gets from the shared counter."""
@@ -139,80 +253,130 @@ def worker(j, procs, opts, rank, local_rank, gang, rank_barrier=None, timing=Non
 
     def gang_wait(name):
         if gang is not None:
-            gang[name].wait(timeout=300)
+            gang[name].wait(timeout=600)
+
+    def profiled(on):
+        for d in all_devices():
+            d.profEnable(on)
+            if on:
+                d.profCollect()
+                d.call_log = []
+
+    def collect():
+        prof, call_log = {}, []
+        for d in all_devices():
+            for k, (n, ms) in d.profCollect().items():
+                n0, ms0 = prof.get(k, (0, 0.0))
+                prof[k] = (n0 + n, ms0 + ms)
+            call_log += d.call_log or []
+        return prof, call_log
 
     n_valid = 0
     if args.warmup:
-        n_valid = run_steps(args.warmup, dev, dindex, gidx, mates, table, gene_cn, args.method)[2]
+        n_valid = run_steps(args.warmup, dev, dindex, gidx, inputs, args.method)[2]
     if j == 0 and getattr(args, "profile_host", False):
         import cProfile
         import pstats
         pr = cProfile.Profile()
         pr.enable()
-        run_steps(1, dev, dindex, gidx, mates, table, gene_cn, args.method)
+        run_steps(1, dev, dindex, gidx, inputs, args.method)
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
-    for d in all_devices():
-        d.profEnable(True)
-        d.profCollect()
-        d.call_log = []
+    profiled(True)
     dev.sync()
     gang_wait("ready")
-    if rank_barrier is not None:
-        rank_barrier()
+    if comm is not None:
+        comm.barrier()          # RCCL all-reduce + stream synchronise: every rank is ready
     gang_wait("go")
     t0 = time.perf_counter()
-    last = run_steps(claims(), dev, dindex, gidx, mates, table, gene_cn, args.method)
+    last = run_steps(claims(), dev, dindex, gidx, inputs, args.method)
     if last is not None:
         n_valid = last[2]
     for d in all_devices():
         d.sync()
     gang_wait("done")
-    if rank_barrier is not None:
-        rank_barrier()
-    if timing is not None:
-        timing["elapsed"] = time.perf_counter() - t0
-    prof, call_log = {}, []
-    for d in all_devices():
-        for k, (n, ms) in d.profCollect().items():
-            n0, ms0 = prof.get(k, (0, 0.0))
-            prof[k] = (n0 + n, ms0 + ms)
-        call_log += d.call_log or []
-        d.profEnable(False)
+    if comm is not None:
+        comm.barrier()
+    elapsed = time.perf_counter() - t0
+    prof, call_log = collect()
+    profiled(False)
     if j:
         gang["results"].put({"prof": prof, "call_log": call_log})
         return None
-    alone = None
-    if procs > 1:   # the same launches with the GPU to this process alone (the other workers are done): untimed
-        for d in all_devices():
-            d.profEnable(True)
-            d.profCollect()
-        run_steps(2, dev, dindex, gidx, mates, table, gene_cn, args.method)
-        alone = {}
-        for d in all_devices():
-            for k, (n, ms) in d.profCollect().items():
-                n0, ms0 = alone.get(k, (0, 0.0))
-                alone[k] = (n0 + n, ms0 + ms)
-            d.profEnable(False)
-    return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "sidx": sidx, "gidx": gidx, "gene_cn": gene_cn,
-            "alone": alone}
+    # ---- the roofline basis: the same step in ONE process, ONE gene thread, no prefetch (kernels back to back)
+    serial = None
+    if args.serial_steps > 0:
+        keep = os.environ.get("GK_THREADS")
+        os.environ["GK_THREADS"] = "1"
+        try:
+            run_steps(1, dev, dindex, gidx, inputs, args.method, depth=0)      # contexts of this mode warm
+            profiled(True)
+            t1 = time.perf_counter()
+            run_steps(args.serial_steps, dev, dindex, gidx, inputs, args.method, depth=0)
+            for d in all_devices():
+                d.sync()
+            s_elapsed = time.perf_counter() - t1
+            s_prof, s_log = collect()
+            profiled(False)
+            serial = {"prof": s_prof, "call_log": s_log, "steps": args.serial_steps,
+                      "ms_per_step": 1e3 * s_elapsed / args.serial_steps}
+        finally:
+            if keep is None:
+                del os.environ["GK_THREADS"]
+            else:
+                os.environ["GK_THREADS"] = keep
+    if comm is not None:
+        elapsed = comm.maxF64(elapsed)
+    timing["elapsed"] = elapsed
+    return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm}
+
+
+# ------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh processes (this process has
+    not touched HIP and never will), wait for all of them, pass rank 0's JSON line on."""
+    rdzv = tempfile.mkdtemp(prefix="gk_bench_rdzv_")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", GK_RDZV_DIR=rdzv)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        log(f"[bench] rank exit codes {codes}: fewer than {args.gpus} ranks finished")
+        sys.exit(1)
+    line = [x for x in out0.splitlines() if x.startswith("{")]
+    if not line:
+        log("[bench] rank 0 printed no result line")
+        sys.exit(1)
+    print(line[-1], flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per sample (config 2: 1e6)")
     ap.add_argument("--method", default="pv")
     ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs for the CPU baseline sample (0 = skip)")
+    ap.add_argument("--serial-steps", type=int, default=2,
+                    help="steps of the one-process serial pass after the timed region (roofline basis; 0 = skip)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--profile-host", action="store_true", help="cProfile one extra step to stderr")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"[bench] --gpus {args.gpus} does not match WORLD_SIZE {world}: start one rank per GPU "
+            f"(torchrun --nproc-per-node {args.gpus}, or no launcher at all)")
+        sys.exit(2)
     # Worker processes of this rank on its GPU (see worker()): started first, before anything touches HIP.
     procs = max(1, int(os.environ.get("GK_PROCS_PER_GPU", "3")))
     procs = min(procs, max(1, args.steps))
@@ -249,30 +413,9 @@ def main():
                     return
         threading.Thread(target=watch, daemon=True).start()
 
-    dist = None
-    backend = os.environ.get("GK_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N > 1 path on one GPU
-    if world > 1:
-        import torch
-        import torch.distributed as dist_
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist_.init_process_group(backend)
-        dist = dist_
-
-    def rank_barrier():
-        if dist is not None:
-            import torch
-            if backend == "nccl":
-                torch.cuda.synchronize()
-            dist.barrier()
-            if backend == "nccl":
-                torch.cuda.synchronize()
-
     timing = {}
     try:
-        res = worker(0, procs, vars(args), rank, local_rank, gang, rank_barrier=rank_barrier, timing=timing)
+        res = worker(0, procs, vars(args), rank, local_rank, gang, timing=timing)
     except threading.BrokenBarrierError:
         # a worker process died or never came up; a single-GPU run starts over in one process, a multi-rank
         # run cannot (the other ranks are past their barriers)
@@ -285,10 +428,9 @@ def main():
         procs, gang = 1, None
         if own_threads:
             del os.environ["GK_THREADS"]
-        res = worker(0, 1, vars(args), rank, local_rank, None, rank_barrier=rank_barrier, timing=timing)
+        res = worker(0, 1, vars(args), rank, local_rank, None, timing=timing)
     elapsed = timing["elapsed"]
-    prof, call_log, n_valid = res["prof"], res["call_log"], res["n_valid"]
-    sidx, gidx, gene_cn = res["sidx"], res["gidx"], res["gene_cn"]
+    prof, call_log, n_valid, gidx = res["prof"], res["call_log"], res["n_valid"], res["gidx"]
     for _ in range(procs - 1):
         other = gang["results"].get(timeout=600)
         for k, (n, ms) in other["prof"].items():
@@ -300,85 +442,68 @@ def main():
         for h in helpers:
             h.join(timeout=30)
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     if rank == 0:
+        from kir_graph_amd import roofmodel
         ms_per_step = 1e3 * elapsed / args.steps
         reads_per_step = 2 * args.pairs * world
         value = reads_per_step / (elapsed / args.steps)
-        total_kernel_ms = sum(v[1] for v in prof.values())
-        dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, 0.0))
         if args.verbose:
             for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
                 log(f"[bench] {k:18s} launches {n:6d}  total {ms:9.3f} ms  avg {ms / n:8.4f} ms")
-            log(f"[bench] kernel time {total_kernel_ms / args.steps:.2f} ms of {ms_per_step:.2f} ms per step")
-        roof = roofline(dom, call_log)
-        # the kernel's share of the whole timed region: work of all its launches over the elapsed time (launches of
-        # different workers overlap, so this is not bounded by the per-launch figure above)
-        n_l, t_ms = dom[1]
-        if elapsed > 0 and t_ms > 0 and roof.get("achieved") is not None:
-            share = (t_ms * 1e-3) / elapsed          # sum of launch durations / wall time
-            roof["region"] = {"achieved": roof["achieved"] * share, "unit": roof["unit"], "frac": roof["frac"] * share,
-                              "valu_frac": roof["valu"]["frac"] * share if "valu" in roof else None,
-                              "note": "algorithmic bytes (ops) of all launches of the kernel / elapsed time of the region"}
-        if res.get("alone") and dom[0] in res["alone"] and roof.get("achieved") is not None:
-            # launch durations in the timed region include the time the kernel shares the GPU with the kernels of
-            # the other worker processes; the same launches right after it, one process on the GPU:
-            n1, ms1 = res["alone"][dom[0]]
-            scale = (dom[1][1] / dom[1][0]) / (ms1 / n1) if n1 and ms1 else None
-            roof["one_process"] = {"avg_launch_ms": ms1 / n1, "launches": n1,
-                                   "achieved": roof["achieved"] * scale if scale else None,
-                                   "frac": roof["frac"] * scale if scale else None,
-                                   "valu_frac": roof["valu"]["frac"] * scale if scale and "valu" in roof else None,
-                                   "note": "2 untimed steps after the timed region, no other worker on the GPU"}
+            log(f"[bench] kernel time {sum(v[1] for v in prof.values()) / args.steps:.2f} ms of {ms_per_step:.2f} ms per step")
         out = {
             "metric": "typed 150 bp PE reads/s (pileup+EM) per GPU; achieved HBM GB/s vs roofline",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: 1 synthetic sample per GPU, {2 * args.pairs} 150 bp PE reads, "
-                                   f"synthetic example_index-shaped index ({sum(len(t.alleles) for t in gidx.tables)} "
-                                   f"alleles, 15 genes), --allele-strategy {args.method}, top_n 600",
+            "config": {"workload": f"configs[1]: 1 synthetic sample per step and GPU ({N_DISTINCT} distinct samples in "
+                                   f"rotation), {2 * args.pairs} 150 bp PE reads, synthetic example_index-shaped index "
+                                   f"({sum(len(t.alleles) for t in gidx.tables)} alleles, 15 genes), "
+                                   f"--allele-strategy {args.method}, top_n 600; records start in pinned host memory "
+                                   "(H2D inside the timed region)",
                        "pairs_per_sample": args.pairs, "pairs_passing_filter": int(n_valid),
                        "parallelism": f"samples sharded over {world} GPU(s), no data-path collective; "
                                       f"{procs} worker process(es) per GPU, {os.environ.get('GK_THREADS', '6')} gene threads each"},
-            "roofline": roof,
-            "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
         }
+        serial = res.get("serial")
+        if serial:
+            s_prof, steps = serial["prof"], serial["steps"]
+            table = {k: {"launches_per_step": n / steps, "ms_per_step": ms / steps, "avg_launch_ms": ms / n}
+                     for k, (n, ms) in sorted(s_prof.items(), key=lambda kv: -kv[1][1])}
+            out["kernels_serial"] = {"ms_per_step_wall": serial["ms_per_step"],
+                                     "kernel_ms_per_step": sum(v[1] for v in s_prof.values()) / steps,
+                                     "mode": "one process, one gene thread, no prefetch (GK_PROCS_PER_GPU=1 GK_THREADS=1 "
+                                             "GK_PREFETCH=0): kernels run back to back",
+                                     "kernels": table}
+            out["roofline"] = roofmodel.dominant(s_prof, serial["call_log"])
+        else:
+            out["roofline"] = roofmodel.dominant(prof, call_log)
+            out["roofline"]["note_basis"] = "launch times taken inside the timed region (other workers share the GPU)"
+        traffic = measured_traffic(out["roofline"].get("kernel"))
+        if traffic is not None:
+            out["roofline"]["traffic"] = traffic[0]
+            out["roofline"]["traffic_source"] = traffic[1]
+        out["kernel_ms_per_step"] = {k: v[1] / args.steps for k, v in prof.items()}
         if args.cpu_pairs and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
-            out["cpu_baseline"] = cpu_baseline(sidx, gidx, gene_cn, args.method, args.cpu_pairs, seed=99)
+            out["cpu_baseline"] = cpu_baseline(args.method, args.cpu_pairs)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if res.get("comm") is not None:
+        res["comm"].close()
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch of ``kernel`` from the committed PMC passes over this same command
-    (profiles/r01_bench_traffic.json, made by tools/collect_profiles.sh), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_traffic.json")
+    """HBM bytes per launch of ``kernel`` from the committed PMC passes over the serial form of this command
+    (profiles/r02_bench_traffic.json, made by tools/collect_profiles.sh), or None."""
+    path = os.path.join(ROOT, "profiles", "r02_bench_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        return float(t["traffic_bytes_per_launch"]) if t.get("kernel") == kernel else None
+        if t.get("kernel") == kernel:
+            return float(t["traffic_bytes_per_launch"]), ("profiles/r02_bench_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                                                          "WRITE_SIZE passes of this command, one process, serial)")
     except (OSError, ValueError, KeyError):
-        return None
-
-
-def roofline(dom, call_log):
-    """Roofline entry of the dominant kernel (algorithmic bytes stated in DESIGN.md)."""
-    from kir_graph_amd import roofmodel
-    name, (launches, total_ms) = dom
-    out = roofmodel.summarise(call_log, name, total_ms, launches)
-    traffic = measured_traffic(name)
-    if traffic is not None:
-        out["traffic"] = traffic
-        out["traffic_source"] = "profiles/r01_bench_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
-    return out
+        pass
+    return None
 
 
 if __name__ == "__main__":

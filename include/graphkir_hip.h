@@ -289,6 +289,27 @@ int gk_cn_fit(gk_ctx* ctx, const double* x, const double* density, int32_t bins,
 int gk_cn_assign(gk_ctx* ctx, const double* x, int32_t bins, double base, const double* dev, int32_t n_cn,
                  int32_t first_cn, double space, int32_t* cn_of_bin_out);
 
+/* ---- cohort collective (one rank per GPU, RCCL over xGMI): the pooling of the gene depths of all samples
+ * before the single copy-number fit of `--cn-cohort` (kir_cn.py:61, 167-177; main.py:572-589) when the
+ * samples are sharded over ranks.  librccl.so is opened on first use.  One rank calls gk_comm_unique_id and
+ * hands the 128 bytes to the others (host-side rendezvous, kir_graph_amd/comm.py); all call gk_comm_create.
+ *   gk_allgather_f64:      recv[r*n .. (r+1)*n) = send of rank r, host buffers, on every rank
+ *   gk_allreduce_max_f64:  element-wise maximum over the ranks, in place (bench.py: max-over-ranks time)
+ *   gk_comm_barrier:       all ranks arrived and the context's stream has drained */
+typedef struct gk_comm gk_comm;
+int gk_comm_unique_id(void* id_out, size_t capacity);
+int gk_comm_create(gk_ctx* ctx, const void* id, size_t id_bytes, int32_t rank, int32_t world, gk_comm** out);
+int gk_comm_destroy(gk_comm* comm);
+int gk_allgather_f64(gk_comm* comm, const double* send, double* recv, int64_t n);
+int gk_allreduce_max_f64(gk_comm* comm, double* inout, int64_t n);
+int gk_comm_barrier(gk_comm* comm);
+
+/* ---- pinned host memory for the packed records of a sample (the packer's output on its way to HBM) and a
+ * host-to-device copy that is only queued on the context's stream (gk_h2d waits for it). */
+int gk_host_alloc(size_t bytes, void** out);
+int gk_host_free(void* p);
+int gk_h2d_async(gk_ctx* ctx, gk_dptr dst, const void* src, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

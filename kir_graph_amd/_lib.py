@@ -8,7 +8,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-import sys
 from pathlib import Path
 
 import numpy as np
@@ -136,6 +135,15 @@ _SIGS = {
                              C.c_int32, C.c_uint64]),
     "gk_em_distinct": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_int32)]),
+    "gk_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "gk_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "gk_comm_destroy": (C.c_int, [C.c_void_p]),
+    "gk_allgather_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "gk_allreduce_max_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "gk_comm_barrier": (C.c_int, [C.c_void_p]),
+    "gk_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "gk_host_free": (C.c_int, [C.c_void_p]),
+    "gk_h2d_async": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]),
     "gk_em_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                             C.c_double, C.c_void_p, C.POINTER(C.c_int32)]),
 }
@@ -152,14 +160,6 @@ def lib():
             raise GkError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). The typing path has no CPU fallback.")
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "torch" not in sys.modules:
-            # A multi-rank run also uses torch.distributed, and PyTorch ships its own copy of the HIP runtime:
-            # when it is loaded first, this library binds to that copy and the process has ONE runtime; the
-            # other order leaves two, and the second one to initialise finds no device.
-            try:
-                import torch  # noqa: F401
-            except ImportError:
-                pass
         handle = C.CDLL(str(path))
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)

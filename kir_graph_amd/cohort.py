@@ -6,8 +6,9 @@ shards embarrassingly: one process per GPU, every rank tabulates and types its o
 merges the per-sample TSVs.  The only exchange is ``--cn-cohort``: the reference pools the raw gene
 depths of all samples into one list before fitting ONE copy-number model (kir_cn.py:61, 167-186).
 Here every rank contributes the depths of its samples through a single all-gather
-(``torch.distributed``: backend ``nccl`` = RCCL over xGMI on the GPUs, ``gloo`` in CPU tests); the
-payload is 8 x (genes + 1) bytes per sample, so the collective is latency bound.
+(``comm.Comm.allgatherF64``: ``gk_allgather_f64`` = RCCL over xGMI when every rank has its own GPU, the
+rendezvous directory otherwise and in the CPU tests); the payload is 8 x (genes + 1) bytes per sample, so
+the collective is latency bound.
 """
 from __future__ import annotations
 
@@ -69,23 +70,49 @@ def overlapped(items, work, lanes: int = 2):
             yield pending.pop(0).result()
 
 
-def shardSamples(n_samples: int, world: int) -> list[list[int]]:
-    """Round-robin assignment of sample indices to ranks (deterministic, known to every rank)."""
-    return [list(range(r, n_samples, world)) for r in range(world)]
+def shardSamples(n_samples: int, world: int, weights=None) -> list[list[int]]:
+    """Assignment of sample indices to ranks, deterministic and known to every rank.
+
+    With ``weights`` (a cost per sample, e.g. the size of its read files): longest processing time first --
+    samples in descending weight go to the least loaded rank (ties: lowest index / lowest rank), SURVEY.md
+    section 8(e); a rank works through its samples in cohort order.  Without: round robin."""
+    if weights is None:
+        return [list(range(r, n_samples, world)) for r in range(world)]
+    assert len(weights) == n_samples
+    load = [0.0] * world
+    shards: list[list[int]] = [[] for _ in range(world)]
+    for i in sorted(range(n_samples), key=lambda i: (-float(weights[i]), i)):
+        r = min(range(world), key=lambda r: (load[r], len(shards[r]), r))
+        shards[r].append(i)
+        load[r] += float(weights[i])
+    return [sorted(s) for s in shards]
+
+
+def sampleWeights(paths: list) -> list[float] | None:
+    """Cost estimate per sample = bytes of its input files (every rank sees the same files); None when a
+    file is missing (the caller then falls back to round robin)."""
+    out = []
+    for group in paths:
+        total = 0
+        for p in ([group] if isinstance(group, str) else group):
+            if not p:
+                continue
+            try:
+                total += os.path.getsize(p)
+            except OSError:
+                return None
+        out.append(float(total))
+    return out if any(out) else None
 
 
 class Comm:
-    """Thin wrapper over an initialised ``torch.distributed`` process group."""
+    """The cohort's samples over the ranks of a launch (``comm.Comm`` does the exchange)."""
 
-    def __init__(self, n_samples: int, device: str | None = None):
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError("torch.distributed is not initialised")
-        self.dist = dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+    def __init__(self, n_samples: int, transport, weights=None):
+        self.transport = transport
+        self.rank, self.world = transport.rank, transport.world
         self.n_samples = n_samples
-        self.shards = shardSamples(n_samples, self.world)
-        self.device = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
+        self.shards = shardSamples(n_samples, self.world, weights)
 
     @property
     def mine(self) -> list[int]:
@@ -95,13 +122,10 @@ class Comm:
         """Pool the gene depths of the whole cohort, in cohort sample order then gene order.
 
         ``local_depths[i]`` belongs to cohort sample ``self.mine[i]``.  One all-gather of a
-        ``[max_local, 1 + genes]`` float64 tensor per rank."""
-        import torch
+        ``[max_local, 1 + genes]`` float64 block per rank (kir_cn.py:61, 167-177)."""
         assert len(local_depths) == len(self.mine)
-        genes = sorted(set().union(*[d.keys() for d in local_depths])) if local_depths else []
-        n_gene = torch.tensor([len(genes)], dtype=torch.int64, device=self.device)
-        self.dist.all_reduce(n_gene, op=self.dist.ReduceOp.MAX)
-        G = int(n_gene.item())
+        n_gene = [len(d) for d in local_depths]
+        G = int(self.transport.maxF64(float(max(n_gene, default=0))))
         max_local = max(len(s) for s in self.shards)
         buf = np.full((max_local, 1 + G), np.nan, dtype=np.float64)
         buf[:, 0] = -1
@@ -110,37 +134,31 @@ class Comm:
                 raise ValueError("all samples of a cohort must report the same genes (samtools depth -aa)")
             buf[i, 0] = gi
             buf[i, 1:] = [d[g] for g in d]          # the sample's own (sorted-gene) order
-        mine = torch.from_numpy(buf).to(self.device)
-        out = torch.empty((self.world * max_local, 1 + G), dtype=mine.dtype, device=self.device)
-        self.dist.all_gather_into_tensor(out, mine)   # ranks concatenated along dim 0
-        rows = out.reshape(-1, 1 + G).cpu().numpy()
+        rows = self.transport.allgatherF64(buf.ravel()).reshape(-1, 1 + G)
         rows = rows[rows[:, 0] >= 0]
         rows = rows[np.argsort(rows[:, 0], kind="stable")]
         if len(rows) != self.n_samples:
             raise RuntimeError(f"cohort all-gather returned {len(rows)} of {self.n_samples} samples")
         return [float(v) for v in rows[:, 1:].reshape(-1)]
 
+    def gatherInCohortOrder(self, mine: list) -> list:
+        """Per-sample items of every rank (``mine[k]`` belongs to sample ``self.mine[k]``) back in cohort order."""
+        everyone = self.transport.allgatherObject(list(mine))
+        out = [None] * self.n_samples
+        for r, idxs in enumerate(self.shards):
+            for k, gi in enumerate(idxs):
+                if k < len(everyone[r]):
+                    out[gi] = everyone[r][k]
+        return out
+
     def barrier(self) -> None:
-        self.dist.barrier()
+        self.transport.barrier()
+
+    def close(self) -> None:
+        self.transport.close()
 
 
-def initFromEnv(backend: str | None = None):
-    """Initialise ``torch.distributed`` from RANK / WORLD_SIZE / MASTER_* (torchrun); None if single."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
-        return None
-    import torch
-    import torch.distributed as dist
-    if backend is None:
-        # more ranks than GPUs on this node (several processes per GPU, each with its own interpreter lock):
-        # RCCL wants one rank per device, and the only exchange is a few hundred bytes -- gloo carries it
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        one_per_gpu = torch.cuda.is_available() and local_world <= torch.cuda.device_count()
-        backend = "nccl" if one_per_gpu else "gloo"
-    if backend == "nccl":
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        dist.init_process_group(backend)
-    return dist
+def initFromEnv(dev=None, backend: str | None = None):
+    """The launch's ``comm.Comm`` (RANK / WORLD_SIZE / LOCAL_RANK from torchrun or ``bench.py --gpus``), None if single."""
+    from . import comm
+    return comm.initFromEnv(dev=dev, backend=backend)

@@ -83,6 +83,8 @@ class Tabulation:
         if info.err_flags & 1:
             raise AssertionError("variant window has left > right (graphkir/hisat2.py:744)")
         self._novel_keys = None
+        if self.dev.call_log is not None:
+            self.dev.call_log.append(("tab_count", self.n_pairs, self.n_valid, self.n_ids))
 
     @property
     def n_var_total(self) -> int:
@@ -341,6 +343,9 @@ class DeviceModel:
     def _launchLog(self) -> None:
         vbeg, vend, mask, words = self._geom
         self._known_at_launch = self._logs.n_known
+        if self.dev.call_log is not None:    # ids of the rows: the sample's average list length (no sync for a count)
+            per_row = self.tab.n_ids / max(self.tab.n_valid, 1)
+            self.dev.call_log.append(("compat_kernel", self.n_rows, self.n_allele, per_row * self.n_rows, 8))
         check(lib().gk_compat_log(self.dev.ctx, self.tab.handle, self.rows.ptr, self.n_rows, self.vflag.ptr, vbeg, vend,
                                   mask.ptr, words, self.n_allele, self._keep_empty, self._logs.handle, self.L.ptr))
 
@@ -390,7 +395,10 @@ class DeviceModel:
         out = np.empty((n_sets, len(cols)), dtype=np.float64)
         if self.dev.call_log is not None:
             n_prev_cols = 0 if ids_p is None else len(np.unique(prev_ids))
-            self.dev.call_log.append(("maxsum_chunks", self.n_rows, n_sets, c_prev, len(cols), n_prev_cols))
+            # the library runs the second allele of the search as a symmetric table (gk_search.hip: gk_maxsum)
+            symmetric = bool(c_prev == 1 and n_sets == len(cols) and n_sets > 32 and
+                             np.array_equal(np.sort(prev_ids.ravel()), np.sort(cols)) and len(np.unique(cols)) == n_sets)
+            self.dev.call_log.append(("maxsum_chunks", self.n_rows, n_sets, c_prev, len(cols), n_prev_cols, symmetric))
         check(lib().gk_maxsum(self.dev.ctx, self.L.ptr, self.n_rows, self.n_rows, ids_p, n_sets, c_prev,
                               cols.ctypes.data, len(cols), out.ctypes.data))
         return out

@@ -10,8 +10,10 @@ readMapping 124-168, alleleTyping 171-220, getCommonName 223-250).  What differs
 * additive flags: ``--alignment`` (use existing name-collated SAM/BAM instead of running hisat2),
   ``--no-variant-json``; ``--allele-strategy`` also accepts ``pv`` (= full) and maps ``report`` to
   the EM strategy (the reference forwards ``report`` to a factory that rejects it, main.py:192);
-* launched under ``torchrun`` the samples are sharded over the ranks (one GPU each); ``--cn-cohort``
-  then pools the gene depths with one all-gather (``cohort.Comm``), rank 0 merges the outputs;
+* launched with RANK / WORLD_SIZE / LOCAL_RANK set (``torchrun`` or any launcher) the samples are sharded over
+  the ranks (one GPU each, largest inputs first); ``--cn-cohort`` then pools the gene depths with one
+  all-gather (``cohort.Comm`` -> ``gk_allgather_f64``, RCCL), rank 0 merges the outputs;
+* a sample is typed and released as soon as its copy numbers are known (memory does not grow with the cohort);
 * index building, WGS extraction and plotting are outside this build: the index files must exist.
 """
 from __future__ import annotations
@@ -61,14 +63,18 @@ def hisatMap(index: str, f1: str, f2: str, output_file: str, threads: int = 1) -
     runTool("samtools", ["samtools", "index", f"-@{threads}", f"{name}.bam"])
 
 
-def readMapping(names, reads, index, index_ref, exon_region_only=False, alignments=None, write_json=True):
-    """Graph mapping (external) -> tabulation (GPU) -> depth (GPU), per sample (main.py:124-168)."""
+def mapSamples(names, reads, index, index_ref, exon_region_only=False, alignments=None, write_json=True):
+    """Graph mapping (external) -> tabulation (GPU) -> depth (GPU), one sample at a time (main.py:124-168).
+
+    Yields ``(alignment file, "{name}.variant", SampleData, depth file)`` per sample, in order.  When a sample
+    is yielded its by-products are on disk and its depth is computed, so what only they needed -- the SAM
+    text of the pairs and the packed records in HBM -- has been released: the consumer holds the CSR of the
+    tabulation only (and closes it after typing), whatever the size of the cohort."""
     gk = GkIndex.load(index_ref)
     gene_len = readLocusLengths(index_ref)
     dev = defaultDevice()
     from .engine import DeviceIndex
     dindex = DeviceIndex(dev, gk)
-    bam_files, processed, depth_files = [], [], []
 
     def prepare(k: int):
         """External mapping (when needed) + native packing of sample k: host work, off the GPU's path."""
@@ -89,13 +95,13 @@ def readMapping(names, reads, index, index_ref, exon_region_only=False, alignmen
     # (three samples ahead on three threads: the serial stretches of one ingest leave cores to the others)
     ahead = max(1, int(os.environ.get("GK_INGEST_AHEAD", "3")))
     for name, source, pack in cohort.prefetched(range(len(names)), prepare, depth=ahead, workers=ahead):
-        bam_files.append(source)
         name += ".variant"
         logger.info(f"[Graph] Filter mapping ({name})")
         if pack is not None:
             data = extractVariantFromPacked(pack, gk, dev=dev, dindex=dindex)
         else:   # BAM name-collated through samtools like the reference (hisat2.readBam)
             data = extractVariant(readPair(source), gk, dev=dev, dindex=dindex)
+        del pack
         if write_json:
             writeSampleJson(data, name + ".json")
             # the reference also rewrites the filtered pairs as BAM (hisat2.py:936-940)
@@ -103,23 +109,45 @@ def readMapping(names, reads, index, index_ref, exon_region_only=False, alignmen
             saveReadsToBam(data, name + ".no_multi", source, filter_multi_mapped=True)
         else:   # compact hand-off instead: CSR + string table, no SAM text (hisat2.writeCompact)
             writeCompact(data, name + ".npz", index_ref=index_ref)
-        processed.append((name, data))
-        name += ".no_multi"
-        logger.info(f"[Graph] Calculate read depth to {name}.depth.tsv")
-        depthOfSample(data, gene_len, name + ".depth.tsv")
-        name += ".depth"
+        depth_name = name + ".no_multi"
+        logger.info(f"[Graph] Calculate read depth to {depth_name}.depth.tsv")
+        depthOfSample(data, gene_len, depth_name + ".depth.tsv")
+        depth_name += ".depth"
         if exon_region_only:
-            logger.info(f"[Graph] Filter exon read to {name}.exon.tsv")
-            filterDepth(name + ".tsv", name + ".exon.tsv", readExons(index_ref))
-            name += ".exon"
-        depth_files.append(name + ".tsv")
+            logger.info(f"[Graph] Filter exon read to {depth_name}.exon.tsv")
+            filterDepth(depth_name + ".tsv", depth_name + ".exon.tsv", readExons(index_ref))
+            depth_name += ".exon"
+        releaseInputs(data)
+        yield source, name, data, depth_name + ".tsv"
+
+
+def releaseInputs(data: SampleData) -> None:
+    """Drop what only the by-products and the depth needed: the SAM text of the pairs (host) and the packed
+    records (HBM, 256 B per pair).  The tabulation's lists stay for typing."""
+    data.pairs_text = None
+    data._reads = None
+    mates = getattr(data.tab, "mates", None)
+    if mates is not None:
+        mates.free()
+        data.tab.mates = None
+
+
+def readMapping(names, reads, index, index_ref, exon_region_only=False, alignments=None, write_json=True):
+    """List form of ``mapSamples`` with the reference's return value (bam files, processed, depth files)."""
+    bam_files, processed, depth_files = [], [], []
+    for source, name, data, depth_file in mapSamples(names, reads, index, index_ref, exon_region_only,
+                                                     alignments, write_json):
+        bam_files.append(source)
+        processed.append((name, data))
+        depth_files.append(depth_file)
     return bam_files, processed, depth_files
 
 
-def alleleTyping(processed_bam, cn_files: list[str], method: str = "full") -> list[str]:
+def alleleTyping(processed_bam, cn_files: list[str], method: str = "full", release: bool = False) -> list[str]:
     """Allele typing of every sample; writes ``{name}{suffix}.tsv`` and ``.possible.tsv`` (171-220).
 
-    ``processed_bam`` entries are names (the ``.json`` next to them is loaded) or (name, SampleData)."""
+    ``processed_bam`` entries are names (the ``.json`` next to them is loaded) or (name, SampleData);
+    ``release``: close every SampleData's tabulation once its results are taken (the pipeline does)."""
     allele_files = []
     for entry, cn_file in zip(processed_bam, cn_files):
         name, source = entry if isinstance(entry, tuple) else (entry, entry + ".json")
@@ -131,13 +159,15 @@ def alleleTyping(processed_bam, cn_files: list[str], method: str = "full") -> li
         t = selectKirTypingModel(method, source, top_n=600, variant_correction=True)
         cn = loadCN(cn_file)
         called_alleles, warning_genes = t.typing(cn)
+        if release and isinstance(source, SampleData):      # the caller is done with this sample: free its HBM
+            source.tab.close()
         logger.info(f"[Allele] {called_alleles} ({name})")
         name += suffix
         pd.DataFrame({"name": [name], "alleles": ["_".join(called_alleles)],
                       "warnings": ["_".join(warning_genes)]}).to_csv(name + ".tsv", sep="\t", index=False)
         allele_files.append(name + ".tsv")
         try:
-            possible = t.getAllPossibleTyping()
+            possible = t.getAllPossibleTyping()       # reads the ranked results on the host only
         except NotImplementedError:      # EM strategy has no possible-set table (kir_typing.py:63-68)
             possible = []
         pd.DataFrame(possible).fillna("").to_csv(name + ".possible.tsv", index=False, sep="\t")
@@ -238,54 +268,75 @@ def main(args: argparse.Namespace) -> None:
     if not Path(index_ref + ".snp").exists():
         raise FileNotFoundError(f"{index_ref}.snp/.link/.locus not found: building the index is outside this build")
 
-    # shard the cohort over ranks (one GPU per process)
-    dist = cohort.initFromEnv()
-    comm = cohort.Comm(len(names)) if dist is not None else None
+    # shard the cohort over ranks (one GPU per process): longest processing time first by input size
+    transport = cohort.initFromEnv()
+    comm = None
+    if transport is not None:
+        inputs = args.alignment if args.alignment else [list(r) for r in reads]
+        comm = cohort.Comm(len(names), transport, weights=cohort.sampleWeights(inputs))
     mine = comm.mine if comm else list(range(len(names)))
     pick = lambda xs: [xs[i] for i in mine]   # noqa: E731
 
-    bam_files, processed, depth_files = readMapping(
-        pick(names), pick(reads), index, index_ref, exon_region_only=args.cn_exon,
-        alignments=pick(args.alignment) if args.alignment else None, write_json=not args.no_variant_json)
     my_cn = pick(cn_files)
-
     kwargs = {"base_dev": float(args.cn_dist_dev), "start_base": 2}
-    if all(cn_files):
-        pass
-    elif not args.cn_cohort:
-        for i, depth_file in enumerate(depth_files):
-            if my_cn[i]:
-                continue
-            name = str(Path(depth_file).with_suffix(f".{args.cn_select}.{args.cn_algorithm}"))
-            logger.info(f"[CN] Copy number estimation per sample ({name})")
-            predictSamplesCN([depth_file], [name + ".tsv"], "", cluster_method=args.cn_algorithm,
+    method = {"pv": "full", "report": "em"}.get(args.allele_strategy, args.allele_strategy)
+    pooled_fit = args.cn_cohort and not all(cn_files)
+    allele_files: list[str] = []
+    waiting: list[tuple[str, object]] = []      # samples that wait for the pooled copy-number fit
+    depth_files: list[str] = []
+    retained = 0
+    budget = int(float(os.environ.get("GK_RETAIN_GB", "64")) * 2**30)   # tabulations kept in HBM until the pooled fit
+    samples = mapSamples(pick(names), pick(reads), index, index_ref, exon_region_only=args.cn_exon,
+                         alignments=pick(args.alignment) if args.alignment else None,
+                         write_json=not args.no_variant_json)
+    for i, (_, name, data, depth_file) in enumerate(samples):
+        depth_files.append(depth_file)
+        if pooled_fit:
+            # every sample's depth is needed before any can be typed: keep the tabulation on the device while it
+            # fits the budget, else park it in the compact side-format and reload it for typing
+            size = 4 * (data.tab.n_ids + 4 * data.tab.n_valid) + 6 * data.tab.n_valid
+            if not args.step_skip_typing and retained + size > budget:
+                if args.no_variant_json:
+                    parked = name + ".npz"          # already written by mapSamples
+                else:
+                    parked = name + ".json"
+                data.tab.close()
+                waiting.append((name, parked))
+            else:
+                retained += size
+                waiting.append((name, data))
+            continue
+        if not my_cn[i]:
+            cn_name = str(Path(depth_file).with_suffix(f".{args.cn_select}.{args.cn_algorithm}"))
+            logger.info(f"[CN] Copy number estimation per sample ({cn_name})")
+            predictSamplesCN([depth_file], [cn_name + ".tsv"], "", cluster_method=args.cn_algorithm,
                              cluster_method_kwargs=kwargs, assume_3DL3_diploid=not args.cn_3dl3_not_diploid,
-                             save_cn_model_path=name + ".json", select_mode=args.cn_select)
-            my_cn[i] = name + ".tsv"
-    else:
+                             save_cn_model_path=cn_name + ".json", select_mode=args.cn_select)
+            my_cn[i] = cn_name + ".tsv"
+        # copy numbers known: type the sample now and release it (memory does not grow with the cohort)
+        if not args.step_skip_typing:
+            allele_files += alleleTyping([(name, data)], [my_cn[i]], method=method, release=True)
+        else:
+            data.tab.close()
+    if pooled_fit:
         suffix = f".{args.cn_select}.cohort.{args.cn_algorithm}"
         my_cn = [str(Path(p).with_suffix(suffix + ".tsv")) for p in depth_files]
         logger.info(f"[CN] Copy number estimation by cohort ({cohort_name + suffix})")
         predictSamplesCN(depth_files, my_cn, cluster_method=args.cn_algorithm, cluster_method_kwargs=kwargs,
                          save_cn_model_path=cohort_name + suffix + ".json", select_mode=args.cn_select, comm=comm)
-
-    allele_files: list[str] = []
-    if not args.step_skip_typing:
-        method = {"pv": "full", "report": "em"}.get(args.allele_strategy, args.allele_strategy)
-        allele_files = alleleTyping(processed, my_cn, method=method)
+        for (name, source), cn_file in zip(waiting, my_cn):
+            if args.step_skip_typing:
+                if isinstance(source, SampleData):
+                    source.tab.close()
+                continue
+            entry = (name, source) if isinstance(source, SampleData) or source.endswith(".npz") else name
+            allele_files += alleleTyping([entry], [cn_file], method=method, release=True)
 
     # merge on rank 0, in cohort order
     if comm is not None:
-        all_cn, all_al = [None] * comm.world, [None] * comm.world
-        dist.all_gather_object(all_cn, my_cn)
-        dist.all_gather_object(all_al, allele_files)
+        cn_sorted = comm.gatherInCohortOrder(my_cn)
+        al_sorted = comm.gatherInCohortOrder(allele_files)
         if comm.rank == 0:
-            cn_sorted, al_sorted = [""] * len(names), [""] * len(names)
-            for r, idxs in enumerate(comm.shards):
-                for k, gi in enumerate(idxs):
-                    cn_sorted[gi] = all_cn[r][k]
-                    if all_al[r]:
-                        al_sorted[gi] = all_al[r][k]
             my_cn, allele_files = cn_sorted, [a for a in al_sorted if a]
     if comm is None or comm.rank == 0:
         logger.info(f"[CN] Saved copy number in {cohort_name}.cn.tsv")
@@ -295,7 +346,7 @@ def main(args: argparse.Namespace) -> None:
             mergeAllele(allele_files, cohort_name + ".allele.tsv")
     if comm is not None:
         comm.barrier()
-        dist.destroy_process_group()
+        comm.close()
     logger.info("[Main] Success")
 
 

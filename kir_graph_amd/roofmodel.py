@@ -1,46 +1,143 @@
 """
 Algorithmic bytes / operations of the hot kernels (DESIGN.md section "Roofline accounting").
 
-``maxsum_chunks`` (one launch = one copy-number step of one gene): it must read, once, the
-candidate columns and the columns of the previous sets of the gene's log-likelihood table
-``L`` (f64, column-major ``[allele][read]``) and write the ``T x A`` scores:
+Every model takes the launch geometries recorded by ``engine`` (``Device.call_log``) and returns
+``(bytes, ops)`` per launch -- lower bounds: what the kernel must read and write once, and the
+arithmetic it cannot avoid.  ``dominant`` picks the kernel with the largest time per step and prices it
+against the roof that bounds it.
+
+``maxsum_chunks`` (one launch = one copy-number step of one gene): reads, once, the candidate columns and
+the columns of the previous sets of the gene's log-likelihood table ``L`` (f64, column-major
+``[allele][read]``) and writes the ``T x A`` scores:
 
     bytes = 8 * R * (n_cols + n_prev_cols) + 8 * n_sets * n_cols
-    ops   = 2 * R * n_sets * n_cols            (one f64 max + one f64 add per read, set, column)
+    ops   = 2 * R * (outputs computed)         (one f64 max + one f64 add per read and output)
 
-These are lower bounds (no re-reads counted); the kernel re-reads L tiles through L2/MALL.
+A symmetric launch (the second allele of the search: set t IS column t) computes the tiles on or above the
+diagonal only (gk_search.hip), so ``outputs computed`` counts the 32 x 32 tiles with tile_a >= tile_t.
+It is a (max,+) contraction: f64 VALU bound, the HBM figure is reported next to it.
+
+``minsum_u8`` (integer bound of the same step): u8 mismatch counts, 4 reads per v_sad_u8.
+``compat_kernel`` / ``tab_count``: byte streams, HBM bound.
 """
 from __future__ import annotations
 
 F64_VALU_PEAK_OPS = 78.6e12 / 2   # v_max_f64 / v_add_f64 issue rate = half the FMA-counted 78.6 TFLOP/s
+# 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one VALU lane-operation per lane and clock
+VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9
 HBM_PEAK_GBS = 8000.0
+TILE = 32
 
 
-def maxsumLaunch(n_rows: int, n_sets: int, c_prev: int, n_cols: int, n_prev_cols: int) -> tuple[float, float]:
+def symmetricOutputs(n: int) -> int:
+    """Outputs a symmetric maxsum launch computes: (t, a) with tile(a) >= tile(t), both < n."""
+    total = 0
+    for t0 in range(0, n, TILE):
+        rows = min(TILE, n - t0)
+        total += rows * (n - t0)          # columns of tiles t0 .. end
+    return total
+
+
+def maxsumLaunch(n_rows: int, n_sets: int, c_prev: int, n_cols: int, n_prev_cols: int,
+                 symmetric: bool = False) -> tuple[float, float]:
     by = 8.0 * n_rows * (n_cols + n_prev_cols) + 8.0 * n_sets * n_cols
-    ops = 2.0 * n_rows * n_sets * n_cols
-    return by, ops
+    outputs = symmetricOutputs(n_cols) if symmetric else n_sets * n_cols
+    return by, 2.0 * n_rows * outputs
+
+
+def minsumLaunch(n_rows: int, n_sets: int, n_cols: int, n_prev_cols: int, symmetric: bool = False
+                 ) -> tuple[float, float]:
+    """u8 tables: bytes = R * (n_cols + n_prev_cols) + 4 * outputs; ops = one v_sad_u8 lane-op per 4 reads
+    and output."""
+    outputs = symmetricOutputs(n_cols) if symmetric else n_sets * n_cols
+    return 1.0 * n_rows * (n_cols + n_prev_cols) + 4.0 * n_sets * n_cols, n_rows * outputs / 4.0
+
+
+def compatLaunch(n_rows: int, n_allele: int, n_ids: float, out_bytes: int = 8) -> tuple[float, float]:
+    """reads the rows' id lists (4 B per id, 16 B of offsets per row), writes the f64 (and u8) table; one
+    select + one multiply per id and allele."""
+    return 4.0 * n_ids + 16.0 * n_rows + float(out_bytes) * n_rows * n_allele, 2.0 * n_ids * n_allele
+
+
+def tabLaunch(n_pairs: int, n_valid: int, n_ids: int) -> tuple[float, float]:
+    """reads 2 x 128-byte records per pair, writes the four id lists."""
+    return 256.0 * n_pairs + 4.0 * n_ids + 22.0 * n_valid, 0.0
+
+
+def setsumLaunch(n_rows: int, n_sets: int, c: int, n_distinct: int) -> tuple[float, float]:
+    """exact value + shares of the contender sets: reads their distinct columns once; c max + 1 add per read, set."""
+    return 8.0 * n_rows * n_distinct + 8.0 * n_sets * (c + 1), float(n_rows) * n_sets * (c + 1)
+
+
+def _priced(kernel: str, calls: list[tuple]) -> tuple[float, float, str, float]:
+    """(bytes, ops, bound, ops peak) summed over the recorded launches of ``kernel``."""
+    by = ops = 0.0
+    bound, peak = "hbm", 0.0
+    for c in calls:
+        if kernel == "maxsum_chunks":
+            b, o = maxsumLaunch(*c[1:7])
+            bound, peak = "valu", F64_VALU_PEAK_OPS
+        elif kernel == "minsum_u8":
+            b, o = minsumLaunch(*c[1:6])
+            bound, peak = "valu", VALU_LANE_OPS
+        elif kernel == "compat_kernel":
+            b, o = compatLaunch(*c[1:5])
+        elif kernel == "tab_count":
+            b, o = tabLaunch(*c[1:4])
+        elif kernel in ("fraction_chunks", "setsum_chunks"):
+            b, o = setsumLaunch(*c[1:5])
+        else:
+            return 0.0, 0.0, "hbm", 0.0
+        by += b
+        ops += o
+    return by, ops, bound, peak
 
 
 def summarise(call_log: list[tuple], kernel: str, total_ms: float, launches: int) -> dict:
     """Roofline entry for ``kernel`` from the recorded launch geometries and its HIP-event time."""
     calls = [c for c in call_log if c[0] == kernel]
-    if kernel != "maxsum_chunks" or not calls or total_ms <= 0:
-        return {"kernel": kernel, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": None, "traffic": None, "launches": launches,
-                "avg_launch_ms": total_ms / max(launches, 1)}
-    by = ops = 0.0
-    for _, r, t, c, a, pc in calls:
-        b, o = maxsumLaunch(r, t, c, a, pc)
-        by += b
-        ops += o
+    base = {"kernel": kernel, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": None, "traffic": None, "launches": launches, "avg_launch_ms": total_ms / max(launches, 1)}
+    if not calls or total_ms <= 0:
+        return base
+    by, ops, bound, peak = _priced(kernel, calls)
+    if by <= 0:
+        return base
     sec = total_ms / 1e3
+    # the log holds one entry per API call; a call may issue more than one launch of the kernel (e.g. the
+    # two template variants of maxsum), so per-launch figures divide by the launches the events counted
     gbs = by / sec / 1e9
-    return {
-        "kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": gbs / HBM_PEAK_GBS, "traffic": None, "launches": launches,
-        "avg_launch_ms": total_ms / max(launches, 1), "algorithmic_bytes_per_launch": by / len(calls),
-        "note": "the (max,+) contraction is f64-VALU bound, not HBM bound; see valu",
-        "valu": {"achieved": ops / sec / 1e12, "peak": F64_VALU_PEAK_OPS / 1e12, "unit": "Tops/s f64 (max+add)",
-                 "frac": ops / sec / F64_VALU_PEAK_OPS},
-    }
+    hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+    out = dict(base)
+    out["algorithmic_bytes_per_launch"] = by / max(launches, 1)
+    if bound == "valu":
+        tops = ops / sec / 1e12
+        unit = "Tops/s f64 (max+add)" if kernel == "maxsum_chunks" else "T lane-ops/s (v_sad_u8, 4 reads each)"
+        out.update({"bound": "valu", "achieved": tops, "peak": peak / 1e12, "unit": unit, "frac": ops / sec / peak,
+                    "algorithmic_ops_per_launch": ops / max(launches, 1), "hbm": hbm,
+                    "note": "a (max,+) / (min,+) contraction: VALU-issue bound, the HBM roof is shown beside it; "
+                            "symmetric launches are credited with the triangle of tiles they compute"})
+    else:
+        out.update(hbm)
+        out["bound"] = "hbm"
+    return out
+
+
+def dominant(prof: dict[str, tuple[int, float]], call_log: list[tuple]) -> dict:
+    """Roofline entry of the kernel with the largest total time in ``prof`` ({name: (launches, ms)})."""
+    if not prof:
+        return summarise([], "none", 0.0, 0)
+    name, (launches, total_ms) = max(prof.items(), key=lambda kv: kv[1][1])
+    out = summarise(call_log, name, total_ms, launches)
+    total = sum(v[1] for v in prof.values())
+    out["share_of_kernel_time"] = total_ms / total if total else None
+    # the other priced kernels, for the record
+    others = {}
+    for k, (n, ms) in prof.items():
+        if k != name and ms > 0.02 * total:
+            e = summarise(call_log, k, ms, n)
+            if e.get("achieved") is not None:
+                others[k] = {f: e[f] for f in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
+    if others:
+        out["other_kernels"] = others
+    return out

@@ -188,3 +188,36 @@ def test_command_line_fits_copy_numbers_itself(device, tmp_path):
                 assert sum(a.split("*")[0] == g.split("*")[0] for a in called) == int(c), (mode, k, g)
         if mode == "cohort":
             assert (out / "cohort.p75.cohort.LCND.json").exists()
+
+
+def test_two_ranks_cn_cohort_equals_one_process(device, tmp_path):
+    """configs[3] in small: ``--cn-cohort`` under two ranks (both on this GPU, so the exchange goes through the
+    rendezvous directory; with a GPU per rank it is gk_allgather_f64 on RCCL -- same payload, same order).
+    Every rank fits the pooled depths itself: the per-sample CN tables of both ranks, the merged cohort tables
+    and the allele calls must equal the single-process run byte for byte."""
+    import subprocess
+    import sys
+    sidx, folder, sams, samples = _cohort(tmp_path, n_samples=5, n_pairs=4000)
+    one = tmp_path / "one"
+    _run(folder, one, sams, ["--cn-cohort"])
+    two = tmp_path / "two"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "kir_graph_amd.main", "--step-skip-extraction", "--index-folder", folder,
+           "--output-folder", str(two), "--allele-strategy", "pv", "--no-variant-json", "--cn-cohort",
+           "--log-level", "WARNING"] + [x for s in sams for x in ("--alignment", s)]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE="2",
+                   GK_COMM_BACKEND="file", GK_RDZV_DIR=str(tmp_path / "rdzv"), PYTHONPATH=root, GK_THREADS="2")
+        procs.append(subprocess.Popen(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (_, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    names = sorted(p.name for p in one.iterdir())
+    assert names == sorted(p.name for p in two.iterdir())
+    for n in names:
+        if n.endswith((".tsv", ".cohort.LCND.json")) and ".depth.tsv" not in n[-10:]:
+            a = (one / n).read_text().replace(str(one), "@")
+            b = (two / n).read_text().replace(str(two), "@")
+            assert a == b, n
+    assert sum(n.endswith(".p75.cohort.LCND.tsv") for n in names) == 5
