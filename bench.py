@@ -328,7 +328,9 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None):
     if comm is not None:
         elapsed = comm.maxF64(elapsed)
     timing["elapsed"] = elapsed
-    return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm}
+    from kir_graph_amd.typing_mulit_allele import SEARCH_STATS
+    return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm,
+            "search_steps": dict(SEARCH_STATS)}
 
 
 # ------------------------------------------------------------------------------------------ launcher
@@ -484,6 +486,7 @@ def main():
             out["roofline"]["traffic"] = traffic[0]
             out["roofline"]["traffic_source"] = traffic[1]
         out["kernel_ms_per_step"] = {k: v[1] / args.steps for k, v in prof.items()}
+        out["search_steps"] = res.get("search_steps")    # worker 0: steps bounded by integers / redone with f64 only
         if args.cpu_pairs and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.method, args.cpu_pairs)
         print(json.dumps(out), flush=True)

@@ -205,6 +205,30 @@ int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int3
 int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets,
               int32_t c, gk_dptr d_P);
 
+/* ---- integer bound of a search step (typing_mulit_allele.py:534-567; SURVEY.md section 8 "integer reformulation").
+ * gk_compat_log_miss = gk_compat_log that also writes the mismatch counts miss[r, a] as a u8 table
+ *   d_miss8 [n_allele][ldm] (ldm a multiple of 64 >= n_rows, rows past the end zero), derived from the
+ *   log-likelihoods; *d_flags (uint32) gets bit 0 when some count is >= 100 (products near underflow: the caller
+ *   must then use gk_maxsum for this gene).
+ * gk_miss_colsum: d_msum uint32 [n_cols] = column sums of that table.
+ * gk_bound_step: M[t, j] = sum_r min(miss[r, cols[j]], min_k miss[r, ids[t*c_prev + k]]) for every candidate,
+ *   restricted to first[t*n_cols + j] != 0 (first occurrences of an allele multiset, uniqueAllele 456-476);
+ *   returns the candidates with M <= M_T, the top_n-th smallest (hdr_out = {candidates, M_T, selected, 0};
+ *   idx_out / m_out hold min(selected, cap) entries in no particular order: flat index t*n_cols + j and M).
+ *   Two sets with different M are ordered by M in float64 as well, so the reference's top_n-by-value (567)
+ *   lies inside the selection.
+ * gk_setsum: exact float64 value (540-542 for one set: sum_r max_j L[r, ids[k,j]], numpy's tree) and the
+ *   abundance shares (575-580) of the given sets in one pass. */
+int gk_compat_log_miss(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag,
+                       int32_t vbeg, int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele,
+                       int32_t keep_empty, gk_lut* lut, gk_dptr d_log, gk_dptr d_miss8, int64_t ldm, gk_dptr d_flags);
+int gk_miss_colsum(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int32_t n_cols, gk_dptr d_msum);
+int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_dptr d_msum, const int32_t* ids,
+                  int32_t n_sets, int32_t c_prev, const int32_t* cols, int32_t n_cols, const uint8_t* first,
+                  int32_t top_n, int32_t cap, uint32_t* hdr_out, int32_t* idx_out, uint32_t* m_out);
+int gk_setsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
+              double* value_out, double* frac_out);
+
 /* ---- EM strategy: typing_em.py:68-188.
  * gk_em_sets: per-row candidate-allele bit sets (getCandidateAllelePerRead + getMostFreqAllele).
  * gk_em_run:  SQUAREM EM on weighted distinct sets (hisatEMnp 107-188), one workgroup. */

@@ -135,6 +135,15 @@ _SIGS = {
                              C.c_int32, C.c_uint64]),
     "gk_em_distinct": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_int32)]),
+    "gk_compat_log_miss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_int32, C.c_int32,
+                                     C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64,
+                                     C.c_int64, C.c_uint64]),
+    "gk_miss_colsum": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_uint64]),
+    "gk_bound_step": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_int32,
+                                C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                C.c_void_p, C.c_void_p]),
+    "gk_setsum": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                            C.c_void_p, C.c_void_p]),
     "gk_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
     "gk_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "gk_comm_destroy": (C.c_int, [C.c_void_p]),

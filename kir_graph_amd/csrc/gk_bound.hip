@@ -1,0 +1,355 @@
+// Integer bound of a likelihood search step: which candidate sets can reach the top_n cut.
+//
+//   gk_miss_colsum / gk_bound_step      AlleleTyping.addCandidate   typing_mulit_allele.py:534-567
+//
+// The reference scores every candidate set S (a previous set + one more allele) with
+// value(S) = sum_r max_{a in S} log_probs[r, a] in float64, sorts ALL of them and keeps the best top_n
+// (plus ties).  For one read every allele shares the number of listed variants n_r, and
+// log_probs[r, a] = (n_r - m) log10(.999) - 3 m up to 1e-12, m = miss[r, a] = how many of them disagree with
+// the allele ("integer reformulation"), so
+//     value(S) = const - 2.99957 * M(S) + noise,   M(S) = sum_r min_{a in S} miss[r, a],  |noise| < 1e-4,
+// and two sets with different M are ordered by M alone.  This file computes M for all T x A candidates on
+// packed bytes and returns the sets with M <= M_T (the T-th smallest among first occurrences): only those
+// can be among the reference's top_n-by-value, and only for those the exact float64 sums are formed
+// afterwards (gk_setsum, with numpy's summation tree).  Everything whose order the float noise decides --
+// sets with equal M -- is inside that selection, so ranks and ties stay the reference's.
+//
+// Mapping to CDNA4: min(a, b) = (a + b - |a - b|) / 2, so M = (sum P + sum m - SAD) / 2 and the inner loop is
+// ONE v_sad_u8 (four reads) with accumulate per 4 (read, set, allele) triples -- 8x fewer instructions than
+// the f64 max + add of the exact kernel, on 8x fewer bytes.  Workgroup = 64 sets x 64 alleles x one slice of
+// the reads; operands are staged through LDS as 16-byte words ([column][8 words + 1 pad]: the b128 reads of
+// 8 consecutive columns fall on disjoint banks), a lane owns a strided 4 x 4 block of outputs and reads
+// 8 words per 64 SADs.  Integer sums are associative, so the reads are cut into as many slices as fill the
+// GPU; a second small kernel adds the slices, and a single-workgroup radix select finds M_T and compacts
+// the selection.
+#include <algorithm>
+
+#include "gk_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kBT = 64, kBA = 64;   // sets x alleles per workgroup
+constexpr int kW = 8;               // staged 16-byte words (of 16 reads) per column and block
+constexpr int kLd = kW + 1;         // padded words per staged column
+constexpr int kStage = (kBT + kBA) * kW / kThreads;   // words fetched per thread and block (4)
+constexpr uint32_t kNotFirst = 0xFFFFFFFFu;
+constexpr int kSelThreads = 1024;
+constexpr int kBins = 2048;
+
+__device__ inline uint32_t sad4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+
+__device__ inline uint32_t min_u8x4(uint32_t a, uint32_t b) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int k = 0; k < 32; k += 8) r |= min((a >> k) & 255u, (b >> k) & 255u) << k;
+  return r;
+}
+
+// msum[a] = sum over the reads of column a (u8 table [n_cols][ldm], rows past the end are zero)
+__global__ __launch_bounds__(kThreads) void colsum_u8(const uint8_t* __restrict__ m, int64_t ldm, uint32_t* __restrict__ out) {
+  const uint4* col = reinterpret_cast<const uint4*>(m + (int64_t)blockIdx.x * ldm);
+  const int64_t n16 = ldm / 16;
+  uint32_t acc = 0;
+  for (int64_t i = threadIdx.x; i < n16; i += kThreads) {
+    const uint4 w = col[i];
+    acc = sad4(w.x, 0, acc); acc = sad4(w.y, 0, acc); acc = sad4(w.z, 0, acc); acc = sad4(w.w, 0, acc);
+  }
+  __shared__ uint32_t part[kThreads];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+}
+
+// P[t][r] = min over the c columns of set t (allele_prob of a set in mismatch counts, line 569), psum[t] = its sum
+__global__ __launch_bounds__(kThreads) void setmin_u8(const uint8_t* __restrict__ m, int64_t ldm,
+                                                      const int32_t* __restrict__ ids, int c, uint8_t* __restrict__ P,
+                                                      uint32_t* __restrict__ psum) {
+  const int t = blockIdx.x;
+  const int64_t n16 = ldm / 16;
+  uint4* dst = reinterpret_cast<uint4*>(P + (int64_t)t * ldm);
+  uint32_t acc = 0;
+  for (int64_t i = threadIdx.x; i < n16; i += kThreads) {
+    uint4 w = reinterpret_cast<const uint4*>(m + (int64_t)ids[t * c] * ldm)[i];
+    for (int k = 1; k < c; ++k) {
+      const uint4 v = reinterpret_cast<const uint4*>(m + (int64_t)ids[t * c + k] * ldm)[i];
+      w.x = min_u8x4(w.x, v.x); w.y = min_u8x4(w.y, v.y); w.z = min_u8x4(w.z, v.z); w.w = min_u8x4(w.w, v.w);
+    }
+    dst[i] = w;
+    acc = sad4(w.x, 0, acc); acc = sad4(w.y, 0, acc); acc = sad4(w.z, 0, acc); acc = sad4(w.w, 0, acc);
+  }
+  __shared__ uint32_t part[kThreads];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) psum[t] = part[0];
+}
+
+// partial[slice][t][a] = sum over the slice's reads of |P_t[r] - m_a[r]|
+__global__ __launch_bounds__(kThreads, 2) void minsum_sad(const uint8_t* __restrict__ Pbase, int64_t ldp,
+                                                          const int32_t* __restrict__ pcol, int n_sets,
+                                                          const uint8_t* __restrict__ Cbase, int64_t ldc,
+                                                          const int32_t* __restrict__ cols, int n_cols, int64_t n16,
+                                                          int blocks_per_slice, int tiles_a,
+                                                          uint32_t* __restrict__ partial) {
+  __shared__ uint4 lds[(kBT + kBA) * kLd];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tile_t = blockIdx.x / tiles_a, tile_a = blockIdx.x % tiles_a;
+  const int t0 = tile_t * kBT, c0 = tile_a * kBA;
+  const int64_t blk0 = (int64_t)blockIdx.y * blocks_per_slice;
+  const int64_t n_blk = (n16 + kW - 1) / kW;
+  const int64_t blk1 = min<int64_t>(blk0 + blocks_per_slice, n_blk);
+
+  // staging: thread -> word (tid & 7) of columns (tid >> 3) + 32 q; columns 0..63 are the sets, 64..127 the alleles
+  const int sw = tid & (kW - 1);
+  const uint4* src[kStage];
+#pragma unroll
+  for (int q = 0; q < kStage; ++q) {
+    const int c = (tid >> 3) + 32 * q;
+    int64_t base;
+    if (c < kBT) {
+      const int t = t0 + c;
+      base = (int64_t)(t < n_sets ? (pcol ? pcol[t] : t) : 0) * ldp;
+      src[q] = reinterpret_cast<const uint4*>(Pbase + base);
+    } else {
+      const int a = c0 + c - kBT;
+      base = (int64_t)(a < n_cols ? cols[a] : cols[0]) * ldc;
+      src[q] = reinterpret_cast<const uint4*>(Cbase + base);
+    }
+  }
+  uint4 pre[kStage];
+  auto fetch = [&](int64_t blk) {
+    const int64_t w = blk * kW + sw;
+#pragma unroll
+    for (int q = 0; q < kStage; ++q) pre[q] = w < n16 ? src[q][w] : make_uint4(0, 0, 0, 0);
+  };
+
+  const int tx = lane & 7, ty = lane >> 3;
+  const int sb = (wid >> 1) * 32 + ty, cb = kBT + (wid & 1) * 32 + tx;   // + 8 x, + 8 y
+  uint32_t acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = 0;
+
+  if (blk0 < blk1) fetch(blk0);
+  for (int64_t blk = blk0; blk < blk1; ++blk) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kStage; ++q) lds[((tid >> 3) + 32 * q) * kLd + sw] = pre[q];
+    __syncthreads();
+    if (blk + 1 < blk1) fetch(blk + 1);
+#pragma unroll
+    for (int i = 0; i < kW; ++i) {
+      uint4 p[4], c[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) p[x] = lds[(sb + 8 * x) * kLd + i];
+#pragma unroll
+      for (int y = 0; y < 4; ++y) c[y] = lds[(cb + 8 * y) * kLd + i];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          uint32_t a = acc[x][y];
+          a = sad4(p[x].x, c[y].x, a);
+          a = sad4(p[x].y, c[y].y, a);
+          a = sad4(p[x].z, c[y].z, a);
+          a = sad4(p[x].w, c[y].w, a);
+          acc[x][y] = a;
+        }
+    }
+  }
+  uint32_t* out = partial + (int64_t)blockIdx.y * n_sets * n_cols;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const int t = t0 + sb + 8 * x;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int a = c0 + cb - kBT + 8 * y;
+      if (t < n_sets && a < n_cols) out[(int64_t)t * n_cols + a] = acc[x][y];
+    }
+  }
+}
+
+// M[t][a] = (psum[t] + msum[col a] - sum of the slices) / 2 for first occurrences, kNotFirst otherwise
+__global__ __launch_bounds__(kThreads) void minsum_finish(const uint32_t* __restrict__ partial, int n_slices,
+                                                          int64_t n_out, int n_cols, const uint32_t* __restrict__ psum,
+                                                          const int32_t* __restrict__ pcol,
+                                                          const uint32_t* __restrict__ msum,
+                                                          const int32_t* __restrict__ cols,
+                                                          const uint8_t* __restrict__ first, uint32_t* __restrict__ M) {
+  const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (o >= n_out) return;
+  if (!first[o]) { M[o] = kNotFirst; return; }
+  uint32_t sad = 0;
+  for (int s = 0; s < n_slices; ++s) sad += partial[(int64_t)s * n_out + o];
+  const int t = (int)(o / n_cols), a = (int)(o % n_cols);
+  const uint32_t sp = pcol ? msum[pcol[t]] : psum[t];
+  M[o] = (sp + msum[cols[a]] - sad) >> 1;
+}
+
+// The T-th smallest M among the candidates (T = top_n) and the candidates at or below it.
+// One workgroup: three histogram rounds (11 + 11 + 10 bits from the top) fix M_T, a last pass appends the
+// selection (flat index, M) in no particular order.  hdr = {candidates, M_T, selected, 0}.
+__global__ __launch_bounds__(kSelThreads) void select_cut(const uint32_t* __restrict__ M, int64_t n, int top_n, int cap,
+                                                          uint32_t* __restrict__ hdr, int32_t* __restrict__ idx_out,
+                                                          uint32_t* __restrict__ m_out) {
+  __shared__ uint32_t hist[kBins];
+  __shared__ uint32_t s_prefix, s_rank, s_count, s_sel;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_count = 0; s_sel = 0; }
+  __syncthreads();
+  uint32_t mine = 0;
+  for (int64_t i = tid; i < n; i += kSelThreads) mine += M[i] != kNotFirst;
+  atomicAdd(&s_count, mine);
+  __syncthreads();
+  const uint32_t n_cand = s_count;
+  if (n_cand == 0) {
+    if (tid == 0) { hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; }
+    return;
+  }
+  uint32_t rank = (uint32_t)min<int64_t>(top_n, n_cand) - 1;   // 0-based rank of the cut value
+  uint32_t prefix = 0;                                         // bits fixed so far (from the top)
+  const int shifts[3] = {21, 10, 0};
+  const int widths[3] = {11, 11, 10};
+  for (int round = 0; round < 3; ++round) {
+    for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
+    __syncthreads();
+    const int sh = shifts[round], wd = widths[round];
+    const uint32_t hi_mask = round == 0 ? 0u : ~((1u << (sh + wd)) - 1u);
+    for (int64_t i = tid; i < n; i += kSelThreads) {
+      const uint32_t v = M[i];
+      if (v != kNotFirst && (v & hi_mask) == prefix) atomicAdd(&hist[(v >> sh) & ((1u << wd) - 1u)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t run = 0;
+      int b = 0;
+      for (; b < (1 << wd); ++b) {
+        if (run + hist[b] > rank) break;
+        run += hist[b];
+      }
+      s_prefix = prefix | ((uint32_t)b << sh);
+      s_rank = rank - run;
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    rank = s_rank;
+  }
+  const uint32_t cut = prefix;
+  for (int64_t i = tid; i < n; i += kSelThreads) {
+    const uint32_t v = M[i];
+    if (v != kNotFirst && v <= cut) {
+      const uint32_t k = atomicAdd(&s_sel, 1u);
+      if (k < (uint32_t)cap) { idx_out[k] = (int32_t)i; m_out[k] = v; }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { hdr[0] = n_cand; hdr[1] = cut; hdr[2] = s_sel; hdr[3] = 0; }
+}
+
+}  // namespace
+
+extern "C" {
+
+// msum_out (device, uint32 [n_cols]) = column sums of the mismatch table written by gk_compat_log_miss
+int gk_miss_colsum(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int32_t n_cols, gk_dptr d_msum) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && d_miss8 && d_msum && n_cols > 0 && ldm > 0 && ldm % 64 == 0, "bad mismatch table");
+  GK_KERNEL(colsum_u8, dim3((unsigned)n_cols), dim3(kThreads), 0, ctx->stream, gk_ptr<uint8_t>(d_miss8), ldm,
+            gk_ptr<uint32_t>(d_msum));
+  GK_HIP(hipGetLastError());
+  return GK_OK;
+}
+
+int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_dptr d_msum, const int32_t* ids,
+                  int32_t n_sets, int32_t c_prev, const int32_t* cols, int32_t n_cols, const uint8_t* first,
+                  int32_t top_n, int32_t cap, uint32_t* hdr_out, int32_t* idx_out, uint32_t* m_out) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && d_miss8 && d_msum && ids && cols && first && hdr_out && idx_out && m_out, "null pointer");
+  GK_REQUIRE(n_sets >= 1 && n_cols >= 1 && c_prev >= 1 && c_prev <= 8 && top_n >= 1 && cap >= 1, "bad bound arguments");
+  GK_REQUIRE(ldm >= n_rows && ldm % 64 == 0 && n_rows > 0, "mismatch table stride must be a multiple of 64 rows");
+  GK_REQUIRE(n_rows < (int64_t)16000000, "too many reads for 32-bit mismatch totals");
+  hipStream_t st = ctx->stream;
+  const int64_t n_out = (int64_t)n_sets * n_cols;
+  // parameters through the context's pinned staging: [ids | cols | first mask]
+  const size_t n_ids = (size_t)n_sets * c_prev;
+  const size_t par_bytes = (n_ids + (size_t)n_cols) * sizeof(int32_t) + (size_t)n_out;
+  if (ctx->pinned_bytes < par_bytes) {
+    if (ctx->pinned) GK_HIP(hipHostFree(ctx->pinned));
+    ctx->pinned_bytes = std::max<size_t>(par_bytes * 2, 1 << 16);
+    GK_HIP(hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+  }
+  char* stage = (char*)ctx->pinned;
+  memcpy(stage, ids, n_ids * sizeof(int32_t));
+  memcpy(stage + n_ids * sizeof(int32_t), cols, (size_t)n_cols * sizeof(int32_t));
+  memcpy(stage + (n_ids + n_cols) * sizeof(int32_t), first, (size_t)n_out);
+  char* d_par = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_par, par_bytes));
+  GK_HIP(hipMemcpyAsync(d_par, stage, par_bytes, hipMemcpyHostToDevice, st));
+  const int32_t* d_ids = (const int32_t*)d_par;
+  const int32_t* d_cols = d_ids + n_ids;
+  const uint8_t* d_first = (const uint8_t*)(d_cols + n_cols);
+
+  const uint8_t* miss = gk_ptr<uint8_t>(d_miss8);
+  uint8_t* d_P = nullptr;
+  uint32_t* d_psum = nullptr;
+  if (c_prev >= 2) {   // previous sets of two or more alleles become one column each
+    GK_HIP(gk_pool_malloc(ctx, (void**)&d_P, (size_t)n_sets * (size_t)ldm));
+    GK_HIP(gk_pool_malloc(ctx, (void**)&d_psum, (size_t)n_sets * sizeof(uint32_t)));
+    GK_PROF(ctx, GK_K_SETMIN, GK_KERNEL(setmin_u8, dim3((unsigned)n_sets), dim3(kThreads), 0, st, miss, ldm, d_ids,
+                                        c_prev, d_P, d_psum));
+  }
+  const int64_t n16 = ldm / 16;
+  const int64_t n_blk = (n16 + kW - 1) / kW;
+  const int tiles_t = (n_sets + kBT - 1) / kBT, tiles_a = (n_cols + kBA - 1) / kBA;
+  // enough slices of the reads to fill the GPU (256 CUs x 2 workgroups x 4), at least 16 blocks each
+  int64_t want = (2048 + (int64_t)tiles_t * tiles_a - 1) / ((int64_t)tiles_t * tiles_a);
+  want = std::max<int64_t>(1, std::min<int64_t>(want, std::max<int64_t>(1, n_blk / 16)));
+  const int blocks_per_slice = (int)((n_blk + want - 1) / want);
+  const int n_slices = (int)((n_blk + blocks_per_slice - 1) / blocks_per_slice);
+  uint32_t *d_partial = nullptr, *d_M = nullptr, *d_hdr = nullptr, *d_mout = nullptr;
+  int32_t* d_idx = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * n_slices * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_M, (size_t)n_out * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_hdr, 4 * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_idx, (size_t)cap * sizeof(int32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_mout, (size_t)cap * sizeof(uint32_t)));
+  GK_PROF_EXACT(ctx, GK_K_MINSUM,
+                GK_KERNEL(minsum_sad, dim3((unsigned)(tiles_t * tiles_a), (unsigned)n_slices), dim3(kThreads), 0, st,
+                          c_prev >= 2 ? d_P : miss, ldm, c_prev >= 2 ? (const int32_t*)nullptr : d_ids, n_sets, miss,
+                          ldm, d_cols, n_cols, n16, blocks_per_slice, tiles_a, d_partial));
+  GK_PROF(ctx, GK_K_SELECT_CUT,
+          GK_KERNEL(minsum_finish, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, d_partial,
+                    n_slices, n_out, n_cols, d_psum, c_prev >= 2 ? (const int32_t*)nullptr : d_ids,
+                    gk_ptr<uint32_t>(d_msum), d_cols, d_first, d_M));
+  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_cut, dim3(1), dim3(kSelThreads), 0, st, d_M, n_out, top_n, cap, d_hdr,
+                                          d_idx, d_mout));
+  GK_HIP(hipGetLastError());
+  GK_HIP(hipMemcpyAsync(hdr_out, d_hdr, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  GK_HIP(hipStreamSynchronize(st));
+  const uint32_t n_sel = std::min<uint32_t>(hdr_out[2], (uint32_t)cap);
+  if (n_sel) {
+    GK_HIP(hipMemcpyAsync(idx_out, d_idx, (size_t)n_sel * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GK_HIP(hipMemcpyAsync(m_out, d_mout, (size_t)n_sel * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    GK_HIP(hipStreamSynchronize(st));
+  }
+  gk_pool_free(ctx, d_partial);
+  gk_pool_free(ctx, d_M);
+  gk_pool_free(ctx, d_hdr);
+  gk_pool_free(ctx, d_idx);
+  gk_pool_free(ctx, d_mout);
+  gk_pool_free(ctx, d_par);
+  gk_pool_free(ctx, d_P);
+  gk_pool_free(ctx, d_psum);
+  return GK_OK;
+}
+
+}  // extern "C"

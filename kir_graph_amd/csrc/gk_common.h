@@ -63,7 +63,7 @@ struct gk_ctx {
 enum {
   GK_K_TAB_COUNT = 0, GK_K_TAB_EMIT, GK_K_SCAN, GK_K_NOVEL, GK_K_COUNT_IDS, GK_K_SELECT, GK_K_COMPAT,
   GK_K_LUT_COLLECT, GK_K_LUT_APPLY, GK_K_MAXSUM, GK_K_COMBINE, GK_K_FRACTION, GK_K_SETMAX, GK_K_EM_SETS,
-  GK_K_EM_RUN, GK_K_N
+  GK_K_EM_RUN, GK_K_SETMIN, GK_K_MINSUM, GK_K_SELECT_CUT, GK_K_N
 };
 // Per-kernel timing.  GK_PROF brackets a launch with two events recorded on the stream (cheap; under
 // multi-stream load the span also counts the time the kernel waits for CUs that other streams are using).

@@ -364,7 +364,9 @@ constexpr int kFracSets = kThreads / 8;   // sets per workgroup
 constexpr int kFracRows = 32;             // staged rows per block (4 row-steps of the 8 lanes)
 constexpr int kFracLd = kFracRows + 9;    // + up to 7 tail rows of the leaf, odd stride
 
-template <int kC>
+// kValue: the set's likelihood sum_r max_j L[r, ids[k][j]] (typing_mulit_allele.py:540-542 for ONE set) rides along as
+// one more accumulator -- same terms, same tree, hence the bits of maxsum_chunks -- and is stored after the shares.
+template <int kC, bool kValue>
 __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __restrict__ L, int64_t ld,
                                                             const int32_t* __restrict__ tile_col_off,
                                                             const int32_t* __restrict__ tile_cols,
@@ -388,9 +390,10 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
 #pragma unroll
   for (int q = 1; q <= kC; ++q) inv[q] = 1.0 / (double)q;   // exact IEEE quotients, as numpy's bool / int
   inv[0] = 0.0;
-  double st[kC], hold[kC];
+  constexpr int kO = kC + (kValue ? 1 : 0);   // accumulators per set: the shares, then the value
+  double st[kO], hold[kO];
 #pragma unroll
-  for (int q = 0; q < kC; ++q) st[q] = hold[q] = 0.0;
+  for (int q = 0; q < kO; ++q) st[q] = hold[q] = 0.0;
 
   // acc += the row's shares; staged row index r (0..kFracLd)
   auto add_terms = [&](int r, double* acc) {
@@ -409,6 +412,7 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
     for (int q = 2; q <= kC; ++q) share = cnt == q ? inv[q] : share;
 #pragma unroll
     for (int q = 0; q < kC; ++q) acc[q] += v[q] == best ? share : 0.0;   // 0.0 + x == x: first term exact
+    if (kValue) acc[kC] += best;
   };
 
   for (int li = span.leaf_begin; li < span.leaf_end; ++li) {
@@ -416,9 +420,9 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
     const int64_t r0 = span.row0 + cur.start;
     const int len = cur.len;
     const int n8 = len < 8 ? 0 : len - (len & 7);   // rows summed by the 8 strided accumulators
-    double acc[kC];
+    double acc[kO];
 #pragma unroll
-    for (int q = 0; q < kC; ++q) acc[q] = 0.0;
+    for (int q = 0; q < kO; ++q) acc[q] = 0.0;
     const int n_blocks = n8 ? (n8 + kFracRows - 1) / kFracRows : 1;
     for (int sb = 0; sb < n_blocks; ++sb) {
       const int b0 = sb * kFracRows;
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
       if (last) {
         if (n8) {
 #pragma unroll
-          for (int q = 0; q < kC; ++q) acc[q] = group_sum8(acc[q]);
+          for (int q = 0; q < kO; ++q) acc[q] = group_sum8(acc[q]);
         }
         for (int r = n8; r < len; ++r) add_terms(kFracRows + r - n8, acc);   // same in every lane
       }
@@ -448,31 +452,31 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
     {
       const bool mine = (j == cur.slot);
 #pragma unroll
-      for (int q = 0; q < kC; ++q) st[q] = mine ? acc[q] : st[q];
+      for (int q = 0; q < kO; ++q) st[q] = mine ? acc[q] : st[q];
     }
     const int n_fold = cur.n_add & 0xFF;
     for (int a = 0; a < n_fold; ++a) {
       const int s = cur.slot - a;
       const bool mine = (j == s - 1);
 #pragma unroll
-      for (int q = 0; q < kC; ++q) {
+      for (int q = 0; q < kO; ++q) {
         const double other = dpp_f64<kDppShl1>(st[q]);
         st[q] = mine ? st[q] + other : st[q];
       }
     }
     if (cur.n_add & kLeafHold) {      // left child of the span complete: park its sum (lane 0)
 #pragma unroll
-      for (int q = 0; q < kC; ++q) hold[q] = st[q];
+      for (int q = 0; q < kO; ++q) hold[q] = st[q];
     }
     if (cur.n_add & kLeafAddHold) {   // right child complete
 #pragma unroll
-      for (int q = 0; q < kC; ++q) st[q] = hold[q] + st[q];
+      for (int q = 0; q < kO; ++q) st[q] = hold[q] + st[q];
     }
   }
   if (j == 0 && live) {
     const int64_t ko = perm[k];
 #pragma unroll
-    for (int q = 0; q < kC; ++q) partial[((int64_t)blockIdx.y * n_sets + ko) * kC + q] = st[q];
+    for (int q = 0; q < kO; ++q) partial[((int64_t)blockIdx.y * n_sets + ko) * kO + q] = st[q];
   }
 }
 
@@ -727,8 +731,8 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   return GK_OK;
 }
 
-int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
-                double* frac_out) {
+static int set_shares(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
+                      double* frac_out, double* value_out) {
   gk_bind(ctx);
   GK_REQUIRE(ctx && ids && frac_out && n_rows > 0 && ld >= n_rows && n_sets > 0, "bad fraction arguments");
   GK_REQUIRE(c >= 1 && c <= kMaxC, "copy number beyond supported set size");
@@ -787,17 +791,21 @@ int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int3
   if (rc) return rc;
   hipStream_t st = ctx->stream;
   double *d_partial = nullptr, *d_out = nullptr;
-  const int64_t n_out = (int64_t)n_sets * c;
+  const int per_set = c + (value_out ? 1 : 0);
+  const int64_t n_out = (int64_t)n_sets * per_set;
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * dp.n_spans * sizeof(double)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_out * sizeof(double)));
   const dim3 grid((unsigned)n_tiles, (unsigned)dp.n_spans);
   const size_t lds = (size_t)max_dist * kFracLd * sizeof(double);   // <= 256 columns * 41 * 8 = 84 KB
-#define GK_FRAC_LAUNCH(C)                                                                                            \
+#define GK_FRAC_LAUNCH_V(C, V)                                                                                       \
   if (lds > 48 * 1024)                                                                                               \
-    GK_HIP(hipFuncSetAttribute((const void*)fraction_chunks<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    GK_HIP(hipFuncSetAttribute((const void*)fraction_chunks<C, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
   GK_PROF(ctx, GK_K_FRACTION,                                                                                        \
-          GK_KERNEL(fraction_chunks<C>, grid, dim3(kThreads), lds, st, gk_ptr<double>(d_L), ld, dp.ids,     \
+          GK_KERNEL((fraction_chunks<C, V>), grid, dim3(kThreads), lds, st, gk_ptr<double>(d_L), ld, dp.ids,     \
                              dp.ids + o_cols, dp.ids + o_local, dp.ids + o_perm, n_sets, dp.spans, dp.leaves, d_partial))
+#define GK_FRAC_LAUNCH(C)                 \
+  if (value_out) { GK_FRAC_LAUNCH_V(C, true); } \
+  else { GK_FRAC_LAUNCH_V(C, false); }
   switch (c) {
     case 1: GK_FRAC_LAUNCH(1); break;
     case 2: GK_FRAC_LAUNCH(2); break;
@@ -809,16 +817,42 @@ int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int3
     default: GK_FRAC_LAUNCH(8); break;
   }
 #undef GK_FRAC_LAUNCH
+#undef GK_FRAC_LAUNCH_V
+  // with the value riding along the sums are handed back undivided (the caller divides the shares by n_rows)
   GK_PROF(ctx, GK_K_COMBINE,
           GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st,
-                             d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, (double)n_rows, d_out));
+                             d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top,
+                             value_out ? 0.0 : (double)n_rows, d_out));
   GK_HIP(hipGetLastError());
-  GK_HIP(hipMemcpyAsync(frac_out, d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
-  GK_HIP(hipStreamSynchronize(st));
+  if (!value_out) {
+    GK_HIP(hipMemcpyAsync(frac_out, d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+    GK_HIP(hipStreamSynchronize(st));
+  } else {
+    std::vector<double> both((size_t)n_out);
+    GK_HIP(hipMemcpyAsync(both.data(), d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+    GK_HIP(hipStreamSynchronize(st));
+    const double rows = (double)n_rows;
+    for (int k = 0; k < n_sets; ++k) {
+      const double* src = both.data() + (size_t)k * per_set;
+      for (int q = 0; q < c; ++q) frac_out[(size_t)k * c + q] = src[q] / rows;   // the IEEE quotient numpy forms (580)
+      value_out[k] = src[c];
+    }
+  }
   gk_pool_free(ctx, d_partial);
   gk_pool_free(ctx, d_out);
   gk_pool_free(ctx, dp.base);
   return GK_OK;
+}
+
+int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
+                double* frac_out) {
+  return set_shares(ctx, d_L, n_rows, ld, ids, n_sets, c, frac_out, nullptr);
+}
+
+int gk_setsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
+              double* value_out, double* frac_out) {
+  GK_REQUIRE(value_out, "null output");
+  return set_shares(ctx, d_L, n_rows, ld, ids, n_sets, c, frac_out, value_out);
 }
 
 int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,

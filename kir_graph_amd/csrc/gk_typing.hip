@@ -198,7 +198,8 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
                                                                 const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
                                                                 const uint32_t* mask_t, int words, int n_allele, int a_base,
                                                                 double* probs, uint8_t* miss_out, uint16_t* nvar_out,
-                                                                LutView lut, double empty_p) {
+                                                                LutView lut, double empty_p, uint8_t* miss8, int64_t ldm,
+                                                                uint32_t* bound_flags) {
   const int n_span = vend - vbeg;   // mask_t: [words][n_span], see transpose_mask
   constexpr int kPassAlleles = 64 * kSlots;
   constexpr int kPassWords = 2 * kSlots;   // bit-row words covering one pass
@@ -327,9 +328,10 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
       double val0 = 0.0, val1 = 0.0;
       for (int idx = tid; idx < n_pass * kTileRows; idx += kCompatThreads) {
         const int al = idx / kTileRows, r = idx % kTileRows;
-        if (r >= n_r) continue;
-        double v = tile[al * kTileLd + r];
-        if (kLog) {
+        const bool in = r < n_r;
+        if (!in && !(kLog && miss8)) continue;
+        double v = in ? tile[al * kTileLd + r] : 1.0;
+        if (kLog && in) {
           // one read's alleles share a handful of values: most lookups end in these two registers
           const uint64_t key = (uint64_t)__double_as_longlong(v);
           if (key != key0) {
@@ -346,7 +348,28 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
           }
           v = val0;
         }
-        probs[(int64_t)(a_base + al) * n_rows + row0 + r] = v;
+        if (in) probs[(int64_t)(a_base + al) * n_rows + row0 + r] = v;
+        if (kLog && miss8) {
+          // The mismatch count of (read, allele) read back from the log-likelihood: -L = 3 m + 0.000434 (n - m),
+          // so m = floor(-L / 3 + 1/4) for any list shorter than ~5000 ids.  u8 table [allele][ldm], four rows of
+          // a quad packed into one store; rows past the end hold 0 (they add nothing to any |a - b| sum).
+          // A count >= 100 (the product is about to leave the normal range / underflow, L = -inf) raises the
+          // flag that sends the gene to the exact search; NaN (log10 not defined yet) is rewritten by the next pass.
+          uint32_t m = 0;
+          if (in) {
+            const double t = __builtin_fma(v, -1.0 / 3.0, 0.25);
+            if (t < 100.0) m = (uint32_t)(int)t;
+            else { m = 255u; if (v == v) atomicOr(bound_flags, 1u); }
+          }
+          uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xF9, 0xF, 0xF, true);      // lane + 1 of the quad
+          uint32_t packed = m | (x << 8);
+          x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9, 0xF, 0xF, true);               // lane + 2
+          packed |= x << 16;
+          x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9, 0xF, 0xF, true);               // lane + 3
+          packed |= x << 24;
+          if ((r & 3) == 0)
+            *reinterpret_cast<uint32_t*>(miss8 + (int64_t)(a_base + al) * ldm + row0 + r) = packed;
+        }
       }
     }
     __syncthreads();
@@ -356,7 +379,7 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
 template <bool kLog>
 int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int vbeg, int vend,
                   gk_dptr d_mask, int words, int n_allele, double* out, uint8_t* miss, uint16_t* nvar, LutView view,
-                  int keep_empty) {
+                  int keep_empty, uint8_t* miss8 = nullptr, int64_t ldm = 0, uint32_t* bound_flags = nullptr) {
   const double empty_p = keep_empty ? 0.999 : 1.0;
   int64_t want = (n_rows + kTileRows - 1) / kTileRows;
   const dim3 grid((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048)), block(kCompatThreads);
@@ -372,7 +395,7 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
   GK_PROF(ctx, GK_K_COMPAT,                                                                                        \
           GK_KERNEL((compat_kernel<kLog, S, !kLog>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows, \
                              tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, mask_t,  \
-                             words, n_allele, a_base, out, miss, nvar, view, empty_p))
+                             words, n_allele, a_base, out, miss, nvar, view, empty_p, miss8, ldm, bound_flags))
     switch (slots) {
       case 1: GK_COMPAT_LAUNCH(1); break;
       case 2: GK_COMPAT_LAUNCH(2); break;
@@ -580,6 +603,23 @@ int gk_compat_log(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
   GK_REQUIRE(d_log, "null output");
   return launch_compat<true>(ctx, tab, d_rows, n_rows, d_vflag, vbeg, vend, d_mask, words, n_allele,
                              gk_ptr<double>(d_log), nullptr, nullptr, gk_lut_view(lut), keep_empty);
+}
+
+int gk_compat_log_miss(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg,
+                       int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty, gk_lut* lut,
+                       gk_dptr d_log, gk_dptr d_miss8, int64_t ldm, gk_dptr d_flags) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && tab && lut, "null pointer");
+  GK_REQUIRE(words >= 1 && n_allele >= 0 && n_allele <= words * 32 && vend >= vbeg, "bad mask geometry");
+  if (n_rows == 0 || n_allele == 0) return GK_OK;
+  GK_REQUIRE(d_log && d_miss8 && d_flags, "null output");
+  GK_REQUIRE(ldm >= n_rows && ldm % 64 == 0, "mismatch table stride must be a multiple of 64 rows");
+  // rows past the end of every column are zero, and so is the flag word, before the kernel writes
+  GK_HIP(hipMemsetAsync(gk_ptr<void>(d_miss8), 0, (size_t)n_allele * (size_t)ldm, ctx->stream));
+  GK_HIP(hipMemsetAsync(gk_ptr<void>(d_flags), 0, sizeof(uint32_t), ctx->stream));
+  return launch_compat<true>(ctx, tab, d_rows, n_rows, d_vflag, vbeg, vend, d_mask, words, n_allele,
+                             gk_ptr<double>(d_log), nullptr, nullptr, gk_lut_view(lut), keep_empty,
+                             gk_ptr<uint8_t>(d_miss8), ldm, gk_ptr<uint32_t>(d_flags));
 }
 
 }  // extern "C"

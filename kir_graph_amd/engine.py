@@ -30,6 +30,18 @@ def _i32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+def searchMode() -> str:
+    """``bound`` (default): a search step first bounds every candidate set with integer mismatch totals and forms
+    the exact float64 sums only for the sets that can reach the cut; ``exact``: float64 sums for every candidate
+    (GK_SEARCH=exact).  Both give the reference's bits; ``bound`` falls back to ``exact`` for a step whose order
+    would depend on numpy's tie order among sets it did not sum."""
+    import os
+    mode = os.environ.get("GK_SEARCH", "bound")
+    if mode not in ("bound", "exact"):
+        raise ValueError(f"GK_SEARCH={mode!r}: expected 'bound' or 'exact'")
+    return mode
+
+
 class DeviceIndex:
     """Index tables in HBM (``gk_index``) + allele bit rows per gene."""
 
@@ -333,9 +345,18 @@ class DeviceModel:
         self._geom = (vbeg, vend, mask, words)
         self._want_miss = want_miss
         self._known_at_launch = -1
+        # integer bound of the search (csrc/gk_bound.hip): u8 mismatch counts next to the log-likelihoods
+        self.miss8 = self.msum = self._bound_flags = None
+        self.ldm = 0
+        self._bound_ok: bool | None = None
         if n_rows == 0 or n_allele == 0:
             return
         self.L = self.dev.alloc((n_allele, n_rows), np.float64)
+        if searchMode() == "bound" and n_rows < 16_000_000:
+            self.ldm = (n_rows + 63) // 64 * 64
+            self.miss8 = self.dev.alloc((n_allele, self.ldm), np.uint8)
+            self.msum = self.dev.alloc(n_allele, np.uint32)
+            self._bound_flags = self.dev.alloc(1, np.uint32)
         self._launchLog()
         if want_miss:
             self._launchProbs()
@@ -346,8 +367,16 @@ class DeviceModel:
         if self.dev.call_log is not None:    # ids of the rows: the sample's average list length (no sync for a count)
             per_row = self.tab.n_ids / max(self.tab.n_valid, 1)
             self.dev.call_log.append(("compat_kernel", self.n_rows, self.n_allele, per_row * self.n_rows, 8))
-        check(lib().gk_compat_log(self.dev.ctx, self.tab.handle, self.rows.ptr, self.n_rows, self.vflag.ptr, vbeg, vend,
-                                  mask.ptr, words, self.n_allele, self._keep_empty, self._logs.handle, self.L.ptr))
+        if self.miss8 is None:
+            check(lib().gk_compat_log(self.dev.ctx, self.tab.handle, self.rows.ptr, self.n_rows, self.vflag.ptr, vbeg,
+                                      vend, mask.ptr, words, self.n_allele, self._keep_empty, self._logs.handle,
+                                      self.L.ptr))
+            return
+        check(lib().gk_compat_log_miss(self.dev.ctx, self.tab.handle, self.rows.ptr, self.n_rows, self.vflag.ptr, vbeg,
+                                       vend, mask.ptr, words, self.n_allele, self._keep_empty, self._logs.handle,
+                                       self.L.ptr, self.miss8.ptr, self.ldm, self._bound_flags.ptr))
+        check(lib().gk_miss_colsum(self.dev.ctx, self.miss8.ptr, self.ldm, self.n_allele, self.msum.ptr))
+        self._bound_ok = None
 
     def _launchProbs(self) -> None:
         """The un-logged products (and the mismatch counts): only built when somebody asks for them."""
@@ -382,6 +411,50 @@ class DeviceModel:
         else:
             raise _lib.GkError("log10 value table did not settle")
         self._known_at_launch = -1
+
+    # ---- integer bound of a search step
+    @property
+    def boundOk(self) -> bool:
+        """The mismatch table exists and no count came near the underflow range (call after ``finishLog``)."""
+        if self.miss8 is None:
+            return False
+        if self._bound_ok is None:
+            self._bound_ok = int(self._bound_flags.download()[0]) == 0
+        return self._bound_ok
+
+    def boundStep(self, prev_ids: np.ndarray, cols: np.ndarray, first: np.ndarray, top_n: int, cap: int):
+        """Candidates (t, j) = prev_ids[t] + [cols[j]] that can reach the top_n cut: those with
+        M = sum_r min(miss) <= the top_n-th smallest M among ``first``.  Returns (candidates, M_T, flat indices
+        ascending, their M) or None when more than ``cap`` qualify."""
+        prev_ids, cols = _i32(prev_ids), _i32(cols)
+        n_sets, c_prev = prev_ids.shape
+        first = np.ascontiguousarray(first, dtype=np.uint8)
+        assert first.size == n_sets * len(cols)
+        hdr = np.zeros(4, dtype=np.uint32)
+        idx = np.empty(cap, dtype=np.int32)
+        mm = np.empty(cap, dtype=np.uint32)
+        if self.dev.call_log is not None:
+            self.dev.call_log.append(("minsum_sad", self.n_rows, n_sets, len(cols),
+                                      len(np.unique(prev_ids)) if c_prev == 1 else n_sets, False))
+        check(lib().gk_bound_step(self.dev.ctx, self.miss8.ptr, self.ldm, self.n_rows, self.msum.ptr,
+                                  prev_ids.ctypes.data, n_sets, c_prev, cols.ctypes.data, len(cols), first.ctypes.data,
+                                  top_n, cap, hdr.ctypes.data, idx.ctypes.data, mm.ctypes.data))
+        n_sel = int(hdr[2])
+        if n_sel > cap:
+            return None
+        order = np.argsort(idx[:n_sel], kind="stable")
+        return int(hdr[0]), int(hdr[1]), idx[:n_sel][order].astype(np.int64), mm[:n_sel][order]
+
+    def setsum(self, ids: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """(value [k], fraction [k, c]) of the given sets: exact float64, numpy's summation tree."""
+        ids = _i32(ids)
+        value = np.empty(ids.shape[0], dtype=np.float64)
+        frac = np.empty(ids.shape, dtype=np.float64)
+        if self.dev.call_log is not None:
+            self.dev.call_log.append(("fraction_chunks", self.n_rows, ids.shape[0], ids.shape[1], len(np.unique(ids))))
+        check(lib().gk_setsum(self.dev.ctx, self.L.ptr, self.n_rows, self.n_rows, ids.ctypes.data, ids.shape[0],
+                              ids.shape[1], value.ctypes.data, frac.ctypes.data))
+        return value, frac
 
     # ---- reductions (numpy summation tree on the device)
     def maxsum(self, prev_ids: np.ndarray | None, cols: np.ndarray) -> np.ndarray:
@@ -438,6 +511,6 @@ class DeviceModel:
         return self.L.download().reshape(self.n_allele, self.n_rows).T if self.L else np.array([])
 
     def free(self) -> None:
-        for b in (self._probs, self.L, self.miss, self.nvar):
+        for b in (self._probs, self.L, self.miss, self.nvar, self.miss8, self.msum, self._bound_flags):
             if b is not None:
                 b.free()

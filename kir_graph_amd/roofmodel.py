@@ -17,7 +17,7 @@ A symmetric launch (the second allele of the search: set t IS column t) computes
 diagonal only (gk_search.hip), so ``outputs computed`` counts the 32 x 32 tiles with tile_a >= tile_t.
 It is a (max,+) contraction: f64 VALU bound, the HBM figure is reported next to it.
 
-``minsum_u8`` (integer bound of the same step): u8 mismatch counts, 4 reads per v_sad_u8.
+``minsum_sad`` (integer bound of the same step): u8 mismatch counts, 4 reads per v_sad_u8.
 ``compat_kernel`` / ``tab_count``: byte streams, HBM bound.
 """
 from __future__ import annotations
@@ -77,7 +77,7 @@ def _priced(kernel: str, calls: list[tuple]) -> tuple[float, float, str, float]:
         if kernel == "maxsum_chunks":
             b, o = maxsumLaunch(*c[1:7])
             bound, peak = "valu", F64_VALU_PEAK_OPS
-        elif kernel == "minsum_u8":
+        elif kernel == "minsum_sad":
             b, o = minsumLaunch(*c[1:6])
             bound, peak = "valu", VALU_LANE_OPS
         elif kernel == "compat_kernel":

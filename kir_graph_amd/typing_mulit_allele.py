@@ -34,6 +34,8 @@ from .index import buildMask
 from .msa2hisat import Variant
 from .utils import logger
 
+# search steps served by the integer bound / steps it handed back to the exact kernels (diagnostics)
+SEARCH_STATS = {"bounded": 0, "redone_exactly": 0}
 _default_logs: dict[int, LogTable] = {}
 _default_logs_lock = threading.Lock()
 
@@ -439,7 +441,7 @@ class AlleleTyping:
             self.addCandidate()
             self.addHomoResultForCn(cn)
         else:
-            if cn >= 2 and 32 < self._model.n_allele <= self.top_n and self._model.n_rows:
+            if cn >= 2 and 32 < self._model.n_allele <= self.top_n and self._model.n_rows and not self._model.boundOk:
                 # Every allele survives the first step, so the second step scores all allele pairs:
                 # the symmetric table is computed first -- its diagonal sum max(L_a, L_a) = sum L_a IS
                 # the first step's column sum (same terms, same summation tree), so no separate
@@ -538,7 +540,9 @@ class AlleleTyping:
         owner = searches[0][0]
         n_round = max(len(c) for _, c in searches)
         for k in range(n_round):
-            active = [(model, model._candidateSteps(cands[k])) for model, cands in searches if k < len(cands)]
+            # searches in lock-step share launches of the exact kernels; the integer bound is per search
+            active = [(model, model._candidateSteps(cands[k], allow_bound=False))
+                      for model, cands in searches if k < len(cands)]
             pending = []
             for model, gen in active:
                 try:
@@ -558,7 +562,68 @@ class AlleleTyping:
                             pass
                 pending = nxt
 
-    def _candidateSteps(self, candidate_allele: Optional[list[str]] = None):
+    def _boundedStep(self, prev: TypingResult, prev_ids: np.ndarray, cols: np.ndarray) -> Optional[TypingResult]:
+        """One copy-number step through the integer bound (csrc/gk_bound.hip), or None when the step has to be
+        done with float64 sums for every candidate.
+
+        The reference sorts the float64 scores of ALL N first-occurrence candidates (567) and keeps those that
+        reach the top_n-th value.  Scores of sets with different mismatch totals M differ by ~3 per unit, far
+        beyond float noise, so that head lies inside {M <= M_T}: the device selects these sets by M and only
+        their float64 values, per-allele sums and shares are formed -- the same numbers as in the full table.
+        What the full table would add is numpy's argsort order among EQUAL values; it matters only where it
+        is visible in the result: a tie across a cut (which tied sets survive) or between rows that agree in
+        all three ranking keys (their order in the result).  Such a step returns None and is redone exactly."""
+        m, T = self._model, self.top_n
+        first = firstOfSets(prev_ids, cols, m.n_allele)
+        N = int(np.count_nonzero(first))
+        if N == 0:
+            return None
+        sel = m.boundStep(prev_ids, cols, first, T, cap=4 * T + 4096)
+        if sel is None:
+            return None                                     # a flood of ties at the cut
+        _, _, idx, _ = sel
+        t_idx, a_idx = np.divmod(idx, len(cols))
+        ids = np.concatenate([prev_ids[t_idx], cols[a_idx][:, None]], axis=1)
+        value, frac = m.setsum(ids)
+        # the reference's head: rows of the sorted table that reach the top_n-th value (567, 605-609)
+        n_top = min(max(T, N // 5), N)
+        if N > T:
+            v_cut = np.partition(value, len(value) - T)[len(value) - T]          # T-th largest
+            head = np.flatnonzero(value >= v_cut)
+            if n_top > T:
+                if len(head) > n_top:
+                    return None                             # ties run past the N // 5 cut
+            elif len(head) != T:
+                return None                                 # ties across the top_n cut
+        else:
+            head = np.arange(len(value))
+        ids, value, frac = ids[head], value[head], frac[head]
+        sum_indv = self._colsums()[ids]
+        key1, key2 = -value, -sum_indv.sum(axis=1)
+        if len(head) > T:
+            b = np.lexsort((key2, key1))[T - 1]
+            contend = np.nonzero((key1 < key1[b]) | ((key1 == key1[b]) & (key2 <= key2[b])))[0]
+        else:
+            contend = np.arange(len(head))
+        fc = frac[contend]
+        uneven = np.abs(fc - fc.mean(axis=1, keepdims=True)).sum(axis=1)
+        k1, k2 = key1[contend], key2[contend]
+        sub = np.lexsort((uneven, k2, k1))
+        look = sub[:T + 1]                                  # rows of the result and the first one cut off
+        same = (k1[look][1:] == k1[look][:-1]) & (k2[look][1:] == k2[look][:-1]) & \
+               (uneven[look][1:] == uneven[look][:-1])
+        if same.any():
+            return None                                     # rows equal in every key: their order is argsort's
+        sub = sub[:T]
+        order = contend[sub]
+        kept = ids[order]
+        res = TypingResult(
+            n=prev.n + 1, value=value[order], value_sum_indv=sum_indv[order], allele_id=kept,
+            allele_name=LazyNames(kept, self.id_to_allele), allele_prob=LazyAlleleProb([(m, kept)]),
+            fraction=fc[sub], fraction_uniq=np.ones(kept.shape))
+        return res
+
+    def _candidateSteps(self, candidate_allele: Optional[list[str]] = None, allow_bound: bool = True):
         m = self._model
         if not m.n_rows:
             logger.warning("[Allele] Empty reads for typing. Skip")
@@ -583,6 +648,12 @@ class AlleleTyping:
 
         prev = self.result[-1]
         prev_ids = np.asarray(prev.allele_id, dtype=np.int64)
+        if allow_bound and m.boundOk and len(np.unique(cols)) == len(cols):
+            res = self._boundedStep(prev, prev_ids, np.asarray(cols, dtype=np.int64))
+            SEARCH_STATS["bounded" if res is not None else "redone_exactly"] += 1
+            if res is not None:
+                self.result.append(res)
+                return res
         table = getattr(self, "_pair_table", None)
         if table is not None and prev_ids.shape[1] == 1:
             score = table[prev_ids[:, 0]][:, np.asarray(cols, dtype=np.int64)].ravel()

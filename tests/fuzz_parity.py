@@ -95,7 +95,8 @@ def main():
         if n % 10 == 0:
             print(f"[fuzz] {n} cases ok ({time.time() - t0:.0f}s), last: seed {seed}: {info}", flush=True)
         seed += 1
-    print(f"[fuzz] {n} cases, all equal to the oracle")
+    from kir_graph_amd.typing_mulit_allele import SEARCH_STATS
+    print(f"[fuzz] {n} cases, all equal to the oracle; search steps: {SEARCH_STATS}")
 
 
 if __name__ == "__main__":

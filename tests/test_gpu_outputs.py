@@ -219,5 +219,9 @@ def test_two_ranks_cn_cohort_equals_one_process(device, tmp_path):
         if n.endswith((".tsv", ".cohort.LCND.json")) and ".depth.tsv" not in n[-10:]:
             a = (one / n).read_text().replace(str(one), "@")
             b = (two / n).read_text().replace(str(two), "@")
+            if n.endswith(".json"):     # the saved model: same fit; raw_df lists the saving rank's own samples only
+                a, b = json.loads(a), json.loads(b)
+                a.pop("raw_df"), b.pop("raw_df")
+                assert a["data"] == b["data"] and len(a["data"]) == 5 * 15     # the pooled depths, cohort order
             assert a == b, n
     assert sum(n.endswith(".p75.cohort.LCND.tsv") for n in names) == 5

@@ -79,3 +79,72 @@ def test_second_allele_table_is_mirrored_exactly(device, n_allele):
     want = np.maximum(L[:, cols], prev.T[:, :, None]).sum(axis=1)
     assert np.array_equal(out, want)
     dL.free()
+
+
+@pytest.mark.parametrize("n_rows,n_allele,n_sets,c_prev,top_n", [(5, 9, 3, 1, 4), (1000, 33, 40, 1, 25), (8200, 70, 100, 2, 60),
+                                                                 (20011, 130, 129, 3, 600), (129, 17, 16, 1, 1000),
+                                                                 (70001, 200, 200, 1, 600)])
+def test_bound_step_selects_what_numpy_selects(device, n_rows, n_allele, n_sets, c_prev, top_n):
+    """gk_miss_colsum / gk_bound_step straight through the C ABI on a random u8 mismatch table:
+    M = sum_r min(miss) for every candidate, the top_n-th smallest among the masked candidates, and the
+    selection {masked, M <= M_T} -- against numpy."""
+    rng = np.random.default_rng(7 * n_rows + n_allele)
+    miss = rng.integers(0, 4, (n_allele, n_rows)).astype(np.uint8)
+    miss[:, rng.integers(0, n_rows, max(1, n_rows // 50))] += 40         # a few far-off reads
+    ldm = (n_rows + 63) // 64 * 64
+    table8 = np.zeros((n_allele, ldm), dtype=np.uint8)
+    table8[:, :n_rows] = miss
+    d_miss = device.put(table8)
+    d_msum = device.alloc(n_allele, np.uint32)
+    check(lib().gk_miss_colsum(device.ctx, d_miss.ptr, ldm, n_allele, d_msum.ptr))
+    assert np.array_equal(d_msum.download(), miss.sum(axis=1, dtype=np.uint64).astype(np.uint32))
+    cols = np.ascontiguousarray(rng.permutation(n_allele)[:max(1, n_allele - 3)], dtype=np.int32)
+    ids = np.ascontiguousarray(rng.integers(0, n_allele, (n_sets, c_prev)), dtype=np.int32)
+    first = (rng.random((n_sets, len(cols))) < 0.8).astype(np.uint8)
+    cap = 4 * top_n + 4096
+    hdr = np.zeros(4, dtype=np.uint32)
+    idx = np.empty(cap, dtype=np.int32)
+    mm = np.empty(cap, dtype=np.uint32)
+    check(lib().gk_bound_step(device.ctx, d_miss.ptr, ldm, n_rows, d_msum.ptr, ids.ctypes.data, n_sets, c_prev,
+                              cols.ctypes.data, len(cols), first.ctypes.data, top_n, cap, hdr.ctypes.data,
+                              idx.ctypes.data, mm.ctypes.data))
+    prev = miss[ids].min(axis=1).astype(np.int64)                        # [set][read]
+    M = np.stack([np.minimum(prev, miss[c].astype(np.int64)[None, :]).sum(axis=1) for c in cols], axis=1)
+    flat, mask = M.ravel(), first.ravel().astype(bool)
+    n_cand = int(mask.sum())
+    assert int(hdr[0]) == n_cand
+    cut = np.sort(flat[mask])[min(top_n, n_cand) - 1]
+    assert int(hdr[1]) == cut
+    want = np.flatnonzero(mask & (flat <= cut))
+    assert int(hdr[2]) == len(want)
+    if len(want) <= cap:
+        order = np.argsort(idx[:len(want)])
+        assert np.array_equal(idx[:len(want)][order], want)
+        assert np.array_equal(mm[:len(want)][order], flat[want])
+    d_miss.free()
+    d_msum.free()
+
+
+@pytest.mark.parametrize("n_rows,c", [(5, 2), (1000, 2), (8200, 3), (20011, 4), (129, 1)])
+def test_setsum_gives_the_bits_of_maxsum_and_fraction(device, n_rows, c):
+    """gk_setsum = value of gk_maxsum (one set at a time) + shares of gk_fraction, same bits."""
+    rng = np.random.default_rng(n_rows + c)
+    n_allele, n_sets = 60, 90
+    L = table(rng, n_rows, n_allele)
+    dL = device.put(np.ascontiguousarray(L.T))
+    ids = np.ascontiguousarray(rng.integers(0, n_allele, (n_sets, c)), dtype=np.int32)
+    value, frac, frac0 = np.empty(n_sets), np.empty((n_sets, c)), np.empty((n_sets, c))
+    check(lib().gk_setsum(device.ctx, dL.ptr, n_rows, n_rows, ids.ctypes.data, n_sets, c, value.ctypes.data,
+                          frac.ctypes.data))
+    check(lib().gk_fraction(device.ctx, dL.ptr, n_rows, n_rows, ids.ctypes.data, n_sets, c, frac0.ctypes.data))
+    assert np.array_equal(frac, frac0)
+    best = np.asfortranarray(L[:, ids].max(axis=2))      # reads x sets, the read axis contiguous per set
+    assert np.array_equal(value, best.sum(axis=0))
+    if c >= 2:      # the same number as the search's own expression (540-542): previous set + one more column
+        cols = np.arange(n_allele, dtype=np.int32)
+        out = np.empty((n_sets, n_allele))
+        prev = np.ascontiguousarray(ids[:, :c - 1])
+        check(lib().gk_maxsum(device.ctx, dL.ptr, n_rows, n_rows, prev.ctypes.data, n_sets, c - 1, cols.ctypes.data,
+                              n_allele, out.ctypes.data))
+        assert np.array_equal(value, out[np.arange(n_sets), ids[:, c - 1]])
+    dL.free()

@@ -117,3 +117,61 @@ def test_fast_json_writer_is_byte_identical(device, tmp_path):
         if n_pairs > 100:
             assert data.tab.n_novel > 0 and data.tab.n_valid > 8192
         data.tab.close()
+
+
+def test_bounded_search_equals_exact_search(device, small_case, monkeypatch):
+    """GK_SEARCH=bound (integer bound first, float64 sums for the sets that can reach the cut) and GK_SEARCH=exact
+    (float64 sums for every candidate) give the same bits in every field of every copy-number step; the mismatch
+    table the bound works on equals the counts read off the log-likelihoods."""
+    from kir_graph_amd.hisat2 import extractVariant, pairLines
+    from kir_graph_amd.kir_typing import selectKirTypingModel
+    sidx, gidx, sample = small_case
+    data = extractVariant(pairLines(synth.toSamLines(sample)), gidx, dev=device)
+    gene_cn = {g: (k % 4) + 1 for k, g in enumerate(sidx.genes)}
+    results = {}
+    for mode in ("exact", "bound"):
+        monkeypatch.setenv("GK_SEARCH", mode)
+        monkeypatch.setenv("GK_THREADS", "1")
+        for method, top_n in (("full", 600), ("full", 7), ("exonfirst_1", 60)):
+            typer = selectKirTypingModel(method, data, top_n=top_n, variant_correction=True)
+            calls = typer.typing(gene_cn)
+            results[(mode, method, top_n)] = (calls, typer._result)
+    for (mode, method, top_n), (calls, res) in results.items():
+        if mode != "bound":
+            continue
+        want_calls, want = results[("exact", method, top_n)]
+        assert calls == want_calls
+        for gene in want:
+            assert len(res[gene]) == len(want[gene])
+            for x, y in zip(res[gene], want[gene]):
+                for f in ("value", "value_sum_indv", "allele_id", "fraction"):
+                    assert np.array_equal(np.asarray(getattr(x, f)), np.asarray(getattr(y, f))), (method, top_n, gene, f)
+
+
+def test_mismatch_table_equals_counts_from_the_lists(device, small_case, monkeypatch):
+    """The u8 table written next to the log-likelihoods (gk_compat_log_miss) holds exactly the integer
+    mismatch counts of gk_compat's own tally (miss[r, a])."""
+    from kir_graph_amd.engine import DeviceModel
+    from kir_graph_amd.hisat2 import extractVariant, pairLines
+    from kir_graph_amd.typing_mulit_allele import sharedLogTable
+    monkeypatch.setenv("GK_SEARCH", "bound")
+    sidx, gidx, sample = small_case
+    data = extractVariant(pairLines(synth.toSamLines(sample)), gidx, dev=device)
+    tab = data.tab
+    from kir_graph_amd.engine import DeviceIndex
+    for g, t in enumerate(gidx.tables):
+        rows, n_rows = tab.selectGene(g, False)
+        if not n_rows:
+            continue
+        vflag = device.alloc(max(tab.n_var_total, 1), np.uint8).zero()
+        mask = tab.dindex.masks[g]
+        a = DeviceModel(tab, rows, n_rows, vflag, t.vbeg, t.vend, mask, t.words, t.n_allele, sharedLogTable(device))
+        a.finishLog()
+        b = DeviceModel(tab, rows, n_rows, vflag, t.vbeg, t.vend, mask, t.words, t.n_allele, sharedLogTable(device),
+                        want_miss=True)
+        assert a.boundOk
+        got = a.miss8.download().reshape(t.n_allele, a.ldm)
+        want = b.miss.download().reshape(t.n_allele, n_rows)
+        assert np.array_equal(got[:, :n_rows], want)
+        assert not got[:, n_rows:].any()
+        assert np.array_equal(a.msum.download(), want.sum(axis=1, dtype=np.uint32))
