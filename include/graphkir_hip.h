@@ -229,6 +229,32 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
 int gk_setsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
               double* value_out, double* frac_out);
 
+/* ---- the whole greedy search of one gene, host half included: AlleleTyping.addCandidate called n_steps times
+ * (typing_mulit_allele.py:478-598 with 156-214, 456-476), in the calling thread, without the host language's
+ * interpreter.  Every step: first occurrences of the candidate multisets, gk_bound_step + gk_setsum (when
+ * d_miss8 / d_msum are given) or gk_maxsum + gk_fraction, the top_n cut and the stable three-key ranking.
+ * `argsort` stands for numpy.argsort wherever the reference calls it (its order among equal values is part of
+ * the result): ascending order of `values` into `order_out`, 0 on success.  colsum_in (may be NULL) = the
+ * per-allele column sums when the caller already has them.  Results per step (0-based; step s holds sets of
+ * s + 1 alleles): rows, then value[rows], value_sum_indv[rows][n], allele ids[rows][n], fraction[rows][n]. */
+typedef int (*gk_argsort_fn)(const double* values, int64_t n, int64_t* order_out);
+typedef struct gk_search gk_search;
+int gk_search_run(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, int32_t n_allele, gk_dptr d_miss8,
+                  int64_t ldm, gk_dptr d_msum, const int32_t* cols, int32_t n_cols, int32_t n_steps, int32_t top_n,
+                  gk_argsort_fn argsort, const double* colsum_in, gk_search** out);
+int gk_search_steps(gk_search* s, int32_t* n_steps);
+int gk_search_info(gk_search* s, int32_t step, int32_t* n, int64_t* rows, int32_t* bounded);
+int gk_search_copy(gk_search* s, int32_t step, double* value, double* sum_indv, int32_t* ids, double* frac);
+int gk_search_colsum(gk_search* s, double* out);
+/* launch geometries of the run, 7 int64 per device call: kind (0 gk_maxsum, 1 gk_bound_step, 2 gk_setsum /
+ * gk_fraction) and the arguments of the roofline model (kir_graph_amd/roofmodel.py) */
+int gk_search_log(gk_search* s, int64_t* out, int64_t capacity, int64_t* n_out);
+int gk_search_destroy(gk_search* s);
+/* isHomozygous (typing_mulit_allele.py:835-857) on flat observations (position, label code, negative?, count):
+ * *homozygous = 0 when some position shows a second allele above 0.1 and 1 / (2 cn) of its kept counts. */
+int gk_site_verdict(const int64_t* pos, const int64_t* code, const uint8_t* negative, const int64_t* count, int64_t n,
+                    int32_t cn, int32_t* homozygous);
+
 /* ---- EM strategy: typing_em.py:68-188.
  * gk_em_sets: per-row candidate-allele bit sets (getCandidateAllelePerRead + getMostFreqAllele).
  * gk_em_run:  SQUAREM EM on weighted distinct sets (hisatEMnp 107-188), one workgroup. */

@@ -144,6 +144,18 @@ _SIGS = {
                                 C.c_void_p, C.c_void_p]),
     "gk_setsum": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                             C.c_void_p, C.c_void_p]),
+    "gk_search_run": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_int64,
+                                C.c_uint64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                C.POINTER(C.c_void_p)]),
+    "gk_search_steps": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "gk_search_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int32)]),
+    "gk_search_copy": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gk_search_colsum": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gk_search_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "gk_search_destroy": (C.c_int, [C.c_void_p]),
+    "gk_site_verdict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                  C.POINTER(C.c_int32)]),
     "gk_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
     "gk_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "gk_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -158,6 +170,22 @@ _SIGS = {
 }
 
 EXPORTED = sorted(_SIGS)
+
+# numpy.argsort as the callback of gk_search_run (the reference's own sort: its order among equal values is part
+# of the result).  ctypes takes the interpreter lock for the few microseconds of the call.
+ARGSORT_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64))
+
+
+def _numpy_argsort(values, n, order_out):
+    try:
+        v = np.ctypeslib.as_array(values, shape=(n,))
+        np.ctypeslib.as_array(order_out, shape=(n,))[:] = np.argsort(v)
+        return 0
+    except Exception:      # never let an exception cross the C frame
+        return 1
+
+
+NUMPY_ARGSORT = ARGSORT_FN(_numpy_argsort)
 
 
 def lib():

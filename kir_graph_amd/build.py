@@ -10,7 +10,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 SOURCES = ["gk_runtime.hip", "gk_scan.hip", "gk_tabulate.hip", "gk_typing.hip", "gk_lut.hip",
            "gk_search.hip", "gk_bound.hip", "gk_em.hip", "gk_cn.hip", "gk_depth.hip", "gk_sampack.cpp", "gk_bamread.cpp", "gk_textout.cpp",
-           "gk_comm.cpp"]
+           "gk_comm.cpp", "gk_hostsearch.cpp"]
 
 
 def hipcc() -> str:

@@ -196,43 +196,67 @@ __global__ __launch_bounds__(kThreads) void minsum_finish(const uint32_t* __rest
 }
 
 // The T-th smallest M among the candidates (T = top_n) and the candidates at or below it.
-// One workgroup: three histogram rounds (11 + 11 + 10 bits from the top) fix M_T, a last pass appends the
-// selection (flat index, M) in no particular order.  hdr = {candidates, M_T, selected, 0}.
+// One workgroup of 16 waves.  The totals of a step lie in a narrow band (they share most reads), so the
+// values are first reduced to (M - min) and the select runs over the bits that band needs: one or two
+// histogram rounds of 11 bits instead of three over 32.  Every wave counts into its OWN histogram (16 x 2048
+// counters = 128 KB of the CU's 160 KB LDS): lanes of one wave hitting a popular bin serialise among
+// themselves only.  A last pass appends the selection (flat index, M) in no particular order.
+// hdr = {candidates, M_T, selected, 0}.
+constexpr int kSelWaves = kSelThreads / 64;
+
 __global__ __launch_bounds__(kSelThreads) void select_cut(const uint32_t* __restrict__ M, int64_t n, int top_n, int cap,
                                                           uint32_t* __restrict__ hdr, int32_t* __restrict__ idx_out,
                                                           uint32_t* __restrict__ m_out) {
-  __shared__ uint32_t hist[kBins];
-  __shared__ uint32_t s_prefix, s_rank, s_count, s_sel;
-  const int tid = threadIdx.x;
-  if (tid == 0) { s_count = 0; s_sel = 0; }
+  extern __shared__ uint32_t hist[];   // [kSelWaves][kBins]
+  __shared__ uint32_t s_prefix, s_rank, s_count, s_sel, s_min, s_max;
+  const int tid = threadIdx.x, wid = tid >> 6;
+  if (tid == 0) { s_count = 0; s_sel = 0; s_min = kNotFirst; s_max = 0; }
   __syncthreads();
-  uint32_t mine = 0;
-  for (int64_t i = tid; i < n; i += kSelThreads) mine += M[i] != kNotFirst;
-  atomicAdd(&s_count, mine);
+  uint32_t mine = 0, lo = kNotFirst, hi = 0;
+  for (int64_t i = tid; i < n; i += kSelThreads) {
+    const uint32_t v = M[i];
+    if (v != kNotFirst) { ++mine; lo = min(lo, v); hi = max(hi, v); }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    mine += __shfl_xor(mine, off, 64);
+    lo = min(lo, (uint32_t)__shfl_xor(lo, off, 64));
+    hi = max(hi, (uint32_t)__shfl_xor(hi, off, 64));
+  }
+  if ((tid & 63) == 0) { atomicAdd(&s_count, mine); atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
   __syncthreads();
   const uint32_t n_cand = s_count;
   if (n_cand == 0) {
     if (tid == 0) { hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; }
     return;
   }
+  const uint32_t base = s_min, span = s_max - s_min;
+  const int n_bits = span ? 32 - __builtin_clz(span) : 1;
+  const int rounds = (n_bits + 10) / 11;
   uint32_t rank = (uint32_t)min<int64_t>(top_n, n_cand) - 1;   // 0-based rank of the cut value
-  uint32_t prefix = 0;                                         // bits fixed so far (from the top)
-  const int shifts[3] = {21, 10, 0};
-  const int widths[3] = {11, 11, 10};
-  for (int round = 0; round < 3; ++round) {
-    for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
+  uint32_t prefix = 0;                                         // bits of (M_T - base) fixed so far
+  uint32_t* my_hist = hist + wid * kBins;
+  for (int round = rounds - 1; round >= 0; --round) {
+    for (int b = tid; b < kSelWaves * kBins; b += kSelThreads) hist[b] = 0;
     __syncthreads();
-    const int sh = shifts[round], wd = widths[round];
-    const uint32_t hi_mask = round == 0 ? 0u : ~((1u << (sh + wd)) - 1u);
+    const int sh = 11 * round;
+    const uint32_t hi_mask = round == rounds - 1 ? 0u : ~((1u << (sh + 11)) - 1u);
     for (int64_t i = tid; i < n; i += kSelThreads) {
       const uint32_t v = M[i];
-      if (v != kNotFirst && (v & hi_mask) == prefix) atomicAdd(&hist[(v >> sh) & ((1u << wd) - 1u)], 1u);
+      if (v == kNotFirst) continue;
+      const uint32_t d = v - base;
+      if ((d & hi_mask) == prefix) atomicAdd(&my_hist[(d >> sh) & (kBins - 1)], 1u);
+    }
+    __syncthreads();
+    for (int b = tid; b < kBins; b += kSelThreads) {   // fold the waves' histograms into the first one
+      uint32_t c = 0;
+      for (int w = 0; w < kSelWaves; ++w) c += hist[w * kBins + b];
+      hist[b] = c;
     }
     __syncthreads();
     if (tid == 0) {
       uint32_t run = 0;
       int b = 0;
-      for (; b < (1 << wd); ++b) {
+      for (; b < kBins - 1; ++b) {
         if (run + hist[b] > rank) break;
         run += hist[b];
       }
@@ -242,12 +266,22 @@ __global__ __launch_bounds__(kSelThreads) void select_cut(const uint32_t* __rest
     __syncthreads();
     prefix = s_prefix;
     rank = s_rank;
+    __syncthreads();
   }
-  const uint32_t cut = prefix;
+  const uint32_t cut = base + prefix;
   for (int64_t i = tid; i < n; i += kSelThreads) {
     const uint32_t v = M[i];
-    if (v != kNotFirst && v <= cut) {
-      const uint32_t k = atomicAdd(&s_sel, 1u);
+    const bool take = v != kNotFirst && v <= cut;
+    // one atomic per wave: the lanes that take an element get consecutive slots
+    const uint64_t takers = __ballot(take);
+    uint32_t first_slot = 0;
+    if (takers) {
+      const int leader = __ffsll((unsigned long long)takers) - 1;
+      if ((tid & 63) == leader) first_slot = atomicAdd(&s_sel, (uint32_t)__popcll(takers));
+      first_slot = __shfl(first_slot, leader, 64);
+    }
+    if (take) {
+      const uint32_t k = first_slot + (uint32_t)__popcll(takers & ((1ull << (tid & 63)) - 1ull));
       if (k < (uint32_t)cap) { idx_out[k] = (int32_t)i; m_out[k] = v; }
     }
   }
@@ -330,8 +364,14 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
           GK_KERNEL(minsum_finish, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, d_partial,
                     n_slices, n_out, n_cols, d_psum, c_prev >= 2 ? (const int32_t*)nullptr : d_ids,
                     gk_ptr<uint32_t>(d_msum), d_cols, d_first, d_M));
-  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_cut, dim3(1), dim3(kSelThreads), 0, st, d_M, n_out, top_n, cap, d_hdr,
-                                          d_idx, d_mout));
+  constexpr size_t kSelLds = (size_t)kSelWaves * kBins * sizeof(uint32_t);   // 128 KB of per-wave histograms
+  static bool lds_opt_in = false;
+  if (!lds_opt_in) {
+    GK_HIP(hipFuncSetAttribute((const void*)select_cut, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSelLds));
+    lds_opt_in = true;
+  }
+  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_cut, dim3(1), dim3(kSelThreads), kSelLds, st, d_M, n_out, top_n, cap,
+                                          d_hdr, d_idx, d_mout));
   GK_HIP(hipGetLastError());
   GK_HIP(hipMemcpyAsync(hdr_out, d_hdr, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   GK_HIP(hipStreamSynchronize(st));

@@ -40,6 +40,12 @@ _default_logs: dict[int, LogTable] = {}
 _default_logs_lock = threading.Lock()
 
 
+def nativeSearch() -> bool:
+    """The steps of a gene's search run inside the library (``gk_search_run``) unless GK_NATIVE_SEARCH=0."""
+    import os
+    return os.environ.get("GK_NATIVE_SEARCH", "1") != "0"
+
+
 def sharedLogTable(dev: Device) -> LogTable:
     """One log10 value table per GPU, shared by all its contexts (values recur across genes, samples
     and host threads, so every value is evaluated by numpy once per process)."""
@@ -441,17 +447,72 @@ class AlleleTyping:
             self.addCandidate()
             self.addHomoResultForCn(cn)
         else:
-            if cn >= 2 and 32 < self._model.n_allele <= self.top_n and self._model.n_rows and not self._model.boundOk:
+            if cn >= 2 and 32 < self._model.n_allele <= self.top_n and self._model.n_rows \
+                    and not self._model.boundOk and not nativeSearch():
                 # Every allele survives the first step, so the second step scores all allele pairs:
                 # the symmetric table is computed first -- its diagonal sum max(L_a, L_a) = sum L_a IS
                 # the first step's column sum (same terms, same summation tree), so no separate
                 # column-sum launch is needed and the second step reads its scores out of the table.
                 self._pair_table = self._model.pairTable()
                 self._colsum_all = np.ascontiguousarray(np.diagonal(self._pair_table))
-            for _ in range(cn):
-                self.addCandidate()
+            if nativeSearch() and self._model.n_rows:
+                self._searchNatively(cn)
+            else:
+                for _ in range(cn):
+                    self.addCandidate()
         self.result[-1].print()
         return self.result[-1]
+
+    def _searchNatively(self, cn: int) -> None:
+        """All ``cn`` steps of ``addCandidate()`` in one library call (``gk_search_run``): the same device
+        kernels, the host half of every step in C++ on this thread instead of numpy under the interpreter
+        lock; ``numpy.argsort`` is handed in as a callback wherever its tie order is part of the result."""
+        import ctypes as C
+        from . import _lib
+        from ._lib import check, lib
+        m = self._model
+        cols = np.arange(m.n_allele, dtype=np.int32)
+        bound = m.boundOk
+        colsum = None if self._colsum_all is None else np.ascontiguousarray(self._colsum_all, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib().gk_search_run(m.dev.ctx, m.L.ptr, m.n_rows, m.n_rows, m.n_allele,
+                                  m.miss8.ptr if bound else 0, m.ldm, m.msum.ptr if bound else 0,
+                                  cols.ctypes.data, len(cols), cn, self.top_n, _lib.NUMPY_ARGSORT,
+                                  None if colsum is None else colsum.ctypes.data, C.byref(h)))
+        try:
+            if self._colsum_all is None:
+                self._colsum_all = np.empty(m.n_allele, dtype=np.float64)
+                check(lib().gk_search_colsum(h, self._colsum_all.ctypes.data))
+            for step in range(cn):
+                n, rows, bounded = C.c_int32(), C.c_int64(), C.c_int32()
+                check(lib().gk_search_info(h, step, C.byref(n), C.byref(rows), C.byref(bounded)))
+                k, c = int(rows.value), int(n.value)
+                value = np.empty(k, dtype=np.float64)
+                sum_indv, frac = np.empty((k, c), dtype=np.float64), np.empty((k, c), dtype=np.float64)
+                ids32 = np.empty((k, c), dtype=np.int32)
+                check(lib().gk_search_copy(h, step, value.ctypes.data, sum_indv.ctypes.data, ids32.ctypes.data,
+                                           frac.ctypes.data))
+                ids = ids32.astype(np.int64)
+                if step:
+                    SEARCH_STATS["bounded" if bounded.value else "redone_exactly"] += 1
+                self.result.append(TypingResult(
+                    n=c, value=value, value_sum_indv=sum_indv, allele_id=ids,
+                    allele_name=LazyNames(ids, self.id_to_allele), allele_prob=LazyAlleleProb([(m, ids)]),
+                    fraction=frac if step else np.ones(ids.shape), fraction_uniq=np.ones(ids.shape)))
+            if m.dev.call_log is not None:
+                n_log = C.c_int64()
+                check(lib().gk_search_log(h, None, 0, C.byref(n_log)))
+                raw = np.empty(n_log.value, dtype=np.int64)
+                check(lib().gk_search_log(h, raw.ctypes.data, len(raw), C.byref(n_log)))
+                for kind, a, b, c_, d, e, f in raw.reshape(-1, 7).tolist():
+                    if kind == 0:
+                        m.dev.call_log.append(("maxsum_chunks", a, b, c_, d, e, bool(f)))
+                    elif kind == 1:
+                        m.dev.call_log.append(("minsum_sad", a, b, c_, d, False))
+                    else:
+                        m.dev.call_log.append(("fraction_chunks", a, b, c_, d))
+        finally:
+            lib().gk_search_destroy(h)
 
     def addHomoResultForCn(self, cn: int) -> None:
         if cn > 1:
@@ -767,6 +828,15 @@ class AlleleTyping:
             ent_code = np.concatenate([code[hp], code[hn]])
             ent_neg = np.concatenate([np.zeros(int(hp.sum()), bool), np.ones(int(hn.sum()), bool)])
             ent_cnt = np.concatenate([pos[hp], neg[hn]])
+            if nativeSearch():
+                import ctypes as C
+                from ._lib import check, lib
+                p_, c_ = np.ascontiguousarray(ent_pos, dtype=np.int64), np.ascontiguousarray(ent_code, dtype=np.int64)
+                n_, k_ = np.ascontiguousarray(ent_neg, dtype=np.uint8), np.ascontiguousarray(ent_cnt, dtype=np.int64)
+                verdict = C.c_int32()
+                check(lib().gk_site_verdict(p_.ctypes.data, c_.ctypes.data, n_.ctypes.data, k_.ctypes.data, len(p_), cn,
+                                            C.byref(verdict)))
+                return bool(verdict.value)
             return self._siteVerdict(ent_pos, ent_code, ent_neg, ent_cnt, cn)
         else:
             site = defaultdict(lambda: defaultdict(int))

@@ -129,15 +129,19 @@ def test_bounded_search_equals_exact_search(device, small_case, monkeypatch):
     data = extractVariant(pairLines(synth.toSamLines(sample)), gidx, dev=device)
     gene_cn = {g: (k % 4) + 1 for k, g in enumerate(sidx.genes)}
     results = {}
-    for mode in ("exact", "bound"):
-        monkeypatch.setenv("GK_SEARCH", mode)
+    # exact = float64 sums for every candidate, python host (the round-1 path); the others must give its bits:
+    # the integer bound, and the search loop run natively inside the library (gk_search_run), bounded or not
+    for mode, search, native in (("exact", "exact", "0"), ("bound", "bound", "0"), ("native", "bound", "1"),
+                                 ("native_exact", "exact", "1")):
+        monkeypatch.setenv("GK_SEARCH", search)
+        monkeypatch.setenv("GK_NATIVE_SEARCH", native)
         monkeypatch.setenv("GK_THREADS", "1")
         for method, top_n in (("full", 600), ("full", 7), ("exonfirst_1", 60)):
             typer = selectKirTypingModel(method, data, top_n=top_n, variant_correction=True)
             calls = typer.typing(gene_cn)
             results[(mode, method, top_n)] = (calls, typer._result)
     for (mode, method, top_n), (calls, res) in results.items():
-        if mode != "bound":
+        if mode == "exact":
             continue
         want_calls, want = results[("exact", method, top_n)]
         assert calls == want_calls

@@ -218,6 +218,15 @@ def test_site_verdict_equals_reference_loop():
         got = AlleleTyping._siteVerdict(pos, code, neg, cnt, cn)
         assert got == (hits == 0), trial
         verdicts.add(got)
+        # the native form (gk_site_verdict, host code of the library) gives the same verdict
+        import ctypes as C
+        from kir_graph_amd._lib import check, lib
+        p64, c64 = np.ascontiguousarray(pos, dtype=np.int64), np.ascontiguousarray(code, dtype=np.int64)
+        n8, k64 = np.ascontiguousarray(neg, dtype=np.uint8), np.ascontiguousarray(cnt, dtype=np.int64)
+        verdict = C.c_int32()
+        check(lib().gk_site_verdict(p64.ctypes.data, c64.ctypes.data, n8.ctypes.data, k64.ctypes.data, n, cn,
+                                    C.byref(verdict)))
+        assert bool(verdict.value) == got, trial
     assert verdicts == {True, False}
 
 
