@@ -282,7 +282,11 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None):
         run_steps(1, dev, dindex, gidx, inputs, args.method)
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
-    profiled(True)
+    # per-kernel events inside the timed region cost ~3 ms per step (a profiling signal per dispatch): only on request;
+    # the roofline comes from the serial pass after the region
+    in_region = bool(getattr(args, "verbose", False)) or os.environ.get("GK_BENCH_PROFILE") == "1"
+    if in_region:
+        profiled(True)
     dev.sync()
     gang_wait("ready")
     if comm is not None:
@@ -298,7 +302,7 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None):
     if comm is not None:
         comm.barrier()
     elapsed = time.perf_counter() - t0
-    prof, call_log = collect()
+    prof, call_log = collect() if in_region else ({}, [])
     profiled(False)
     if j:
         gang["results"].put({"prof": prof, "call_log": call_log})
@@ -485,7 +489,8 @@ def main():
         if traffic is not None:
             out["roofline"]["traffic"] = traffic[0]
             out["roofline"]["traffic_source"] = traffic[1]
-        out["kernel_ms_per_step"] = {k: v[1] / args.steps for k, v in prof.items()}
+        if prof:     # --verbose: launch times inside the timed region (kernels of all workers overlap there)
+            out["kernel_ms_per_step"] = {k: v[1] / args.steps for k, v in prof.items()}
         out["search_steps"] = res.get("search_steps")    # worker 0: steps bounded by integers / redone with f64 only
         if args.cpu_pairs and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.method, args.cpu_pairs)

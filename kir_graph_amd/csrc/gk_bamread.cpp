@@ -467,6 +467,14 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
     const uint32_t size = rd32(d.data() + o);
     o += 4;
     if (size < 32 || o + size > d.size()) return bad("alignment block");
+    {
+      // every walker below (text rendering, binary packing, pileup, name collation) trusts these fields: the
+      // variable-length parts must lie inside the block and the query name must end in NUL inside its field
+      const uint8_t* r = d.data() + o;
+      const uint64_t l_name = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
+      const uint64_t need = 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq;
+      if (l_name < 1 || need > size || r[32 + l_name - 1] != 0) return bad("alignment block");
+    }
     b->recs.push_back({(uint64_t)o, size});
     o += size;
   }
@@ -608,17 +616,18 @@ int gk_bam_pack(gk_bam* b, gk_packer* pk) {
       size_t used = 0;
       long ival = 0;
       bool is_int = true;
+      const size_t avail = (size_t)(end - v);   // a value is only read once it is known to lie inside the record
       switch (type) {
         case 'A': used = 1; is_int = false; break;
-        case 'c': used = 1; ival = (int8_t)v[0]; break;
-        case 'C': used = 1; ival = v[0]; break;
-        case 's': used = 2; ival = (int16_t)rd16(v); break;
-        case 'S': used = 2; ival = rd16(v); break;
-        case 'i': used = 4; ival = rds32(v); break;
-        case 'I': used = 4; ival = (long)rd32(v); break;
+        case 'c': if (avail < 1) return; used = 1; ival = (int8_t)v[0]; break;
+        case 'C': if (avail < 1) return; used = 1; ival = v[0]; break;
+        case 's': if (avail < 2) return; used = 2; ival = (int16_t)rd16(v); break;
+        case 'S': if (avail < 2) return; used = 2; ival = rd16(v); break;
+        case 'i': if (avail < 4) return; used = 4; ival = rds32(v); break;
+        case 'I': if (avail < 4) return; used = 4; ival = (long)rd32(v); break;
         case 'f': used = 4; is_int = false; break;
         case 'Z': case 'H': {
-          const void* z = memchr(v, 0, (size_t)(end - v));
+          const void* z = memchr(v, 0, avail);
           if (!z) return;
           const size_t n = (const uint8_t*)z - v;
           if (type == 'Z' && t0 == 'M' && t1 == 'D' && !r.has_md) { r.has_md = true; r.md = std::string_view((const char*)v, n); }
@@ -627,7 +636,7 @@ int gk_bam_pack(gk_bam* b, gk_packer* pk) {
           break;
         }
         case 'B': {
-          if (v + 5 > end) return;
+          if (avail < 5) return;
           const char sub = (char)v[0];
           const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
           used = 5 + (size_t)rd32(v + 1) * w; is_int = false;

@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Runs inside a process started with LD_PRELOAD=libasan: loads the sanitized host library and drives the
+BGZF / BAM / SAM parsers with valid inputs and with a loop of mutated ones (truncated streams, corrupted
+deflate blocks, random byte flips in the uncompressed records, hostile length fields).  Any out-of-bounds read,
+overflow or other undefined behaviour aborts the process; a clean run prints OK.
+
+    python tests/asan/driver.py <library> <n_mutants> <seed>
+"""
+import ctypes as C
+import os
+import random
+import struct
+import sys
+import tempfile
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from bamwriter import _bgzf_block, bamBytes  # noqa: E402
+
+lib = C.CDLL(sys.argv[1])
+n_mutants, seed = int(sys.argv[2]), int(sys.argv[3])
+lib.gk_last_error.restype = C.c_char_p
+lib.gk_packer_string.restype = C.c_char_p
+
+GENES = ["KIR2DL1*BACKBONE", "KIR3DL3*BACKBONE"]
+
+
+def sam_lines(rng, n_pairs=120):
+    """Name-collated SAM lines with the tags the decoder reads (hand-rolled: numpy is kept out of the
+    sanitized process)."""
+    lines = ["@HD\tVN:1.0\tSO:queryname"] + [f"@SQ\tSN:{g}\tLN:9000" for g in GENES]
+    for q in range(n_pairs):
+        g = rng.choice(GENES)
+        a = rng.randrange(1, 8000)
+        b = a + rng.randrange(100, 400)
+        for flag, pos, mpos in ((99, a, b), (147, b, a)):
+            kind = rng.randrange(6)
+            seq = "".join(rng.choice("ACGT") for _ in range(150))
+            if kind == 0:
+                cigar, md, extra = "150M", "150", ""
+            elif kind == 1:
+                k = rng.randrange(1, 148)
+                cigar, md, extra = "150M", f"{k}A{149 - k}", f"\tZs:Z:{k}|S|hv{rng.randrange(99)}"
+            elif kind == 2:
+                cigar, md, extra = "50M2D100M", "50^CA100", "\tZs:Z:50|D|hv7"
+            elif kind == 3:
+                cigar, md, extra = "10M2I138M", "148", ""
+            elif kind == 4:
+                cigar, md, extra = "5S145M", "145", ""
+            else:
+                cigar, md, extra = "70M80S", "70", ""
+            nm = rng.choice(["NM:i:0", "NM:i:1", "NM:i:5", ""])
+            tags = "\t".join(t for t in (nm, f"MD:Z:{md}", "NH:i:%d" % rng.choice([1, 1, 2]), "XS:A:+", "ZB:B:c,1,2,3") if t)
+            lines.append(f"r{q}\t{flag}\t{g}\t{pos}\t60\t{cigar}\t=\t{mpos}\t{b - a}\t{seq}\t{'I' * 150}\t{tags}{extra}")
+    return lines
+
+
+def write_bgzf(raw: bytes, path: str, block=5000):
+    with open(path, "wb") as f:
+        for i in range(0, len(raw), block):
+            f.write(_bgzf_block(raw[i:i + block]))
+        f.write(_bgzf_block(b""))
+
+
+def exercise(path: str) -> int:
+    """Open + every walker of the reader on one file; returns the open() code."""
+    names = (C.c_char_p * len(GENES))(*[g.encode() for g in GENES])
+    for name_sorted in (1, 0):
+        h = C.c_void_p()
+        rc = lib.gk_bam_open(path.encode(), name_sorted, C.byref(h))
+        if rc:
+            return rc
+        n_rec, n_hdr, n_ref = C.c_int64(), C.c_int64(), C.c_int32()
+        lib.gk_bam_info(h, C.byref(n_rec), C.byref(n_hdr), C.byref(n_ref))
+        hdr = C.create_string_buffer(max(n_hdr.value, 1))
+        lib.gk_bam_header(h, hdr, n_hdr.value)
+        buf = C.create_string_buffer(1 << 16)
+        wrote = C.c_int64(1)
+        text = []
+        while wrote.value:
+            if lib.gk_bam_next(h, buf, len(buf), C.byref(wrote)):
+                break
+            text.append(buf.raw[:wrote.value])
+        lib.gk_bam_close(h)
+        # binary packing of the same records
+        h = C.c_void_p()
+        if lib.gk_bam_open(path.encode(), name_sorted, C.byref(h)) == 0:
+            pk = C.c_void_p()
+            if lib.gk_packer_create(names, len(GENES), None, 0, C.byref(pk)) == 0:
+                lib.gk_bam_pack(h, pk)
+                lib.gk_packer_destroy(pk)
+            off = (C.c_int64 * (n_ref.value + 1))(*[9000 * i for i in range(n_ref.value + 1)])
+            counts = (C.c_uint32 * (9000 * max(n_ref.value, 1) * 6))()
+            if 0 < n_ref.value <= 4:
+                lib.gk_bam_pileup(h, off, n_ref.value, counts)
+            lib.gk_bam_close(h)
+        # the rendered text through the SAM packer and the BAM writer
+        blob = b"".join(text)
+        pk = C.c_void_p()
+        if blob and lib.gk_packer_create(names, len(GENES), None, 0, C.byref(pk)) == 0:
+            lib.gk_packer_feed(pk, blob, len(blob), 1)
+            lib.gk_packer_destroy(pk)
+        if blob:
+            out = path + ".rewrite.bam"
+            sam = hdr.raw[:n_hdr.value] + blob
+            lib.gk_bam_write(out.encode(), sam, len(sam), 1)
+    return 0
+
+
+def main():
+    rng = random.Random(seed)
+    tmp = tempfile.mkdtemp(prefix="gk_asan_")
+    raw = bamBytes(sam_lines(rng))
+    good = os.path.join(tmp, "good.bam")
+    write_bgzf(raw, good)
+    assert exercise(good) == 0, lib.gk_last_error()
+    opened = refused = 0
+    first_rec = raw.index(b"r0\0") - 36 if b"r0\0" in raw else 64
+    for k in range(n_mutants):
+        kind = rng.randrange(7)
+        path = os.path.join(tmp, f"m{k % 8}.bam")
+        if kind == 0:      # truncated uncompressed stream
+            write_bgzf(raw[:rng.randrange(0, len(raw))], path)
+        elif kind == 1:    # random byte flips in the records
+            b = bytearray(raw)
+            for _ in range(rng.randrange(1, 12)):
+                b[rng.randrange(first_rec, len(b))] = rng.randrange(256)
+            write_bgzf(bytes(b), path)
+        elif kind == 2:    # hostile length fields (block_size, l_read_name, n_cigar_op, l_seq, B-array counts)
+            b = bytearray(raw)
+            at = rng.randrange(first_rec, len(b) - 4)
+            b[at:at + 4] = struct.pack("<I", rng.choice([0, 1, 31, 32, 0x7FFFFFFF, 0xFFFFFFFF, rng.randrange(1 << 20)]))
+            write_bgzf(bytes(b), path)
+        elif kind == 3:    # corrupted compressed file
+            with open(good, "rb") as f:
+                z = bytearray(f.read())
+            for _ in range(rng.randrange(1, 6)):
+                z[rng.randrange(len(z))] = rng.randrange(256)
+            with open(path, "wb") as f:
+                f.write(z)
+        elif kind == 4:    # truncated compressed file
+            with open(good, "rb") as f:
+                z = f.read()
+            with open(path, "wb") as f:
+                f.write(z[:rng.randrange(len(z))])
+        elif kind == 5:    # header damage: magic, l_text, n_ref, reference names
+            b = bytearray(raw)
+            at = rng.randrange(0, first_rec)
+            b[at] = rng.randrange(256)
+            write_bgzf(bytes(b), path)
+        else:              # a plain gzip member instead of BGZF, or garbage
+            with open(path, "wb") as f:
+                f.write(zlib.compress(raw[:rng.randrange(len(raw))]) if rng.random() < 0.5 else os.urandom(rng.randrange(4000)))
+        if exercise(path) == 0:
+            opened += 1
+        else:
+            refused += 1
+    # SAM text straight into the packer: damaged lines must end in an error code, never in a bad read
+    names = (C.c_char_p * len(GENES))(*[g.encode() for g in GENES])
+    lines = sam_lines(rng, 60)[3:]
+    for k in range(n_mutants):
+        bad = list(lines)
+        for _ in range(rng.randrange(1, 5)):
+            i = rng.randrange(len(bad))
+            s = bytearray(bad[i].encode())
+            if s:
+                how = rng.randrange(3)
+                if how == 0:
+                    s[rng.randrange(len(s))] = rng.choice(b"\t:0A^|,*\x00\xff")
+                elif how == 1:
+                    del s[rng.randrange(len(s)):]
+                else:
+                    s += b"\t" + rng.choice([b"Zs:Z:", b"Zs:Z:9|S", b"MD:Z:", b"NM:i:", b"NH:i:99999999999", b"Zs:Z:|||"])
+            bad[i] = s.decode("latin1")
+        blob = ("\n".join(bad) + ("\n" if rng.random() < 0.8 else "")).encode("latin1")
+        pk = C.c_void_p()
+        assert lib.gk_packer_create(names, len(GENES), None, 0, C.byref(pk)) == 0
+        cut = rng.randrange(len(blob) + 1)
+        lib.gk_packer_feed(pk, blob[:cut], cut, 0)
+        lib.gk_packer_feed(pk, blob[cut:], len(blob) - cut, 1)
+        lib.gk_packer_destroy(pk)
+    print(f"OK mutants {n_mutants}: {opened} opened and walked, {refused} refused")
+
+
+if __name__ == "__main__":
+    main()
