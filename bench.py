@@ -114,6 +114,8 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
     from kir_graph_amd.engine import Tabulation
     from kir_graph_amd.hisat2 import SampleData
     from kir_graph_amd.kir_typing import hostThreads, selectKirTypingModel
+    if method == "exonfirst":      # the command line types `--allele-strategy exonfirst` as exonfirst_1 (main.py:186-187)
+        method = "exonfirst_1"
     depth = int(os.environ.get("GK_PREFETCH", "1")) if depth is None else depth
     lanes = int(os.environ.get("GK_SAMPLE_LANES", "1"))   # 2: two samples typed at a time (gain varies from box to box)
     ingest = dev.worker(lanes * hostThreads())   # a context of its own: the typing lanes use workers 0..lanes*n-1
@@ -220,7 +222,7 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None):
     sidx, gidx, by_gene = build_index()
     t_in = time.time()
     inputs, samples = [], []
-    for i in range(max(1, min(N_DISTINCT, args.steps + args.warmup))):
+    for i in range(max(1, min(args.distinct, args.steps + args.warmup))):
         sample, rec, table = build_sample(sidx, gidx, by_gene, 1031 + 7 * rank + i, args.pairs)
         inputs.append((PinnedRecords(rec), table, sample.gene_cn))
         samples.append(sample)
@@ -367,6 +369,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per sample (config 2: 1e6)")
     ap.add_argument("--method", default="pv")
+    ap.add_argument("--distinct", type=int, default=N_DISTINCT, help="distinct samples a rank rotates through")
     ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs for the CPU baseline sample (0 = skip)")
     ap.add_argument("--serial-steps", type=int, default=2,
                     help="steps of the one-process serial pass after the timed region (roofline basis; 0 = skip)")
@@ -462,7 +465,8 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: 1 synthetic sample per step and GPU ({N_DISTINCT} distinct samples in "
+            "config": {"workload": f"{'configs[1]' if args.pairs == 1_000_000 else 'configs[2]' if args.pairs == 10_000_000 else 'custom'}: "
+                                   f"1 synthetic sample per step and GPU ({args.distinct} distinct samples in "
                                    f"rotation), {2 * args.pairs} 150 bp PE reads, synthetic example_index-shaped index "
                                    f"({sum(len(t.alleles) for t in gidx.tables)} alleles, 15 genes), "
                                    f"--allele-strategy {args.method}, top_n 600; records start in pinned host memory "

@@ -229,6 +229,7 @@ class TypingWithReport(_GenesInParallel):
     def __init__(self, filename_variant_json, device: Device | None = None):
         super().__init__()
         self._data = _sample(filename_variant_json, device)
+        self.em_info: dict[str, dict] = {}      # per gene: iterations used, distinct candidate sets
 
     def typingPerGene(self, gene: str, cn: int) -> tuple[list[str], int]:
         tab, _ = self._context()
@@ -237,8 +238,10 @@ class TypingWithReport(_GenesInParallel):
         report: list[Hisat2AlleleResult] = []
         if view.g is not None and view.alleles and view.n_rows:
             t = self._data.index.tables[view.g]
+            info: dict = {}
             report = hisat2TypingPerGene(tab, view.rows, view.n_rows, view.vbeg, view.vbeg + view.n_span,
-                                         view.mask, t.words, view.alleles)
+                                         view.mask, t.words, view.alleles, info=info)
+            self.em_info[gene] = info
         # descending abundance; ties by allele name (the reference leaves them to set order)
         report.sort(key=lambda r: (-r.prob, r.allele))
         if not report:
