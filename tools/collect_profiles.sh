@@ -1,26 +1,37 @@
+#!/bin/bash
+# Regenerates the round's evidence under gpurun_out/rNN (run on the GPU box through gpurun); the summaries that are
+# judged are then copied into profiles/ by hand (tools/collect_profiles.sh prints the copy commands at the end).
+#   bash tools/collect_profiles.sh [round tag, default r02]
 set -e
 R=$GRAFT_REPO_ROOT
-# the calibration tool is built on first use
-[ -x $R/tools/fetch_calib.bin ] || hipcc --offload-arch=gfx950 -O3 $R/tools/fetch_calib.hip -o $R/tools/fetch_calib.bin
-O=$R/gpurun_out/r01
+TAG=${1:-r02}
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
+# 1. the driver's own command: throughput line with roofline (serial pass) and CPU baseline
 python bench.py --verbose > $O/bench.json 2> $O/bench.err
+echo "[collect] bench done"
+# 2. the roofline basis under rocprofv3: ONE process, ONE gene thread, no prefetch -- kernels back to back, the
+#    same mode as the bench's own serial pass (children are not allowed under the profiler on this pool)
 cd /tmp && export TMPDIR=/tmp
-# the profiled runs are one process per GPU (GK_PROCS_PER_GPU=1): child processes under the profiler are not
-# allowed on this pool, and the per-kernel durations are then not stretched by the other workers' kernels
-export GK_PROCS_PER_GPU=1
-rocprofv3 --kernel-trace --stats -d $O/stats -o b --output-format csv -- python3 $R/bench.py --cpu-pairs 0 > $O/bench_under_rocprof.json 2> $O/stats.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace -d $O/pmc_sq1 -o p --output-format csv -- python3 $R/tools/bench_maxsum.py 67000 220 600 2 3 > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_SMEM --kernel-trace -d $O/pmc_sq2 -o p --output-format csv -- python3 $R/tools/bench_maxsum.py 67000 220 600 2 3 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o p --output-format csv -- python3 $R/tools/bench_maxsum.py 67000 220 600 2 3 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o p --output-format csv -- python3 $R/tools/bench_maxsum.py 67000 220 600 2 3 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/cal_fetch -o p --output-format csv -- $R/tools/fetch_calib.bin > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/cal_write -o p --output-format csv -- $R/tools/fetch_calib.bin > /dev/null 2>&1
+export GK_PROCS_PER_GPU=1 GK_THREADS=1 GK_PREFETCH=0
+SERIAL="python3 $R/bench.py --cpu-pairs 0 --steps 6 --warmup 2 --serial-steps 2"
+rocprofv3 --kernel-trace --stats -d $O/stats -o b --output-format csv -- $SERIAL > $O/bench_under_rocprof.json 2> $O/stats.err
+echo "[collect] kernel stats done"
+# 3. HBM traffic of every kernel over the same command: FETCH_SIZE and WRITE_SIZE in separate passes (the guide's
+#    recipe; FETCH_SIZE counts half of coalesced reads on gfx950, corrected in tools/pmc_traffic.py)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/bench_fetch -o p --output-format csv -- $SERIAL > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/bench_write -o p --output-format csv -- $SERIAL > /dev/null 2>&1
+echo "[collect] traffic passes done"
+# 4. issue / stall / LDS counters of the same command, two passes (counter groups that fit together)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace -d $O/pmc_sq1 -o p --output-format csv -- $SERIAL > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_SMEM --kernel-trace -d $O/pmc_sq2 -o p --output-format csv -- $SERIAL > /dev/null 2>&1
+echo "[collect] SQ passes done"
+for k in compat_kernel tab_count minsum_sad fraction_chunks maxsum_chunks select_cut count_ids; do
+  python3 $R/tools/pmc_traffic.py $O/bench_fetch/p_counter_collection.csv $O/bench_write/p_counter_collection.csv $k > $O/traffic_$k.json
+  python3 $R/tools/pmc_summary.py $O $k > $O/pmc_$k.txt
+done
 ls $O $O/stats
 cat $O/bench.json
-# HBM traffic of the dominant kernel over the bench's own launch mix (two more passes, as the guide prescribes)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/bench_fetch -o p --output-format csv -- python3 $R/bench.py --cpu-pairs 0 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/bench_write -o p --output-format csv -- python3 $R/bench.py --cpu-pairs 0 > /dev/null 2>&1
-python3 $R/tools/pmc_traffic.py $O/bench_fetch/p_counter_collection.csv $O/bench_write/p_counter_collection.csv maxsum_chunks > $O/bench_traffic.json
-cat $O/bench_traffic.json
+echo "copy: $O/bench.json -> profiles/${TAG}_bench.json; $O/stats/b_kernel_stats.csv -> profiles/${TAG}_bench_serial_kernel_stats.csv;"
+echo "      $O/bench_under_rocprof.json; $O/traffic_<dominant>.json -> profiles/${TAG}_bench_traffic.json; $O/pmc_*.txt"

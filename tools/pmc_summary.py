@@ -10,11 +10,11 @@ import os
 import sys
 
 root, kernel = sys.argv[1], sys.argv[2]
-for d in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write", "cal_fetch", "cal_write"):
+for d in ("pmc_sq1", "pmc_sq2", "bench_fetch", "bench_write", "pmc_fetch", "pmc_write", "cal_fetch", "cal_write"):
     path = os.path.join(root, d, "p_counter_collection.csv")
     if not os.path.exists(path):
         continue
-    want = kernel if d.startswith("pmc") else ""
+    want = "" if d.startswith("cal") else kernel
     acc, n, dur = collections.defaultdict(float), collections.Counter(), collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
