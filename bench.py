@@ -194,7 +194,7 @@ def cpu_baseline(method, n_pairs):
 
 
 # ------------------------------------------------------------------------------------------ one worker process
-def worker(j, procs, opts, rank, local_rank, gang, timing=None):
+def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=None):
     """Worker j of `procs` on this rank's GPU: builds the inputs, warms up, then types its share of the
     rank's `steps` samples between the common start and end.
 
@@ -309,9 +309,13 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None):
     if j:
         gang["results"].put({"prof": prof, "call_log": call_log})
         return None
+    if comm is not None:
+        elapsed = comm.maxF64(elapsed)
+    timing["elapsed"] = elapsed
+    others = helpers_done() if helpers_done is not None else []      # the other workers have left the GPU
     # ---- the roofline basis: the same step in ONE process, ONE gene thread, no prefetch (kernels back to back)
     serial = None
-    if args.serial_steps > 0:
+    if args.serial_steps > 0 and rank == 0:
         keep = os.environ.get("GK_THREADS")
         os.environ["GK_THREADS"] = "1"
         try:
@@ -331,12 +335,9 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None):
                 del os.environ["GK_THREADS"]
             else:
                 os.environ["GK_THREADS"] = keep
-    if comm is not None:
-        elapsed = comm.maxF64(elapsed)
-    timing["elapsed"] = elapsed
     from kir_graph_amd.typing_mulit_allele import SEARCH_STATS
     return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm,
-            "search_steps": dict(SEARCH_STATS)}
+            "search_steps": dict(SEARCH_STATS), "others": others}
 
 
 # ------------------------------------------------------------------------------------------ launcher
@@ -422,9 +423,17 @@ def main():
                     return
         threading.Thread(target=watch, daemon=True).start()
 
+    def helpers_done():
+        """Results of the other workers, collected as soon as the timed region is over; the workers have exited
+        (and released the GPU) when this returns."""
+        got = [gang["results"].get(timeout=600) for _ in range(len(helpers))] if gang is not None else []
+        for h in helpers:
+            h.join(timeout=60)
+        return got
+
     timing = {}
     try:
-        res = worker(0, procs, vars(args), rank, local_rank, gang, timing=timing)
+        res = worker(0, procs, vars(args), rank, local_rank, gang, timing=timing, helpers_done=helpers_done)
     except threading.BrokenBarrierError:
         # a worker process died or never came up; a single-GPU run starts over in one process, a multi-rank
         # run cannot (the other ranks are past their barriers)
@@ -440,8 +449,7 @@ def main():
         res = worker(0, 1, vars(args), rank, local_rank, None, timing=timing)
     elapsed = timing["elapsed"]
     prof, call_log, n_valid, gidx = res["prof"], res["call_log"], res["n_valid"], res["gidx"]
-    for _ in range(procs - 1):
-        other = gang["results"].get(timeout=600)
+    for other in res.get("others", []):
         for k, (n, ms) in other["prof"].items():
             n0, ms0 = prof.get(k, (0, 0.0))
             prof[k] = (n0 + n, ms0 + ms)

@@ -20,8 +20,8 @@
 // the reads; operands are staged through LDS as 16-byte words ([column][8 words + 1 pad]: the b128 reads of
 // 8 consecutive columns fall on disjoint banks), a lane owns a strided 4 x 4 block of outputs and reads
 // 8 words per 64 SADs.  Integer sums are associative, so the reads are cut into as many slices as fill the
-// GPU; a second small kernel adds the slices, and a single-workgroup radix select finds M_T and compacts
-// the selection.
+// GPU; a second small kernel adds the slices, and a two-level radix select over three more one-element-per-
+// thread kernels finds M_T and compacts the selection.
 #include <algorithm>
 
 #include "gk_common.h"
@@ -34,7 +34,6 @@ constexpr int kW = 8;               // staged 16-byte words (of 16 reads) per co
 constexpr int kLd = kW + 1;         // padded words per staged column
 constexpr int kStage = (kBT + kBA) * kW / kThreads;   // words fetched per thread and block (4)
 constexpr uint32_t kNotFirst = 0xFFFFFFFFu;
-constexpr int kSelThreads = 1024;
 constexpr int kBins = 2048;
 
 __device__ inline uint32_t sad4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
@@ -178,115 +177,147 @@ __global__ __launch_bounds__(kThreads, 2) void minsum_sad(const uint8_t* __restr
   }
 }
 
-// M[t][a] = (psum[t] + msum[col a] - sum of the slices) / 2 for first occurrences, kNotFirst otherwise
+// Selection state of one step in HBM (zeroed before the kernels run): the candidates' count and range, the two
+// histogram levels of the radix select, the number of sets selected.
+struct SelState {
+  uint32_t count, inv_min, max, selected;   // inv_min = ~min, so that zero is the identity of atomicMax
+  uint32_t cut, pad[3];
+  uint32_t hist1[kBins], hist2[kBins];
+};
+
+// M[t][a] = (psum[t] + msum[col a] - sum of the slices) / 2 for first occurrences, kNotFirst otherwise;
+// count / min / max of the candidates through one atomic per wave
 __global__ __launch_bounds__(kThreads) void minsum_finish(const uint32_t* __restrict__ partial, int n_slices,
                                                           int64_t n_out, int n_cols, const uint32_t* __restrict__ psum,
                                                           const int32_t* __restrict__ pcol,
                                                           const uint32_t* __restrict__ msum,
                                                           const int32_t* __restrict__ cols,
-                                                          const uint8_t* __restrict__ first, uint32_t* __restrict__ M) {
+                                                          const uint8_t* __restrict__ first, uint32_t* __restrict__ M,
+                                                          SelState* __restrict__ state) {
   const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (o >= n_out) return;
-  if (!first[o]) { M[o] = kNotFirst; return; }
-  uint32_t sad = 0;
-  for (int s = 0; s < n_slices; ++s) sad += partial[(int64_t)s * n_out + o];
-  const int t = (int)(o / n_cols), a = (int)(o % n_cols);
-  const uint32_t sp = pcol ? msum[pcol[t]] : psum[t];
-  M[o] = (sp + msum[cols[a]] - sad) >> 1;
-}
-
-// The T-th smallest M among the candidates (T = top_n) and the candidates at or below it.
-// One workgroup of 16 waves.  The totals of a step lie in a narrow band (they share most reads), so the
-// values are first reduced to (M - min) and the select runs over the bits that band needs: one or two
-// histogram rounds of 11 bits instead of three over 32.  Every wave counts into its OWN histogram (16 x 2048
-// counters = 128 KB of the CU's 160 KB LDS): lanes of one wave hitting a popular bin serialise among
-// themselves only.  A last pass appends the selection (flat index, M) in no particular order.
-// hdr = {candidates, M_T, selected, 0}.
-constexpr int kSelWaves = kSelThreads / 64;
-
-__global__ __launch_bounds__(kSelThreads) void select_cut(const uint32_t* __restrict__ M, int64_t n, int top_n, int cap,
-                                                          uint32_t* __restrict__ hdr, int32_t* __restrict__ idx_out,
-                                                          uint32_t* __restrict__ m_out) {
-  extern __shared__ uint32_t hist[];   // [kSelWaves][kBins]
-  __shared__ uint32_t s_prefix, s_rank, s_count, s_sel, s_min, s_max;
-  const int tid = threadIdx.x, wid = tid >> 6;
-  if (tid == 0) { s_count = 0; s_sel = 0; s_min = kNotFirst; s_max = 0; }
-  __syncthreads();
-  uint32_t mine = 0, lo = kNotFirst, hi = 0;
-  for (int64_t i = tid; i < n; i += kSelThreads) {
-    const uint32_t v = M[i];
-    if (v != kNotFirst) { ++mine; lo = min(lo, v); hi = max(hi, v); }
+  uint32_t v = kNotFirst;
+  if (o < n_out && first[o]) {
+    uint32_t sad = 0;
+    for (int s = 0; s < n_slices; ++s) sad += partial[(int64_t)s * n_out + o];
+    const int t = (int)(o / n_cols), a = (int)(o % n_cols);
+    const uint32_t sp = pcol ? msum[pcol[t]] : psum[t];
+    v = (sp + msum[cols[a]] - sad) >> 1;
   }
+  if (o < n_out) M[o] = v;
+  uint32_t cnt = v != kNotFirst, inv_lo = v != kNotFirst ? ~v : 0u, hi = v != kNotFirst ? v : 0u;
   for (int off = 32; off > 0; off >>= 1) {
-    mine += __shfl_xor(mine, off, 64);
-    lo = min(lo, (uint32_t)__shfl_xor(lo, off, 64));
+    cnt += __shfl_xor(cnt, off, 64);
+    inv_lo = max(inv_lo, (uint32_t)__shfl_xor(inv_lo, off, 64));
     hi = max(hi, (uint32_t)__shfl_xor(hi, off, 64));
   }
-  if ((tid & 63) == 0) { atomicAdd(&s_count, mine); atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
-  __syncthreads();
-  const uint32_t n_cand = s_count;
-  if (n_cand == 0) {
-    if (tid == 0) { hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; }
-    return;
+  if ((threadIdx.x & 63) == 0 && cnt) {
+    atomicAdd(&state->count, cnt);
+    atomicMax(&state->inv_min, inv_lo);
+    atomicMax(&state->max, hi);
   }
-  const uint32_t base = s_min, span = s_max - s_min;
+}
+
+// The candidates at or below the T-th smallest M (T = top_n), by a two-level radix select that every
+// workgroup can finish on its own: the totals of a step lie in a narrow band, so values are reduced to
+// d = (M - min) >> sh0 with sh0 chosen so that d has at most 22 bits (sh0 = 0 unless the band is wider than
+// 4 M: then the cut is rounded UP to a multiple of 2^sh0 -- a superset, which the caller accepts);
+// level 1 counts d >> 11, level 2 counts d & 2047 inside the level-1 bin that holds rank T.  The kernels are
+// tiny (one element per thread); each reads the finished histogram of the level above and locates the cut bin
+// itself with a block scan, so no single-workgroup pass over the candidates is needed.
+struct SelGeom { uint32_t base, sh0; };
+
+__device__ inline SelGeom sel_geom(const SelState* st) {
+  const uint32_t base = ~st->inv_min, span = st->max - base;
   const int n_bits = span ? 32 - __builtin_clz(span) : 1;
-  const int rounds = (n_bits + 10) / 11;
-  uint32_t rank = (uint32_t)min<int64_t>(top_n, n_cand) - 1;   // 0-based rank of the cut value
-  uint32_t prefix = 0;                                         // bits of (M_T - base) fixed so far
-  uint32_t* my_hist = hist + wid * kBins;
-  for (int round = rounds - 1; round >= 0; --round) {
-    for (int b = tid; b < kSelWaves * kBins; b += kSelThreads) hist[b] = 0;
+  return SelGeom{base, (uint32_t)(n_bits > 22 ? n_bits - 22 : 0)};
+}
+
+// bin of `hist` (kBins counters) that holds 0-based rank `rank`, and the rank inside that bin; all threads of the
+// workgroup (kThreads) call it and get the same answer
+__device__ inline void find_bin(const uint32_t* __restrict__ hist, uint32_t rank, uint32_t* bin, uint32_t* rank_in) {
+  __shared__ uint32_t run[kThreads];
+  __shared__ uint32_t s_bin, s_rank;
+  constexpr int kPer = kBins / kThreads;
+  uint32_t local[kPer], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) { local[k] = hist[threadIdx.x * kPer + k]; sum += local[k]; }
+  run[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < kThreads; off <<= 1) {   // inclusive scan
+    const uint32_t add = threadIdx.x >= (unsigned)off ? run[threadIdx.x - off] : 0u;
     __syncthreads();
-    const int sh = 11 * round;
-    const uint32_t hi_mask = round == rounds - 1 ? 0u : ~((1u << (sh + 11)) - 1u);
-    for (int64_t i = tid; i < n; i += kSelThreads) {
-      const uint32_t v = M[i];
-      if (v == kNotFirst) continue;
-      const uint32_t d = v - base;
-      if ((d & hi_mask) == prefix) atomicAdd(&my_hist[(d >> sh) & (kBins - 1)], 1u);
-    }
-    __syncthreads();
-    for (int b = tid; b < kBins; b += kSelThreads) {   // fold the waves' histograms into the first one
-      uint32_t c = 0;
-      for (int w = 0; w < kSelWaves; ++w) c += hist[w * kBins + b];
-      hist[b] = c;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t run = 0;
-      int b = 0;
-      for (; b < kBins - 1; ++b) {
-        if (run + hist[b] > rank) break;
-        run += hist[b];
-      }
-      s_prefix = prefix | ((uint32_t)b << sh);
-      s_rank = rank - run;
-    }
-    __syncthreads();
-    prefix = s_prefix;
-    rank = s_rank;
+    run[threadIdx.x] += add;
     __syncthreads();
   }
-  const uint32_t cut = base + prefix;
-  for (int64_t i = tid; i < n; i += kSelThreads) {
-    const uint32_t v = M[i];
-    const bool take = v != kNotFirst && v <= cut;
-    // one atomic per wave: the lanes that take an element get consecutive slots
-    const uint64_t takers = __ballot(take);
-    uint32_t first_slot = 0;
-    if (takers) {
-      const int leader = __ffsll((unsigned long long)takers) - 1;
-      if ((tid & 63) == leader) first_slot = atomicAdd(&s_sel, (uint32_t)__popcll(takers));
-      first_slot = __shfl(first_slot, leader, 64);
-    }
-    if (take) {
-      const uint32_t k = first_slot + (uint32_t)__popcll(takers & ((1ull << (tid & 63)) - 1ull));
-      if (k < (uint32_t)cap) { idx_out[k] = (int32_t)i; m_out[k] = v; }
+  const uint32_t before = run[threadIdx.x] - sum;
+  if (threadIdx.x == 0) { s_bin = kBins - 1; s_rank = 0; }
+  __syncthreads();
+  if (rank >= before && rank < before + sum) {   // exactly one thread
+    uint32_t acc = before;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      if (rank < acc + local[k]) { s_bin = threadIdx.x * kPer + k; s_rank = rank - acc; break; }
+      acc += local[k];
     }
   }
   __syncthreads();
-  if (tid == 0) { hdr[0] = n_cand; hdr[1] = cut; hdr[2] = s_sel; hdr[3] = 0; }
+  *bin = s_bin;
+  *rank_in = s_rank;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void select_hist1(const uint32_t* __restrict__ M, int64_t n, SelState* __restrict__ st) {
+  if (st->count == 0) return;
+  const SelGeom g = sel_geom(st);
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) {
+    const uint32_t v = M[i];
+    if (v != kNotFirst) atomicAdd(&st->hist1[((v - g.base) >> g.sh0) >> 11], 1u);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void select_hist2(const uint32_t* __restrict__ M, int64_t n, int top_n,
+                                                         SelState* __restrict__ st) {
+  if (st->count == 0) return;
+  const SelGeom g = sel_geom(st);
+  uint32_t bin1, rank1;
+  find_bin(st->hist1, (uint32_t)min<int64_t>(top_n, st->count) - 1, &bin1, &rank1);
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) {
+    const uint32_t v = M[i];
+    if (v != kNotFirst) {
+      const uint32_t d = (v - g.base) >> g.sh0;
+      if ((d >> 11) == bin1) atomicAdd(&st->hist2[d & (kBins - 1)], 1u);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void select_append(const uint32_t* __restrict__ M, int64_t n, int top_n, int cap,
+                                                          SelState* __restrict__ st, int32_t* __restrict__ idx_out,
+                                                          uint32_t* __restrict__ m_out) {
+  if (st->count == 0) return;
+  const SelGeom g = sel_geom(st);
+  uint32_t bin1, rank1, bin2, rank2;
+  find_bin(st->hist1, (uint32_t)min<int64_t>(top_n, st->count) - 1, &bin1, &rank1);
+  find_bin(st->hist2, rank1, &bin2, &rank2);
+  // the largest M whose reduced value is (bin1, bin2): the T-th smallest itself when sh0 == 0
+  const uint64_t cut64 = (uint64_t)g.base + ((((uint64_t)bin1 << 11 | bin2) + 1) << g.sh0) - 1;
+  const uint32_t cut = cut64 > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)cut64;
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->cut = cut;
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const uint32_t v = i < n ? M[i] : kNotFirst;
+  const bool take = v != kNotFirst && v <= cut;
+  const uint64_t takers = __ballot(take);   // one atomic per wave: its takers get consecutive slots
+  if (!takers) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((unsigned long long)takers) - 1;
+  uint32_t first_slot = 0;
+  if (lane == leader) first_slot = atomicAdd(&st->selected, (uint32_t)__popcll(takers));
+  first_slot = __shfl(first_slot, leader, 64);
+  if (take) {
+    const uint32_t k = first_slot + (uint32_t)__popcll(takers & ((1ull << lane) - 1ull));
+    if (k < (uint32_t)cap) { idx_out[k] = (int32_t)i; m_out[k] = v; }
+  }
 }
 
 }  // namespace
@@ -349,32 +380,36 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
   want = std::max<int64_t>(1, std::min<int64_t>(want, std::max<int64_t>(1, n_blk / 16)));
   const int blocks_per_slice = (int)((n_blk + want - 1) / want);
   const int n_slices = (int)((n_blk + blocks_per_slice - 1) / blocks_per_slice);
-  uint32_t *d_partial = nullptr, *d_M = nullptr, *d_hdr = nullptr, *d_mout = nullptr;
+  uint32_t *d_partial = nullptr, *d_M = nullptr, *d_mout = nullptr;
+  SelState* d_state = nullptr;
   int32_t* d_idx = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * n_slices * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_M, (size_t)n_out * sizeof(uint32_t)));
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d_hdr, 4 * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_state, sizeof(SelState)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_idx, (size_t)cap * sizeof(int32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_mout, (size_t)cap * sizeof(uint32_t)));
   GK_PROF_EXACT(ctx, GK_K_MINSUM,
                 GK_KERNEL(minsum_sad, dim3((unsigned)(tiles_t * tiles_a), (unsigned)n_slices), dim3(kThreads), 0, st,
                           c_prev >= 2 ? d_P : miss, ldm, c_prev >= 2 ? (const int32_t*)nullptr : d_ids, n_sets, miss,
                           ldm, d_cols, n_cols, n16, blocks_per_slice, tiles_a, d_partial));
+  GK_HIP(hipMemsetAsync(d_state, 0, sizeof(SelState), st));
+  const dim3 per_elem((unsigned)((n_out + kThreads - 1) / kThreads));
   GK_PROF(ctx, GK_K_SELECT_CUT,
-          GK_KERNEL(minsum_finish, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, d_partial,
-                    n_slices, n_out, n_cols, d_psum, c_prev >= 2 ? (const int32_t*)nullptr : d_ids,
-                    gk_ptr<uint32_t>(d_msum), d_cols, d_first, d_M));
-  constexpr size_t kSelLds = (size_t)kSelWaves * kBins * sizeof(uint32_t);   // 128 KB of per-wave histograms
-  static bool lds_opt_in = false;
-  if (!lds_opt_in) {
-    GK_HIP(hipFuncSetAttribute((const void*)select_cut, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSelLds));
-    lds_opt_in = true;
-  }
-  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_cut, dim3(1), dim3(kSelThreads), kSelLds, st, d_M, n_out, top_n, cap,
-                                          d_hdr, d_idx, d_mout));
+          GK_KERNEL(minsum_finish, per_elem, dim3(kThreads), 0, st, d_partial, n_slices, n_out, n_cols, d_psum,
+                    c_prev >= 2 ? (const int32_t*)nullptr : d_ids, gk_ptr<uint32_t>(d_msum), d_cols, d_first, d_M,
+                    d_state));
+  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_hist1, per_elem, dim3(kThreads), 0, st, d_M, n_out, d_state));
+  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_hist2, per_elem, dim3(kThreads), 0, st, d_M, n_out, top_n, d_state));
+  GK_PROF(ctx, GK_K_SELECT_CUT,
+          GK_KERNEL(select_append, per_elem, dim3(kThreads), 0, st, d_M, n_out, top_n, cap, d_state, d_idx, d_mout));
   GK_HIP(hipGetLastError());
-  GK_HIP(hipMemcpyAsync(hdr_out, d_hdr, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  uint32_t head[8];
+  GK_HIP(hipMemcpyAsync(head, d_state, sizeof(head), hipMemcpyDeviceToHost, st));
   GK_HIP(hipStreamSynchronize(st));
+  hdr_out[0] = head[0];   // candidates
+  hdr_out[1] = head[4];   // the cut: the top_n-th smallest M (rounded up to 2^sh0 - 1 when the band is wider than 2^22)
+  hdr_out[2] = head[3];   // selected
+  hdr_out[3] = 0;
   const uint32_t n_sel = std::min<uint32_t>(hdr_out[2], (uint32_t)cap);
   if (n_sel) {
     GK_HIP(hipMemcpyAsync(idx_out, d_idx, (size_t)n_sel * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -383,7 +418,7 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
   }
   gk_pool_free(ctx, d_partial);
   gk_pool_free(ctx, d_M);
-  gk_pool_free(ctx, d_hdr);
+  gk_pool_free(ctx, d_state);
   gk_pool_free(ctx, d_idx);
   gk_pool_free(ctx, d_mout);
   gk_pool_free(ctx, d_par);
