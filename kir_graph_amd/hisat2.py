@@ -257,21 +257,29 @@ def indexFingerprint(index: GkIndex) -> np.ndarray:
                     dtype=np.uint64)
 
 
-def writeCompact(data: SampleData, filename: str, index_ref: str = "") -> None:
+def writeCompact(data: SampleData, filename: str, index_ref: str = "", background=None):
     """Binary side-format of the ``.variant.json`` hand-off (hisat2.py:847-866): the tabulation's CSR
     (offsets + variant ordinals in list order lpv, rpv, lnv, rnv), backbone and NH per pair, the keys
     of the novel variants and the inserted-string table -- ~4 bytes per variant hit instead of JSON
     with embedded SAM text.  Index variants are not stored: ``index_ref`` names the index files and
-    a fingerprint of the packed keys is checked on load."""
+    a fingerprint of the packed keys is checked on load.
+
+    ``background``: an executor; the arrays are fetched from the device now, the file (a few hundred MB for
+    a deep sample, most of the time is the archive's CRC) is written there and the future is returned."""
     tab = data.tab
     if getattr(tab, "_variant_src", None) is not None:
         raise ValueError("compact files are written from tabulations made against an index")
-    np.savez(filename if filename.endswith(".npz") else filename + ".npz",
-             format=np.array(COMPACT_FORMAT), index_ref=np.array(index_ref), fingerprint=indexFingerprint(data.index),
-             genes=np.array(data.index.genes), off=tab.offsets(), ids=tab.ids(), pair_gene=tab.pairGene(),
-             pair_nh=tab.pairNH(), novel_key=tab.novelKeys(), novel_base=np.array(tab.novel_base),
-             ins_strings=np.array(data.ins_strings if data.ins_strings else [""]),
-             n_ins=np.array(len(data.ins_strings or [])))
+    path = filename if filename.endswith(".npz") else filename + ".npz"
+    fields = dict(
+        format=np.array(COMPACT_FORMAT), index_ref=np.array(index_ref), fingerprint=indexFingerprint(data.index),
+        genes=np.array(data.index.genes), off=tab.offsets(), ids=tab.ids(), pair_gene=tab.pairGene(),
+        pair_nh=tab.pairNH(), novel_key=tab.novelKeys(), novel_base=np.array(tab.novel_base),
+        ins_strings=np.array(data.ins_strings if data.ins_strings else [""]),
+        n_ins=np.array(len(data.ins_strings or [])))
+    if background is None:
+        np.savez(path, **fields)
+        return None
+    return background.submit(np.savez, path, **fields)
 
 
 _index_cache: dict[str, GkIndex] = {}

@@ -94,6 +94,19 @@ def mapSamples(names, reads, index, index_ref, exon_region_only=False, alignment
     # the next sample is mapped / packed on a helper thread while this one is tabulated and written out
     # (three samples ahead on three threads: the serial stretches of one ingest leave cores to the others)
     ahead = max(1, int(os.environ.get("GK_INGEST_AHEAD", "3")))
+    from concurrent.futures import ThreadPoolExecutor
+    writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gk-write")   # compact hand-off files, off this thread
+    writes = []
+    try:
+        yield from _mapLoop(names, prepare, ahead, gk, gene_len, dev, dindex, index_ref, exon_region_only, write_json,
+                            writer, writes)
+    finally:
+        for w in writes:
+            w.result()          # every hand-off file is complete (and any write error surfaces) before we return
+        writer.shutdown()
+
+
+def _mapLoop(names, prepare, ahead, gk, gene_len, dev, dindex, index_ref, exon_region_only, write_json, writer, writes):
     for name, source, pack in cohort.prefetched(range(len(names)), prepare, depth=ahead, workers=ahead):
         name += ".variant"
         logger.info(f"[Graph] Filter mapping ({name})")
@@ -108,7 +121,7 @@ def mapSamples(names, reads, index, index_ref, exon_region_only=False, alignment
             saveReadsToBam(data, name, source)
             saveReadsToBam(data, name + ".no_multi", source, filter_multi_mapped=True)
         else:   # compact hand-off instead: CSR + string table, no SAM text (hisat2.writeCompact)
-            writeCompact(data, name + ".npz", index_ref=index_ref)
+            writes.append(writeCompact(data, name + ".npz", index_ref=index_ref, background=writer))
         depth_name = name + ".no_multi"
         logger.info(f"[Graph] Calculate read depth to {depth_name}.depth.tsv")
         depthOfSample(data, gene_len, depth_name + ".depth.tsv")

@@ -39,7 +39,15 @@ for b in bams:
 argv += ["--cn-provided"] + cns
 args = cli.createParser().parse_args(argv + extra)
 t = time.time()
-cli.main(args)
+if os.environ.get("GK_CLI_PROFILE") == "1":     # where does the main thread spend its time?
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    cli.main(args)
+    pr.disable()
+    pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(35)
+else:
+    cli.main(args)
 dt = time.time() - t
 if rank == 0:
   print(f"command line: {dt:.2f}s for {n_samples} samples = {dt / n_samples:.2f}s per sample of {2 * n_pairs} reads "
