@@ -95,7 +95,7 @@ def mapSamples(names, reads, index, index_ref, exon_region_only=False, alignment
     # (three samples ahead on three threads: the serial stretches of one ingest leave cores to the others)
     ahead = max(1, int(os.environ.get("GK_INGEST_AHEAD", "3")))
     from concurrent.futures import ThreadPoolExecutor
-    writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gk-write")   # compact hand-off files, off this thread
+    writer = ThreadPoolExecutor(max_workers=2, thread_name_prefix="gk-write")   # compact hand-off files, off this thread
     writes = []
     try:
         yield from _mapLoop(names, prepare, ahead, gk, gene_len, dev, dindex, index_ref, exon_region_only, write_json,

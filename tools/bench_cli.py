@@ -8,6 +8,7 @@ from kir_graph_amd import main as cli, packed, synth
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 n_samples = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 extra = sys.argv[3:]
+n_made = min(n_samples, int(os.environ.get("GK_CLI_DISTINCT", "3")))   # distinct samples synthesised; the rest are copies
 # under torchrun every rank runs this script: rank 0 writes the inputs, the others wait for them
 rank = int(os.environ.get("RANK", "0"))
 tmp = os.path.join(tempfile.gettempdir(), f"gk_cli_{n_pairs}_{n_samples}_{os.environ.get('MASTER_PORT', os.getppid())}")
@@ -21,7 +22,12 @@ if rank == 0:
     sidx.write(prefix)
     header = ["@HD\tVN:1.0\tSO:coordinate"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
     t = time.time()
+    import shutil
     for k in range(n_samples):
+        if k >= n_made:       # a copy of an earlier sample under its own name (same work for the pipeline)
+            shutil.copy(bams[k % n_made], bams[k])
+            shutil.copy(cns[k % n_made], cns[k])
+            continue
         s = synth.makeSample(sidx, seed=100 + k, n_pairs=n_pairs)
         lines = synth.toSamLines(s)
         packed.writeBam(bams[k], "\n".join(header + lines) + "\n")
