@@ -380,14 +380,16 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
   want = std::max<int64_t>(1, std::min<int64_t>(want, std::max<int64_t>(1, n_blk / 16)));
   const int blocks_per_slice = (int)((n_blk + want - 1) / want);
   const int n_slices = (int)((n_blk + blocks_per_slice - 1) / blocks_per_slice);
-  uint32_t *d_partial = nullptr, *d_M = nullptr, *d_mout = nullptr;
-  SelState* d_state = nullptr;
-  int32_t* d_idx = nullptr;
+  uint32_t *d_partial = nullptr, *d_M = nullptr;
+  // selection state, indices and totals in ONE block, so that one copy brings the result back
+  char* d_sel = nullptr;
+  const size_t sel_bytes = sizeof(SelState) + (size_t)cap * (sizeof(int32_t) + sizeof(uint32_t));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * n_slices * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_M, (size_t)n_out * sizeof(uint32_t)));
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d_state, sizeof(SelState)));
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d_idx, (size_t)cap * sizeof(int32_t)));
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d_mout, (size_t)cap * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_sel, sel_bytes));
+  SelState* d_state = (SelState*)d_sel;
+  int32_t* d_idx = (int32_t*)(d_sel + sizeof(SelState));
+  uint32_t* d_mout = (uint32_t*)(d_idx + cap);
   GK_PROF_EXACT(ctx, GK_K_MINSUM,
                 GK_KERNEL(minsum_sad, dim3((unsigned)(tiles_t * tiles_a), (unsigned)n_slices), dim3(kThreads), 0, st,
                           c_prev >= 2 ? d_P : miss, ldm, c_prev >= 2 ? (const int32_t*)nullptr : d_ids, n_sets, miss,
@@ -403,24 +405,23 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
   GK_PROF(ctx, GK_K_SELECT_CUT,
           GK_KERNEL(select_append, per_elem, dim3(kThreads), 0, st, d_M, n_out, top_n, cap, d_state, d_idx, d_mout));
   GK_HIP(hipGetLastError());
-  uint32_t head[8];
-  GK_HIP(hipMemcpyAsync(head, d_state, sizeof(head), hipMemcpyDeviceToHost, st));
+  // one copy, one wait: the header first, then as many entries as were selected (the three parts are adjacent)
+  std::vector<char> back(sel_bytes);
+  GK_HIP(hipMemcpyAsync(back.data(), d_sel, sel_bytes, hipMemcpyDeviceToHost, st));
   GK_HIP(hipStreamSynchronize(st));
+  const uint32_t* head = (const uint32_t*)back.data();
   hdr_out[0] = head[0];   // candidates
   hdr_out[1] = head[4];   // the cut: the top_n-th smallest M (rounded up to 2^sh0 - 1 when the band is wider than 2^22)
   hdr_out[2] = head[3];   // selected
   hdr_out[3] = 0;
   const uint32_t n_sel = std::min<uint32_t>(hdr_out[2], (uint32_t)cap);
   if (n_sel) {
-    GK_HIP(hipMemcpyAsync(idx_out, d_idx, (size_t)n_sel * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    GK_HIP(hipMemcpyAsync(m_out, d_mout, (size_t)n_sel * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    GK_HIP(hipStreamSynchronize(st));
+    memcpy(idx_out, back.data() + sizeof(SelState), (size_t)n_sel * sizeof(int32_t));
+    memcpy(m_out, back.data() + sizeof(SelState) + (size_t)cap * sizeof(int32_t), (size_t)n_sel * sizeof(uint32_t));
   }
   gk_pool_free(ctx, d_partial);
   gk_pool_free(ctx, d_M);
-  gk_pool_free(ctx, d_state);
-  gk_pool_free(ctx, d_idx);
-  gk_pool_free(ctx, d_mout);
+  gk_pool_free(ctx, d_sel);
   gk_pool_free(ctx, d_par);
   gk_pool_free(ctx, d_P);
   gk_pool_free(ctx, d_psum);
