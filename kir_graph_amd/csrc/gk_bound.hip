@@ -185,15 +185,13 @@ struct SelState {
   uint32_t hist1[kBins], hist2[kBins];
 };
 
-// M[t][a] = (psum[t] + msum[col a] - sum of the slices) / 2 for first occurrences, kNotFirst otherwise;
-// count / min / max of the candidates through one atomic per wave
+// M[t][a] = (psum[t] + msum[col a] - sum of the slices) / 2 for first occurrences, kNotFirst otherwise
 __global__ __launch_bounds__(kThreads) void minsum_finish(const uint32_t* __restrict__ partial, int n_slices,
                                                           int64_t n_out, int n_cols, const uint32_t* __restrict__ psum,
                                                           const int32_t* __restrict__ pcol,
                                                           const uint32_t* __restrict__ msum,
                                                           const int32_t* __restrict__ cols,
-                                                          const uint8_t* __restrict__ first, uint32_t* __restrict__ M,
-                                                          SelState* __restrict__ state) {
+                                                          const uint8_t* __restrict__ first, uint32_t* __restrict__ M) {
   const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   uint32_t v = kNotFirst;
   if (o < n_out && first[o]) {
@@ -204,16 +202,32 @@ __global__ __launch_bounds__(kThreads) void minsum_finish(const uint32_t* __rest
     v = (sp + msum[cols[a]] - sad) >> 1;
   }
   if (o < n_out) M[o] = v;
-  uint32_t cnt = v != kNotFirst, inv_lo = v != kNotFirst ? ~v : 0u, hi = v != kNotFirst ? v : 0u;
+}
+
+// count / min / max of the candidates: a few workgroups stride over M, one atomic triple each
+constexpr int kSelBlocks = 64;   // workgroups of the strided select passes
+
+__global__ __launch_bounds__(kThreads) void select_stats(const uint32_t* __restrict__ M, int64_t n, SelState* __restrict__ st) {
+  uint32_t cnt = 0, inv_lo = 0, hi = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+    const uint32_t v = M[i];
+    if (v != kNotFirst) { ++cnt; inv_lo = max(inv_lo, ~v); hi = max(hi, v); }
+  }
   for (int off = 32; off > 0; off >>= 1) {
     cnt += __shfl_xor(cnt, off, 64);
     inv_lo = max(inv_lo, (uint32_t)__shfl_xor(inv_lo, off, 64));
     hi = max(hi, (uint32_t)__shfl_xor(hi, off, 64));
   }
-  if ((threadIdx.x & 63) == 0 && cnt) {
-    atomicAdd(&state->count, cnt);
-    atomicMax(&state->inv_min, inv_lo);
-    atomicMax(&state->max, hi);
+  __shared__ uint32_t part[3][kThreads / 64];
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = cnt; part[1][threadIdx.x >> 6] = inv_lo; part[2][threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kThreads / 64; ++w) { cnt += part[0][w]; inv_lo = max(inv_lo, part[1][w]); hi = max(hi, part[2][w]); }
+    if (cnt) {
+      atomicAdd(&st->count, cnt);
+      atomicMax(&st->inv_min, inv_lo);
+      atomicMax(&st->max, hi);
+    }
   }
 }
 
@@ -266,30 +280,41 @@ __device__ inline void find_bin(const uint32_t* __restrict__ hist, uint32_t rank
   __syncthreads();
 }
 
+// histogram passes: a few workgroups stride over M, each counts into its own LDS histogram (the totals crowd into
+// few bins: global atomics on them would serialise) and adds its non-empty bins to the global one
 __global__ __launch_bounds__(kThreads) void select_hist1(const uint32_t* __restrict__ M, int64_t n, SelState* __restrict__ st) {
   if (st->count == 0) return;
+  __shared__ uint32_t local[kBins];
+  for (int b = threadIdx.x; b < kBins; b += kThreads) local[b] = 0;
+  __syncthreads();
   const SelGeom g = sel_geom(st);
-  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i < n) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
     const uint32_t v = M[i];
-    if (v != kNotFirst) atomicAdd(&st->hist1[((v - g.base) >> g.sh0) >> 11], 1u);
+    if (v != kNotFirst) atomicAdd(&local[((v - g.base) >> g.sh0) >> 11], 1u);
   }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kBins; b += kThreads)
+    if (local[b]) atomicAdd(&st->hist1[b], local[b]);
 }
 
 __global__ __launch_bounds__(kThreads) void select_hist2(const uint32_t* __restrict__ M, int64_t n, int top_n,
                                                          SelState* __restrict__ st) {
   if (st->count == 0) return;
+  __shared__ uint32_t local[kBins];
+  for (int b = threadIdx.x; b < kBins; b += kThreads) local[b] = 0;
   const SelGeom g = sel_geom(st);
   uint32_t bin1, rank1;
-  find_bin(st->hist1, (uint32_t)min<int64_t>(top_n, st->count) - 1, &bin1, &rank1);
-  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i < n) {
+  find_bin(st->hist1, (uint32_t)min<int64_t>(top_n, st->count) - 1, &bin1, &rank1);   // ends with a barrier
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
     const uint32_t v = M[i];
     if (v != kNotFirst) {
       const uint32_t d = (v - g.base) >> g.sh0;
-      if ((d >> 11) == bin1) atomicAdd(&st->hist2[d & (kBins - 1)], 1u);
+      if ((d >> 11) == bin1) atomicAdd(&local[d & (kBins - 1)], 1u);
     }
   }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kBins; b += kThreads)
+    if (local[b]) atomicAdd(&st->hist2[b], local[b]);
 }
 
 __global__ __launch_bounds__(kThreads) void select_append(const uint32_t* __restrict__ M, int64_t n, int top_n, int cap,
@@ -398,10 +423,11 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
   const dim3 per_elem((unsigned)((n_out + kThreads - 1) / kThreads));
   GK_PROF(ctx, GK_K_SELECT_CUT,
           GK_KERNEL(minsum_finish, per_elem, dim3(kThreads), 0, st, d_partial, n_slices, n_out, n_cols, d_psum,
-                    c_prev >= 2 ? (const int32_t*)nullptr : d_ids, gk_ptr<uint32_t>(d_msum), d_cols, d_first, d_M,
-                    d_state));
-  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_hist1, per_elem, dim3(kThreads), 0, st, d_M, n_out, d_state));
-  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_hist2, per_elem, dim3(kThreads), 0, st, d_M, n_out, top_n, d_state));
+                    c_prev >= 2 ? (const int32_t*)nullptr : d_ids, gk_ptr<uint32_t>(d_msum), d_cols, d_first, d_M));
+  const dim3 strided((unsigned)std::min<int64_t>(kSelBlocks, (n_out + kThreads - 1) / kThreads));
+  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_stats, strided, dim3(kThreads), 0, st, d_M, n_out, d_state));
+  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_hist1, strided, dim3(kThreads), 0, st, d_M, n_out, d_state));
+  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_hist2, strided, dim3(kThreads), 0, st, d_M, n_out, top_n, d_state));
   GK_PROF(ctx, GK_K_SELECT_CUT,
           GK_KERNEL(select_append, per_elem, dim3(kThreads), 0, st, d_M, n_out, top_n, cap, d_state, d_idx, d_mout));
   GK_HIP(hipGetLastError());

@@ -18,7 +18,8 @@ diagonal only (gk_search.hip), so ``outputs computed`` counts the 32 x 32 tiles 
 It is a (max,+) contraction: f64 VALU bound, the HBM figure is reported next to it.
 
 ``minsum_sad`` (integer bound of the same step): u8 mismatch counts, 4 reads per v_sad_u8.
-``compat_kernel`` / ``tab_count``: byte streams, HBM bound.
+``compat_kernel``: 4 VALU lane-operations per (id, allele) -- VALU bound (65 % VALU-busy measured), HBM beside it.
+``tab_count``: a byte stream, HBM bound by construction (divergent walk: far below the roof).
 """
 from __future__ import annotations
 
@@ -54,9 +55,10 @@ def minsumLaunch(n_rows: int, n_sets: int, n_cols: int, n_prev_cols: int, symmet
 
 
 def compatLaunch(n_rows: int, n_allele: int, n_ids: float, out_bytes: int = 8) -> tuple[float, float]:
-    """reads the rows' id lists (4 B per id, 16 B of offsets per row), writes the f64 (and u8) table; one
-    select + one multiply per id and allele."""
-    return 4.0 * n_ids + 16.0 * n_rows + float(out_bytes) * n_rows * n_allele, 2.0 * n_ids * n_allele
+    """reads the rows' id lists (4 B per id, 16 B of offsets per row), writes the f64 (and u8) table; per id and
+    allele the floor of the per-lane formulation is 4 VALU lane-operations (bit -> mask, two half-word selects of
+    0.999 / 0.001, one f64 multiply: the ordered product cannot be reassociated)."""
+    return 4.0 * n_ids + 16.0 * n_rows + float(out_bytes) * n_rows * n_allele, 4.0 * n_ids * n_allele
 
 
 def tabLaunch(n_pairs: int, n_valid: int, n_ids: int) -> tuple[float, float]:
@@ -82,6 +84,7 @@ def _priced(kernel: str, calls: list[tuple]) -> tuple[float, float, str, float]:
             bound, peak = "valu", VALU_LANE_OPS
         elif kernel == "compat_kernel":
             b, o = compatLaunch(*c[1:5])
+            bound, peak = "valu", VALU_LANE_OPS
         elif kernel == "tab_count":
             b, o = tabLaunch(*c[1:4])
         elif kernel in ("fraction_chunks", "setsum_chunks"):
@@ -112,11 +115,13 @@ def summarise(call_log: list[tuple], kernel: str, total_ms: float, launches: int
     out["algorithmic_bytes_per_launch"] = by / max(launches, 1)
     if bound == "valu":
         tops = ops / sec / 1e12
-        unit = "Tops/s f64 (max+add)" if kernel == "maxsum_chunks" else "T lane-ops/s (v_sad_u8, 4 reads each)"
+        unit = {"maxsum_chunks": "Tops/s f64 (max+add)", "minsum_sad": "T lane-ops/s (v_sad_u8, 4 reads each)",
+                "compat_kernel": "T lane-ops/s (4 VALU per id and allele)"}.get(kernel, "T lane-ops/s")
         out.update({"bound": "valu", "achieved": tops, "peak": peak / 1e12, "unit": unit, "frac": ops / sec / peak,
                     "algorithmic_ops_per_launch": ops / max(launches, 1), "hbm": hbm,
-                    "note": "a (max,+) / (min,+) contraction: VALU-issue bound, the HBM roof is shown beside it; "
-                            "symmetric launches are credited with the triangle of tiles they compute"})
+                    "note": "VALU-issue bound (ordered f64 products / a (max,+) or (min,+) contraction): priced against "
+                            "the vector issue rate, the HBM roof is shown beside it; symmetric launches are credited "
+                            "with the triangle of tiles they compute"})
     else:
         out.update(hbm)
         out["bound"] = "hbm"
