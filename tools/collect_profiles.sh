@@ -9,7 +9,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 # 1. the driver's own command: throughput line with roofline (serial pass) and CPU baseline
-python bench.py --verbose > $O/bench.json 2> $O/bench.err
+python bench.py > $O/bench.json 2> $O/bench.err
 echo "[collect] bench done"
 # 2. the roofline basis under rocprofv3: ONE process, ONE gene thread, no prefetch -- kernels back to back, the
 #    same mode as the bench's own serial pass (children are not allowed under the profiler on this pool)
