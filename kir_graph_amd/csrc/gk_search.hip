@@ -386,10 +386,6 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
   int loc[kC];
 #pragma unroll
   for (int q = 0; q < kC; ++q) loc[q] = live ? local_idx[k * kC + q] * kFracLd : 0;
-  double inv[kC + 1];
-#pragma unroll
-  for (int q = 1; q <= kC; ++q) inv[q] = 1.0 / (double)q;   // exact IEEE quotients, as numpy's bool / int
-  inv[0] = 0.0;
   constexpr int kO = kC + (kValue ? 1 : 0);   // accumulators per set: the shares, then the value
   double st[kO], hold[kO];
 #pragma unroll
@@ -407,9 +403,9 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
     int cnt = 0;
 #pragma unroll
     for (int q = 0; q < kC; ++q) cnt += v[q] == best ? 1 : 0;
-    double share = inv[1];
+    double share = 1.0;   // 1 / (number of alleles sharing the maximum): exact IEEE quotients, as numpy's bool / int
 #pragma unroll
-    for (int q = 2; q <= kC; ++q) share = cnt == q ? inv[q] : share;
+    for (int q = 2; q <= kC; ++q) share = cnt == q ? (1.0 / (double)q) : share;
 #pragma unroll
     for (int q = 0; q < kC; ++q) acc[q] += v[q] == best ? share : 0.0;   // 0.0 + x == x: first term exact
     if (kValue) acc[kC] += best;
@@ -478,6 +474,53 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
 #pragma unroll
     for (int q = 0; q < kO; ++q) partial[((int64_t)blockIdx.y * n_sets + ko) * kO + q] = st[q];
   }
+}
+
+// Column sums log_probs[:, cols].sum(axis=0) (typing_mulit_allele.py:514) with numpy's tree.  An 8-lane group
+// owns one column over one span (lane j = numpy's strided accumulator j, stack slot j), so a workgroup of 256 threads
+// sums 32 columns.  No LDS staging: every element is read exactly once, straight from HBM -- the 8 lanes of a group
+// read 64 contiguous bytes per row-step and all row-steps of a leaf are in flight together.  (gk_maxsum used to run this
+// case through the (max,+) kernel with one live set per 32 x 32 tile at two workgroups per CU.)
+constexpr int kColsPerGroup = kThreads / 8;
+
+__global__ __launch_bounds__(kThreads) void colsum_chunks(const double* __restrict__ L, int64_t ld,
+                                                          const int32_t* __restrict__ cols, int n_cols,
+                                                          const Span* __restrict__ spans,
+                                                          const Leaf* __restrict__ leaves, double* __restrict__ partial) {
+  const int tid = threadIdx.x, j = tid & 7;
+  const int c = blockIdx.x * kColsPerGroup + (tid >> 3);
+  const bool live = c < n_cols;
+  const Span span = spans[blockIdx.y];
+  const double* col = L + (int64_t)cols[live ? c : 0] * ld + span.row0;
+  double st = 0.0, hold = 0.0;
+  for (int li = span.leaf_begin; li < span.leaf_end; ++li) {
+    const Leaf cur = leaves[li];
+    const double* a = col + cur.start;
+    const int len = cur.len;
+    const int n8 = len < 8 ? 0 : len - (len & 7);
+    double acc = 0.0;
+    if (n8) {
+      double v[kBlockRows / 8];
+#pragma unroll
+      for (int q = 0; q < kBlockRows / 8; ++q) v[q] = 8 * q < n8 ? a[8 * q + j] : 0.0;   // all loads of the leaf in flight
+      acc = v[0];
+#pragma unroll
+      for (int q = 1; q < kBlockRows / 8; ++q)
+        if (8 * q < n8) acc += v[q];                     // r[j] += a[i + j], in row order
+      acc = group_sum8(acc);                             // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+    }
+    for (int r = n8; r < len; ++r) acc += a[r];           // sequential tail (the whole leaf when shorter than 8)
+    st = (j == cur.slot) ? acc : st;
+    const int n_fold = cur.n_add & 0xFF;
+    for (int f = 0; f < n_fold; ++f) {
+      const int s = cur.slot - f;
+      const double other = dpp_f64<kDppShl1>(st);
+      st = (j == s - 1) ? st + other : st;
+    }
+    if (cur.n_add & kLeafHold) hold = st;
+    if (cur.n_add & kLeafAddHold) st = hold + st;
+  }
+  if (j == 0 && live) partial[(int64_t)blockIdx.y * n_cols + c] = st;
 }
 
 __global__ __launch_bounds__(kThreads) void setmax_kernel(const double* __restrict__ L, int64_t n_rows, int64_t ld,
@@ -701,6 +744,10 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
             GK_KERNEL(maxsum_chunks<true>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
                                c_prev >= 2 ? d_P : gk_ptr<double>(d_L), ld, dp.ids, n_sets, dp.cols, n_cols, dp.spans,
                                dp.leaves, tiles_t * tiles_a, symmetric ? 1 : 0, d_partial));
+  } else if (n_sets == 1) {
+    GK_PROF_EXACT(ctx, GK_K_MAXSUM,
+            GK_KERNEL(colsum_chunks, dim3((unsigned)((n_cols + kColsPerGroup - 1) / kColsPerGroup), (unsigned)dp.n_spans),
+                      dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld, dp.cols, n_cols, dp.spans, dp.leaves, d_partial));
   } else {
     GK_PROF_EXACT(ctx, GK_K_MAXSUM,
             GK_KERNEL(maxsum_chunks<false>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
