@@ -369,21 +369,18 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
   GK_REQUIRE(n_rows < (int64_t)16000000, "too many reads for 32-bit mismatch totals");
   hipStream_t st = ctx->stream;
   const int64_t n_out = (int64_t)n_sets * n_cols;
-  // parameters through the context's pinned staging: [ids | cols | first mask]
+  // parameters through the context's pinned ring: [ids | cols | first mask]
   const size_t n_ids = (size_t)n_sets * c_prev;
   const size_t par_bytes = (n_ids + (size_t)n_cols) * sizeof(int32_t) + (size_t)n_out;
-  if (ctx->pinned_bytes < par_bytes) {
-    if (ctx->pinned) GK_HIP(hipHostFree(ctx->pinned));
-    ctx->pinned_bytes = std::max<size_t>(par_bytes * 2, 1 << 16);
-    GK_HIP(hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
-  }
-  char* stage = (char*)ctx->pinned;
-  memcpy(stage, ids, n_ids * sizeof(int32_t));
-  memcpy(stage + n_ids * sizeof(int32_t), cols, (size_t)n_cols * sizeof(int32_t));
-  memcpy(stage + (n_ids + n_cols) * sizeof(int32_t), first, (size_t)n_out);
   char* d_par = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_par, par_bytes));
-  GK_HIP(hipMemcpyAsync(d_par, stage, par_bytes, hipMemcpyHostToDevice, st));
+  {
+    std::vector<char> packed(par_bytes);   // one copy instead of three (every runtime call is contended by the gene threads)
+    memcpy(packed.data(), ids, n_ids * sizeof(int32_t));
+    memcpy(packed.data() + n_ids * sizeof(int32_t), cols, (size_t)n_cols * sizeof(int32_t));
+    memcpy(packed.data() + (n_ids + n_cols) * sizeof(int32_t), first, (size_t)n_out);
+    GK_HIP(gk_send(ctx, d_par, packed.data(), par_bytes));
+  }
   const int32_t* d_ids = (const int32_t*)d_par;
   const int32_t* d_cols = d_ids + n_ids;
   const uint8_t* d_first = (const uint8_t*)(d_cols + n_cols);
@@ -433,8 +430,7 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
   GK_HIP(hipGetLastError());
   // one copy, one wait: the header first, then as many entries as were selected (the three parts are adjacent)
   std::vector<char> back(sel_bytes);
-  GK_HIP(hipMemcpyAsync(back.data(), d_sel, sel_bytes, hipMemcpyDeviceToHost, st));
-  GK_HIP(hipStreamSynchronize(st));
+  GK_HIP(gk_fetch(ctx, back.data(), d_sel, sel_bytes));
   const uint32_t* head = (const uint32_t*)back.data();
   hdr_out[0] = head[0];   // candidates
   hdr_out[1] = head[4];   // the cut: the top_n-th smallest M (rounded up to 2^sh0 - 1 when the band is wider than 2^22)

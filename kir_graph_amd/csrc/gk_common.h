@@ -40,9 +40,15 @@ struct gk_ctx {
   // small reusable device scratch (scan partials, counters)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
-  // pinned host staging for small parameter arrays
+  // pinned host staging: a ring for host -> device parameters (gk_send) and a bounce area for device -> host
+  // results (gk_fetch_*).  Copies to / from pageable memory go through a staging path inside the runtime that the
+  // host threads of a process share; with a dozen gene threads that path was the throughput limit of one process.
   void* pinned = nullptr;
-  size_t pinned_bytes = 0;
+  size_t pinned_bytes = 0, pinned_head = 0;
+  void* bounce = nullptr;
+  size_t bounce_bytes = 0, bounce_head = 0;
+  struct Pending { void* dst; size_t off, bytes; };
+  std::vector<Pending> fetches;
   // reduction-tree programs of gk_search.hip, one device block per row count (they depend on nothing else)
   std::map<int64_t, void*> tree_programs;
   struct TreeHead { size_t o_leaf, o_span, o_cs, o_co, o_top; int n_spans, n_chunks; };
@@ -90,6 +96,17 @@ hipEvent_t gk_prof_stop_event();
   hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, gk_prof_start_event(), gk_prof_stop_event(), 0, __VA_ARGS__)
 
 int gk_ctx_scratch(gk_ctx* ctx, size_t bytes, void** out);
+
+// host -> device through the context's pinned ring: queued on the stream, `src` may be reused at once
+hipError_t gk_send(gk_ctx* ctx, void* dst_dev, const void* src, size_t bytes);
+// device -> host through the pinned bounce area: queue any number of copies, then wait once (stream synchronise)
+// and have them delivered to their destinations; gk_fetch = queue + wait
+hipError_t gk_fetch_queue(gk_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
+hipError_t gk_fetch_wait(gk_ctx* ctx);
+static inline hipError_t gk_fetch(gk_ctx* ctx, void* dst, const void* src_dev, size_t bytes) {
+  hipError_t e = gk_fetch_queue(ctx, dst, src_dev, bytes);
+  return e != hipSuccess ? e : gk_fetch_wait(ctx);
+}
 
 // Make the context's GPU the current HIP device of the calling host thread.  Every entry point of
 // the C ABI starts with it: contexts are driven from pool threads (gene workers, sample prefetch)

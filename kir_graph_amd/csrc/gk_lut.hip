@@ -136,13 +136,11 @@ int gk_lut_pending(gk_lut* l, int32_t* n_total, int32_t* n_known) {
   gk_bind(l ? l->ctx : nullptr);
   GK_REQUIRE(l && n_total && n_known, "null pointer");
   uint32_t c = 0;
-  GK_HIP(hipMemcpyAsync(&c, l->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, l->ctx->stream));
-  GK_HIP(hipStreamSynchronize(l->ctx->stream));
+  GK_HIP(gk_fetch(l->ctx, &c, l->d_count, sizeof(uint32_t)));
   if ((int64_t)c > (int64_t)l->n_known) {
     // new values: let every stream of the device finish, so that all claimed entries are written
     GK_HIP(hipDeviceSynchronize());
-    GK_HIP(hipMemcpyAsync(&c, l->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, l->ctx->stream));
-    GK_HIP(hipStreamSynchronize(l->ctx->stream));
+    GK_HIP(gk_fetch(l->ctx, &c, l->d_count, sizeof(uint32_t)));
   }
   if ((uint64_t)c * 2 > (1ull << l->log2cap)) {
     gk_set_error("probability value table overflow (%u distinct values)", c);
@@ -157,9 +155,7 @@ int gk_lut_export(gk_lut* l, int32_t first, int32_t count, double* keys_out) {
   gk_bind(l ? l->ctx : nullptr);
   GK_REQUIRE(l && keys_out && first >= 0 && count >= 0, "bad arguments");
   if (!count) return GK_OK;
-  GK_HIP(hipMemcpyAsync(keys_out, l->d_list + first, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                        l->ctx->stream));
-  GK_HIP(hipStreamSynchronize(l->ctx->stream));
+  GK_HIP(gk_fetch(l->ctx, keys_out, l->d_list + first, (size_t)count * sizeof(uint64_t)));
   return GK_OK;
 }
 
@@ -167,8 +163,7 @@ int gk_lut_define(gk_lut* l, int32_t first, int32_t count, const double* log_val
   gk_bind(l ? l->ctx : nullptr);
   GK_REQUIRE(l && log_vals && first == l->n_known && count >= 0, "values must be defined in order");
   if (!count) return GK_OK;
-  GK_HIP(hipMemcpyAsync(l->d_vals + first, log_vals, (size_t)count * sizeof(double), hipMemcpyHostToDevice,
-                        l->ctx->stream));
+  GK_HIP(gk_send(l->ctx, l->d_vals + first, log_vals, (size_t)count * sizeof(double)));
   GK_KERNEL(lut_publish, dim3((unsigned)((count + kThreads - 1) / kThreads)), dim3(kThreads), 0, l->ctx->stream, l->d_list,
             l->d_vals, (uint32_t)first, (uint32_t)count, l->d_keys, l->d_slot_val, (uint32_t)((1ull << l->log2cap) - 1));
   GK_HIP(hipGetLastError());

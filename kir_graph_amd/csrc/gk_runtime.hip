@@ -1,4 +1,6 @@
 // Runtime plumbing of the C ABI: context, memory, timing, errors.
+#include <algorithm>
+
 #include "gk_common.h"
 
 static thread_local char g_err[512] = "";
@@ -55,6 +57,7 @@ int gk_ctx_destroy(gk_ctx* ctx) {
   for (auto& kv : ctx->pool_live) hipFree(kv.first);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
+  if (ctx->bounce) hipHostFree(ctx->bounce);
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
   hipStreamDestroy(ctx->stream);
@@ -99,7 +102,7 @@ int gk_h2d(gk_ctx* ctx, gk_dptr dst, const void* src, size_t bytes) {
   gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   if (!bytes) return GK_OK;
-  GK_HIP(hipMemcpyAsync(gk_ptr<void>(dst), src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  GK_HIP(gk_send(ctx, gk_ptr<void>(dst), src, bytes));
   GK_HIP(hipStreamSynchronize(ctx->stream));
   return GK_OK;
 }
@@ -108,8 +111,7 @@ int gk_d2h(gk_ctx* ctx, void* dst, gk_dptr src, size_t bytes) {
   gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   if (!bytes) return GK_OK;
-  GK_HIP(hipMemcpyAsync(dst, gk_ptr<void>(src), bytes, hipMemcpyDeviceToHost, ctx->stream));
-  GK_HIP(hipStreamSynchronize(ctx->stream));
+  GK_HIP(gk_fetch(ctx, dst, gk_ptr<void>(src), bytes));
   return GK_OK;
 }
 
@@ -138,6 +140,61 @@ int gk_timer_stop_ms(gk_ctx* ctx, float* ms) {
 }
 
 }  // extern "C"
+
+// ---- pinned staging (see gk_ctx)
+constexpr size_t kStageDirect = (size_t)4 << 20;   // larger transfers go straight to / from the caller's memory
+
+hipError_t gk_send(gk_ctx* ctx, void* dst_dev, const void* src, size_t bytes) {
+  if (!bytes) return hipSuccess;
+  if (bytes > kStageDirect) return hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+  const size_t need = (bytes + 63) / 64 * 64;
+  if (ctx->pinned_bytes < need || ctx->pinned_head + need > ctx->pinned_bytes) {
+    // the ring is full (or too small): every copy queued from it has left once the stream has drained
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return e;
+    if (ctx->pinned_bytes < need * 4) {
+      if (ctx->pinned) hipHostFree(ctx->pinned);
+      ctx->pinned = nullptr;
+      ctx->pinned_bytes = std::max<size_t>(need * 4, (size_t)1 << 20);
+      e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault);
+      if (e != hipSuccess) { ctx->pinned_bytes = 0; return e; }
+    }
+    ctx->pinned_head = 0;
+  }
+  char* slot = (char*)ctx->pinned + ctx->pinned_head;
+  ctx->pinned_head += need;
+  memcpy(slot, src, bytes);
+  return hipMemcpyAsync(dst_dev, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
+}
+
+hipError_t gk_fetch_queue(gk_ctx* ctx, void* dst, const void* src_dev, size_t bytes) {
+  if (!bytes) return hipSuccess;
+  if (bytes > kStageDirect) return hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  const size_t need = (bytes + 63) / 64 * 64;
+  if (ctx->bounce_head + need > ctx->bounce_bytes) {
+    hipError_t e = gk_fetch_wait(ctx);          // deliver what is queued, then the area is free
+    if (e != hipSuccess) return e;
+    if (ctx->bounce_bytes < need) {
+      if (ctx->bounce) hipHostFree(ctx->bounce);
+      ctx->bounce = nullptr;
+      ctx->bounce_bytes = std::max<size_t>(need * 2, (size_t)1 << 20);
+      e = hipHostMalloc(&ctx->bounce, ctx->bounce_bytes, hipHostMallocDefault);
+      if (e != hipSuccess) { ctx->bounce_bytes = 0; return e; }
+    }
+  }
+  const size_t off = ctx->bounce_head;
+  ctx->bounce_head += need;
+  ctx->fetches.push_back({dst, off, bytes});
+  return hipMemcpyAsync((char*)ctx->bounce + off, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+}
+
+hipError_t gk_fetch_wait(gk_ctx* ctx) {
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  for (const auto& f : ctx->fetches) memcpy(f.dst, (const char*)ctx->bounce + f.off, f.bytes);
+  ctx->fetches.clear();
+  ctx->bounce_head = 0;
+  return e;
+}
 
 static size_t pool_class(size_t bytes) {
   if (bytes < 256) return 256;

@@ -167,8 +167,7 @@ int gk_compact(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int
                                              d_flag, d_values, n, cnt, d_out, cnt + blocks2));
     GK_HIP(hipGetLastError());
     uint32_t total = 0;
-    GK_HIP(hipMemcpyAsync(&total, cnt + blocks2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP(hipStreamSynchronize(ctx->stream));
+    GK_HIP(gk_fetch(ctx, &total, cnt + blocks2, sizeof(uint32_t)));
     gk_pool_free(ctx, cnt);
     if (n_out) *n_out = total;
     return GK_OK;
@@ -184,8 +183,7 @@ int gk_compact(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int
   }
   GK_PROF(ctx, GK_K_SCAN, GK_KERNEL(scatter_selected, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, d_values, n, d_out));
   uint32_t total = 0;
-  GK_HIP(hipMemcpyAsync(&total, pos + n, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  GK_HIP(hipStreamSynchronize(ctx->stream));
+  GK_HIP(gk_fetch(ctx, &total, pos + n, sizeof(uint32_t)));
   gk_pool_free(ctx, pos);
   if (n_out) *n_out = total;
   return GK_OK;

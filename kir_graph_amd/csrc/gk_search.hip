@@ -651,8 +651,8 @@ int upload_program(gk_ctx* ctx, int64_t n_rows, const int32_t* ids, size_t n_ids
       ctx->tree_heads.clear();
     }
     GK_HIP(gk_pool_malloc(ctx, (void**)&prog, buf.size()));
-    GK_HIP(hipMemcpyAsync(prog, buf.data(), buf.size(), hipMemcpyHostToDevice, ctx->stream));
-    GK_HIP(hipStreamSynchronize(ctx->stream));   // buf is pageable and goes out of scope
+    GK_HIP(gk_send(ctx, prog, buf.data(), buf.size()));
+    GK_HIP(hipStreamSynchronize(ctx->stream));   // a large program goes straight from buf, which goes out of scope
     ctx->tree_programs[n_rows] = prog;
     ctx->tree_heads[n_rows] = head;
   }
@@ -666,16 +666,13 @@ int upload_program(gk_ctx* ctx, int64_t n_rows, const int32_t* ids, size_t n_ids
   d.n_chunks = head.n_chunks;
   // per-call parameters
   const size_t n_par = std::max<size_t>(n_ids + n_cols, 1);
-  if (ctx->pinned_bytes < n_par * sizeof(int32_t)) {
-    if (ctx->pinned) GK_HIP(hipHostFree(ctx->pinned));
-    ctx->pinned_bytes = std::max<size_t>(n_par * sizeof(int32_t) * 2, 1 << 16);
-    GK_HIP(hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
-  }
-  int32_t* stage = (int32_t*)ctx->pinned;
-  if (n_ids) memcpy(stage, ids, n_ids * sizeof(int32_t));
-  if (n_cols) memcpy(stage + n_ids, cols, n_cols * sizeof(int32_t));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d.base, n_par * sizeof(int32_t)));
-  GK_HIP(hipMemcpyAsync(d.base, stage, n_par * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  {
+    std::vector<int32_t> packed(n_par);   // ids then columns, one copy
+    if (n_ids) memcpy(packed.data(), ids, n_ids * sizeof(int32_t));
+    if (n_cols) memcpy(packed.data() + n_ids, cols, n_cols * sizeof(int32_t));
+    GK_HIP(gk_send(ctx, d.base, packed.data(), n_par * sizeof(int32_t)));
+  }
   d.ids = (int32_t*)d.base;
   d.cols = (int32_t*)d.base + n_ids;
   return GK_OK;
@@ -760,16 +757,14 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   GK_HIP(hipGetLastError());
   if (symmetric) {
     std::vector<double> sq((size_t)n_out);
-    GK_HIP(hipMemcpyAsync(sq.data(), d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
-    GK_HIP(hipStreamSynchronize(st));
+    GK_HIP(gk_fetch(ctx, sq.data(), d_out, (size_t)n_out * sizeof(double)));
     for (int t = 0; t < n_sets; ++t) {
       const int x = row_of_set[t];
       double* dst = out + (size_t)t * n_cols;
       for (int y = 0; y < n_cols; ++y) dst[y] = x <= y ? sq[(size_t)x * n_cols + y] : sq[(size_t)y * n_cols + x];
     }
   } else {
-    GK_HIP(hipMemcpyAsync(out, d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
-    GK_HIP(hipStreamSynchronize(st));
+    GK_HIP(gk_fetch(ctx, out, d_out, (size_t)n_out * sizeof(double)));
   }
   gk_pool_free(ctx, d_partial);
   gk_pool_free(ctx, d_out);
@@ -872,12 +867,10 @@ static int set_shares(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, cons
                              value_out ? 0.0 : (double)n_rows, d_out));
   GK_HIP(hipGetLastError());
   if (!value_out) {
-    GK_HIP(hipMemcpyAsync(frac_out, d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
-    GK_HIP(hipStreamSynchronize(st));
+    GK_HIP(gk_fetch(ctx, frac_out, d_out, (size_t)n_out * sizeof(double)));
   } else {
     std::vector<double> both((size_t)n_out);
-    GK_HIP(hipMemcpyAsync(both.data(), d_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
-    GK_HIP(hipStreamSynchronize(st));
+    GK_HIP(gk_fetch(ctx, both.data(), d_out, (size_t)n_out * sizeof(double)));
     const double rows = (double)n_rows;
     for (int k = 0; k < n_sets; ++k) {
       const double* src = both.data() + (size_t)k * per_set;
@@ -909,7 +902,7 @@ int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   hipStream_t st = ctx->stream;
   int32_t* d_ids = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_ids, (size_t)n_sets * c * sizeof(int32_t)));
-  GK_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n_sets * c * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  GK_HIP(gk_send(ctx, d_ids, ids, (size_t)n_sets * c * sizeof(int32_t)));
   int64_t want = (n_rows + kThreads - 1) / kThreads;
   unsigned bx = (unsigned)(want < 1024 ? want : 1024);
   GK_PROF(ctx, GK_K_SETMAX,

@@ -590,10 +590,10 @@ int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t
 
   uint32_t totals[2] = {0, 0};
   int err = 0;
-  GK_HIP(hipMemcpyAsync(&totals[0], cnt + 4 * n_pairs, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  GK_HIP(hipMemcpyAsync(&totals[1], prefix + n_words, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  GK_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  GK_HIP(hipStreamSynchronize(st));
+  GK_HIP(gk_fetch_queue(ctx, &totals[0], cnt + 4 * n_pairs, sizeof(uint32_t)));
+  GK_HIP(gk_fetch_queue(ctx, &totals[1], prefix + n_words, sizeof(uint32_t)));
+  GK_HIP(gk_fetch_queue(ctx, &err, d_err, sizeof(int)));
+  GK_HIP(gk_fetch_wait(ctx));
   tab->n_ids = totals[0];
   tab->n_novel = (int32_t)totals[1];
   tab->err_flags = err & 3;   // bit 2 (a window beyond the saved bits) only selects the pass-2 kernel

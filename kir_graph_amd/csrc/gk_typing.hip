@@ -437,8 +437,7 @@ static int build_partition(gk_ctx* ctx, gk_tab* tab, int multiple) {
                      n_bins, n_tiles, goff);
   GK_HIP(hipGetLastError());
   std::vector<uint32_t> host((size_t)n_bins + 1);
-  GK_HIP(hipMemcpyAsync(host.data(), goff, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  GK_HIP(hipStreamSynchronize(ctx->stream));
+  GK_HIP(gk_fetch(ctx, host.data(), goff, host.size() * sizeof(uint32_t)));
   part.gene_off.assign(host.begin(), host.end());
   gk_pool_free(ctx, hist);
   gk_pool_free(ctx, goff);
@@ -570,10 +569,10 @@ int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vfla
     GK_HIP(gk_pool_malloc(ctx, (void**)&vals, (size_t)(2 * n) * sizeof(uint32_t)));
     GK_KERNEL(gather_surviving, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream, ord, n, cnt, cnt + nv,
                        gk_ptr<uint8_t>(d_vflag), vals);
-    GK_HIP(hipMemcpyAsync(ord_out, ord, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP(hipMemcpyAsync(pos_out, vals, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP(hipMemcpyAsync(neg_out, vals + n, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP(hipStreamSynchronize(ctx->stream));
+    GK_HIP(gk_fetch_queue(ctx, ord_out, ord, (size_t)n * sizeof(int32_t)));
+    GK_HIP(gk_fetch_queue(ctx, pos_out, vals, (size_t)n * sizeof(uint32_t)));
+    GK_HIP(gk_fetch_queue(ctx, neg_out, vals + n, (size_t)n * sizeof(uint32_t)));
+    GK_HIP(gk_fetch_wait(ctx));
     gk_pool_free(ctx, vals);
   }
   gk_pool_free(ctx, flag);
