@@ -335,6 +335,30 @@ class Device:
             self.ctx = None
 
 
+_pinned_ok: bool | None = None
+
+
+def pinnedEmpty(count: int, dtype) -> np.ndarray:
+    """``np.empty(count, dtype)`` in pinned host memory when a GPU is there (the packed records of a sample on
+    their way to HBM: the copy then runs at PCIe speed instead of through the runtime's pageable staging);
+    plain memory otherwise.  The block is returned to the runtime when the array is garbage collected."""
+    global _pinned_ok
+    dtype = np.dtype(dtype)
+    nbytes = int(count) * dtype.itemsize
+    if _pinned_ok is None:
+        _pinned_ok = deviceCount() > 0
+    if not _pinned_ok or nbytes < (1 << 20):
+        return np.empty(count, dtype=dtype)
+    p = C.c_void_p()
+    if lib().gk_host_alloc(nbytes, C.byref(p)) != 0 or not p.value:
+        return np.empty(count, dtype=dtype)
+    import weakref
+    raw = (C.c_uint8 * nbytes).from_address(p.value)
+    arr = np.frombuffer(raw, dtype=dtype, count=count)
+    weakref.finalize(raw, lib().gk_host_free, C.c_void_p(p.value))     # arr keeps `raw` alive through its base
+    return arr
+
+
 def deviceCount() -> int:
     n = C.c_int()
     rc = lib().gk_device_count(C.byref(n))

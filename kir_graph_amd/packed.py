@@ -223,7 +223,8 @@ def _withPacker(index: GkIndex, table: InsTable | None, feed):
         n_lines, n_reads, n_pairs, n_strange, n_str = (C.c_int64() for _ in range(5))
         check(lib().gk_packer_counts(pk, C.byref(n_lines), C.byref(n_reads), C.byref(n_pairs), C.byref(n_strange),
                                      C.byref(n_str)))
-        rec = np.empty(2 * n_pairs.value, dtype=MATE_DTYPE)          # filled by gk_packer_records
+        from ._lib import pinnedEmpty
+        rec = pinnedEmpty(2 * n_pairs.value, MATE_DTYPE)             # filled by gk_packer_records; pinned when a GPU is there
         pair_lines = np.empty((n_pairs.value, 2), dtype=np.int64)
         check(lib().gk_packer_records(pk, rec.ctypes.data if len(rec) else None,
                                       pair_lines.ctypes.data if len(pair_lines) else None))
