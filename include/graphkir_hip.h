@@ -329,6 +329,11 @@ int gk_bam_pileup(gk_bam* bam, const int64_t* gene_off, int32_t n_gene, uint32_t
 int gk_depth(gk_ctx* ctx, gk_tab* tab, gk_dptr d_mates, int32_t multiple, const int64_t* gene_off,
              int32_t n_gene, uint32_t* depth_out);
 
+/* the `samtools depth -aa` text of that table ("gene\tpos\tdepth", positions 1-based, no header), as
+ * samtools_utils.readSamtoolsDepth / kir_cn.predictSamplesCN read it (samtools_utils.py:17-22) */
+int gk_depth_write_tsv(const char* path, const char* const* genes, const int64_t* gene_off, int32_t n_genes,
+                       const uint32_t* depth);
+
 /* ---- copy-number model (LCND / "CNgroup"): cn_model.py:124-204.
  * gk_cn_fit:    loglik_out[j] = sum_x log(max_n N(x; bases[j]*n, dev[n]) * space + 1e-9) * density[x]
  *               for n = first_cn .. first_cn + n_cn - 1 (CNgroup.fit 153-164, calcCNGroupProb 179-204)

@@ -127,6 +127,7 @@ _SIGS = {
     "gk_packer_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gk_packer_string": (C.c_char_p, [C.c_void_p, C.c_int64]),
     "gk_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "gk_depth_write_tsv": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gk_cn_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                             C.c_int32, C.c_int32, C.c_double, C.c_void_p]),
     "gk_cn_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_int32,
@@ -300,8 +301,8 @@ class Device:
         return DeviceBuffer(self, a.shape, a.dtype).upload(a)
 
     def view(self, ptr: int, count: int, dtype) -> np.ndarray:
-        """Download ``count`` items of ``dtype`` from a raw device address."""
-        out = np.empty(count, dtype=dtype)
+        """Download ``count`` items of ``dtype`` from a raw device address (large ones into pinned memory)."""
+        out = pinnedEmpty(count, dtype) if count * np.dtype(dtype).itemsize >= (8 << 20) else np.empty(count, dtype=dtype)
         if count:
             check(lib().gk_d2h(self.ctx, _np_ptr(out), ptr, out.nbytes))
         return out

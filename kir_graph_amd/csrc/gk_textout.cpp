@@ -133,3 +133,51 @@ extern "C" int gk_json_write_reads(const char* path, const char* sam_text, int64
   if (!ok) { gk_set_error("short write to %s", path); return GK_ERR_ARG; }
   return GK_OK;
 }
+
+
+// `samtools depth -aa` text (samtools_utils.py:9-22 reads it back): one line "gene\tpos\tdepth" per position of
+// every backbone, positions 1-based, no header.  gene_off[g] .. gene_off[g + 1] are gene g's positions in `depth`.
+extern "C" int gk_depth_write_tsv(const char* path, const char* const* genes, const int64_t* gene_off, int32_t n_genes,
+                                  const uint32_t* depth) {
+  if (!path || (n_genes && (!genes || !gene_off || !depth))) {
+    gk_set_error("null argument");
+    return GK_ERR_ARG;
+  }
+  FILE* f = fopen(path, "wb");
+  if (!f) {
+    gk_set_error("cannot write %s", path);
+    return GK_ERR_ARG;
+  }
+  std::string buf;
+  buf.reserve(1 << 20);
+  auto put_uint = [&buf](uint64_t v) {
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) buf.push_back(tmp[--n]);
+  };
+  bool ok = true;
+  for (int32_t g = 0; g < n_genes && ok; ++g) {
+    const std::string name = genes[g];
+    for (int64_t i = gene_off[g]; i < gene_off[g + 1]; ++i) {
+      buf += name;
+      buf.push_back('\t');
+      put_uint((uint64_t)(i - gene_off[g] + 1));
+      buf.push_back('\t');
+      put_uint(depth[i]);
+      buf.push_back('\n');
+      if (buf.size() > (1 << 20) - 256) {
+        ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        buf.clear();
+        if (!ok) break;
+      }
+    }
+  }
+  if (ok && !buf.empty()) ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) {
+    gk_set_error("short write to %s", path);
+    return GK_ERR_ARG;
+  }
+  return GK_OK;
+}

@@ -124,7 +124,7 @@ def _mapLoop(names, prepare, ahead, gk, gene_len, dev, dindex, index_ref, exon_r
             writes.append(writeCompact(data, name + ".npz", index_ref=index_ref, background=writer))
         depth_name = name + ".no_multi"
         logger.info(f"[Graph] Calculate read depth to {depth_name}.depth.tsv")
-        depthOfSample(data, gene_len, depth_name + ".depth.tsv")
+        depthOfSample(data, gene_len, depth_name + ".depth.tsv", want_frame=False)
         depth_name += ".depth"
         if exon_region_only:
             logger.info(f"[Graph] Filter exon read to {depth_name}.exon.tsv")

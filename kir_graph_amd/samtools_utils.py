@@ -34,9 +34,13 @@ def readLocusLengths(index: str) -> dict[str, int]:
     return out
 
 
-def depthOfSample(data, gene_len: dict[str, int], file_depth: str | None = None, multiple: bool = False
-                  ) -> pd.DataFrame:
-    """``gene, pos (1-based), depth`` for every position of every backbone, like ``samtools depth -aa``."""
+def depthOfSample(data, gene_len: dict[str, int], file_depth: str | None = None, multiple: bool = False,
+                  want_frame: bool = True) -> pd.DataFrame | None:
+    """``gene, pos (1-based), depth`` for every position of every backbone, like ``samtools depth -aa``.
+
+    The file (when asked for) is written natively (``gk_depth_write_tsv``: the same text ``DataFrame.to_csv`` gives,
+    at a fraction of the time); ``want_frame=False`` skips building the DataFrame (the pipeline only needs the file)."""
+    import ctypes as C
     tab = data.tab
     genes = data.index.genes
     lens = np.array([gene_len[g] for g in genes], dtype=np.int64)
@@ -45,11 +49,13 @@ def depthOfSample(data, gene_len: dict[str, int], file_depth: str | None = None,
     depth = np.empty(int(off[-1]), dtype=np.uint32)
     check(lib().gk_depth(tab.dev.ctx, tab.handle, tab.mates.ptr, int(multiple), off.ctypes.data, len(genes),
                          depth.ctypes.data))
-    df = pd.DataFrame({
+    if file_depth:
+        names = (C.c_char_p * len(genes))(*[g.encode() for g in genes])
+        check(lib().gk_depth_write_tsv(file_depth.encode(), names, off.ctypes.data, len(genes), depth.ctypes.data))
+    if not want_frame:
+        return None
+    return pd.DataFrame({
         "gene": np.repeat(np.array(genes, dtype=object), lens),
         "pos": np.concatenate([np.arange(1, n + 1) for n in lens]) if len(lens) else np.zeros(0, np.int64),
         "depth": depth.astype(np.int64),
     })
-    if file_depth:
-        df.to_csv(file_depth, sep="\t", header=False, index=False)
-    return df

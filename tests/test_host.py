@@ -697,3 +697,24 @@ def test_pileup_ratios_and_correction_table_match_reference_fixture():
         j = "ACGTN".index(val)
         shown = chr(table[pos, j]) if table[pos, j] else val
         assert shown == fixed, (pos, val, shown, fixed)
+
+
+def test_native_depth_tsv_equals_pandas(tmp_path):
+    """gk_depth_write_tsv writes the text DataFrame.to_csv(sep='\\t', header=False, index=False) gives for the
+    ``samtools depth -aa`` table (gene, 1-based position, depth)."""
+    import ctypes as C
+    import pandas as pd
+    from kir_graph_amd._lib import check, lib
+    rng = np.random.default_rng(3)
+    genes = ["KIR2DL1*BACKBONE", "KIR2DL4*BACKBONE", "KIR3DL3*BACKBONE"]
+    lens = np.array([1500, 1, 977])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    depth = rng.integers(0, 5000, int(off[-1])).astype(np.uint32)
+    depth[:3] = [0, 4294967295, 10]
+    names = (C.c_char_p * len(genes))(*[g.encode() for g in genes])
+    path = str(tmp_path / "d.tsv")
+    check(lib().gk_depth_write_tsv(path.encode(), names, off.ctypes.data, len(genes), depth.ctypes.data))
+    df = pd.DataFrame({"gene": np.repeat(np.array(genes, dtype=object), lens),
+                       "pos": np.concatenate([np.arange(1, n + 1) for n in lens]), "depth": depth.astype(np.int64)})
+    df.to_csv(tmp_path / "p.tsv", sep="\t", header=False, index=False)
+    assert open(path).read() == (tmp_path / "p.tsv").read_text()
