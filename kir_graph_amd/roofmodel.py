@@ -78,7 +78,10 @@ def _priced(kernel: str, calls: list[tuple]) -> tuple[float, float, str, float]:
     for c in calls:
         if kernel == "maxsum_chunks":
             b, o = maxsumLaunch(*c[1:7])
-            bound, peak = "valu", F64_VALU_PEAK_OPS
+            if c[2] == 1 and c[3] == 0:      # column sums (colsum_chunks): one add per element, a pure HBM stream
+                o = 0.0
+            else:
+                bound, peak = "valu", F64_VALU_PEAK_OPS
         elif kernel == "minsum_sad":
             b, o = minsumLaunch(*c[1:6])
             bound, peak = "valu", VALU_LANE_OPS
