@@ -13,6 +13,7 @@ readMapping 124-168, alleleTyping 171-220, getCommonName 223-250).  What differs
 * launched with RANK / WORLD_SIZE / LOCAL_RANK set (``torchrun`` or any launcher) the samples are sharded over
   the ranks (one GPU each, largest inputs first); ``--cn-cohort`` then pools the gene depths with one
   all-gather (``cohort.Comm`` -> ``gk_allgather_f64``, RCCL), rank 0 merges the outputs;
+* ``--ranks N`` starts the N rank processes itself (no launcher needed);
 * a sample is typed and released as soon as its copy numbers are known (memory does not grow with the cohort);
 * index building, WGS extraction and plotting are outside this build: the index files must exist.
 """
@@ -224,6 +225,10 @@ def createParser() -> argparse.ArgumentParser:
     p.add_argument("--alignment", action="append",
                    help="Existing name-collated alignments (SAM / SAM.gz / BAM), one per sample: skips hisat2")
     p.add_argument("--no-variant-json", action="store_true", help="Do not write {name}.variant.json")
+    p.add_argument("--ranks", type=int, default=1,
+                   help="Start this many rank processes (samples are sharded over them; ranks map to GPUs round robin, "
+                        "so 3 x the GPU count keeps every GPU busy).  Not needed under torchrun / any launcher that "
+                        "sets RANK and WORLD_SIZE.")
     return p
 
 
@@ -363,8 +368,28 @@ def main(args: argparse.Namespace) -> None:
     logger.info("[Main] Success")
 
 
+def spawnRanks(n: int, argv: list[str]) -> int:
+    """``--ranks N`` without a launcher: start N copies of this command as ranks 0..N-1 (fresh processes; this
+    one never touches the GPU), wait for all of them, return the worst exit code."""
+    import subprocess
+    import sys
+    import tempfile
+    rdzv = tempfile.mkdtemp(prefix="gk_rdzv_")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   GK_RDZV_DIR=rdzv)
+        procs.append(subprocess.Popen([sys.executable, "-m", "kir_graph_amd.main"] + argv, env=env))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
 def entrypoint() -> None:
-    main(createParser().parse_args())
+    import sys
+    args = createParser().parse_args()
+    if args.ranks > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawnRanks(args.ranks, sys.argv[1:]))
+    main(args)
 
 
 if __name__ == "__main__":

@@ -225,3 +225,25 @@ def test_two_ranks_cn_cohort_equals_one_process(device, tmp_path):
                 assert a["data"] == b["data"] and len(a["data"]) == 5 * 15     # the pooled depths, cohort order
             assert a == b, n
     assert sum(n.endswith(".p75.cohort.LCND.tsv") for n in names) == 5
+
+
+def test_ranks_flag_starts_the_ranks_itself(device, tmp_path):
+    """``python -m kir_graph_amd.main --ranks 2`` without a launcher: the same cohort tables as one process."""
+    import subprocess
+    import sys
+    sidx, folder, sams, samples = _cohort(tmp_path, n_samples=4, n_pairs=3000)
+    one = tmp_path / "one"
+    _run(folder, one, sams, ["--cn-cohort"])
+    two = tmp_path / "two"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "kir_graph_amd.main", "--step-skip-extraction", "--index-folder", folder,
+           "--output-folder", str(two), "--allele-strategy", "pv", "--no-variant-json", "--cn-cohort", "--ranks", "2",
+           "--log-level", "WARNING"] + [x for s in sams for x in ("--alignment", s)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run(cmd, env=dict(env, PYTHONPATH=root, GK_THREADS="2"), cwd=root, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    for name in ("cohort.cn.tsv", "cohort.allele.tsv"):
+        a = (one / name).read_text().replace(str(one), "@")
+        b = (two / name).read_text().replace(str(two), "@")
+        assert a == b, name

@@ -14,20 +14,32 @@ dindex = DeviceIndex(dev, gidx)
 tab = Tabulation(dindex, dev.put(rec))
 logs = LogTable(dev)
 models = []
-def run():
+def run(products_only=False):
     for g, t in enumerate(gidx.tables):
         rows, n = tab.selectGene(g)
         vflag = dev.alloc(tab.n_var_total, np.uint8).zero()
         dm = DeviceModel(tab, rows, n, vflag, t.vbeg, t.vend, dindex.masks[g], t.words, t.n_allele, logs)
         dm.finishLog()
+        if products_only:
+            dm.probs          # gk_compat: the ordered products alone (no value table, no mismatch bytes)
         dm.free(); rows.free(); vflag.free()
-run()
-dev.profEnable(True); dev.profCollect()
-t0 = time.perf_counter()
-for _ in range(3):
-    run()
-dev.sync()
-wall = (time.perf_counter() - t0) / 3
-for k, (n, ms) in dev.profCollect().items():
-    print(f"{k:16s} {n / 3:5.1f} launches/step  {ms / 3:8.3f} ms/step")
-print(f"wall {wall * 1e3:.2f} ms")
+
+def measure(label, **kw):
+    run(**kw)
+    dev.profEnable(True); dev.profCollect()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        run(**kw)
+    dev.sync()
+    wall = (time.perf_counter() - t0) / 3
+    print(f"--- {label}")
+    for k, (n, ms) in dev.profCollect().items():
+        print(f"{k:16s} {n / 3:5.1f} launches/step  {ms / 3:8.3f} ms/step")
+    print(f"wall {wall * 1e3:.2f} ms")
+    dev.profEnable(False)
+
+os.environ["GK_SEARCH"] = "bound"
+measure("log-likelihoods + u8 mismatch table (gk_compat_log_miss): the product path")
+os.environ["GK_SEARCH"] = "exact"
+measure("log-likelihoods only (gk_compat_log)")
+measure("log-likelihoods, then the plain products once more (gk_compat): compat_kernel = both", products_only=True)
