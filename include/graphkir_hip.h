@@ -160,6 +160,18 @@ int gk_variant_correct(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag)
 int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag, int64_t max_out,
                          int32_t* ord_out, uint32_t* pos_out, uint32_t* neg_out, int64_t* n_out);
 
+/* The same restricted to one backbone: index ordinals [vbeg, vend) and the novel variants on backbone `gene`. */
+int gk_variant_surviving_gene(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag, int32_t gene, int32_t vbeg,
+                              int32_t vend, int64_t max_out, int32_t* ord_out, uint32_t* pos_out, uint32_t* neg_out,
+                              int64_t* n_out);
+/* errorCorrection + removeEmptyReads (302-338, 274-281) for EVERY gene of a sample at once (variants of different
+ * backbones are disjoint, so one tally, one pass of the thresholds and one stable compaction give what the per-gene
+ * calls give).  d_vflag uint8 [n_var + n_novel] and d_cnt uint32 [2][n_var + n_novel] are zeroed and filled here;
+ * d_rows int32 [n_valid] receives the rows with a surviving id grouped by backbone in row order (NH == 1 only
+ * unless `multiple`), gene_off_out int64 [n_gene + 1] their bounds.  Needs a tabulation made by gk_tabulate. */
+int gk_sample_prepare(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_vflag, gk_dptr d_cnt, gk_dptr d_rows,
+                      int64_t* gene_off_out);
+
 /* ---- compatibility: reads2AlleleProb (typing_mulit_allele.py:340-381).
  * d_mask uint32 [vend-vbeg][words]: allele bit rows of the gene's index variants.
  * Outputs are column-major [allele][row] with leading dimension n_rows:

@@ -87,6 +87,9 @@ _SIGS = {
                                          C.c_int32, C.c_int32]),
     "gk_variant_surviving": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "gk_variant_surviving_gene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "gk_sample_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "gk_variant_correct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "gk_compat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_int32, C.c_int32,
                             C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]),
@@ -267,6 +270,21 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+class DeviceSlice(DeviceBuffer):
+    """Part of another buffer (not owned: freeing it does nothing; the parent must outlive it)."""
+
+    def __init__(self, parent: DeviceBuffer, offset_items: int, count: int, dev: "Device | None" = None):
+        self.dev = dev or parent.dev
+        self.shape = (int(count),)
+        self.dtype = parent.dtype
+        self.nbytes = int(count) * self.dtype.itemsize
+        self.ptr = parent.ptr + int(offset_items) * self.dtype.itemsize
+        self._parent = parent
+
+    def free(self) -> None:
+        self.ptr = 0
 
 
 class Device:

@@ -125,6 +125,63 @@ __global__ __launch_bounds__(kThreads) void flag_nonempty(const int32_t* rows, i
   flag[i] = alive;
 }
 
+// The same tally for ALL genes of a sample in one launch (gk_sample_prepare): `rows` are the rows grouped by
+// backbone, workgroup b owns rows [wg_row0[b], wg_row1[b]) of gene wg_gene[b] -- one gene per workgroup, so
+// the LDS counters cover that gene's index variants [gene_vbeg[g], gene_vbeg[g + 1]).
+__global__ __launch_bounds__(kThreads) void count_ids_genes(const int32_t* __restrict__ rows,
+                                                            const int32_t* __restrict__ wg_gene,
+                                                            const int64_t* __restrict__ wg_row0,
+                                                            const int64_t* __restrict__ wg_row1,
+                                                            const int32_t* __restrict__ gene_vbeg, int max_local,
+                                                            const uint32_t* __restrict__ off,
+                                                            const uint32_t* __restrict__ ids,
+                                                            const uint8_t* __restrict__ vflag, uint32_t* cnt_pos,
+                                                            uint32_t* cnt_neg) {
+  extern __shared__ uint32_t hist[];   // [2][n_local]
+  const int g = wg_gene[blockIdx.x];
+  const int vbeg = gene_vbeg[g];
+  const int n_local = min(gene_vbeg[g + 1] - vbeg, max_local);
+  for (int i = threadIdx.x; i < 2 * n_local; i += kThreads) hist[i] = 0;
+  __syncthreads();
+  constexpr int kGroup = 16;
+  const int lane = threadIdx.x & (kGroup - 1);
+  const int64_t r0 = wg_row0[blockIdx.x], r1 = wg_row1[blockIdx.x];
+  for (int64_t i = r0 + threadIdx.x / kGroup; i < r1; i += kThreads / kGroup) {
+    const int64_t row = rows[i];
+    const uint32_t b = off[4 * row], mid = off[4 * row + 2], e = off[4 * row + 4];
+    for (uint32_t k = b + lane; k < e; k += kGroup) {
+      const uint32_t v = ids[k];
+      const bool positive = k < mid;
+      if (vflag[v] & (positive ? 1 : 2)) continue;
+      const uint32_t l = v - (uint32_t)vbeg;
+      if (l < (uint32_t)n_local) atomicAdd(&hist[(positive ? 0 : n_local) + l], 1u);
+      else atomicAdd(positive ? &cnt_pos[v] : &cnt_neg[v], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * n_local; i += kThreads) {
+    const uint32_t c = hist[i];
+    if (c) atomicAdd(i < n_local ? &cnt_pos[vbeg + i] : &cnt_neg[vbeg + i - n_local], c);
+  }
+}
+
+// kept[g] = rows of gene g with flag != 0 (rows grouped by gene: [gene_off[g], gene_off[g + 1]))
+__global__ __launch_bounds__(kThreads) void count_flags_per_gene(const uint32_t* __restrict__ flag,
+                                                                 const int64_t* __restrict__ gene_off,
+                                                                 uint32_t* __restrict__ kept) {
+  const int g = blockIdx.x;
+  uint32_t c = 0;
+  for (int64_t i = gene_off[g] + threadIdx.x; i < gene_off[g + 1]; i += kThreads) c += flag[i] != 0;
+  __shared__ uint32_t part[kThreads];
+  part[threadIdx.x] = c;
+  __syncthreads();
+  for (int s2 = kThreads / 2; s2 > 0; s2 >>= 1) {
+    if (threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) kept[g] = part[0];
+}
+
 constexpr int kMaxSlots = 4;   // alleles per lane and pass: up to 256 alleles per pass
 constexpr int kCompatWaves = 8;          // 8 waves share one 16-row tile: 32 waves per CU at 34 KB of LDS per block
 constexpr int kCompatThreads = 64 * kCompatWaves;
@@ -524,10 +581,18 @@ int gk_variant_correct(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag)
 }
 
 namespace {
+// gene >= 0: only the variants of that backbone count -- index ordinals [vbeg, vend) and novel variants whose key
+// names it (tallies shared by all genes of a sample, gk_sample_prepare)
 __global__ __launch_bounds__(kThreads) void flag_surviving(const uint32_t* cnt_pos, const uint32_t* cnt_neg,
-                                                           const uint8_t* vflag, int64_t n, uint32_t* flag) {
+                                                           const uint8_t* vflag, int64_t n, uint32_t* flag, int gene,
+                                                           int vbeg, int vend, int n_index,
+                                                           const uint64_t* __restrict__ novel_key) {
   const int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (v >= n) return;
+  if (gene >= 0) {
+    const bool mine = v < n_index ? (v >= vbeg && v < vend) : (int)(novel_key[v - n_index] >> GK_KEY_REF_SHIFT) == gene;
+    if (!mine) { flag[v] = 0; return; }
+  }
   const uint8_t f = vflag[v];
   flag[v] = ((!(f & 1) && cnt_pos[v]) || (!(f & 2) && cnt_neg[v])) ? 1u : 0u;
 }
@@ -545,8 +610,8 @@ __global__ __launch_bounds__(kThreads) void gather_surviving(const int32_t* ord,
 
 /* Variants whose tally survives the drop flags: ordinals + (positive, negative) counts, compacted on
  * the device (feeds isHomozygous, typing_mulit_allele.py:807-857).  Host arrays must hold max_out. */
-int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag, int64_t max_out, int32_t* ord_out,
-                         uint32_t* pos_out, uint32_t* neg_out, int64_t* n_out) {
+static int variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag, int64_t max_out, int32_t* ord_out,
+                             uint32_t* pos_out, uint32_t* neg_out, int64_t* n_out, int gene, int vbeg, int vend) {
   gk_bind(ctx);
   GK_REQUIRE(ctx && tab && ord_out && pos_out && neg_out && n_out, "null pointer");
   const int64_t nv = (int64_t)tab->n_var + tab->n_novel;
@@ -558,7 +623,7 @@ int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vfla
   GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)nv * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&ord, (size_t)nv * sizeof(int32_t)));
   GK_KERNEL(flag_surviving, dim3(nblk(nv)), dim3(kThreads), 0, ctx->stream, cnt, cnt + nv,
-                     gk_ptr<uint8_t>(d_vflag), nv, flag);
+                     gk_ptr<uint8_t>(d_vflag), nv, flag, gene, vbeg, vend, tab->n_var, tab->d_novel_key);
   int64_t n = 0;
   int rc = gk_compact(ctx, flag, nullptr, nv, ord, &n);
   if (rc == GK_OK && n > max_out) {
@@ -578,6 +643,109 @@ int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vfla
   gk_pool_free(ctx, flag);
   gk_pool_free(ctx, ord);
   if (rc == GK_OK) *n_out = n;
+  return rc;
+}
+
+int gk_variant_surviving(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag, int64_t max_out, int32_t* ord_out,
+                         uint32_t* pos_out, uint32_t* neg_out, int64_t* n_out) {
+  return variant_surviving(ctx, tab, d_cnt, d_vflag, max_out, ord_out, pos_out, neg_out, n_out, -1, 0, 0);
+}
+
+/* The same restricted to one backbone: its index variants [vbeg, vend) and the novel variants on it (for tallies
+ * that cover every gene of the sample, gk_sample_prepare). */
+int gk_variant_surviving_gene(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag, int32_t gene, int32_t vbeg,
+                              int32_t vend, int64_t max_out, int32_t* ord_out, uint32_t* pos_out, uint32_t* neg_out,
+                              int64_t* n_out) {
+  GK_REQUIRE(gene >= 0 && vend >= vbeg, "bad gene range");
+  return variant_surviving(ctx, tab, d_cnt, d_vflag, max_out, ord_out, pos_out, neg_out, n_out, gene, vbeg, vend);
+}
+
+/* errorCorrection + removeEmptyReads (typing_mulit_allele.py:302-338, 274-281) for EVERY gene of a sample at once.
+ * The variants of different backbones are disjoint, so one tally over all rows (grouped by backbone, NH == 1 unless
+ * `multiple`), one pass of the thresholds and one compaction give what the per-gene calls give -- in ~8 launches and
+ * one wait instead of six launches and a wait per gene.
+ *   d_vflag  uint8  [n_var + n_novel]      zeroed here, then bit0 / bit1 = dropped from positive / negative lists
+ *   d_cnt    uint32 [2][n_var + n_novel]   tallies of the uncorrected lists (masked by d_vflag = those of the corrected)
+ *   d_rows   int32  [n_valid]              rows with a surviving id, grouped by backbone in row order
+ *   gene_off_out int64 [n_gene + 1]        rows of gene g = d_rows[gene_off_out[g] .. gene_off_out[g + 1]) */
+int gk_sample_prepare(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_vflag, gk_dptr d_cnt, gk_dptr d_rows,
+                      int64_t* gene_off_out) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && tab && tab->idx && d_vflag && d_cnt && d_rows && gene_off_out, "null pointer");
+  const int n_gene = tab->idx->n_gene;
+  const int64_t nv = (int64_t)tab->n_var + tab->n_novel;
+  hipStream_t st = ctx->stream;
+  for (int g = 0; g <= n_gene; ++g) gene_off_out[g] = 0;
+  GK_HIP(hipMemsetAsync(gk_ptr<void>(d_vflag), 0, (size_t)std::max<int64_t>(nv, 1), st));
+  GK_HIP(hipMemsetAsync(gk_ptr<void>(d_cnt), 0, (size_t)std::max<int64_t>(2 * nv, 1) * sizeof(uint32_t), st));
+  if (tab->n_valid == 0) return GK_OK;
+  gk_tab::GenePartition& part = tab->part[multiple ? 1 : 0];
+  {
+    std::lock_guard<std::mutex> lock(tab->part_mutex);
+    if (part.gene_off.empty()) {
+      int rc = build_partition(ctx, tab, multiple);
+      if (rc) { part.gene_off.clear(); return rc; }
+    }
+  }
+  GK_REQUIRE((int)part.gene_off.size() >= n_gene + 1, "partition does not cover the genes");
+  const int64_t n_rows = part.gene_off[n_gene];
+  if (n_rows == 0) return GK_OK;
+  // workgroups: a share of ~2048 per gene in proportion to its rows, never two genes in one workgroup
+  std::vector<int32_t> wg_gene;
+  std::vector<int64_t> wg_row0, wg_row1, goff(part.gene_off.begin(), part.gene_off.begin() + n_gene + 1);
+  const int64_t per_wg = std::max<int64_t>(64, (n_rows + 2047) / 2048);
+  int max_span = 0;
+  for (int g = 0; g < n_gene; ++g) {
+    max_span = std::max(max_span, tab->idx->gene_vbeg[g + 1] - tab->idx->gene_vbeg[g]);
+    for (int64_t r = goff[g]; r < goff[g + 1]; r += per_wg) {
+      wg_gene.push_back(g);
+      wg_row0.push_back(r);
+      wg_row1.push_back(std::min(goff[g + 1], r + per_wg));
+    }
+  }
+  const int max_local = std::min(max_span, 60 * 1024 / 8);   // LDS budget per workgroup
+  const size_t n_wg = wg_gene.size();
+  char* d_tab = nullptr;
+  const size_t o_row0 = (n_wg * sizeof(int32_t) + 15) / 16 * 16, o_row1 = o_row0 + n_wg * sizeof(int64_t),
+               o_goff = o_row1 + n_wg * sizeof(int64_t), tab_bytes = o_goff + (size_t)(n_gene + 1) * sizeof(int64_t);
+  {
+    std::vector<char> packed(tab_bytes);
+    memcpy(packed.data(), wg_gene.data(), n_wg * sizeof(int32_t));
+    memcpy(packed.data() + o_row0, wg_row0.data(), n_wg * sizeof(int64_t));
+    memcpy(packed.data() + o_row1, wg_row1.data(), n_wg * sizeof(int64_t));
+    memcpy(packed.data() + o_goff, goff.data(), (size_t)(n_gene + 1) * sizeof(int64_t));
+    GK_HIP(gk_pool_malloc(ctx, (void**)&d_tab, tab_bytes));
+    GK_HIP(gk_send(ctx, d_tab, packed.data(), tab_bytes));
+  }
+  uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
+  uint8_t* vflag = gk_ptr<uint8_t>(d_vflag);
+  GK_PROF(ctx, GK_K_COUNT_IDS,
+          GK_KERNEL(count_ids_genes, dim3((unsigned)n_wg), dim3(kThreads), (size_t)max_local * 8, st, part.d_rows,
+                    (const int32_t*)d_tab, (const int64_t*)(d_tab + o_row0), (const int64_t*)(d_tab + o_row1),
+                    tab->idx->d_gene_vbeg, max_local, tab->d_off, tab->d_ids, vflag, cnt, cnt + nv));
+  GK_PROF(ctx, GK_K_COUNT_IDS, GK_KERNEL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, st, cnt, cnt + nv, nv, vflag));
+  // rows with a surviving id, compacted in place of the grouping (stable: the groups stay contiguous and ordered)
+  uint32_t *flag = nullptr, *kept = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)n_rows * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&kept, (size_t)n_gene * sizeof(uint32_t)));
+  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(flag_nonempty, dim3(nblk(n_rows)), dim3(kThreads), 0, st, part.d_rows, n_rows,
+                                      tab->d_off, tab->d_ids, vflag, flag));
+  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(count_flags_per_gene, dim3((unsigned)n_gene), dim3(kThreads), 0, st, flag,
+                                      (const int64_t*)(d_tab + o_goff), kept));
+  GK_HIP(hipGetLastError());
+  int64_t n_kept = 0;
+  int rc = gk_compact(ctx, flag, part.d_rows, n_rows, gk_ptr<int32_t>(d_rows), &n_kept);   // waits for the stream
+  if (rc == GK_OK) {
+    std::vector<uint32_t> host((size_t)n_gene);
+    GK_HIP(gk_fetch(ctx, host.data(), kept, (size_t)n_gene * sizeof(uint32_t)));
+    int64_t run = 0;
+    for (int g = 0; g < n_gene; ++g) { gene_off_out[g] = run; run += host[g]; }
+    gene_off_out[n_gene] = run;
+    if (run != n_kept) { gk_set_error("non-empty rows per gene do not add up"); rc = GK_ERR_ASSERT; }
+  }
+  gk_pool_free(ctx, flag);
+  gk_pool_free(ctx, kept);
+  gk_pool_free(ctx, d_tab);
   return rc;
 }
 

@@ -19,7 +19,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Device, DeviceBuffer, TabInfo, check, lib
+from ._lib import Device, DeviceBuffer, DeviceSlice, TabInfo, check, lib
 from .index import GkIndex, KEY_POS_SHIFT, KEY_TYP_SHIFT, KEY_VAL_MASK
 from .msa2hisat import Variant
 
@@ -107,8 +107,36 @@ class Tabulation:
 
     def close(self) -> None:
         if self.handle and not getattr(self, "_borrowed", False):
+            for prep in (getattr(self, "_prepared", None) or {}).values():
+                for b in prep[:3]:
+                    b.free()
+            self._prepared = {}
             lib().gk_tab_destroy(self.handle)
         self.handle = None
+
+    def prepared(self, dev: Device, multiple: bool = False):
+        """Error correction + removal of empty reads of EVERY gene at once (``gk_sample_prepare``), computed by
+        the first caller and shared by all gene threads: (drop flags, tallies, rows grouped by gene, bounds).
+        None for tabulations that were not made by ``gk_tabulate`` (no index handle / novel keys on the device)."""
+        if self.dindex is None or not self.info.d_pair_src:      # host lists / compact files: no index handle in the library
+            return None
+        import threading
+        root = getattr(self, "_root", self)
+        lock = root.__dict__.setdefault("_prep_lock", threading.Lock())
+        store = root.__dict__.setdefault("_prepared", {})
+        with lock:
+            prep = store.get(bool(multiple))
+            if prep is None:
+                nv = max(self.n_var_total, 1)
+                vflag = dev.alloc(nv, np.uint8)
+                cnt = dev.alloc(2 * nv, np.uint32)
+                rows = dev.alloc(max(self.n_valid, 1), np.int32)
+                off = np.zeros(len(self.dindex.host.genes) + 1, dtype=np.int64)
+                check(lib().gk_sample_prepare(dev.ctx, self.handle, int(multiple), vflag.ptr, cnt.ptr, rows.ptr,
+                                              off.ctypes.data))
+                dev.sync()
+                prep = store[bool(multiple)] = (vflag, cnt, rows, off)
+        return prep
 
     def on(self, dev: Device) -> "Tabulation":
         """The same tabulation driven from another context (stream) of the same GPU.
@@ -121,6 +149,7 @@ class Tabulation:
         other = copy.copy(self)
         other.dev = dev
         other._borrowed = True
+        other._root = getattr(self, "_root", self)     # shared per-sample state lives on the owning tabulation
         return other
 
     # ---- host views (outputs / tests)
@@ -249,16 +278,23 @@ class Tabulation:
         cnt.free()
         return None
 
-    def survivingCounts(self, cnt: DeviceBuffer, vflag: DeviceBuffer) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """(ordinals, positive tally, negative tally) of variants with a surviving observation."""
+    def survivingCounts(self, cnt: DeviceBuffer, vflag: DeviceBuffer, gene: tuple[int, int, int] | None = None
+                        ) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(ordinals, positive tally, negative tally) of variants with a surviving observation.
+        ``gene`` = (backbone ordinal, vbeg, vend): only that backbone's variants (tallies shared by all genes)."""
         cap = 1 << 16
         while True:
             o = np.empty(cap, dtype=np.int32)
             p = np.empty(cap, dtype=np.uint32)
             q = np.empty(cap, dtype=np.uint32)
             n = C.c_int64()
-            rc = lib().gk_variant_surviving(self.dev.ctx, self.handle, cnt.ptr, vflag.ptr, cap, o.ctypes.data,
-                                            p.ctypes.data, q.ctypes.data, C.byref(n))
+            if gene is None:
+                rc = lib().gk_variant_surviving(self.dev.ctx, self.handle, cnt.ptr, vflag.ptr, cap, o.ctypes.data,
+                                                p.ctypes.data, q.ctypes.data, C.byref(n))
+            else:
+                rc = lib().gk_variant_surviving_gene(self.dev.ctx, self.handle, cnt.ptr, vflag.ptr, gene[0], gene[1],
+                                                     gene[2], cap, o.ctypes.data, p.ctypes.data, q.ctypes.data,
+                                                     C.byref(n))
             if rc == -5 and cap < self.n_var_total:
                 cap = min(cap * 8, max(self.n_var_total, 1))
                 continue

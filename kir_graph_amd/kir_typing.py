@@ -71,6 +71,18 @@ class Typing:
         raise NotImplementedError
 
 
+def batchedPreamble() -> bool:
+    """Error correction + empty-read removal for all genes of a sample at once (``gk_sample_prepare``);
+    GK_BATCH_PREAMBLE=0 keeps the per-gene calls."""
+    import os
+    return os.environ.get("GK_BATCH_PREAMBLE", "1") != "0"
+
+
+def _lib_slice(buf, offset: int, count: int, dev):
+    from ._lib import DeviceSlice
+    return DeviceSlice(buf, offset, count, dev)
+
+
 def hostThreads() -> int:
     """Host threads that type genes concurrently (each with its own HIP stream); GK_THREADS overrides."""
     import os
@@ -78,7 +90,7 @@ def hostThreads() -> int:
 
 
 class _GeneView:
-    """Per-gene handles into a tabulated sample."""
+    """Per-gene handles into a tabulated sample (the gene's rows are selected on first use)."""
 
     def __init__(self, data: SampleData, gene: str, multiple: bool, tab=None):
         self.data, self.gene = data, gene
@@ -87,19 +99,33 @@ class _GeneView:
         self.g = g
         tab = tab or data.tab
         self.tab = tab
+        self._multiple = multiple
+        self._rows = None
         if g is None:
-            self.rows, self.n_rows = tab.dev.alloc(1, np.int32), 0
+            self._rows = (tab.dev.alloc(1, np.int32), 0)
             self.vbeg = self.n_span = 0
             self.mask, self.alleles, self.variants = None, [], []
             self.novel = lambda: []
             return
         t = idx.tables[g]
-        self.rows, self.n_rows = tab.selectGene(g, multiple)
         self.vbeg, self.n_span = t.vbeg, t.vend - t.vbeg
         self.mask = tab.dindex.masks[g]
         self.alleles = t.alleles
         self.variants = idx.variants[t.vbeg:t.vend]          # index part; novel ones are built lazily
         self.novel = lambda: data.novelOfGene(gene)
+
+    def _select(self):
+        if self._rows is None:
+            self._rows = self.tab.selectGene(self.g, self._multiple)
+        return self._rows
+
+    @property
+    def rows(self):
+        return self._select()[0]
+
+    @property
+    def n_rows(self) -> int:
+        return self._select()[1]
 
     def groupCache(self) -> dict:
         """Per-gene store of the exon allele groups (index-only data, computed on first use)."""
@@ -193,13 +219,24 @@ class TypingWithPosNegAllele(_GenesInParallel):
             # in createHomoResult for cn >= 2 with automatic zygosity; soft-fail here)
             self._result[gene] = []
             return [f"{pure_gene}*"] * cn, 0
-        reads = ReadSet(tab, view.rows, view.n_rows)
         if not self._exon_first and not self._exon_only:
+            prep = tab.prepared(tab.dev, self._multiple) if self._variant_correction and batchedPreamble() else None
+            if prep is not None:
+                # error correction and empty-read removal were done for every gene of the sample in one go
+                vflag, cnt, rows_all, off = prep
+                a, b = int(off[view.g]), int(off[view.g + 1])
+                rows = _lib_slice(rows_all, a, b - a, tab.dev)
+                reads = ReadSet(tab, rows, b - a, vflag)
+                prepared = (rows, b - a, vflag, cnt, (view.g, view.vbeg, view.vbeg + view.n_span))
+            else:
+                reads, prepared = ReadSet(tab, view.rows, view.n_rows), None
             typ: AlleleTyping = AlleleTyping(
                 reads, view.variants, force_homo=force_homo, top_n=self._top_n,
                 variant_correction=self._variant_correction, logs=logs, _vbeg=view.vbeg,
-                _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles, _novel=view.novel, _defer_log=True)
+                _n_span=view.n_span, _mask=view.mask, _alleles=view.alleles, _novel=view.novel, _defer_log=True,
+                _prepared=prepared)
         else:
+            reads = ReadSet(tab, view.rows, view.n_rows)
             typ = AlleleTypingExonFirst(
                 reads, view.variants, force_homo=force_homo, top_n=self._top_n, exon_only=self._exon_only,
                 candidate_set_threshold=self._exon_candidate_threshold, logs=logs, _vbeg=view.vbeg,

@@ -343,7 +343,9 @@ class AlleleTyping:
                  no_empty: bool = True, variant_correction: bool = True, *, device: Device | None = None,
                  logs: LogTable | None = None, _vbeg: int = 0, _n_span: int | None = None,
                  _mask: DeviceBuffer | None = None, _alleles: list[str] | None = None, _defer_log: bool = False,
-                 _novel=None):
+                 _novel=None, _prepared: tuple | None = None):
+        """``_prepared`` = (rows with a surviving id, their count, shared drop flags, shared tallies, (gene, vbeg, vend)):
+        error correction and removal of empty reads already done for the whole sample (``Tabulation.prepared``)."""
         self.top_n = top_n
         self._no_empty = no_empty
         self.force_homo = force_homo
@@ -368,12 +370,17 @@ class AlleleTyping:
         n_span = len(variants) if _n_span is None else _n_span
         self._span = (_vbeg, _vbeg + n_span)
         self._tally = None
-        if variant_correction:
-            self._tally = tab.errorCorrection(rs.rows, rs.n_rows, rs.vflag, span=self._span, keep=True)
-        if no_empty:
-            rows, n_rows = tab.selectNonEmpty(rs.rows, rs.n_rows, rs.vflag)
-        else:   # reads without information stay and score 0.999 for every allele (372-374)
-            rows, n_rows = rs.rows, rs.n_rows
+        self._tally_gene = None       # (gene, vbeg, vend) when the tallies cover every gene of the sample
+        if _prepared is not None:
+            assert variant_correction and no_empty
+            rows, n_rows, _, self._tally, self._tally_gene = _prepared       # rs.vflag IS the shared, corrected one
+        else:
+            if variant_correction:
+                self._tally = tab.errorCorrection(rs.rows, rs.n_rows, rs.vflag, span=self._span, keep=True)
+            if no_empty:
+                rows, n_rows = tab.selectNonEmpty(rs.rows, rs.n_rows, rs.vflag)
+            else:   # reads without information stay and score 0.999 for every allele (372-374)
+                rows, n_rows = rs.rows, rs.n_rows
         self._readset = ReadSet(tab, rows, n_rows, rs.vflag)
         n_allele = len(names)
         words = max(1, (n_allele + 31) // 32)
@@ -769,7 +776,7 @@ class AlleleTyping:
         if cnt is None:   # no correction pass ran: tally now
             cnt = self._dev.alloc(2 * tab.n_var_total, np.uint32)
             tab.countVariants(rs.rows, rs.n_rows, rs.vflag, cnt, self._span)
-        out = tab.survivingCounts(cnt, rs.vflag)
+        out = tab.survivingCounts(cnt, rs.vflag, gene=self._tally_gene if cnt is self._tally else None)
         if cnt is not self._tally:
             cnt.free()
         return out

@@ -131,10 +131,13 @@ def test_bounded_search_equals_exact_search(device, small_case, monkeypatch):
     results = {}
     # exact = float64 sums for every candidate, python host (the round-1 path); the others must give its bits:
     # the integer bound, and the search loop run natively inside the library (gk_search_run), bounded or not
+    # ("exact" also keeps the per-gene error correction / empty-read removal; the others take them from the one
+    # pass over the whole sample, gk_sample_prepare)
     for mode, search, native in (("exact", "exact", "0"), ("bound", "bound", "0"), ("native", "bound", "1"),
                                  ("native_exact", "exact", "1")):
         monkeypatch.setenv("GK_SEARCH", search)
         monkeypatch.setenv("GK_NATIVE_SEARCH", native)
+        monkeypatch.setenv("GK_BATCH_PREAMBLE", "0" if mode == "exact" else "1")
         monkeypatch.setenv("GK_THREADS", "1")
         for method, top_n in (("full", 600), ("full", 7), ("exonfirst_1", 60)):
             typer = selectKirTypingModel(method, data, top_n=top_n, variant_correction=True)
