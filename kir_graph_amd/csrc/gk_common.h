@@ -127,6 +127,7 @@ struct gk_index {
   int32_t* d_gene_vbeg = nullptr;
   int32_t* d_bucket = nullptr;      // 16-bp position buckets into d_key, all genes back to back
   int32_t* d_gene_boff = nullptr;   // [n_gene + 1] first bucket of each gene
+  uint32_t* d_del_bits = nullptr;   // bit v = index variant v is a deletion ((n_var + 31) / 32 + 2 words, zero padded)
   int32_t n_var = 0, n_gene = 0;
   std::vector<int32_t> gene_vbeg;
 };

@@ -88,6 +88,7 @@ struct IndexView {
   // + code(read base)] = the base to use instead (0 = keep), codes A C G T N; null = no correction
   const uint8_t* corr;
   const int64_t* gene_pos0;   // [n_gene + 1]
+  const uint32_t* del_bits;   // bit v = index variant v is a deletion (two zero words of padding at the end)
 };
 
 // first ordinal whose key is >= k, where k = (ref, pos, ...)
@@ -319,6 +320,53 @@ __device__ inline uint32_t cooperative_negatives(WaveNeg& wv, const IndexView& i
   return wv.kept[lane];
 }
 
+// Pass 1's form of the negative filter, 32 candidates at a time: a mate's window [lo, lo + len) starts as all
+// ones; its own positives are cleared by ordinal (a handful of events), and only the DELETIONS of the window -- found
+// through the index's static deletion bitmap -- are looked at one by one for the right-edge rule.  Substitutions to N
+// (which exclude the four bases at their position) and windows beyond the saved 256 bits are rare and take the
+// candidate-by-candidate loop.  The kept bits land in `words` (LDS, kMaskWords per lane); returns the kept count.
+__device__ inline uint32_t window_negatives(const IndexView& ix, const uint32_t* evw, int n_ev, uint32_t any_n,
+                                            uint32_t right, uint32_t lo, uint32_t len, uint32_t* words) {
+#pragma unroll
+  for (int w = 0; w < kMaskWords; ++w) words[w] = 0;
+  if (len == 0) return 0;
+  if (any_n || len > 32u * kMaskWords) {
+    uint32_t kept = 0;
+    for (uint32_t c = 0; c < len; ++c) {
+      const uint32_t i = lo + c;
+      if (negative_kept(ix.key[i], (int)i, ix, evw, n_ev, any_n, right)) {
+        ++kept;
+        if (c < 32u * kMaskWords) words[c >> 5] |= 1u << (c & 31u);
+      }
+    }
+    return kept;
+  }
+  const uint32_t n_words = (len + 31u) >> 5;
+  for (uint32_t w = 0; w < n_words; ++w) {
+    const uint32_t left = len - 32u * w;
+    words[w] = left >= 32u ? ~0u : ((1u << left) - 1u);
+  }
+  for (int e = 0; e < n_ev; ++e) {                       // a positive of this mate is not a negative
+    const uint32_t word = evw[e] & ~kEvIsN;
+    const uint32_t rel = word - lo;                       // novel events carry bit 31: far outside any window
+    if (rel < len) words[rel >> 5] &= ~(1u << (rel & 31u));
+  }
+  for (uint32_t w = 0; w < n_words; ++w) {               // deletions reaching within 10 bases of the right edge
+    const uint32_t first = lo + 32u * w, sh = first & 31u;
+    const uint32_t a = ix.del_bits[first >> 5], b = ix.del_bits[(first >> 5) + 1];
+    uint32_t dels = (sh ? (a >> sh) | (b << (32u - sh)) : a) & words[w];
+    while (dels) {
+      const int bit = __ffs(dels) - 1;
+      dels &= dels - 1;
+      const uint64_t k = ix.key[first + (uint32_t)bit];
+      if (gk_key_pos(k) + gk_key_val(k) + 10u >= right) words[w] &= ~(1u << bit);
+    }
+  }
+  uint32_t kept = 0;
+  for (uint32_t w = 0; w < n_words; ++w) kept += (uint32_t)__popc(words[w]);
+  return kept;
+}
+
 // pass 1: validity, counts, novel registration.  One lane per mate; mates of a pair sit in
 // adjacent lanes so the pair verdict is one lane shuffle.
 __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int64_t n_mates, IndexView ix,
@@ -329,7 +377,7 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
                                                       uint32_t* mask_save /*[n_mates][kMaskWords]*/) {
   __shared__ uint32_t rec[kThreads * kRecLd];
   __shared__ uint32_t evs[kThreads * kEvLd];
-  __shared__ WaveNeg wneg[kThreads / 64];
+  __shared__ uint32_t wmask[kThreads * (kMaskWords + 1)];   // kept bits of the lane's window (odd stride)
   const int64_t m0 = (int64_t)blockIdx.x * kThreads;
   stage_mates(mates, m0, n_mates, rec);
   const int64_t m = m0 + threadIdx.x;
@@ -356,10 +404,10 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
       enumerate = true;
     }
   }
-  const int wid = threadIdx.x >> 6;
-  const uint32_t n_neg = cooperative_negatives<false>(wneg[wid], ix, evs + wid * 64 * kEvLd,
-                                                      enumerate ? (uint32_t)(wk.hi - wk.lo) : 0u, (uint32_t)wk.lo, wk.right,
-                                                      (uint32_t)wk.n, wk.any_n, 0u, nullptr);
+  uint32_t* const my_words = wmask + threadIdx.x * (kMaskWords + 1);
+  const uint32_t n_neg = enumerate ? window_negatives(ix, evw, wk.n, wk.any_n, wk.right, (uint32_t)wk.lo,
+                                                      (uint32_t)(wk.hi - wk.lo), my_words)
+                                   : 0u;
   if (!in) return;
   cnt[4 * pair + side] = n_pos;
   cnt[4 * pair + 2 + side] = n_neg;
@@ -370,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
     if (len > 32u * kMaskWords) atomicOr(err_flags, 4);   // does not fit the saved bits: the host takes the two-walk path
     lo_save[m] = (uint32_t)wk.lo;
     const uint32_t n_words = min((len + 31u) >> 5, (uint32_t)kMaskWords);
-    for (uint32_t w = 0; w < n_words; ++w) mask_save[m * kMaskWords + w] = wneg[wid].mask[threadIdx.x & 63][w];
+    for (uint32_t w = 0; w < n_words; ++w) mask_save[m * kMaskWords + w] = my_words[w];
   }
 }
 
@@ -509,6 +557,11 @@ int gk_index_create(gk_ctx* ctx, const uint64_t* key, int32_t n_var, const int32
   GK_HIP(hipMemcpyAsync(idx->d_gene_vbeg, gene_vbeg, (size_t)(n_gene + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   GK_HIP(hipMemcpyAsync(idx->d_bucket, bucket.data(), bucket.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   GK_HIP(hipMemcpyAsync(idx->d_gene_boff, boff.data(), boff.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  std::vector<uint32_t> del_bits((size_t)(n_var + 31) / 32 + 2, 0u);
+  for (int32_t v = 0; v < n_var; ++v)
+    if (gk_key_typ(key[v]) == GK_TYP_DEL) del_bits[(size_t)v >> 5] |= 1u << (v & 31);
+  GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_del_bits, del_bits.size() * sizeof(uint32_t)));
+  GK_HIP(hipMemcpyAsync(idx->d_del_bits, del_bits.data(), del_bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   GK_HIP(hipStreamSynchronize(ctx->stream));
   *out = idx;
   return GK_OK;
@@ -522,6 +575,7 @@ int gk_index_destroy(gk_index* idx) {
   gk_pool_free(ctx,idx->d_gene_vbeg);
   gk_pool_free(ctx,idx->d_bucket);
   gk_pool_free(ctx,idx->d_gene_boff);
+  gk_pool_free(ctx,idx->d_del_bits);
   delete idx;
   return GK_OK;
 }
@@ -567,7 +621,7 @@ int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t
   GK_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
 
   const IndexView ix{idx->d_key, idx->d_bucket, idx->d_gene_boff, idx->n_var, idx->n_gene,
-                     gk_ptr<uint8_t>(d_corr), gk_ptr<int64_t>(d_gene_pos0)};
+                     gk_ptr<uint8_t>(d_corr), gk_ptr<int64_t>(d_gene_pos0), idx->d_del_bits};
   if (n_mates) {
     GK_PROF(ctx, GK_K_TAB_COUNT, GK_KERNEL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
                        nt, cnt, valid, d_err, ev_save, lo_save, mask_save));
