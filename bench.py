@@ -481,7 +481,8 @@ def main():
                                    "(H2D inside the timed region)",
                        "pairs_per_sample": args.pairs, "pairs_passing_filter": int(n_valid),
                        "parallelism": f"samples sharded over {world} GPU(s), no data-path collective; "
-                                      f"{procs} worker process(es) per GPU, {os.environ.get('GK_THREADS', '6')} gene threads each"},
+                                      f"{procs} worker process(es) per GPU, {os.environ.get('GK_THREADS', '6')} gene threads each",
+                       "rank_barrier": (res["comm"].backend if res.get("comm") is not None else None)},
         }
         serial = res.get("serial")
         if serial:

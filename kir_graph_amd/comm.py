@@ -182,9 +182,11 @@ def worldFromEnv() -> tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))))
 
 
-def initFromEnv(dev=None, backend: str | None = None) -> Comm | None:
+def initFromEnv(dev=None, backend: str | None = None, fallback: bool = True) -> Comm | None:
     """The launch's communicator, or None for a single process.  ``backend`` None: ``GK_COMM_BACKEND``, else
-    rccl when every local rank has a GPU of its own, file otherwise."""
+    rccl when every local rank has a GPU of its own, file otherwise.  ``fallback``: when the RCCL communicator
+    cannot be set up on some rank (no librccl, no device, initialisation error) ALL ranks agree -- through the
+    rendezvous directory -- to carry the few control messages over the file backend instead, and say so."""
     rank, world, _ = worldFromEnv()
     if world <= 1:
         return None
@@ -193,7 +195,34 @@ def initFromEnv(dev=None, backend: str | None = None) -> Comm | None:
         from ._lib import deviceCount
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         backend = "rccl" if 0 < local_world <= deviceCount() else "file"
-    if backend == "rccl" and dev is None:
-        from .kir_typing import defaultDevice
-        dev = defaultDevice()
-    return Comm(rank, world, FileStore(rendezvousDir()), dev=dev, backend=backend)
+    store = FileStore(rendezvousDir())
+    if backend != "rccl":
+        return Comm(rank, world, store, dev=dev, backend=backend)
+    made, why = None, ""
+    try:
+        if dev is None:
+            from .kir_typing import defaultDevice
+            dev = defaultDevice()
+        made = Comm(rank, world, store, dev=dev, backend="rccl")
+    except Exception as e:            # noqa: BLE001 -- whatever went wrong, the ranks must agree on what to do next
+        if not fallback:
+            raise
+        why = f"{type(e).__name__}: {e}"
+    store.set(f"rccl_ok.r{rank}", b"1" if made is not None else b"0")
+    everyone = [store.get(f"rccl_ok.r{r}") == b"1" for r in range(world)]
+    if all(everyone):
+        return made
+    if not fallback:
+        raise CommError("RCCL communicator failed on ranks " + str([r for r, ok in enumerate(everyone) if not ok]))
+    import sys
+    print(f"[comm] rank {rank}: RCCL communicator unavailable ({why or 'another rank failed'}); "
+          "control messages go through the rendezvous directory", file=sys.stderr, flush=True)
+    if made is not None and made._handle is not None:
+        from ._lib import lib
+        lib().gk_comm_destroy(made._handle)
+        made._handle = None
+    other = Comm.__new__(Comm)
+    other.rank, other.world, other.store, other.backend = rank, world, store, "file"
+    other._seq, other._handle, other._dev = 0, None, dev     # no rank has used the store's rounds yet
+    other.barrier()
+    return other

@@ -44,6 +44,10 @@ WORKER = textwrap.dedent("""
             def close(self):
                 dist.destroy_process_group()
         transport = Transport()
+    elif os.environ["GK_TEST_TRANSPORT"] == "rccl_fallback":
+        # no GPU here: the RCCL communicator cannot be made on any rank, and all ranks agree on the file backend
+        transport = comm.initFromEnv(backend="rccl")
+        assert transport.backend == "file" and transport.world == 2
     else:
         transport = comm.initFromEnv(backend="file")
         assert transport.backend == "file" and transport.world == 2
@@ -128,3 +132,7 @@ def test_allgather_depths_world_size_2_file_backend(tmp_path):
 
 def test_allgather_depths_world_size_2_gloo(tmp_path):
     _run_two_ranks(tmp_path, "gloo")
+
+
+def test_rccl_failure_falls_back_to_the_file_backend_on_every_rank(tmp_path):
+    _run_two_ranks(tmp_path, "rccl_fallback")
