@@ -128,6 +128,12 @@ struct gk_index {
   int32_t* d_bucket = nullptr;      // 16-bp position buckets into d_key, all genes back to back
   int32_t* d_gene_boff = nullptr;   // [n_gene + 1] first bucket of each gene
   uint32_t* d_del_bits = nullptr;   // bit v = index variant v is a deletion ((n_var + 31) / 32 + 2 words, zero padded)
+  // per backbone position p (gene g: entries d_gene_pbase[g] .. d_gene_pbase[g + 1]): first ordinal whose key is
+  // >= (g, p, single, 'A') / (g, p, single, 'T') -- the two bounds of a variant window and the entry point of a
+  // substitution look-up, one read instead of bucket + bisection
+  int32_t* d_lb_a = nullptr;
+  int32_t* d_lb_t = nullptr;
+  int32_t* d_gene_pbase = nullptr;
   int32_t n_var = 0, n_gene = 0;
   std::vector<int32_t> gene_vbeg;
 };

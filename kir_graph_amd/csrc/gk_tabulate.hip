@@ -89,6 +89,9 @@ struct IndexView {
   const uint8_t* corr;
   const int64_t* gene_pos0;   // [n_gene + 1]
   const uint32_t* del_bits;   // bit v = index variant v is a deletion (two zero words of padding at the end)
+  const int32_t* lb_a;        // per position: first ordinal with key >= (gene, pos, single, 'A')
+  const int32_t* lb_t;        // ... >= (gene, pos, single, 'T')
+  const int32_t* gene_pbase;  // [n_gene + 1] first table entry of every gene
 };
 
 // first ordinal whose key is >= k, where k = (ref, pos, ...)
@@ -106,6 +109,26 @@ __device__ inline int lower_bound_key(const IndexView& ix, uint32_t ref, uint32_
   }
   return lo;
 }
+
+// first ordinal whose key is >= (ref, pos, single, 'A') ('T' with `t`): the bounds of a variant window
+// (getVariantsBoundary, hisat2.py:692-713), read from the per-position tables; positions past a gene's last variant
+// give the gene's end
+__device__ inline int lower_bound_single(const IndexView& ix, uint32_t ref, uint32_t pos, bool t) {
+  if ((int)ref >= ix.n_gene)
+    return lower_bound_key(ix, ref, pos, gk_make_key(ref, pos, GK_TYP_SINGLE, t ? 'T' : 'A'));
+  const int base = ix.gene_pbase[ref], n_pos = ix.gene_pbase[ref + 1] - base;
+  const int p = min((int)pos, n_pos - 1);      // the last entry of a gene is its end ordinal for both tables
+  return (t ? ix.lb_t : ix.lb_a)[base + p];
+}
+
+// lower bound of a substitution key: the table entry of its position, then at most a few steps over the
+// substitutions listed there (they share a cache line)
+__device__ inline int lower_bound_snp(const IndexView& ix, uint32_t ref, uint32_t pos, uint64_t k) {
+  int i = lower_bound_single(ix, ref, pos, false);
+  while (i < ix.n_var && ix.key[i] < k) ++i;
+  return i;
+}
+
 
 __device__ inline uint32_t hash64(uint64_t k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
@@ -187,7 +210,7 @@ __device__ inline void walk_mate(const MateView& r, const IndexView& ix, const N
       }
     }
     const uint64_t k = gk_make_key(ref, pos, typ, val);
-    const int i = lower_bound_key(ix, ref, pos, k);
+    const int i = typ == GK_TYP_SINGLE ? lower_bound_snp(ix, ref, pos, k) : lower_bound_key(ix, ref, pos, k);
     const bool known = i < ix.n_var && ix.key[i] == k;
     const bool is_n = typ == GK_TYP_SINGLE && val == 'N';
     if (is_n) wk.any_n = 1;
@@ -230,8 +253,8 @@ __device__ inline void walk_mate(const MateView& r, const IndexView& ix, const N
   // index records carry length 0, novel ones their walker length
   wk.right = (last_is_event && wk.n > 0) ? last_pos + (last_novel ? last_len : 0u) : cur;
   // getVariantsBoundary: [single 'A' at the left edge, single 'T' at the right edge)
-  wk.lo = lower_bound_key(ix, ref, pos0, gk_make_key(ref, pos0, GK_TYP_SINGLE, 'A'));
-  wk.hi = lower_bound_key(ix, ref, wk.right, gk_make_key(ref, wk.right, GK_TYP_SINGLE, 'T'));
+  wk.lo = lower_bound_single(ix, ref, pos0, false);
+  wk.hi = lower_bound_single(ix, ref, wk.right, true);
   wk.bad_window = wk.lo > wk.hi;
 }
 
@@ -557,6 +580,29 @@ int gk_index_create(gk_ctx* ctx, const uint64_t* key, int32_t n_var, const int32
   GK_HIP(hipMemcpyAsync(idx->d_gene_vbeg, gene_vbeg, (size_t)(n_gene + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   GK_HIP(hipMemcpyAsync(idx->d_bucket, bucket.data(), bucket.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   GK_HIP(hipMemcpyAsync(idx->d_gene_boff, boff.data(), boff.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  // per-position bounds: gene g has (last variant position + 2) entries, the last one = the gene's end ordinal
+  std::vector<int32_t> pbase((size_t)n_gene + 1, 0), lb_a, lb_t;
+  for (int g = 0; g < n_gene; ++g) {
+    const int32_t v0 = gene_vbeg[g], v1 = gene_vbeg[g + 1];
+    const uint32_t n_pos = v1 > v0 ? gk_key_pos(key[v1 - 1]) + 2u : 1u;
+    pbase[g + 1] = pbase[g] + (int32_t)n_pos;
+    int32_t ia = v0, it = v0;
+    for (uint32_t p = 0; p + 1 < n_pos; ++p) {
+      const uint64_t ka = gk_make_key((uint32_t)g, p, GK_TYP_SINGLE, 'A'), kt = gk_make_key((uint32_t)g, p, GK_TYP_SINGLE, 'T');
+      while (ia < v1 && key[ia] < ka) ++ia;
+      while (it < v1 && key[it] < kt) ++it;
+      lb_a.push_back(ia);
+      lb_t.push_back(it);
+    }
+    lb_a.push_back(v1);
+    lb_t.push_back(v1);
+  }
+  GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_lb_a, lb_a.size() * sizeof(int32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_lb_t, lb_t.size() * sizeof(int32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_gene_pbase, pbase.size() * sizeof(int32_t)));
+  GK_HIP(hipMemcpyAsync(idx->d_lb_a, lb_a.data(), lb_a.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  GK_HIP(hipMemcpyAsync(idx->d_lb_t, lb_t.data(), lb_t.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  GK_HIP(hipMemcpyAsync(idx->d_gene_pbase, pbase.data(), pbase.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   std::vector<uint32_t> del_bits((size_t)(n_var + 31) / 32 + 2, 0u);
   for (int32_t v = 0; v < n_var; ++v)
     if (gk_key_typ(key[v]) == GK_TYP_DEL) del_bits[(size_t)v >> 5] |= 1u << (v & 31);
@@ -576,6 +622,9 @@ int gk_index_destroy(gk_index* idx) {
   gk_pool_free(ctx,idx->d_bucket);
   gk_pool_free(ctx,idx->d_gene_boff);
   gk_pool_free(ctx,idx->d_del_bits);
+  gk_pool_free(ctx,idx->d_lb_a);
+  gk_pool_free(ctx,idx->d_lb_t);
+  gk_pool_free(ctx,idx->d_gene_pbase);
   delete idx;
   return GK_OK;
 }
@@ -621,7 +670,8 @@ int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t
   GK_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
 
   const IndexView ix{idx->d_key, idx->d_bucket, idx->d_gene_boff, idx->n_var, idx->n_gene,
-                     gk_ptr<uint8_t>(d_corr), gk_ptr<int64_t>(d_gene_pos0), idx->d_del_bits};
+                     gk_ptr<uint8_t>(d_corr), gk_ptr<int64_t>(d_gene_pos0), idx->d_del_bits, idx->d_lb_a, idx->d_lb_t,
+                     idx->d_gene_pbase};
   if (n_mates) {
     GK_PROF(ctx, GK_K_TAB_COUNT, GK_KERNEL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
                        nt, cnt, valid, d_err, ev_save, lo_save, mask_save));
