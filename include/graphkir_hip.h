@@ -293,6 +293,9 @@ int gk_packer_feed(gk_packer* pk, const char* text, size_t n_bytes, int32_t fina
 int gk_packer_counts(gk_packer* pk, int64_t* n_lines, int64_t* n_reads, int64_t* n_pairs, int64_t* n_strange,
                      int64_t* n_strings);
 int gk_packer_error(gk_packer* pk, int32_t* kind, int64_t* line_index);
+/* records are written straight into mates_out (capacity in records, 2 per pair) instead of the packer's own
+ * storage -- e.g. gk_host_alloc memory, so the upload starts from where the decoder wrote; before the first feed */
+int gk_packer_set_output(gk_packer* pk, gk_mate* mates_out, int64_t capacity);
 int gk_packer_records(gk_packer* pk, gk_mate* mates_out, int64_t* pair_lines_out);
 const char* gk_packer_string(gk_packer* pk, int64_t i);
 

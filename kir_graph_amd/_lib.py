@@ -128,6 +128,7 @@ _SIGS = {
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gk_packer_error": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "gk_packer_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gk_packer_set_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "gk_packer_string": (C.c_char_p, [C.c_void_p, C.c_int64]),
     "gk_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "gk_depth_write_tsv": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -14,11 +14,13 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -31,15 +33,8 @@
 
 void gk_set_error(const char* fmt, ...);
 
-// byte buffer whose resize() leaves new bytes uninitialised: the inflated stream is hundreds of megabytes
-// that the inflating threads are about to overwrite (and first-touch in parallel)
-template <typename T>
-struct RawInit : std::allocator<T> {
-  template <typename U> struct rebind { using other = RawInit<U>; };
-  template <typename U> void construct(U* p) noexcept { ::new ((void*)p) U; }
-  template <typename U, typename... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
-};
-using Bytes = std::vector<uint8_t, RawInit<uint8_t>>;
+// the inflated stream is hundreds of megabytes that the inflating threads are about to overwrite
+using Bytes = std::vector<uint8_t, GkRawInit<uint8_t>>;
 
 struct gk_bam {
   Bytes data;                           // inflated BAM stream
@@ -228,7 +223,7 @@ int name_order(const char* a0, const char* b0) {
 // are compared then), unless both are whole -- then the names are equal.
 constexpr int kNameKey = 16;
 struct SortRec {
-  uint8_t key[kNameKey];
+  uint64_t k0, k1;   // the key bytes as two big-endian numbers: their order is the bytes' order
   uint64_t off;
   uint32_t size;
   uint8_t kept;      // key bytes that are meaningful
@@ -238,9 +233,10 @@ struct SortRec {
 
 void name_key(const char* name, SortRec& r) {
   const unsigned char* p = (const unsigned char*)name;
+  uint8_t key[kNameKey];
   int n = 0;
   bool room = true;
-  auto put = [&](unsigned v) { if (n < kNameKey) r.key[n++] = (uint8_t)v; else room = false; };
+  auto put = [&](unsigned v) { if (n < kNameKey) key[n++] = (uint8_t)v; else room = false; };
   while (*p && room) {
     if (isdigit(*p)) {
       const unsigned char* z = p;
@@ -259,7 +255,12 @@ void name_key(const char* name, SortRec& r) {
   if (room) put(0);
   r.kept = (uint8_t)n;
   r.whole = room ? 1 : 0;
-  for (int i = n; i < kNameKey; ++i) r.key[i] = 0;
+  for (int i = n; i < kNameKey; ++i) key[i] = 0;
+  uint64_t a, b;
+  memcpy(&a, key, 8);
+  memcpy(&b, key + 8, 8);
+  r.k0 = __builtin_bswap64(a);
+  r.k1 = __builtin_bswap64(b);
 }
 
 void append_int(std::string& s, long long v) {
@@ -458,106 +459,216 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
     b->ref_names.emplace_back((const char*)d.data() + o, strnlen((const char*)d.data() + o, l_name));
     o += l_name + 4;   // name, l_ref
   }
-  b->recs.reserve(d.size() / 200);
-  while (o + 4 <= d.size()) {
-    // the walk is a pointer chase (the next record starts where this one says); the records lie back to
-    // back, so the lines a few records ahead can be requested now
-    __builtin_prefetch(d.data() + o + 768);
-    __builtin_prefetch(d.data() + o + 1536);
-    const uint32_t size = rd32(d.data() + o);
-    o += 4;
-    if (size < 32 || o + size > d.size()) return bad("alignment block");
-    {
-      // every walker below (text rendering, binary packing, pileup, name collation) trusts these fields: the
-      // variable-length parts must lie inside the block and the query name must end in NUL inside its field
-      const uint8_t* r = d.data() + o;
-      const uint64_t l_name = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
-      const uint64_t need = 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq;
-      if (l_name < 1 || need > size || r[32 + l_name - 1] != 0) return bad("alignment block");
+  // Record index.  A record starts where the one before it ends, so the walk over the stream is a pointer chase;
+  // it is cut into segments that are chased at once.  Inside a segment the start of the first record is not
+  // known: a thread picks the first offset that looks like a record and whose chain of block sizes stays valid,
+  // and chases from there.  Its chain is only taken over once the true chain -- chased record by record from the
+  // previous segment's end -- lands on one of its offsets: from that offset on the two chains are the same chain.
+  // A guess that never meets the true chain costs time (that segment is chased serially), never correctness.
+  const size_t n_bytes = d.size();
+  const uint8_t* const base0 = d.data();
+  const int64_t n_ref_i = (int64_t)n_ref;
+  auto valid_at = [&](size_t s, uint32_t& size) {   // s: offset of a block_size field
+    if (s + 4 > n_bytes) return false;
+    size = rd32(base0 + s);
+    if (size < 32 || s + 4 + (size_t)size > n_bytes) return false;
+    // every walker below (text rendering, binary packing, pileup, name collation) trusts these fields: the
+    // variable-length parts must lie inside the block and the query name must end in NUL inside its field
+    const uint8_t* r = base0 + s + 4;
+    const uint64_t l_name = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
+    const uint64_t need = 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq;
+    return l_name >= 1 && need <= size && r[32 + l_name - 1] == 0;
+  };
+  auto plausible = [&](size_t s) {                  // stricter: only used to pick where a guessed chain starts
+    uint32_t size;
+    if (!valid_at(s, size) || size > (1u << 24)) return false;
+    const uint8_t* r = base0 + s + 4;
+    const int64_t ref_id = rds32(r), pos = rds32(r + 4), next_ref = rds32(r + 20), next_pos = rds32(r + 24);
+    if (ref_id < -1 || ref_id >= n_ref_i || next_ref < -1 || next_ref >= n_ref_i || pos < -1 || next_pos < -1) return false;
+    const uint32_t l_name = r[8];
+    for (uint32_t i = 0; i + 1 < l_name; ++i)
+      if (r[32 + i] < '!' || r[32 + i] > '~') return false;
+    return true;
+  };
+  struct Segment {
+    size_t lo = 0, hi = 0;
+    std::vector<gk_bam::Rec> chain;   // records chased from the guessed start, in order
+    size_t chain_end = 0;             // offset after the last of them (where the chain stopped or left the segment)
+    std::vector<gk_bam::Rec> serial;  // records of the true chain before it met the guessed one (usually none)
+    size_t take_from = 0, take_n = 0; // the part of `chain` from where the two met
+    size_t out_at = 0;
+  };
+  const size_t span = n_bytes - o;
+  size_t n_seg = std::min<size_t>((size_t)ingest_threads() * 4, std::max<size_t>(span >> 20, 1));
+  if (getenv("GK_BAM_INDEX_SEGMENTS")) n_seg = std::max<size_t>(1, (size_t)atol(getenv("GK_BAM_INDEX_SEGMENTS")));   // tests: many small segments
+  std::vector<Segment> seg(n_seg);
+  for (size_t t = 0; t < n_seg; ++t) { seg[t].lo = o + span * t / n_seg; seg[t].hi = o + span * (t + 1) / n_seg; }
+  auto chase = [&](Segment& sg, bool known_start) {
+    size_t c = sg.lo;
+    const size_t give_up = std::min(sg.hi, sg.lo + ((size_t)1 << 20));
+    while (c < give_up) {
+      if (!known_start && !plausible(c)) { ++c; continue; }
+      sg.chain.clear();
+      size_t s = c;
+      bool broke = false;
+      while (s < sg.hi) {
+        __builtin_prefetch(base0 + s + 768);
+        __builtin_prefetch(base0 + s + 1536);
+        uint32_t size;
+        if (!valid_at(s, size)) { broke = true; break; }
+        sg.chain.push_back({(uint64_t)s + 4, size});
+        s += 4 + (size_t)size;
+      }
+      sg.chain_end = s;
+      // a chain that breaks early was a wrong guess (or a damaged file: the true chain will say so); one that
+      // runs for a while is kept even if it breaks later, the merge takes it no further than the break
+      if (known_start || !broke || sg.chain.size() >= 64) return;
+      ++c;
     }
-    b->recs.push_back({(uint64_t)o, size});
-    o += size;
+    sg.chain.clear();
+    sg.chain_end = sg.lo;
+  };
+  {
+    std::atomic<size_t> next_seg{0};
+    auto run = [&] {
+      for (size_t t; (t = next_seg.fetch_add(1)) < n_seg;) {
+        seg[t].chain.reserve((seg[t].hi - seg[t].lo) / 256 + 16);
+        chase(seg[t], t == 0);
+      }
+    };
+    const int n_thr = (int)std::min<size_t>((size_t)ingest_threads(), n_seg);
+    if (n_thr <= 1) {
+      run();
+    } else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < n_thr; ++t) pool.emplace_back(run);
+      for (auto& th : pool) th.join();
+    }
+  }
+  size_t n_rec = 0;
+  for (size_t t = 0; t < n_seg; ++t) {   // the true chain, segment by segment
+    Segment& sg = seg[t];
+    auto it = sg.chain.begin();
+    while (o < sg.hi && o + 4 <= n_bytes) {
+      it = std::lower_bound(it, sg.chain.end(), (uint64_t)o + 4, [](const gk_bam::Rec& r, uint64_t v) { return r.off < v; });
+      if (it != sg.chain.end() && it->off == (uint64_t)o + 4) {   // met: the rest of the guessed chain is the true one
+        sg.take_from = (size_t)(it - sg.chain.begin());
+        sg.take_n = sg.chain.size() - sg.take_from;
+        o = sg.chain_end;
+        if (o < sg.hi) return bad("alignment block");             // the chain stopped inside the segment: at a bad record
+        break;
+      }
+      uint32_t size;
+      if (!valid_at(o, size)) return bad("alignment block");
+      sg.serial.push_back({(uint64_t)o + 4, size});               // not met yet: one record of the true chain at a time
+      o += 4 + (size_t)size;
+    }
+    sg.out_at = n_rec;
+    n_rec += sg.serial.size() + sg.take_n;
+  }
+  b->recs.resize(n_rec);
+  {
+    std::atomic<size_t> next_seg{0};
+    auto run = [&] {
+      for (size_t t; (t = next_seg.fetch_add(1)) < n_seg;) {
+        const Segment& sg = seg[t];
+        std::copy(sg.serial.begin(), sg.serial.end(), b->recs.begin() + (ptrdiff_t)sg.out_at);
+        std::copy(sg.chain.begin() + (ptrdiff_t)sg.take_from, sg.chain.begin() + (ptrdiff_t)(sg.take_from + sg.take_n),
+                  b->recs.begin() + (ptrdiff_t)(sg.out_at + sg.serial.size()));
+      }
+    };
+    const int n_thr = (int)std::min<size_t>((size_t)ingest_threads(), n_seg);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_thr; ++t) pool.emplace_back(run);
+    run();
+    for (auto& th : pool) th.join();
   }
   if (o != d.size()) return bad("trailing bytes");
   b->name_sorted = name_sorted != 0;
   clock.lap("index");
   if (name_sorted) {
     const uint8_t* base = d.data();
+    // A strict total order (name, then READ1 before READ2, then the place in the file), so that any sort gives the
+    // order a stable sort by name and mate gives.  The keys usually decide without touching the records.
     auto before = [base](const SortRec& x, const SortRec& y) {
-      const int c = memcmp(x.key, y.key, std::min(x.kept, y.kept));   // the keys usually decide without touching the records
-      if (c) return c < 0;
-      if (!(x.whole && y.whole)) {
+      if (x.whole & y.whole) {          // unused key bytes are zero and no name byte is: whole keys compare as they are
+        if (x.k0 != y.k0) return x.k0 < y.k0;
+        if (x.k1 != y.k1) return x.k1 < y.k1;
+      } else {                          // the first min(kept) bytes only
+        const unsigned m = std::min(x.kept, y.kept);
+        const unsigned s0 = m >= 8 ? 0 : 8 * (8 - m), s1 = m >= 16 ? 0 : 8 * (16 - m);
+        const uint64_t a0 = m ? x.k0 >> s0 : 0, b0 = m ? y.k0 >> s0 : 0;
+        if (a0 != b0) return a0 < b0;
+        const uint64_t a1 = m > 8 ? x.k1 >> s1 : 0, b1 = m > 8 ? y.k1 >> s1 : 0;
+        if (a1 != b1) return a1 < b1;
         const int t = name_order((const char*)base + x.off + 32, (const char*)base + y.off + 32);
         if (t) return t < 0;
       }
-      return x.mate < y.mate;   // READ1 (0x40) before READ2 (0x80)
+      if (x.mate != y.mate) return x.mate < y.mate;   // READ1 (0x40) before READ2 (0x80)
+      return x.off < y.off;
     };
-    // stable merge sort over the ingest threads: keyed records, sorted runs, then one parallel multiway merge
+    // Sample sort over the ingest threads: keyed records, splitters from a sample, one scatter into buckets whose
+    // key ranges follow one another, then every bucket sorted on its own (a bucket fits a core's cache).
     const size_t n = b->recs.size();
-    std::vector<SortRec> recs(n);
-    int runs = 1;
-    while (runs * 2 <= ingest_threads() && (size_t)runs * 2 * 4096 <= n) runs *= 2;
-    auto bound = [&](int i) { return n * (size_t)i / (size_t)runs; };
-    {
+    std::vector<SortRec, GkRawInit<SortRec>> recs(n), sorted(n);
+    const int n_thr = (int)std::max<size_t>(1, std::min<size_t>((size_t)ingest_threads(), n / 4096));
+    auto part = [&](int t) { return n * (size_t)t / (size_t)n_thr; };
+    auto on_all = [&](const std::function<void(int)>& work) {
+      if (n_thr == 1) { work(0); return; }
       std::vector<std::thread> pool;
-      for (int i = 0; i < runs; ++i)
-        pool.emplace_back([&, i] {
-          for (size_t k = bound(i); k < bound(i + 1); ++k) {
-            SortRec& r = recs[k];
-            r.off = b->recs[k].off;
-            r.size = b->recs[k].size;
-            r.mate = (uint8_t)(rd16(base + r.off + 14) & 0xC0u);
-            name_key((const char*)base + r.off + 32, r);
-          }
-          std::stable_sort(recs.begin() + bound(i), recs.begin() + bound(i + 1), before);
-        });
+      for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+      work(0);
       for (auto& th : pool) th.join();
-    }
-    if (runs > 1) {
-      // Parallel stable multiway merge.  Splitters cut every run at lower_bound, so records equivalent to
-      // a splitter land in the same part whatever run they come from; inside a part the runs are merged
-      // in run order with std::merge (left range first on ties): the concatenated parts are the stable order.
+    };
+    on_all([&](int t) {
+      for (size_t k = part(t); k < part(t + 1); ++k) {
+        SortRec& r = recs[k];
+        r.off = b->recs[k].off;
+        r.size = b->recs[k].size;
+        r.mate = (uint8_t)(rd16(base + r.off + 14) & 0xC0u);
+        name_key((const char*)base + r.off + 32, r);
+      }
+    });
+    const size_t n_bucket = n < 16384 ? 1 : std::min<size_t>(256, std::max<size_t>(4, n / 16384));
+    if (n_bucket == 1) {
+      std::sort(recs.begin(), recs.end(), before);
+      sorted.swap(recs);
+    } else {
       std::vector<SortRec> sample;
-      for (int r = 0; r < runs; ++r)
-        for (int k = 1; k < runs; ++k) sample.push_back(recs[bound(r) + (bound(r + 1) - bound(r)) * (size_t)k / (size_t)runs]);
+      const size_t n_sample = n_bucket * 32;
+      for (size_t i = 0; i < n_sample; ++i) sample.push_back(recs[(n - 1) * i / (n_sample - 1)]);
       std::sort(sample.begin(), sample.end(), before);
-      std::vector<std::vector<size_t>> cut((size_t)runs, std::vector<size_t>((size_t)runs + 1));
-      for (int r = 0; r < runs; ++r) {
-        cut[(size_t)r][0] = bound(r);
-        cut[(size_t)r][(size_t)runs] = bound(r + 1);
-        for (int k = 1; k < runs; ++k)
-          cut[(size_t)r][(size_t)k] = (size_t)(std::lower_bound(recs.begin() + bound(r), recs.begin() + bound(r + 1),
-                                                                sample[(size_t)k * sample.size() / (size_t)runs], before) - recs.begin());
+      std::vector<SortRec> splitter;     // bucket q holds the records x with splitter[q-1] <= x < splitter[q]
+      for (size_t q = 1; q < n_bucket; ++q) splitter.push_back(sample[q * n_sample / n_bucket]);
+      std::vector<uint8_t> bucket_of(n);
+      std::vector<std::vector<size_t>> count((size_t)n_thr, std::vector<size_t>(n_bucket, 0));
+      on_all([&](int t) {
+        std::vector<size_t>& c = count[(size_t)t];
+        for (size_t k = part(t); k < part(t + 1); ++k) {
+          const size_t q = (size_t)(std::upper_bound(splitter.begin(), splitter.end(), recs[k], before) - splitter.begin());
+          bucket_of[k] = (uint8_t)q;
+          ++c[q];
+        }
+      });
+      std::vector<size_t> bucket_at(n_bucket + 1, 0);
+      for (size_t q = 0; q < n_bucket; ++q) {
+        size_t at = bucket_at[q];
+        for (int t = 0; t < n_thr; ++t) { const size_t c = count[(size_t)t][q]; count[(size_t)t][q] = at; at += c; }
+        bucket_at[q + 1] = at;
       }
-      std::vector<SortRec> merged(n);
-      std::vector<size_t> part_off((size_t)runs + 1, 0);
-      for (int k = 0; k < runs; ++k) {
-        size_t len = 0;
-        for (int r = 0; r < runs; ++r) len += cut[(size_t)r][(size_t)k + 1] - cut[(size_t)r][(size_t)k];
-        part_off[(size_t)k + 1] = part_off[(size_t)k] + len;
-      }
-      std::vector<std::thread> pool;
-      for (int k = 0; k < runs; ++k)
-        pool.emplace_back([&, k] {
-          std::vector<std::vector<SortRec>> level;
-          for (int r = 0; r < runs; ++r)
-            level.emplace_back(recs.begin() + cut[(size_t)r][(size_t)k], recs.begin() + cut[(size_t)r][(size_t)k + 1]);
-          while (level.size() > 1) {
-            std::vector<std::vector<SortRec>> next;
-            for (size_t i = 0; i < level.size(); i += 2) {
-              if (i + 1 == level.size()) { next.push_back(std::move(level[i])); break; }
-              std::vector<SortRec> both(level[i].size() + level[i + 1].size());
-              std::merge(level[i].begin(), level[i].end(), level[i + 1].begin(), level[i + 1].end(), both.begin(), before);
-              next.push_back(std::move(both));
-            }
-            level = std::move(next);
-          }
-          std::copy(level[0].begin(), level[0].end(), merged.begin() + part_off[(size_t)k]);
-        });
-      for (auto& th : pool) th.join();
-      recs.swap(merged);
+      on_all([&](int t) {
+        std::vector<size_t>& at = count[(size_t)t];
+        for (size_t k = part(t); k < part(t + 1); ++k) sorted[at[bucket_of[k]]++] = recs[k];
+      });
+      std::atomic<size_t> next_bucket{0};
+      on_all([&](int) {
+        for (size_t q; (q = next_bucket.fetch_add(1)) < n_bucket;)
+          std::sort(sorted.begin() + (ptrdiff_t)bucket_at[q], sorted.begin() + (ptrdiff_t)bucket_at[q + 1], before);
+      });
     }
-    for (size_t k = 0; k < n; ++k) b->recs[k] = {recs[k].off, recs[k].size};
+    on_all([&](int t) {
+      for (size_t k = part(t); k < part(t + 1); ++k) b->recs[k] = {sorted[k].off, sorted[k].size};
+    });
   }
   clock.lap("name sort");
   *out = b;
@@ -583,30 +694,48 @@ int gk_bam_pack(gk_bam* b, gk_packer* pk) {
     k.next_pos = (long)rds32(p + 24) + 1;
     k.mate_same_ref = next_ref >= 0 && next_ref == ref_id;
   };
+  std::vector<int> gene_of_ref(b->ref_names.size());   // reference id of the file -> backbone ordinal of the index
+  for (size_t i = 0; i < gene_of_ref.size(); ++i) gene_of_ref[i] = gk_packer_gene_of(pk, b->ref_names[i]);
+  auto soon = [&](int64_t i, bool head_only) {   // in name order the records are scattered over the inflated stream
+    const gk_bam::Rec& rec = b->recs[(size_t)i];
+    const uint8_t* p = base + rec.off;
+    for (uint32_t o = 0; o < (head_only ? 128u : rec.size); o += 64) __builtin_prefetch(p + o);
+  };
   auto full = [&](int64_t i, GkAlnRecord& r) {
     const gk_bam::Rec& rec = b->recs[(size_t)i];
     const uint8_t* p = base + rec.off;
     const uint32_t l_name = p[8], n_cig = rd16(p + 12), l_seq = rd32(p + 16);
-    r.ref = ref_name(rds32(p));
+    const int32_t ref_id = rds32(p);
+    r.ref = ref_name(ref_id);
+    r.gene = (ref_id >= 0 && (size_t)ref_id < gene_of_ref.size()) ? gene_of_ref[(size_t)ref_id] : gk_packer_gene_of(pk, r.ref);
     r.flag = rd16(p + 14);
     r.pos = (long)rds32(p + 4) + 1;
     const uint8_t* cig = p + 32 + l_name;
     const uint8_t* seq = cig + 4ull * n_cig;
     const uint8_t* tags = seq + (l_seq + 1) / 2 + l_seq;
     const uint8_t* end = p + rec.size;
-    r.cigar_text.clear();
-    if (n_cig == 0) r.cigar_text.push_back('*');
-    for (uint32_t c = 0; c < n_cig; ++c) {
-      const uint32_t v = rd32(cig + 4ull * c);
-      append_int(r.cigar_text, v >> 4);
-      r.cigar_text.push_back((v & 15u) < 9 ? "MIDNSHP=X"[v & 15u] : '?');
+    bool plain = n_cig >= 1 && l_seq >= 1;   // every op one of M I D N S: CIGAR and SEQ go over as they are
+    for (uint32_t c = 0; c < n_cig && plain; ++c) plain = (cig[4ull * c] & 15u) <= 4u;
+    if (plain) {
+      r.bam_cigar = cig; r.n_bam_cigar = n_cig;
+      r.bam_seq = seq; r.l_bam_seq = l_seq;
+      r.cigar = r.seq = std::string_view();
+    } else {                                 // the rare rest as the text a SAM line would hold
+      r.bam_cigar = r.bam_seq = nullptr;
+      r.cigar_text.clear();
+      if (n_cig == 0) r.cigar_text.push_back('*');
+      for (uint32_t c = 0; c < n_cig; ++c) {
+        const uint32_t v = rd32(cig + 4ull * c);
+        append_int(r.cigar_text, v >> 4);
+        r.cigar_text.push_back((v & 15u) < 9 ? "MIDNSHP=X"[v & 15u] : '?');
+      }
+      static const char kBase[] = "=ACMGRSVTWYHKDBN";
+      r.seq_text.resize(l_seq ? l_seq : 1);
+      if (!l_seq) r.seq_text[0] = '*';
+      for (uint32_t q = 0; q < l_seq; ++q) r.seq_text[q] = kBase[(seq[q >> 1] >> ((~q & 1u) << 2)) & 15u];
+      r.cigar = r.cigar_text;
+      r.seq = r.seq_text;
     }
-    static const char kBase[] = "=ACMGRSVTWYHKDBN";
-    r.seq_text.resize(l_seq ? l_seq : 1);
-    if (!l_seq) r.seq_text[0] = '*';
-    for (uint32_t q = 0; q < l_seq; ++q) r.seq_text[q] = kBase[(seq[q >> 1] >> ((~q & 1u) << 2)) & 15u];
-    r.cigar = r.cigar_text;
-    r.seq = r.seq_text;
     r.has_nm = r.has_md = r.has_zs = false;
     r.nh = 1;
     bool has_nh = false;
@@ -650,7 +779,8 @@ int gk_bam_pack(gk_bam* b, gk_packer* pk) {
       tags = v + used;
     }
   };
-  return gk_packer_feed_records(pk, (int64_t)b->recs.size(), b->name_sorted, key, full);
+  if (b->name_sorted) return gk_packer_feed_records(pk, (int64_t)b->recs.size(), true, key, full, soon);
+  return gk_packer_feed_records(pk, (int64_t)b->recs.size(), false, key, full);
 }
 
 int gk_bam_close(gk_bam* b) {

@@ -60,7 +60,20 @@ struct gk_packer {
   std::vector<std::string> ins_strings;
   uint32_t n_index_ins = 0;
   std::unordered_map<std::string, Pending> waiting;
-  std::vector<gk_mate> mates;
+  std::vector<gk_mate, GkRawInit<gk_mate>> own;   // the records, unless the caller gave a place for them
+  gk_mate* ext = nullptr;            // caller's buffer (gk_packer_set_output) of ext_cap records
+  int64_t ext_cap = 0;
+  size_t n_mates = 0;                // records made so far (2 per pair)
+  gk_mate* mates() { return ext ? ext : own.data(); }
+  bool resize_mates(size_t n) {      // new records are NOT initialised: the decoder writes every byte of them
+    if (ext) {
+      if ((int64_t)n > ext_cap) return false;
+    } else {
+      own.resize(n);
+    }
+    n_mates = n;
+    return true;
+  }
   std::vector<int64_t> pair_lines;   // 2 per pair: line index of left (later) and right (earlier) record
   struct Job { sv left, right; std::string right_owned; int64_t left_idx, right_idx; };
   std::vector<Job> jobs;             // pairs emitted by the pairing pass of the current chunk
@@ -109,18 +122,101 @@ bool to_long(sv s, long& v) {   // Python int(): optional sign, digits, surround
 
 struct Fail { int kind; std::string msg; };
 
+// What a walk leaves behind: the M / I / D ops, the MD mismatches and the inserted strings.  The first
+// GK_MAX_CIG ops and GK_MAX_MM mismatches are kept (what a record can hold); the counts run on so that the
+// capacity verdict comes after the walk's own checks, like a walk into growing lists.
 struct Walked {
-  std::vector<std::pair<int, long>> ops;        // (GK_CIG_*, length)
-  std::vector<std::pair<long, int>> mms;        // (ref offset, read base)
+  uint16_t cig[GK_MAX_CIG];                     // len << 4 | GK_CIG_*
+  gk_mm mm[GK_MAX_MM];
+  size_t n_ops = 0, n_mm = 0, n_indel = 0;      // ops walked (S excluded), mismatches, I + D ops
+  bool long_op = false, far_mm = false;         // an op longer than 4095 / a mismatch beyond reference offset 65535
   std::vector<std::string> ins;                 // inserted strings in I-op order (interned at merge time)
   bool clipped = false;
+  void reset() { n_ops = n_mm = n_indel = 0; long_op = far_mm = clipped = false; ins.clear(); }
+  void op(int kind, long n) {
+    if (n_ops < GK_MAX_CIG) cig[n_ops] = (uint16_t)(((unsigned long)n << 4) | (unsigned)kind);
+    long_op = long_op || n > 4095;
+    ++n_ops;
+  }
+  void mismatch(long ref_off, unsigned char base) {
+    if (n_mm < GK_MAX_MM) { mm[n_mm].ref_off = (uint16_t)ref_off; mm[n_mm].base = base; }
+    far_mm = far_mm || ref_off > 0xFFFF;
+    ++n_mm;
+  }
 };
 
 bool is_acgt(const MdTok& t) { return t.kind == 1 && (t.ch == 'A' || t.ch == 'C' || t.ch == 'G' || t.ch == 'T'); }
 
+// CIGAR and SEQ of a SAM line.  The ops are what re.findall(r"(\d+)(\w)") yields: digit runs followed by one
+// word character; anything else is skipped.
+struct TextSource {
+  sv seq;
+  std::vector<std::pair<char, long>>& ops;
+  TextSource(sv cigar, sv seq_, std::vector<std::pair<char, long>>& scratch) : seq(seq_), ops(scratch) {
+    ops.clear();
+    for (size_t i = 0; i < cigar.size();) {
+      if (!isdigit((unsigned char)cigar[i])) { ++i; continue; }
+      long n = 0;
+      size_t j = i;
+      while (j < cigar.size() && isdigit((unsigned char)cigar[j])) n = n * 10 + (cigar[j++] - '0');
+      if (j >= cigar.size() || !(isalnum((unsigned char)cigar[j]) || cigar[j] == '_')) {
+        // regex backtracking: with no word character after the digits, "\d+" gives its last digit to "\w"
+        if (j - i < 2) { i = j; continue; }
+        ops.push_back({cigar[j - 1], n / 10});
+        i = j;
+      } else {
+        ops.push_back({cigar[j], n});
+        i = j + 1;
+      }
+    }
+  }
+  size_t n_ops() const { return ops.size(); }
+  char op(size_t i, long& n) const { n = ops[i].second; return ops[i].first; }
+  long seq_size() const { return (long)seq.size(); }
+  unsigned char base(long i) const { return (unsigned char)seq[(size_t)i]; }
+  std::string bases(long a, long n) const { return std::string(seq.substr((size_t)a, (size_t)n)); }
+};
+
+// CIGAR and SEQ as they lie in a BAM record (see GkAlnRecord): no text is made of them
+struct BamSource {
+  const uint8_t *cig, *seq4;
+  uint32_t n_cig, l_seq;
+  static constexpr const char* kBase = "=ACMGRSVTWYHKDBN";
+  size_t n_ops() const { return n_cig; }
+  char op(size_t i, long& n) const {
+    const uint8_t* p = cig + 4 * i;
+    const uint32_t v = (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+    n = (long)(v >> 4);
+    return "MIDNS"[v & 15u];
+  }
+  long seq_size() const { return (long)l_seq; }
+  unsigned char base(long i) const { return (unsigned char)kBase[(seq4[i >> 1] >> ((~i & 1) << 2)) & 15u]; }
+  std::string bases(long a, long n) const {
+    std::string s((size_t)n, ' ');
+    for (long i = 0; i < n; ++i) s[(size_t)i] = (char)base(a + i);
+    return s;
+  }
+};
+
 // CIGAR / MD / Zs co-walk with the reference's consumption checks (see packed.py::_walkText)
-bool walk_text(sv cigar, sv seq, bool has_md, sv md_s, bool has_zs, sv zs_s, Walked& w, Fail& f) {
-  static thread_local std::vector<MdTok> md;   // scratch of the decoding thread: no allocation per mate
+struct ZsEntry { long gap; char kind; };
+
+// what one decoding thread reuses from mate to mate (no allocation per mate, no thread-local look-ups)
+struct Scratch {
+  std::vector<MdTok> md;
+  std::vector<ZsEntry> zs;
+  Walked w;
+  std::vector<std::pair<char, long>> text_ops;
+  std::string seen_ref;              // neighbouring records are mostly of one backbone: the last name looked up
+  int seen_id = -1;
+  GkAlnRecord pr[2];                 // their text buffers keep their capacity from pair to pair
+};
+
+template <typename Source>
+bool walk_alignment(const Source& src, bool has_md, sv md_s, bool has_zs, sv zs_s, Scratch& sc, Fail& f) {
+  std::vector<MdTok>& md = sc.md;
+  std::vector<ZsEntry>& zs = sc.zs;
+  Walked& w = sc.w;
   md.clear();
   if (has_md) {
     for (size_t i = 0; i < md_s.size();) {
@@ -133,8 +229,6 @@ bool walk_text(sv cigar, sv seq, bool has_md, sv md_s, bool has_zs, sv zs_s, Wal
       }
     }
   }
-  struct Zs { long gap; char kind; };
-  static thread_local std::vector<Zs> zs;
   zs.clear();
   if (has_zs && !zs_s.empty()) {
     size_t a = 0;
@@ -154,6 +248,7 @@ bool walk_text(sv cigar, sv seq, bool has_md, sv md_s, bool has_zs, sv zs_s, Wal
       a = c + 1;
     }
   }
+  const long seq_size = src.seq_size();
   long ref = 0, ri = 0, owed = 0, zpos = 0;
   size_t mi = 0, zi = 0;
   auto take_zs = [&](char kind) {
@@ -163,39 +258,26 @@ bool walk_text(sv cigar, sv seq, bool has_md, sv md_s, bool has_zs, sv zs_s, Wal
     }
   };
   auto md_is_zero = [&](size_t i) { return i < md.size() && md[i].kind == 0 && md[i].num == 0; };
-  // re.findall(r"(\d+)(\w)"): digit runs followed by one word character; anything else is skipped
-  for (size_t i = 0; i < cigar.size();) {
-    if (!isdigit((unsigned char)cigar[i])) { ++i; continue; }
-    long n = 0;
-    size_t j = i;
-    while (j < cigar.size() && isdigit((unsigned char)cigar[j])) n = n * 10 + (cigar[j++] - '0');
-    char op;
-    if (j >= cigar.size() || !(isalnum((unsigned char)cigar[j]) || cigar[j] == '_')) {
-      // regex backtracking: with no word character after the digits, "\d+" gives its last digit to "\w"
-      if (j - i < 2) { i = j; continue; }
-      n /= 10;
-      op = cigar[j - 1];
-      i = j;
-    } else {
-      op = cigar[j];
-      i = j + 1;
-    }
+  const size_t n_src = src.n_ops();
+  for (size_t k = 0; k < n_src; ++k) {
+    long n;
+    const char op = src.op(k, n);
     if (md_is_zero(mi)) ++mi;
     if (op == 'M') {
-      w.ops.push_back({GK_CIG_M, n});
+      w.op(GK_CIG_M, n);
       long done = 0;
       for (;;) {
         if (owed <= done && mi < md.size() && md[mi].kind == 0) { owed += md[mi].num; ++mi; }
         if (owed >= n) { owed -= n; break; }
-        if (ri + owed >= (long)seq.size() || mi >= md.size()) { f = {1, "MD / SEQ exhausted inside an M op"}; return false; }
-        const char base = seq[ri + owed];
+        if (ri + owed >= seq_size || mi >= md.size()) { f = {1, "MD / SEQ exhausted inside an M op"}; return false; }
+        const unsigned char base = src.base(ri + owed);
         if (md_is_zero(mi)) ++mi;
         if (mi >= md.size()) { f = {1, "MD exhausted inside an M op"}; return false; }
         if (!is_acgt(md[mi])) { f = {1, "MD mismatch token is not a base"}; return false; }
-        if (md[mi].ch == base) { f = {1, "MD reference base equals the read base"}; return false; }
+        if ((unsigned char)md[mi].ch == base) { f = {1, "MD reference base equals the read base"}; return false; }
         ++mi;
         take_zs('S');
-        w.mms.push_back({ref + owed, (unsigned char)base});
+        w.mismatch(ref + owed, base);
         owed += 1;
         done = owed;
         if (owed == n) { owed = 0; break; }
@@ -203,13 +285,15 @@ bool walk_text(sv cigar, sv seq, bool has_md, sv md_s, bool has_zs, sv zs_s, Wal
       ref += n;
       ri += n;
     } else if (op == 'I') {
-      w.ops.push_back({GK_CIG_I, n});
+      w.op(GK_CIG_I, n);
+      ++w.n_indel;
       take_zs('I');
-      w.ins.emplace_back(seq.substr((size_t)std::min<long>(ri, (long)seq.size()),
-                                    (size_t)std::max<long>(0, std::min<long>(n, (long)seq.size() - ri))));
+      const long at = std::min<long>(ri, seq_size);
+      w.ins.emplace_back(src.bases(at, std::max<long>(0, std::min<long>(n, seq_size - ri))));
       ri += n;
     } else if (op == 'D') {
-      w.ops.push_back({GK_CIG_D, n});
+      w.op(GK_CIG_D, n);
+      ++w.n_indel;
       if (mi >= md.size() || !(md[mi].kind == 1 && md[mi].ch == '^')) { f = {1, "MD has no deletion at a D op"}; return false; }
       ++mi;
       while (mi < md.size() && is_acgt(md[mi])) ++mi;
@@ -230,7 +314,7 @@ bool walk_text(sv cigar, sv seq, bool has_md, sv md_s, bool has_zs, sv zs_s, Wal
   if (md_is_zero(mi)) ++mi;
   if (zi != zs.size()) { f = {1, "Zs entries do not line up with the alignment"}; return false; }
   if (mi != md.size()) { f = {1, "MD not fully consumed"}; return false; }
-  if (ri != (long)seq.size()) { f = {1, "CIGAR does not cover the read"}; return false; }
+  if (ri != seq_size) { f = {1, "CIGAR does not cover the read"}; return false; }
   return true;
 }
 
@@ -282,12 +366,16 @@ bool fail(gk_packer* pk, const Fail& f, int64_t line_index) {
 
 // one emitted pair: left = the later line, right = the earlier one (readPair yields (line, next_line)).
 // Pure function of the two lines and the gene table: safe to run for many pairs at once.
-struct Decoded {
-  gk_mate rec[2];
+struct Outcome {
   std::vector<std::string> ins[2];   // inserted strings met by the walk of each mate, in order
   bool store_ins[2] = {false, false};   // ... and whether the record keeps their ids (not for clipped mates)
   Fail fail{0, ""};
   int64_t fail_line = -1;
+};
+
+struct Decoded : Outcome {
+  gk_mate* rec = nullptr;            // the pair's two records, in their final place
+  Scratch sc;
 };
 
 void decode_records(const gk_packer* pk, const GkAlnRecord* pr, const int64_t* idx, Decoded& out);
@@ -297,7 +385,7 @@ void decode_pair(const gk_packer* pk, sv left, int64_t left_idx, sv right, int64
   Fail f{0, ""};
   sv lines[2] = {left, right};
   int64_t idx[2] = {left_idx, right_idx};
-  memset(out.rec, 0, sizeof(out.rec));
+  memset(out.rec, 0, 2 * sizeof(gk_mate));
   for (int s = 0; s < 2; ++s)
     if (!parse_record(lines[s], pr[s], f)) { out.fail = f; out.fail_line = idx[s]; return; }
   decode_records(pk, pr, idx, out);
@@ -307,61 +395,79 @@ void decode_pair(const gk_packer* pk, sv left, int64_t left_idx, sv right, int64
 void decode_records(const gk_packer* pk, const GkAlnRecord* pr, const int64_t* idx, Decoded& out) {
   Fail f{0, ""};
   auto failed = [&](const Fail& why, int64_t line) { out.fail = why; out.fail_line = line; };
-  memset(out.rec, 0, sizeof(out.rec));
+  memset(out.rec, 0, 2 * sizeof(gk_mate));
   const bool both = passes(pr[0]) && passes(pr[1]);
   for (int s = 0; s < 2; ++s) {
     const GkAlnRecord& p = pr[s];
     gk_mate& r = out.rec[s];
-    // neighbouring records are mostly of one backbone: remember the last name looked up (per packer and thread)
-    static thread_local uint64_t seen_pk = 0;
-    static thread_local std::string seen_ref;
-    static thread_local int seen_id = -1;
-    if (seen_pk != pk->serial || sv(seen_ref) != p.ref) {
-      auto g = pk->gene_id.find(std::string(p.ref));
-      if (g == pk->gene_id.end()) return failed({4, "reference is not a backbone of the index"}, idx[s]);
-      seen_pk = pk->serial; seen_ref.assign(p.ref); seen_id = (int)g->second;
+    Scratch& sc = out.sc;
+    int gene = p.gene;
+    if (gene == GkAlnRecord::kGeneByName) {
+      if (sc.seen_id < 0 || sv(sc.seen_ref) != p.ref) {
+        auto g = pk->gene_id.find(std::string(p.ref));
+        if (g == pk->gene_id.end()) return failed({4, "reference is not a backbone of the index"}, idx[s]);
+        sc.seen_ref.assign(p.ref); sc.seen_id = (int)g->second;
+      }
+      gene = sc.seen_id;
     }
+    if (gene < 0) return failed({4, "reference is not a backbone of the index"}, idx[s]);
+    const int seen_id = gene;
     r.pos0 = (uint32_t)(p.pos - 1);
     r.flag = (uint16_t)(p.flag & 0xFFFF);
     r.ref = (uint8_t)seen_id;
     r.nh = (uint8_t)std::min<long>(p.nh, 255);
     r.nm = p.has_nm ? (uint8_t)std::min<long>(std::max<long>(p.nm, 0), 254) : (uint8_t)GK_NM_ABSENT;
     if (!both) continue;
-    static thread_local Walked w;
-    w.ops.clear(); w.mms.clear(); w.ins.clear(); w.clipped = false;
-    const bool walked = walk_text(p.cigar, p.seq, p.has_md, p.md, p.has_zs, p.zs, w, f);
-    out.ins[s] = std::move(w.ins);   // strings met before a failure are interned too, like a one-by-one walk
+    Walked& w = sc.w;
+    w.reset();
+    const bool binary = p.bam_cigar != nullptr;
+    const bool walked =
+        binary ? walk_alignment(BamSource{p.bam_cigar, p.bam_seq, p.n_bam_cigar, p.l_bam_seq}, p.has_md, p.md, p.has_zs, p.zs, sc, f)
+               : walk_alignment(TextSource(p.cigar, p.seq, sc.text_ops), p.has_md, p.md, p.has_zs, p.zs, sc, f);
+    out.ins[s].swap(w.ins);          // strings met before a failure are interned too, like a one-by-one walk
+    w.ins.clear();                   // (swapped, not moved: both lists keep their storage from pair to pair)
     if (!walked) return failed(f, idx[s]);
     if (w.clipped) {   // its strings are still interned at merge time, the record keeps none of them
       // keep the CIGAR (S ops included) for read depth when it fits, else only the clip marker
-      std::vector<std::pair<int, long>> full;
-      sv cg = p.cigar;
-      for (size_t i = 0; i < cg.size();) {
-        if (!isdigit((unsigned char)cg[i])) { ++i; continue; }
-        long n = 0;
-        while (i < cg.size() && isdigit((unsigned char)cg[i])) n = n * 10 + (cg[i++] - '0');
-        if (i >= cg.size()) break;
-        const char op = cg[i++];
-        full.push_back({op == 'S' ? GK_CIG_S : op == 'M' ? GK_CIG_M : op == 'I' ? GK_CIG_I : GK_CIG_D, n});
+      uint16_t full[GK_MAX_CIG];
+      size_t n_full = 0;
+      bool fits = true;
+      auto add = [&](char op, long n) {
+        if (n_full < GK_MAX_CIG)
+          full[n_full] = (uint16_t)(((unsigned long)n << 4) | (unsigned)(op == 'S' ? GK_CIG_S : op == 'M' ? GK_CIG_M : op == 'I' ? GK_CIG_I : GK_CIG_D));
+        fits = fits && n <= 4095;
+        ++n_full;
+      };
+      if (binary) {
+        const BamSource src{p.bam_cigar, p.bam_seq, p.n_bam_cigar, p.l_bam_seq};
+        for (size_t i = 0; i < src.n_ops(); ++i) {
+          long n;
+          const char op = src.op(i, n);
+          add(op, n);
+        }
+      } else {
+        sv cg = p.cigar;
+        for (size_t i = 0; i < cg.size();) {
+          if (!isdigit((unsigned char)cg[i])) { ++i; continue; }
+          long n = 0;
+          while (i < cg.size() && isdigit((unsigned char)cg[i])) n = n * 10 + (cg[i++] - '0');
+          if (i >= cg.size()) break;
+          add(cg[i++], n);
+        }
       }
-      bool fits = full.size() <= GK_MAX_CIG;
-      for (auto& o : full) fits = fits && o.second <= 4095;
-      if (!fits) { full.clear(); full.push_back({GK_CIG_S, 0}); }
-      r.n_cig = (uint8_t)full.size();
-      for (size_t i = 0; i < full.size(); ++i) r.cig[i] = (uint16_t)((full[i].second << 4) | full[i].first);
+      fits = fits && n_full <= GK_MAX_CIG;
+      if (!fits) { n_full = 1; full[0] = (uint16_t)GK_CIG_S; }   // {S, 0}
+      r.n_cig = (uint8_t)n_full;
+      for (size_t i = 0; i < n_full; ++i) r.cig[i] = full[i];
       continue;
     }
-    size_t n_ev = w.mms.size();
-    for (auto& o : w.ops) n_ev += (o.first == GK_CIG_I || o.first == GK_CIG_D) ? 1 : 0;
-    bool fits = w.ops.size() <= GK_MAX_CIG && w.mms.size() <= GK_MAX_MM && out.ins[s].size() <= GK_MAX_INS &&
-                n_ev <= GK_MAX_EVENTS;
-    for (auto& o : w.ops) fits = fits && o.second <= 4095;
-    for (auto& m : w.mms) fits = fits && m.first <= 0xFFFF;
+    const bool fits = w.n_ops <= GK_MAX_CIG && w.n_mm <= GK_MAX_MM && out.ins[s].size() <= GK_MAX_INS &&
+                      w.n_mm + w.n_indel <= GK_MAX_EVENTS && !w.long_op && !w.far_mm;
     if (!fits) return failed({3, "record does not fit gk_mate"}, idx[s]);
-    r.n_cig = (uint8_t)w.ops.size(); r.n_mm = (uint8_t)w.mms.size(); r.n_ins = (uint8_t)out.ins[s].size();
+    r.n_cig = (uint8_t)w.n_ops; r.n_mm = (uint8_t)w.n_mm; r.n_ins = (uint8_t)out.ins[s].size();
     out.store_ins[s] = true;
-    for (size_t i = 0; i < w.ops.size(); ++i) r.cig[i] = (uint16_t)((w.ops[i].second << 4) | w.ops[i].first);
-    for (size_t i = 0; i < w.mms.size(); ++i) { r.mm[i].ref_off = (uint16_t)w.mms[i].first; r.mm[i].base = (uint8_t)w.mms[i].second; }
+    for (size_t i = 0; i < w.n_ops; ++i) r.cig[i] = w.cig[i];
+    for (size_t i = 0; i < w.n_mm; ++i) { r.mm[i].ref_off = w.mm[i].ref_off; r.mm[i].base = w.mm[i].base; }
   }
 }
 
@@ -387,14 +493,16 @@ void on_threads(size_t n, const Work& work) {
 // in one pass over the few pairs that met an inserted string or failed.
 struct Special {
   size_t pair;
-  Decoded d;
+  Outcome d;
 };
 
 template <typename DecodeOne, typename LineOf>
 bool decode_all(gk_packer* pk, size_t n, const DecodeOne& decode, const LineOf& line_of) {
   if (!n) return true;
-  const size_t first = pk->mates.size() / 2;
-  pk->mates.resize(2 * (first + n));
+  const size_t first = pk->n_mates / 2;
+  if (!pk->resize_mates(2 * (first + n)))
+    return fail(pk, Fail{3, "more records than the output buffer of gk_packer_set_output holds"}, -1);
+  gk_mate* const mates = pk->mates();
   pk->pair_lines.resize(2 * (first + n));
   std::vector<std::vector<Special>> special((size_t)pack_threads() + 1);
   on_threads(n, [&](int t, size_t a, size_t b) {
@@ -402,20 +510,30 @@ bool decode_all(gk_packer* pk, size_t n, const DecodeOne& decode, const LineOf& 
     for (size_t i = a; i < b; ++i) {
       d.ins[0].clear(); d.ins[1].clear();
       d.store_ins[0] = d.store_ins[1] = false;
-      d.fail = Fail{0, ""};
+      d.fail.kind = 0;
+      d.fail.msg.clear();
       d.fail_line = -1;
+      d.rec = mates + 2 * (first + i);
       decode(i, d);
-      gk_mate* dst = pk->mates.data() + 2 * (first + i);
-      dst[0] = d.rec[0];
-      dst[1] = d.rec[1];
       pk->pair_lines[2 * (first + i)] = line_of(i, 0);
       pk->pair_lines[2 * (first + i) + 1] = line_of(i, 1);
-      if (d.fail.kind || !d.ins[0].empty() || !d.ins[1].empty()) special[(size_t)t].push_back(Special{i, d});
+      if (!d.fail.kind && d.ins[0].empty() && d.ins[1].empty()) continue;
+      // A string that is in the table already (an index string, or one met in an earlier feed) has its final id:
+      // the table is not written to while the threads decode.  Only pairs with a string met for the first time,
+      // or with a failure, wait for the ordered pass.
+      bool settled = !d.fail.kind;
+      for (int s = 0; s < 2 && settled; ++s)
+        for (size_t q = 0; q < d.ins[s].size(); ++q) {
+          auto it = pk->ins_id.find(d.ins[s][q]);
+          if (it == pk->ins_id.end()) { settled = false; break; }
+          if (d.store_ins[s] && q < GK_MAX_INS) d.rec[s].ins[q] = it->second;
+        }
+      if (!settled) special[(size_t)t].push_back(Special{i, static_cast<const Outcome&>(d)});
     }
   });
   for (auto& list : special) {   // threads own ascending ranges: this walks the pairs in order
     for (Special& sp : list) {
-      gk_mate* dst = pk->mates.data() + 2 * (first + sp.pair);
+      gk_mate* dst = mates + 2 * (first + sp.pair);
       for (int s = 0; s < 2; ++s) {
         for (size_t q = 0; q < sp.d.ins[s].size(); ++q) {
           auto it = pk->ins_id.find(sp.d.ins[s][q]);
@@ -431,7 +549,7 @@ bool decode_all(gk_packer* pk, size_t n, const DecodeOne& decode, const LineOf& 
         }
       }
       if (sp.d.fail.kind) {   // the pairs before it stay, like a one-by-one walk
-        pk->mates.resize(2 * (first + sp.pair));
+        pk->resize_mates(2 * (first + sp.pair));
         pk->pair_lines.resize(2 * (first + sp.pair));
         return fail(pk, sp.d.fail, sp.d.fail_line);
       }
@@ -499,9 +617,15 @@ bool feed_line(gk_packer* pk, sv line, int64_t index) {
 }  // namespace
 
 // Records of another source (BAM) through the same pairing rule, decoder and merge as SAM text.
+int gk_packer_gene_of(const gk_packer* pk, std::string_view ref) {
+  auto g = pk->gene_id.find(std::string(ref));
+  return g == pk->gene_id.end() ? -1 : (int)g->second;
+}
+
 int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
                            const std::function<void(int64_t, GkAlnKey&)>& key,
-                           const std::function<void(int64_t, GkAlnRecord&)>& full) {
+                           const std::function<void(int64_t, GkAlnRecord&)>& full,
+                           const std::function<void(int64_t, bool)>& soon) {
   if (!pk || n < 0) { gk_set_error("bad packer arguments"); return GK_ERR_ARG; }
   if (pk->err_kind) return GK_ERR_ASSERT;
   if (!pk->waiting.empty() || !pk->carry.empty()) { gk_set_error("text and record input cannot be mixed"); return GK_ERR_ARG; }
@@ -541,12 +665,19 @@ int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
     }
     // Only records of one name can pair and they are adjacent: the table is per name, and the usual
     // group -- exactly two records -- is settled by comparing the two keys directly.
+    // Every record is keyed once: the key that ended a group starts the next.
     GkAlnKey first, second, third;
-    for (int64_t i = a; i < b;) {
-      key(i, first);
-      int64_t e = i + 1;
-      if (e < b) { key(e, second); if (second.name == first.name) ++e; }
-      if (e == i + 2 && (e == b || (key(e, third), third.name != first.name))) {
+    auto single = [&](const GkAlnKey& only) { if (only.mate_same_ref) out.n_reads += 1; };   // waits for a mate that never comes
+    int64_t i = a;
+    if (i < b) key(i, first);
+    while (i < b) {
+      if (soon && i + 32 < b) soon(i + 32, true);
+      if (i + 1 == b) { single(first); break; }
+      key(i + 1, second);
+      if (second.name != first.name) { single(first); first = second; i += 1; continue; }
+      bool more = false;
+      if (i + 2 < b) { key(i + 2, third); more = third.name == first.name; }
+      if (!more) {
         if (first.mate_same_ref) out.n_reads += 1;
         if (second.mate_same_ref) out.n_reads += 1;
         // the second record finds the waiting first one iff (ref, its mate position, secondary flag) agree
@@ -559,13 +690,21 @@ int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
             out.pairs.push_back(i);
           }
         }
-        i = e;
+        i += 2;
+        if (i < b) first = third;
         continue;
       }
-      while (e < b && (key(e, second), second.name == first.name)) ++e;
+      int64_t e = i + 3;   // three or more records of one name: the general rule over the group
+      bool ended = false;
+      while (e < b) {
+        key(e, second);
+        if (second.name != first.name) { ended = true; break; }
+        ++e;
+      }
       waiting.clear();
       for (int64_t j = i; j < e; ++j) { key(j, k); general(j); }
       i = e;
+      if (ended) first = second;
     }
   };
   std::vector<int64_t> cuts{0};
@@ -599,11 +738,16 @@ int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
     pk->n_pairs += (int64_t)pc.pairs.size() / 2;
   }
   clock.lap("pairing");
+  constexpr size_t kAhead = 6;
   // (2) decode on threads, (3) ordered pass over the pairs with inserted strings
   const bool merged = decode_all(
       pk, pairs.size() / 2,
       [&](size_t i, Decoded& out) {
-        static thread_local GkAlnRecord pr[2];   // their text buffers keep their capacity from pair to pair
+        GkAlnRecord* pr = out.sc.pr;
+        if (soon && 2 * (i + kAhead) + 1 < pairs.size()) {   // the records are far apart in memory: ask for them early
+          soon(pairs[2 * (i + kAhead)], false);
+          soon(pairs[2 * (i + kAhead) + 1], false);
+        }
         const int64_t idx[2] = {base + pairs[2 * i], base + pairs[2 * i + 1]};
         full(pairs[2 * i], pr[0]);
         full(pairs[2 * i + 1], pr[1]);
@@ -687,7 +831,7 @@ int gk_packer_counts(gk_packer* pk, int64_t* n_lines, int64_t* n_reads, int64_t*
   if (!pk) return GK_ERR_ARG;
   if (n_lines) *n_lines = pk->n_lines;
   if (n_reads) *n_reads = pk->n_reads;
-  if (n_pairs) *n_pairs = (int64_t)pk->mates.size() / 2;
+  if (n_pairs) *n_pairs = (int64_t)pk->n_mates / 2;
   if (n_strange) *n_strange = pk->n_strange;
   if (n_strings) *n_strings = (int64_t)pk->ins_strings.size();
   return GK_OK;
@@ -701,14 +845,27 @@ int gk_packer_error(gk_packer* pk, int32_t* kind, int64_t* line_index) {
   return GK_OK;
 }
 
-// Copy out the records (2 per pair) and the line indices (left, right) of every pair.
+// Records go straight into the caller's buffer (e.g. pinned memory, so the upload can start from where the
+// decoder wrote) instead of the packer's own storage.  Call before the first feed; capacity in records (2 per
+// pair; a BAM file of n alignment records yields at most n).  A feed that would overflow it fails with kind 3.
+int gk_packer_set_output(gk_packer* pk, gk_mate* mates_out, int64_t capacity) {
+  if (!pk || !mates_out || capacity < 0) { gk_set_error("bad packer arguments"); return GK_ERR_ARG; }
+  if (pk->n_mates) { gk_set_error("gk_packer_set_output after records were made"); return GK_ERR_ARG; }
+  pk->ext = mates_out;
+  pk->ext_cap = capacity;
+  return GK_OK;
+}
+
+// Copy out the records (2 per pair; nothing to copy when they were written to the buffer of
+// gk_packer_set_output, mates_out may then be that buffer or null) and the line indices (left, right) of every pair.
 int gk_packer_records(gk_packer* pk, gk_mate* mates_out, int64_t* pair_lines_out) {
   if (!pk) return GK_ERR_ARG;
-  if (mates_out && !pk->mates.empty()) {   // first touch of the caller's pages: worth spreading over the threads
-    const size_t bytes = pk->mates.size() * sizeof(gk_mate), piece = 1u << 22;
+  if (mates_out && pk->n_mates && mates_out != pk->mates()) {   // first touch of the caller's pages: worth spreading over the threads
+    const size_t bytes = pk->n_mates * sizeof(gk_mate), piece = 1u << 22;
+    const char* from = (const char*)pk->mates();
     on_threads((bytes + piece - 1) / piece, [&](int, size_t a, size_t b) {
       const size_t lo = a * piece, hi = std::min(bytes, b * piece);
-      if (hi > lo) memcpy((char*)mates_out + lo, (const char*)pk->mates.data() + lo, hi - lo);
+      if (hi > lo) memcpy((char*)mates_out + lo, from + lo, hi - lo);
     });
   }
   if (pair_lines_out && !pk->pair_lines.empty())

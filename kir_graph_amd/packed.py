@@ -204,16 +204,22 @@ def packPairs(pairs, index: GkIndex, table: InsTable | None = None) -> tuple[np.
 _ERR_KINDS = {1: AssertionError, 2: NotImplementedError, 3: PackCapacityError, 4: ValueError}
 
 
-def _withPacker(index: GkIndex, table: InsTable | None, feed):
-    """Create a native packer, let ``feed(handle)`` push alignments into it, collect the result."""
+def _withPacker(index: GkIndex, table: InsTable | None, feed, capacity: int | None = None):
+    """Create a native packer, let ``feed(handle)`` push alignments into it, collect the result.
+    ``capacity``: upper bound of the records the input can yield, when known beforehand -- the decoder then
+    writes them straight into the (pinned) array that is returned instead of into storage of its own."""
     import ctypes as C
-    from ._lib import check, lib
+    from ._lib import check, lib, pinnedEmpty
     table = table or InsTable(index)
     genes = (C.c_char_p * len(index.genes))(*[g.encode() for g in index.genes])
     strings = (C.c_char_p * max(1, len(table.strings)))(*[s.encode() for s in table.strings])
     pk = C.c_void_p()
     check(lib().gk_packer_create(genes, len(index.genes), strings, len(table.strings), C.byref(pk)))
     try:
+        rec = None
+        if capacity:
+            rec = pinnedEmpty(capacity, MATE_DTYPE)
+            check(lib().gk_packer_set_output(pk, rec.ctypes.data, capacity))
         feed(pk)
         kind, line = C.c_int32(), C.c_int64()
         check(lib().gk_packer_error(pk, C.byref(kind), C.byref(line)))
@@ -223,11 +229,13 @@ def _withPacker(index: GkIndex, table: InsTable | None, feed):
         n_lines, n_reads, n_pairs, n_strange, n_str = (C.c_int64() for _ in range(5))
         check(lib().gk_packer_counts(pk, C.byref(n_lines), C.byref(n_reads), C.byref(n_pairs), C.byref(n_strange),
                                      C.byref(n_str)))
-        from ._lib import pinnedEmpty
-        rec = pinnedEmpty(2 * n_pairs.value, MATE_DTYPE)             # filled by gk_packer_records; pinned when a GPU is there
+        if rec is None:
+            rec = pinnedEmpty(2 * n_pairs.value, MATE_DTYPE)         # filled by gk_packer_records; pinned when a GPU is there
+            dst = rec.ctypes.data if len(rec) else None
+        else:
+            rec, dst = rec[:2 * n_pairs.value], None                 # already in place
         pair_lines = np.empty((n_pairs.value, 2), dtype=np.int64)
-        check(lib().gk_packer_records(pk, rec.ctypes.data if len(rec) else None,
-                                      pair_lines.ctypes.data if len(pair_lines) else None))
+        check(lib().gk_packer_records(pk, dst, pair_lines.ctypes.data if len(pair_lines) else None))
         for i in range(len(table.strings), n_str.value):
             table.intern(lib().gk_packer_string(pk, i).decode())
         counts = {"lines": n_lines.value, "reads": n_reads.value, "pairs": n_pairs.value, "strange": n_strange.value}
@@ -263,7 +271,9 @@ def packBam(path: str, index: GkIndex, table: InsTable | None = None, name_sorte
     h = C.c_void_p()
     check(lib().gk_bam_open(path.encode(), int(name_sorted), C.byref(h)))
     try:
-        return _withPacker(index, table, lambda pk: lib().gk_bam_pack(h, pk))
+        n_rec = C.c_int64()
+        check(lib().gk_bam_info(h, C.byref(n_rec), None, None))
+        return _withPacker(index, table, lambda pk: lib().gk_bam_pack(h, pk), capacity=n_rec.value)
     finally:
         lib().gk_bam_close(h)
 

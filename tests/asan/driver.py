@@ -89,6 +89,9 @@ def exercise(path: str) -> int:
         if lib.gk_bam_open(path.encode(), name_sorted, C.byref(h)) == 0:
             pk = C.c_void_p()
             if lib.gk_packer_create(names, len(GENES), None, 0, C.byref(pk)) == 0:
+                if name_sorted:   # records straight into a caller's buffer of exactly the promised size
+                    out_buf = (C.c_uint8 * (128 * max(n_rec.value, 1)))()
+                    lib.gk_packer_set_output(pk, out_buf, C.c_int64(n_rec.value))
                 lib.gk_bam_pack(h, pk)
                 lib.gk_packer_destroy(pk)
             off = (C.c_int64 * (n_ref.value + 1))(*[9000 * i for i in range(n_ref.value + 1)])

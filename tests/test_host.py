@@ -490,7 +490,7 @@ def test_name_collation_on_random_name_shapes(tmp_path):
     stems = ["r", "read", "A00123:45:HXXXXXXXX:1:", "x", "", "r0", "sample_long_prefix_over_sixteen_bytes/", "7", "00"]
     pieces = ["", "a", "b", ":", "_", "-", "0", "00", "000", "1", "9", "10", "007", "12345678901", "123456789", "99999999999999"]
     names = set()
-    while len(names) < 17000:     # 34 k records: all eight sorted runs and the multiway merge take part
+    while len(names) < 17000:     # 34 k records and more: splitters, buckets and the per-bucket sorts take part
         k = int(rng.integers(1, 6))
         name = stems[int(rng.integers(len(stems)))] + "".join(
             pieces[int(rng.integers(len(pieces)))] if rng.random() < 0.5 else str(int(rng.integers(0, 3000))).zfill(int(rng.integers(0, 7)))
@@ -505,6 +505,9 @@ def test_name_collation_on_random_name_shapes(tmp_path):
         pos = 100 + i
         lines.append(f"{name}\t147\t{g}\t{pos + 200}\t60\t10M\t=\t{pos}\t-210\tACGTACGTAC\tIIIIIIIIII\tNM:i:0")   # READ2 first in the file
         lines.append(f"{name}\t99\t{g}\t{pos}\t60\t10M\t=\t{pos + 200}\t210\tACGTACGTAC\tIIIIIIIIII\tNM:i:0")
+    for i, name in enumerate(names[::40]):     # more records of some names, far away in the file: ties keep the file's order
+        for flag in (355, 403, 99, 147, 355):
+            lines.append(f"{name}\t{flag}\t{g}\t{7 + i}\t60\t10M\t=\t{9 + i}\t0\tACGTACGTAC\tIIIIIIIIII\tNM:i:{flag % 3}")
     header = ["@HD\tVN:1.0\tSO:unsorted", f"@SQ\tSN:{g}\tLN:100000"]
     path = str(tmp_path / "n.bam")
     samToBam(header + lines, path, block=20000)
@@ -718,3 +721,127 @@ def test_native_depth_tsv_equals_pandas(tmp_path):
                        "pos": np.concatenate([np.arange(1, n + 1) for n in lens]), "depth": depth.astype(np.int64)})
     df.to_csv(tmp_path / "p.tsv", sep="\t", header=False, index=False)
     assert open(path).read() == (tmp_path / "p.tsv").read_text()
+
+
+def test_bam_binary_hand_over_equals_text_path_on_awkward_records(tmp_path):
+    """gk_bam_pack hands CIGAR / SEQ over as they lie in the record when every op is one of M I D N S and as text
+    otherwise: either way the records, the string table and the exceptions are those of the SAM-text packer
+    fed with the rendered lines (csrc/gk_sampack.cpp: TextSource / BamSource under one walk)."""
+    from bamwriter import samToBam
+    sidx = synth.makeIndex(seed=5, n_genes=3, var_range=(200, 300), allele_range=(10, 20))
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    sample = synth.makeSample(sidx, seed=21, n_pairs=400)
+    records = synth.toSamLines(sample)
+    header = ["@HD\tVN:1.0\tSO:queryname"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+
+    def edit(lines, k, **kw):
+        """Pair k with fields of its first mate replaced (cigar / seq / md / zs / nm)."""
+        f = lines[2 * k].split("\t")
+        if "cigar" in kw:
+            f[5] = kw["cigar"]
+        if "seq" in kw:
+            f[9] = kw["seq"]
+            f[10] = "I" * len(f[9]) if f[9] != "*" else "*"
+        for i in range(11, len(f)):
+            for tag, key in (("MD:Z:", "md"), ("Zs:Z:", "zs"), ("NM:i:", "nm")):
+                if f[i].startswith(tag) and key in kw:
+                    f[i] = tag + str(kw[key])
+        f = [c for c in f if not (c.startswith("Zs:Z:") and kw.get("zs") == "")]
+        lines[2 * k] = "\t".join(f)
+
+    def both_ways(lines, tag):
+        path = str(tmp_path / f"{tag}.bam")
+        samToBam(header + lines, path, block=20000)
+        outcomes = []
+        for run in (lambda: packed.packBam(path, gidx), lambda: packed.packText(packed.bamChunks(path), gidx)):
+            try:
+                rec, table, pl, counts = run()
+                outcomes.append(("ok", rec.tobytes(), table.strings, pl.tolist(), counts))
+            except Exception as e:    # noqa: BLE001 -- the kind and the line are what is compared
+                outcomes.append((type(e).__name__, str(e).split(":")[0].split()[-1], str(e).split(":", 1)[-1]))   # kind, line, why
+        assert outcomes[0] == outcomes[1], tag
+        return outcomes[0]
+
+    n = 150
+    # shapes that must come out as records: clips (short, long, too many ops to keep), long runs, many ops
+    good = list(records)
+    edit(good, 3, cigar=f"10S{n - 10}M", md=str(n - 10), zs="", nm=0)
+    edit(good, 5, cigar=f"5S{n - 12}M7S", md=str(n - 12), zs="", nm=0)
+    edit(good, 7, cigar="1S" + "1M1I" * 8 + f"{n - 17}M", md=str(n - 17 + 8), zs="", nm=0)      # 18 ops, clipped
+    edit(good, 9, cigar="2M1I" * 6 + f"{n - 18}M", md=str(n - 18 + 12), zs="", nm=0)            # 13 ops, 6 strings
+    edit(good, 11, cigar=f"{n}M", md="0A0C0G" + str(n - 3), seq="TTT" + "A" * (n - 3), zs="", nm=3)
+    assert both_ways(good, "good")[0] == "ok"
+    # shapes the reference raises on, or that only the text walk spells right: one file each, the bad pair in the middle
+    cases = {
+        "hard_clip": dict(cigar=f"5H{n}M", md=str(n), zs="", nm=0),          # H: NotImplementedError
+        "pad": dict(cigar=f"70M2P{n - 70}M", md=str(n), zs="", nm=0),
+        "eq_single_digit": dict(cigar=f"{n - 5}M5=", md=str(n - 5), zs="", nm=0),   # "5=" is skipped by (\d+)(\w)
+        "eq_two_digits": dict(cigar=f"{n - 15}M15=", md=str(n - 15), zs="", nm=0),  # "15=" reads as op '5' of length 1
+        "x_op": dict(cigar=f"{n - 5}M5X", md=str(n - 5), zs="", nm=0),
+        "splice": dict(cigar=f"70M100N{n - 70}M", md=str(n), zs="", nm=0),
+        "no_cigar": dict(cigar="*", md=str(n), zs="", nm=0),
+        "no_seq": dict(cigar=f"{n}M", seq="*", md=str(n), zs="", nm=0),
+        "short_cigar": dict(cigar=f"{n - 1}M", md=str(n - 1), zs="", nm=0),
+        "md_short": dict(cigar=f"{n}M", md=str(n - 1), zs="", nm=0),
+        "md_same_base": dict(cigar=f"{n}M", md="0A" + str(n - 1), seq="A" * n, zs="", nm=1),
+        "md_no_deletion": dict(cigar=f"70M2D{n - 70}M", md=str(n), zs="", nm=0),
+        "zs_unused": dict(cigar=f"{n}M", md=str(n), zs="3|S|hv1", nm=0),
+        "too_many_ops": dict(cigar="2M1I" * 8 + f"{n - 24}M", md=str(n - 24 + 16), zs="", nm=0),   # 17 ops, not clipped
+        "long_insert_run": dict(cigar=f"4M4096I{n - 4}M", md=str(n), zs="", nm=0),
+    }
+    kinds = {}
+    for tag, kw in cases.items():
+        lines = list(records)
+        edit(lines, 200, **kw)
+        kinds[tag] = both_ways(lines, tag)[0]
+    assert kinds["splice"] == "NotImplementedError" and kinds["hard_clip"] == "NotImplementedError"
+    assert kinds["md_short"] == "AssertionError" and kinds["too_many_ops"] == "PackCapacityError"
+
+
+def test_record_index_is_the_same_however_the_stream_is_cut(tmp_path, monkeypatch):
+    """gk_bam_open indexes the records on several threads from guessed starting points and keeps a guess only from
+    where the true chain meets it: any number of segments gives the records of the one-segment walk, and a damaged
+    block size is refused wherever the cuts fall."""
+    import struct
+    from bamwriter import bamBytes, _bgzf_block
+    sidx = synth.makeIndex(seed=5, n_genes=3, var_range=(200, 300), allele_range=(10, 20))
+    sample = synth.makeSample(sidx, seed=33, n_pairs=700)
+    header = ["@HD\tVN:1.0\tSO:unsorted"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+    lines = synth.toSamLines(sample)
+    # names and tags full of bytes that look like record heads: zeros, small integers, printable runs
+    for k in range(0, len(lines), 7):
+        lines[k] += "\tXB:B:I," + ",".join(str(v) for v in (40, 0, 0, 300, 1, 0, 36, 0))
+    raw = bamBytes(header + lines)
+
+    def write(data, name):
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            for i in range(0, len(data), 30000):
+                f.write(_bgzf_block(data[i:i + 30000]))
+            f.write(_bgzf_block(b""))
+        return path
+
+    good = write(raw, "good.bam")
+    want = None
+    for n_seg in ("1", "2", "5", "64", "1000", "100000"):
+        monkeypatch.setenv("GK_BAM_INDEX_SEGMENTS", n_seg)
+        got = b"".join(packed.bamChunks(good, name_sorted=False))
+        want = want or got
+        assert got == want, n_seg
+    assert want.decode().split("\n")[:-1] == lines
+    # a block size that points past the end, one that is too small, one that lands inside the next record
+    first = raw.index(b"r0000")
+    starts = [first - 36]
+    while starts[-1] < len(raw):
+        starts.append(starts[-1] + 4 + struct.unpack_from("<I", raw, starts[-1])[0])
+    assert starts[-1] == len(raw)
+    for which, value in ((len(starts) // 2, 0x7FFFFFF0), (len(starts) // 3, 31), (len(starts) - 3, None)):
+        at = starts[which]
+        size = struct.unpack_from("<I", raw, at)[0]
+        bad = bytearray(raw)
+        bad[at:at + 4] = struct.pack("<I", value if value is not None else size + 9)
+        path = write(bytes(bad), f"bad{which}.bam")
+        for n_seg in ("1", "3", "64", "1000"):
+            monkeypatch.setenv("GK_BAM_INDEX_SEGMENTS", n_seg)
+            with pytest.raises(_lib.GkError, match="malformed BAM"):
+                list(packed.bamChunks(path, name_sorted=False))
