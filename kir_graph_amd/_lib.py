@@ -7,6 +7,7 @@ is visible when a context is created, the typing path raises.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import os
 from pathlib import Path
 
@@ -356,12 +357,50 @@ class Device:
 
 
 _pinned_ok: bool | None = None
+# Pinning and unpinning hundreds of megabytes costs tens of milliseconds each way and holds the runtime's lock
+# meanwhile (measured: 48 ms + 44 ms for a sample's id array), so blocks go back to a pool instead of to the
+# runtime: a few size classes per order of magnitude, GK_PINNED_POOL_GB (default 4) of idle blocks at most.
+_pool_lock = threading.Lock()
+_pool: dict[int, list[int]] = {}
+_pool_idle = 0
+
+
+def _pinnedClass(nbytes: int) -> int:
+    """Size class of a request: the next multiple of an eighth of its power of two (at least 1 MiB)."""
+    step = max(1 << 20, 1 << max(0, nbytes.bit_length() - 4))
+    return (nbytes + step - 1) // step * step
+
+
+def _pinnedTake(nbytes: int) -> tuple[int, int]:
+    """(address, size class) of a pinned block of at least ``nbytes``; address 0 when the runtime has none."""
+    global _pool_idle
+    cls = _pinnedClass(nbytes)
+    with _pool_lock:
+        free = _pool.get(cls)
+        if free:
+            _pool_idle -= cls
+            return free.pop(), cls
+    p = C.c_void_p()
+    if lib().gk_host_alloc(cls, C.byref(p)) != 0 or not p.value:
+        return 0, cls
+    return p.value, cls
+
+
+def _pinnedGive(address: int, cls: int) -> None:
+    global _pool_idle
+    limit = int(float(os.environ.get("GK_PINNED_POOL_GB", "4")) * (1 << 30))
+    with _pool_lock:
+        if _pool_idle + cls <= limit:
+            _pool.setdefault(cls, []).append(address)
+            _pool_idle += cls
+            return
+    lib().gk_host_free(C.c_void_p(address))
 
 
 def pinnedEmpty(count: int, dtype) -> np.ndarray:
     """``np.empty(count, dtype)`` in pinned host memory when a GPU is there (the packed records of a sample on
     their way to HBM: the copy then runs at PCIe speed instead of through the runtime's pageable staging);
-    plain memory otherwise.  The block is returned to the runtime when the array is garbage collected."""
+    plain memory otherwise.  The block goes back to the pool when the array is garbage collected."""
     global _pinned_ok
     dtype = np.dtype(dtype)
     nbytes = int(count) * dtype.itemsize
@@ -369,13 +408,13 @@ def pinnedEmpty(count: int, dtype) -> np.ndarray:
         _pinned_ok = deviceCount() > 0
     if not _pinned_ok or nbytes < (1 << 20):
         return np.empty(count, dtype=dtype)
-    p = C.c_void_p()
-    if lib().gk_host_alloc(nbytes, C.byref(p)) != 0 or not p.value:
+    address, cls = _pinnedTake(nbytes)
+    if not address:
         return np.empty(count, dtype=dtype)
     import weakref
-    raw = (C.c_uint8 * nbytes).from_address(p.value)
+    raw = (C.c_uint8 * nbytes).from_address(address)
     arr = np.frombuffer(raw, dtype=dtype, count=count)
-    weakref.finalize(raw, lib().gk_host_free, C.c_void_p(p.value))     # arr keeps `raw` alive through its base
+    weakref.finalize(raw, _pinnedGive, address, cls)     # arr keeps `raw` alive through its base
     return arr
 
 

@@ -23,6 +23,8 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -34,14 +36,111 @@
 void gk_set_error(const char* fmt, ...);
 
 // the inflated stream is hundreds of megabytes that the inflating threads are about to overwrite
-using Bytes = std::vector<uint8_t, GkRawInit<uint8_t>>;
+// Blocks of hundreds of megabytes (the inflated stream, the file, the sort's records) are handed back to a pool
+// when a file is closed and taken from it when the next one is opened: a fresh block of that size costs a page
+// fault per 4 KiB when it is first written (measured on the GPU box: 0.6 s of system time per 2 M-read sample,
+// a quarter of the ingest's CPU time), a recycled one is already mapped.  GK_BLOCK_POOL_GB (default 6) of idle
+// blocks at most; a request takes the smallest idle block that holds it and is not more than twice its size.
+namespace {
+struct BlockPool {
+  std::mutex lock;
+  std::vector<std::pair<void*, size_t>> idle;
+  size_t idle_bytes = 0;
+  static size_t limit() {
+    const char* e = getenv("GK_BLOCK_POOL_GB");
+    return (size_t)((e ? atof(e) : 6.0) * (double)((size_t)1 << 30));
+  }
+  void* take(size_t n, size_t& cap) {
+    {
+      std::lock_guard<std::mutex> g(lock);
+      size_t best = idle.size();
+      for (size_t i = 0; i < idle.size(); ++i)
+        if (idle[i].second >= n && idle[i].second <= 2 * n + (1u << 20) && (best == idle.size() || idle[i].second < idle[best].second)) best = i;
+      if (best != idle.size()) {
+        void* p = idle[best].first;
+        cap = idle[best].second;
+        idle_bytes -= cap;
+        idle.erase(idle.begin() + (ptrdiff_t)best);
+        return p;
+      }
+    }
+    cap = n + n / 16;   // room for the next file to be a little larger
+    return malloc(cap ? cap : 1);
+  }
+  void give(void* p, size_t cap) {
+    if (!p) return;
+    {
+      std::lock_guard<std::mutex> g(lock);
+      if (cap >= (1u << 20) && idle_bytes + cap <= limit()) {
+        idle.emplace_back(p, cap);
+        idle_bytes += cap;
+        return;
+      }
+    }
+    free(p);
+  }
+};
+BlockPool& block_pool() { static BlockPool* pool = new BlockPool(); return *pool; }   // never destroyed: threads may outlive main
+}  // namespace
+
+// array of trivially copyable items in a pooled block; new items are not initialised
+template <typename T>
+class Pooled {
+ public:
+  Pooled() = default;
+  explicit Pooled(size_t n) { resize(n); }
+  Pooled(const Pooled&) = delete;
+  Pooled& operator=(const Pooled&) = delete;
+  ~Pooled() { release(); }
+  T* data() { return p_; }
+  const T* data() const { return p_; }
+  T* begin() { return p_; }
+  T* end() { return p_ + size_; }
+  size_t size() const { return size_; }
+  bool empty() const { return size_ == 0; }
+  T& operator[](size_t i) { return p_[i]; }
+  const T& operator[](size_t i) const { return p_[i]; }
+  void clear() { size_ = 0; }
+  bool reserve(size_t n) {
+    if (n <= cap_) return true;
+    size_t cap_bytes = 0;
+    T* q = (T*)block_pool().take(n * sizeof(T), cap_bytes);
+    if (!q) return false;
+    if (size_) memcpy((void*)q, (const void*)p_, size_ * sizeof(T));
+    block_pool().give(p_, cap_ * sizeof(T) + slack_);
+    p_ = q;
+    cap_ = cap_bytes / sizeof(T);
+    slack_ = cap_bytes - cap_ * sizeof(T);
+    return true;
+  }
+  void resize(size_t n) {
+    if (!reserve(n)) throw std::bad_alloc();
+    size_ = n;
+  }
+  void append(const T* from, size_t n) {
+    if (size_ + n > cap_ && !reserve(std::max(size_ + n, 2 * cap_))) throw std::bad_alloc();
+    memcpy((void*)(p_ + size_), (const void*)from, n * sizeof(T));
+    size_ += n;
+  }
+  void swap(Pooled& o) { std::swap(p_, o.p_); std::swap(size_, o.size_); std::swap(cap_, o.cap_); std::swap(slack_, o.slack_); }
+  void release() {
+    block_pool().give(p_, cap_ * sizeof(T) + slack_);
+    p_ = nullptr;
+    size_ = cap_ = slack_ = 0;
+  }
+
+ private:
+  T* p_ = nullptr;
+  size_t size_ = 0, cap_ = 0, slack_ = 0;
+};
+using Bytes = Pooled<uint8_t>;
 
 struct gk_bam {
   Bytes data;                           // inflated BAM stream
   std::string header;                   // SAM header text ('@' lines)
   std::vector<std::string> ref_names;
   struct Rec { uint64_t off; uint32_t size; };
-  std::vector<Rec> recs;                // in output order after sorting
+  Pooled<Rec> recs;                     // in output order after sorting
   bool name_sorted = false;             // recs are in query-name order
   size_t next = 0;                      // next record to render
   std::string staged;                   // rendered lines not handed out yet
@@ -60,7 +159,7 @@ bool inflate_members(const Bytes& in, Bytes& out) {
   memset(&zs, 0, sizeof(zs));
   if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
   out.clear();
-  out.reserve(in.size() * 4);
+  if (!out.reserve(in.size() * 4)) return false;
   std::vector<uint8_t> buf(1 << 20);
   zs.next_in = const_cast<Bytef*>(in.data());
   zs.avail_in = 0;
@@ -76,7 +175,7 @@ bool inflate_members(const Bytes& in, Bytes& out) {
     zs.next_out = buf.data();
     zs.avail_out = (uInt)buf.size();
     const int rc = inflate(&zs, Z_NO_FLUSH);
-    out.insert(out.end(), buf.data(), buf.data() + (buf.size() - zs.avail_out));
+    out.append(buf.data(), buf.size() - zs.avail_out);
     if (rc == Z_STREAM_END) {
       if (zs.avail_in == 0 && consumed >= in.size()) break;
       if (inflateReset(&zs) != Z_OK) { ok = false; break; }   // next member
@@ -437,7 +536,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
     gk_set_error("%s is not a BGZF / gzip stream or is truncated", path);
     return GK_ERR_ARG;
   }
-  raw.clear(); raw.shrink_to_fit();
+  raw.release();
   clock.lap("inflate");
   const Bytes& d = b->data;
   auto bad = [&](const char* what) {
@@ -610,7 +709,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
     // Sample sort over the ingest threads: keyed records, splitters from a sample, one scatter into buckets whose
     // key ranges follow one another, then every bucket sorted on its own (a bucket fits a core's cache).
     const size_t n = b->recs.size();
-    std::vector<SortRec, GkRawInit<SortRec>> recs(n), sorted(n);
+    Pooled<SortRec> recs(n), sorted(n);
     const int n_thr = (int)std::max<size_t>(1, std::min<size_t>((size_t)ingest_threads(), n / 4096));
     auto part = [&](int t) { return n * (size_t)t / (size_t)n_thr; };
     auto on_all = [&](const std::function<void(int)>& work) {

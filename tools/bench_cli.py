@@ -16,7 +16,7 @@ folder = os.path.join(tmp, "index")
 prefix = os.path.join(folder, "kir_2100_withexon_ab_2dl1s1.leftalign.mut01")
 bams = [os.path.join(tmp, f"s{k}.bam") for k in range(n_samples)]
 cns = [os.path.join(tmp, f"s{k}.cn.tsv") for k in range(n_samples)]
-if rank == 0:
+if rank == 0 and not os.path.exists(os.path.join(tmp, "ready")):   # a second run from the same shell reuses the inputs
     os.makedirs(folder, exist_ok=True)
     sidx = synth.makeIndex(seed=2022)
     sidx.write(prefix)
@@ -55,6 +55,10 @@ if os.environ.get("GK_CLI_PROFILE") == "1":     # where does the main thread spe
 else:
     cli.main(args)
 dt = time.time() - t
+import resource
+ru = resource.getrusage(resource.RUSAGE_SELF)
+print(f"process CPU: {ru.ru_utime:.1f}s user + {ru.ru_stime:.1f}s system over {dt:.1f}s of wall = {(ru.ru_utime + ru.ru_stime) / dt:.1f} cores busy, "
+      f"{(ru.ru_utime + ru.ru_stime) / n_samples:.2f} core-s per sample (input generation included when this run made them)", file=sys.stderr)
 if rank == 0:
   print(f"command line: {dt:.2f}s for {n_samples} samples = {dt / n_samples:.2f}s per sample of {2 * n_pairs} reads "
       f"({2 * n_pairs * n_samples / dt / 1e6:.2f} M reads/s end to end; flags {extra})")
