@@ -68,6 +68,32 @@ typedef struct gk_mate {
   uint32_t ins[GK_MAX_INS]; /* string-table id of the k-th I op */
 } gk_mate;
 
+/* A mate that does not fit gk_mate (more ops, mismatches, inserted strings or events than it holds, an op longer
+ * than 4095, a mismatch beyond reference offset 65535) is kept in a second, rarely used format.  Both mates of
+ * such a pair go there: their gk_mate records keep the header fields, carry n_cig == GK_SPILLED and, in ins[0],
+ * the index of the pair in the wide array (records 2 * index and 2 * index + 1).  The device walks wide pairs with
+ * the same code as the others, one workgroup per pair, events in global memory. */
+#define GK_SPILLED 0xFF
+#define GK_WIDE_CIG 128
+#define GK_WIDE_MM 256
+#define GK_WIDE_INS 120
+#define GK_WIDE_EVENTS 384 /* mismatches + I ops + D ops of one wide mate */
+typedef struct gk_mate_wide {
+  uint32_t pos0;
+  uint16_t flag;
+  uint8_t ref;
+  uint8_t nh;
+  uint8_t nm;
+  uint8_t rsv0;
+  uint16_t n_cig;
+  uint16_t n_mm;
+  uint16_t n_ins;
+  uint32_t cig[GK_WIDE_CIG]; /* len << 4 | op, lengths up to 2^28 - 1 */
+  uint32_t mm[GK_WIDE_MM];   /* ref_off << 8 | read base (ASCII), offsets up to 2^24 - 1 */
+  uint32_t ins[GK_WIDE_INS]; /* string-table id of the k-th I op */
+  uint8_t rsv1[16];
+} gk_mate_wide; /* 2048 bytes */
+
 typedef struct gk_ctx gk_ctx;
 typedef struct gk_index gk_index;
 typedef struct gk_tab gk_tab;
@@ -130,6 +156,12 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates, int64_t n_pairs, gk
  * d_gene_pos0 int64 [n_gene + 1] = first position of every backbone in that table. */
 int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates, int64_t n_pairs, gk_dptr d_corr,
                           gk_dptr d_gene_pos0, gk_tab** out);
+/* Same for a sample with pairs in the wide format (gk_mate_wide above): wide = host array of 2 * n_spill records,
+ * spill_pair = the pairs they stand for, ascending (as gk_packer_spill_records hands them out).  The tabulation
+ * keeps a device copy of the wide records (gk_depth reads their CIGARs).  n_spill == 0: gk_tabulate_corrected. */
+int gk_tabulate_spilled(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates, int64_t n_pairs, gk_dptr d_corr,
+                        gk_dptr d_gene_pos0, const gk_mate_wide* wide, const int64_t* spill_pair, int64_t n_spill,
+                        gk_tab** out);
 /* Same handle from host CSR lists (the `.variant.json` hand-off of hisat2.py:847-866 loaded by
  * loadReadsAndVariantsData): off[4*n_valid+1] in list order lpv, rpv, lnv, rnv; ordinals < n_var_total. */
 int gk_tab_from_csr(gk_ctx* ctx, int32_t n_var_total, int64_t n_valid, const uint32_t* off, const uint32_t* ids,
@@ -297,6 +329,9 @@ int gk_packer_error(gk_packer* pk, int32_t* kind, int64_t* line_index);
  * storage -- e.g. gk_host_alloc memory, so the upload starts from where the decoder wrote; before the first feed */
 int gk_packer_set_output(gk_packer* pk, gk_mate* mates_out, int64_t capacity);
 int gk_packer_records(gk_packer* pk, gk_mate* mates_out, int64_t* pair_lines_out);
+/* pairs kept in the wide format: their count, then their records (2 per pair) and their pair indices (ascending) */
+int gk_packer_spilled(gk_packer* pk, int64_t* n_spilled_pairs);
+int gk_packer_spill_records(gk_packer* pk, gk_mate_wide* wide_out, int64_t* pair_index_out);
 const char* gk_packer_string(gk_packer* pk, int64_t i);
 
 /* ---- host ingest (no GPU, no samtools): BGZF / BAM -> SAM text lines, replacing the

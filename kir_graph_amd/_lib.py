@@ -34,6 +34,15 @@ MATE_DTYPE = np.dtype([
 ])
 assert MATE_DTYPE.itemsize == 128
 
+# gk_mate_wide: 2048 bytes, the rarely used second format for pairs that do not fit gk_mate
+MATE_WIDE_DTYPE = np.dtype([
+    ("pos0", "<u4"), ("flag", "<u2"), ("ref", "u1"), ("nh", "u1"), ("nm", "u1"), ("rsv0", "u1"),
+    ("n_cig", "<u2"), ("n_mm", "<u2"), ("n_ins", "<u2"),
+    ("cig", "<u4", (128,)), ("mm", "<u4", (256,)), ("ins", "<u4", (120,)), ("rsv1", "u1", (16,)),
+])
+assert MATE_WIDE_DTYPE.itemsize == 2048
+SPILLED = 0xFF
+
 CIG_M, CIG_I, CIG_D, CIG_S = 0, 1, 2, 4
 NM_ABSENT = 255
 MAX_CIG, MAX_MM, MAX_INS, MAX_EV = 14, 16, 6, 22
@@ -74,6 +83,8 @@ _SIGS = {
     "gk_index_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "gk_index_destroy": (C.c_int, [C.c_void_p]),
     "gk_tabulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_void_p)]),
+    "gk_tabulate_spilled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint64,
+                                     C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "gk_tabulate_corrected": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint64,
                                         C.POINTER(C.c_void_p)]),
     "gk_tab_from_csr": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -130,6 +141,8 @@ _SIGS = {
     "gk_packer_error": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "gk_packer_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gk_packer_set_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "gk_packer_spilled": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "gk_packer_spill_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gk_packer_string": (C.c_char_p, [C.c_void_p, C.c_int64]),
     "gk_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "gk_depth_write_tsv": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

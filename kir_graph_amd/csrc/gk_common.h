@@ -150,6 +150,8 @@ struct gk_tab {
   uint8_t* d_pair_gene = nullptr;
   uint8_t* d_pair_nh = nullptr;
   uint64_t* d_novel_key = nullptr;
+  gk_mate_wide* d_wide = nullptr;   // pairs in the wide format (2 records each): gk_depth reads their CIGARs
+  int64_t n_spill = 0;
   // rows grouped by backbone in row order, built once per (multiple) flavour on first use:
   // [0] reads mapped to one backbone only, [1] every read
   struct GenePartition {

@@ -13,6 +13,7 @@ namespace {
 constexpr int kThreads = 256;
 
 __global__ __launch_bounds__(kThreads) void depth_mark(const gk_mate* __restrict__ mates,
+                                                       const gk_mate_wide* __restrict__ wide,
                                                        const int32_t* __restrict__ pair_src,
                                                        const uint8_t* __restrict__ pair_nh, int64_t n_valid,
                                                        int multiple, const int64_t* __restrict__ gene_off, int n_gene,
@@ -25,9 +26,7 @@ __global__ __launch_bounds__(kThreads) void depth_mark(const gk_mate* __restrict
   if (m.ref >= n_gene) return;
   const int64_t base = gene_off[m.ref], len = gene_off[m.ref + 1] - base;
   int64_t cur = m.pos0;
-  const int n_cig = m.n_cig < GK_MAX_CIG ? m.n_cig : GK_MAX_CIG;
-  for (int c = 0; c < n_cig; ++c) {
-    const uint32_t op = m.cig[c] & 15u, n = m.cig[c] >> 4;
+  auto run = [&](uint32_t op, uint32_t n) {
     if (op == GK_CIG_M) {
       const int64_t a = cur < 0 ? 0 : cur, b = cur + n > len ? len : cur + n;
       if (b > a) {
@@ -38,7 +37,16 @@ __global__ __launch_bounds__(kThreads) void depth_mark(const gk_mate* __restrict
     } else if (op == GK_CIG_D) {
       cur += n;
     }
+  };
+  if (m.n_cig == GK_SPILLED) {   // the pair is in the wide array (gk_mate_wide): its CIGAR is there
+    if (!wide) return;
+    const gk_mate_wide& x = wide[2 * (int64_t)m.ins[0] + (t & 1)];
+    const int n_cig = x.n_cig < GK_WIDE_CIG ? x.n_cig : GK_WIDE_CIG;
+    for (int c = 0; c < n_cig; ++c) run(x.cig[c] & 15u, x.cig[c] >> 4);
+    return;
   }
+  const int n_cig = m.n_cig < GK_MAX_CIG ? m.n_cig : GK_MAX_CIG;
+  for (int c = 0; c < n_cig; ++c) run(m.cig[c] & 15u, m.cig[c] >> 4);
 }
 
 __global__ __launch_bounds__(kThreads) void depth_finish(const uint32_t* excl, const uint32_t* diff, int64_t n,
@@ -65,7 +73,7 @@ extern "C" int gk_depth(gk_ctx* ctx, gk_tab* tab, gk_dptr d_mates, int32_t multi
   GK_HIP(hipMemcpyAsync(d_off, gene_off, (size_t)(n_gene + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
   if (tab->n_valid)
     GK_KERNEL(depth_mark, dim3((unsigned)((2 * tab->n_valid + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
-                       gk_ptr<const gk_mate>(d_mates), tab->d_pair_src, tab->d_pair_nh, tab->n_valid, multiple, d_off,
+                       gk_ptr<const gk_mate>(d_mates), tab->d_wide, tab->d_pair_src, tab->d_pair_nh, tab->n_valid, multiple, d_off,
                        n_gene, diff);
   GK_HIP(hipMemcpyAsync(scan, diff, (size_t)(total + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   int rc = gk_scan_u32(ctx, scan, total + 1, nullptr);

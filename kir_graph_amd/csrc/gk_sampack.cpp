@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -64,6 +65,8 @@ struct gk_packer {
   gk_mate* ext = nullptr;            // caller's buffer (gk_packer_set_output) of ext_cap records
   int64_t ext_cap = 0;
   size_t n_mates = 0;                // records made so far (2 per pair)
+  std::vector<gk_mate_wide> wide;    // pairs that do not fit gk_mate (2 records per pair) ...
+  std::vector<int64_t> spill_pair;   // ... and which pairs they are, ascending
   gk_mate* mates() { return ext ? ext : own.data(); }
   bool resize_mates(size_t n) {      // new records are NOT initialised: the decoder writes every byte of them
     if (ext) {
@@ -126,21 +129,24 @@ struct Fail { int kind; std::string msg; };
 // GK_MAX_CIG ops and GK_MAX_MM mismatches are kept (what a record can hold); the counts run on so that the
 // capacity verdict comes after the walk's own checks, like a walk into growing lists.
 struct Walked {
-  uint16_t cig[GK_MAX_CIG];                     // len << 4 | GK_CIG_*
-  gk_mm mm[GK_MAX_MM];
+  uint32_t cig[GK_WIDE_CIG];                    // len << 4 | GK_CIG_* (for a clipped mate: its whole CIGAR, S ops included)
+  uint32_t mm[GK_WIDE_MM];                      // ref_off << 8 | read base
   size_t n_ops = 0, n_mm = 0, n_indel = 0;      // ops walked (S excluded), mismatches, I + D ops
-  bool long_op = false, far_mm = false;         // an op longer than 4095 / a mismatch beyond reference offset 65535
+  bool long_op = false, far_mm = false;         // an op longer than 4095 / a mismatch beyond reference offset 65535: not a gk_mate
+  bool huge = false;                            // an op of 2^28 or more / a mismatch at offset 2^24 or beyond: not even a wide one
   std::vector<std::string> ins;                 // inserted strings in I-op order (interned at merge time)
   bool clipped = false;
-  void reset() { n_ops = n_mm = n_indel = 0; long_op = far_mm = clipped = false; ins.clear(); }
+  void reset() { n_ops = n_mm = n_indel = 0; long_op = far_mm = huge = clipped = false; ins.clear(); }
   void op(int kind, long n) {
-    if (n_ops < GK_MAX_CIG) cig[n_ops] = (uint16_t)(((unsigned long)n << 4) | (unsigned)kind);
+    if (n_ops < GK_WIDE_CIG) cig[n_ops] = (uint32_t)(((unsigned long)n << 4) | (unsigned)kind);
     long_op = long_op || n > 4095;
+    huge = huge || n >= (1l << 28);
     ++n_ops;
   }
   void mismatch(long ref_off, unsigned char base) {
-    if (n_mm < GK_MAX_MM) { mm[n_mm].ref_off = (uint16_t)ref_off; mm[n_mm].base = base; }
+    if (n_mm < GK_WIDE_MM) mm[n_mm] = (uint32_t)(((unsigned long)ref_off << 8) | base);
     far_mm = far_mm || ref_off > 0xFFFF;
+    huge = huge || ref_off >= (1l << 24);
     ++n_mm;
   }
 };
@@ -205,7 +211,8 @@ struct ZsEntry { long gap; char kind; };
 struct Scratch {
   std::vector<MdTok> md;
   std::vector<ZsEntry> zs;
-  Walked w;
+  Walked w[2];                       // left and right mate of the pair being decoded
+  int side = 0;                      // the one being walked
   std::vector<std::pair<char, long>> text_ops;
   std::string seen_ref;              // neighbouring records are mostly of one backbone: the last name looked up
   int seen_id = -1;
@@ -216,7 +223,7 @@ template <typename Source>
 bool walk_alignment(const Source& src, bool has_md, sv md_s, bool has_zs, sv zs_s, Scratch& sc, Fail& f) {
   std::vector<MdTok>& md = sc.md;
   std::vector<ZsEntry>& zs = sc.zs;
-  Walked& w = sc.w;
+  Walked& w = sc.w[sc.side];
   md.clear();
   if (has_md) {
     for (size_t i = 0; i < md_s.size();) {
@@ -369,12 +376,15 @@ bool fail(gk_packer* pk, const Fail& f, int64_t line_index) {
 struct Outcome {
   std::vector<std::string> ins[2];   // inserted strings met by the walk of each mate, in order
   bool store_ins[2] = {false, false};   // ... and whether the record keeps their ids (not for clipped mates)
+  bool spilled = false;              // the pair does not fit two gk_mate records: it is in `wide`
+  size_t spill_slot = 0;             // ... which the decoding thread filed under this number of its own list
   Fail fail{0, ""};
   int64_t fail_line = -1;
 };
 
 struct Decoded : Outcome {
   gk_mate* rec = nullptr;            // the pair's two records, in their final place
+  gk_mate_wide wide[2];              // ... and in the wide format when `spilled`
   Scratch sc;
 };
 
@@ -418,7 +428,8 @@ void decode_records(const gk_packer* pk, const GkAlnRecord* pr, const int64_t* i
     r.nh = (uint8_t)std::min<long>(p.nh, 255);
     r.nm = p.has_nm ? (uint8_t)std::min<long>(std::max<long>(p.nm, 0), 254) : (uint8_t)GK_NM_ABSENT;
     if (!both) continue;
-    Walked& w = sc.w;
+    sc.side = s;
+    Walked& w = sc.w[s];
     w.reset();
     const bool binary = p.bam_cigar != nullptr;
     const bool walked =
@@ -429,14 +440,10 @@ void decode_records(const gk_packer* pk, const GkAlnRecord* pr, const int64_t* i
     if (!walked) return failed(f, idx[s]);
     if (w.clipped) {   // its strings are still interned at merge time, the record keeps none of them
       // keep the CIGAR (S ops included) for read depth when it fits, else only the clip marker
-      uint16_t full[GK_MAX_CIG];
-      size_t n_full = 0;
-      bool fits = true;
+      w.n_ops = 0;
+      w.long_op = w.huge = false;
       auto add = [&](char op, long n) {
-        if (n_full < GK_MAX_CIG)
-          full[n_full] = (uint16_t)(((unsigned long)n << 4) | (unsigned)(op == 'S' ? GK_CIG_S : op == 'M' ? GK_CIG_M : op == 'I' ? GK_CIG_I : GK_CIG_D));
-        fits = fits && n <= 4095;
-        ++n_full;
+        w.op(op == 'S' ? GK_CIG_S : op == 'M' ? GK_CIG_M : op == 'I' ? GK_CIG_I : GK_CIG_D, n);
       };
       if (binary) {
         const BamSource src{p.bam_cigar, p.bam_seq, p.n_bam_cigar, p.l_bam_seq};
@@ -455,19 +462,52 @@ void decode_records(const gk_packer* pk, const GkAlnRecord* pr, const int64_t* i
           add(cg[i++], n);
         }
       }
-      fits = fits && n_full <= GK_MAX_CIG;
-      if (!fits) { n_full = 1; full[0] = (uint16_t)GK_CIG_S; }   // {S, 0}
-      r.n_cig = (uint8_t)n_full;
-      for (size_t i = 0; i < n_full; ++i) r.cig[i] = full[i];
+      const bool narrow_ok = w.n_ops <= GK_MAX_CIG && !w.long_op;
+      const bool wide_ok = w.n_ops <= GK_WIDE_CIG && !w.huge;
+      if (!narrow_ok && wide_ok) out.spilled = true;                                        // its M runs count for the depth
+      if (!narrow_ok && !wide_ok) { w.n_ops = 1; w.cig[0] = (uint32_t)GK_CIG_S; }           // {S, 0}: in neither format
+      if (narrow_ok || !wide_ok) {
+        r.n_cig = (uint8_t)w.n_ops;
+        for (size_t i = 0; i < w.n_ops; ++i) r.cig[i] = (uint16_t)w.cig[i];
+      }
+      w.n_mm = 0;
       continue;
     }
-    const bool fits = w.n_ops <= GK_MAX_CIG && w.n_mm <= GK_MAX_MM && out.ins[s].size() <= GK_MAX_INS &&
+    const size_t n_ins = out.ins[s].size();
+    const bool fits = w.n_ops <= GK_MAX_CIG && w.n_mm <= GK_MAX_MM && n_ins <= GK_MAX_INS &&
                       w.n_mm + w.n_indel <= GK_MAX_EVENTS && !w.long_op && !w.far_mm;
-    if (!fits) return failed({3, "record does not fit gk_mate"}, idx[s]);
-    r.n_cig = (uint8_t)w.n_ops; r.n_mm = (uint8_t)w.n_mm; r.n_ins = (uint8_t)out.ins[s].size();
     out.store_ins[s] = true;
-    for (size_t i = 0; i < w.n_ops; ++i) r.cig[i] = w.cig[i];
-    for (size_t i = 0; i < w.n_mm; ++i) { r.mm[i].ref_off = w.mm[i].ref_off; r.mm[i].base = w.mm[i].base; }
+    if (!fits) {
+      // the second format (gk_mate_wide) takes the pair; beyond that one too the mate cannot be represented
+      const bool wide_fits = w.n_ops <= GK_WIDE_CIG && w.n_mm <= GK_WIDE_MM && n_ins <= GK_WIDE_INS &&
+                             w.n_mm + w.n_indel <= GK_WIDE_EVENTS && !w.huge;
+      if (!wide_fits) return failed({3, "record does not fit gk_mate_wide"}, idx[s]);
+      out.spilled = true;
+      continue;
+    }
+    r.n_cig = (uint8_t)w.n_ops; r.n_mm = (uint8_t)w.n_mm; r.n_ins = (uint8_t)n_ins;
+    for (size_t i = 0; i < w.n_ops; ++i) r.cig[i] = (uint16_t)w.cig[i];
+    for (size_t i = 0; i < w.n_mm; ++i) { r.mm[i].ref_off = (uint16_t)(w.mm[i] >> 8); r.mm[i].base = (uint8_t)(w.mm[i] & 0xFFu); }
+  }
+  if (!out.spilled) return;
+  // both mates move to the wide array; their gk_mate records keep the header and point there (the index of the
+  // pair in that array is known once the pairs of all threads are in order: decode_all fills ins[0])
+  for (int s = 0; s < 2; ++s) {
+    gk_mate& r = out.rec[s];
+    const Walked& w = out.sc.w[s];
+    gk_mate_wide& x = out.wide[s];
+    memset(&x, 0, sizeof(x));
+    x.pos0 = r.pos0; x.flag = r.flag; x.ref = r.ref; x.nh = r.nh; x.nm = r.nm;
+    x.n_cig = (uint16_t)w.n_ops;
+    x.n_mm = (uint16_t)w.n_mm;
+    x.n_ins = (uint16_t)(out.store_ins[s] ? out.ins[s].size() : 0);
+    for (size_t i = 0; i < w.n_ops; ++i) x.cig[i] = w.cig[i];
+    for (size_t i = 0; i < w.n_mm; ++i) x.mm[i] = w.mm[i];
+    gk_mate header;
+    memset(&header, 0, sizeof(header));
+    header.pos0 = r.pos0; header.flag = r.flag; header.ref = r.ref; header.nh = r.nh; header.nm = r.nm;
+    header.n_cig = GK_SPILLED;
+    r = header;
   }
 }
 
@@ -505,11 +545,15 @@ bool decode_all(gk_packer* pk, size_t n, const DecodeOne& decode, const LineOf& 
   gk_mate* const mates = pk->mates();
   pk->pair_lines.resize(2 * (first + n));
   std::vector<std::vector<Special>> special((size_t)pack_threads() + 1);
+  struct Spill { size_t pair; gk_mate_wide w[2]; };
+  std::vector<std::vector<Spill>> spills((size_t)pack_threads() + 1);   // per thread, ascending pairs
   on_threads(n, [&](int t, size_t a, size_t b) {
-    Decoded d;
+    std::unique_ptr<Decoded> holder(new Decoded());   // two wide records inside: not for the stack
+    Decoded& d = *holder;
     for (size_t i = a; i < b; ++i) {
       d.ins[0].clear(); d.ins[1].clear();
       d.store_ins[0] = d.store_ins[1] = false;
+      d.spilled = false;
       d.fail.kind = 0;
       d.fail.msg.clear();
       d.fail_line = -1;
@@ -517,6 +561,11 @@ bool decode_all(gk_packer* pk, size_t n, const DecodeOne& decode, const LineOf& 
       decode(i, d);
       pk->pair_lines[2 * (first + i)] = line_of(i, 0);
       pk->pair_lines[2 * (first + i) + 1] = line_of(i, 1);
+      if (d.fail.kind) d.spilled = false;
+      if (d.spilled) {
+        d.spill_slot = spills[(size_t)t].size();
+        spills[(size_t)t].push_back(Spill{i, {d.wide[0], d.wide[1]}});
+      }
       if (!d.fail.kind && d.ins[0].empty() && d.ins[1].empty()) continue;
       // A string that is in the table already (an index string, or one met in an earlier feed) has its final id:
       // the table is not written to while the threads decode.  Only pairs with a string met for the first time,
@@ -526,13 +575,31 @@ bool decode_all(gk_packer* pk, size_t n, const DecodeOne& decode, const LineOf& 
         for (size_t q = 0; q < d.ins[s].size(); ++q) {
           auto it = pk->ins_id.find(d.ins[s][q]);
           if (it == pk->ins_id.end()) { settled = false; break; }
-          if (d.store_ins[s] && q < GK_MAX_INS) d.rec[s].ins[q] = it->second;
+          if (!d.store_ins[s]) continue;
+          if (d.spilled) {
+            if (q < GK_WIDE_INS) spills[(size_t)t][d.spill_slot].w[s].ins[q] = it->second;
+          } else if (q < GK_MAX_INS) {
+            d.rec[s].ins[q] = it->second;
+          }
         }
       if (!settled) special[(size_t)t].push_back(Special{i, static_cast<const Outcome&>(d)});
     }
   });
-  for (auto& list : special) {   // threads own ascending ranges: this walks the pairs in order
-    for (Special& sp : list) {
+  // the wide pairs of all threads, in pair order, join the packer's wide array; their gk_mate records learn where
+  auto file_spills = [&](size_t n_kept) {
+    for (auto& list : spills)
+      for (Spill& sp : list) {
+        if (sp.pair >= n_kept) continue;
+        const uint32_t at = (uint32_t)(pk->wide.size() / 2);
+        pk->wide.push_back(sp.w[0]);
+        pk->wide.push_back(sp.w[1]);
+        pk->spill_pair.push_back((int64_t)(first + sp.pair));
+        mates[2 * (first + sp.pair)].ins[0] = at;
+        mates[2 * (first + sp.pair) + 1].ins[0] = at;
+      }
+  };
+  for (size_t t = 0; t < special.size(); ++t) {   // threads own ascending ranges: this walks the pairs in order
+    for (Special& sp : special[t]) {
       gk_mate* dst = mates + 2 * (first + sp.pair);
       for (int s = 0; s < 2; ++s) {
         for (size_t q = 0; q < sp.d.ins[s].size(); ++q) {
@@ -545,16 +612,23 @@ bool decode_all(gk_packer* pk, size_t n, const DecodeOne& decode, const LineOf& 
           } else {
             id = it->second;
           }
-          if (sp.d.store_ins[s] && q < GK_MAX_INS) dst[s].ins[q] = id;
+          if (!sp.d.store_ins[s]) continue;
+          if (sp.d.spilled) {
+            if (q < GK_WIDE_INS) spills[t][sp.d.spill_slot].w[s].ins[q] = id;
+          } else if (q < GK_MAX_INS) {
+            dst[s].ins[q] = id;
+          }
         }
       }
       if (sp.d.fail.kind) {   // the pairs before it stay, like a one-by-one walk
+        file_spills(sp.pair);
         pk->resize_mates(2 * (first + sp.pair));
         pk->pair_lines.resize(2 * (first + sp.pair));
         return fail(pk, sp.d.fail, sp.d.fail_line);
       }
     }
   }
+  file_spills(n);
   return true;
 }
 
@@ -870,6 +944,19 @@ int gk_packer_records(gk_packer* pk, gk_mate* mates_out, int64_t* pair_lines_out
   }
   if (pair_lines_out && !pk->pair_lines.empty())
     memcpy(pair_lines_out, pk->pair_lines.data(), pk->pair_lines.size() * sizeof(int64_t));
+  return GK_OK;
+}
+
+int gk_packer_spilled(gk_packer* pk, int64_t* n_spilled_pairs) {
+  if (!pk || !n_spilled_pairs) return GK_ERR_ARG;
+  *n_spilled_pairs = (int64_t)pk->spill_pair.size();
+  return GK_OK;
+}
+
+int gk_packer_spill_records(gk_packer* pk, gk_mate_wide* wide_out, int64_t* pair_index_out) {
+  if (!pk) return GK_ERR_ARG;
+  if (wide_out && !pk->wide.empty()) memcpy(wide_out, pk->wide.data(), pk->wide.size() * sizeof(gk_mate_wide));
+  if (pair_index_out && !pk->spill_pair.empty()) memcpy(pair_index_out, pk->spill_pair.data(), pk->spill_pair.size() * sizeof(int64_t));
   return GK_OK;
 }
 

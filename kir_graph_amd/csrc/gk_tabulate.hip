@@ -46,7 +46,9 @@ constexpr uint32_t kEvOrdMask = (1u << 26) - 1;
 
 // a staged record, read out of LDS
 struct MateView {
+  static constexpr int kCapCig = GK_MAX_CIG, kCapMm = GK_MAX_MM, kCapIns = GK_MAX_INS, kCapEv = kMaxEv;
   const uint32_t* w;
+  __device__ bool spilled() const { return n_cig() == GK_SPILLED; }   // the pair is in the wide array
   __device__ uint32_t pos0() const { return w[0]; }
   __device__ uint32_t flag() const { return w[1] & 0xFFFFu; }
   __device__ uint32_t ref() const { return (w[1] >> 16) & 0xFFu; }
@@ -62,6 +64,24 @@ struct MateView {
   __device__ uint32_t ins(int i) const { return w[kInsWord + i]; }
   __device__ bool passes() const { return (flag() & 2u) && nm() != GK_NM_ABSENT && nm() <= 4u; }
 };
+
+// a record of the wide format (gk_mate_wide), read where it lies in global memory: such pairs are rare
+struct WideView {
+  static constexpr int kCapCig = GK_WIDE_CIG, kCapMm = GK_WIDE_MM, kCapIns = GK_WIDE_INS, kCapEv = GK_WIDE_EVENTS;
+  const gk_mate_wide* p;
+  __device__ uint32_t pos0() const { return p->pos0; }
+  __device__ uint32_t flag() const { return p->flag; }
+  __device__ uint32_t ref() const { return p->ref; }
+  __device__ uint32_t nm() const { return p->nm; }
+  __device__ uint32_t n_cig() const { return p->n_cig; }
+  __device__ uint32_t n_mm() const { return p->n_mm; }
+  __device__ uint32_t cig(int i) const { return p->cig[i]; }
+  __device__ uint32_t mm_off(int i) const { return p->mm[i] >> 8; }
+  __device__ uint32_t mm_base(int i) const { return p->mm[i] & 0xFFu; }
+  __device__ uint32_t ins(int i) const { return p->ins[i]; }
+  __device__ bool passes() const { return (flag() & 2u) && nm() != GK_NM_ABSENT && nm() <= 4u; }
+};
+static_assert(sizeof(gk_mate_wide) == 2048, "gk_mate_wide layout");
 
 // the workgroup's records [m0, m0 + 256) -> LDS, coalesced
 __device__ inline void stage_mates(const gk_mate* mates, int64_t m0, int64_t n_mates, uint32_t* rec) {
@@ -181,13 +201,15 @@ struct Walked {
 
 // ev_out (pass 1 only, may be null): the positive list of the mate as it will be emitted -- the ordinal of a
 // known variant, kEvNovel | slot of the novel table otherwise -- so that pass 2 need not walk again.
-template <bool kEmit>
-__device__ inline void walk_mate(const MateView& r, const IndexView& ix, const NovelTable& nt, int64_t m,
+// seq_stride: sequence numbers of novel variants are mate * seq_stride + event (first appearance = smallest);
+// the stride is the event capacity of the widest record format present in the sample.
+template <bool kEmit, typename View>
+__device__ inline void walk_mate(const View& r, const IndexView& ix, const NovelTable& nt, int64_t m, uint32_t seq_stride,
                                  uint32_t* evw, uint32_t* ids, uint32_t o_pos, uint32_t o_pos_end, uint32_t* ev_out,
                                  Walked& wk) {
   wk.n = 0; wk.clipped = false; wk.overflow = false; wk.drop = false; wk.any_n = 0; wk.bad_window = false;
   wk.lo = wk.hi = 0; wk.right = 0;
-  const int n_cig = min((int)r.n_cig(), GK_MAX_CIG);
+  const int n_cig = min((int)r.n_cig(), View::kCapCig);
   // a soft-clipped read yields no variants at all and registers no novel ones (hisat2.py:681-684: returned before findVariantId)
   for (int c = 0; c < n_cig; ++c) wk.clipped |= (r.cig(c) & 15u) == GK_CIG_S;
   if (wk.clipped) return;
@@ -196,11 +218,11 @@ __device__ inline void walk_mate(const MateView& r, const IndexView& ix, const N
   const uint32_t ref = r.ref(), pos0 = r.pos0();
   uint32_t cur = pos0;
   int mi = 0, ii = 0;
-  const int n_mm = min((int)r.n_mm(), GK_MAX_MM);
+  const int n_mm = min((int)r.n_mm(), View::kCapMm);
 
   auto event = [&](uint32_t pos, uint32_t len, uint32_t typ, uint32_t val) {
     last_is_event = true;
-    if (wk.n >= kMaxEv) { wk.overflow = true; return; }
+    if (wk.n >= View::kCapEv) { wk.overflow = true; return; }
     if (ix.corr && typ == GK_TYP_SINGLE && (int)ref < ix.n_gene) {
       const int code = val == 'A' ? 0 : val == 'C' ? 1 : val == 'G' ? 2 : val == 'T' ? 3 : val == 'N' ? 4 : -1;
       const int64_t at = ix.gene_pos0[ref] + pos;
@@ -221,7 +243,7 @@ __device__ inline void walk_mate(const MateView& r, const IndexView& ix, const N
         ids[o_pos + wk.n] = known ? (uint32_t)i : (uint32_t)ix.n_var + novel_rank(nt, k);
     } else {
       uint32_t saved = (uint32_t)i;
-      if (!known) saved = kEvNovel | novel_insert(nt, k, (uint32_t)(m * kMaxEv + wk.n));
+      if (!known) saved = kEvNovel | novel_insert(nt, k, (uint32_t)(m * seq_stride + wk.n));
       if (ev_out) ev_out[wk.n] = saved;
     }
     last_pos = pos; last_len = len; last_novel = !known;
@@ -243,7 +265,7 @@ __device__ inline void walk_mate(const MateView& r, const IndexView& ix, const N
       if (seg < end) last_is_event = false;  // trailing match segment
       cur = end;
     } else if (op == GK_CIG_I) {
-      event(cur, len, GK_TYP_INS, ii < GK_MAX_INS ? r.ins(ii) : 0u);
+      event(cur, len, GK_TYP_INS, ii < View::kCapIns ? r.ins(ii) : 0u);
       ++ii;
     } else if (op == GK_CIG_D) {
       event(cur, len, GK_TYP_DEL, len);
@@ -393,7 +415,7 @@ __device__ inline uint32_t window_negatives(const IndexView& ix, const uint32_t*
 // pass 1: validity, counts, novel registration.  One lane per mate; mates of a pair sit in
 // adjacent lanes so the pair verdict is one lane shuffle.
 __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int64_t n_mates, IndexView ix,
-                                                      NovelTable nt, uint32_t* cnt /*[4*n_pairs+1]*/,
+                                                      NovelTable nt, uint32_t seq_stride, uint32_t* cnt /*[4*n_pairs+1]*/,
                                                       uint32_t* valid /*[n_pairs]*/, int* err_flags,
                                                       uint32_t* ev_save /*[n_mates][kMaxEv]*/,
                                                       uint32_t* lo_save /*[n_mates]*/,
@@ -407,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
   const bool in = m < n_mates;
   const MateView r{rec + threadIdx.x * kRecLd};
   uint32_t* evw = evs + threadIdx.x * kEvLd;
-  const bool ok = in && r.passes();
+  const bool ok = in && r.passes() && !r.spilled();   // wide pairs: tab_count_wide writes their counts afterwards
   const bool ok_other = __shfl_xor((int)ok, 1, 64) != 0;
   const bool pair_ok = ok && ok_other;
   const int64_t pair = m >> 1;
@@ -417,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
   wk.n = 0; wk.lo = wk.hi = 0; wk.right = 0; wk.any_n = 0;
   bool enumerate = false;
   if (pair_ok) {
-    walk_mate<false>(r, ix, nt, m, evw, nullptr, 0, 0, ev_save + m * kMaxEv, wk);
+    walk_mate<false>(r, ix, nt, m, seq_stride, evw, nullptr, 0, 0, ev_save + m * kMaxEv, wk);
     if (wk.overflow) atomicOr(err_flags, 2);
     if (wk.clipped) {
     } else if (wk.bad_window) {
@@ -510,19 +532,74 @@ __global__ __launch_bounds__(kThreads) void tab_emit(const gk_mate* mates, int64
   const int64_t pair = m >> 1;
   const int side = (int)(m & 1);
   uint32_t o_pos = 0, o_pos_end = 0, o_neg = 0, o_neg_end = 0;
-  if (m < n_mates && valid[pair]) {
+  const MateView r{rec + threadIdx.x * kRecLd};
+  if (m < n_mates && valid[pair] && !r.spilled()) {   // wide pairs: tab_emit_wide writes their lists
     o_pos = off[4 * pair + side]; o_pos_end = off[4 * pair + side + 1];
     o_neg = off[4 * pair + 2 + side]; o_neg_end = off[4 * pair + 2 + side + 1];
   }
-  const MateView r{rec + threadIdx.x * kRecLd};
   uint32_t* evw = evs + threadIdx.x * kEvLd;
   Walked wk;
   wk.n = 0; wk.lo = wk.hi = 0; wk.right = 0; wk.any_n = 0;
-  if (o_pos != o_pos_end || o_neg != o_neg_end) walk_mate<true>(r, ix, nt, m, evw, ids, o_pos, o_pos_end, nullptr, wk);
+  if (o_pos != o_pos_end || o_neg != o_neg_end) walk_mate<true>(r, ix, nt, m, 0u, evw, ids, o_pos, o_pos_end, nullptr, wk);
   const int wid = threadIdx.x >> 6;
   // a mate with an empty negative list has nothing to enumerate (its window may still be non-empty)
   cooperative_negatives<true>(wneg[wid], ix, evs + wid * 64 * kEvLd, o_neg != o_neg_end ? (uint32_t)(wk.hi - wk.lo) : 0u,
                               (uint32_t)wk.lo, wk.right, (uint32_t)wk.n, wk.any_n, o_neg, ids);
+}
+
+// The pairs of the wide format, one lane per mate (mates of a pair in adjacent lanes), records and event words in
+// global memory, windows enumerated candidate by candidate: the same walk and the same rules as above, without the
+// staging -- there are a handful of such pairs in a sample, if any.
+__global__ __launch_bounds__(64) void tab_count_wide(const gk_mate_wide* wide, const int64_t* spill_pair, int64_t n_spill,
+                                                     IndexView ix, NovelTable nt, uint32_t seq_stride, uint32_t* cnt,
+                                                     uint32_t* valid, int* err_flags, uint32_t* evw_all) {
+  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool in = t < 2 * n_spill;
+  const WideView r{wide + (in ? t : 0)};
+  const bool ok = in && r.passes();
+  const bool ok_other = __shfl_xor((int)ok, 1, 64) != 0;
+  const bool pair_ok = ok && ok_other;
+  if (!in) return;
+  const int64_t pair = spill_pair[t >> 1];
+  const int side = (int)(t & 1);
+  uint32_t* evw = evw_all + t * GK_WIDE_EVENTS;
+  uint32_t n_pos = 0, n_neg = 0;
+  if (pair_ok) {
+    Walked wk;
+    walk_mate<false>(r, ix, nt, 2 * pair + side, seq_stride, evw, nullptr, 0, 0, nullptr, wk);
+    if (wk.overflow) atomicOr(err_flags, 2);
+    if (wk.clipped) {
+    } else if (wk.bad_window) {
+      atomicOr(err_flags, 1);
+    } else if (!wk.drop) {
+      n_pos = (uint32_t)wk.n;
+      for (int i = wk.lo; i < wk.hi; ++i)
+        n_neg += negative_kept(ix.key[i], i, ix, evw, wk.n, wk.any_n, wk.right) ? 1u : 0u;
+    }
+  }
+  cnt[4 * pair + side] = n_pos;
+  cnt[4 * pair + 2 + side] = n_neg;
+  if (side == 0) valid[pair] = pair_ok ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(64) void tab_emit_wide(const gk_mate_wide* wide, const int64_t* spill_pair, int64_t n_spill,
+                                                    IndexView ix, NovelTable nt, const uint32_t* off,
+                                                    const uint32_t* valid, uint32_t* ids, uint32_t* evw_all) {
+  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (t >= 2 * n_spill) return;
+  const int64_t pair = spill_pair[t >> 1];
+  const int side = (int)(t & 1);
+  if (!valid[pair]) return;
+  const uint32_t o_pos = off[4 * pair + side], o_pos_end = off[4 * pair + side + 1];
+  const uint32_t o_neg = off[4 * pair + 2 + side], o_neg_end = off[4 * pair + 2 + side + 1];
+  if (o_pos == o_pos_end && o_neg == o_neg_end) return;
+  const WideView r{wide + t};
+  uint32_t* evw = evw_all + t * GK_WIDE_EVENTS;
+  Walked wk;
+  walk_mate<true>(r, ix, nt, 2 * pair + side, 0u, evw, ids, o_pos, o_pos_end, nullptr, wk);
+  uint32_t at = o_neg;
+  for (int i = wk.lo; i < wk.hi && at < o_neg_end; ++i)
+    if (negative_kept(ix.key[i], i, ix, evw, wk.n, wk.any_n, wk.right)) ids[at++] = (uint32_t)i;
 }
 
 __global__ __launch_bounds__(kThreads) void gather_pairs(const gk_mate* mates, const int32_t* pair_src, int64_t n_valid,
@@ -635,8 +712,22 @@ int gk_tabulate(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, 
 
 int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, gk_dptr d_corr,
                           gk_dptr d_gene_pos0, gk_tab** out) {
+  return gk_tabulate_spilled(ctx, idx, d_mates_p, n_pairs, d_corr, d_gene_pos0, nullptr, nullptr, 0, out);
+}
+
+int gk_tabulate_spilled(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, gk_dptr d_corr,
+                        gk_dptr d_gene_pos0, const gk_mate_wide* wide, const int64_t* spill_pair, int64_t n_spill,
+                        gk_tab** out) {
   gk_bind(ctx);
   GK_REQUIRE(ctx && idx && out && n_pairs >= 0, "bad tabulate arguments");
+  GK_REQUIRE(n_spill >= 0 && n_spill <= n_pairs && (n_spill == 0 || (wide && spill_pair)), "bad wide-pair arguments");
+  for (int64_t k = 0; k < n_spill; ++k)
+    GK_REQUIRE(spill_pair[k] >= 0 && spill_pair[k] < n_pairs && (k == 0 || spill_pair[k - 1] < spill_pair[k]),
+               "wide pairs must name pairs of the sample, ascending");
+  // sequence numbers of novel variants are 32-bit: mate * (event capacity of the widest format present) + event
+  const uint32_t seq_stride = n_spill ? (uint32_t)GK_WIDE_EVENTS : (uint32_t)kMaxEv;
+  GK_REQUIRE((uint64_t)2 * (uint64_t)n_pairs * seq_stride < (1ull << 32),
+             "too many pairs for one call when some are in the wide format: split the sample");
   GK_REQUIRE((d_corr == 0) == (d_gene_pos0 == 0), "correction table and position offsets come together");
   GK_REQUIRE(n_pairs < (1ll << 26), "more than 2^26 pairs per call");
   const gk_mate* mates = gk_ptr<const gk_mate>(d_mates_p);
@@ -674,14 +765,27 @@ int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t
                      idx->d_gene_pbase};
   if (n_mates) {
     GK_PROF(ctx, GK_K_TAB_COUNT, GK_KERNEL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
-                       nt, cnt, valid, d_err, ev_save, lo_save, mask_save));
+                       nt, seq_stride, cnt, valid, d_err, ev_save, lo_save, mask_save));
+  }
+  int64_t* d_spill_pair = nullptr;
+  uint32_t* wide_ev = nullptr;
+  if (n_spill) {   // the wide pairs overwrite the zeros the kernel above left for them
+    GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_wide, (size_t)(2 * n_spill) * sizeof(gk_mate_wide)));
+    GK_HIP(gk_pool_malloc(ctx, (void**)&d_spill_pair, (size_t)n_spill * sizeof(int64_t)));
+    GK_HIP(gk_pool_malloc(ctx, (void**)&wide_ev, (size_t)(2 * n_spill) * GK_WIDE_EVENTS * sizeof(uint32_t)));
+    GK_HIP(hipMemcpyAsync(tab->d_wide, wide, (size_t)(2 * n_spill) * sizeof(gk_mate_wide), hipMemcpyHostToDevice, st));
+    GK_HIP(hipMemcpyAsync(d_spill_pair, spill_pair, (size_t)n_spill * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    GK_HIP(hipStreamSynchronize(st));   // the caller's arrays are free again
+    tab->n_spill = n_spill;
+    GK_KERNEL(tab_count_wide, dim3(nblk(2 * n_spill, 64)), dim3(64), 0, st, tab->d_wide, d_spill_pair, n_spill, ix, nt,
+              seq_stride, cnt, valid, d_err, wide_ev);
   }
   // offsets over input pairs (invalid pairs contribute zeros)
   int rc = gk_scan_u32(ctx, cnt, 4 * n_pairs, cnt + 4 * n_pairs);
   if (rc) return rc;
 
   // novel ranks
-  const int64_t n_seq = n_mates * kMaxEv;
+  const int64_t n_seq = n_mates * (int64_t)seq_stride;
   const int64_t n_words = (n_seq + 31) / 32 + 1;
   uint32_t *bitmap = nullptr, *prefix = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&bitmap, (size_t)n_words * sizeof(uint32_t)));
@@ -714,9 +818,12 @@ int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t
   if (n_mates) {
     // pass 2: from what pass 1 saved; the second walk only when some window did not fit the saved bits
     const bool two_walks = getenv("GK_TAB_TWO_WALKS") != nullptr;   // development / test switch
-    if ((err & 4) || two_walks) {
+    if ((err & 4) || two_walks || n_spill) {   // (tab_expand reads what pass 1 saved: nothing for wide pairs)
       GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix, nt,
                          cnt, valid, tab->d_ids));
+      if (n_spill)
+        GK_KERNEL(tab_emit_wide, dim3(nblk(2 * n_spill, 64)), dim3(64), 0, st, tab->d_wide, d_spill_pair, n_spill, ix, nt,
+                  cnt, valid, tab->d_ids, wide_ev);
     } else {
       GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_expand, dim3(nblk(n_mates)), dim3(kThreads), 0, st, n_mates, idx->n_var,
                          nt.rank, cnt, valid, ev_save, lo_save, mask_save, tab->d_ids));
@@ -735,9 +842,11 @@ int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t
   GK_HIP(hipStreamSynchronize(st));
   gk_pool_free(ctx,cnt); gk_pool_free(ctx,valid); gk_pool_free(ctx,d_err); gk_pool_free(ctx,bitmap); gk_pool_free(ctx,prefix);
   gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save);
+  gk_pool_free(ctx,d_spill_pair); gk_pool_free(ctx,wide_ev);
   gk_pool_free(ctx,nt.keys); gk_pool_free(ctx,nt.seq); gk_pool_free(ctx,nt.rank);
   if (err & 2) {
-    gk_set_error("a filter-passing mate carries more than %d variant events", kMaxEv);
+    gk_set_error("a filter-passing mate carries more variant events than its record format allows (%d, wide %d)", kMaxEv,
+                 GK_WIDE_EVENTS);
     gk_tab_destroy(tab);
     return GK_ERR_CAPACITY;
   }
@@ -788,6 +897,7 @@ int gk_tab_destroy(gk_tab* tab) {
   gk_ctx* ctx = tab->ctx;
   gk_pool_free(ctx,tab->d_pair_src); gk_pool_free(ctx,tab->d_off); gk_pool_free(ctx,tab->d_ids);
   gk_pool_free(ctx,tab->d_pair_gene); gk_pool_free(ctx,tab->d_pair_nh); gk_pool_free(ctx,tab->d_novel_key);
+  gk_pool_free(ctx,tab->d_wide);
   for (auto& part : tab->part)
     if (part.d_rows) gk_pool_free(part.owner, part.d_rows);
   delete tab;

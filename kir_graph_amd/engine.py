@@ -65,10 +65,13 @@ class Tabulation:
     """Result of ``gk_tabulate`` for one sample (replaces the ``.variant.json`` hand-off)."""
 
     def __init__(self, dindex: DeviceIndex, mates, novel_base: int = 0, dev: Device | None = None,
-                 correction: tuple[np.ndarray, np.ndarray] | None = None):
+                 correction: tuple[np.ndarray, np.ndarray] | None = None,
+                 spill: tuple[np.ndarray, np.ndarray] | None = None):
         """``dev``: context (stream) that runs the tabulation; defaults to the index's own.
         ``correction``: (``pileup.correctionTable`` uint8 [positions][5], first position of every backbone
-        int64 [genes + 1]) -- the pileup error correction of mismatches, off when None."""
+        int64 [genes + 1]) -- the pileup error correction of mismatches, off when None.
+        ``spill``: (records of the pairs that do not fit ``gk_mate``, in the wide format, 2 per pair; the pairs they
+        stand for, ascending) as the packer hands them out -- None when every pair fits."""
         self.dev, self.dindex = dev or dindex.dev, dindex
         if isinstance(mates, np.ndarray):
             assert mates.dtype == _lib.MATE_DTYPE
@@ -77,13 +80,22 @@ class Tabulation:
             self.mates = mates
         self.n_pairs = self.mates.size // 2
         h = C.c_void_p()
-        if correction is None:
-            check(lib().gk_tabulate(self.dev.ctx, dindex.handle, self.mates.ptr, self.n_pairs, C.byref(h)))
-        else:
+        d_table = d_pos0 = None
+        if correction is not None:
             table, pos0 = correction
             assert table.dtype == np.uint8 and table.shape == (int(pos0[-1]), 5) and len(pos0) == len(dindex.host.genes) + 1
             d_table = self.dev.put(np.ascontiguousarray(table).reshape(-1) if table.size else np.zeros(1, np.uint8))
             d_pos0 = self.dev.put(np.ascontiguousarray(pos0, dtype=np.int64))
+        if spill is not None and len(spill[1]):
+            wide = np.ascontiguousarray(spill[0], dtype=_lib.MATE_WIDE_DTYPE)
+            which = np.ascontiguousarray(spill[1], dtype=np.int64)
+            assert len(wide) == 2 * len(which)
+            check(lib().gk_tabulate_spilled(self.dev.ctx, dindex.handle, self.mates.ptr, self.n_pairs,
+                                            d_table.ptr if d_table else 0, d_pos0.ptr if d_pos0 else 0,
+                                            wide.ctypes.data, which.ctypes.data, len(which), C.byref(h)))
+        elif correction is None:
+            check(lib().gk_tabulate(self.dev.ctx, dindex.handle, self.mates.ptr, self.n_pairs, C.byref(h)))
+        else:
             check(lib().gk_tabulate_corrected(self.dev.ctx, dindex.handle, self.mates.ptr, self.n_pairs,
                                               d_table.ptr, d_pos0.ptr, C.byref(h)))
         self.handle = h

@@ -337,9 +337,11 @@ def extractVariant(pair_reads: Iterable[tuple[str, str]], index: GkIndex | list[
     dev = dev or Device()
     dindex = dindex or DeviceIndex(dev, index)
     pairs = list(pair_reads)
-    rec, table = packPairs(pairs, index)
+    spill: list = []
+    rec, table = packPairs(pairs, index, spill=spill)
     base = Variant.novel_id
-    tab = Tabulation(dindex, rec, novel_base=base)
+    from .packed import spillArrays
+    tab = Tabulation(dindex, rec, novel_base=base, spill=spillArrays(spill))
     Variant.novel_id = base + tab.n_novel
     logger.info(f"[Graph] Filterd pairs: {tab.n_valid}")
     return SampleData(tab, index, None, pairs_text=pairs, ins_strings=table.strings)
@@ -372,7 +374,10 @@ def extractVariantFromPacked(pack: dict, index: GkIndex, dev: Device | None = No
     dindex = dindex or DeviceIndex(dev, index)
     logger.info(f"[Graph] Reads: {pack['counts']['reads']} Pairs: {pack['counts']['pairs']}")
     base = Variant.novel_id
-    tab = Tabulation(dindex, pack["records"], novel_base=base, correction=correction)
+    spill = pack["counts"].get("spill")
+    if spill is not None:
+        logger.info(f"[Graph] Pairs beyond the 128-byte record, kept in the wide format: {len(spill[1])}")
+    tab = Tabulation(dindex, pack["records"], novel_base=base, correction=correction, spill=spill)
     Variant.novel_id = base + tab.n_novel
     logger.info(f"[Graph] Filterd pairs: {tab.n_valid}")
     return SampleData(tab, index, None, pairs_text=pack["pairs_text"], ins_strings=pack["strings"])

@@ -149,12 +149,22 @@ def _walkText(pos0: int, cigar: str, seq: str, md_s: str | None, zs_s: str | Non
     return ops, mms, ins, clipped
 
 
-def packPairs(pairs, index: GkIndex, table: InsTable | None = None) -> tuple[np.ndarray, InsTable]:
-    """[(left_line, right_line)] -> mate records (2 per pair, left first)."""
+WIDE_CIG, WIDE_MM, WIDE_INS, WIDE_EV = 128, 256, 120, 384      # gk_mate_wide (include/graphkir_hip.h)
+
+
+def packPairs(pairs, index: GkIndex, table: InsTable | None = None, spill: list | None = None) -> tuple[np.ndarray, InsTable]:
+    """[(left_line, right_line)] -> mate records (2 per pair, left first).
+
+    ``spill``: a list that receives ``(pair index, two gk_mate_wide records)`` for every pair that does not fit
+    ``gk_mate`` (``spillArrays`` turns it into what ``Tabulation`` takes); without it such a pair raises
+    ``PackCapacityError``."""
+    from ._lib import MATE_WIDE_DTYPE, SPILLED
     table = table or InsTable(index)
     pairs = list(pairs)
     rec = np.zeros(2 * len(pairs), dtype=MATE_DTYPE)
     for p, pair in enumerate(pairs):
+        walked = [None, None]          # per side: (ops, mismatches, string ids) when the pair has to go wide
+        too_big = False
         heads = []
         for line in pair:
             cols = line.strip().split("\t")
@@ -180,16 +190,28 @@ def packPairs(pairs, index: GkIndex, table: InsTable | None = None) -> tuple[np.
                 # depth: keep its CIGAR when it fits (S ops included), else just the clip marker
                 full = [(CIG_S if o == "S" else {"M": CIG_M, "I": CIG_I, "D": CIG_D}[o], int(n))
                         for n, o in _CIGAR.findall(cols[5])]
-                if len(full) > MAX_CIG or any(n > MAX_OPLEN for _, n in full):
+                narrow = len(full) <= MAX_CIG and all(n <= MAX_OPLEN for _, n in full)
+                wide = len(full) <= WIDE_CIG and all(n < (1 << 28) for _, n in full)
+                if not narrow and wide and spill is not None:
+                    too_big = True            # its M runs count for the depth: the whole CIGAR goes wide
+                elif not narrow:
                     full = [(CIG_S, 0)]
-                r["n_cig"] = len(full)
-                for i, (o, n) in enumerate(full):
-                    r["cig"][i] = (n << 4) | o
+                walked[side] = (full, [], [])
+                if narrow or not wide or spill is None:
+                    r["n_cig"] = len(full)
+                    for i, (o, n) in enumerate(full):
+                        r["cig"][i] = (n << 4) | o
                 continue
             n_ev = len(mms) + sum(1 for o, _ in ops if o in (CIG_I, CIG_D))
+            walked[side] = (ops, mms, ins)
             if (len(ops) > MAX_CIG or len(mms) > MAX_MM or len(ins) > MAX_INS or n_ev > MAX_EV
                     or any(n > MAX_OPLEN for _, n in ops) or any(off > 0xFFFF for off, _ in mms)):
-                raise PackCapacityError(f"record does not fit gk_mate: {cols[0]} {cols[5]}")
+                fits_wide = (len(ops) <= WIDE_CIG and len(mms) <= WIDE_MM and len(ins) <= WIDE_INS and n_ev <= WIDE_EV
+                             and all(n < (1 << 28) for _, n in ops) and all(off < (1 << 24) for off, _ in mms))
+                if spill is None or not fits_wide:
+                    raise PackCapacityError(f"record does not fit gk_mate{'_wide' if spill is not None else ''}: {cols[0]} {cols[5]}")
+                too_big = True
+                continue
             r["n_cig"], r["n_mm"], r["n_ins"] = len(ops), len(mms), len(ins)
             for i, (o, n) in enumerate(ops):
                 r["cig"][i] = (n << 4) | o
@@ -198,7 +220,37 @@ def packPairs(pairs, index: GkIndex, table: InsTable | None = None) -> tuple[np.
                 r["mm"][i]["base"] = b
             for i, s in enumerate(ins):
                 r["ins"][i] = s
+        if too_big:
+            wide = np.zeros(2, dtype=MATE_WIDE_DTYPE)
+            for side in range(2):
+                r, x = rec[2 * p + side], wide[side]
+                for f in ("pos0", "flag", "ref", "nh", "nm"):
+                    x[f] = r[f]
+                ops, mms, ins = walked[side]
+                x["n_cig"], x["n_mm"], x["n_ins"] = len(ops), len(mms), len(ins)
+                for i, (o, n) in enumerate(ops):
+                    x["cig"][i] = (n << 4) | o
+                for i, (off, b) in enumerate(mms):
+                    x["mm"][i] = (off << 8) | b
+                for i, sid in enumerate(ins):
+                    x["ins"][i] = sid
+                head = np.zeros(1, dtype=MATE_DTYPE)[0]
+                for f in ("pos0", "flag", "ref", "nh", "nm"):
+                    head[f] = r[f]
+                head["n_cig"] = SPILLED
+                head["ins"][0] = len(spill)
+                rec[2 * p + side] = head
+            spill.append((p, wide))
     return rec, table
+
+
+def spillArrays(spill: list):
+    """``packPairs``' spill list -> (wide records, pair indices) as ``Tabulation(spill=...)`` takes them; None when empty."""
+    from ._lib import MATE_WIDE_DTYPE
+    if not spill:
+        return None
+    return (np.concatenate([w for _, w in spill]).astype(MATE_WIDE_DTYPE, copy=False),
+            np.array([p for p, _ in spill], dtype=np.int64))
 
 
 _ERR_KINDS = {1: AssertionError, 2: NotImplementedError, 3: PackCapacityError, 4: ValueError}
@@ -239,6 +291,14 @@ def _withPacker(index: GkIndex, table: InsTable | None, feed, capacity: int | No
         for i in range(len(table.strings), n_str.value):
             table.intern(lib().gk_packer_string(pk, i).decode())
         counts = {"lines": n_lines.value, "reads": n_reads.value, "pairs": n_pairs.value, "strange": n_strange.value}
+        n_spill = C.c_int64()
+        check(lib().gk_packer_spilled(pk, C.byref(n_spill)))
+        if n_spill.value:   # pairs that do not fit gk_mate travel in the wide format beside the records
+            from ._lib import MATE_WIDE_DTYPE
+            wide = np.empty(2 * n_spill.value, dtype=MATE_WIDE_DTYPE)
+            which = np.empty(n_spill.value, dtype=np.int64)
+            check(lib().gk_packer_spill_records(pk, wide.ctypes.data, which.ctypes.data))
+            counts["spill"] = (wide, which)
         return rec, table, pair_lines, counts
     finally:
         lib().gk_packer_destroy(pk)

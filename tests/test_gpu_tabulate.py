@@ -206,3 +206,142 @@ def test_both_second_passes_give_the_same_tabulation(device, small_case, monkeyp
                    [tuple(map(tuple, (r["lpv"], r["rpv"], r["lnv"], r["rnv"]))) for r in ref["reads"]]
             tab.close()
         dindex.close()
+
+
+def _rewrite(line, **kw):
+    f = line.split("\t")
+    if "cigar" in kw:
+        f[5] = kw["cigar"]
+    if "seq" in kw:
+        f[9] = kw["seq"]
+        f[10] = "I" * len(f[9])
+    out = []
+    for c in f:
+        for tag, key in (("MD:Z:", "md"), ("Zs:Z:", "zs"), ("NM:i:", "nm")):
+            if c.startswith(tag) and key in kw:
+                c = None if kw[key] is None else tag + str(kw[key])
+                break
+        if c is not None:
+            out.append(c)
+    return "\t".join(out)
+
+
+def test_pairs_beyond_the_128_byte_record_take_the_wide_format(device, tmp_path):
+    """Mates with more mismatches / ops / events than gk_mate holds, an op longer than 4095 or a clipped CIGAR of
+    many ops are kept as gk_mate_wide and walked by tab_count_wide / tab_emit_wide: lists, novel-variant ids in
+    first-appearance order and read depth equal the oracle's, through the native packers (SAM text, BAM) and the
+    Python one; the rest of the sample is unchanged by their presence."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from bamwriter import samToBam
+    from kir_graph_amd.hisat2 import extractVariant, extractVariantFromText, pairLines
+    from kir_graph_amd.index import GkIndex
+    from kir_graph_amd.msa2hisat import Variant
+    from kir_graph_amd.samtools_utils import depthOfSample
+    from oracle import depth as odepth
+    sidx = synth.makeIndex(seed=21, n_genes=3, len_range=(9000, 11000), var_range=(200, 300), allele_range=(10, 20))
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    sample = synth.makeSample(sidx, seed=5, n_pairs=600)
+    lines = synth.toSamLines(sample)
+    rng = np.random.default_rng(3)
+
+    def backbone_of(line):
+        f = line.split("\t")
+        bb = sidx.backbone[f[2]]
+        return (bb if isinstance(bb, str) else bytes(bytearray(bb)).decode()), int(f[3]) - 1
+
+    def many_mismatches(line, n_mm):
+        """150M with n_mm substitutions against the backbone (mostly novel variants), MD to match."""
+        bb, pos0 = backbone_of(line)
+        ref = bb[pos0:pos0 + 150]
+        assert len(ref) == 150
+        at = sorted(rng.choice(150, size=n_mm, replace=False).tolist())
+        seq, md, last = list(ref), "", 0
+        for p in at:
+            seq[p] = "ACGT"[("ACGT".index(ref[p]) + 1 + int(rng.integers(3))) % 4]
+            md += f"{p - last}{ref[p]}"
+            last = p + 1
+        md += str(150 - last)
+        return _rewrite(line, cigar="150M", seq="".join(seq), md=md, zs=None, nm=0)
+
+    def plain(line, cigar, read_len):
+        """A read that copies the backbone under `cigar` (M and D only): MD = match runs and deleted bases."""
+        bb, pos0 = backbone_of(line)
+        import re
+        seq, md, cur, run = "", "", pos0, 0
+        for n, op in re.findall(r"(\d+)([MDS])", cigar):
+            n = int(n)
+            if op == "M":
+                seq += bb[cur:cur + n]; cur += n; run += n
+            elif op == "D":
+                md += f"{run}^{bb[cur:cur + n]}"; run = 0; cur += n
+            else:
+                seq += "A" * n
+        md += str(run)
+        assert len(seq) == read_len
+        return _rewrite(line, cigar=cigar, seq=seq, md=md, zs=None, nm=0)
+
+    def roomy(p, span=150):
+        return all(l.split("\t")[5] == "150M" and ot.passesFilter(l) and
+                   backbone_of(l)[1] + span + 150 < len(backbone_of(l)[0]) for l in lines[2 * p:2 * p + 2])
+    picks = [p for p in range(600) if roomy(p)]
+    far = [p for p in picks if roomy(p, 4500)]
+    assert len(picks) >= 8 and far
+    wide_pairs = {}
+    # 30 mismatches on one mate, 20 on the other (more than 16 per mate / 22 events)
+    k0 = picks[2]
+    lines[2 * k0] = many_mismatches(lines[2 * k0], 30)
+    lines[2 * k0 + 1] = many_mismatches(lines[2 * k0 + 1], 20)
+    wide_pairs[k0] = "mismatches"
+    # a novel deletion longer than 4095 (the mate yields no lists, its M runs count for the depth)
+    k = next(p for p in far if p not in wide_pairs)
+    lines[2 * k] = plain(lines[2 * k], "70M4200D80M", 150)
+    wide_pairs[k] = "long deletion"
+    # 19 ops of short novel deletions on one mate (more than 14)
+    k2 = next(p for p in picks if p not in wide_pairs)
+    lines[2 * k2 + 1] = plain(lines[2 * k2 + 1], "10M1D" * 9 + "60M", 150)
+    wide_pairs[k2] = "many ops"
+    # a clipped mate with 18 ops: no variants, but its CIGAR counts for the depth
+    k3 = next(p for p in picks if p not in wide_pairs)
+    lines[2 * k3] = plain(lines[2 * k3], "5S" + "8M1D" * 8 + "81M", 150)
+    wide_pairs[k3] = "clipped, many ops"
+
+    ref = ot.tabulateLines(lines, gidx.variants)
+    ref_nov = [(v.id, v.pos, v.typ, v.ref, v.val, v.length) for v in ref["variants"] if str(v.id).startswith("nv")]
+    gene_len = {g: len(sidx.backbone[g]) for g in sidx.genes}
+    kept = [(l, r, ot.nhOf(l)) for l, r in ot.pairMates(lines) if ot.passesFilter(l) and ot.passesFilter(r)]
+    want_depth = odepth.depthFromPairs(kept, gene_len)
+
+    header = ["@HD\tVN:1.0\tSO:queryname"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+    sam = str(tmp_path / "s.sam")
+    with open(sam, "w") as f:
+        f.write("\n".join(header + lines) + "\n")
+    bam = str(tmp_path / "s.bam")
+    samToBam(header + lines, bam)
+    dindex = DeviceIndex(device, gidx)
+    spilled = None
+    for how in ("sam", "bam", "python"):
+        Variant.novel_id = 0
+        if how == "python":
+            data = extractVariant(pairLines(lines), gidx, dev=device, dindex=dindex)
+        else:
+            data = extractVariantFromText(sam if how == "sam" else bam, gidx, dev=device, dindex=dindex, keep_text=False)
+        n_spill = int(data.tab.mates.download()["n_cig"][::2].tolist().count(0xFF)) if hasattr(data.tab.mates, "download") else None
+        got = device_lists(data.tab)
+        assert len(got) == len(ref["reads"]), how
+        for i, (g, r) in enumerate(zip(got, ref["reads"])):
+            for key in ("lpv", "rpv", "lnv", "rnv"):
+                assert g[key] == r[key], (how, i, key)
+        nov = data.tab.novelVariants(data.ins_strings)
+        assert [(v.id, v.pos, v.typ, v.ref, v.val, v.length) for v in nov] == ref_nov, how
+        df = depthOfSample(data, gene_len)
+        for g in sidx.genes:
+            assert np.array_equal(df[df["gene"] == g]["depth"].to_numpy(), want_depth[g]), (how, g)
+        if n_spill is not None:
+            assert n_spill == len(wide_pairs), how
+        data.tab.close()
+    # the 30-mismatch mate really carries more positives than a gk_mate could
+    longest = max(len(r["lpv"]) + len(r["rpv"]) for r in ref["reads"])
+    assert longest > 22
+    dindex.close()

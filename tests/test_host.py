@@ -756,7 +756,9 @@ def test_bam_binary_hand_over_equals_text_path_on_awkward_records(tmp_path):
         for run in (lambda: packed.packBam(path, gidx), lambda: packed.packText(packed.bamChunks(path), gidx)):
             try:
                 rec, table, pl, counts = run()
-                outcomes.append(("ok", rec.tobytes(), table.strings, pl.tolist(), counts))
+                spill = counts.pop("spill", None)
+                spill = (spill[0].tobytes(), spill[1].tolist()) if spill else None
+                outcomes.append(("ok", rec.tobytes(), table.strings, pl.tolist(), counts, spill))
             except Exception as e:    # noqa: BLE001 -- the kind and the line are what is compared
                 outcomes.append((type(e).__name__, str(e).split(":")[0].split()[-1], str(e).split(":", 1)[-1]))   # kind, line, why
         assert outcomes[0] == outcomes[1], tag
@@ -770,7 +772,8 @@ def test_bam_binary_hand_over_equals_text_path_on_awkward_records(tmp_path):
     edit(good, 7, cigar="1S" + "1M1I" * 8 + f"{n - 17}M", md=str(n - 17 + 8), zs="", nm=0)      # 18 ops, clipped
     edit(good, 9, cigar="2M1I" * 6 + f"{n - 18}M", md=str(n - 18 + 12), zs="", nm=0)            # 13 ops, 6 strings
     edit(good, 11, cigar=f"{n}M", md="0A0C0G" + str(n - 3), seq="TTT" + "A" * (n - 3), zs="", nm=3)
-    assert both_ways(good, "good")[0] == "ok"
+    out = both_ways(good, "good")
+    assert out[0] == "ok" and out[5][1] == [7]      # the clipped mate with 18 ops keeps its whole CIGAR in the wide format
     # shapes the reference raises on, or that only the text walk spells right: one file each, the bad pair in the middle
     cases = {
         "hard_clip": dict(cigar=f"5H{n}M", md=str(n), zs="", nm=0),          # H: NotImplementedError
@@ -793,9 +796,16 @@ def test_bam_binary_hand_over_equals_text_path_on_awkward_records(tmp_path):
     for tag, kw in cases.items():
         lines = list(records)
         edit(lines, 200, **kw)
-        kinds[tag] = both_ways(lines, tag)[0]
+        out = both_ways(lines, tag)
+        kinds[tag] = out[0]
+        if tag == "too_many_ops":
+            assert out[5][1] == [200]               # beyond gk_mate, inside gk_mate_wide
     assert kinds["splice"] == "NotImplementedError" and kinds["hard_clip"] == "NotImplementedError"
-    assert kinds["md_short"] == "AssertionError" and kinds["too_many_ops"] == "PackCapacityError"
+    assert kinds["md_short"] == "AssertionError" and kinds["too_many_ops"] == "ok"
+    # beyond the wide format too: the capacity error stays
+    lines = list(records)
+    edit(lines, 200, cigar="1M1I" * 70 + f"{n - 140}M", md=str(n - 70), zs="", nm=0)     # 141 ops
+    assert both_ways(lines, "beyond_wide")[0] == "PackCapacityError"
 
 
 def test_record_index_is_the_same_however_the_stream_is_cut(tmp_path, monkeypatch):
@@ -845,3 +855,46 @@ def test_record_index_is_the_same_however_the_stream_is_cut(tmp_path, monkeypatc
             monkeypatch.setenv("GK_BAM_INDEX_SEGMENTS", n_seg)
             with pytest.raises(_lib.GkError, match="malformed BAM"):
                 list(packed.bamChunks(path, name_sorted=False))
+
+
+def test_wide_records_of_the_native_and_the_python_packer_agree():
+    """Pairs that do not fit gk_mate: both packers file the same gk_mate_wide records under the same pair numbers
+    and leave the same marker records (n_cig == GK_SPILLED, ins[0] = place in the wide array) behind."""
+    sidx = synth.makeIndex(seed=5, n_genes=3, var_range=(200, 300), allele_range=(10, 20))
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    sample = synth.makeSample(sidx, seed=21, n_pairs=300)
+    lines = synth.toSamLines(sample)
+    n = 150
+
+    def edit(k, side, cigar, md, seq=None):
+        f = lines[2 * k + side].split("\t")
+        f[5] = cigar
+        if seq:
+            f[9] = seq
+        f = [c for c in f if not c.startswith("Zs:Z:")]
+        f = ["MD:Z:" + md if c.startswith("MD:Z:") else "NM:i:0" if c.startswith("NM:i:") else c for c in f]
+        lines[2 * k + side] = "\t".join(f)
+
+    ok = [k for k in range(300) if all(int(l.split("\t")[1]) & 2 and "NM:i:" in l for l in lines[2 * k:2 * k + 2])]
+    a, b, c, d = ok[3], ok[10], ok[11], ok[40]
+    edit(a, 0, "2M1I" * 8 + f"{n - 24}M", str(n - 8))                          # 17 ops, 8 inserted strings
+    edit(b, 1, "1S" + "1M1I" * 8 + f"{n - 17}M", str(n - 9))                   # clipped, 18 ops
+    edit(c, 0, f"{n}M", "".join("0C" for _ in range(20)) + str(n - 20), "A" * n)   # 20 mismatches
+    edit(c, 1, f"70M5000D{n - 70}M", "70^" + "A" * 5000 + str(n - 70))          # a 5000-base deletion
+    edit(d, 0, "1M1I" * 60 + f"{n - 120}M", str(n - 60))                        # 121 ops, 60 strings: still wide
+    text = ("\n".join(lines) + "\n").encode()
+    rec, table, pair_lines, counts = packed.packText([text], gidx)
+    wide, which = counts["spill"]
+    spill = []
+    rec_py, table_py = packed.packPairs(list(pairLines(lines)), gidx, spill=spill)
+    wide_py, which_py = packed.spillArrays(spill)
+    assert sorted(which.tolist()) == which.tolist() == which_py.tolist() == sorted([a, b, c, d])
+    assert wide.tobytes() == wide_py.tobytes() and rec.tobytes() == rec_py.tobytes()
+    assert table.strings == table_py.strings
+    marked = np.flatnonzero(rec["n_cig"] == _lib.SPILLED)
+    assert marked.tolist() == sorted([2 * k + s for k in (a, b, c, d) for s in (0, 1)])
+    assert rec["ins"][marked, 0].tolist() == [0, 0, 1, 1, 2, 2, 3, 3]
+    assert int(wide["n_ins"].max()) == 60 and int(wide["n_mm"].max()) == 20 and int((wide["cig"] >> 4).max()) == 5000
+    # without a spill list the Python packer keeps its old limit
+    with pytest.raises(packed.PackCapacityError):
+        packed.packPairs(list(pairLines(lines)), gidx)
