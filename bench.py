@@ -176,6 +176,12 @@ def cpu_baseline(method, n_pairs):
         cores = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         pass
+    try:      # a container's CPU quota (cgroup v2: "<quota> <period>" or "max ..."): the cores that can really run at once
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
     n_way = max(1, min(cores, 32))
     out = {"value": single, "unit": "reads/s", "cores": 1, "kind": "port",
            "sample": f"{n_pairs} pairs of the same synthetic workload (R_g <= 8 k per gene: the reference's own "

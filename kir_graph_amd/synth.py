@@ -500,3 +500,35 @@ def toSamLines(sample: SynthSample, zs_seed: int = 7, with_zs: bool = True) -> l
                 f"r{int(sample.pair_qname[r]):09d}", str(fl), g, str(int(sample.pos0[m]) + 1), "60",
                 cigar, "=", str(int(sample.pos0[o]) + 1), str(tlen), seq, "I" * len(seq), *tags]))
     return lines
+
+
+def withManyMismatches(lines: list[str], index: "SynthIndex", pairs: list[int], rng, n_mm=(17, 60)) -> list[str]:
+    """SAM lines with the mates of ``pairs`` (pure-match mates only) rewritten to carry many substitutions against the
+    backbone -- MD to match, no Zs, NM:i:0 so the mate still passes the filter: more mismatches than a ``gk_mate``
+    holds, i.e. test input for the wide record format.  Returns a new list."""
+    out = list(lines)
+    for p in pairs:
+        for m in (2 * p, 2 * p + 1):
+            f = out[m].split("\t")
+            if not f[5].endswith("M") or not f[5][:-1].isdigit():
+                continue
+            n = int(f[5][:-1])
+            bb = index.backbone[f[2]]
+            bb = bb if isinstance(bb, str) else bytes(bytearray(bb)).decode()
+            pos0 = int(f[3]) - 1
+            ref = bb[pos0:pos0 + n]
+            if len(ref) != n or n != len(f[9]):
+                continue
+            k = int(rng.integers(n_mm[0], min(n_mm[1], n) + 1))
+            at = sorted(rng.choice(n, size=k, replace=False).tolist())
+            seq, md, last = list(ref), "", 0
+            for q in at:
+                seq[q] = "ACGT"[("ACGT".index(ref[q]) + 1 + int(rng.integers(3))) % 4] if ref[q] in "ACGT" else "A"
+                md += f"{q - last}{ref[q]}"
+                last = q + 1
+            md += str(n - last)
+            f[9] = "".join(seq)
+            f = [c for c in f if not c.startswith("Zs:Z:")]
+            f = ["MD:Z:" + md if c.startswith("MD:Z:") else "NM:i:0" if c.startswith("NM:i:") else c for c in f]
+            out[m] = "\t".join(f)
+    return out

@@ -21,6 +21,8 @@ from oracle import em as oem, tabulate as ot, typing as oty  # noqa: E402
 
 
 WIDE = os.environ.get("GK_FUZZ_WIDE") == "1"     # wide genes: several allele slots / tiles per gene, fewer cases
+SPILL = os.environ.get("GK_FUZZ_SPILL") == "1"   # some pairs with more mismatches than a gk_mate holds
+WIDE_SEEN = [0]
 
 
 def one(seed: int, dev) -> str:
@@ -38,9 +40,13 @@ def one(seed: int, dev) -> str:
                               gene_cn=gene_cn,
                               err_rate=float(rng.choice([0.0, 0.001, 0.01])), frac_multi=float(rng.choice([0.0, 0.05, 0.3])))
     lines = synth.toSamLines(sample)
+    if SPILL:     # a few pairs beyond the 128-byte record: they take the wide format (tab_count_wide / tab_emit_wide)
+        lines = synth.withManyMismatches(lines, sidx, rng.choice(sample.n_pairs, size=min(6, sample.n_pairs), replace=False).tolist(), rng)
     ref = ot.tabulateLines(lines, sidx.variants)
-    rec, table, _, _ = packed.packText([("\n".join(lines) + "\n").encode()], gidx)
-    tab = Tabulation(DeviceIndex(dev, gidx), dev.put(rec))
+    rec, table, _, counts = packed.packText([("\n".join(lines) + "\n").encode()], gidx)
+    if SPILL and "spill" in counts:
+        WIDE_SEEN[0] += len(counts["spill"][1])
+    tab = Tabulation(DeviceIndex(dev, gidx), dev.put(rec), spill=counts.get("spill"))
     data = SampleData(tab, gidx, None, ins_strings=table.strings)
     got_reads = data.reads()
     assert len(got_reads) == len(ref["reads"]), "pair count"
@@ -96,7 +102,8 @@ def main():
             print(f"[fuzz] {n} cases ok ({time.time() - t0:.0f}s), last: seed {seed}: {info}", flush=True)
         seed += 1
     from kir_graph_amd.typing_mulit_allele import SEARCH_STATS
-    print(f"[fuzz] {n} cases, all equal to the oracle; search steps: {SEARCH_STATS}")
+    print(f"[fuzz] {n} cases, all equal to the oracle; search steps: {SEARCH_STATS}"
+          + (f"; pairs in the wide record format: {WIDE_SEEN[0]}" if SPILL else ""))
 
 
 if __name__ == "__main__":
