@@ -191,7 +191,8 @@ __global__ __launch_bounds__(kThreads) void minsum_finish(const uint32_t* __rest
                                                           const int32_t* __restrict__ pcol,
                                                           const uint32_t* __restrict__ msum,
                                                           const int32_t* __restrict__ cols,
-                                                          const uint8_t* __restrict__ first, uint32_t* __restrict__ M) {
+                                                          const uint8_t* __restrict__ first, uint32_t* __restrict__ M,
+                                                          SelState* __restrict__ st) {
   const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   uint32_t v = kNotFirst;
   if (o < n_out && first[o]) {
@@ -202,17 +203,8 @@ __global__ __launch_bounds__(kThreads) void minsum_finish(const uint32_t* __rest
     v = (sp + msum[cols[a]] - sad) >> 1;
   }
   if (o < n_out) M[o] = v;
-}
-
-// count / min / max of the candidates: a few workgroups stride over M, one atomic triple each
-constexpr int kSelBlocks = 64;   // workgroups of the strided select passes
-
-__global__ __launch_bounds__(kThreads) void select_stats(const uint32_t* __restrict__ M, int64_t n, SelState* __restrict__ st) {
-  uint32_t cnt = 0, inv_lo = 0, hi = 0;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
-    const uint32_t v = M[i];
-    if (v != kNotFirst) { ++cnt; inv_lo = max(inv_lo, ~v); hi = max(hi, v); }
-  }
+  // count / min / max of the candidates for the select passes below (one atomic triple per workgroup)
+  uint32_t cnt = v != kNotFirst ? 1u : 0u, inv_lo = v != kNotFirst ? ~v : 0u, hi = v != kNotFirst ? v : 0u;
   for (int off = 32; off > 0; off >>= 1) {
     cnt += __shfl_xor(cnt, off, 64);
     inv_lo = max(inv_lo, (uint32_t)__shfl_xor(inv_lo, off, 64));
@@ -230,6 +222,8 @@ __global__ __launch_bounds__(kThreads) void select_stats(const uint32_t* __restr
     }
   }
 }
+
+constexpr int kSelBlocks = 64;   // workgroups of the strided select passes
 
 // The candidates at or below the T-th smallest M (T = top_n), by a two-level radix select that every
 // workgroup can finish on its own: the totals of a step lie in a narrow band, so values are reduced to
@@ -420,9 +414,9 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
   const dim3 per_elem((unsigned)((n_out + kThreads - 1) / kThreads));
   GK_PROF(ctx, GK_K_SELECT_CUT,
           GK_KERNEL(minsum_finish, per_elem, dim3(kThreads), 0, st, d_partial, n_slices, n_out, n_cols, d_psum,
-                    c_prev >= 2 ? (const int32_t*)nullptr : d_ids, gk_ptr<uint32_t>(d_msum), d_cols, d_first, d_M));
+                    c_prev >= 2 ? (const int32_t*)nullptr : d_ids, gk_ptr<uint32_t>(d_msum), d_cols, d_first, d_M,
+                    d_state));
   const dim3 strided((unsigned)std::min<int64_t>(kSelBlocks, (n_out + kThreads - 1) / kThreads));
-  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_stats, strided, dim3(kThreads), 0, st, d_M, n_out, d_state));
   GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_hist1, strided, dim3(kThreads), 0, st, d_M, n_out, d_state));
   GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_hist2, strided, dim3(kThreads), 0, st, d_M, n_out, top_n, d_state));
   GK_PROF(ctx, GK_K_SELECT_CUT,
