@@ -469,33 +469,59 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
 
 // pass 2 without a second walk: the lists are written from what pass 1 saved -- the positive list as
 // ordinals / novel-table slots, the negative list as the window's first ordinal + the kept bits.
-__global__ __launch_bounds__(kThreads) void tab_expand(int64_t n_mates, int n_var, const uint32_t* rank,
-                                                       const uint32_t* off, const uint32_t* valid,
-                                                       const uint32_t* ev_save, const uint32_t* lo_save,
-                                                       const uint32_t* mask_save, uint32_t* ids) {
-  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (m >= n_mates) return;
-  const int64_t pair = m >> 1;
-  const int side = (int)(m & 1);
-  if (!valid[pair]) return;
-  const uint32_t o_pos = off[4 * pair + side], n_pos = off[4 * pair + side + 1] - o_pos;
-  const uint32_t o_neg = off[4 * pair + 2 + side], n_neg = off[4 * pair + 2 + side + 1] - o_neg;
-  for (uint32_t e = 0; e < n_pos; ++e) {
-    const uint32_t w = ev_save[m * kMaxEv + e];
-    ids[o_pos + e] = (w & kEvNovel) ? (uint32_t)n_var + rank[w & 0xFFFFFFu] : w;
-  }
-  if (n_neg) {
-    const uint32_t lo = lo_save[m];
-    uint32_t j = 0;
-    for (int w = 0; w < kMaskWords && j < n_neg; ++w) {
-      uint32_t bits = mask_save[m * kMaskWords + w];
-      while (bits) {
-        const int b = __ffs(bits) - 1;
-        bits &= bits - 1;
-        ids[o_neg + j++] = lo + 32u * (uint32_t)w + (uint32_t)b;
+// The lists of the 32 pairs of a wavefront are one contiguous run of `ids` (offsets are in pair order), but a lane
+// writing its own lists touches 64 different cache lines per store.  So the lanes assemble the run in LDS (scattered
+// LDS writes are cheap) and the wave then copies it out in 256-byte rows; a run longer than the staging area (not
+// seen on 150-bp reads: ~70 ids per pair) is written directly.
+constexpr int kExpandThreads = 128;
+constexpr int kExpandWaves = kExpandThreads / 64;
+constexpr uint32_t kExpandCap = 4096;   // ids staged per wavefront (16 KB)
+
+__global__ __launch_bounds__(kExpandThreads) void tab_expand(int64_t n_mates, int n_var, const uint32_t* rank,
+                                                             const uint32_t* off, const uint32_t* valid,
+                                                             const uint32_t* ev_save, const uint32_t* lo_save,
+                                                             const uint32_t* mask_save, uint32_t* ids) {
+  __shared__ uint32_t stage[kExpandWaves][kExpandCap];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t m0 = ((int64_t)blockIdx.x * kExpandWaves + wid) * 64;   // first mate of the wave (an even number: a pair's left mate)
+  if (m0 >= n_mates) return;                                             // wave-uniform
+  const int64_t m = m0 + lane;
+  const int64_t pair0 = m0 >> 1, pair_end = min<int64_t>((m0 + 64) >> 1, n_mates >> 1);
+  const uint32_t run0 = off[4 * pair0], run1 = off[4 * pair_end];      // wave-uniform: the run of the wave's pairs
+  const bool staged = run1 - run0 <= kExpandCap;
+  uint32_t* const mine = &stage[wid][0];
+  auto put = [&](uint32_t slot, uint32_t v) {                          // list slot (a global offset) <- v
+    if (staged) mine[slot - run0] = v;                                  // (wave-uniform choice; ds_write, in order with the reads below)
+    else ids[slot] = v;
+  };
+  if (m < n_mates) {
+    const int64_t pair = m >> 1;
+    const int side = (int)(m & 1);
+    if (valid[pair]) {
+      const uint32_t o_pos = off[4 * pair + side], n_pos = off[4 * pair + side + 1] - o_pos;
+      const uint32_t o_neg = off[4 * pair + 2 + side], n_neg = off[4 * pair + 2 + side + 1] - o_neg;
+      for (uint32_t e = 0; e < n_pos; ++e) {
+        const uint32_t w = ev_save[m * kMaxEv + e];
+        put(o_pos + e, (w & kEvNovel) ? (uint32_t)n_var + rank[w & 0xFFFFFFu] : w);
+      }
+      if (n_neg) {
+        const uint32_t lo = lo_save[m];
+        uint32_t j = 0;
+        for (int w = 0; w < kMaskWords && j < n_neg; ++w) {
+          uint32_t bits = mask_save[m * kMaskWords + w];
+          while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            put(o_neg + j++, lo + 32u * (uint32_t)w + (uint32_t)b);
+          }
+        }
       }
     }
   }
+  if (!staged) return;
+  __builtin_amdgcn_wave_barrier();   // LDS operations of a wave complete in order: the copy below sees the lists
+  for (uint32_t i = lane; i < run1 - run0; i += 64) ids[run0 + i] = mine[i];
 }
 
 // novel ranking: mark first-appearance sequence numbers, prefix-popcount, assign ranks
@@ -825,7 +851,7 @@ int gk_tabulate_spilled(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n
         GK_KERNEL(tab_emit_wide, dim3(nblk(2 * n_spill, 64)), dim3(64), 0, st, tab->d_wide, d_spill_pair, n_spill, ix, nt,
                   cnt, valid, tab->d_ids, wide_ev);
     } else {
-      GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_expand, dim3(nblk(n_mates)), dim3(kThreads), 0, st, n_mates, idx->n_var,
+      GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_expand, dim3(nblk(n_mates, kExpandThreads)), dim3(kExpandThreads), 0, st, n_mates, idx->n_var,
                          nt.rank, cnt, valid, ev_save, lo_save, mask_save, tab->d_ids));
     }
   }
