@@ -510,7 +510,7 @@ bool render(const gk_bam& b, const gk_bam::Rec& r, std::string& s) {
 
 extern "C" {
 
-int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
+static int bam_open_impl(const char* path, int32_t name_sorted, gk_bam** out) {
   if (!path || !out) { gk_set_error("null argument"); return GK_ERR_ARG; }
   FILE* f = fopen(path, "rb");
   if (!f) { gk_set_error("cannot open %s", path); return GK_ERR_ARG; }
@@ -777,7 +777,7 @@ int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
 // The records, in output order, straight into a packer: same pairing, checks and records as feeding
 // the rendered text to gk_packer_feed, without rendering or re-parsing it.  Only what the packer reads
 // is converted (CIGAR and SEQ to text; NM / MD / Zs / NH from the optional fields).
-int gk_bam_pack(gk_bam* b, gk_packer* pk) {
+static int bam_pack_impl(gk_bam* b, gk_packer* pk) {
   if (!b || !pk) { gk_set_error("null handle"); return GK_ERR_ARG; }
   const uint8_t* base = b->data.data();
   auto ref_name = [&](int32_t id) -> std::string_view {
@@ -903,7 +903,7 @@ int gk_bam_header(gk_bam* b, char* text_out, int64_t capacity) {
 
 // Whole lines ('\n' terminated) in output order until the buffer is full; *n_written == 0 at the end.
 // Records are rendered in batches, each batch split over the ingest threads.
-int gk_bam_next(gk_bam* b, char* text_out, int64_t capacity, int64_t* n_written) {
+static int bam_next_impl(gk_bam* b, char* text_out, int64_t capacity, int64_t* n_written) {
   if (!b || !text_out || !n_written || capacity < 1) { gk_set_error("bad arguments"); return GK_ERR_ARG; }
   int64_t w = 0;
   while (true) {
@@ -958,6 +958,31 @@ int gk_bam_next(gk_bam* b, char* text_out, int64_t capacity, int64_t* n_written)
 }
 
 }  // extern "C"
+
+// The entry points that allocate with the size of the input: running out of memory is an error code, not an abort
+// (an exception must not cross the C boundary).
+template <typename Call>
+static int guarded(const char* what, const Call& call) {
+  try {
+    return call();
+  } catch (const std::bad_alloc&) {
+    gk_set_error("%s: out of host memory", what);
+    return GK_ERR_CAPACITY;
+  } catch (const std::exception& e) {
+    gk_set_error("%s: %s", what, e.what());
+    return GK_ERR_ARG;
+  }
+}
+
+extern "C" int gk_bam_open(const char* path, int32_t name_sorted, gk_bam** out) {
+  return guarded("gk_bam_open", [&] { return bam_open_impl(path, name_sorted, out); });
+}
+extern "C" int gk_bam_pack(gk_bam* b, gk_packer* pk) {
+  return guarded("gk_bam_pack", [&] { return bam_pack_impl(b, pk); });
+}
+extern "C" int gk_bam_next(gk_bam* b, char* text_out, int64_t capacity, int64_t* n_written) {
+  return guarded("gk_bam_next", [&] { return bam_next_impl(b, text_out, capacity, n_written); });
+}
 
 // ---------------------------------------------------------------------------------------------
 // BAM writer: SAM text (header lines + alignment lines) -> BGZF-compressed BAM, the native form of

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -856,7 +857,7 @@ int gk_packer_destroy(gk_packer* pk) {
 
 // Feed a chunk of SAM text (lines may straddle chunks; pass final != 0 with the last chunk).
 // Returns GK_OK, or GK_ERR_ASSERT / GK_ERR_ARG with the details available from gk_packer_error.
-int gk_packer_feed(gk_packer* pk, const char* text, size_t n_bytes, int32_t final) {
+static int packer_feed_impl(gk_packer* pk, const char* text, size_t n_bytes, int32_t final) {
   if (!pk || (!text && n_bytes)) { gk_set_error("bad packer arguments"); return GK_ERR_ARG; }
   if (pk->err_kind) return GK_ERR_ASSERT;
   std::string owned;
@@ -898,6 +899,15 @@ int gk_packer_feed(gk_packer* pk, const char* text, size_t n_bytes, int32_t fina
     return GK_ERR_ASSERT;
   }
   return GK_OK;
+}
+
+int gk_packer_feed(gk_packer* pk, const char* text, size_t n_bytes, int32_t final) {
+  try {
+    return packer_feed_impl(pk, text, n_bytes, final);
+  } catch (const std::bad_alloc&) {      // an exception must not cross the C boundary
+    gk_set_error("gk_packer_feed: out of host memory");
+    return GK_ERR_CAPACITY;
+  }
 }
 
 int gk_packer_counts(gk_packer* pk, int64_t* n_lines, int64_t* n_reads, int64_t* n_pairs, int64_t* n_strange,
