@@ -203,7 +203,26 @@ def initFromEnv(dev=None, backend: str | None = None, fallback: bool = True) -> 
         if dev is None:
             from .kir_typing import defaultDevice
             dev = defaultDevice()
-        made = Comm(rank, world, store, dev=dev, backend="rccl")
+        # The communicator is made on a helper thread with a deadline (GK_RCCL_INIT_TIMEOUT seconds, default 300):
+        # an initialisation that never returns (a bootstrap that cannot reach its peers) must not hang the run --
+        # it counts as a failure, and the ranks fall back together like for any other failure.
+        import threading
+        box: dict = {}
+
+        def make():
+            try:
+                box["comm"] = Comm(rank, world, store, dev=dev, backend="rccl")
+            except Exception as e:    # noqa: BLE001 -- reported below
+                box["error"] = e
+
+        worker = threading.Thread(target=make, name="gk-rccl-init", daemon=True)
+        worker.start()
+        worker.join(float(os.environ.get("GK_RCCL_INIT_TIMEOUT", "300")))
+        if worker.is_alive():
+            raise CommError("RCCL communicator initialisation did not return in time")
+        if "error" in box:
+            raise box["error"]
+        made = box["comm"]
     except Exception as e:            # noqa: BLE001 -- whatever went wrong, the ranks must agree on what to do next
         if not fallback:
             raise
