@@ -147,8 +147,24 @@ class Tabulation:
                 check(lib().gk_sample_prepare(dev.ctx, self.handle, int(multiple), vflag.ptr, cnt.ptr, rows.ptr,
                                               off.ctypes.data))
                 dev.sync()
-                prep = store[bool(multiple)] = (vflag, cnt, rows, off)
+                # the surviving tallies of every gene in one compaction and one download (isHomozygous reads them per
+                # gene: ten small compactions with two waits each otherwise), with the backbone of every entry
+                o, p, q = Tabulation.survivingCounts(self.on(dev), cnt, vflag)
+                n_index = self.dindex.host.n_variant
+                gene_of = np.searchsorted(self.dindex.host.gene_vbeg, o, side="right") - 1
+                if len(o) and int(o[-1]) >= n_index:
+                    novel = o >= n_index
+                    gene_of[novel] = (self.novelKeys()[o[novel] - n_index] >> np.uint64(56)).astype(gene_of.dtype)
+                prep = store[bool(multiple)] = (vflag, cnt, rows, off, (o, p, q, gene_of))
         return prep
+
+    @staticmethod
+    def survivingOfGene(prep, g: int):
+        """(ordinals, positive tally, negative tally) of gene ``g`` out of ``prepared()``'s sample-wide list: what
+        ``survivingCounts(cnt, vflag, gene=(g, vbeg, vend))`` returns, without a device call."""
+        o, p, q, gene_of = prep[4]
+        mine = gene_of == g
+        return o[mine], p[mine], q[mine]
 
     def on(self, dev: Device) -> "Tabulation":
         """The same tabulation driven from another context (stream) of the same GPU.

@@ -223,11 +223,12 @@ class TypingWithPosNegAllele(_GenesInParallel):
             prep = tab.prepared(tab.dev, self._multiple) if self._variant_correction and batchedPreamble() else None
             if prep is not None:
                 # error correction and empty-read removal were done for every gene of the sample in one go
-                vflag, cnt, rows_all, off = prep
+                vflag, cnt, rows_all, off = prep[:4]
                 a, b = int(off[view.g]), int(off[view.g + 1])
                 rows = _lib_slice(rows_all, a, b - a, tab.dev)
                 reads = ReadSet(tab, rows, b - a, vflag)
-                prepared = (rows, b - a, vflag, cnt, (view.g, view.vbeg, view.vbeg + view.n_span))
+                prepared = (rows, b - a, vflag, cnt, (view.g, view.vbeg, view.vbeg + view.n_span),
+                            type(tab).survivingOfGene(prep, view.g))
             else:
                 reads, prepared = ReadSet(tab, view.rows, view.n_rows), None
             typ: AlleleTyping = AlleleTyping(

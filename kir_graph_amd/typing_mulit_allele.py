@@ -371,9 +371,11 @@ class AlleleTyping:
         self._span = (_vbeg, _vbeg + n_span)
         self._tally = None
         self._tally_gene = None       # (gene, vbeg, vend) when the tallies cover every gene of the sample
+        self._surviving = None
         if _prepared is not None:
             assert variant_correction and no_empty
-            rows, n_rows, _, self._tally, self._tally_gene = _prepared       # rs.vflag IS the shared, corrected one
+            rows, n_rows, _, self._tally, self._tally_gene = _prepared[:5]   # rs.vflag IS the shared, corrected one
+            self._surviving = _prepared[5] if len(_prepared) > 5 else None      # this gene's surviving tallies, if fetched already
         else:
             if variant_correction:
                 self._tally = tab.errorCorrection(rs.rows, rs.n_rows, rs.vflag, span=self._span, keep=True)
@@ -773,6 +775,8 @@ class AlleleTyping:
         rs = self._readset
         tab = rs.tab
         cnt = self._tally
+        if cnt is not None and self._surviving is not None:   # came with the sample-wide tallies (Tabulation.prepared)
+            return self._surviving
         if cnt is None:   # no correction pass ran: tally now
             cnt = self._dev.alloc(2 * tab.n_var_total, np.uint32)
             tab.countVariants(rs.rows, rs.n_rows, rs.vflag, cnt, self._span)
