@@ -160,12 +160,14 @@ struct NovelTable {
   uint32_t* seq;    // min (mate * kMaxEv + event) over insertions
   uint32_t* rank;   // first-appearance rank (filled by rank kernel)
   uint32_t mask;
+  int* flags;       // bit 3 is raised when a key finds no slot within kNovelProbes: the host retries with a larger table
 };
+constexpr uint32_t kNovelProbes = 2048;   // far beyond any chain at the load factor the host accepts (0.5)
 
-// returns the slot of the key (the table never fills: its capacity is checked by the host)
+// returns the slot of the key; when the table is (nearly) full the search is cut short and reported
 __device__ inline uint32_t novel_insert(const NovelTable& t, uint64_t key, uint32_t seq) {
   uint32_t s = hash64(key) & t.mask;
-  for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+  for (uint32_t probe = 0; probe <= min(t.mask, kNovelProbes); ++probe) {
     unsigned long long prev = atomicCAS((unsigned long long*)&t.keys[s], (unsigned long long)kEmpty,
                                         (unsigned long long)key);
     if (prev == kEmpty || prev == key) {
@@ -174,6 +176,7 @@ __device__ inline uint32_t novel_insert(const NovelTable& t, uint64_t key, uint3
     }
     s = (s + 1) & t.mask;
   }
+  atomicOr(t.flags, 8);
   return 0;
 }
 
@@ -741,9 +744,35 @@ int gk_tabulate_corrected(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t
   return gk_tabulate_spilled(ctx, idx, d_mates_p, n_pairs, d_corr, d_gene_pos0, nullptr, nullptr, 0, out);
 }
 
+static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, gk_dptr d_corr,
+                               gk_dptr d_gene_pos0, const gk_mate_wide* wide, const int64_t* spill_pair,
+                               int64_t n_spill, uint32_t log2cap, bool* table_too_small, gk_tab** out);
+
 int gk_tabulate_spilled(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, gk_dptr d_corr,
                         gk_dptr d_gene_pos0, const gk_mate_wide* wide, const int64_t* spill_pair, int64_t n_spill,
                         gk_tab** out) {
+  // Hash table of the novel variants: a slot per mate to begin with (distinct novel variants are few -- read errors
+  // repeat, positions are finite -- while the worst case, every event of every mate novel, would need 44 slots per
+  // mate: 2^24 slots, i.e. 200 MB to clear and three passes over them per sample).  A sample that fills half of it
+  // is tabulated again with a table eight times the size.
+  uint32_t log2cap = 16;
+  while ((1ull << log2cap) < (uint64_t)(2 * std::max<int64_t>(n_pairs, 0)) && log2cap < 30) ++log2cap;
+  if (const char* e = getenv("GK_NOVEL_LOG2CAP")) log2cap = (uint32_t)std::min(30, std::max(4, atoi(e)));   // tests: force the retries
+  uint32_t log2max = 16;
+  while ((1ull << log2max) < (uint64_t)(2 * std::max<int64_t>(n_pairs, 0)) * GK_WIDE_EVENTS * 2 && log2max < 31) ++log2max;
+  for (;;) {
+    bool too_small = false;
+    const int rc = tabulate_with_table(ctx, idx, d_mates_p, n_pairs, d_corr, d_gene_pos0, wide, spill_pair, n_spill, log2cap,
+                                       &too_small, out);
+    if (!too_small) return rc;
+    if (log2cap >= log2max) return rc;
+    log2cap = std::min(log2cap + 3, log2max);
+  }
+}
+
+static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, gk_dptr d_corr,
+                               gk_dptr d_gene_pos0, const gk_mate_wide* wide, const int64_t* spill_pair,
+                               int64_t n_spill, uint32_t log2cap, bool* table_too_small, gk_tab** out) {
   gk_bind(ctx);
   GK_REQUIRE(ctx && idx && out && n_pairs >= 0, "bad tabulate arguments");
   GK_REQUIRE(n_spill >= 0 && n_spill <= n_pairs && (n_spill == 0 || (wide && spill_pair)), "bad wide-pair arguments");
@@ -762,11 +791,7 @@ int gk_tabulate_spilled(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n
   gk_tab* tab = new gk_tab();
   tab->ctx = ctx; tab->idx = idx; tab->n_pairs = n_pairs; tab->n_var = idx->n_var;
 
-  // novel hash table: at most kMaxEv novel events per mate, load factor <= 0.5, >= 2^16 slots
-  uint32_t log2cap = 16;
-  while ((1ull << log2cap) < (uint64_t)n_mates * kMaxEv * 2 && log2cap < 30) ++log2cap;
-  // most events are known variants or repeats: start small and rely on the bound only up to 2^24
-  if (log2cap > 24) log2cap = 24;
+  // novel hash table of 2^log2cap slots, load factor <= 0.5 (checked below)
   NovelTable nt;
   const size_t cap = 1ull << log2cap;
   nt.mask = (uint32_t)(cap - 1);
@@ -785,6 +810,7 @@ int gk_tabulate_spilled(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n
   GK_HIP(gk_pool_malloc(ctx, (void**)&valid, (size_t)(n_pairs + 1) * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_err, sizeof(int)));
   GK_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
+  nt.flags = d_err;
 
   const IndexView ix{idx->d_key, idx->d_bucket, idx->d_gene_boff, idx->n_var, idx->n_gene,
                      gk_ptr<uint8_t>(d_corr), gk_ptr<int64_t>(d_gene_pos0), idx->d_del_bits, idx->d_lb_a, idx->d_lb_t,
@@ -831,8 +857,15 @@ int gk_tabulate_spilled(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n
   tab->n_ids = totals[0];
   tab->n_novel = (int32_t)totals[1];
   tab->err_flags = err & 3;   // bit 2 (a window beyond the saved bits) only selects the pass-2 kernel
-  if ((uint64_t)tab->n_novel * 2 > cap) {
-    gk_set_error("novel variant table overflow (%d novel variants)", tab->n_novel);
+  if ((err & 8) || (uint64_t)tab->n_novel * 2 > cap) {   // (a full table stops taking keys: the count is then a lower bound)
+    gk_set_error("novel variant table overflow (%d novel variants in %llu slots)", tab->n_novel, (unsigned long long)cap);
+    *table_too_small = true;
+    GK_HIP(hipStreamSynchronize(st));
+    gk_pool_free(ctx,cnt); gk_pool_free(ctx,valid); gk_pool_free(ctx,d_err); gk_pool_free(ctx,bitmap); gk_pool_free(ctx,prefix);
+    gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save);
+    gk_pool_free(ctx,d_spill_pair); gk_pool_free(ctx,wide_ev);
+    gk_pool_free(ctx,nt.keys); gk_pool_free(ctx,nt.seq); gk_pool_free(ctx,nt.rank);
+    gk_tab_destroy(tab);
     return GK_ERR_CAPACITY;
   }
 

@@ -345,3 +345,21 @@ def test_pairs_beyond_the_128_byte_record_take_the_wide_format(device, tmp_path)
     longest = max(len(r["lpv"]) + len(r["rpv"]) for r in ref["reads"])
     assert longest > 22
     dindex.close()
+
+
+def test_a_novel_table_that_fills_up_is_retried_larger(device, small_case, monkeypatch):
+    """The hash table of the novel variants starts at a slot per mate; a sample that fills half of it (or whose keys
+    find no slot within the probe bound) is tabulated again with a table eight times the size.  Forced here with a
+    16-slot table: same lists, same novel variants in the same order as with the default size."""
+    sidx, gidx, sample = small_case
+    rec, table = packed.packSample(sample, gidx)
+    dindex = DeviceIndex(device, gidx)
+    want_tab = Tabulation(dindex, rec)
+    want = (want_tab.offsets().tolist(), want_tab.ids().tolist(), want_tab.novelKeys().tolist())
+    assert want_tab.n_novel > 8          # more than half of 16 slots: the first attempts must fail
+    want_tab.close()
+    monkeypatch.setenv("GK_NOVEL_LOG2CAP", "4")
+    tab = Tabulation(dindex, rec)
+    assert (tab.offsets().tolist(), tab.ids().tolist(), tab.novelKeys().tolist()) == want
+    tab.close()
+    dindex.close()
