@@ -298,6 +298,12 @@ int gk_search_destroy(gk_search* s);
  * *homozygous = 0 when some position shows a second allele above 0.1 and 1 / (2 cn) of its kept counts. */
 int gk_site_verdict(const int64_t* pos, const int64_t* code, const uint8_t* negative, const int64_t* count, int64_t n,
                     int32_t cn, int32_t* homozygous);
+/* the same verdict straight from the surviving tallies (gk_variant_surviving*): ordinals into `keys` (index keys
+ * followed by the sample's novel keys) with their positive / negative counts; label_of_insert[id] = the label code of an
+ * inserted string (a one-base insertion prints like a substitution of that base) */
+int gk_site_verdict_tallies(const uint64_t* keys, int64_t n_keys, const int64_t* label_of_insert, int64_t n_insert,
+                            const int32_t* ordinal, const uint32_t* positive, const uint32_t* negative, int64_t n,
+                            int32_t cn, int32_t* homozygous);
 
 /* ---- EM strategy: typing_em.py:68-188.
  * gk_em_sets: per-row candidate-allele bit sets (getCandidateAllelePerRead + getMostFreqAllele).

@@ -468,15 +468,12 @@ int gk_search_destroy(gk_search* s) {
 // Per position the reference sums counts per label, skips positions with one label or only negative labels,
 // keeps counts > 3, needs their total >= 20, and calls the position heterozygous when the second largest kept
 // share is > 0.1 and > 1 / (2 cn).  *homozygous = 1 when no position is heterozygous.
-int gk_site_verdict(const int64_t* pos, const int64_t* code, const uint8_t* negative, const int64_t* count, int64_t n,
-                    int32_t cn, int32_t* homozygous) {
-  GK_REQUIRE(homozygous && cn >= 1 && (n == 0 || (pos && code && negative && count)), "bad verdict arguments");
-  *homozygous = 1;
-  if (n == 0) return GK_OK;
-  struct Obs { int64_t pos, label; int64_t cnt; };
-  std::vector<Obs> obs((size_t)n);
-  for (int64_t i = 0; i < n; ++i) obs[i] = Obs{pos[i], (code[i] << 1) | (negative[i] ? 1 : 0), count[i]};
-  std::sort(obs.begin(), obs.end(), [](const Obs& a, const Obs& b) {
+namespace {
+struct SiteObs { int64_t pos, label; int64_t cnt; };
+
+// the verdict over flat (position, label, count) observations; label = code << 1 | negative
+int sites_homozygous(std::vector<SiteObs>& obs, int32_t cn) {
+  std::sort(obs.begin(), obs.end(), [](const SiteObs& a, const SiteObs& b) {
     return a.pos != b.pos ? a.pos < b.pos : a.label < b.label;
   });
   std::vector<int64_t> counts;
@@ -504,8 +501,50 @@ int gk_site_verdict(const int64_t* pos, const int64_t* code, const uint8_t* nega
     // counts are descending: the kept ones are a prefix; the second largest share decides
     const double second = (double)counts[1] / (double)total;
     if (!(second > 0.1)) continue;          // `major` then has one entry (shares are descending too)
-    if (second > (1.0 / (double)(cn * 2))) { *homozygous = 0; return GK_OK; }
+    if (second > (1.0 / (double)(cn * 2))) return 0;
   }
+  return 1;
+}
+}  // namespace
+
+int gk_site_verdict(const int64_t* pos, const int64_t* code, const uint8_t* negative, const int64_t* count, int64_t n,
+                    int32_t cn, int32_t* homozygous) {
+  GK_REQUIRE(homozygous && cn >= 1 && (n == 0 || (pos && code && negative && count)), "bad verdict arguments");
+  *homozygous = 1;
+  if (n == 0) return GK_OK;
+  std::vector<SiteObs> obs((size_t)n);
+  for (int64_t i = 0; i < n; ++i) obs[i] = SiteObs{pos[i], (code[i] << 1) | (negative[i] ? 1 : 0), count[i]};
+  *homozygous = sites_homozygous(obs, cn);
+  return GK_OK;
+}
+
+// The same verdict straight from the surviving tallies: ordinals into `keys` (index keys followed by the sample's
+// novel keys), their positive / negative counts.  Deletions are skipped (typing_mulit_allele.py:829-831); the label
+// of a variant is str(val) in the reference -- the substituted base, or the inserted string (label_of_insert[id]:
+// a one-base insertion prints like a substitution of that base, longer ones get codes of their own).
+int gk_site_verdict_tallies(const uint64_t* keys, int64_t n_keys, const int64_t* label_of_insert, int64_t n_insert,
+                            const int32_t* ordinal, const uint32_t* positive, const uint32_t* negative, int64_t n,
+                            int32_t cn, int32_t* homozygous) {
+  GK_REQUIRE(homozygous && cn >= 1 && (n == 0 || (keys && ordinal && positive && negative)), "bad verdict arguments");
+  *homozygous = 1;
+  std::vector<SiteObs> obs;
+  obs.reserve((size_t)n * 2);
+  for (int64_t i = 0; i < n; ++i) {
+    GK_REQUIRE(ordinal[i] >= 0 && ordinal[i] < n_keys, "tally ordinal outside the key table");
+    const uint64_t k = keys[ordinal[i]];
+    const uint32_t typ = (uint32_t)(k >> GK_KEY_TYP_SHIFT) & 3u;
+    if (typ == GK_TYP_DEL) continue;
+    const int64_t val = (int64_t)(k & GK_KEY_VAL_MASK);
+    int64_t code = val;
+    if (typ == GK_TYP_INS) {
+      GK_REQUIRE(label_of_insert && n_insert > 0, "insertion without a label table");
+      code = label_of_insert[std::min<int64_t>(val, n_insert - 1)];
+    }
+    const int64_t pos = (int64_t)((k >> GK_KEY_POS_SHIFT) & 0xFFFFFFu);
+    if (positive[i]) obs.push_back(SiteObs{pos, code << 1, (int64_t)positive[i]});
+    if (negative[i]) obs.push_back(SiteObs{pos, (code << 1) | 1, (int64_t)negative[i]});
+  }
+  if (!obs.empty()) *homozygous = sites_homozygous(obs, cn);
   return GK_OK;
 }
 

@@ -231,6 +231,20 @@ class Tabulation:
         self._id_names = names
         return names
 
+    def labelTables(self):
+        """(keys of every ordinal -- index variants, then this sample's novel ones --, label code of every inserted
+        string) for ``gk_site_verdict_tallies``; None for list-built tabulations (no packed keys)."""
+        if getattr(self, "_variant_src", None) is not None:
+            return None
+        root = getattr(self, "_root", self)
+        tables = root.__dict__.get("_label_tables")
+        if tables is None:
+            keys_all = np.ascontiguousarray(np.concatenate([self.dindex.host.key, self.novelKeys()]), dtype=np.uint64)
+            strings = getattr(self, "ins_strings", None) or self.dindex.host.ins_strings
+            ins_code = np.array([ord(s) if len(s) == 1 else 256 + i for i, s in enumerate(strings)] or [0], dtype=np.int64)
+            tables = root.__dict__["_label_tables"] = (keys_all, ins_code)
+        return tables
+
     def labelCodes(self, ordinals):
         """Vectorised (pos, label code, is_deletion) of ordinals; equal codes <=> equal ``str(val)``.
 

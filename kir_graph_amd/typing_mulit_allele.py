@@ -825,8 +825,20 @@ class AlleleTyping:
         if cn <= 1:
             return False
         seen, pos, neg = self._variantCounts()       # surviving variants only, compacted on the device
-        pos, neg = pos.astype(np.int64), neg.astype(np.int64)
         tab = self._readset.tab
+        tables = tab.labelTables() if nativeSearch() else None
+        if tables is not None:      # labels, the screen of lines 835-840 and the verdict in one native call
+            import ctypes as C
+            from ._lib import check, lib
+            keys_all, ins_code = tables
+            o_ = np.ascontiguousarray(seen, dtype=np.int32)
+            p_, n_ = np.ascontiguousarray(pos, dtype=np.uint32), np.ascontiguousarray(neg, dtype=np.uint32)
+            verdict = C.c_int32()
+            check(lib().gk_site_verdict_tallies(keys_all.ctypes.data, len(keys_all), ins_code.ctypes.data, len(ins_code),
+                                                o_.ctypes.data, p_.ctypes.data, n_.ctypes.data, len(o_), cn,
+                                                C.byref(verdict)))
+            return bool(verdict.value)
+        pos, neg = pos.astype(np.int64), neg.astype(np.int64)
         fields = tab.labelCodes(seen)
         if fields is not None:
             # vectorised screen: only positions with >= 2 distinct observations, one of them positive,

@@ -898,3 +898,67 @@ def test_wide_records_of_the_native_and_the_python_packer_agree():
     # without a spill list the Python packer keeps its old limit
     with pytest.raises(packed.PackCapacityError):
         packed.packPairs(list(pairLines(lines)), gidx)
+
+
+def test_site_verdict_from_tallies_equals_reference_loop():
+    """gk_site_verdict_tallies: ordinals + positive / negative tallies -> the verdict of typing_mulit_allele.py:829-857,
+    labels being str(val) (a one-base insertion prints like a substitution of that base, deletions are skipped)."""
+    import ctypes as C
+    from collections import defaultdict
+    from kir_graph_amd.index import packKey
+    rng = np.random.default_rng(11)
+    strings = ["A", "C", "AC", "GGT", "T"]
+    ins_code = np.array([ord(s) if len(s) == 1 else 256 + i for i, s in enumerate(strings)], dtype=np.int64)
+    verdicts = set()
+    for trial in range(300):
+        n_keys = int(rng.integers(5, 80))
+        keys, labels, is_del, positions = [], [], [], []
+        for _ in range(n_keys):
+            pos = int(rng.integers(0, 10))
+            typ = int(rng.choice([0, 1, 1, 1, 2]))            # insertion, substitution, deletion ranks of the key
+            if typ == 1:
+                val = int(rng.choice([65, 67, 71, 84]))
+                label = chr(val)
+            elif typ == 0:
+                val = int(rng.integers(len(strings)))
+                label = strings[val]
+            else:
+                val = int(rng.integers(1, 9))
+                label = str(val)
+            keys.append(packKey(int(rng.integers(0, 3)), pos, typ, val))
+            labels.append(label); is_del.append(typ == 2); positions.append(pos)
+        keys = np.array(keys, dtype=np.uint64)
+        n = int(rng.integers(1, n_keys + 1))
+        ords = np.sort(rng.choice(n_keys, size=n, replace=False)).astype(np.int32)
+        big = rng.random(n) < 0.7
+        pcount = np.where(rng.random(n) < 0.6, np.where(big, rng.integers(4, 60, n), rng.integers(1, 4, n)), 0).astype(np.uint32)
+        ncount = np.where(rng.random(n) < 0.6, np.where(big, rng.integers(4, 60, n), rng.integers(1, 4, n)), 0).astype(np.uint32)
+        cn = int(rng.integers(2, 5))
+        site = defaultdict(lambda: defaultdict(int))
+        for o, p_, n_ in zip(ords.tolist(), pcount.tolist(), ncount.tolist()):
+            if is_del[o]:
+                continue
+            if p_:
+                site[positions[o]][labels[o]] += p_
+            if n_:
+                site[positions[o]][f"*{labels[o]}"] += n_
+        hits = 0
+        for obs in site.values():
+            if len(obs) <= 1 or all("*" in k for k in obs):
+                continue
+            counts = [c for c in sorted(obs.values(), reverse=True) if c > 3]
+            total = sum(counts)
+            if total < 20:
+                continue
+            major = [c / total for c in counts if c / total > 0.1]
+            if len(major) == 1:
+                continue
+            if major[1] > (1 / (cn * 2)):
+                hits += 1
+        verdict = C.c_int32()
+        _lib.check(_lib.lib().gk_site_verdict_tallies(keys.ctypes.data, len(keys), ins_code.ctypes.data, len(ins_code),
+                                                      ords.ctypes.data, pcount.ctypes.data, ncount.ctypes.data, n, cn,
+                                                      C.byref(verdict)))
+        assert bool(verdict.value) == (hits == 0), trial
+        verdicts.add(bool(verdict.value))
+    assert verdicts == {True, False}
