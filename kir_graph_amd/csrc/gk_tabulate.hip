@@ -751,12 +751,12 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
 int gk_tabulate_spilled(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n_pairs, gk_dptr d_corr,
                         gk_dptr d_gene_pos0, const gk_mate_wide* wide, const int64_t* spill_pair, int64_t n_spill,
                         gk_tab** out) {
-  // Hash table of the novel variants: a slot per mate to begin with (distinct novel variants are few -- read errors
+  // Hash table of the novel variants: a slot per mate to begin with, 2^22 at most (distinct novel variants are few -- read errors
   // repeat, positions are finite -- while the worst case, every event of every mate novel, would need 44 slots per
   // mate: 2^24 slots, i.e. 200 MB to clear and three passes over them per sample).  A sample that fills half of it
   // is tabulated again with a table eight times the size.
   uint32_t log2cap = 16;
-  while ((1ull << log2cap) < (uint64_t)(2 * std::max<int64_t>(n_pairs, 0)) && log2cap < 30) ++log2cap;
+  while ((1ull << log2cap) < (uint64_t)(2 * std::max<int64_t>(n_pairs, 0)) && log2cap < 22) ++log2cap;   // at most 4 M slots to begin with
   if (const char* e = getenv("GK_NOVEL_LOG2CAP")) log2cap = (uint32_t)std::min(30, std::max(4, atoi(e)));   // tests: force the retries
   uint32_t log2max = 16;
   while ((1ull << log2max) < (uint64_t)(2 * std::max<int64_t>(n_pairs, 0)) * GK_WIDE_EVENTS * 2 && log2max < 31) ++log2max;
