@@ -134,6 +134,7 @@ struct gk_index {
   int32_t* d_lb_a = nullptr;
   int32_t* d_lb_t = nullptr;
   int32_t* d_gene_pbase = nullptr;
+  int32_t* d_snp_ord = nullptr;     // per position and base (A, C, G, T): ordinal of that substitution, -1 when the index has none
   int32_t n_var = 0, n_gene = 0;
   std::vector<int32_t> gene_vbeg;
 };

@@ -112,6 +112,7 @@ struct IndexView {
   const int32_t* lb_a;        // per position: first ordinal with key >= (gene, pos, single, 'A')
   const int32_t* lb_t;        // ... >= (gene, pos, single, 'T')
   const int32_t* gene_pbase;  // [n_gene + 1] first table entry of every gene
+  const int32_t* snp_ord;     // per position, 4 entries: ordinal of the substitution to A / C / G / T there, -1 = none
 };
 
 // first ordinal whose key is >= k, where k = (ref, pos, ...)
@@ -235,8 +236,19 @@ __device__ inline void walk_mate(const View& r, const IndexView& ix, const Novel
       }
     }
     const uint64_t k = gk_make_key(ref, pos, typ, val);
-    const int i = typ == GK_TYP_SINGLE ? lower_bound_snp(ix, ref, pos, k) : lower_bound_key(ix, ref, pos, k);
-    const bool known = i < ix.n_var && ix.key[i] == k;
+    int i;
+    bool known;
+    const int base_code = val == 'A' ? 0 : val == 'C' ? 1 : val == 'G' ? 2 : val == 'T' ? 3 : -1;
+    if (typ == GK_TYP_SINGLE && base_code >= 0 && (int)ref < ix.n_gene) {
+      // a substitution to a plain base: its ordinal (or "not in the index") is ONE table read, not a bound look-up, a
+      // short scan over the keys of the position and a key comparison -- three to four dependent L2 round trips
+      const int tbase = ix.gene_pbase[ref], n_pos = ix.gene_pbase[ref + 1] - tbase;
+      i = (int)pos < n_pos - 1 ? ix.snp_ord[(int64_t)(tbase + (int)pos) * 4 + base_code] : -1;
+      known = i >= 0;
+    } else {
+      i = typ == GK_TYP_SINGLE ? lower_bound_snp(ix, ref, pos, k) : lower_bound_key(ix, ref, pos, k);
+      known = i < ix.n_var && ix.key[i] == k;
+    }
     const bool is_n = typ == GK_TYP_SINGLE && val == 'N';
     if (is_n) wk.any_n = 1;
     evw[wk.n] = (known ? (uint32_t)i : (kEvNovel | (pos & 0xFFFFFFu))) | (is_n ? kEvIsN : 0u);
@@ -687,7 +699,7 @@ int gk_index_create(gk_ctx* ctx, const uint64_t* key, int32_t n_var, const int32
   GK_HIP(hipMemcpyAsync(idx->d_bucket, bucket.data(), bucket.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   GK_HIP(hipMemcpyAsync(idx->d_gene_boff, boff.data(), boff.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   // per-position bounds: gene g has (last variant position + 2) entries, the last one = the gene's end ordinal
-  std::vector<int32_t> pbase((size_t)n_gene + 1, 0), lb_a, lb_t;
+  std::vector<int32_t> pbase((size_t)n_gene + 1, 0), lb_a, lb_t, snp_ord;
   for (int g = 0; g < n_gene; ++g) {
     const int32_t v0 = gene_vbeg[g], v1 = gene_vbeg[g + 1];
     const uint32_t n_pos = v1 > v0 ? gk_key_pos(key[v1 - 1]) + 2u : 1u;
@@ -699,10 +711,20 @@ int gk_index_create(gk_ctx* ctx, const uint64_t* key, int32_t n_var, const int32
       while (it < v1 && key[it] < kt) ++it;
       lb_a.push_back(ia);
       lb_t.push_back(it);
+      for (const char base : {'A', 'C', 'G', 'T'}) {     // the substitutions listed at p lie between the two bounds
+        const uint64_t kb = gk_make_key((uint32_t)g, p, GK_TYP_SINGLE, (uint32_t)base);
+        int32_t at = -1;
+        for (int32_t v = ia; v < v1 && key[v] <= kb; ++v)
+          if (key[v] == kb) at = v;
+        snp_ord.push_back(at);
+      }
     }
     lb_a.push_back(v1);
     lb_t.push_back(v1);
+    for (int q = 0; q < 4; ++q) snp_ord.push_back(-1);
   }
+  GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_snp_ord, snp_ord.size() * sizeof(int32_t)));
+  GK_HIP(hipMemcpyAsync(idx->d_snp_ord, snp_ord.data(), snp_ord.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_lb_a, lb_a.size() * sizeof(int32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_lb_t, lb_t.size() * sizeof(int32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&idx->d_gene_pbase, pbase.size() * sizeof(int32_t)));
@@ -731,6 +753,7 @@ int gk_index_destroy(gk_index* idx) {
   gk_pool_free(ctx,idx->d_lb_a);
   gk_pool_free(ctx,idx->d_lb_t);
   gk_pool_free(ctx,idx->d_gene_pbase);
+  gk_pool_free(ctx,idx->d_snp_ord);
   delete idx;
   return GK_OK;
 }
@@ -814,7 +837,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
 
   const IndexView ix{idx->d_key, idx->d_bucket, idx->d_gene_boff, idx->n_var, idx->n_gene,
                      gk_ptr<uint8_t>(d_corr), gk_ptr<int64_t>(d_gene_pos0), idx->d_del_bits, idx->d_lb_a, idx->d_lb_t,
-                     idx->d_gene_pbase};
+                     idx->d_gene_pbase, idx->d_snp_ord};
   if (n_mates) {
     GK_PROF(ctx, GK_K_TAB_COUNT, GK_KERNEL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
                        nt, seq_stride, cnt, valid, d_err, ev_save, lo_save, mask_save));
