@@ -372,8 +372,8 @@ def launch_ranks(args, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=96)     # long enough for the ramp and the uneven finish of the workers not to show (1 % at 96 steps, 4 % at 24)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per sample (config 2: 1e6)")
     ap.add_argument("--method", default="pv")
     ap.add_argument("--distinct", type=int, default=N_DISTINCT, help="distinct samples a rank rotates through")

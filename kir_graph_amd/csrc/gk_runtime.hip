@@ -1,6 +1,9 @@
 // Runtime plumbing of the C ABI: context, memory, timing, errors.
 #include <algorithm>
 
+#include <mutex>
+#include <cstring>
+
 #include "gk_common.h"
 
 static thread_local char g_err[512] = "";
@@ -39,6 +42,19 @@ int gk_ctx_create(int device, gk_ctx** out) {
   }
   GK_REQUIRE(device >= 0 && device < c, "device ordinal out of range");
   GK_HIP(hipSetDevice(device));
+  {
+    // How a host thread waits for the GPU (GK_WAIT_POLICY = spin | yield | block; default: the runtime's choice).
+    // Set once per process and device, before the first stream exists; an error (flags already fixed) is ignored.
+    static std::once_flag once;
+    std::call_once(once, [] {
+      const char* e = getenv("GK_WAIT_POLICY");
+      if (!e) return;
+      const unsigned flags = !strcmp(e, "spin") ? hipDeviceScheduleSpin : !strcmp(e, "yield") ? hipDeviceScheduleYield
+                             : !strcmp(e, "block") ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+      (void)hipSetDeviceFlags(flags);
+      (void)hipGetLastError();
+    });
+  }
   gk_ctx* ctx = new gk_ctx();
   ctx->device = device;
   GK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
