@@ -798,7 +798,16 @@ static int bam_pack_impl(gk_bam* b, gk_packer* pk) {
   auto soon = [&](int64_t i, bool head_only) {   // in name order the records are scattered over the inflated stream
     const gk_bam::Rec& rec = b->recs[(size_t)i];
     const uint8_t* p = base + rec.off;
-    for (uint32_t o = 0; o < (head_only ? 128u : rec.size); o += 64) __builtin_prefetch(p + o);
+    if (head_only || rec.size <= 320) {
+      for (uint32_t o = 0; o < (head_only ? 128u : rec.size); o += 64) __builtin_prefetch(p + o);
+      return;
+    }
+    // a long record: its head (fixed fields, name, CIGAR, first bases) and its tail (the optional fields); the base
+    // qualities in between are never read, and a core has only so many line fills in flight
+    __builtin_prefetch(p);
+    __builtin_prefetch(p + 64);
+    __builtin_prefetch(p + 128);
+    for (uint32_t o = rec.size - 192; o < rec.size; o += 64) __builtin_prefetch(p + o);
   };
   auto full = [&](int64_t i, GkAlnRecord& r) {
     const gk_bam::Rec& rec = b->recs[(size_t)i];
