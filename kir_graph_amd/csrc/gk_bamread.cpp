@@ -689,7 +689,34 @@ static int bam_open_impl(const char* path, int32_t name_sorted, gk_bam** out) {
     const uint8_t* base = d.data();
     // A strict total order (name, then READ1 before READ2, then the place in the file), so that any sort gives the
     // order a stable sort by name and mate gives.  The keys usually decide without touching the records.
-    auto before = [base](const SortRec& x, const SortRec& y) {
+    // Read names of one run share a long prefix (instrument, run, flow cell, lane): it decides nothing and would
+    // fill the 16-byte keys, sending every comparison to the records.  The keys (and the full comparison) start
+    // after the prefix common to ALL names, cut back so that it does not end inside or right after a digit run
+    // (a run compares as a number: it must be seen whole).
+    size_t lcp = 0;
+    if (!b->recs.empty()) {
+      const char* first = (const char*)base + b->recs[0].off + 32;
+      const size_t n_all = b->recs.size();
+      const int n_lcp_thr = (int)std::max<size_t>(1, std::min<size_t>((size_t)ingest_threads(), n_all / 4096));
+      std::vector<size_t> part_lcp((size_t)n_lcp_thr, strlen(first));
+      std::vector<std::thread> pool;
+      auto scan = [&](int t) {
+        size_t keep = part_lcp[(size_t)t];
+        for (size_t k = n_all * (size_t)t / (size_t)n_lcp_thr; k < n_all * (size_t)(t + 1) / (size_t)n_lcp_thr && keep; ++k) {
+          const char* name = (const char*)base + b->recs[k].off + 32;
+          size_t i = 0;
+          while (i < keep && name[i] == first[i]) ++i;   // stops at the name's NUL at the latest: first[i] != 0 for i < keep
+          keep = i;
+        }
+        part_lcp[(size_t)t] = keep;
+      };
+      for (int t = 1; t < n_lcp_thr; ++t) pool.emplace_back(scan, t);
+      scan(0);
+      for (auto& th : pool) th.join();
+      lcp = *std::min_element(part_lcp.begin(), part_lcp.end());
+      while (lcp > 0 && isdigit((unsigned char)first[lcp - 1])) --lcp;
+    }
+    auto before = [base, lcp](const SortRec& x, const SortRec& y) {
       if (x.whole & y.whole) {          // unused key bytes are zero and no name byte is: whole keys compare as they are
         if (x.k0 != y.k0) return x.k0 < y.k0;
         if (x.k1 != y.k1) return x.k1 < y.k1;
@@ -700,7 +727,7 @@ static int bam_open_impl(const char* path, int32_t name_sorted, gk_bam** out) {
         if (a0 != b0) return a0 < b0;
         const uint64_t a1 = m > 8 ? x.k1 >> s1 : 0, b1 = m > 8 ? y.k1 >> s1 : 0;
         if (a1 != b1) return a1 < b1;
-        const int t = name_order((const char*)base + x.off + 32, (const char*)base + y.off + 32);
+        const int t = name_order((const char*)base + x.off + 32 + lcp, (const char*)base + y.off + 32 + lcp);
         if (t) return t < 0;
       }
       if (x.mate != y.mate) return x.mate < y.mate;   // READ1 (0x40) before READ2 (0x80)
@@ -725,7 +752,7 @@ static int bam_open_impl(const char* path, int32_t name_sorted, gk_bam** out) {
         r.off = b->recs[k].off;
         r.size = b->recs[k].size;
         r.mate = (uint8_t)(rd16(base + r.off + 14) & 0xC0u);
-        name_key((const char*)base + r.off + 32, r);
+        name_key((const char*)base + r.off + 32 + lcp, r);
       }
     });
     const size_t n_bucket = n < 16384 ? 1 : std::min<size_t>(256, std::max<size_t>(4, n / 16384));

@@ -962,3 +962,44 @@ def test_site_verdict_from_tallies_equals_reference_loop():
         assert bool(verdict.value) == (hits == 0), trial
         verdicts.add(bool(verdict.value))
     assert verdicts == {True, False}
+
+
+def test_name_collation_with_a_long_common_prefix(tmp_path):
+    """Names of one sequencing run share instrument / run / flow cell / lane: the sort keys start after the prefix
+    common to all names (cut back to the start of a digit run it would split), and the order is still the plain
+    comparator's -- also when the common prefix ends in digits, in zeros, or is the whole of the shortest name."""
+    import functools
+    from bamwriter import samToBam
+    rng = np.random.default_rng(23)
+    g = "KIR_TEST*BACKBONE"
+    header = ["@HD\tVN:1.0\tSO:unsorted", f"@SQ\tSN:{g}\tLN:100000"]
+
+    def order(x, y):
+        fx, fy = x.split("\t", 2), y.split("\t", 2)
+        return _name_order(fx[0], fy[0]) or (int(fx[1]) & 192) - (int(fy[1]) & 192)
+
+    families = {
+        "illumina": lambda i: f"A00123:45:HXXXXXXXX:{1 + i % 2}:{1101 + int(rng.integers(0, 80))}:{int(rng.integers(1000, 30000))}:{int(rng.integers(1000, 99999))}",
+        "digits_at_the_cut": lambda i: f"run7_read10{int(rng.integers(0, 500000))}",        # common prefix ends inside a number
+        "zeros_at_the_cut": lambda i: f"s00{int(rng.integers(0, 300000)):0{int(rng.integers(1, 8))}d}x",
+        "one_is_the_prefix": lambda i: "frag" if i == 0 else f"frag{'' if i % 3 else '.'}{int(rng.integers(0, 900000))}",
+    }
+    for tag, make in families.items():
+        names = []
+        seen = set()
+        i = 0
+        while len(names) < 9000:          # 18 k records: the bucket path of the sample sort
+            nm = make(i)
+            i += 1
+            if nm not in seen:
+                seen.add(nm)
+                names.append(nm)
+        lines = []
+        for k, name in enumerate(names):
+            pos = 100 + k
+            lines.append(f"{name}\t147\t{g}\t{pos + 200}\t60\t10M\t=\t{pos}\t-210\tACGTACGTAC\tIIIIIIIIII\tNM:i:0")
+            lines.append(f"{name}\t99\t{g}\t{pos}\t60\t10M\t=\t{pos + 200}\t210\tACGTACGTAC\tIIIIIIIIII\tNM:i:0")
+        path = str(tmp_path / f"{tag}.bam")
+        samToBam(header + lines, path, block=20000)
+        got = b"".join(packed.bamChunks(path, chunk_bytes=1 << 15)).decode().split("\n")[:-1]
+        assert got == sorted(lines, key=functools.cmp_to_key(order)), tag
