@@ -117,11 +117,14 @@ def buildMask(variants: list[Variant], alleles: list[str]) -> np.ndarray:
     words = max(1, (len(alleles) + 31) // 32)
     col = {a: i for i, a in enumerate(alleles)}
     mask = np.zeros((len(variants), words), dtype=np.uint32)
-    for i, v in enumerate(variants):
-        for a in v.allele:
-            j = col.get(a)
-            if j is not None:
-                mask[i, j >> 5] |= np.uint32(1 << (j & 31))
+    rows, cols = [], []
+    for i, v in enumerate(variants):          # (variant, allele) incidences as two flat lists, set in one numpy call
+        js = [col[a] for a in v.allele if a in col]
+        cols += js
+        rows += [i] * len(js)
+    if rows:
+        r, c = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+        np.bitwise_or.at(mask, (r, c >> 5), (np.uint32(1) << (c & 31).astype(np.uint32)))
     return mask
 
 
