@@ -44,6 +44,20 @@ WORKER = textwrap.dedent("""
             def close(self):
                 dist.destroy_process_group()
         transport = Transport()
+    elif os.environ["GK_TEST_TRANSPORT"] == "rccl_hang":
+        # the communicator's set-up never returns on rank 1 (a bootstrap that cannot reach its peers) and fails on
+        # rank 0: after the deadline both ranks carry on over the file backend
+        import threading
+        real = comm.Comm.__init__
+        def stuck(self, rank, world, store, dev=None, backend="rccl"):
+            if backend == "rccl" and rank == 1:
+                threading.Event().wait()          # for ever
+            real(self, rank, world, store, dev=dev, backend=backend)
+        comm.Comm.__init__ = stuck
+        os.environ["GK_RCCL_INIT_TIMEOUT"] = "2"
+        transport = comm.initFromEnv(dev=object(), backend="rccl")
+        comm.Comm.__init__ = real
+        assert transport.backend == "file" and transport.world == 2
     elif os.environ["GK_TEST_TRANSPORT"] == "rccl_fallback":
         # no GPU here: the RCCL communicator cannot be made on any rank, and all ranks agree on the file backend
         transport = comm.initFromEnv(backend="rccl")
@@ -136,3 +150,7 @@ def test_allgather_depths_world_size_2_gloo(tmp_path):
 
 def test_rccl_failure_falls_back_to_the_file_backend_on_every_rank(tmp_path):
     _run_two_ranks(tmp_path, "rccl_fallback")
+
+
+def test_rccl_set_up_that_never_returns_falls_back_after_the_deadline(tmp_path):
+    _run_two_ranks(tmp_path, "rccl_hang")
