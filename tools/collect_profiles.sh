@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the round's evidence under gpurun_out/rNN (run on the GPU box through gpurun); the summaries that are
-# judged are then copied into profiles/ by hand (tools/collect_profiles.sh prints the copy commands at the end).
+# judged are then copied into profiles/ in the build container: bash tools/install_profiles.sh <tag>.
 #   bash tools/collect_profiles.sh [round tag, default r02]
 set -e
 R=$GRAFT_REPO_ROOT
@@ -33,5 +33,4 @@ for k in compat_kernel tab_count minsum_sad fraction_chunks maxsum_chunks select
 done
 ls $O $O/stats
 cat $O/bench.json
-echo "copy: $O/bench.json -> profiles/${TAG}_bench.json; $O/stats/b_kernel_stats.csv -> profiles/${TAG}_bench_serial_kernel_stats.csv;"
-echo "      $O/bench_under_rocprof.json; $O/traffic_<dominant>.json -> profiles/${TAG}_bench_traffic.json; $O/pmc_*.txt"
+echo "then, in the build container: bash tools/install_profiles.sh $TAG   (copies the summaries into profiles/)"
