@@ -186,6 +186,59 @@ def test_native_search_host_half_equals_the_oracle(host_search, bound):
     assert exact_steps > 0 and (bounded_steps > 0) == bound
 
 
+def test_site_verdicts_of_the_host_only_build(host_search):
+    """gk_site_verdict_tallies of the host-only build (the one the sanitizers see) against the plain loop of
+    typing_mulit_allele.py:829-857 on random tallies: substitutions, insertions of one and several bases, deletions."""
+    from collections import defaultdict
+    from kir_graph_amd.index import packKey
+    rng = np.random.default_rng(3)
+    strings = ["A", "G", "AT", "CCG"]
+    ins_code = np.array([ord(x) if len(x) == 1 else 256 + i for i, x in enumerate(strings)], dtype=np.int64)
+    seen = set()
+    for trial in range(200):
+        n_keys = int(rng.integers(4, 60))
+        keys, labels, positions, dels = [], [], [], []
+        for _ in range(n_keys):
+            pos, typ = int(rng.integers(0, 8)), int(rng.choice([0, 1, 1, 2]))
+            val = int(rng.choice([65, 67, 71, 84])) if typ == 1 else int(rng.integers(len(strings))) if typ == 0 else int(rng.integers(1, 6))
+            keys.append(packKey(0, pos, typ, val))
+            labels.append(chr(val) if typ == 1 else strings[val] if typ == 0 else str(val))
+            positions.append(pos); dels.append(typ == 2)
+        keys = np.array(keys, dtype=np.uint64)
+        n = int(rng.integers(1, n_keys + 1))
+        ords = np.sort(rng.choice(n_keys, size=n, replace=False)).astype(np.int32)
+        pc = np.where(rng.random(n) < 0.6, rng.integers(1, 50, n), 0).astype(np.uint32)
+        nc = np.where(rng.random(n) < 0.6, rng.integers(1, 50, n), 0).astype(np.uint32)
+        cn = int(rng.integers(2, 5))
+        site = defaultdict(lambda: defaultdict(int))
+        for o, a, b in zip(ords.tolist(), pc.tolist(), nc.tolist()):
+            if dels[o]:
+                continue
+            if a:
+                site[positions[o]][labels[o]] += a
+            if b:
+                site[positions[o]]["*" + labels[o]] += b
+        hits = 0
+        for obs in site.values():
+            if len(obs) <= 1 or all("*" in k for k in obs):
+                continue
+            counts = [c for c in sorted(obs.values(), reverse=True) if c > 3]
+            total = sum(counts)
+            if total < 20:
+                continue
+            major = [c / total for c in counts if c / total > 0.1]
+            if len(major) > 1 and major[1] > (1 / (cn * 2)):
+                hits += 1
+        verdict = C.c_int32()
+        rc = host_search.gk_site_verdict_tallies(keys.ctypes.data_as(C.c_void_p), C.c_int64(len(keys)),
+                                                 ins_code.ctypes.data_as(C.c_void_p), C.c_int64(len(ins_code)),
+                                                 ords.ctypes.data_as(C.c_void_p), pc.ctypes.data_as(C.c_void_p),
+                                                 nc.ctypes.data_as(C.c_void_p), C.c_int64(n), C.c_int32(cn), C.byref(verdict))
+        assert rc == 0 and bool(verdict.value) == (hits == 0), trial
+        seen.add(bool(verdict.value))
+    assert seen == {True, False}
+
+
 def _clang_asan():
     import glob
     hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
@@ -195,13 +248,13 @@ def _clang_asan():
 def test_host_search_under_sanitizers():
     """The same comparison with the host half built with AddressSanitizer + UndefinedBehaviorSanitizer (host compile
     of the ROCm clang; its runtime is preloaded into a child interpreter): no out-of-bounds access, no overflow, no
-    misaligned or invalid value on any of the 80 searches."""
+    misaligned or invalid value on any of the 80 searches and 200 site verdicts."""
     import sys
     asan = _clang_asan()
     if asan is None or os.environ.get("GK_HOSTSEARCH_SANITIZE") == "1":
         pytest.skip("no clang sanitizer runtime (or already inside the sanitized run)")
     env = dict(os.environ, GK_HOSTSEARCH_SANITIZE="1", LD_PRELOAD=asan,      # (the UBSan checks live in the ASan runtime)
                ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
-    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "equals_the_oracle",
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "equals_the_oracle or host_only_build",
                           "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert res.returncode == 0 and "2 passed" in res.stdout, (res.stdout[-1500:], res.stderr[-3000:])
+    assert res.returncode == 0 and "3 passed" in res.stdout, (res.stdout[-1500:], res.stderr[-3000:])
