@@ -74,6 +74,8 @@ def one(seed: int) -> str:
                               err_rate=float(rng.choice([0.0, 0.001, 0.01])),
                               frac_multi=float(rng.choice([0.0, 0.05, 0.3])))
     lines = synth.toSamLines(sample)
+    if os.environ.get("GK_FUZZ_SPILL") == "1":   # a few pairs with 17-60 mismatches per mate: what the HIP path keeps in its wide record format
+        lines = synth.withManyMismatches(lines, sidx, rng.choice(sample.n_pairs, size=min(6, sample.n_pairs), replace=False).tolist(), rng)
     d = tempfile.mkdtemp()
     sidx.write(d + "/ix")
     rv = rh.getVariants(d + "/ix")
