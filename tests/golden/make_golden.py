@@ -305,6 +305,52 @@ def typing_case():
     return out
 
 
+# ------------------------------------------------------------------ T12: reads beyond the 128-byte device record
+def t12_wide():
+    """The reference's lists and novel variants for a small sample in which some pairs carry more than the 128-byte
+    device record holds (17-60 substitutions per mate, a 4200-base novel deletion, 19 CIGAR ops): the HIP path keeps
+    such pairs in its wide record format (gk_mate_wide) and must give exactly these lists."""
+    import re
+    sidx = synth.makeIndex(seed=77, n_genes=2, len_range=(9000, 11000), var_range=(200, 300), allele_range=(10, 20))
+    prefix, text = index_text(sidx)
+    rv = rh.getVariants(prefix)
+    sample = synth.makeSample(sidx, seed=78, n_pairs=240)
+    lines = synth.toSamLines(sample)
+    rng = np.random.default_rng(79)
+    plain = [p for p in range(240) if all(l.split("\t")[5] == "150M" and int(l.split("\t")[1]) & 2 for l in lines[2 * p:2 * p + 2])]
+    lines = synth.withManyMismatches(lines, sidx, plain[3:40:6], rng)
+
+    def copy_of_backbone(line, cigar):
+        f = line.split("\t")
+        bb = sidx.backbone[f[2]]
+        bb = bb if isinstance(bb, str) else bytes(bytearray(bb)).decode()
+        cur, run, seq, md = int(f[3]) - 1, 0, "", ""
+        for n, op in re.findall(r"(\d+)([MD])", cigar):
+            n = int(n)
+            if op == "M":
+                seq += bb[cur:cur + n]; cur += n; run += n
+            else:
+                md += f"{run}^{bb[cur:cur + n]}"; run = 0; cur += n
+        md += str(run)
+        f[5], f[9], f[10] = cigar, seq, "I" * len(seq)
+        f = [c for c in f if not c.startswith("Zs:Z:")]
+        f = ["MD:Z:" + md if c.startswith("MD:Z:") else "NM:i:0" if c.startswith("NM:i:") else c for c in f]
+        return "\t".join(f)
+
+    far = [p for p in plain[40:] if int(lines[2 * p].split("\t")[3]) + 4600 < len(sidx.backbone[lines[2 * p].split("\t")[2]])]
+    lines[2 * far[0]] = copy_of_backbone(lines[2 * far[0]], "70M4200D80M")
+    lines[2 * far[1] + 1] = copy_of_backbone(lines[2 * far[1] + 1], "10M1D" * 9 + "60M")
+    rh.readBam = lambda f: lines
+    kept = [p for p in rh.readPair("x") if rh.filterRead(p[0]) and rh.filterRead(p[1])]
+    RV.novel_id = 0
+    data = rh.extractVariant(kept, rv)
+    return {"index": text, "lines": lines,
+            "reads": [{"lpv": r.lpv, "lnv": r.lnv, "rpv": r.rpv, "rnv": r.rnv, "multiple": r.multiple,
+                       "backbone": r.backbone} for r in data["reads"]],
+            "novel": [[v.id, v.typ, v.pos, v.val, v.length, v.ref] for v in data["variants"] if v.id.startswith("nv")],
+            "most_positives": max(len(r.lpv) + len(r.rpv) for r in data["reads"])}
+
+
 # ------------------------------------------------------------------ T8: copy number
 def t8_cn():
     import pandas as pd
@@ -409,3 +455,5 @@ if __name__ == "__main__":
         dump("t10_sums.json.gz", {"numpy": np.__version__, "cases": t10_sums()})
     if want("t11"):
         dump("t11_pileup.json.gz", t11_pileup())
+    if want("t12"):
+        dump("t12_wide.json.gz", t12_wide())

@@ -104,3 +104,29 @@ def test_em_abundances(typed_case):
         got = sorted([[r.allele, r.count, r.prob] for r in typer._result[gene]])
         assert [g[:2] for g in got] == [r[:2] for r in rows]
         assert np.allclose([g[2] for g in got], unhex([r[2] for r in rows]), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("how", ["python packer", "native packer"])
+def test_reads_beyond_the_128_byte_record_equal_the_reference(device, tmp_path, how):
+    """T12 (fixture made by the reference itself): pairs with 17-60 substitutions per mate, a 4200-base novel deletion
+    and 19 CIGAR ops take the wide record format (gk_mate_wide, tab_count_wide / tab_emit_wide) and give the reference's
+    lists and novel variants -- ids in first-appearance order included."""
+    from kir_graph_amd.hisat2 import extractVariantFromText
+    t12 = load("t12_wide.json.gz")
+    gidx = index_from(t12["index"], tmp_path)
+    Variant.novel_id = 0
+    if how == "python packer":
+        data = extractVariant(pairLines(t12["lines"]), gidx, dev=device)
+    else:
+        sam = tmp_path / "t12.sam"
+        sam.write_text("\n".join(t12["lines"]) + "\n")
+        data = extractVariantFromText(str(sam), gidx, dev=device, keep_text=False)
+    assert int(np.count_nonzero(data.tab.mates.download()["n_cig"] == 0xFF)) >= 2 * 8      # the wide pairs are there
+    reads = data.reads()
+    assert len(reads) == len(t12["reads"])
+    for got, want in zip(reads, t12["reads"]):
+        assert (got.lpv, got.lnv, got.rpv, got.rnv) == (want["lpv"], want["lnv"], want["rpv"], want["rnv"])
+        assert got.multiple == want["multiple"] and got.backbone == want["backbone"]
+    novel = [[v.id, v.typ, v.pos, v.val, v.length, v.ref] for v in data.variants if str(v.id).startswith("nv")]
+    assert novel == t12["novel"]
+    data.tab.close()

@@ -238,3 +238,18 @@ def test_pileup_correction_rule(t11):
         else:
             v = Variant(pos=pos, typ="single", ref=t11["gene"], val=val, length=1)
         assert str(ot.pileupCorrect(v, ratio).val) == str(want), (pos, val)
+
+
+def test_tabulate_reads_beyond_the_128_byte_record():
+    """T12: the reference's lists for pairs with 17-60 substitutions per mate, a 4200-base novel deletion and 19 CIGAR
+    ops -- the inputs the HIP path keeps in its wide record format; the oracle has no capacity and must agree."""
+    t12 = load("t12_wide.json.gz")
+    variants = getVariants(write_index(t12["index"]))
+    data = ot.tabulateLines(t12["lines"], variants)
+    assert len(data["reads"]) == len(t12["reads"])
+    for got, want in zip(data["reads"], t12["reads"]):
+        for k in ("lpv", "lnv", "rpv", "rnv", "multiple", "backbone"):
+            assert got[k] == want[k]
+    novel = [[v.id, v.typ, v.pos, v.val, v.length, v.ref] for v in data["variants"] if str(v.id).startswith("nv")]
+    assert novel == t12["novel"]
+    assert t12["most_positives"] > 44        # more events than two gk_mate records could hold
