@@ -25,6 +25,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                   GK_PROCS_PER_GPU=1 GK_THREADS=1 GK_PREFETCH=0, profiles/)
   cpu_baseline    the oracle (CPU restatement of the reference) on a bounded sample of the same
                   workload, one core and N-way over the host's cores
+  host            what the step costs on the host: core-seconds per step (user + system time of every worker
+                  process of rank 0 over the timed region, getrusage), cores busy on average, the cores the rank was
+                  allowed (``--cores-per-gpu K`` pins every rank and its workers to K cores of its own before
+                  anything touches HIP: the budget an 8-GPU node leaves each rank)
 """
 from __future__ import annotations
 
@@ -46,6 +50,41 @@ N_DISTINCT = 3          # distinct samples a rank rotates through
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def allowed_cores() -> list[int]:
+    try:
+        return sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return list(range(os.cpu_count() or 1))
+
+
+def cgroup_cores() -> int | None:
+    """The container's CPU quota in cores (cgroup v2 cpu.max), None when unlimited / unknown."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1, int(quota) // int(period))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def pin_rank(local_rank: int, k: int) -> list[int]:
+    """``--cores-per-gpu K``: this rank (and every worker process / thread it starts later) runs on K cores of its
+    own -- cores [local_rank * K, (local_rank + 1) * K) of the allowed set, wrapping around when the set is smaller.
+    Must run before the first HIP call (the runtime's helper threads inherit the mask)."""
+    cores = allowed_cores()
+    mine = [cores[(local_rank * k + i) % len(cores)] for i in range(min(k, len(cores)))]
+    os.sched_setaffinity(0, set(mine))
+    return sorted(set(mine))
+
+
+def cpu_seconds() -> float:
+    """User + system time of this process (all its threads) so far."""
+    import resource
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    return ru.ru_utime + ru.ru_stime
 
 
 # ------------------------------------------------------------------------------------------ inputs
@@ -171,17 +210,10 @@ def cpu_baseline(method, n_pairs):
     import multiprocessing as mp
     t_tab, t_typ = _oracle_leg((99, n_pairs, method))
     single = 2 * n_pairs / (t_tab + t_typ)
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
-    try:      # a container's CPU quota (cgroup v2: "<quota> <period>" or "max ..."): the cores that can really run at once
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            cores = max(1, min(cores, int(quota) // int(period)))
-    except (OSError, ValueError):
-        pass
+    cores = len(allowed_cores())
+    quota = cgroup_cores()      # a container's CPU quota: the cores that can really run at once
+    if quota is not None:
+        cores = max(1, min(cores, quota))
     n_way = max(1, min(cores, 32))
     out = {"value": single, "unit": "reads/s", "cores": 1, "kind": "port",
            "sample": f"{n_pairs} pairs of the same synthetic workload (R_g <= 8 k per gene: the reference's own "
@@ -239,9 +271,15 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
     dev.sync()
     comm = None
     if j == 0 and world > 1:
-        comm = gk_comm.initFromEnv(dev=dev, backend=backend)
-        if comm.world != args.gpus:
-            raise RuntimeError(f"bench.py: --gpus {args.gpus} but {comm.world} ranks joined")
+        # a scaling run must not quietly measure something else: when the RCCL communicator cannot be made on some
+        # rank every rank stops with a non-zero code (the file backend is used only when it was asked for)
+        try:
+            comm = gk_comm.initFromEnv(dev=dev, backend=backend, fallback=False)
+        except gk_comm.CommError as e:
+            log(f"[bench] rank {rank}: {e}; not falling back (GK_BENCH_BACKEND=file rehearses the launch without RCCL)")
+            os._exit(4)
+        if comm.world != args.gpus or comm.backend != backend:
+            raise RuntimeError(f"bench.py: --gpus {args.gpus} on {backend} but {comm.world} ranks joined on {comm.backend}")
 
     def claims():
         """Samples of the timed region for this worker: all of them, or whatever it gets from the shared counter."""
@@ -301,11 +339,13 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
         comm.barrier()          # RCCL all-reduce + stream synchronise: every rank is ready
     gang_wait("go")
     t0 = time.perf_counter()
+    cpu0 = cpu_seconds()
     last = run_steps(claims(), dev, dindex, gidx, inputs, args.method)
     if last is not None:
         n_valid = last[2]
     for d in all_devices():
         d.sync()
+    cpu_s = cpu_seconds() - cpu0          # this worker's host time for its share of the steps (waits that spin included)
     gang_wait("done")
     if comm is not None:
         comm.barrier()
@@ -313,7 +353,7 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
     prof, call_log = collect() if in_region else ({}, [])
     profiled(False)
     if j:
-        gang["results"].put({"prof": prof, "call_log": call_log})
+        gang["results"].put({"prof": prof, "call_log": call_log, "cpu_s": cpu_s})
         return None
     if comm is not None:
         elapsed = comm.maxF64(elapsed)
@@ -343,26 +383,32 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
                 os.environ["GK_THREADS"] = keep
     from kir_graph_amd.typing_mulit_allele import SEARCH_STATS
     return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm,
-            "search_steps": dict(SEARCH_STATS), "others": others}
+            "search_steps": dict(SEARCH_STATS), "others": others, "cpu_s": cpu_s + sum(o.get("cpu_s", 0.0) for o in others)}
 
 
 # ------------------------------------------------------------------------------------------ launcher
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh processes (this process has
-    not touched HIP and never will), wait for all of them, pass rank 0's JSON line on."""
+    not touched HIP and never will), supervise them -- a rank that fails ends the launch for all, at once -- and
+    pass rank 0's JSON line on."""
+    import uuid
+    from kir_graph_amd.comm import superviseRanks
     rdzv = tempfile.mkdtemp(prefix="gk_bench_rdzv_")
+    token = uuid.uuid4().hex
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
-                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", GK_RDZV_DIR=rdzv)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    codes = [p.wait() for p in procs]
-    if any(codes):
-        log(f"[bench] rank exit codes {codes}: fewer than {args.gpus} ranks finished")
+    with tempfile.TemporaryFile() as out0:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                       LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", GK_RDZV_DIR=rdzv, GK_RDZV_TOKEN=token)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        failed = superviseRanks(procs, rdzv, token)
+        out0.seek(0)
+        text = out0.read().decode(errors="replace")
+    if failed:
+        log(f"[bench] rank exit codes {[p.returncode for p in procs]}: fewer than {args.gpus} ranks finished")
         sys.exit(1)
-    line = [x for x in out0.splitlines() if x.startswith("{")]
+    line = [x for x in text.splitlines() if x.startswith("{")]
     if not line:
         log("[bench] rank 0 printed no result line")
         sys.exit(1)
@@ -380,6 +426,9 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs for the CPU baseline sample (0 = skip)")
     ap.add_argument("--serial-steps", type=int, default=2,
                     help="steps of the one-process serial pass after the timed region (roofline basis; 0 = skip)")
+    ap.add_argument("--cores-per-gpu", type=int, default=0,
+                    help="pin every rank (its worker processes and threads) to this many host cores of its own, "
+                         "before anything touches HIP (0 = no pinning)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--profile-host", action="store_true", help="cProfile one extra step to stderr")
     args = ap.parse_args()
@@ -393,6 +442,8 @@ def main():
         log(f"[bench] --gpus {args.gpus} does not match WORLD_SIZE {world}: start one rank per GPU "
             f"(torchrun --nproc-per-node {args.gpus}, or no launcher at all)")
         sys.exit(2)
+    cores_before = allowed_cores()
+    pinned = pin_rank(local_rank, args.cores_per_gpu) if args.cores_per_gpu > 0 else None
     # Worker processes of this rank on its GPU (see worker()): started first, before anything touches HIP.
     procs = max(1, int(os.environ.get("GK_PROCS_PER_GPU", "4")))
     procs = min(procs, max(1, args.steps))
@@ -504,13 +555,18 @@ def main():
         else:
             out["roofline"] = roofmodel.dominant(prof, call_log)
             out["roofline"]["note_basis"] = "launch times taken inside the timed region (other workers share the GPU)"
-        traffic = measured_traffic(out["roofline"].get("kernel"))
-        if traffic is not None:
-            out["roofline"]["traffic"] = traffic[0]
-            out["roofline"]["traffic_source"] = traffic[1]
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(out["roofline"].get("kernel"))
         if prof:     # --verbose: launch times inside the timed region (kernels of all workers overlap there)
             out["kernel_ms_per_step"] = {k: v[1] / args.steps for k, v in prof.items()}
         out["search_steps"] = res.get("search_steps")    # worker 0: steps bounded by integers / redone with f64 only
+        cpu_s = float(res.get("cpu_s", 0.0))
+        out["host"] = {"host_core_s_per_step": cpu_s / args.steps, "cores_busy": cpu_s / elapsed if elapsed else None,
+                       "cores_per_gpu": args.cores_per_gpu or None, "pinned_to": pinned,
+                       "cores_allowed": len(cores_before), "cgroup_quota_cores": cgroup_cores(),
+                       "worker_processes": procs, "gene_threads": int(os.environ.get("GK_THREADS", "6")),
+                       "wait_policy": os.environ.get("GK_WAIT_POLICY", "runtime default"),
+                       "note": "user + system time of rank 0's worker processes over the timed region (getrusage); "
+                               "a host thread that spins on the GPU counts as busy"}
         if args.cpu_pairs and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.method, args.cpu_pairs)
         print(json.dumps(out), flush=True)
@@ -519,18 +575,30 @@ def main():
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch of ``kernel`` from the committed PMC passes over the serial form of this command
-    (profiles/r02_bench_traffic.json, made by tools/collect_profiles.sh), or None."""
-    path = os.path.join(ROOT, "profiles", "r02_bench_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("kernel") == kernel:
-            return float(t["traffic_bytes_per_launch"]), ("profiles/r02_bench_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                                                          "WRITE_SIZE passes of this command, one process, serial)")
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    """(HBM bytes per launch of ``kernel``, where the figure comes from) from the committed PMC passes over the serial
+    form of this command (profiles/rNN_traffic_<kernel>.json, made by tools/collect_profiles.sh) -- but only from a
+    file that was measured on THIS code: the file records the digest of the device sources it ran
+    (kir_graph_amd.build.sourceDigest) and a file with another digest, or none, is refused.  (None, why) then."""
+    import glob
+    from kir_graph_amd.build import sourceDigest
+    digest = sourceDigest(kernel)
+    stale = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{kernel}.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("kernel") != kernel:
+                continue
+            if t.get("csrc_sha16") != digest:
+                stale.append(os.path.basename(path))
+                continue
+            return float(t["traffic_bytes_per_launch"]), (f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / "
+                                                          f"WRITE_SIZE passes of this command, one process, serial; "
+                                                          f"device sources {digest} = the running code)")
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, (f"no PMC pass of the running device sources ({digest}) is committed"
+                  + (f"; refused as stale: {', '.join(stale)}" if stale else ""))
 
 
 if __name__ == "__main__":

@@ -28,6 +28,39 @@ def outOfDate(lib: Path) -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
+# device source files a kernel's code comes from (everything under csrc/ for a kernel that is not listed)
+KERNEL_SOURCES = {
+    "compat_kernel": ["gk_typing.hip", "gk_lut.h", "gk_common.h"],
+    "count_ids": ["gk_typing.hip", "gk_common.h"],
+    "tab_count": ["gk_tabulate.hip", "gk_common.h"],
+    "tab_emit": ["gk_tabulate.hip", "gk_common.h"],
+    "minsum_sad": ["gk_bound.hip", "gk_common.h"],
+    "select_cut": ["gk_bound.hip", "gk_common.h"],
+    "setmin_u8": ["gk_bound.hip", "gk_common.h"],
+    "fraction_chunks": ["gk_search.hip", "gk_common.h"],
+    "maxsum_chunks": ["gk_search.hip", "gk_common.h"],
+    "combine_chunks": ["gk_search.hip", "gk_common.h"],
+}
+
+
+def sourceDigest(kernel: str | None = None) -> str:
+    """sha256 (first 16 hex digits) of the device sources ``kernel`` is compiled from (``KERNEL_SOURCES``; all of
+    ``csrc/*.hip`` and ``csrc/*.h`` when the kernel is not listed): what a measurement of that kernel belongs to.
+    ``bench.py`` only reports a committed HBM-traffic figure whose recorded digest equals the running code's
+    (tools/pmc_traffic.py writes it)."""
+    import hashlib
+    h = hashlib.sha256()
+    names = KERNEL_SOURCES.get(kernel or "")
+    if names is None:
+        files = sorted((PKG / "csrc").glob("*.hip")) + sorted((PKG / "csrc").glob("*.h"))
+    else:
+        files = [PKG / "csrc" / n for n in names]
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 # Per-source extra flags (none needed at present).
 EXTRA_FLAGS: dict[str, list[str]] = {}
 

@@ -18,7 +18,9 @@ Backends:
 There is no ``torch`` here: the launcher only has to export RANK / WORLD_SIZE / LOCAL_RANK (``torchrun``
 does, ``bench.py --gpus N`` does it itself).  The rendezvous is a directory of small files on the node
 (``GK_RDZV_DIR``, else a name derived from the launcher's pid + start time + MASTER_PORT, which all ranks of a
-launch share and no other launch does); rank 0 removes it on ``close``.
+launch share and no other launch does); rank 0 removes it on ``close``.  Every key carries the launch's token
+(``launchToken``), so keys that a crashed run left in a reused ``GK_RDZV_DIR`` are never read (rank 0 removes them).
+A rank that fails writes an ``abort`` key: peers waiting in ``FileStore.get`` stop at once instead of after the timeout.
 """
 from __future__ import annotations
 
@@ -46,36 +48,58 @@ def _parentStamp() -> str:
     return f"{ppid}_{start}"
 
 
+def launchToken() -> str:
+    """What every rank of ONE launch can compute and no other launch shares: ``GK_RDZV_TOKEN`` when the ranks are
+    started by hand, else the launcher's pid + start time, MASTER_PORT and the elastic restart count."""
+    tok = os.environ.get("GK_RDZV_TOKEN")
+    if tok:
+        return "".join(c if c.isalnum() or c in "_-" else "_" for c in tok)
+    port = os.environ.get("MASTER_PORT", "0")
+    gen = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    return f"{_parentStamp()}_{port}_{gen}"
+
+
 def rendezvousDir() -> str:
     d = os.environ.get("GK_RDZV_DIR")
     if d:
         return d
-    port = os.environ.get("MASTER_PORT", "0")
-    gen = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gk_rdzv_{_parentStamp()}_{port}_{gen}")
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gk_rdzv_{launchToken()}")
 
 
 class FileStore:
-    """Write-once keys in a directory: ``set`` is atomic (rename), ``get`` waits for the key."""
+    """Write-once keys in a directory: ``set`` is atomic (rename), ``get`` waits for the key.  File names start with
+    the launch token: a directory that still holds the keys of a dead run (a reused ``GK_RDZV_DIR``) cannot feed
+    them to this one; ``purgeOthers`` (rank 0) removes them."""
 
-    def __init__(self, path: str, timeout: float = 600.0):
+    def __init__(self, path: str, timeout: float = 600.0, token: str | None = None):
         self.path, self.timeout = path, timeout
+        self.token = launchToken() if token is None else token
         os.makedirs(path, exist_ok=True)
 
+    def _name(self, key: str) -> str:
+        return os.path.join(self.path, f"{self.token}.{key}")
+
     def set(self, key: str, value: bytes) -> None:
-        tmp = os.path.join(self.path, f".{key}.{os.getpid()}.tmp")
+        tmp = os.path.join(self.path, f".{self.token}.{key}.{os.getpid()}.tmp")
         with open(tmp, "wb") as f:
             f.write(value)
-        os.replace(tmp, os.path.join(self.path, key))
+        os.replace(tmp, self._name(key))
 
     def get(self, key: str) -> bytes:
-        target = os.path.join(self.path, key)
-        t0, nap = time.monotonic(), 0.0002
+        target, abort = self._name(key), self._name("abort")
+        t0, nap, polls = time.monotonic(), 0.0002, 0
         while True:
             try:
                 with open(target, "rb") as f:
                     return f.read()
             except FileNotFoundError:
+                polls += 1
+                if polls % 16 == 0 and os.path.exists(abort):
+                    try:
+                        why = open(abort, "rb").read().decode(errors="replace")
+                    except OSError:
+                        why = ""
+                    raise CommError(f"rendezvous: another rank gave up ({why or 'no reason recorded'})") from None
                 if time.monotonic() - t0 > self.timeout:
                     raise CommError(f"rendezvous: {key} did not appear in {self.path} within {self.timeout:.0f}s "
                                     "(a rank died or never started)") from None
@@ -84,32 +108,74 @@ class FileStore:
 
     def drop(self, key: str) -> None:
         try:
-            os.remove(os.path.join(self.path, key))
+            os.remove(self._name(key))
         except FileNotFoundError:
             pass
+
+    def abort(self, why: str) -> None:
+        """Tell the ranks that wait in ``get`` that this one will not write again."""
+        try:
+            if not os.path.exists(self._name("abort")):
+                self.set("abort", why.encode()[:400])
+        except OSError:
+            pass
+
+    def purgeOthers(self, older_than: float = 600.0) -> int:
+        """Remove the keys of other launches that nobody can still be waiting for (older than the ``get`` timeout:
+        what a crashed run left behind); returns how many.  Hygiene only -- such keys are never read."""
+        n = 0
+        prefix = self.token + "."
+        now = time.time()
+        try:
+            names = os.listdir(self.path)
+        except OSError:
+            return 0
+        for name in names:
+            if name.startswith(prefix) or name.startswith("." + prefix):
+                continue
+            full = os.path.join(self.path, name)
+            try:
+                if now - os.path.getmtime(full) >= older_than:
+                    os.remove(full)
+                    n += 1
+            except OSError:
+                pass
+        return n
 
 
 class Comm:
     """The ranks of one launch.  ``dev``: the rank's ``_lib.Device`` (needed by the ``rccl`` backend)."""
 
-    def __init__(self, rank: int, world: int, store: FileStore, dev=None, backend: str = "rccl"):
+    def __init__(self, rank: int, world: int, store: FileStore, dev=None, backend: str = "rccl", abandoned=None):
+        """``abandoned`` (a ``threading.Event``): set by a caller that has stopped waiting for this constructor; a
+        communicator that comes up afterwards is destroyed at once and NO collective is issued on it (its peers
+        have moved on: the collective would never complete)."""
         if backend not in ("rccl", "file"):
             raise ValueError(f"unknown backend {backend!r}")
         self.rank, self.world, self.store, self.backend = rank, world, store, backend
         self._seq = 0
         self._handle = None
         self._dev = dev
+        self._cdev = None
+        if rank == 0:
+            store.purgeOthers()
         if backend == "rccl":
-            from ._lib import check, lib
+            from ._lib import Device, check, lib
             if dev is None:
                 raise CommError("the rccl backend needs the rank's device context")
+            # a context (stream, staging) of its own on the rank's GPU: collectives never queue behind, or in front
+            # of, the typing kernels, and a collective that cannot complete cannot block the compute stream
+            self._cdev = Device(dev.ordinal)
             if rank == 0:
                 uid = C.create_string_buffer(128)
                 check(lib().gk_comm_unique_id(uid, 128))
                 store.set("rccl_id", uid.raw)
             uid = store.get("rccl_id")
             h = C.c_void_p()
-            check(lib().gk_comm_create(dev.ctx, uid, len(uid), rank, world, C.byref(h)))
+            check(lib().gk_comm_create(self._cdev.ctx, uid, len(uid), rank, world, C.byref(h)))
+            if abandoned is not None and abandoned.is_set():
+                lib().gk_comm_destroy(h)
+                raise CommError("RCCL communicator came up after its deadline; destroyed unused")
             self._handle = h
         self.barrier()      # everyone is here (and, with rccl, the communicator works) before anything is removed
 
@@ -152,6 +218,9 @@ class Comm:
         return float(v[0])
 
     def barrier(self) -> None:
+        """Every rank has reached this point; with a device, the work queued on the rank's own stream is done."""
+        if hasattr(self._dev, "sync"):
+            self._dev.sync()
         if self._handle is None:
             self._round(b"")
             return
@@ -166,6 +235,9 @@ class Comm:
             from ._lib import lib
             lib().gk_comm_destroy(self._handle)
             self._handle = None
+        if self._cdev is not None:
+            self._cdev.close()
+            self._cdev = None
         # rank 0 removes the directory once every other rank has said it will not read from it again
         if self.rank:
             self.store.set(f"bye.r{self.rank}", b"")
@@ -174,6 +246,41 @@ class Comm:
                 self.store.get(f"bye.r{r}")
             shutil.rmtree(self.store.path, ignore_errors=True)
         self.store = None
+
+
+def superviseRanks(procs: list, rdzv: str, token: str, grace: float = 20.0) -> int:
+    """Wait for the rank processes of a launch (``subprocess.Popen`` objects whose environment carries
+    ``GK_RDZV_DIR=rdzv`` and ``GK_RDZV_TOKEN=token``).  When one exits non-zero the others are told at once
+    (``abort`` key: their ``FileStore.get`` raises), given ``grace`` seconds to leave and then terminated; the
+    rendezvous directory is removed whatever happened.  Returns 0 when every rank returned 0, else 1 (a rank killed
+    by a signal counts as a failure, not as a small positive code)."""
+    store = None
+    failed_at = None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            if failed_at is None and any(c not in (None, 0) for c in codes):
+                failed_at = time.monotonic()
+                bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+                store = store or FileStore(rdzv, token=token)
+                store.abort(f"rank {bad[0][0]} exited with code {bad[0][1]}")
+            if failed_at is not None and time.monotonic() - failed_at > grace:
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                for p in procs:
+                    try:
+                        p.wait(timeout=10)
+                    except Exception:      # noqa: BLE001
+                        p.kill()
+                break
+            time.sleep(0.05)
+        codes = [p.wait() for p in procs]
+        return 0 if all(c == 0 for c in codes) else 1
+    finally:
+        shutil.rmtree(rdzv, ignore_errors=True)
 
 
 def worldFromEnv() -> tuple[int, int, int]:
@@ -186,7 +293,9 @@ def initFromEnv(dev=None, backend: str | None = None, fallback: bool = True) -> 
     """The launch's communicator, or None for a single process.  ``backend`` None: ``GK_COMM_BACKEND``, else
     rccl when every local rank has a GPU of its own, file otherwise.  ``fallback``: when the RCCL communicator
     cannot be set up on some rank (no librccl, no device, initialisation error) ALL ranks agree -- through the
-    rendezvous directory -- to carry the few control messages over the file backend instead, and say so."""
+    rendezvous directory -- to carry the few control messages over the file backend instead, and say so; with
+    ``fallback=False`` (``bench.py --gpus N``: a scaling run must not quietly measure something else) every rank
+    raises ``CommError`` instead."""
     rank, world, _ = worldFromEnv()
     if world <= 1:
         return None
@@ -208,10 +317,11 @@ def initFromEnv(dev=None, backend: str | None = None, fallback: bool = True) -> 
         # it counts as a failure, and the ranks fall back together like for any other failure.
         import threading
         box: dict = {}
+        abandoned = threading.Event()
 
         def make():
             try:
-                box["comm"] = Comm(rank, world, store, dev=dev, backend="rccl")
+                box["comm"] = Comm(rank, world, store, dev=dev, backend="rccl", abandoned=abandoned)
             except Exception as e:    # noqa: BLE001 -- reported below
                 box["error"] = e
 
@@ -219,20 +329,27 @@ def initFromEnv(dev=None, backend: str | None = None, fallback: bool = True) -> 
         worker.start()
         worker.join(float(os.environ.get("GK_RCCL_INIT_TIMEOUT", "300")))
         if worker.is_alive():
+            # the helper is told that nobody waits for it: if ncclCommInitRank returns later it destroys the
+            # communicator and issues nothing on it (Comm.__init__); it works on a context of its own, so the
+            # rank's compute stream is not involved either way
+            abandoned.set()
             raise CommError("RCCL communicator initialisation did not return in time")
         if "error" in box:
             raise box["error"]
         made = box["comm"]
     except Exception as e:            # noqa: BLE001 -- whatever went wrong, the ranks must agree on what to do next
-        if not fallback:
-            raise
         why = f"{type(e).__name__}: {e}"
     store.set(f"rccl_ok.r{rank}", b"1" if made is not None else b"0")
     everyone = [store.get(f"rccl_ok.r{r}") == b"1" for r in range(world)]
     if all(everyone):
         return made
     if not fallback:
-        raise CommError("RCCL communicator failed on ranks " + str([r for r, ok in enumerate(everyone) if not ok]))
+        if made is not None and made._handle is not None:
+            from ._lib import lib
+            lib().gk_comm_destroy(made._handle)
+            made._handle = None
+        raise CommError("RCCL communicator failed on ranks " + str([r for r, ok in enumerate(everyone) if not ok])
+                        + (f" (this rank: {why})" if why else ""))
     import sys
     print(f"[comm] rank {rank}: RCCL communicator unavailable ({why or 'another rank failed'}); "
           "control messages go through the rendezvous directory", file=sys.stderr, flush=True)
@@ -242,6 +359,6 @@ def initFromEnv(dev=None, backend: str | None = None, fallback: bool = True) -> 
         made._handle = None
     other = Comm.__new__(Comm)
     other.rank, other.world, other.store, other.backend = rank, world, store, "file"
-    other._seq, other._handle, other._dev = 0, None, dev     # no rank has used the store's rounds yet
+    other._seq, other._handle, other._dev, other._cdev = 0, None, dev, None     # no rank has used the store's rounds yet
     other.barrier()
     return other

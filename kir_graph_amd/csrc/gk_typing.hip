@@ -377,6 +377,10 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
         }
       }
       if (kMiss && nvar_out && lane == 0 && a_base == 0) nvar_out[i] = (uint16_t)min(nvar, 65535u);
+      // the count read back from the log-likelihood below (m = floor(-L / 3 + 1/4)) is exact only while
+      // 0.000434 (n - m) < 3/4 * 3, i.e. for rows of fewer than ~5000 factors: a longer row sends the gene to the
+      // exact search (wide records and windows beyond 256 variants can produce such rows)
+      if (kLog && miss8 && nvar >= 4096u && lane == 0) atomicOr(bound_flags, 1u);
     }
     __syncthreads();
     if (probs) {

@@ -327,11 +327,10 @@ def extractVariant(pair_reads: Iterable[tuple[str, str]], index: GkIndex | list[
     """SAM pairs -> tabulated sample on the device (extractVariant, hisat2.py:803-844).
 
     Pairs are decoded to packed records on the host, then filterRead + the variant walk +
-    positive/negative extraction run in ``gk_tabulate``.
+    positive/negative extraction run in ``gk_tabulate``.  ``pileup``: the dictionary of ``getPileupBaseRatio``
+    (``{(ref, pos): {base: share, "all": depth}}``); every mismatch goes through ``hisat2.errorCorrection``
+    (609-654) before its id is looked up -- as a per-position table on the device (``gk_tabulate_corrected``).
     """
-    if pileup is not None:
-        raise NotImplementedError("pileup error correction is disabled in the CLI (graphkir/main.py:149); "
-                                  "not implemented on the device path")
     if not isinstance(index, GkIndex):
         index = GkIndex.fromVariants(index)
     dev = dev or Device()
@@ -341,7 +340,11 @@ def extractVariant(pair_reads: Iterable[tuple[str, str]], index: GkIndex | list[
     rec, table = packPairs(pairs, index, spill=spill)
     base = Variant.novel_id
     from .packed import spillArrays
-    tab = Tabulation(dindex, rec, novel_base=base, spill=spillArrays(spill))
+    correction = None
+    if pileup:      # the reference's `if pileup:` (hisat2.py:685): None and an empty dictionary both mean "off"
+        from .pileup import correctionFromRatios
+        correction = correctionFromRatios(pileup, index)
+    tab = Tabulation(dindex, rec, novel_base=base, spill=spillArrays(spill), correction=correction)
     Variant.novel_id = base + tab.n_novel
     logger.info(f"[Graph] Filterd pairs: {tab.n_valid}")
     return SampleData(tab, index, None, pairs_text=pairs, ins_strings=table.strings)

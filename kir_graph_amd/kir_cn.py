@@ -114,8 +114,6 @@ def predictSamplesCN(samples_depth_tsv: list[str], samples_cn: list[str], diploi
     ``comm``: optional collective (``cohort.Comm``) when the listed samples are this rank's shard
     of a cohort; the depths of all ranks are all-gathered before the fit."""
     assert len(samples_depth_tsv) == len(samples_cn)
-    if per_gene:
-        raise NotImplementedError("per_gene CN prediction is not reachable from the CLI and not implemented")
     tables = []
     for depth_file in samples_depth_tsv:
         logger.info(f"[CN] Select {select_mode} of depths per gene ({depth_file})")
@@ -124,19 +122,57 @@ def predictSamplesCN(samples_depth_tsv: list[str], samples_cn: list[str], diploi
         tables.append(df)
     logger.info(f"[CN] Predict CN from {len(tables)} samples")
     depths_dict = [dict(zip(t["gene"], t["depth"])) for t in tables]
-    pooled = None
-    if comm is not None:
-        pooled = comm.allgatherDepths(depths_dict)
-    cns, model = depthToCN(depths_dict, diploid_depth, cluster_method=cluster_method,
-                           cluster_method_kwargs=cluster_method_kwargs,
-                           assume_3DL3_diploid=assume_3DL3_diploid, pooled_values=pooled)
-    model.raw_df = [t.to_dict() for t in tables]
-    if save_cn_model_path and (comm is None or comm.rank == 0):
-        model.save(save_cn_model_path)
+    if per_gene:
+        cns = _predictPerGene(tables, samples_depth_tsv, cluster_method, cluster_method_kwargs, save_cn_model_path, comm)
+    else:
+        pooled = None
+        if comm is not None:
+            pooled = comm.allgatherDepths(depths_dict)
+        cns, model = depthToCN(depths_dict, diploid_depth, cluster_method=cluster_method,
+                               cluster_method_kwargs=cluster_method_kwargs,
+                               assume_3DL3_diploid=assume_3DL3_diploid, pooled_values=pooled)
+        model.raw_df = [t.to_dict() for t in tables]
+        if save_cn_model_path and (comm is None or comm.rank == 0):
+            model.save(save_cn_model_path)
     for filename, cn, depths in zip(samples_cn, cns, depths_dict):
         df1 = pd.DataFrame(list(cn.items()), columns=["gene", "cn"])
         df2 = pd.DataFrame(list(depths.items()), columns=["gene", "depth"])
         df1.merge(df2, on="gene").to_csv(filename, index=False, sep="\t")
+
+
+def _predictPerGene(tables: list[pd.DataFrame], samples_depth_tsv: list[str], cluster_method: str,
+                    cluster_method_kwargs: dict[str, Any], save_cn_model_path: str | None, comm) -> list[dict[str, int]]:
+    """``per_gene=True`` (kir_cn.py:195-222): one model per gene, fitted to that gene's depth in every sample -- no
+    diploid-depth file, no 3DL3 assumption.  The reference keys the depths of one gene by ``gene + "-" + depth file``
+    and maps a key back to its sample with ``key.split("-")[1]`` (line 217): a depth-file path that contains ``-``
+    raises ``KeyError`` there, and so it does here."""
+    if comm is not None:
+        raise NotImplementedError("per_gene copy numbers fit every gene over the whole cohort: run them on one rank")
+    from .utils import NumpyEncoder
+    file_index = {name: i for i, name in enumerate(samples_depth_tsv)}
+    df_depths = pd.concat(tables)
+    df_depths["gene_sampleid"] = df_depths["gene"] + "-" + df_depths["depth_file"]
+    cns: list[dict[str, int]] = [{} for _ in tables]
+    models = []
+    for gene in sorted(set(df_depths["gene"])):
+        logger.info(f"[CN] Predict per gene: {gene}")
+        gene_depths = df_depths[df_depths["gene"] == gene]
+        gene_cns, gene_model = depthToCN([dict(zip(gene_depths["gene_sampleid"], gene_depths["depth"]))],
+                                         cluster_method=cluster_method, cluster_method_kwargs=cluster_method_kwargs)
+        gene_model.raw_df = [gene_depths.to_dict()]
+        models.append((gene, gene_model))
+        for gene_and_id, cn in gene_cns[0].items():
+            cns[file_index[gene_and_id.split("-")[1]]][gene] = cn
+    if save_cn_model_path:
+        data = []
+        for gene, model in models:
+            data.append(model.getParams())
+            data[-1]["gene"] = gene
+            with open(save_cn_model_path + f".{gene}.json", "w") as f:
+                json.dump(data[-1], f, cls=NumpyEncoder)
+        with open(save_cn_model_path, "w") as f:
+            json.dump(data, f, cls=NumpyEncoder)
+    return cns
 
 
 def loadCN(filename_cn: str) -> dict[str, int]:

@@ -292,6 +292,18 @@ def main(args: argparse.Namespace) -> None:
     if transport is not None:
         inputs = args.alignment if args.alignment else [list(r) for r in reads]
         comm = cohort.Comm(len(names), transport, weights=cohort.sampleWeights(inputs))
+        try:
+            return _runCohort(args, names, reads, cn_files, index, index_ref, cohort_name, comm)
+        except BaseException as e:     # the other ranks must not wait out their timeouts for this one
+            if transport.store is not None:
+                transport.store.abort(f"rank {transport.rank}: {type(e).__name__}: {e}")
+            raise
+    return _runCohort(args, names, reads, cn_files, index, index_ref, cohort_name, comm)
+
+
+def _runCohort(args, names, reads, cn_files, index, index_ref, cohort_name, comm) -> None:
+    """Tabulation, depth, copy numbers, typing and the merges for this rank's share of the cohort (main.py:124-250,
+    572-603)."""
     mine = comm.mine if comm else list(range(len(names)))
     pick = lambda xs: [xs[i] for i in mine]   # noqa: E731
 
@@ -370,18 +382,21 @@ def main(args: argparse.Namespace) -> None:
 
 def spawnRanks(n: int, argv: list[str]) -> int:
     """``--ranks N`` without a launcher: start N copies of this command as ranks 0..N-1 (fresh processes; this
-    one never touches the GPU), wait for all of them, return the worst exit code."""
+    one never touches the GPU) and supervise them: a rank that fails ends the launch for all (``comm.superviseRanks``),
+    the rendezvous directory is removed either way.  Returns 0 or 1."""
     import subprocess
     import sys
     import tempfile
+    import uuid
+    from .comm import superviseRanks
     rdzv = tempfile.mkdtemp(prefix="gk_rdzv_")
+    token = uuid.uuid4().hex
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   GK_RDZV_DIR=rdzv)
+                   GK_RDZV_DIR=rdzv, GK_RDZV_TOKEN=token)
         procs.append(subprocess.Popen([sys.executable, "-m", "kir_graph_amd.main"] + argv, env=env))
-    codes = [p.wait() for p in procs]
-    return max(abs(c) for c in codes)
+    return superviseRanks(procs, rdzv, token)
 
 
 def entrypoint() -> None:

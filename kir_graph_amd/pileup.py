@@ -89,3 +89,32 @@ def correctionTable(counts: np.ndarray) -> np.ndarray:
         minority = deep & ~(np.nan_to_num(ratio[:, j]) > 0.2) & (replacement != ord(BASES[j]))
         table[minority, j] = replacement[minority]
     return table
+
+
+def correctionFromRatios(pileup: PileupCount, index: GkIndex) -> tuple[np.ndarray, np.ndarray]:
+    """(correction table uint8 [positions][5], first position of every backbone) from the reference's own
+    dictionary form ``{(ref, pos): {"A": 0.2, "C": 0.8, "all": 30}}`` (``getPileupBaseRatio`` 57-81): what
+    ``extractVariant(pairs, variants, pileup=...)`` hands to ``hisat2.errorCorrection`` (609-654) per mismatch.
+    A backbone's table reaches to its last listed position; mismatches beyond have no entry and stay."""
+    n_pos = np.zeros(len(index.genes), dtype=np.int64)
+    for (ref, pos) in pileup:
+        g = index.gene_id.get(ref)
+        if g is not None and pos >= 0:
+            n_pos[g] = max(n_pos[g], int(pos) + 1)
+    pos0 = np.concatenate([[0], np.cumsum(n_pos)]).astype(np.int64)
+    table = np.zeros((int(pos0[-1]), 5), dtype=np.uint8)
+    for (ref, pos), p in pileup.items():
+        g = index.gene_id.get(ref)
+        if g is None or pos < 0 or not p or p["all"] < 20:
+            continue
+        bases = [(b, r) for b, r in p.items() if b != "all"]
+        if any(r >= 0.8 for _, r in bases):
+            rep = str(max(bases, key=lambda t: t[1])[0])
+        else:
+            rep = "N"
+        if len(rep) != 1:
+            raise ValueError(f"pileup entry {ref}:{pos} names {rep!r}: a base is one character")
+        for j, b in enumerate("ACGTN"):
+            if not p.get(b, 0) > 0.2 and rep != b:
+                table[pos0[g] + int(pos), j] = ord(rep)
+    return table, pos0

@@ -161,3 +161,19 @@ def predictCN(depth_tables: list[pd.DataFrame], mode: str = "p75", method: str =
     samples = [geneDepths(df, mode) for df in depth_tables]
     cns, model = depthsToCN(samples, method, kwargs, assume_3DL3_diploid)
     return cns, samples, model
+
+
+def predictCNPerGene(depth_tables: list[pd.DataFrame], mode: str = "p75", method: str = "CNgroup",
+                     kwargs: dict | None = None):
+    """predictSamplesCN(per_gene=True), kir_cn.py:195-222: one fit per gene over that gene's depth in every sample
+    (no diploid-depth file, no 3DL3 assumption).  Returns (cn dict per sample, {gene: model})."""
+    samples = [geneDepths(df, mode) for df in depth_tables]
+    cns: list[dict[str, int]] = [{} for _ in samples]
+    models = {}
+    for gene in sorted({g for s in samples for g in s}):
+        keyed = {f"{gene}-{i}": s[gene] for i, s in enumerate(samples) if gene in s}
+        got, model = depthsToCN([keyed], method, kwargs)
+        models[gene] = model
+        for key, cn in got[0].items():
+            cns[int(key.rsplit("-", 1)[1])][gene] = cn
+    return cns, samples, models

@@ -386,6 +386,33 @@ def t8_cn():
                              cluster_method=method, cluster_method_kwargs=kw if method == "LCND" else {},
                              save_cn_model_path=f"{d}/c.json", select_mode="p75")
         out["cohort"][method] = [open(f"{d}/c{si}.cn.tsv").read() for si in range(3)]
+    # per_gene=True (kir_cn.py:195-222): one model per gene over every sample's depth of that gene; three more
+    # samples are drawn AFTER everything above (the entries above stay what they were), six per gene in all
+    extra = []
+    for si, d1 in enumerate([36, 28, 33], start=3):
+        cns = [int(rng.choice([0, 1, 2, 2, 3])) for _ in genes]
+        rows = []
+        for g, c in zip(genes, cns):
+            L = int(rng.integers(300, 600))
+            dep = rng.poisson(d1 * c + 0.01, L) if c else np.zeros(L, int)
+            rows += [(g + "*BACKBONE", i + 1, int(x)) for i, x in enumerate(dep)]
+        pd.DataFrame(rows, columns=["gene", "pos", "depth"]).to_csv(f"{d}/s{si}.depth.tsv", sep="\t", header=False,
+                                                                    index=False)
+        extra.append(rows)
+    out["per_gene"] = {"depth_tables_extra": extra}
+    assert "-" not in d          # kir_cn.py:217 maps "gene-file" keys back with split("-")[1]
+    for method in ("LCND", "KDE"):
+        rcn.predictSamplesCN([f"{d}/s{si}.depth.tsv" for si in range(6)], [f"{d}/g{si}.cn.tsv" for si in range(6)],
+                             cluster_method=method, cluster_method_kwargs=kw if method == "LCND" else {},
+                             save_cn_model_path=f"{d}/g.json", select_mode="p75", per_gene=True)
+        models = json.load(open(f"{d}/g.json"))
+        out["per_gene"][method] = {
+            "tsv": [open(f"{d}/g{si}.cn.tsv").read() for si in range(6)],
+            "models": [{"gene": m["gene"], "base": float(m["base"]).hex(), "x_max": float(m["x_max"]).hex(),
+                        "bin_num": m["bin_num"]} if method == "LCND" else
+                       {"gene": m["gene"], "x_max": float(m["x_max"]).hex(), "local_min": fl(m["local_min"])}
+                       for m in models],
+            "model_files": sorted(os.path.basename(f) for f in os.listdir(d) if f.startswith("g.json"))}
     return out
 
 

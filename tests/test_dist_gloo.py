@@ -49,10 +49,10 @@ WORKER = textwrap.dedent("""
         # rank 0: after the deadline both ranks carry on over the file backend
         import threading
         real = comm.Comm.__init__
-        def stuck(self, rank, world, store, dev=None, backend="rccl"):
+        def stuck(self, rank, world, store, dev=None, backend="rccl", **kw):
             if backend == "rccl" and rank == 1:
                 threading.Event().wait()          # for ever
-            real(self, rank, world, store, dev=dev, backend=backend)
+            real(self, rank, world, store, dev=dev, backend=backend, **kw)
         comm.Comm.__init__ = stuck
         os.environ["GK_RCCL_INIT_TIMEOUT"] = "2"
         transport = comm.initFromEnv(dev=object(), backend="rccl")
@@ -62,6 +62,31 @@ WORKER = textwrap.dedent("""
         # no GPU here: the RCCL communicator cannot be made on any rank, and all ranks agree on the file backend
         transport = comm.initFromEnv(backend="rccl")
         assert transport.backend == "file" and transport.world == 2
+    elif os.environ["GK_TEST_TRANSPORT"] == "rccl_strict":
+        # bench.py --gpus N: no quiet fallback -- every rank raises, none hangs
+        try:
+            comm.initFromEnv(backend="rccl", fallback=False)
+        except comm.CommError as e:
+            assert "RCCL communicator failed on ranks [0, 1]" in str(e), e
+            if os.environ["RANK"] == "0":
+                print("OK strict")
+            sys.exit(0)
+        raise AssertionError("strict mode fell back")
+    elif os.environ["GK_TEST_TRANSPORT"] == "dies":
+        # rank 1 fails before its first collective: rank 0 must learn of it at once, not after the 600 s timeout
+        import time
+        transport = comm.initFromEnv(backend="file")
+        if transport.rank == 1:
+            transport.store.abort("rank 1: ValueError: all samples of a cohort must report the same genes")
+            sys.exit(3)
+        t0 = time.time()
+        try:
+            transport.allgatherF64(np.array([1.0]))
+        except comm.CommError as e:
+            assert "another rank gave up" in str(e) and time.time() - t0 < 30, (e, time.time() - t0)
+            print("OK abort seen")
+            sys.exit(0)
+        raise AssertionError("the collective returned although rank 1 never joined it")
     else:
         transport = comm.initFromEnv(backend="file")
         assert transport.backend == "file" and transport.world == 2
@@ -122,7 +147,7 @@ def test_sample_weights_from_file_sizes(tmp_path):
     assert sampleWeights([str(a), str(tmp_path / "missing")]) is None
 
 
-def _run_two_ranks(tmp_path, transport):
+def _run_two_ranks(tmp_path, transport, codes=(0, 0)):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = 29500 + (os.getpid() % 500)
@@ -134,8 +159,8 @@ def _run_two_ranks(tmp_path, transport):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=240) for p in procs]
-    for p, (out, err) in zip(procs, outs):
-        assert p.returncode == 0, err[-2000:]
+    for p, (out, err), want in zip(procs, outs, codes):
+        assert p.returncode == want, err[-2000:]
     assert "OK" in outs[0][0]
 
 
@@ -154,3 +179,109 @@ def test_rccl_failure_falls_back_to_the_file_backend_on_every_rank(tmp_path):
 
 def test_rccl_set_up_that_never_returns_falls_back_after_the_deadline(tmp_path):
     _run_two_ranks(tmp_path, "rccl_hang")
+
+
+def test_strict_mode_raises_on_every_rank_instead_of_falling_back(tmp_path):
+    _run_two_ranks(tmp_path, "rccl_strict")
+
+
+def test_a_rank_that_gives_up_ends_the_wait_of_the_others(tmp_path):
+    _run_two_ranks(tmp_path, "dies", codes=(0, 3))
+
+
+def test_keys_of_a_dead_run_in_a_reused_directory_are_not_read(tmp_path):
+    """GK_RDZV_DIR reused after a crash: the old run's payloads (named by round and rank only) must not be taken
+    for this launch's -- every key carries the launch token."""
+    import numpy as np
+    rdzv = tmp_path / "rdzv"
+    rdzv.mkdir()
+    for name in ("x0.r1", "x1.r1", "x2.r1", "rccl_id", "rccl_ok.r1", "bye.r1",
+                 "12345_999_29500_0.x0.r1", "12345_999_29500_0.x1.r1"):
+        (rdzv / name).write_bytes(np.array([-777.0, -777.0, -777.0, -777.0]).tobytes())
+    _run_two_ranks(tmp_path, "file")         # pooled depths are checked inside the workers: no -777 anywhere
+
+
+def test_supervisor_ends_the_launch_when_one_rank_fails(tmp_path):
+    """comm.superviseRanks (main.spawnRanks, bench.launch_ranks): the surviving rank is told through the abort key,
+    the rendezvous directory is removed, the launch reports failure -- within seconds."""
+    import time
+    import uuid
+    from kir_graph_amd.comm import superviseRanks
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, os.environ["GK_ROOT"])
+        import numpy as np
+        from kir_graph_amd import comm
+        if os.environ["RANK"] == "1":
+            os._exit(9)                      # dies without a word
+        t = comm.initFromEnv(backend="file")
+    """))
+    rdzv, token = tmp_path / "rdzv", uuid.uuid4().hex
+    rdzv.mkdir()
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), GK_ROOT=ROOT,
+                                       GK_RDZV_DIR=str(rdzv), GK_RDZV_TOKEN=token), stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    t0 = time.time()
+    assert superviseRanks(procs, str(rdzv), token, grace=60.0) == 1
+    assert time.time() - t0 < 30                       # rank 0 left on the abort key, not on a timeout or a kill
+    assert "another rank gave up (rank 1 exited with code 9)" in procs[0].stderr.read()
+    assert not rdzv.exists()
+
+
+def test_a_communicator_that_comes_up_after_its_deadline_is_destroyed_unused(tmp_path, monkeypatch):
+    """the helper thread that outlives the RCCL-init deadline must not run a collective (its peers
+    are on the file backend: it would never complete) and must not leak the communicator."""
+    import threading
+    import pytest
+    from kir_graph_amd import _lib, comm
+    calls = []
+    release = threading.Event()
+
+    class FakeLib:
+        def gk_comm_unique_id(self, buf, n):
+            return 0
+        def gk_comm_create(self, ctx, uid, n, rank, world, out):
+            release.wait(10)                  # ncclCommInitRank returns late
+            calls.append("create")
+            return 0
+        def gk_comm_destroy(self, h):
+            calls.append("destroy")
+            return 0
+        def gk_comm_barrier(self, h):
+            calls.append("barrier")
+            return 0
+
+    class FakeDevice:
+        ordinal, ctx = 0, None
+        def __init__(self, ordinal=0):
+            pass
+        def sync(self):
+            calls.append("sync")
+        def close(self):
+            pass
+
+    monkeypatch.setattr(_lib, "lib", lambda: FakeLib())
+    monkeypatch.setattr(_lib, "check", lambda rc: None)
+    monkeypatch.setattr(_lib, "Device", FakeDevice)
+    store = comm.FileStore(str(tmp_path / "rdzv"), token="t")
+    abandoned = threading.Event()
+    box = {}
+
+    def make():
+        try:
+            comm.Comm(0, 1, store, dev=FakeDevice(), backend="rccl", abandoned=abandoned)
+        except comm.CommError as e:
+            box["error"] = str(e)
+
+    th = threading.Thread(target=make)
+    th.start()
+    th.join(0.3)
+    assert th.is_alive()                      # the deadline passes ...
+    abandoned.set()
+    release.set()                             # ... then the communicator comes up
+    th.join(10)
+    assert not th.is_alive()
+    assert "after its deadline" in box.get("error", "")
+    assert calls == ["create", "destroy"]     # no barrier, no leak

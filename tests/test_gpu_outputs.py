@@ -127,6 +127,42 @@ def test_predict_samples_cn_writes_the_references_tsv(device, tmp_path):
             assert open(f"{d}/c{si}.cn.tsv").read() == want, (method, si)
 
 
+def test_predict_samples_cn_per_gene_writes_the_references_tsv(device, tmp_path):
+    """``predictSamplesCN(per_gene=True)`` (kir_cn.py:195-222): one model per gene over six samples -- the CN TSVs,
+    the per-gene model files and their parameters equal the reference's."""
+    import shutil
+    import tempfile
+    t8 = load("t8_cn.json.gz")
+    # the reference maps "gene-file" keys back with split("-")[1]: a path with "-" in it (pytest's tmp_path) is a KeyError
+    d = tempfile.mkdtemp(dir="/tmp", prefix="gkpergene")
+    assert "-" not in d
+    for si, rows in enumerate(t8["depth_tables"] + t8["per_gene"]["depth_tables_extra"]):
+        pd.DataFrame(rows, columns=["gene", "pos", "depth"]).to_csv(f"{d}/s{si}.depth.tsv", sep="\t", header=False,
+                                                                    index=False)
+    kw = {"base_dev": 0.08, "start_base": 2}
+    for method in ("LCND", "KDE"):
+        want = t8["per_gene"][method]
+        predictSamplesCN([f"{d}/s{si}.depth.tsv" for si in range(6)], [f"{d}/g{si}.cn.tsv" for si in range(6)],
+                         cluster_method=method, cluster_method_kwargs=kw if method == "LCND" else {},
+                         save_cn_model_path=f"{d}/g.json", select_mode="p75", per_gene=True)
+        for si, text in enumerate(want["tsv"]):
+            assert open(f"{d}/g{si}.cn.tsv").read() == text, (method, si)
+        assert sorted(f for f in os.listdir(d) if f.startswith("g.json")) == want["model_files"]
+        models = json.load(open(f"{d}/g.json"))
+        assert [m["gene"] for m in models] == [m["gene"] for m in want["models"]]
+        for got, ref in zip(models, want["models"]):
+            assert float(got["x_max"]) == float.fromhex(ref["x_max"])
+            if method == "LCND":
+                assert float(got["base"]) == pytest.approx(float.fromhex(ref["base"]), rel=1e-12)
+                assert got["bin_num"] == ref["bin_num"]
+            assert json.load(open(f"{d}/g.json.{ref['gene']}.json"))["gene"] == ref["gene"]
+    os.makedirs(f"{d}/a-b")
+    shutil.copy(f"{d}/s0.depth.tsv", f"{d}/a-b/s0.depth.tsv")
+    with pytest.raises(KeyError):
+        predictSamplesCN([f"{d}/a-b/s0.depth.tsv"], [f"{d}/a-b/s0.cn.tsv"], cluster_method="KDE", per_gene=True)
+    shutil.rmtree(d, ignore_errors=True)
+
+
 def _cohort(tmp_path, n_samples=3, n_pairs=6000):
     """Synthetic index with all 15 genes (KIR3DL3 among them) + samples as SAM text + their truth."""
     sidx = synth.makeIndex(seed=21, n_genes=15, var_range=(60, 120), allele_range=(6, 12), len_range=(2500, 4000))

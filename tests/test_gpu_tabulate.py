@@ -139,6 +139,19 @@ def test_pileup_error_correction_matches_oracle(device, tmp_path):
         ref_nov = [v for v in ref["variants"] if str(v.id).startswith("nv")]
         assert [(v.id, v.pos, v.typ, v.ref, v.val, v.length) for v in nov] == \
                [(v.id, v.pos, v.typ, v.ref, v.val, v.length) for v in ref_nov]
+    # the text API with the reference's own argument (extractVariant(pairs, variants, pileup=...), hisat2.py:803-844):
+    # the ratio dictionary becomes the device table (pileup.correctionFromRatios); same lists, same novel variants
+    from kir_graph_amd.hisat2 import extractVariant, pairLines
+    Variant.novel_id = 0
+    data = extractVariant(pairLines(collated), gidx, dev=device, pileup=opile.pileupOfLines(by_coord))
+    assert device_lists(data.tab) == results["on"][0]
+    assert [(v.id, v.pos, v.typ, v.val) for v in data.tab.novelVariants(data.ins_strings)] == \
+           [(v.id, v.pos, v.typ, v.val) for v in results["on"][1]]
+    data.tab.close()
+    Variant.novel_id = 0
+    data = extractVariant(pairLines(collated), gidx, dev=device, pileup={})      # `if pileup:` -- empty means off
+    assert device_lists(data.tab) == results["off"][0]
+    data.tab.close()
     # the correction did something: distinct read errors at one site collapse onto the majority base
     assert len(results["on"][1]) < len(results["off"][1])
     assert results["on"][0] != results["off"][0]

@@ -129,6 +129,8 @@ def test_bounded_search_equals_exact_search(device, small_case, monkeypatch):
     data = extractVariant(pairLines(synth.toSamLines(sample)), gidx, dev=device)
     gene_cn = {g: (k % 4) + 1 for k, g in enumerate(sidx.genes)}
     results = {}
+    from kir_graph_amd.typing_mulit_allele import SEARCH_STATS
+    stats = {}
     # exact = float64 sums for every candidate, python host (the round-1 path); the others must give its bits:
     # the integer bound, and the search loop run natively inside the library (gk_search_run), bounded or not
     # ("exact" also keeps the per-gene error correction / empty-read removal; the others take them from the one
@@ -139,10 +141,16 @@ def test_bounded_search_equals_exact_search(device, small_case, monkeypatch):
         monkeypatch.setenv("GK_NATIVE_SEARCH", native)
         monkeypatch.setenv("GK_BATCH_PREAMBLE", "0" if mode == "exact" else "1")
         monkeypatch.setenv("GK_THREADS", "1")
+        before = dict(SEARCH_STATS)
         for method, top_n in (("full", 600), ("full", 7), ("exonfirst_1", 60)):
             typer = selectKirTypingModel(method, data, top_n=top_n, variant_correction=True)
             calls = typer.typing(gene_cn)
             results[(mode, method, top_n)] = (calls, typer._result)
+        stats[mode] = {k: SEARCH_STATS[k] - before[k] for k in before}
+    # the comparison below covers both routes of a step only if both were taken: steps served by the integer bound
+    # and steps it handed back to the exact kernels (ties across a cut / rows equal in all three keys)
+    for mode in ("bound", "native"):
+        assert stats[mode]["bounded"] > 0 and stats[mode]["redone_exactly"] > 0, (mode, stats)
     for (mode, method, top_n), (calls, res) in results.items():
         if mode == "exact":
             continue

@@ -702,6 +702,36 @@ def test_pileup_ratios_and_correction_table_match_reference_fixture():
         assert shown == fixed, (pos, val, shown, fixed)
 
 
+def test_correction_table_from_the_references_ratio_dictionary():
+    """``extractVariant(pairs, variants, pileup=...)`` (hisat2.py:803-844) takes the dictionary of getPileupBaseRatio;
+    ``pileup.correctionFromRatios`` turns it into the device table.  Against the REFERENCE's own ratio entries and
+    its ``errorCorrection`` outputs (T11)."""
+    import gzip
+    import json
+    from types import SimpleNamespace
+    from kir_graph_amd import pileup as pp
+    with gzip.open(os.path.join(os.path.dirname(__file__), "golden", "t11_pileup.json.gz"), "rt") as f:
+        t11 = json.load(f)
+    g = t11["gene"]
+    ratios = {}
+    for r in t11["ratio"]:          # the reference's entries, keys in the reference's order
+        ratios[(g, r["pos"])] = {k: (r["entry"][k] if k == "all" else float.fromhex(r["entry"][k])) for k in r["order"]}
+    ratios[("KIRX*BACKBONE", 3)] = {"A": 1.0, "all": 50}        # a backbone the index does not have: ignored
+    index = SimpleNamespace(genes=["KIR0*BACKBONE", g], gene_id={"KIR0*BACKBONE": 0, g: 1})
+    table, pos0 = pp.correctionFromRatios(ratios, index)
+    assert pos0.tolist() == [0, 0, max(r["pos"] for r in t11["ratio"]) + 1] and table.shape == (pos0[-1], 5)
+    seen = 0
+    for pos, val, fixed in t11["fixes"]:
+        if ":" in val or pos >= pos0[-1]:
+            continue
+        j = "ACGTN".index(val)
+        shown = chr(table[pos0[1] + pos, j]) if table[pos0[1] + pos, j] else val
+        assert shown == fixed, (pos, val, shown, fixed)
+        seen += shown != val
+    assert seen >= 5
+    assert pp.correctionFromRatios({}, index)[0].shape == (0, 5)
+
+
 def test_native_depth_tsv_equals_pandas(tmp_path):
     """gk_depth_write_tsv writes the text DataFrame.to_csv(sep='\\t', header=False, index=False) gives for the
     ``samtools depth -aa`` table (gene, 1-based position, depth)."""

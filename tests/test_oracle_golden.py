@@ -190,6 +190,28 @@ def test_copy_number():
             assert dict(zip(ref["gene"], ref["cn"])) == {k: int(v) for k, v in got.items()}
 
 
+def test_copy_number_per_gene():
+    """predictSamplesCN(per_gene=True) of the reference (kir_cn.py:195-222) on six samples: one model per gene."""
+    t8 = load("t8_cn.json.gz")
+    rows = t8["depth_tables"] + t8["per_gene"]["depth_tables_extra"]
+    tables = [pd.DataFrame(r, columns=["gene", "pos", "depth"]) for r in rows]
+    kw = {"base_dev": 0.08, "start_base": 2}
+    for method in ("LCND", "KDE"):
+        want = t8["per_gene"][method]
+        cns, samples, models = ocn.predictCNPerGene(tables, "p75", method, kw if method == "LCND" else {})
+        for got, text in zip(cns, want["tsv"]):
+            ref = pd.read_csv(io.StringIO(text), sep="\t")
+            assert dict(zip(ref["gene"], ref["cn"])) == {k: int(v) for k, v in got.items()}, method
+        for m in want["models"]:
+            mine = models[m["gene"]]
+            assert mine.x_max == float.fromhex(m["x_max"]), (method, m["gene"])
+            if method == "LCND":
+                assert mine.base == pytest.approx(float.fromhex(m["base"]), rel=1e-12)
+                assert mine.bin_num == m["bin_num"]
+            else:
+                close(mine.local_min, unhex(m["local_min"]), rel=1e-9)
+
+
 def test_numpy_reduction_tree():
     """Pure-Python restatement of numpy's add.reduce tree (the device follows the same tree)."""
     from oracle.sumtree import numpySum

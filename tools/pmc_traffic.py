@@ -3,7 +3,10 @@
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM section; calibrated with tools/fetch_calib.hip): both
 counters are KiB, FETCH_SIZE reports half of the bytes of coalesced reads, WRITE_SIZE is exact."""
-import csv, json, sys
+import csv, json, os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kir_graph_amd.build import sourceDigest
 
 def total(path, counter, kernel):
     s = n = 0
@@ -14,7 +17,7 @@ def total(path, counter, kernel):
 
 fetch, n_f = total(sys.argv[1], "FETCH_SIZE", sys.argv[3])
 write, n_w = total(sys.argv[2], "WRITE_SIZE", sys.argv[3])
-print(json.dumps({"kernel": sys.argv[3], "launches": n_f, "fetch_size_kib": fetch, "write_size_kib": write,
+print(json.dumps({"kernel": sys.argv[3], "csrc_sha16": sourceDigest(sys.argv[3]), "launches": n_f, "fetch_size_kib": fetch, "write_size_kib": write,
                   "traffic_bytes_per_launch": (2 * fetch / max(n_f, 1) + write / max(n_w, 1)) * 1024,
                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python bench.py`; "
                             "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024"}))
