@@ -226,6 +226,12 @@ int gk_lut_pending(gk_lut* lut, int32_t* n_total, int32_t* n_known);     /* sync
 int gk_lut_export(gk_lut* lut, int32_t first, int32_t count, double* keys_out);
 int gk_lut_define(gk_lut* lut, int32_t first, int32_t count, const double* log_vals);
 int gk_lut_apply(gk_lut* lut, gk_dptr d_in, gk_dptr d_out, int64_t n);
+/* pending + export + host log10 + define in one call, serialised inside the library (typing_mulit_allele.py:263:
+ * np.log10 -- the binding hands numpy.log10 in, so the bits are numpy's on the machine at hand).  Outputs may be NULL:
+ * values newly defined, values defined in all, entries claimed by kernels still running elsewhere. */
+typedef int (*gk_log10_fn)(const double* values, int64_t n, double* out);
+int gk_lut_resolve(gk_lut* lut, gk_log10_fn log10_fn, int32_t* n_new, int32_t* n_known, int32_t* n_undefined);
+int gk_lut_known(gk_lut* lut, int32_t* n_known);
 /* reads2AlleleProb and np.log10 in one pass (typing_mulit_allele.py:257-263): gk_compat's product,
  * mapped through the value table as it is written; d_log is column-major double [allele][row].
  * A product whose log10 is not defined yet is inserted into the table and stored as NaN: when
@@ -286,6 +292,32 @@ typedef struct gk_search gk_search;
 int gk_search_run(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, int32_t n_allele, gk_dptr d_miss8,
                   int64_t ldm, gk_dptr d_msum, const int32_t* cols, int32_t n_cols, int32_t n_steps, int32_t top_n,
                   gk_argsort_fn argsort, const double* colsum_in, gk_search** out);
+/* ---- the searches of ALL genes of one sample in one call (kir_typing.py:103-132 is the reference's gene loop; per gene
+ * typing_mulit_allele.py:340-381 for the table and 478-598 for the search).  The genes advance in lock-step on the
+ * calling thread and the context's ONE stream: compatibility tables of every gene, one wait; column sums of every gene,
+ * one wait; then step 2, 3, ... of every gene that has one -- bound, wait, exact sums of the selections, wait, ranking.
+ * A sample costs about ten stream synchronisations whatever its number of genes, so one host thread feeds the GPU.
+ * A job names the gene's rows (after error correction / empty-read removal: gk_sample_prepare), its variant span and
+ * bit rows, and the tables the caller allocated: d_L double [n_allele][n_rows]; optionally d_miss8 u8 [n_allele][ldm],
+ * d_msum uint32 [n_allele], d_flags uint32 [1] for the integer bound.  n_steps = copy-number steps to run (1 for a
+ * gene typed as homozygous).  Outputs per job: bound_ok (the integer bound served the gene), passes (how often its table
+ * was written: > 1 when the value table met new products), and out[i] = its search (gk_search_*; NULL without rows). */
+typedef struct gk_gene_job {
+  gk_dptr d_rows;
+  int64_t n_rows;
+  gk_dptr d_mask;
+  gk_dptr d_L;
+  gk_dptr d_miss8;
+  int64_t ldm;
+  gk_dptr d_msum;
+  gk_dptr d_flags;
+  int32_t vbeg, vend;
+  int32_t words, n_allele;
+  int32_t n_steps, top_n;
+  int32_t bound_ok, passes; /* out */
+} gk_gene_job;
+int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_gene_job* jobs, int32_t n_jobs,
+                     gk_argsort_fn argsort, gk_log10_fn log10_fn, gk_search** out);
 int gk_search_steps(gk_search* s, int32_t* n_steps);
 int gk_search_info(gk_search* s, int32_t step, int32_t* n, int64_t* rows, int32_t* bounded);
 int gk_search_copy(gk_search* s, int32_t step, double* value, double* sum_indv, int32_t* ids, double* frac);

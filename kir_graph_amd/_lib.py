@@ -48,6 +48,16 @@ NM_ABSENT = 255
 MAX_CIG, MAX_MM, MAX_INS, MAX_EV = 14, 16, 6, 22
 
 
+class GeneJob(C.Structure):
+    """``gk_gene_job`` (include/graphkir_hip.h): one gene of ``gk_sample_search``."""
+    _fields_ = [
+        ("d_rows", C.c_uint64), ("n_rows", C.c_int64), ("d_mask", C.c_uint64), ("d_L", C.c_uint64),
+        ("d_miss8", C.c_uint64), ("ldm", C.c_int64), ("d_msum", C.c_uint64), ("d_flags", C.c_uint64),
+        ("vbeg", C.c_int32), ("vend", C.c_int32), ("words", C.c_int32), ("n_allele", C.c_int32),
+        ("n_steps", C.c_int32), ("top_n", C.c_int32), ("bound_ok", C.c_int32), ("passes", C.c_int32),
+    ]
+
+
 class TabInfo(C.Structure):
     _fields_ = [
         ("n_pairs", C.c_int64), ("n_valid", C.c_int64), ("n_ids", C.c_int64),
@@ -166,6 +176,11 @@ _SIGS = {
     "gk_search_run": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_int64,
                                 C.c_uint64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                 C.POINTER(C.c_void_p)]),
+    "gk_sample_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "gk_lut_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int32)]),
+    "gk_lut_known": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "gk_search_steps": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "gk_search_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                  C.POINTER(C.c_int32)]),
@@ -207,6 +222,23 @@ def _numpy_argsort(values, n, order_out):
 
 
 NUMPY_ARGSORT = ARGSORT_FN(_numpy_argsort)
+
+# numpy.log10 as the callback of gk_lut_resolve / gk_sample_search (typing_mulit_allele.py:263): the bits of the
+# log-likelihoods are numpy's on the machine at hand
+LOG10_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double))
+
+
+def _numpy_log10(values, n, out):
+    try:
+        v = np.ctypeslib.as_array(values, shape=(n,))
+        with np.errstate(divide="ignore"):
+            np.ctypeslib.as_array(out, shape=(n,))[:] = np.log10(v)
+        return 0
+    except Exception:      # never let an exception cross the C frame
+        return 1
+
+
+NUMPY_LOG10 = LOG10_FN(_numpy_log10)
 
 
 def lib():

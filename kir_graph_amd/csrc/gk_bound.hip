@@ -24,7 +24,7 @@
 // thread kernels finds M_T and compacts the selection.
 #include <algorithm>
 
-#include "gk_common.h"
+#include "gk_calls.h"
 
 namespace {
 
@@ -357,23 +357,47 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
                   int32_t n_sets, int32_t c_prev, const int32_t* cols, int32_t n_cols, const uint8_t* first,
                   int32_t top_n, int32_t cap, uint32_t* hdr_out, int32_t* idx_out, uint32_t* m_out) {
   gk_bind(ctx);
-  GK_REQUIRE(ctx && d_miss8 && d_msum && ids && cols && first && hdr_out && idx_out && m_out, "null pointer");
+  GK_REQUIRE(hdr_out && idx_out && m_out, "null pointer");
+  GkBoundCall call;
+  int rc = gk_bound_enqueue(ctx, d_miss8, ldm, n_rows, d_msum, ids, n_sets, c_prev, cols, n_cols, first, top_n, cap, call);
+  if (rc == GK_OK && gk_fetch_wait(ctx) != hipSuccess) {
+    gk_set_error("bound step: waiting for the stream failed");
+    rc = GK_ERR_HIP;
+  }
+  if (rc == GK_OK) gk_bound_collect(ctx, call, hdr_out, idx_out, m_out);
+  else gk_release(ctx, call.temps);
+  return rc;
+}
+
+}  // extern "C"
+
+int gk_bound_enqueue(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_dptr d_msum, const int32_t* ids,
+                     int32_t n_sets, int32_t c_prev, const int32_t* cols, int32_t n_cols, const uint8_t* first,
+                     int32_t top_n, int32_t cap, GkBoundCall& call) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && d_miss8 && d_msum && ids && cols && first, "null pointer");
   GK_REQUIRE(n_sets >= 1 && n_cols >= 1 && c_prev >= 1 && c_prev <= 8 && top_n >= 1 && cap >= 1, "bad bound arguments");
   GK_REQUIRE(ldm >= n_rows && ldm % 64 == 0 && n_rows > 0, "mismatch table stride must be a multiple of 64 rows");
   GK_REQUIRE(n_rows < (int64_t)16000000, "too many reads for 32-bit mismatch totals");
   hipStream_t st = ctx->stream;
   const int64_t n_out = (int64_t)n_sets * n_cols;
+  auto take = [&](void** p, size_t bytes) -> hipError_t {
+    hipError_t e = gk_pool_malloc(ctx, p, bytes);
+    if (e == hipSuccess) call.temps.push_back(*p);
+    return e;
+  };
   // parameters through the context's pinned ring: [ids | cols | first mask]
   const size_t n_ids = (size_t)n_sets * c_prev;
   const size_t par_bytes = (n_ids + (size_t)n_cols) * sizeof(int32_t) + (size_t)n_out;
   char* d_par = nullptr;
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d_par, par_bytes));
+  GK_HIP(take((void**)&d_par, par_bytes));
   {
-    std::vector<char> packed(par_bytes);   // one copy instead of three (every runtime call is contended by the gene threads)
+    std::vector<char> packed(par_bytes);   // one copy instead of three (every runtime call is contended by the host threads)
     memcpy(packed.data(), ids, n_ids * sizeof(int32_t));
     memcpy(packed.data() + n_ids * sizeof(int32_t), cols, (size_t)n_cols * sizeof(int32_t));
     memcpy(packed.data() + (n_ids + n_cols) * sizeof(int32_t), first, (size_t)n_out);
     GK_HIP(gk_send(ctx, d_par, packed.data(), par_bytes));
+    if (par_bytes > gk_stage_direct()) GK_HIP(hipStreamSynchronize(st));   // sent straight from `packed`
   }
   const int32_t* d_ids = (const int32_t*)d_par;
   const int32_t* d_cols = d_ids + n_ids;
@@ -383,8 +407,8 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
   uint8_t* d_P = nullptr;
   uint32_t* d_psum = nullptr;
   if (c_prev >= 2) {   // previous sets of two or more alleles become one column each
-    GK_HIP(gk_pool_malloc(ctx, (void**)&d_P, (size_t)n_sets * (size_t)ldm));
-    GK_HIP(gk_pool_malloc(ctx, (void**)&d_psum, (size_t)n_sets * sizeof(uint32_t)));
+    GK_HIP(take((void**)&d_P, (size_t)n_sets * (size_t)ldm));
+    GK_HIP(take((void**)&d_psum, (size_t)n_sets * sizeof(uint32_t)));
     GK_PROF(ctx, GK_K_SETMIN, GK_KERNEL(setmin_u8, dim3((unsigned)n_sets), dim3(kThreads), 0, st, miss, ldm, d_ids,
                                         c_prev, d_P, d_psum));
   }
@@ -400,9 +424,9 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
   // selection state, indices and totals in ONE block, so that one copy brings the result back
   char* d_sel = nullptr;
   const size_t sel_bytes = sizeof(SelState) + (size_t)cap * (sizeof(int32_t) + sizeof(uint32_t));
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * n_slices * sizeof(uint32_t)));
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d_M, (size_t)n_out * sizeof(uint32_t)));
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d_sel, sel_bytes));
+  GK_HIP(take((void**)&d_partial, (size_t)n_out * n_slices * sizeof(uint32_t)));
+  GK_HIP(take((void**)&d_M, (size_t)n_out * sizeof(uint32_t)));
+  GK_HIP(take((void**)&d_sel, sel_bytes));
   SelState* d_state = (SelState*)d_sel;
   int32_t* d_idx = (int32_t*)(d_sel + sizeof(SelState));
   uint32_t* d_mout = (uint32_t*)(d_idx + cap);
@@ -422,26 +446,24 @@ int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_
   GK_PROF(ctx, GK_K_SELECT_CUT,
           GK_KERNEL(select_append, per_elem, dim3(kThreads), 0, st, d_M, n_out, top_n, cap, d_state, d_idx, d_mout));
   GK_HIP(hipGetLastError());
-  // one copy, one wait: the header first, then as many entries as were selected (the three parts are adjacent)
-  std::vector<char> back(sel_bytes);
-  GK_HIP(gk_fetch(ctx, back.data(), d_sel, sel_bytes));
-  const uint32_t* head = (const uint32_t*)back.data();
+  // one copy: the header first, then the entries (the three parts are adjacent)
+  call.cap = cap;
+  call.state_bytes = sizeof(SelState);
+  call.back.resize(sel_bytes);
+  GK_HIP(gk_fetch_queue(ctx, call.back.data(), d_sel, sel_bytes));
+  return GK_OK;
+}
+
+void gk_bound_collect(gk_ctx* ctx, GkBoundCall& call, uint32_t* hdr_out, int32_t* idx_out, uint32_t* m_out) {
+  const uint32_t* head = (const uint32_t*)call.back.data();
   hdr_out[0] = head[0];   // candidates
   hdr_out[1] = head[4];   // the cut: the top_n-th smallest M (rounded up to 2^sh0 - 1 when the band is wider than 2^22)
   hdr_out[2] = head[3];   // selected
   hdr_out[3] = 0;
-  const uint32_t n_sel = std::min<uint32_t>(hdr_out[2], (uint32_t)cap);
+  const uint32_t n_sel = std::min<uint32_t>(hdr_out[2], (uint32_t)call.cap);
   if (n_sel) {
-    memcpy(idx_out, back.data() + sizeof(SelState), (size_t)n_sel * sizeof(int32_t));
-    memcpy(m_out, back.data() + sizeof(SelState) + (size_t)cap * sizeof(int32_t), (size_t)n_sel * sizeof(uint32_t));
+    memcpy(idx_out, call.back.data() + call.state_bytes, (size_t)n_sel * sizeof(int32_t));
+    memcpy(m_out, call.back.data() + call.state_bytes + (size_t)call.cap * sizeof(int32_t), (size_t)n_sel * sizeof(uint32_t));
   }
-  gk_pool_free(ctx, d_partial);
-  gk_pool_free(ctx, d_M);
-  gk_pool_free(ctx, d_sel);
-  gk_pool_free(ctx, d_par);
-  gk_pool_free(ctx, d_P);
-  gk_pool_free(ctx, d_psum);
-  return GK_OK;
+  gk_release(ctx, call.temps);
 }
-
-}  // extern "C"

@@ -97,8 +97,11 @@ hipEvent_t gk_prof_stop_event();
 
 int gk_ctx_scratch(gk_ctx* ctx, size_t bytes, void** out);
 
-// host -> device through the context's pinned ring: queued on the stream, `src` may be reused at once
+// host -> device through the context's pinned ring: queued on the stream, `src` may be reused at once -- unless the
+// transfer is larger than gk_stage_direct() bytes: that one is queued straight from `src`, which must then stay valid
+// until the stream has passed it
 hipError_t gk_send(gk_ctx* ctx, void* dst_dev, const void* src, size_t bytes);
+size_t gk_stage_direct();
 // device -> host through the pinned bounce area: queue any number of copies, then wait once (stream synchronise)
 // and have them delivered to their destinations; gk_fetch = queue + wait
 hipError_t gk_fetch_queue(gk_ctx* ctx, void* dst, const void* src_dev, size_t bytes);

@@ -21,7 +21,8 @@
 #include <unordered_map>
 #include <unordered_set>
 
-#include "gk_common.h"
+#include "gk_calls.h"
+#include "gk_lut.h"
 
 namespace {
 
@@ -200,225 +201,433 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
               const int32_t* cols, int32_t n_cols, double* out);
 int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
                 double* frac_out);
-int gk_setsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
-              double* value_out, double* frac_out);
-int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_dptr d_msum, const int32_t* ids,
-                  int32_t n_sets, int32_t c_prev, const int32_t* cols, int32_t n_cols, const uint8_t* first,
-                  int32_t top_n, int32_t cap, uint32_t* hdr_out, int32_t* idx_out, uint32_t* m_out);
+int gk_compat_log_miss(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg,
+                       int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty, gk_lut* lut,
+                       gk_dptr d_log, gk_dptr d_miss8, int64_t ldm, gk_dptr d_flags);
+int gk_compat_log(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg,
+                  int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty, gk_lut* lut,
+                  gk_dptr d_log);
+int gk_miss_colsum(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int32_t n_cols, gk_dptr d_msum);
+
+}  // extern "C"
+
+namespace {
+
+// The search of ONE gene as a sequence of phases, each cut where the host needs something from the device:
+//   colsums   -> (wait) -> first step
+//   per further step:  prepare (first occurrences) -> bound enqueue -> (wait) -> selection -> set sums enqueue -> (wait)
+//                      -> ranking; a step the bound cannot serve is done with float64 sums for every candidate (blocking).
+// gk_search_run drives one of these with a wait after every enqueue; gk_sample_search drives all genes of a sample in
+// lock-step, so that ONE wait covers the step of every gene (typing_mulit_allele.py:478-598 per gene).
+struct GeneSearch {
+  gk_ctx* ctx = nullptr;
+  gk_dptr d_L = 0, d_miss8 = 0, d_msum = 0;
+  int64_t n_rows = 0, ld = 0, ldm = 0;
+  int n_allele = 0, n_steps = 0, T = 0, A = 0;
+  std::vector<int32_t> cols;
+  gk_argsort_fn argsort = nullptr;
+  bool bound = false, unique_cols = true;
+  std::unique_ptr<gk_search> S;
+  // state of the step in flight
+  std::vector<uint8_t> first;
+  int64_t N = 0;
+  GkBoundCall bcall;
+  GkSumCall scall;
+  Head sel;                     // sets selected by the bound, list order
+  Step st;
+  bool bound_in_flight = false, sums_in_flight = false, step_done = false;
+
+  int init(gk_ctx* c, gk_dptr L, int64_t rows, int64_t ld_, int32_t n_allele_, gk_dptr miss8, int64_t ldm_, gk_dptr msum,
+           const int32_t* cols_, int32_t n_cols, int32_t n_steps_, int32_t top_n, gk_argsort_fn fn) {
+    GK_REQUIRE(c && L && cols_ && fn, "null pointer");
+    GK_REQUIRE(rows > 0 && ld_ >= rows && n_allele_ > 0 && n_cols > 0 && n_steps_ >= 1 && n_steps_ <= 8 && top_n >= 1,
+               "bad search arguments");
+    for (int a = 0; a < n_cols; ++a) GK_REQUIRE(cols_[a] >= 0 && cols_[a] < n_allele_, "candidate allele out of range");
+    ctx = c; d_L = L; n_rows = rows; ld = ld_; n_allele = n_allele_; d_miss8 = miss8; ldm = ldm_; d_msum = msum;
+    cols.assign(cols_, cols_ + n_cols);
+    n_steps = n_steps_; T = top_n; A = n_cols; argsort = fn;
+    bound = d_miss8 != 0 && d_msum != 0;
+    S.reset(new gk_search());
+    S->n_allele = n_allele;
+    S->colsum.resize((size_t)n_allele);
+    std::vector<char> seen((size_t)n_allele, 0);
+    for (int a = 0; a < A && unique_cols; ++a) { if (seen[cols[a]]) unique_cols = false; seen[cols[a]] = 1; }
+    return GK_OK;
+  }
+
+  // ---- per-allele column sums = log_probs.sum(axis=0) (line 514), needed by every step (571)
+  int colsum_enqueue() {
+    std::vector<int32_t> every((size_t)n_allele);
+    std::iota(every.begin(), every.end(), 0);
+    int rc = gk_colsum_enqueue(ctx, d_L, n_rows, ld, every.data(), n_allele, scall);
+    if (rc) return rc;
+    S->note(0, n_rows, 1, 0, n_allele, 0, 0);
+    return GK_OK;
+  }
+  void colsum_collect() { gk_colsum_collect(ctx, scall, S->colsum.data()); }
+
+  // ---- first allele (512-532): argsort(score)[::-1][:top_n]
+  int first_step() {
+    const double* colsum = S->colsum.data();
+    std::vector<double> score((size_t)A);
+    for (int a = 0; a < A; ++a) score[a] = colsum[cols[a]];
+    std::vector<int64_t> order((size_t)A);
+    GK_REQUIRE(argsort(score.data(), A, order.data()) == 0, "host argsort failed");
+    Step s1;
+    s1.n = 1;
+    const int keep = std::min(T, A);
+    for (int i = 0; i < keep; ++i) {
+      const int64_t a = order[(size_t)A - 1 - i];
+      GK_REQUIRE(a >= 0 && a < A, "host argsort returned an index out of range");
+      s1.value.push_back(score[a]);
+      s1.sum_indv.push_back(score[a]);
+      s1.ids.push_back(cols[a]);
+      s1.frac.push_back(1.0);
+    }
+    S->steps.push_back(std::move(s1));
+    return GK_OK;
+  }
+
+  bool more() const { return (int)S->steps.size() < n_steps; }
+
+  // ---- a further step: first occurrences, then the integer bound when it applies
+  int step_begin() {
+    const Step& prev = S->steps.back();
+    const int k = prev.n;
+    const int Tp = (int)prev.rows();
+    first_of_sets(prev.ids.data(), Tp, k, cols.data(), A, n_allele, first);
+    N = 0;
+    for (uint8_t f : first) N += f;
+    st = Step();
+    st.n = k + 1;
+    step_done = bound_in_flight = sums_in_flight = false;
+    if (bound && N > 0 && unique_cols) {
+      const int cap = 4 * T + 4096;
+      int rc = gk_bound_enqueue(ctx, d_miss8, ldm, n_rows, d_msum, prev.ids.data(), Tp, k, cols.data(), A, first.data(), T,
+                                cap, bcall);
+      if (rc) return rc;
+      S->note(1, n_rows, Tp, A, k == 1 ? S->distinct(prev.ids.data(), prev.ids.size()) : Tp, 0, 0);
+      bound_in_flight = true;
+    }
+    return GK_OK;
+  }
+
+  // the selection is back: exact sums for the sets that can reach the cut
+  int after_bound() {
+    if (!bound_in_flight) return GK_OK;
+    bound_in_flight = false;
+    const Step& prev = S->steps.back();
+    const int k = prev.n, c = k + 1;
+    const int cap = bcall.cap;
+    uint32_t hdr[4];
+    std::vector<int32_t> idx((size_t)cap);
+    std::vector<uint32_t> mm((size_t)cap);
+    gk_bound_collect(ctx, bcall, hdr, idx.data(), mm.data());
+    const int64_t n_sel = hdr[2];
+    if (n_sel <= 0 || n_sel > cap) return GK_OK;                // a flood of ties at the cut: exact step
+    idx.resize((size_t)n_sel);
+    std::sort(idx.begin(), idx.end());                         // list order of the candidates
+    sel = Head();
+    sel.c = c;
+    sel.ids.resize((size_t)n_sel * c);
+    for (int64_t i = 0; i < n_sel; ++i) {
+      const int t = idx[i] / A, a = idx[i] % A;
+      std::copy(prev.ids.begin() + (size_t)t * k, prev.ids.begin() + (size_t)(t + 1) * k, sel.ids.begin() + (size_t)i * c);
+      sel.ids[(size_t)i * c + k] = cols[a];
+    }
+    int rc = gk_shares_enqueue(ctx, d_L, n_rows, ld, sel.ids.data(), (int32_t)n_sel, c, true, scall);
+    if (rc) return rc;
+    S->note(2, n_rows, n_sel, c, S->distinct(sel.ids.data(), sel.ids.size()), 0, 0);
+    sums_in_flight = true;
+    return GK_OK;
+  }
+
+  // exact values + shares of the selection are back: the reference's head, the ranking, the ambiguity tests
+  int after_sums() {
+    if (!sums_in_flight) return GK_OK;
+    sums_in_flight = false;
+    const double* colsum = S->colsum.data();
+    const int c = sel.c;
+    const int64_t n_sel = (int64_t)sel.ids.size() / c;
+    std::vector<double> value((size_t)n_sel), frac((size_t)n_sel * c);
+    gk_shares_collect(ctx, scall, value.data(), frac.data());
+    // the reference's head: rows of the sorted table that reach the top_n-th value (567, then the cut to top_n)
+    bool ok = true;
+    std::vector<int64_t> head;
+    const int64_t n_top = std::min<int64_t>(std::max<int64_t>(T, N / 5), N);
+    if (N > T) {
+      std::vector<double> tmp(value);
+      std::nth_element(tmp.begin(), tmp.begin() + (T - 1), tmp.end(), [](double x, double y) { return x > y; });
+      const double v_cut = tmp[(size_t)T - 1];
+      for (int64_t i = 0; i < n_sel; ++i)
+        if (value[i] >= v_cut) head.push_back(i);
+      if (n_top > T) ok = (int64_t)head.size() <= n_top;   // ties running past the N // 5 cut
+      else ok = (int64_t)head.size() == T;                 // ties across the top_n cut
+    } else {
+      head.resize((size_t)n_sel);
+      std::iota(head.begin(), head.end(), 0);
+    }
+    if (!ok) return GK_OK;
+    Head hh;
+    hh.c = c;
+    for (int64_t i : head) {
+      hh.value.push_back(value[i]);
+      hh.ids.insert(hh.ids.end(), sel.ids.begin() + (size_t)i * c, sel.ids.begin() + (size_t)(i + 1) * c);
+    }
+    fill_sums(hh, colsum);
+    std::vector<int64_t> contend;
+    contenders(hh, T, contend);
+    std::vector<Key3> keys(contend.size());
+    for (size_t q = 0; q < contend.size(); ++q) {
+      const int64_t i = contend[q];
+      keys[q] = Key3{-hh.value[i], hh.key2[i], unevenness(frac.data() + (size_t)head[i] * c, c)};
+    }
+    std::vector<int64_t> sub;
+    lexsort3(keys, sub);
+    const size_t look = std::min<size_t>(sub.size(), (size_t)T + 1);
+    for (size_t q = 1; q < look && ok; ++q) {
+      const Key3 &x = keys[sub[q - 1]], &y = keys[sub[q]];
+      if (x.k1 == y.k1 && x.k2 == y.k2 && x.k3 == y.k3) ok = false;   // their order would be argsort's
+    }
+    if (!ok) return GK_OK;
+    const size_t keep = std::min<size_t>(sub.size(), (size_t)T);
+    for (size_t q = 0; q < keep; ++q) {
+      const int64_t i = contend[sub[q]];
+      st.value.push_back(hh.value[i]);
+      st.ids.insert(st.ids.end(), hh.ids.begin() + (size_t)i * c, hh.ids.begin() + (size_t)(i + 1) * c);
+      st.sum_indv.insert(st.sum_indv.end(), hh.sum_indv.begin() + (size_t)i * c, hh.sum_indv.begin() + (size_t)(i + 1) * c);
+      const double* f = frac.data() + (size_t)head[i] * c;
+      st.frac.insert(st.frac.end(), f, f + c);
+    }
+    st.bounded = 1;
+    step_done = true;
+    return GK_OK;
+  }
+
+  // ---- float64 sums for every candidate (540-598 as written); blocking
+  int exact_step() {
+    const Step& prev = S->steps.back();
+    const double* colsum = S->colsum.data();
+    const int k = prev.n, c = k + 1;
+    const int Tp = (int)prev.rows();
+    std::vector<double> table((size_t)Tp * A);
+    int rc = gk_maxsum(ctx, d_L, n_rows, ld, prev.ids.data(), Tp, k, cols.data(), A, table.data());
+    if (rc) return rc;
+    {
+      const int64_t d_prev = S->distinct(prev.ids.data(), prev.ids.size());
+      const bool symmetric = k == 1 && Tp == A && Tp > 32 && d_prev == Tp && unique_cols;
+      S->note(0, n_rows, Tp, k, A, k == 1 ? d_prev : Tp, symmetric ? 1 : 0);
+    }
+    std::vector<int64_t> where;            // flat index of the first occurrences, list order
+    std::vector<double> score;
+    where.reserve((size_t)N);
+    score.reserve((size_t)N);
+    for (int64_t i = 0; i < (int64_t)first.size(); ++i)
+      if (first[i]) { where.push_back(i); score.push_back(table[i]); }
+    const int64_t n_keep = std::max<int64_t>(T, N / 5);
+    std::vector<int64_t> order((size_t)N);
+    if (N) GK_REQUIRE(argsort(score.data(), N, order.data()) == 0, "host argsort failed");
+    std::vector<int64_t> top;              // argsort(score)[::-1][:n_keep]
+    for (int64_t i = 0; i < std::min<int64_t>(n_keep, N); ++i) top.push_back(order[(size_t)N - 1 - i]);
+    int64_t head = (int64_t)top.size();
+    if ((int64_t)top.size() > T) {
+      const double v_cut = score[top[(size_t)T - 1]];
+      head = 0;
+      for (int64_t i : top) head += score[i] >= v_cut;      // value is descending: a prefix
+    }
+    top.resize((size_t)head);
+    Head hh;
+    hh.c = c;
+    for (int64_t i : top) {
+      const int64_t flat = where[i];
+      const int t = (int)(flat / A), a = (int)(flat % A);
+      hh.value.push_back(score[i]);
+      hh.ids.insert(hh.ids.end(), prev.ids.begin() + (size_t)t * k, prev.ids.begin() + (size_t)(t + 1) * k);
+      hh.ids.push_back(cols[a]);
+    }
+    fill_sums(hh, colsum);
+    std::vector<int64_t> contend;
+    contenders(hh, T, contend);
+    std::vector<int32_t> cids(contend.size() * c);
+    for (size_t q = 0; q < contend.size(); ++q)
+      std::copy(hh.ids.begin() + (size_t)contend[q] * c, hh.ids.begin() + (size_t)(contend[q] + 1) * c,
+                cids.begin() + q * c);
+    std::vector<double> frac(contend.size() * c);
+    if (!contend.empty()) {
+      rc = gk_fraction(ctx, d_L, n_rows, ld, cids.data(), (int32_t)contend.size(), c, frac.data());
+      if (rc) return rc;
+      S->note(2, n_rows, (int64_t)contend.size(), c, S->distinct(cids.data(), cids.size()), 0, 0);
+    }
+    std::vector<Key3> keys(contend.size());
+    for (size_t q = 0; q < contend.size(); ++q)
+      keys[q] = Key3{-hh.value[contend[q]], hh.key2[contend[q]], unevenness(frac.data() + q * c, c)};
+    std::vector<int64_t> sub;
+    lexsort3(keys, sub);
+    const size_t keep = std::min<size_t>(sub.size(), (size_t)T);
+    st = Step();
+    st.n = c;
+    for (size_t q = 0; q < keep; ++q) {
+      const int64_t i = contend[sub[q]];
+      st.value.push_back(hh.value[i]);
+      st.ids.insert(st.ids.end(), hh.ids.begin() + (size_t)i * c, hh.ids.begin() + (size_t)(i + 1) * c);
+      st.sum_indv.insert(st.sum_indv.end(), hh.sum_indv.begin() + (size_t)i * c, hh.sum_indv.begin() + (size_t)(i + 1) * c);
+      st.frac.insert(st.frac.end(), frac.begin() + sub[q] * c, frac.begin() + (sub[q] + 1) * c);
+    }
+    step_done = true;
+    return GK_OK;
+  }
+
+  void step_end() { S->steps.push_back(std::move(st)); }
+
+  // calls still queued when an error ends the run: their temporaries go back to the pool
+  void abandon() {
+    gk_release(ctx, bcall.temps);
+    gk_release(ctx, scall.temps);
+  }
+};
+
+int wait_stream(gk_ctx* ctx) {
+  if (gk_fetch_wait(ctx) != hipSuccess) {
+    gk_set_error("search: waiting for the stream failed: %s", hipGetErrorString(hipGetLastError()));
+    return GK_ERR_HIP;
+  }
+  return GK_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int gk_search_run(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, int32_t n_allele, gk_dptr d_miss8, int64_t ldm,
                   gk_dptr d_msum, const int32_t* cols, int32_t n_cols, int32_t n_steps, int32_t top_n,
                   gk_argsort_fn argsort, const double* colsum_in, gk_search** out) {
   gk_bind(ctx);
-  GK_REQUIRE(ctx && d_L && cols && argsort && out, "null pointer");
-  GK_REQUIRE(n_rows > 0 && ld >= n_rows && n_allele > 0 && n_cols > 0 && n_steps >= 1 && n_steps <= 8 && top_n >= 1,
-             "bad search arguments");
-  for (int a = 0; a < n_cols; ++a) GK_REQUIRE(cols[a] >= 0 && cols[a] < n_allele, "candidate allele out of range");
-  const bool bound = d_miss8 != 0 && d_msum != 0;
-  std::unique_ptr<gk_search> S(new gk_search());
-  S->n_allele = n_allele;
-  const int T = top_n, A = n_cols;
-
-  // ---- per-allele column sums = log_probs.sum(axis=0) (line 514), needed by every step (571)
-  S->colsum.resize((size_t)n_allele);
+  GK_REQUIRE(out, "null pointer");
+  GeneSearch g;
+  int rc = g.init(ctx, d_L, n_rows, ld, n_allele, d_miss8, ldm, d_msum, cols, n_cols, n_steps, top_n, argsort);
+  if (rc) return rc;
   if (colsum_in) {
-    std::copy(colsum_in, colsum_in + n_allele, S->colsum.begin());
+    std::copy(colsum_in, colsum_in + n_allele, g.S->colsum.begin());
   } else {
-    std::vector<int32_t> every((size_t)n_allele);
-    std::iota(every.begin(), every.end(), 0);
-    int rc = gk_maxsum(ctx, d_L, n_rows, ld, nullptr, 1, 0, every.data(), n_allele, S->colsum.data());
+    rc = g.colsum_enqueue();
+    if (rc == GK_OK) rc = wait_stream(ctx);
+    if (rc) { g.abandon(); return rc; }
+    g.colsum_collect();
+  }
+  rc = g.first_step();
+  while (rc == GK_OK && g.more()) {
+    rc = g.step_begin();
+    if (rc == GK_OK && g.bound_in_flight) {
+      rc = wait_stream(ctx);
+      if (rc == GK_OK) rc = g.after_bound();
+      if (rc == GK_OK && g.sums_in_flight) {
+        rc = wait_stream(ctx);
+        if (rc == GK_OK) rc = g.after_sums();
+      }
+    }
+    if (rc == GK_OK && !g.step_done) rc = g.exact_step();
+    if (rc == GK_OK) g.step_end();
+  }
+  if (rc) { g.abandon(); return rc; }
+  *out = g.S.release();
+  return GK_OK;
+}
+
+/* The searches of ALL genes of a sample in lock-step on the calling thread and ONE stream: the compatibility tables,
+ * then the column sums, then step 2, 3, ... of every gene that has one -- each phase is queued for every gene before
+ * ONE wait, so a sample costs about ten stream synchronisations instead of several per gene and step, and one host
+ * thread keeps the GPU fed (typing_mulit_allele.py:340-381 + 478-598 per gene; kir_typing.py:103-132 is the gene loop).
+ * jobs[i] describes gene i (tables allocated by the caller); out[i] receives its search (gk_search_*), NULL for a
+ * gene without rows.  `log10_fn` = numpy.log10 (value table, see gk_lut_resolve), `argsort` = numpy.argsort. */
+int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_gene_job* jobs, int32_t n_jobs,
+                     gk_argsort_fn argsort, gk_log10_fn log10_fn, gk_search** out) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && tab && lut && jobs && argsort && log10_fn && out && n_jobs >= 0, "null pointer");
+  for (int i = 0; i < n_jobs; ++i) out[i] = nullptr;
+  std::vector<int> live;
+  for (int i = 0; i < n_jobs; ++i) {
+    gk_gene_job& j = jobs[i];
+    j.bound_ok = 0;
+    j.passes = 0;
+    GK_REQUIRE(j.n_rows >= 0 && j.n_allele >= 0 && j.n_steps >= 1 && j.top_n >= 1, "bad gene job");
+    if (j.n_rows > 0 && j.n_allele > 0) {
+      GK_REQUIRE(j.d_rows && j.d_L && j.d_mask && j.words >= 1, "gene job without tables");
+      GK_REQUIRE(!j.d_miss8 || (j.d_msum && j.d_flags && j.ldm >= j.n_rows && j.ldm % 64 == 0), "bad mismatch table");
+      live.push_back(i);
+    }
+  }
+  if (live.empty()) return GK_OK;
+  int rc = GK_OK;
+  // ---- phase 0: the compatibility tables (log-likelihoods through the value table + mismatch counts)
+  std::vector<uint32_t> flags((size_t)n_jobs, 0);
+  for (int pass = 0; pass < 64; ++pass) {
+    int32_t known_at_launch = 0;
+    rc = gk_lut_known(lut, &known_at_launch);
     if (rc) return rc;
-    S->note(0, n_rows, 1, 0, n_allele, 0, 0);
-  }
-  const double* colsum = S->colsum.data();
-
-  // ---- first allele (512-532): argsort(score)[::-1][:top_n]
-  {
-    std::vector<double> score((size_t)A);
-    for (int a = 0; a < A; ++a) score[a] = colsum[cols[a]];
-    std::vector<int64_t> order((size_t)A);
-    GK_REQUIRE(argsort(score.data(), A, order.data()) == 0, "host argsort failed");
-    Step st;
-    st.n = 1;
-    const int keep = std::min(T, A);
-    for (int i = 0; i < keep; ++i) {
-      const int64_t a = order[(size_t)A - 1 - i];
-      GK_REQUIRE(a >= 0 && a < A, "host argsort returned an index out of range");
-      st.value.push_back(score[a]);
-      st.sum_indv.push_back(score[a]);
-      st.ids.push_back(cols[a]);
-      st.frac.push_back(1.0);
-    }
-    S->steps.push_back(std::move(st));
-  }
-
-  std::vector<uint8_t> first;
-  for (int step = 2; step <= n_steps; ++step) {
-    const Step& prev = S->steps.back();
-    const int k = prev.n, c = k + 1;
-    const int Tp = (int)prev.rows();
-    first_of_sets(prev.ids.data(), Tp, k, cols, A, n_allele, first);
-    int64_t N = 0;
-    for (uint8_t f : first) N += f;
-    Step st;
-    st.n = c;
-    bool done = false;
-    bool unique_cols = true;
-    {
-      std::vector<char> seen((size_t)n_allele, 0);
-      for (int a = 0; a < A && unique_cols; ++a) { if (seen[cols[a]]) unique_cols = false; seen[cols[a]] = 1; }
-    }
-
-    // ---------------- integer bound first (see gk_bound.hip): exact sums for the sets that can reach the cut
-    if (bound && N > 0 && unique_cols) {
-      const int cap = 4 * T + 4096;
-      uint32_t hdr[4];
-      std::vector<int32_t> idx((size_t)cap);
-      std::vector<uint32_t> mm((size_t)cap);
-      int rc = gk_bound_step(ctx, d_miss8, ldm, n_rows, d_msum, prev.ids.data(), Tp, k, cols, A, first.data(), T, cap,
-                             hdr, idx.data(), mm.data());
+    for (int i : live) {
+      gk_gene_job& j = jobs[i];
+      j.passes++;
+      if (j.d_miss8) {
+        rc = gk_compat_log_miss(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
+                                j.d_L, j.d_miss8, j.ldm, j.d_flags);
+        if (rc == GK_OK) rc = gk_miss_colsum(ctx, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
+        if (rc == GK_OK && gk_fetch_queue(ctx, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
+      } else {
+        rc = gk_compat_log(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut, j.d_L);
+      }
       if (rc) return rc;
-      S->note(1, n_rows, Tp, A, k == 1 ? S->distinct(prev.ids.data(), prev.ids.size()) : Tp, 0, 0);
-      const int64_t n_sel = hdr[2];
-      if (n_sel > 0 && n_sel <= cap) {
-        idx.resize((size_t)n_sel);
-        std::sort(idx.begin(), idx.end());                         // list order of the candidates
-        Head h;
-        h.c = c;
-        h.ids.resize((size_t)n_sel * c);
-        for (int64_t i = 0; i < n_sel; ++i) {
-          const int t = idx[i] / A, a = idx[i] % A;
-          std::copy(prev.ids.begin() + (size_t)t * k, prev.ids.begin() + (size_t)(t + 1) * k, h.ids.begin() + (size_t)i * c);
-          h.ids[(size_t)i * c + k] = cols[a];
-        }
-        std::vector<double> value((size_t)n_sel), frac((size_t)n_sel * c);
-        rc = gk_setsum(ctx, d_L, n_rows, ld, h.ids.data(), (int32_t)n_sel, c, value.data(), frac.data());
-        if (rc) return rc;
-        S->note(2, n_rows, n_sel, c, S->distinct(h.ids.data(), h.ids.size()), 0, 0);
-        // the reference's head: rows of the sorted table that reach the top_n-th value (567, then the cut to top_n)
-        bool ok = true;
-        std::vector<int64_t> head;
-        const int64_t n_top = std::min<int64_t>(std::max<int64_t>(T, N / 5), N);
-        if (N > T) {
-          std::vector<double> tmp(value);
-          std::nth_element(tmp.begin(), tmp.begin() + (T - 1), tmp.end(), [](double x, double y) { return x > y; });
-          const double v_cut = tmp[(size_t)T - 1];
-          for (int64_t i = 0; i < n_sel; ++i)
-            if (value[i] >= v_cut) head.push_back(i);
-          if (n_top > T) ok = (int64_t)head.size() <= n_top;   // ties running past the N // 5 cut
-          else ok = (int64_t)head.size() == T;                 // ties across the top_n cut
-        } else {
-          head.resize((size_t)n_sel);
-          std::iota(head.begin(), head.end(), 0);
-        }
-        if (ok) {
-          Head hh;
-          hh.c = c;
-          for (int64_t i : head) {
-            hh.value.push_back(value[i]);
-            hh.ids.insert(hh.ids.end(), h.ids.begin() + (size_t)i * c, h.ids.begin() + (size_t)(i + 1) * c);
-          }
-          fill_sums(hh, colsum);
-          std::vector<int64_t> contend;
-          contenders(hh, T, contend);
-          std::vector<Key3> keys(contend.size());
-          for (size_t q = 0; q < contend.size(); ++q) {
-            const int64_t i = contend[q];
-            keys[q] = Key3{-hh.value[i], hh.key2[i], unevenness(frac.data() + (size_t)head[i] * c, c)};
-          }
-          std::vector<int64_t> sub;
-          lexsort3(keys, sub);
-          const size_t look = std::min<size_t>(sub.size(), (size_t)T + 1);
-          for (size_t q = 1; q < look && ok; ++q) {
-            const Key3 &x = keys[sub[q - 1]], &y = keys[sub[q]];
-            if (x.k1 == y.k1 && x.k2 == y.k2 && x.k3 == y.k3) ok = false;   // their order would be argsort's
-          }
-          if (ok) {
-            const size_t keep = std::min<size_t>(sub.size(), (size_t)T);
-            for (size_t q = 0; q < keep; ++q) {
-              const int64_t i = contend[sub[q]];
-              st.value.push_back(hh.value[i]);
-              st.ids.insert(st.ids.end(), hh.ids.begin() + (size_t)i * c, hh.ids.begin() + (size_t)(i + 1) * c);
-              st.sum_indv.insert(st.sum_indv.end(), hh.sum_indv.begin() + (size_t)i * c,
-                                 hh.sum_indv.begin() + (size_t)(i + 1) * c);
-              const double* f = frac.data() + (size_t)head[i] * c;
-              st.frac.insert(st.frac.end(), f, f + c);
-            }
-            st.bounded = 1;
-            done = true;
-          }
-        }
-      }
     }
-
-    // ---------------- float64 sums for every candidate (540-598 as written)
-    if (!done) {
-      std::vector<double> table((size_t)Tp * A);
-      int rc = gk_maxsum(ctx, d_L, n_rows, ld, prev.ids.data(), Tp, k, cols, A, table.data());
-      if (rc) return rc;
-      {
-        const int64_t d_prev = S->distinct(prev.ids.data(), prev.ids.size());
-        const bool symmetric = k == 1 && Tp == A && Tp > 32 && d_prev == Tp && unique_cols;
-        S->note(0, n_rows, Tp, k, A, k == 1 ? d_prev : Tp, symmetric ? 1 : 0);
-      }
-      std::vector<int64_t> where;            // flat index of the first occurrences, list order
-      std::vector<double> score;
-      where.reserve((size_t)N);
-      score.reserve((size_t)N);
-      for (int64_t i = 0; i < (int64_t)first.size(); ++i)
-        if (first[i]) { where.push_back(i); score.push_back(table[i]); }
-      const int64_t n_keep = std::max<int64_t>(T, N / 5);
-      std::vector<int64_t> order((size_t)N);
-      if (N) GK_REQUIRE(argsort(score.data(), N, order.data()) == 0, "host argsort failed");
-      std::vector<int64_t> top;              // argsort(score)[::-1][:n_keep]
-      for (int64_t i = 0; i < std::min<int64_t>(n_keep, N); ++i) top.push_back(order[(size_t)N - 1 - i]);
-      int64_t head = (int64_t)top.size();
-      if ((int64_t)top.size() > T) {
-        const double v_cut = score[top[(size_t)T - 1]];
-        head = 0;
-        for (int64_t i : top) head += score[i] >= v_cut;      // value is descending: a prefix
-      }
-      top.resize((size_t)head);
-      Head hh;
-      hh.c = c;
-      for (int64_t i : top) {
-        const int64_t flat = where[i];
-        const int t = (int)(flat / A), a = (int)(flat % A);
-        hh.value.push_back(score[i]);
-        hh.ids.insert(hh.ids.end(), prev.ids.begin() + (size_t)t * k, prev.ids.begin() + (size_t)(t + 1) * k);
-        hh.ids.push_back(cols[a]);
-      }
-      fill_sums(hh, colsum);
-      std::vector<int64_t> contend;
-      contenders(hh, T, contend);
-      std::vector<int32_t> cids(contend.size() * c);
-      for (size_t q = 0; q < contend.size(); ++q)
-        std::copy(hh.ids.begin() + (size_t)contend[q] * c, hh.ids.begin() + (size_t)(contend[q] + 1) * c,
-                  cids.begin() + q * c);
-      std::vector<double> frac(contend.size() * c);
-      if (!contend.empty()) {
-        rc = gk_fraction(ctx, d_L, n_rows, ld, cids.data(), (int32_t)contend.size(), c, frac.data());
-        if (rc) return rc;
-        S->note(2, n_rows, (int64_t)contend.size(), c, S->distinct(cids.data(), cids.size()), 0, 0);
-      }
-      std::vector<Key3> keys(contend.size());
-      for (size_t q = 0; q < contend.size(); ++q)
-        keys[q] = Key3{-hh.value[contend[q]], hh.key2[contend[q]], unevenness(frac.data() + q * c, c)};
-      std::vector<int64_t> sub;
-      lexsort3(keys, sub);
-      const size_t keep = std::min<size_t>(sub.size(), (size_t)T);
-      for (size_t q = 0; q < keep; ++q) {
-        const int64_t i = contend[sub[q]];
-        st.value.push_back(hh.value[i]);
-        st.ids.insert(st.ids.end(), hh.ids.begin() + (size_t)i * c, hh.ids.begin() + (size_t)(i + 1) * c);
-        st.sum_indv.insert(st.sum_indv.end(), hh.sum_indv.begin() + (size_t)i * c,
-                           hh.sum_indv.begin() + (size_t)(i + 1) * c);
-        st.frac.insert(st.frac.end(), frac.begin() + sub[q] * c, frac.begin() + (sub[q] + 1) * c);
-      }
-    }
-    S->steps.push_back(std::move(st));
+    rc = wait_stream(ctx);          // every key these kernels claimed is stored
+    if (rc) return rc;
+    int32_t n_new = 0, n_known = 0, n_undefined = 0;
+    rc = gk_lut_resolve(lut, log10_fn, &n_new, &n_known, &n_undefined);
+    if (rc) return rc;
+    if (n_known > known_at_launch) continue;    // some values were undefined at launch: write the tables again
+    if (n_undefined == 0) break;                // every value these launches met had its log10 in the table
+    if (pass == 63) { gk_set_error("log10 value table did not settle"); return GK_ERR_ASSERT; }
   }
-  *out = S.release();
+  std::vector<std::unique_ptr<GeneSearch>> gs((size_t)n_jobs);
+  auto fail = [&](int code) {
+    for (auto& g : gs) if (g) g->abandon();
+    return code;
+  };
+  // ---- phase 1: column sums of every gene, first step
+  for (int i : live) {
+    gk_gene_job& j = jobs[i];
+    j.bound_ok = (j.d_miss8 && flags[i] == 0) ? 1 : 0;
+    std::vector<int32_t> cols((size_t)j.n_allele);
+    std::iota(cols.begin(), cols.end(), 0);
+    gs[i].reset(new GeneSearch());
+    rc = gs[i]->init(ctx, j.d_L, j.n_rows, j.n_rows, j.n_allele, j.bound_ok ? j.d_miss8 : 0, j.ldm, j.bound_ok ? j.d_msum : 0,
+                     cols.data(), j.n_allele, j.n_steps, j.top_n, argsort);
+    if (rc == GK_OK) rc = gs[i]->colsum_enqueue();
+    if (rc) return fail(rc);
+  }
+  rc = wait_stream(ctx);
+  if (rc) return fail(rc);
+  for (int i : live) {
+    gs[i]->colsum_collect();
+    rc = gs[i]->first_step();
+    if (rc) return fail(rc);
+  }
+  // ---- further steps, all genes that have one together
+  for (;;) {
+    std::vector<int> todo;
+    for (int i : live) if (gs[i]->more()) todo.push_back(i);
+    if (todo.empty()) break;
+    for (int i : todo) { rc = gs[i]->step_begin(); if (rc) return fail(rc); }
+    rc = wait_stream(ctx);
+    if (rc) return fail(rc);
+    for (int i : todo) { rc = gs[i]->after_bound(); if (rc) return fail(rc); }
+    rc = wait_stream(ctx);
+    if (rc) return fail(rc);
+    for (int i : todo) { rc = gs[i]->after_sums(); if (rc) return fail(rc); }
+    for (int i : todo) {
+      if (!gs[i]->step_done) { rc = gs[i]->exact_step(); if (rc) return fail(rc); }
+      gs[i]->step_end();
+    }
+  }
+  for (int i : live) out[i] = gs[i]->S.release();
   return GK_OK;
 }
 

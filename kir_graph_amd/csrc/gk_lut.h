@@ -14,6 +14,8 @@ struct gk_lut {
                                    // fused lookup load key and value side by side instead of key -> index -> value
   uint32_t* d_count = nullptr;     // number of dense entries
   int32_t n_known = 0;             // entries with a defined value
+  int32_t n_undefined = 0;         // entries the last gk_lut_resolve saw claimed but not stored yet
+  std::mutex resolve_mutex;        // one resolver at a time (host threads of a process share the table)
 };
 
 // a NaN payload no product of 0.999 / 0.001 can produce

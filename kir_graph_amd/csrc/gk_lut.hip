@@ -172,6 +172,48 @@ int gk_lut_define(gk_lut* l, int32_t first, int32_t count, const double* log_val
   return GK_OK;
 }
 
+/* Evaluate log10 (through the caller's function: numpy.log10 in the Python binding, so that the bits are the
+ * reference's on the machine at hand) for the values first seen since the last call, define them.  One resolver at a
+ * time.  The caller's own kernels must have completed.  Kernels of other streams may still be inserting: an entry that is
+ * claimed but not stored yet ends the batch (n_undefined > 0) -- whoever launched that kernel resolves it. */
+int gk_lut_resolve(gk_lut* l, gk_log10_fn log10_fn, int32_t* n_new_out, int32_t* n_known_out, int32_t* n_undefined_out) {
+  GK_REQUIRE(l && log10_fn, "null pointer");
+  std::lock_guard<std::mutex> lock(l->resolve_mutex);
+  int32_t tot = 0, known = 0;
+  int rc = gk_lut_pending(l, &tot, &known);
+  if (rc) return rc;
+  int32_t fresh = tot - known;
+  if (fresh > 0) {
+    std::vector<double> keys((size_t)fresh), vals((size_t)fresh);
+    rc = gk_lut_export(l, known, fresh, keys.data());
+    if (rc) return rc;
+    for (int32_t i = 0; i < fresh; ++i) {
+      uint64_t bits;
+      memcpy(&bits, &keys[i], 8);
+      if (bits == kLutEmptyKey) { fresh = i; break; }   // claimed, not stored yet
+    }
+    if (fresh > 0) {
+      GK_REQUIRE(log10_fn(keys.data(), fresh, vals.data()) == 0, "host log10 failed");
+      rc = gk_lut_define(l, known, fresh, vals.data());
+      if (rc) return rc;
+    }
+  } else {
+    fresh = 0;
+  }
+  l->n_undefined = tot - l->n_known;
+  if (n_new_out) *n_new_out = fresh;
+  if (n_known_out) *n_known_out = l->n_known;
+  if (n_undefined_out) *n_undefined_out = l->n_undefined;
+  return GK_OK;
+}
+
+int gk_lut_known(gk_lut* l, int32_t* n_known) {
+  GK_REQUIRE(l && n_known, "null pointer");
+  std::lock_guard<std::mutex> lock(l->resolve_mutex);
+  *n_known = l->n_known;
+  return GK_OK;
+}
+
 int gk_lut_apply(gk_lut* l, gk_dptr d_in, gk_dptr d_out, int64_t n) {
   gk_bind(l ? l->ctx : nullptr);
   GK_REQUIRE(l, "null table");

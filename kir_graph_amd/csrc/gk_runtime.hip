@@ -159,6 +159,7 @@ int gk_timer_stop_ms(gk_ctx* ctx, float* ms) {
 
 // ---- pinned staging (see gk_ctx)
 constexpr size_t kStageDirect = (size_t)4 << 20;   // larger transfers go straight to / from the caller's memory
+size_t gk_stage_direct() { return kStageDirect; }
 
 hipError_t gk_send(gk_ctx* ctx, void* dst_dev, const void* src, size_t bytes) {
   if (!bytes) return hipSuccess;

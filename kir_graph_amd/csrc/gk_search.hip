@@ -26,7 +26,7 @@
 // small kernel finishes the tree per chunk.
 #include <algorithm>
 
-#include "gk_common.h"
+#include "gk_calls.h"
 
 namespace {
 
@@ -652,7 +652,8 @@ int upload_program(gk_ctx* ctx, int64_t n_rows, const int32_t* ids, size_t n_ids
     }
     GK_HIP(gk_pool_malloc(ctx, (void**)&prog, buf.size()));
     GK_HIP(gk_send(ctx, prog, buf.data(), buf.size()));
-    GK_HIP(hipStreamSynchronize(ctx->stream));   // a large program goes straight from buf, which goes out of scope
+    if (buf.size() > gk_stage_direct())          // a large program goes straight from buf, which goes out of scope
+      GK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->tree_programs[n_rows] = prog;
     ctx->tree_heads[n_rows] = head;
   }
@@ -773,10 +774,57 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   return GK_OK;
 }
 
-static int set_shares(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
-                      double* frac_out, double* value_out) {
+int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
+                double* frac_out) {
   gk_bind(ctx);
-  GK_REQUIRE(ctx && ids && frac_out && n_rows > 0 && ld >= n_rows && n_sets > 0, "bad fraction arguments");
+  GK_REQUIRE(frac_out, "null output");
+  GkSumCall call;
+  int rc = gk_shares_enqueue(ctx, d_L, n_rows, ld, ids, n_sets, c, false, call);
+  if (rc == GK_OK && gk_fetch_wait(ctx) != hipSuccess) { gk_set_error("set shares: waiting for the stream failed"); rc = GK_ERR_HIP; }
+  if (rc == GK_OK) gk_shares_collect(ctx, call, nullptr, frac_out);
+  else gk_release(ctx, call.temps);
+  return rc;
+}
+
+int gk_setsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
+              double* value_out, double* frac_out) {
+  gk_bind(ctx);
+  GK_REQUIRE(value_out && frac_out, "null output");
+  GkSumCall call;
+  int rc = gk_shares_enqueue(ctx, d_L, n_rows, ld, ids, n_sets, c, true, call);
+  if (rc == GK_OK && gk_fetch_wait(ctx) != hipSuccess) { gk_set_error("set sums: waiting for the stream failed"); rc = GK_ERR_HIP; }
+  if (rc == GK_OK) gk_shares_collect(ctx, call, value_out, frac_out);
+  else gk_release(ctx, call.temps);
+  return rc;
+}
+
+int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
+              gk_dptr d_P) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && ids && n_rows > 0 && ld >= n_rows && n_sets > 0 && c >= 1 && c <= kMaxC, "bad setmax arguments");
+  hipStream_t st = ctx->stream;
+  int32_t* d_ids = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_ids, (size_t)n_sets * c * sizeof(int32_t)));
+  GK_HIP(gk_send(ctx, d_ids, ids, (size_t)n_sets * c * sizeof(int32_t)));
+  int64_t want = (n_rows + kThreads - 1) / kThreads;
+  unsigned bx = (unsigned)(want < 1024 ? want : 1024);
+  GK_PROF(ctx, GK_K_SETMAX,
+          GK_KERNEL(setmax_kernel, dim3(bx, (unsigned)n_sets), dim3(kThreads), 0, st, gk_ptr<double>(d_L), n_rows,
+                             ld, d_ids, n_sets, c, gk_ptr<double>(d_P)));
+  GK_HIP(hipGetLastError());
+  GK_HIP(hipStreamSynchronize(st));
+  gk_pool_free(ctx, d_ids);
+  return GK_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// the two halves of the set-share / column-sum calls (gk_calls.h)
+int gk_shares_enqueue(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
+                      bool with_value, GkSumCall& call) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && ids && n_rows > 0 && ld >= n_rows && n_sets > 0, "bad fraction arguments");
   GK_REQUIRE(c >= 1 && c <= kMaxC, "copy number beyond supported set size");
   // Order the sets so that tiles of 32 share columns: the best sets pair a few strong alleles with
   // many partners, so sort by each set's ids taken rarest-first (partners adjacent, hubs shared).
@@ -831,12 +879,15 @@ static int set_shares(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, cons
   DeviceProgram dp;
   int rc = upload_program(ctx, n_rows, plan.data(), plan.size(), nullptr, 0, dp);
   if (rc) return rc;
+  call.temps.push_back(dp.base);
   hipStream_t st = ctx->stream;
   double *d_partial = nullptr, *d_out = nullptr;
-  const int per_set = c + (value_out ? 1 : 0);
+  const int per_set = c + (with_value ? 1 : 0);
   const int64_t n_out = (int64_t)n_sets * per_set;
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * dp.n_spans * sizeof(double)));
+  call.temps.push_back(d_partial);
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_out * sizeof(double)));
+  call.temps.push_back(d_out);
   const dim3 grid((unsigned)n_tiles, (unsigned)dp.n_spans);
   const size_t lds = (size_t)max_dist * kFracLd * sizeof(double);   // <= 256 columns * 41 * 8 = 84 KB
 #define GK_FRAC_LAUNCH_V(C, V)                                                                                       \
@@ -846,7 +897,7 @@ static int set_shares(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, cons
           GK_KERNEL((fraction_chunks<C, V>), grid, dim3(kThreads), lds, st, gk_ptr<double>(d_L), ld, dp.ids,     \
                              dp.ids + o_cols, dp.ids + o_local, dp.ids + o_perm, n_sets, dp.spans, dp.leaves, d_partial))
 #define GK_FRAC_LAUNCH(C)                 \
-  if (value_out) { GK_FRAC_LAUNCH_V(C, true); } \
+  if (with_value) { GK_FRAC_LAUNCH_V(C, true); } \
   else { GK_FRAC_LAUNCH_V(C, false); }
   switch (c) {
     case 1: GK_FRAC_LAUNCH(1); break;
@@ -860,58 +911,67 @@ static int set_shares(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, cons
   }
 #undef GK_FRAC_LAUNCH
 #undef GK_FRAC_LAUNCH_V
-  // with the value riding along the sums are handed back undivided (the caller divides the shares by n_rows)
+  // with the value riding along the sums are handed back undivided (collect divides the shares by n_rows)
   GK_PROF(ctx, GK_K_COMBINE,
           GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st,
                              d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top,
-                             value_out ? 0.0 : (double)n_rows, d_out));
+                             with_value ? 0.0 : (double)n_rows, d_out));
   GK_HIP(hipGetLastError());
-  if (!value_out) {
-    GK_HIP(gk_fetch(ctx, frac_out, d_out, (size_t)n_out * sizeof(double)));
+  call.n_rows = n_rows;
+  call.n_sets = n_sets;
+  call.c = c;
+  call.with_value = with_value;
+  call.back.resize((size_t)n_out);
+  GK_HIP(gk_fetch_queue(ctx, call.back.data(), d_out, (size_t)n_out * sizeof(double)));
+  return GK_OK;
+}
+
+void gk_shares_collect(gk_ctx* ctx, GkSumCall& call, double* value_out, double* frac_out) {
+  const int c = call.c;
+  if (!call.with_value) {
+    if (frac_out) std::copy(call.back.begin(), call.back.end(), frac_out);
   } else {
-    std::vector<double> both((size_t)n_out);
-    GK_HIP(gk_fetch(ctx, both.data(), d_out, (size_t)n_out * sizeof(double)));
-    const double rows = (double)n_rows;
-    for (int k = 0; k < n_sets; ++k) {
-      const double* src = both.data() + (size_t)k * per_set;
-      for (int q = 0; q < c; ++q) frac_out[(size_t)k * c + q] = src[q] / rows;   // the IEEE quotient numpy forms (580)
-      value_out[k] = src[c];
+    const double rows = (double)call.n_rows;
+    const int per_set = c + 1;
+    for (int k = 0; k < call.n_sets; ++k) {
+      const double* src = call.back.data() + (size_t)k * per_set;
+      if (frac_out)
+        for (int q = 0; q < c; ++q) frac_out[(size_t)k * c + q] = src[q] / rows;   // the IEEE quotient numpy forms (580)
+      if (value_out) value_out[k] = src[c];
     }
   }
-  gk_pool_free(ctx, d_partial);
-  gk_pool_free(ctx, d_out);
-  gk_pool_free(ctx, dp.base);
-  return GK_OK;
+  gk_release(ctx, call.temps);
 }
 
-int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
-                double* frac_out) {
-  return set_shares(ctx, d_L, n_rows, ld, ids, n_sets, c, frac_out, nullptr);
-}
-
-int gk_setsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
-              double* value_out, double* frac_out) {
-  GK_REQUIRE(value_out, "null output");
-  return set_shares(ctx, d_L, n_rows, ld, ids, n_sets, c, frac_out, value_out);
-}
-
-int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
-              gk_dptr d_P) {
+int gk_colsum_enqueue(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* cols, int32_t n_cols,
+                      GkSumCall& call) {
   gk_bind(ctx);
-  GK_REQUIRE(ctx && ids && n_rows > 0 && ld >= n_rows && n_sets > 0 && c >= 1 && c <= kMaxC, "bad setmax arguments");
+  GK_REQUIRE(ctx && cols && n_rows > 0 && ld >= n_rows && n_cols > 0, "bad column-sum arguments");
+  DeviceProgram dp;
+  int rc = upload_program(ctx, n_rows, nullptr, 0, cols, (size_t)n_cols, dp);
+  if (rc) return rc;
+  call.temps.push_back(dp.base);
   hipStream_t st = ctx->stream;
-  int32_t* d_ids = nullptr;
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d_ids, (size_t)n_sets * c * sizeof(int32_t)));
-  GK_HIP(gk_send(ctx, d_ids, ids, (size_t)n_sets * c * sizeof(int32_t)));
-  int64_t want = (n_rows + kThreads - 1) / kThreads;
-  unsigned bx = (unsigned)(want < 1024 ? want : 1024);
-  GK_PROF(ctx, GK_K_SETMAX,
-          GK_KERNEL(setmax_kernel, dim3(bx, (unsigned)n_sets), dim3(kThreads), 0, st, gk_ptr<double>(d_L), n_rows,
-                             ld, d_ids, n_sets, c, gk_ptr<double>(d_P)));
+  double *d_partial = nullptr, *d_out = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_cols * dp.n_spans * sizeof(double)));
+  call.temps.push_back(d_partial);
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_cols * sizeof(double)));
+  call.temps.push_back(d_out);
+  GK_PROF_EXACT(ctx, GK_K_MAXSUM,
+          GK_KERNEL(colsum_chunks, dim3((unsigned)((n_cols + kColsPerGroup - 1) / kColsPerGroup), (unsigned)dp.n_spans),
+                    dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld, dp.cols, n_cols, dp.spans, dp.leaves, d_partial));
+  GK_PROF(ctx, GK_K_COMBINE,
+          GK_KERNEL(combine_chunks, dim3((unsigned)((n_cols + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st,
+                             d_partial, (int64_t)n_cols, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, 0.0, d_out));
   GK_HIP(hipGetLastError());
-  GK_HIP(hipStreamSynchronize(st));
-  gk_pool_free(ctx, d_ids);
+  call.n_rows = n_rows;
+  call.n_sets = n_cols;
+  call.back.resize((size_t)n_cols);
+  GK_HIP(gk_fetch_queue(ctx, call.back.data(), d_out, (size_t)n_cols * sizeof(double)));
   return GK_OK;
 }
 
-}  // extern "C"
+void gk_colsum_collect(gk_ctx* ctx, GkSumCall& call, double* out) {
+  if (out) std::copy(call.back.begin(), call.back.end(), out);
+  gk_release(ctx, call.temps);
+}

@@ -371,30 +371,24 @@ class LogTable:
         """Evaluate numpy.log10 for values first seen since the last call; returns how many.
 
         The caller's own kernels must have completed (``Device.sync``).  Kernels of other streams
-        may still be inserting: ``gk_lut_pending`` waits for the device when the table grew, and an
+        may still be inserting: the library waits for the device when the table grew, and an
         entry that is claimed but not stored yet (possible only for kernels launched meanwhile) ends
-        the batch -- whoever launched that kernel resolves it."""
+        the batch -- whoever launched that kernel resolves it.  One resolver at a time, serialised inside the
+        library (``gk_lut_resolve``): host threads and ``gk_sample_search`` share the table."""
         with self._lock:
-            tot, known = C.c_int32(), C.c_int32()
-            check(lib().gk_lut_pending(self.handle, C.byref(tot), C.byref(known)))
-            new = tot.value - known.value
-            if new <= 0:
-                self.n_undefined = 0
-                return 0
-            keys = np.empty(new, dtype=np.float64)
-            check(lib().gk_lut_export(self.handle, known.value, new, keys.ctypes.data))
-            unset = np.flatnonzero(keys.view(np.uint64) == self._EMPTY)
-            if len(unset):
-                new = int(unset[0])
-                keys = keys[:new]
-            if new:
-                with np.errstate(divide="ignore"):
-                    vals = np.log10(keys)
-                check(lib().gk_lut_define(self.handle, known.value, new, vals.ctypes.data))
-                self.n_host_evals += new
-                self.n_known = known.value + new
-            self.n_undefined = tot.value - self.n_known    # claimed by kernels still running elsewhere
-            return new
+            n_new, known, undefined = C.c_int32(), C.c_int32(), C.c_int32()
+            check(lib().gk_lut_resolve(self.handle, _lib.NUMPY_LOG10, C.byref(n_new), C.byref(known), C.byref(undefined)))
+            self.n_host_evals += n_new.value
+            self.n_known = known.value
+            self.n_undefined = undefined.value      # claimed by kernels still running elsewhere
+            return n_new.value
+
+    def known(self) -> int:
+        """Values with a defined log10 right now (another thread or ``gk_sample_search`` may have resolved some)."""
+        n = C.c_int32()
+        check(lib().gk_lut_known(self.handle, C.byref(n)))
+        self.n_known = max(self.n_known, n.value)
+        return n.value
 
     def apply(self, src: DeviceBuffer, dst: DeviceBuffer, n: int) -> None:
         check(lib().gk_lut_apply(self.handle, src.ptr, dst.ptr, n))
@@ -410,9 +404,10 @@ class DeviceModel:
 
     def __init__(self, tab: Tabulation, rows: DeviceBuffer, n_rows: int, vflag: DeviceBuffer,
                  vbeg: int, vend: int, mask: DeviceBuffer, words: int, n_allele: int, logs: LogTable,
-                 want_miss: bool = False, keep_empty: bool = False):
+                 want_miss: bool = False, keep_empty: bool = False, launch: bool = True):
         """``keep_empty``: rows without any kept variant are part of the model and score 0.999 for every
-        allele (``no_empty=False``, typing_mulit_allele.py:372-374)."""
+        allele (``no_empty=False``, typing_mulit_allele.py:372-374).  ``launch=False``: the tables are only
+        allocated; ``gk_sample_search`` fills them together with those of the sample's other genes."""
         self.tab, self.dev = tab, tab.dev
         self._keep_empty = int(bool(keep_empty))
         self.rows, self.n_rows, self.n_allele = rows, n_rows, n_allele
@@ -435,13 +430,14 @@ class DeviceModel:
             self.miss8 = self.dev.alloc((n_allele, self.ldm), np.uint8)
             self.msum = self.dev.alloc(n_allele, np.uint32)
             self._bound_flags = self.dev.alloc(1, np.uint32)
-        self._launchLog()
+        if launch:
+            self._launchLog()
         if want_miss:
             self._launchProbs()
 
     def _launchLog(self) -> None:
         vbeg, vend, mask, words = self._geom
-        self._known_at_launch = self._logs.n_known
+        self._known_at_launch = self._logs.known()
         if self.dev.call_log is not None:    # ids of the rows: the sample's average list length (no sync for a count)
             per_row = self.tab.n_ids / max(self.tab.n_valid, 1)
             self.dev.call_log.append(("compat_kernel", self.n_rows, self.n_allele, per_row * self.n_rows, 8))

@@ -208,6 +208,80 @@ class TypingWithPosNegAllele(_GenesInParallel):
         self._exon_candidate_threshold = exon_candidate_threshold
         self._variant_correction = variant_correction
 
+    def typing(self, gene_cn: dict[str, int], min_reads_num: int = 100) -> tuple[list[str], list[str]]:
+        """The plain likelihood strategy with the sample-wide preamble goes through ``gk_sample_search``: every gene's
+        table and search in ONE library call on one stream (the genes advance in lock-step; ~10 waits per sample).
+        Anything else (exon-first, no correction, GK_SAMPLE_SEARCH=0) keeps a thread and a stream per gene."""
+        if self._wholeSample():
+            return self._typingWholeSample(gene_cn, min_reads_num)
+        return super().typing(gene_cn, min_reads_num)
+
+    def _wholeSample(self) -> bool:
+        import os
+        from .engine import searchMode
+        from .typing_mulit_allele import nativeSearch
+        return (not self._exon_first and not self._exon_only and self._variant_correction and batchedPreamble()
+                and nativeSearch() and os.environ.get("GK_SAMPLE_SEARCH", "1") != "0" and searchMode() in ("bound", "exact"))
+
+    def _typingWholeSample(self, gene_cn: dict[str, int], min_reads_num: int) -> tuple[list[str], list[str]]:
+        import ctypes as C
+        from . import _lib
+        from ._lib import check, lib
+        tab, logs = self._context()
+        prep = tab.prepared(tab.dev, self._multiple)
+        if prep is None:                 # not a gk_tabulate tabulation (host lists / compact files)
+            return super().typing(gene_cn, min_reads_num)
+        vflag, cnt, rows_all, off = prep[:4]
+        todo = [(gene, int(cn)) for gene, cn in gene_cn.items() if cn]
+        entries = []                     # (gene, cn, typ or None, job, homo)
+        for gene, cn in todo:
+            view = _GeneView(self._data, gene, self._multiple, tab=tab)
+            if view.g is None or not view.alleles:
+                entries.append((gene, cn, None, None, False))
+                continue
+            a, b = int(off[view.g]), int(off[view.g + 1])
+            rows = _lib_slice(rows_all, a, b - a, tab.dev)
+            prepared = (rows, b - a, vflag, cnt, (view.g, view.vbeg, view.vbeg + view.n_span),
+                        type(tab).survivingOfGene(prep, view.g))
+            typ = AlleleTyping(ReadSet(tab, rows, b - a, vflag), view.variants,
+                               force_homo=False if isHetrozygous(gene) else None, top_n=self._top_n,
+                               variant_correction=True, logs=logs, _vbeg=view.vbeg, _n_span=view.n_span, _mask=view.mask,
+                               _alleles=view.alleles, _novel=view.novel, _prepared=prepared, _defer_launch=True)
+            if b - a == 0:
+                entries.append((gene, cn, typ, None, False))
+                continue
+            job, homo = typ.geneJob(cn)
+            entries.append((gene, cn, typ, job, homo))
+        live = [e for e in entries if e[3] is not None]
+        if live:
+            jobs = (_lib.GeneJob * len(live))(*[e[3] for e in live])
+            handles = (C.c_void_p * len(live))()
+            check(lib().gk_sample_search(tab.dev.ctx, tab.handle, vflag.ptr, logs.handle, jobs, len(live),
+                                         _lib.NUMPY_ARGSORT, _lib.NUMPY_LOG10, handles))
+            try:
+                for k, (gene, cn, typ, _, homo) in enumerate(live):
+                    typ.adoptJob(jobs[k], C.c_void_p(handles[k]), cn, homo)
+            finally:
+                for h in handles:
+                    if h:
+                        lib().gk_search_destroy(C.c_void_p(h))
+        predict_alleles, warning_genes = [], []
+        self._result = {}
+        for gene, cn, typ, job, _ in entries:
+            pure_gene = gene.split("*")[0]
+            if typ is None:
+                self._result[gene] = []
+                alleles, reads_num = [f"{pure_gene}*"] * cn, 0
+            else:
+                res = typ.result[-1] if job is not None else typ.typing(cn)     # no rows: the reference's empty results
+                self._result[gene] = typ.result
+                alleles = [x if x != "fail" else f"{pure_gene}*" for x in res.selectBest()]
+                reads_num = typ.getReadsNum()
+            predict_alleles.extend(alleles)
+            if reads_num < min_reads_num:
+                warning_genes.append(gene)
+        return predict_alleles, warning_genes
+
     def typingPerGene(self, gene: str, cn: int) -> tuple[list[str], int]:
         logger.debug(f"[Allele] {gene=} {cn=}")
         force_homo = False if isHetrozygous(gene) else None

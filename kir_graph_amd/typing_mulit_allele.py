@@ -343,9 +343,11 @@ class AlleleTyping:
                  no_empty: bool = True, variant_correction: bool = True, *, device: Device | None = None,
                  logs: LogTable | None = None, _vbeg: int = 0, _n_span: int | None = None,
                  _mask: DeviceBuffer | None = None, _alleles: list[str] | None = None, _defer_log: bool = False,
-                 _novel=None, _prepared: tuple | None = None):
+                 _novel=None, _prepared: tuple | None = None, _defer_launch: bool = False):
         """``_prepared`` = (rows with a surviving id, their count, shared drop flags, shared tallies, (gene, vbeg, vend)):
-        error correction and removal of empty reads already done for the whole sample (``Tabulation.prepared``)."""
+        error correction and removal of empty reads already done for the whole sample (``Tabulation.prepared``).
+        ``_defer_launch``: the tables are allocated, not written -- ``gk_sample_search`` writes them and runs the
+        search together with the sample's other genes (``kir_typing.TypingWithPosNegAllele``)."""
         self.top_n = top_n
         self._no_empty = no_empty
         self.force_homo = force_homo
@@ -389,11 +391,11 @@ class AlleleTyping:
         if _mask is None:
             _mask = self._dev.put(buildMask(variants[:n_span], names))
         self._model = DeviceModel(tab, rows, n_rows, rs.vflag, _vbeg, _vbeg + n_span, _mask, words, n_allele,
-                                  self._logs, keep_empty=not no_empty)
+                                  self._logs, keep_empty=not no_empty, launch=not _defer_launch)
         self._colsum_all: np.ndarray | None = None
         self._pair_table: np.ndarray | None = None    # scores of all allele pairs (second step), when formed
         self._reads_cache = None
-        if not _defer_log:
+        if not _defer_log and not _defer_launch:
             self.finish()
         if n_rows == 0:
             logger.warning("[Allele] Error: Empty reads for typing (or Maybe read depth is too low)")
@@ -489,39 +491,77 @@ class AlleleTyping:
                                   cols.ctypes.data, len(cols), cn, self.top_n, _lib.NUMPY_ARGSORT,
                                   None if colsum is None else colsum.ctypes.data, C.byref(h)))
         try:
-            if self._colsum_all is None:
-                self._colsum_all = np.empty(m.n_allele, dtype=np.float64)
-                check(lib().gk_search_colsum(h, self._colsum_all.ctypes.data))
-            for step in range(cn):
-                n, rows, bounded = C.c_int32(), C.c_int64(), C.c_int32()
-                check(lib().gk_search_info(h, step, C.byref(n), C.byref(rows), C.byref(bounded)))
-                k, c = int(rows.value), int(n.value)
-                value = np.empty(k, dtype=np.float64)
-                sum_indv, frac = np.empty((k, c), dtype=np.float64), np.empty((k, c), dtype=np.float64)
-                ids32 = np.empty((k, c), dtype=np.int32)
-                check(lib().gk_search_copy(h, step, value.ctypes.data, sum_indv.ctypes.data, ids32.ctypes.data,
-                                           frac.ctypes.data))
-                ids = ids32.astype(np.int64)
-                if step:
-                    SEARCH_STATS["bounded" if bounded.value else "redone_exactly"] += 1
-                self.result.append(TypingResult(
-                    n=c, value=value, value_sum_indv=sum_indv, allele_id=ids,
-                    allele_name=LazyNames(ids, self.id_to_allele), allele_prob=LazyAlleleProb([(m, ids)]),
-                    fraction=frac if step else np.ones(ids.shape), fraction_uniq=np.ones(ids.shape)))
-            if m.dev.call_log is not None:
-                n_log = C.c_int64()
-                check(lib().gk_search_log(h, None, 0, C.byref(n_log)))
-                raw = np.empty(n_log.value, dtype=np.int64)
-                check(lib().gk_search_log(h, raw.ctypes.data, len(raw), C.byref(n_log)))
-                for kind, a, b, c_, d, e, f in raw.reshape(-1, 7).tolist():
-                    if kind == 0:
-                        m.dev.call_log.append(("maxsum_chunks", a, b, c_, d, e, bool(f)))
-                    elif kind == 1:
-                        m.dev.call_log.append(("minsum_sad", a, b, c_, d, False))
-                    else:
-                        m.dev.call_log.append(("fraction_chunks", a, b, c_, d))
+            self._adoptSearch(h, cn)
         finally:
             lib().gk_search_destroy(h)
+
+    def _adoptSearch(self, h, n_steps: int) -> None:
+        """Results of a native search (``gk_search`` handle) -> ``self.result`` (one TypingResult per step)."""
+        import ctypes as C
+        from ._lib import check, lib
+        m = self._model
+        if self._colsum_all is None:
+            self._colsum_all = np.empty(m.n_allele, dtype=np.float64)
+            check(lib().gk_search_colsum(h, self._colsum_all.ctypes.data))
+        for step in range(n_steps):
+            n, rows, bounded = C.c_int32(), C.c_int64(), C.c_int32()
+            check(lib().gk_search_info(h, step, C.byref(n), C.byref(rows), C.byref(bounded)))
+            k, c = int(rows.value), int(n.value)
+            value = np.empty(k, dtype=np.float64)
+            sum_indv, frac = np.empty((k, c), dtype=np.float64), np.empty((k, c), dtype=np.float64)
+            ids32 = np.empty((k, c), dtype=np.int32)
+            check(lib().gk_search_copy(h, step, value.ctypes.data, sum_indv.ctypes.data, ids32.ctypes.data,
+                                       frac.ctypes.data))
+            ids = ids32.astype(np.int64)
+            if step:
+                SEARCH_STATS["bounded" if bounded.value else "redone_exactly"] += 1
+            self.result.append(TypingResult(
+                n=c, value=value, value_sum_indv=sum_indv, allele_id=ids,
+                allele_name=LazyNames(ids, self.id_to_allele), allele_prob=LazyAlleleProb([(m, ids)]),
+                fraction=frac if step else np.ones(ids.shape), fraction_uniq=np.ones(ids.shape)))
+        if m.dev.call_log is not None:
+            n_log = C.c_int64()
+            check(lib().gk_search_log(h, None, 0, C.byref(n_log)))
+            raw = np.empty(n_log.value, dtype=np.int64)
+            check(lib().gk_search_log(h, raw.ctypes.data, len(raw), C.byref(n_log)))
+            for kind, a, b, c_, d, e, f in raw.reshape(-1, 7).tolist():
+                if kind == 0:
+                    m.dev.call_log.append(("maxsum_chunks", a, b, c_, d, e, bool(f)))
+                elif kind == 1:
+                    m.dev.call_log.append(("minsum_sad", a, b, c_, d, False))
+                else:
+                    m.dev.call_log.append(("fraction_chunks", a, b, c_, d))
+
+    def geneJob(self, cn: int):
+        """(``_lib.GeneJob`` for ``gk_sample_search``, homozygous?) of a model built with ``_defer_launch``: the
+        zygosity decision of ``typing`` (383-410) is taken here, the table and the search run in the library."""
+        from ._lib import GeneJob
+        if cn < 1:
+            raise ValueError(f"CN should be >= 1, got {cn}")
+        homo = self._isHomozygous(cn) if self.force_homo is None else self.force_homo
+        m = self._model
+        vbeg, vend, mask, words = m._geom
+        job = GeneJob(d_rows=m.rows.ptr, n_rows=m.n_rows, d_mask=mask.ptr, d_L=m.L.ptr if m.L else 0,
+                      d_miss8=m.miss8.ptr if m.miss8 else 0, ldm=m.ldm, d_msum=m.msum.ptr if m.msum else 0,
+                      d_flags=m._bound_flags.ptr if m._bound_flags else 0, vbeg=vbeg, vend=vend, words=words,
+                      n_allele=m.n_allele, n_steps=1 if homo else cn, top_n=self.top_n, bound_ok=0, passes=0)
+        return job, homo
+
+    def adoptJob(self, job, handle, cn: int, homo: bool) -> TypingResult:
+        """What ``typing(cn)`` leaves behind, from the gene's part of ``gk_sample_search``."""
+        m = self._model
+        m._bound_ok = bool(job.bound_ok)
+        m._known_at_launch = -1
+        if m.dev.call_log is not None:
+            per_row = m.tab.n_ids / max(m.tab.n_valid, 1)
+            for _ in range(max(1, int(job.passes))):
+                m.dev.call_log.append(("compat_kernel", m.n_rows, m.n_allele, per_row * m.n_rows, 8))
+        self.result = []
+        self._adoptSearch(handle, 1 if homo else cn)
+        if homo:
+            self.addHomoResultForCn(cn)
+        self.result[-1].print()
+        return self.result[-1]
 
     def addHomoResultForCn(self, cn: int) -> None:
         if cn > 1:

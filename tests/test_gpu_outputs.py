@@ -283,3 +283,39 @@ def test_ranks_flag_starts_the_ranks_itself(device, tmp_path):
         a = (one / name).read_text().replace(str(one), "@")
         b = (two / name).read_text().replace(str(two), "@")
         assert a == b, name
+
+
+def test_configs3_in_small_sixteen_samples_over_six_ranks(device, tmp_path):
+    """configs[3] reduced (BASELINE.json: 64 samples x 5 M reads, --cn-cohort, 8 GPUs; the full size is
+    tools/run_cohort_cfg3.py): 16 samples through ``python -m kir_graph_amd.main --cn-cohort --ranks 6`` on this GPU
+    (file backend; the pool allows six processes on a card) -- every TSV equals the single-process run byte for byte,
+    and the copy numbers equal the oracle's fit on the pooled depths (main.py:572-589, kir_cn.py:61, 167-186)."""
+    import subprocess
+    import sys
+    sidx, folder, sams, samples = _cohort(tmp_path, n_samples=16, n_pairs=2500)
+    one = tmp_path / "one"
+    _run(folder, one, sams, ["--cn-cohort"])
+    many = tmp_path / "many"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "kir_graph_amd.main", "--step-skip-extraction", "--index-folder", folder,
+           "--output-folder", str(many), "--allele-strategy", "pv", "--no-variant-json", "--cn-cohort", "--ranks", "6",
+           "--log-level", "WARNING"] + [x for s in sams for x in ("--alignment", s)]
+    res = subprocess.run(cmd, env=dict(os.environ, GK_COMM_BACKEND="file", PYTHONPATH=root, GK_THREADS="2"), cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    names = sorted(p.name for p in one.iterdir())
+    assert names == sorted(p.name for p in many.iterdir())
+    n_tsv = 0
+    for n in names:
+        if n.endswith(".tsv") and not n.endswith(".depth.tsv"):
+            assert (one / n).read_text().replace(str(one), "@") == (many / n).read_text().replace(str(many), "@"), n
+            n_tsv += 1
+    assert n_tsv >= 2 + 3 * 16          # the two cohort tables + cn / allele / possible per sample
+    depth_files = sorted(str(p) for p in many.iterdir() if p.name.endswith(".no_multi.depth.tsv"))
+    tables = [pd.read_csv(f, sep="\t", header=None, names=["gene", "pos", "depth"]) for f in depth_files]
+    want = ocn.predictCN(tables, "p75", "LCND", {"base_dev": 0.08, "start_base": 2}, False)[0]
+    merged = pd.read_csv(many / "cohort.cn.tsv", sep="\t", index_col=0)
+    for f, w in zip(depth_files, want):
+        cn_file = f[:-len(".tsv")] + ".p75.cohort.LCND.tsv"
+        assert {g: int(merged[cn_file][g]) for g in merged.index} == {g: int(c) for g, c in w.items()}
+

@@ -38,7 +38,23 @@ __global__ __launch_bounds__(256) void rate(double* out, double c, uint32_t sel)
       BODY8(OP)
 #undef OP
     } else if (kKind == 6) {
-#define OP(x) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r) : "s"(sel));
+#define OP(x) { uint32_t lo = (uint32_t)__double2loint(x); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(lo) : "v"(r)); x = __hiloint2double(__double2hiint(x), (int)lo); }
+      BODY8(OP)
+#undef OP
+    } else if (kKind == 13) {
+#define OP(x) { uint32_t lo = (uint32_t)__double2loint(x); asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(lo) : "v"(r)); x = __hiloint2double(__double2hiint(x), (int)lo); }
+      BODY8(OP)
+#undef OP
+    } else if (kKind == 14) {
+#define OP(x) { uint32_t lo = (uint32_t)__double2loint(x); asm volatile("v_and_b32 %0, %0, %1" : "+v"(lo) : "v"(r)); x = __hiloint2double(__double2hiint(x), (int)lo); }
+      BODY8(OP)
+#undef OP
+    } else if (kKind == 15) {   // VOP2 form: the mask is VCC
+#define OP(x) { uint32_t lo = (uint32_t)__double2loint(x); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(lo) : "v"(r) : "vcc"); x = __hiloint2double(__double2hiint(x), (int)lo); }
+      BODY8(OP)
+#undef OP
+    } else if (kKind == 16) {   // the select-by-mask factor: 2 x v_cndmask_b32 (SGPR-pair mask) + v_mul_f64
+#define OP(x) { uint32_t hi, lo; asm volatile("v_cndmask_b32 %0, %3, %4, %7\n v_cndmask_b32 %1, %5, %6, %7\n v_mul_f64 %2, %2, %[f]" : "=&v"(hi), "=&v"(lo), "+v"(x) : "v"(0x3F50624D), "v"(0x3FEFF7CE), "v"(0xD2F1A9FC), "v"(0xD916872B), "s"((uint64_t)sel * 0x100000001ull), [f] "v"(c)); acc += hi ^ lo; }
       BODY8(OP)
 #undef OP
     } else if (kKind == 7) {   // 32-bit ops on eight independent registers (the low halves of a0..a7)
@@ -63,6 +79,10 @@ __global__ __launch_bounds__(256) void rate(double* out, double c, uint32_t sel)
 #undef OP
     } else if (kKind == 12) {   // the factor of the compatibility kernel: v_bfe_i32 + 2 x v_bfi_b32 + v_mul_f64
 #define OP(x) { int32_t m; uint32_t hi, lo; asm volatile("v_bfe_i32 %0, %4, %5, 1\n v_bfi_b32 %1, %0, %6, %7\n v_bfi_b32 %2, %0, %8, %9\n v_mul_f64 %3, %3, %[f]" : "=&v"(m), "=&v"(hi), "=&v"(lo), "+v"(x) : "v"(r), "v"(sel), "s"(0x3FEFF7CE), "v"(0x3F50624D), "s"(0xD916872B), "v"(0xD2F1A9FC), [f] "v"(c)); acc += hi ^ lo; }
+      BODY8(OP)
+#undef OP
+    } else if (kKind == 17) {   // what the compatibility kernel compiles to: s_xor_b64 vcc + 2 x v_cndmask_b32_e32 (VOP2) + v_mul_f64
+#define OP(x) { uint32_t hi, lo; asm volatile("s_xor_b64 vcc, %7, %8\n v_cndmask_b32_e32 %0, %3, %4, vcc\n v_cndmask_b32_e32 %1, %5, %6, vcc\n v_mul_f64 %2, %2, %[f]" : "=&v"(hi), "=&v"(lo), "+v"(x) : "v"(0x3F50624D), "v"(0x3FEFF7CE), "v"(0xD2F1A9FC), "v"(0xD916872B), "s"((uint64_t)sel * 0x100000001ull), "s"((uint64_t)sel << 7), [f] "v"(c) : "vcc"); acc += hi ^ lo; }
       BODY8(OP)
 #undef OP
     }
@@ -92,7 +112,26 @@ void run(const char* name, int ops_per_body, int waves_per_simd = 8) {
   hipFree(out);
 }
 
+// shader clock under a VALU load: s_memtime ticks (core clock) against the constant 100 MHz wall clock
+__global__ __launch_bounds__(256) void clock_probe(double* out, unsigned long long* ticks) {
+  double a = threadIdx.x;
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
+  for (int i = 0; i < (1 << 18); ++i) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(a));
+  const unsigned long long c1 = clock64(), w1 = wall_clock64();
+  if (threadIdx.x == 0 && blockIdx.x == 0) { ticks[0] = c1 - c0; ticks[1] = w1 - w0; }
+  out[blockIdx.x * 256 + threadIdx.x] = a;
+}
+
 int main() {
+  {
+    double* out; unsigned long long* t; unsigned long long h[2];
+    hipMalloc(&out, 256 * 8 * 256 * sizeof(double)); hipMalloc(&t, 16);
+    clock_probe<<<256 * 8, 256>>>(out, t);
+    hipMemcpy(h, t, 16, hipMemcpyDeviceToHost);
+    printf("shader clock under a full VALU load: %llu s_memtime ticks in %llu wall ticks of 10 ns = %.0f MHz if s_memtime counts core cycles\n",
+           h[0], h[1], (double)h[0] / ((double)h[1] * 10e-9) / 1e6);
+    hipFree(out); hipFree(t);
+  }
   // guide (MI355X_MICROARCH.md, constants table): v_fma_f32 wave64 = 2 cycles on a SIMD-32 with >= 2 waves, 4 for one wave
   // alone; peak FP32 vector 157.3 TFLOP/s = 78.6 T lane-FMAs/s; f64 vector 78.6 TFLOP/s = 39.3 T lane-FMAs/s
   for (int w : {1, 2, 4, 8}) {
@@ -100,13 +139,18 @@ int main() {
     run<1>("v_add_f64", 8, w);
     run<2>("v_fma_f64", 8, w);
     run<4>("v_max_f64", 8, w);
-    run<6>("v_mul_f32", 8, w);
+    run<6>("v_mul_f32 (VOP2)", 8, w);
+    run<13>("v_fma_f32 (VOP3)", 8, w);
+    run<14>("v_and_b32 (VOP2)", 8, w);
+    run<15>("v_cndmask_b32 (VOP2, vcc)", 8, w);
     run<11>("v_add_u32", 8, w);
     run<7>("v_bfi_b32", 8, w);
     run<8>("v_bfe_i32", 8, w);
-    run<9>("v_cndmask_b32", 8, w);
+    run<9>("v_cndmask_b32 (VOP3, sgpr mask)", 8, w);
     run<10>("v_sad_u8", 8, w);
     run<12>("compat factor (bfe+2bfi+mul64)", 32, w);
+    run<16>("select factor (2cndmask_e64+mul64)", 24, w);
+    run<17>("select factor (vcc: 2cndmask_e32+mul64)", 24, w);
   }
   run<3>("v_readlane_b32", 8);
   run<5>("masked v_mul_f64 pair", 16);
