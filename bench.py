@@ -156,7 +156,7 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
     if method == "exonfirst":      # the command line types `--allele-strategy exonfirst` as exonfirst_1 (main.py:186-187)
         method = "exonfirst_1"
     depth = int(os.environ.get("GK_PREFETCH", "1")) if depth is None else depth
-    lanes = int(os.environ.get("GK_SAMPLE_LANES", "1"))   # 2: two samples typed at a time (gain varies from box to box)
+    lanes = int(os.environ.get("GK_SAMPLE_LANES", "2"))   # samples typed at a time, each on a host thread and a stream of its own
     ingest = dev.worker(lanes * hostThreads())   # a context of its own: the typing lanes use workers 0..lanes*n-1
 
     def stage(k):
@@ -381,8 +381,9 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
                 del os.environ["GK_THREADS"]
             else:
                 os.environ["GK_THREADS"] = keep
-    from kir_graph_amd.typing_mulit_allele import SEARCH_STATS
-    return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm,
+    from kir_graph_amd.typing_mulit_allele import SEARCH_STATS, sharedLogTable
+    n_values = sharedLogTable(dev).known()      # distinct probabilities met so far = entries of the log10 value table
+    return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm, "n_values": n_values,
             "search_steps": dict(SEARCH_STATS), "others": others, "cpu_s": cpu_s + sum(o.get("cpu_s", 0.0) for o in others)}
 
 
@@ -445,11 +446,16 @@ def main():
     cores_before = allowed_cores()
     pinned = pin_rank(local_rank, args.cores_per_gpu) if args.cores_per_gpu > 0 else None
     # Worker processes of this rank on its GPU (see worker()): started first, before anything touches HIP.
-    procs = max(1, int(os.environ.get("GK_PROCS_PER_GPU", "4")))
+    # A sample is typed by ONE host thread on one stream (gk_sample_search: all genes in lock-step, ~10 waits), two
+    # samples at a time per process (GK_SAMPLE_LANES) plus the ingest thread; two such processes keep the GPU fed from
+    # two to three host cores (profiles/r03_host_budget.txt).  Waits block instead of spinning: a rank of an 8-GPU node
+    # has about two cores.
+    os.environ.setdefault("GK_WAIT_POLICY", "block")
+    procs = max(1, int(os.environ.get("GK_PROCS_PER_GPU", "2")))
     procs = min(procs, max(1, args.steps))
-    own_threads = procs > 1 and "GK_THREADS" not in os.environ
+    own_threads = procs > 1 and "GK_THREADS" not in os.environ and os.environ.get("GK_SAMPLE_SEARCH") == "0"
     if own_threads:
-        os.environ["GK_THREADS"] = "3"   # gene threads per process: four processes share the host cores (4 x 3 beat 3 x 4 by 4 %)
+        os.environ["GK_THREADS"] = "3"   # per-gene threads (the round-2 path): four processes of three shared the host cores
     gang, helpers = None, []
     if procs > 1:
         import multiprocessing as mp
@@ -538,7 +544,11 @@ def main():
                                    "(H2D inside the timed region)",
                        "pairs_per_sample": args.pairs, "pairs_passing_filter": int(n_valid),
                        "parallelism": f"samples sharded over {world} GPU(s), no data-path collective; "
-                                      f"{procs} worker process(es) per GPU, {os.environ.get('GK_THREADS', '6')} gene threads each",
+                                      f"{procs} worker process(es) per GPU, {os.environ.get('GK_SAMPLE_LANES', '2')} samples in flight "
+                                      "each (one host thread and one stream per sample: gk_sample_search)"
+                                      if os.environ.get("GK_SAMPLE_SEARCH") != "0" else
+                                      f"samples sharded over {world} GPU(s), no data-path collective; {procs} worker "
+                                      f"process(es) per GPU, {os.environ.get('GK_THREADS', '6')} gene threads each",
                        "rank_barrier": (res["comm"].backend if res.get("comm") is not None else None)},
         }
         serial = res.get("serial")
@@ -559,11 +569,12 @@ def main():
         if prof:     # --verbose: launch times inside the timed region (kernels of all workers overlap there)
             out["kernel_ms_per_step"] = {k: v[1] / args.steps for k, v in prof.items()}
         out["search_steps"] = res.get("search_steps")    # worker 0: steps bounded by integers / redone with f64 only
+        out["value_table_entries"] = res.get("n_values")  # worker 0: distinct probabilities = log10 evaluations on the host
         cpu_s = float(res.get("cpu_s", 0.0))
         out["host"] = {"host_core_s_per_step": cpu_s / args.steps, "cores_busy": cpu_s / elapsed if elapsed else None,
                        "cores_per_gpu": args.cores_per_gpu or None, "pinned_to": pinned,
                        "cores_allowed": len(cores_before), "cgroup_quota_cores": cgroup_cores(),
-                       "worker_processes": procs, "gene_threads": int(os.environ.get("GK_THREADS", "6")),
+                       "worker_processes": procs, "sample_lanes": int(os.environ.get("GK_SAMPLE_LANES", "2")),
                        "wait_policy": os.environ.get("GK_WAIT_POLICY", "runtime default"),
                        "note": "user + system time of rank 0's worker processes over the timed region (getrusage); "
                                "a host thread that spins on the GPU counts as busy"}

@@ -273,6 +273,15 @@ int gk_compat_log_miss(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows,
                        int32_t vbeg, int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele,
                        int32_t keep_empty, gk_lut* lut, gk_dptr d_log, gk_dptr d_miss8, int64_t ldm, gk_dptr d_flags);
 int gk_miss_colsum(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int32_t n_cols, gk_dptr d_msum);
+/* The index form of gk_compat_log_miss (typing_mulit_allele.py:263, 340-381): d_lidx uint16 [n_allele][ldm] = dense index
+ * of every log-likelihood in the value table (0xFFFF while a product's log10 is undefined: resolve and call again);
+ * *d_flags bit 1 = the table holds more than 65535 values (use gk_compat_log_miss).  gk_expand_index writes the float64
+ * form d_L double [n_allele][ld] of such a table. */
+int gk_compat_index(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg,
+                    int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty, gk_lut* lut,
+                    gk_dptr d_lidx, gk_dptr d_miss8, int64_t ldm, gk_dptr d_flags);
+int gk_expand_index(gk_ctx* ctx, gk_lut* lut, gk_dptr d_lidx, int64_t ldi, int64_t n_rows, int32_t n_allele, gk_dptr d_L,
+                    int64_t ld);
 int gk_bound_step(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_dptr d_msum, const int32_t* ids,
                   int32_t n_sets, int32_t c_prev, const int32_t* cols, int32_t n_cols, const uint8_t* first,
                   int32_t top_n, int32_t cap, uint32_t* hdr_out, int32_t* idx_out, uint32_t* m_out);
@@ -298,8 +307,9 @@ int gk_search_run(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, int32_t 
  * one wait; then step 2, 3, ... of every gene that has one -- bound, wait, exact sums of the selections, wait, ranking.
  * A sample costs about ten stream synchronisations whatever its number of genes, so one host thread feeds the GPU.
  * A job names the gene's rows (after error correction / empty-read removal: gk_sample_prepare), its variant span and
- * bit rows, and the tables the caller allocated: d_L double [n_allele][n_rows]; optionally d_miss8 u8 [n_allele][ldm],
- * d_msum uint32 [n_allele], d_flags uint32 [1] for the integer bound.  n_steps = copy-number steps to run (1 for a
+ * bit rows, and the tables the caller allocated: d_L double [n_allele][n_rows] -- or d_lidx for the index form
+ * (2 bytes per entry instead of 8: the sums gather the float64 from the value table) --; optionally d_miss8 u8
+ * [n_allele][ldm], d_msum uint32 [n_allele], d_flags uint32 [1] for the integer bound (required with d_lidx).  n_steps = copy-number steps to run (1 for a
  * gene typed as homozygous).  Outputs per job: bound_ok (the integer bound served the gene), passes (how often its table
  * was written: > 1 when the value table met new products), and out[i] = its search (gk_search_*; NULL without rows). */
 typedef struct gk_gene_job {
@@ -311,10 +321,12 @@ typedef struct gk_gene_job {
   int64_t ldm;
   gk_dptr d_msum;
   gk_dptr d_flags;
+  gk_dptr d_lidx; /* uint16 [n_allele][ldm]: the INDEX form of the table (gk_compat_index) -- given with d_L == 0 */
   int32_t vbeg, vend;
   int32_t words, n_allele;
   int32_t n_steps, top_n;
   int32_t bound_ok, passes; /* out */
+  int32_t indexed, rsv;     /* out: d_lidx holds the table (0: the value table outgrew 16-bit indices, the call worked on a float64 table of its own) */
 } gk_gene_job;
 int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_gene_job* jobs, int32_t n_jobs,
                      gk_argsort_fn argsort, gk_log10_fn log10_fn, gk_search** out);

@@ -53,8 +53,10 @@ class GeneJob(C.Structure):
     _fields_ = [
         ("d_rows", C.c_uint64), ("n_rows", C.c_int64), ("d_mask", C.c_uint64), ("d_L", C.c_uint64),
         ("d_miss8", C.c_uint64), ("ldm", C.c_int64), ("d_msum", C.c_uint64), ("d_flags", C.c_uint64),
+        ("d_lidx", C.c_uint64),
         ("vbeg", C.c_int32), ("vend", C.c_int32), ("words", C.c_int32), ("n_allele", C.c_int32),
         ("n_steps", C.c_int32), ("top_n", C.c_int32), ("bound_ok", C.c_int32), ("passes", C.c_int32),
+        ("indexed", C.c_int32), ("rsv", C.c_int32),
     ]
 
 
@@ -168,6 +170,11 @@ _SIGS = {
                                      C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64,
                                      C.c_int64, C.c_uint64]),
     "gk_miss_colsum": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_uint64]),
+    "gk_compat_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_int32, C.c_int32,
+                                  C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64,
+                                  C.c_int64, C.c_uint64]),
+    "gk_expand_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_uint64,
+                                  C.c_int64]),
     "gk_bound_step": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_int32,
                                 C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),

@@ -21,6 +21,14 @@ int gk_bound_enqueue(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, 
 void gk_bound_collect(gk_ctx* ctx, GkBoundCall& call, uint32_t* hdr_out, int32_t* idx_out, uint32_t* m_out);
 
 // ---- gk_search.hip: exact float64 sums with numpy's tree
+// A gene's table of log-likelihoods, column-major [allele][ld]: float64 values (vals == nullptr), or uint16 dense
+// indices into the value table's array `vals` (the index form, gk_compat_index).
+struct GkTable {
+  gk_dptr d = 0;
+  int64_t ld = 0;
+  const double* vals = nullptr;
+  bool indexed() const { return vals != nullptr; }
+};
 struct GkSumCall {
   std::vector<double> back;        // results as fetched (per set: c shares [+ value]; or one sum per column)
   std::vector<void*> temps;
@@ -29,12 +37,14 @@ struct GkSumCall {
   bool with_value = false;
 };
 // value + shares (value_out != nullptr at collect) or shares only of the given sets (gk_setsum / gk_fraction)
-int gk_shares_enqueue(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
+int gk_shares_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32_t* ids, int32_t n_sets, int32_t c,
                       bool with_value, GkSumCall& call);
 void gk_shares_collect(gk_ctx* ctx, GkSumCall& call, double* value_out, double* frac_out);
 // column sums log_probs[:, cols].sum(axis=0) (gk_maxsum with no previous sets)
-int gk_colsum_enqueue(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* cols, int32_t n_cols,
+int gk_colsum_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32_t* cols, int32_t n_cols,
                       GkSumCall& call);
+// the float64 form of an index table (for the exact (max,+) kernel): d_L double [n_allele][ld], queued on the stream
+int gk_expand_table(gk_ctx* ctx, const GkTable& L, int64_t n_rows, int32_t n_allele, gk_dptr d_L, int64_t ld);
 void gk_colsum_collect(gk_ctx* ctx, GkSumCall& call, double* out);
 
 static inline void gk_release(gk_ctx* ctx, std::vector<void*>& temps) {

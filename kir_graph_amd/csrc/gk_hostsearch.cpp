@@ -20,6 +20,7 @@
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
+#include <chrono>
 
 #include "gk_calls.h"
 #include "gk_lut.h"
@@ -208,6 +209,9 @@ int gk_compat_log(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
                   int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty, gk_lut* lut,
                   gk_dptr d_log);
 int gk_miss_colsum(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int32_t n_cols, gk_dptr d_msum);
+int gk_compat_index(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg, int32_t vend,
+                    gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty, gk_lut* lut, gk_dptr d_lidx,
+                    gk_dptr d_miss8, int64_t ldm, gk_dptr d_flags);
 
 }  // extern "C"
 
@@ -221,7 +225,10 @@ namespace {
 // lock-step, so that ONE wait covers the step of every gene (typing_mulit_allele.py:478-598 per gene).
 struct GeneSearch {
   gk_ctx* ctx = nullptr;
-  gk_dptr d_L = 0, d_miss8 = 0, d_msum = 0;
+  GkTable table;                // the gene's log-likelihoods as the sums read them: float64, or indices + value array
+  gk_dptr d_L = 0;              // the float64 form (the exact (max,+) kernel streams it); 0 in index form until needed
+  void* expanded = nullptr;     // pool block behind d_L when this search made it from the index form
+  gk_dptr d_miss8 = 0, d_msum = 0;
   int64_t n_rows = 0, ld = 0, ldm = 0;
   int n_allele = 0, n_steps = 0, T = 0, A = 0;
   std::vector<int32_t> cols;
@@ -237,9 +244,10 @@ struct GeneSearch {
   Step st;
   bool bound_in_flight = false, sums_in_flight = false, step_done = false;
 
-  int init(gk_ctx* c, gk_dptr L, int64_t rows, int64_t ld_, int32_t n_allele_, gk_dptr miss8, int64_t ldm_, gk_dptr msum,
-           const int32_t* cols_, int32_t n_cols, int32_t n_steps_, int32_t top_n, gk_argsort_fn fn) {
-    GK_REQUIRE(c && L && cols_ && fn, "null pointer");
+  int init(gk_ctx* c, const GkTable& tbl, gk_dptr L, int64_t rows, int64_t ld_, int32_t n_allele_, gk_dptr miss8, int64_t ldm_,
+           gk_dptr msum, const int32_t* cols_, int32_t n_cols, int32_t n_steps_, int32_t top_n, gk_argsort_fn fn) {
+    GK_REQUIRE(c && tbl.d && (L || tbl.indexed()) && cols_ && fn, "null pointer");
+    table = tbl;
     GK_REQUIRE(rows > 0 && ld_ >= rows && n_allele_ > 0 && n_cols > 0 && n_steps_ >= 1 && n_steps_ <= 8 && top_n >= 1,
                "bad search arguments");
     for (int a = 0; a < n_cols; ++a) GK_REQUIRE(cols_[a] >= 0 && cols_[a] < n_allele_, "candidate allele out of range");
@@ -259,7 +267,7 @@ struct GeneSearch {
   int colsum_enqueue() {
     std::vector<int32_t> every((size_t)n_allele);
     std::iota(every.begin(), every.end(), 0);
-    int rc = gk_colsum_enqueue(ctx, d_L, n_rows, ld, every.data(), n_allele, scall);
+    int rc = gk_colsum_enqueue(ctx, table, n_rows, every.data(), n_allele, scall);
     if (rc) return rc;
     S->note(0, n_rows, 1, 0, n_allele, 0, 0);
     return GK_OK;
@@ -272,7 +280,15 @@ struct GeneSearch {
     std::vector<double> score((size_t)A);
     for (int a = 0; a < A; ++a) score[a] = colsum[cols[a]];
     std::vector<int64_t> order((size_t)A);
-    GK_REQUIRE(argsort(score.data(), A, order.data()) == 0, "host argsort failed");
+    // numpy.argsort is an unstable sort: its order among EQUAL values is numpy's own, so it is asked (a call back
+    // into the host language, which may have to wait for the interpreter lock) only when equal values exist;
+    // distinct values have one ascending order, whoever sorts them
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return score[x] != score[y] ? score[x] < score[y] : x < y; });
+    bool plain = true;
+    for (int a = 0; a < A && plain; ++a)
+      plain = score[a] == score[a] && (a == 0 || score[order[a - 1]] != score[order[a]]);   // no NaN, no tie
+    if (!plain) GK_REQUIRE(argsort(score.data(), A, order.data()) == 0, "host argsort failed");
     Step s1;
     s1.n = 1;
     const int keep = std::min(T, A);
@@ -335,7 +351,7 @@ struct GeneSearch {
       std::copy(prev.ids.begin() + (size_t)t * k, prev.ids.begin() + (size_t)(t + 1) * k, sel.ids.begin() + (size_t)i * c);
       sel.ids[(size_t)i * c + k] = cols[a];
     }
-    int rc = gk_shares_enqueue(ctx, d_L, n_rows, ld, sel.ids.data(), (int32_t)n_sel, c, true, scall);
+    int rc = gk_shares_enqueue(ctx, table, n_rows, sel.ids.data(), (int32_t)n_sel, c, true, scall);
     if (rc) return rc;
     S->note(2, n_rows, n_sel, c, S->distinct(sel.ids.data(), sel.ids.size()), 0, 0);
     sums_in_flight = true;
@@ -410,8 +426,16 @@ struct GeneSearch {
     const double* colsum = S->colsum.data();
     const int k = prev.n, c = k + 1;
     const int Tp = (int)prev.rows();
-    std::vector<double> table((size_t)Tp * A);
-    int rc = gk_maxsum(ctx, d_L, n_rows, ld, prev.ids.data(), Tp, k, cols.data(), A, table.data());
+    int rc = GK_OK;
+    if (!d_L) {     // index form: the (max,+) kernel streams float64 operands -- make them once for this gene
+      GK_HIP(gk_pool_malloc(ctx, &expanded, (size_t)n_allele * (size_t)n_rows * sizeof(double)));
+      rc = gk_expand_table(ctx, table, n_rows, n_allele, gk_addr(expanded), n_rows);
+      if (rc) return rc;
+      d_L = gk_addr(expanded);
+      ld = n_rows;
+    }
+    std::vector<double> scores((size_t)Tp * A);
+    rc = gk_maxsum(ctx, d_L, n_rows, ld, prev.ids.data(), Tp, k, cols.data(), A, scores.data());
     if (rc) return rc;
     {
       const int64_t d_prev = S->distinct(prev.ids.data(), prev.ids.size());
@@ -423,7 +447,7 @@ struct GeneSearch {
     where.reserve((size_t)N);
     score.reserve((size_t)N);
     for (int64_t i = 0; i < (int64_t)first.size(); ++i)
-      if (first[i]) { where.push_back(i); score.push_back(table[i]); }
+      if (first[i]) { where.push_back(i); score.push_back(scores[i]); }
     const int64_t n_keep = std::max<int64_t>(T, N / 5);
     std::vector<int64_t> order((size_t)N);
     if (N) GK_REQUIRE(argsort(score.data(), N, order.data()) == 0, "host argsort failed");
@@ -483,6 +507,11 @@ struct GeneSearch {
   void abandon() {
     gk_release(ctx, bcall.temps);
     gk_release(ctx, scall.temps);
+    finish();
+  }
+  // the float64 copy this search made for itself (every kernel that reads it has been waited for)
+  void finish() {
+    if (expanded) { gk_pool_free(ctx, expanded); expanded = nullptr; d_L = 0; }
   }
 };
 
@@ -504,7 +533,8 @@ int gk_search_run(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, int32_t 
   gk_bind(ctx);
   GK_REQUIRE(out, "null pointer");
   GeneSearch g;
-  int rc = g.init(ctx, d_L, n_rows, ld, n_allele, d_miss8, ldm, d_msum, cols, n_cols, n_steps, top_n, argsort);
+  int rc = g.init(ctx, GkTable{d_L, ld, nullptr}, d_L, n_rows, ld, n_allele, d_miss8, ldm, d_msum, cols, n_cols, n_steps, top_n,
+                  argsort);
   if (rc) return rc;
   if (colsum_in) {
     std::copy(colsum_in, colsum_in + n_allele, g.S->colsum.begin());
@@ -529,6 +559,7 @@ int gk_search_run(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, int32_t 
     if (rc == GK_OK) g.step_end();
   }
   if (rc) { g.abandon(); return rc; }
+  g.finish();
   *out = g.S.release();
   return GK_OK;
 }
@@ -549,15 +580,35 @@ int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_
     gk_gene_job& j = jobs[i];
     j.bound_ok = 0;
     j.passes = 0;
+    j.indexed = 0;
     GK_REQUIRE(j.n_rows >= 0 && j.n_allele >= 0 && j.n_steps >= 1 && j.top_n >= 1, "bad gene job");
     if (j.n_rows > 0 && j.n_allele > 0) {
-      GK_REQUIRE(j.d_rows && j.d_L && j.d_mask && j.words >= 1, "gene job without tables");
+      GK_REQUIRE(j.d_rows && (j.d_L || j.d_lidx) && j.d_mask && j.words >= 1, "gene job without tables");
       GK_REQUIRE(!j.d_miss8 || (j.d_msum && j.d_flags && j.ldm >= j.n_rows && j.ldm % 64 == 0), "bad mismatch table");
+      GK_REQUIRE(!j.d_lidx || j.d_miss8, "the index form comes with the mismatch table (same stride)");
       live.push_back(i);
     }
   }
   if (live.empty()) return GK_OK;
   int rc = GK_OK;
+  // GK_SEARCH_TIMING=1: where the calling thread spends the call (host work between the waits / the waits themselves)
+  static const bool timing = getenv("GK_SEARCH_TIMING") != nullptr;
+  using clk = std::chrono::steady_clock;
+  double t_host = 0, t_wait = 0;
+  int n_wait = 0;
+  auto t_mark = clk::now();
+  auto lap = [&](bool waited) {
+    if (!timing) return;
+    const auto now = clk::now();
+    const double ms = std::chrono::duration<double, std::milli>(now - t_mark).count();
+    (waited ? t_wait : t_host) += ms;
+    n_wait += waited ? 1 : 0;
+    t_mark = now;
+  };
+  struct Report {
+    const bool on; double& h; double& w; int& n; int jobs;
+    ~Report() { if (on) fprintf(stderr, "[gk_sample_search] %d genes: host %.2f ms, waits %.2f ms in %d waits\n", jobs, h, w, n); }
+  } report{timing, t_host, t_wait, n_wait, (int)live.size()};
   // ---- phase 0: the compatibility tables (log-likelihoods through the value table + mismatch counts)
   std::vector<uint32_t> flags((size_t)n_jobs, 0);
   for (int pass = 0; pass < 64; ++pass) {
@@ -567,7 +618,12 @@ int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_
     for (int i : live) {
       gk_gene_job& j = jobs[i];
       j.passes++;
-      if (j.d_miss8) {
+      if (j.d_lidx && !j.d_L) {
+        rc = gk_compat_index(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
+                             j.d_lidx, j.d_miss8, j.ldm, j.d_flags);
+        if (rc == GK_OK) rc = gk_miss_colsum(ctx, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
+        if (rc == GK_OK && gk_fetch_queue(ctx, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
+      } else if (j.d_miss8) {
         rc = gk_compat_log_miss(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
                                 j.d_L, j.d_miss8, j.ldm, j.d_flags);
         if (rc == GK_OK) rc = gk_miss_colsum(ctx, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
@@ -577,7 +633,7 @@ int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_
       }
       if (rc) return rc;
     }
-    rc = wait_stream(ctx);          // every key these kernels claimed is stored
+    lap(false); rc = wait_stream(ctx); lap(true);          // every key these kernels claimed is stored
     if (rc) return rc;
     int32_t n_new = 0, n_known = 0, n_undefined = 0;
     rc = gk_lut_resolve(lut, log10_fn, &n_new, &n_known, &n_undefined);
@@ -587,23 +643,46 @@ int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_
     if (pass == 63) { gk_set_error("log10 value table did not settle"); return GK_ERR_ASSERT; }
   }
   std::vector<std::unique_ptr<GeneSearch>> gs((size_t)n_jobs);
+  // a gene whose indices do not fit 16 bits (the value table holds more than 65535 values) takes the float64 form, in a
+  // block of this call's own; every value is defined by now, so one pass writes it
+  std::vector<void*> own_L((size_t)n_jobs, nullptr);
   auto fail = [&](int code) {
     for (auto& g : gs) if (g) g->abandon();
+    for (void* p : own_L) gk_pool_free(ctx, p);
     return code;
   };
+  for (int i : live) {
+    gk_gene_job& j = jobs[i];
+    j.indexed = (j.d_lidx && !j.d_L && !(flags[i] & 2u)) ? 1 : 0;
+    if (j.d_lidx && !j.d_L && !j.indexed) {
+      if (gk_pool_malloc(ctx, &own_L[i], (size_t)j.n_allele * (size_t)j.n_rows * sizeof(double)) != hipSuccess) {
+        gk_set_error("out of device memory for the float64 table of a gene");
+        return fail(GK_ERR_HIP);
+      }
+      rc = gk_compat_log_miss(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
+                              gk_addr(own_L[i]), j.d_miss8, j.ldm, j.d_flags);
+      if (rc == GK_OK) rc = gk_miss_colsum(ctx, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
+      if (rc == GK_OK && gk_fetch_queue(ctx, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
+      if (rc == GK_OK) rc = wait_stream(ctx);
+      if (rc) return fail(rc);
+      j.passes++;
+    }
+  }
   // ---- phase 1: column sums of every gene, first step
   for (int i : live) {
     gk_gene_job& j = jobs[i];
-    j.bound_ok = (j.d_miss8 && flags[i] == 0) ? 1 : 0;
+    j.bound_ok = (j.d_miss8 && (flags[i] & 1u) == 0) ? 1 : 0;
     std::vector<int32_t> cols((size_t)j.n_allele);
     std::iota(cols.begin(), cols.end(), 0);
     gs[i].reset(new GeneSearch());
-    rc = gs[i]->init(ctx, j.d_L, j.n_rows, j.n_rows, j.n_allele, j.bound_ok ? j.d_miss8 : 0, j.ldm, j.bound_ok ? j.d_msum : 0,
-                     cols.data(), j.n_allele, j.n_steps, j.top_n, argsort);
+    const gk_dptr d_L = own_L[i] ? gk_addr(own_L[i]) : j.d_L;
+    const GkTable tbl = j.indexed ? GkTable{j.d_lidx, j.ldm, lut->d_vals} : GkTable{d_L, j.n_rows, nullptr};
+    rc = gs[i]->init(ctx, tbl, j.indexed ? 0 : d_L, j.n_rows, j.n_rows, j.n_allele, j.bound_ok ? j.d_miss8 : 0, j.ldm,
+                     j.bound_ok ? j.d_msum : 0, cols.data(), j.n_allele, j.n_steps, j.top_n, argsort);
     if (rc == GK_OK) rc = gs[i]->colsum_enqueue();
     if (rc) return fail(rc);
   }
-  rc = wait_stream(ctx);
+  lap(false); rc = wait_stream(ctx); lap(true);
   if (rc) return fail(rc);
   for (int i : live) {
     gs[i]->colsum_collect();
@@ -616,10 +695,10 @@ int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_
     for (int i : live) if (gs[i]->more()) todo.push_back(i);
     if (todo.empty()) break;
     for (int i : todo) { rc = gs[i]->step_begin(); if (rc) return fail(rc); }
-    rc = wait_stream(ctx);
+    lap(false); rc = wait_stream(ctx); lap(true);
     if (rc) return fail(rc);
     for (int i : todo) { rc = gs[i]->after_bound(); if (rc) return fail(rc); }
-    rc = wait_stream(ctx);
+    lap(false); rc = wait_stream(ctx); lap(true);
     if (rc) return fail(rc);
     for (int i : todo) { rc = gs[i]->after_sums(); if (rc) return fail(rc); }
     for (int i : todo) {
@@ -627,7 +706,12 @@ int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_
       gs[i]->step_end();
     }
   }
-  for (int i : live) out[i] = gs[i]->S.release();
+  for (int i : live) {
+    gs[i]->finish();
+    out[i] = gs[i]->S.release();
+  }
+  for (void* p : own_L) gk_pool_free(ctx, p);
+  lap(false);
   return GK_OK;
 }
 

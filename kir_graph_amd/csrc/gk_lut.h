@@ -12,6 +12,9 @@ struct gk_lut {
   double* d_vals = nullptr;        // dense index -> log10 (defined for index < n_known)
   double* d_slot_val = nullptr;    // slot -> log10 once defined (kLutEmptyKey's bit pattern until then): lets the
                                    // fused lookup load key and value side by side instead of key -> index -> value
+  uint64_t* d_slot_info = nullptr; // slot -> dense index (bits 0-31) | mismatch count of the value, capped at 255
+                                   // (bits 32-39) once defined, kLutNoInfo until then: what the index form of the
+                                   // table (u16 / u32 per entry instead of the float64) stores
   uint32_t* d_count = nullptr;     // number of dense entries
   int32_t n_known = 0;             // entries with a defined value
   int32_t n_undefined = 0;         // entries the last gk_lut_resolve saw claimed but not stored yet
@@ -20,6 +23,15 @@ struct gk_lut {
 
 // a NaN payload no product of 0.999 / 0.001 can produce
 constexpr uint64_t kLutEmptyKey = 0x7FF8DEADBEEF0001ull;
+constexpr uint64_t kLutNoInfo = ~0ull;
+
+// mismatch count of a (read, allele) entry read back from its log-likelihood: -L = 3 m + 0.000434 (n - m), so
+// m = floor(-L / 3 + 1/4) for any list shorter than ~5000 ids; 255 when the count is >= 100 or L is not finite
+// (the product is about to leave the normal range / underflowed: such a gene takes the exact search)
+__host__ __device__ inline uint32_t gk_miss_of_log(double v) {
+  const double t = v * (-1.0 / 3.0) + 0.25;
+  return (t < 100.0) ? (uint32_t)(int)t : 255u;     // NaN / inf compare false
+}
 
 struct LutView {
   uint64_t* keys;
@@ -28,12 +40,13 @@ struct LutView {
   uint32_t* count;
   const double* vals;
   const double* slot_val;
+  const uint64_t* slot_info;
   uint32_t mask;
   uint32_t n_known;
 };
 
 static inline LutView gk_lut_view(const gk_lut* l) {
-  return LutView{l->d_keys, l->d_slot_idx, l->d_list, l->d_count, l->d_vals, l->d_slot_val,
+  return LutView{l->d_keys, l->d_slot_idx, l->d_list, l->d_count, l->d_vals, l->d_slot_val, l->d_slot_info,
                  (uint32_t)((1ull << l->log2cap) - 1), (uint32_t)l->n_known};
 }
 
@@ -84,3 +97,17 @@ __device__ inline double gk_lut_lookup(const LutView& t, uint64_t k, bool* found
   *found = false;
   return __longlong_as_double(0x7FF8000000000000ll);
 }
+
+// (dense index | mismatch count << 32) of `k` if its log is already defined; kLutNoInfo otherwise
+__device__ inline uint64_t gk_lut_info(const LutView& t, uint64_t k) {
+  uint32_t s = gk_hash64(k) & t.mask;
+  for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+    const uint64_t cur = t.keys[s];
+    const uint64_t info = t.slot_info[s];
+    if (cur == k) return info;
+    if (cur == kLutEmptyKey) break;
+    s = (s + 1) & t.mask;
+  }
+  return kLutNoInfo;
+}
+

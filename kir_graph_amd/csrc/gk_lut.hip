@@ -62,14 +62,19 @@ __global__ __launch_bounds__(kThreads) void lut_apply(const uint64_t* in, double
 // values [first, first + count) of the dense list have just been defined: store each next to its key
 __global__ __launch_bounds__(kThreads) void lut_publish(const uint64_t* list, const double* vals, uint32_t first,
                                                         uint32_t count, const uint64_t* keys, double* slot_val,
-                                                        uint32_t mask) {
+                                                        uint64_t* slot_info, uint32_t mask) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= count) return;
   const uint64_t k = list[first + i];
   uint32_t s = hash64(k) & mask;
   for (uint32_t probe = 0; probe <= mask; ++probe) {
     const uint64_t cur = keys[s];
-    if (cur == k) { slot_val[s] = vals[first + i]; return; }
+    if (cur == k) {
+      const double v = vals[first + i];
+      slot_val[s] = v;
+      slot_info[s] = (uint64_t)(first + i) | ((uint64_t)gk_miss_of_log(v) << 32);
+      return;
+    }
     if (cur == kEmptyKey) return;
     s = (s + 1) & mask;
   }
@@ -95,6 +100,8 @@ int gk_lut_create(gk_ctx* ctx, int32_t log2_capacity, gk_lut** out) {
   GK_HIP(hipMalloc((void**)&l->d_list, cap * sizeof(uint64_t)));
   GK_HIP(hipMalloc((void**)&l->d_vals, cap * sizeof(double)));
   GK_HIP(hipMalloc((void**)&l->d_slot_val, cap * sizeof(double)));
+  GK_HIP(hipMalloc((void**)&l->d_slot_info, cap * sizeof(uint64_t)));
+  GK_HIP(hipMemsetAsync(l->d_slot_info, 0xFF, cap * sizeof(uint64_t), ctx->stream));   // kLutNoInfo
   GK_HIP(hipMalloc((void**)&l->d_count, sizeof(uint32_t)));
   GK_HIP(hipMemsetAsync(l->d_count, 0, sizeof(uint32_t), ctx->stream));
   GK_KERNEL(fill_keys, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, l->d_keys, (uint64_t)cap);
@@ -113,7 +120,7 @@ int gk_lut_destroy(gk_lut* l) {
   gk_bind(l ? l->ctx : nullptr);
   if (!l) return GK_OK;
   hipStreamSynchronize(l->ctx->stream);
-  hipFree(l->d_keys); hipFree(l->d_slot_idx); hipFree(l->d_list); hipFree(l->d_vals); hipFree(l->d_slot_val);
+  hipFree(l->d_keys); hipFree(l->d_slot_idx); hipFree(l->d_list); hipFree(l->d_vals); hipFree(l->d_slot_val); hipFree(l->d_slot_info);
   hipFree(l->d_count);
   delete l;
   return GK_OK;
@@ -165,7 +172,8 @@ int gk_lut_define(gk_lut* l, int32_t first, int32_t count, const double* log_val
   if (!count) return GK_OK;
   GK_HIP(gk_send(l->ctx, l->d_vals + first, log_vals, (size_t)count * sizeof(double)));
   GK_KERNEL(lut_publish, dim3((unsigned)((count + kThreads - 1) / kThreads)), dim3(kThreads), 0, l->ctx->stream, l->d_list,
-            l->d_vals, (uint32_t)first, (uint32_t)count, l->d_keys, l->d_slot_val, (uint32_t)((1ull << l->log2cap) - 1));
+            l->d_vals, (uint32_t)first, (uint32_t)count, l->d_keys, l->d_slot_val, l->d_slot_info,
+            (uint32_t)((1ull << l->log2cap) - 1));
   GK_HIP(hipGetLastError());
   GK_HIP(hipStreamSynchronize(l->ctx->stream));
   l->n_known = first + count;

@@ -27,6 +27,7 @@
 #include <algorithm>
 
 #include "gk_calls.h"
+#include "gk_lut.h"
 
 namespace {
 
@@ -59,6 +60,21 @@ __device__ inline double vmax(double a, double b) {
   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // fmax() would add two canonicalising v_max
   return r;
 }
+
+// A table of log-likelihoods is either the float64 values themselves or, in the index form, uint16 dense indices into
+// the value table's array (gk_lut: `vals`): the reductions below read an entry through this view -- the same float64
+// either way, so the same sums bit for bit.
+template <typename TL> struct TableView;
+template <> struct TableView<double> {
+  const double* base;
+  const double* vals;   // unused
+  __device__ inline double at(int64_t i) const { return base[i]; }
+};
+template <> struct TableView<uint16_t> {
+  const uint16_t* base;
+  const double* vals;
+  __device__ inline double at(int64_t i) const { return vals[base[i]]; }
+};
 
 // cross-lane move inside a 16-lane row as two v_mov_b32_dpp (no LDS round trip like ds_bpermute)
 constexpr int kDppSwap1 = 0xB1;        // quad_perm:[1,0,3,2]  lane ^ 1
@@ -366,8 +382,8 @@ constexpr int kFracLd = kFracRows + 9;    // + up to 7 tail rows of the leaf, od
 
 // kValue: the set's likelihood sum_r max_j L[r, ids[k][j]] (typing_mulit_allele.py:540-542 for ONE set) rides along as
 // one more accumulator -- same terms, same tree, hence the bits of maxsum_chunks -- and is stored after the shares.
-template <int kC, bool kValue>
-__global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __restrict__ L, int64_t ld,
+template <int kC, bool kValue, typename TL>
+__global__ __launch_bounds__(kThreads) void fraction_chunks(TableView<TL> L, int64_t ld,
                                                             const int32_t* __restrict__ tile_col_off,
                                                             const int32_t* __restrict__ tile_cols,
                                                             const int32_t* __restrict__ local_idx,
@@ -427,12 +443,12 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
       __syncthreads();
       for (int idx = tid; idx < n_dist * kFracRows; idx += kThreads) {
         const int col = idx >> 5, r = idx & (kFracRows - 1);
-        if (r < rows_in) fbuf[col * kFracLd + r] = L[(int64_t)cols[col] * ld + r0 + b0 + r];
+        if (r < rows_in) fbuf[col * kFracLd + r] = L.at((int64_t)cols[col] * ld + r0 + b0 + r);
       }
       if (last) {   // sequential tail rows n8 .. len (all rows of a leaf shorter than 8)
         for (int idx = tid; idx < n_dist * 8; idx += kThreads) {
           const int col = idx >> 3, r = n8 + (idx & 7);
-          if (r < len) fbuf[col * kFracLd + kFracRows + (idx & 7)] = L[(int64_t)cols[col] * ld + r0 + r];
+          if (r < len) fbuf[col * kFracLd + kFracRows + (idx & 7)] = L.at((int64_t)cols[col] * ld + r0 + r);
         }
       }
       __syncthreads();
@@ -483,7 +499,8 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(const double* __rest
 // case through the (max,+) kernel with one live set per 32 x 32 tile at two workgroups per CU.)
 constexpr int kColsPerGroup = kThreads / 8;
 
-__global__ __launch_bounds__(kThreads) void colsum_chunks(const double* __restrict__ L, int64_t ld,
+template <typename TL>
+__global__ __launch_bounds__(kThreads) void colsum_chunks(TableView<TL> L, int64_t ld,
                                                           const int32_t* __restrict__ cols, int n_cols,
                                                           const Span* __restrict__ spans,
                                                           const Leaf* __restrict__ leaves, double* __restrict__ partial) {
@@ -491,25 +508,25 @@ __global__ __launch_bounds__(kThreads) void colsum_chunks(const double* __restri
   const int c = blockIdx.x * kColsPerGroup + (tid >> 3);
   const bool live = c < n_cols;
   const Span span = spans[blockIdx.y];
-  const double* col = L + (int64_t)cols[live ? c : 0] * ld + span.row0;
+  const int64_t col = (int64_t)cols[live ? c : 0] * ld + span.row0;
   double st = 0.0, hold = 0.0;
   for (int li = span.leaf_begin; li < span.leaf_end; ++li) {
     const Leaf cur = leaves[li];
-    const double* a = col + cur.start;
+    const int64_t a = col + cur.start;
     const int len = cur.len;
     const int n8 = len < 8 ? 0 : len - (len & 7);
     double acc = 0.0;
     if (n8) {
       double v[kBlockRows / 8];
 #pragma unroll
-      for (int q = 0; q < kBlockRows / 8; ++q) v[q] = 8 * q < n8 ? a[8 * q + j] : 0.0;   // all loads of the leaf in flight
+      for (int q = 0; q < kBlockRows / 8; ++q) v[q] = 8 * q < n8 ? L.at(a + 8 * q + j) : 0.0;   // all loads of the leaf in flight
       acc = v[0];
 #pragma unroll
       for (int q = 1; q < kBlockRows / 8; ++q)
         if (8 * q < n8) acc += v[q];                     // r[j] += a[i + j], in row order
       acc = group_sum8(acc);                             // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
     }
-    for (int r = n8; r < len; ++r) acc += a[r];           // sequential tail (the whole leaf when shorter than 8)
+    for (int r = n8; r < len; ++r) acc += L.at(a + r);     // sequential tail (the whole leaf when shorter than 8)
     st = (j == cur.slot) ? acc : st;
     const int n_fold = cur.n_add & 0xFF;
     for (int f = 0; f < n_fold; ++f) {
@@ -532,6 +549,14 @@ __global__ __launch_bounds__(kThreads) void setmax_kernel(const double* __restri
     for (int k = 0; k < c; ++k) v = vmax(v, L[(int64_t)ids[t * c + k] * ld + r]);
     P[(int64_t)t * ld + r] = v;
   }
+}
+
+// index form -> float64 form of a table (for the exact (max,+) kernel, which streams float64 operands)
+__global__ __launch_bounds__(kThreads) void expand_index(const uint16_t* __restrict__ lidx, int64_t ldi, int64_t n_rows,
+                                                         const double* __restrict__ vals, double* __restrict__ L, int64_t ld) {
+  const int a = blockIdx.y;
+  for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * kThreads)
+    L[(int64_t)a * ld + r] = vals[lidx[(int64_t)a * ldi + r]];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -744,8 +769,9 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
                                dp.leaves, tiles_t * tiles_a, symmetric ? 1 : 0, d_partial));
   } else if (n_sets == 1) {
     GK_PROF_EXACT(ctx, GK_K_MAXSUM,
-            GK_KERNEL(colsum_chunks, dim3((unsigned)((n_cols + kColsPerGroup - 1) / kColsPerGroup), (unsigned)dp.n_spans),
-                      dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld, dp.cols, n_cols, dp.spans, dp.leaves, d_partial));
+            GK_KERNEL(colsum_chunks<double>, dim3((unsigned)((n_cols + kColsPerGroup - 1) / kColsPerGroup), (unsigned)dp.n_spans),
+                      dim3(kThreads), 0, st, TableView<double>{gk_ptr<double>(d_L), nullptr}, ld, dp.cols, n_cols, dp.spans,
+                      dp.leaves, d_partial));
   } else {
     GK_PROF_EXACT(ctx, GK_K_MAXSUM,
             GK_KERNEL(maxsum_chunks<false>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
@@ -779,7 +805,7 @@ int gk_fraction(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int3
   gk_bind(ctx);
   GK_REQUIRE(frac_out, "null output");
   GkSumCall call;
-  int rc = gk_shares_enqueue(ctx, d_L, n_rows, ld, ids, n_sets, c, false, call);
+  int rc = gk_shares_enqueue(ctx, GkTable{d_L, ld, nullptr}, n_rows, ids, n_sets, c, false, call);
   if (rc == GK_OK && gk_fetch_wait(ctx) != hipSuccess) { gk_set_error("set shares: waiting for the stream failed"); rc = GK_ERR_HIP; }
   if (rc == GK_OK) gk_shares_collect(ctx, call, nullptr, frac_out);
   else gk_release(ctx, call.temps);
@@ -791,7 +817,7 @@ int gk_setsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   gk_bind(ctx);
   GK_REQUIRE(value_out && frac_out, "null output");
   GkSumCall call;
-  int rc = gk_shares_enqueue(ctx, d_L, n_rows, ld, ids, n_sets, c, true, call);
+  int rc = gk_shares_enqueue(ctx, GkTable{d_L, ld, nullptr}, n_rows, ids, n_sets, c, true, call);
   if (rc == GK_OK && gk_fetch_wait(ctx) != hipSuccess) { gk_set_error("set sums: waiting for the stream failed"); rc = GK_ERR_HIP; }
   if (rc == GK_OK) gk_shares_collect(ctx, call, value_out, frac_out);
   else gk_release(ctx, call.temps);
@@ -821,10 +847,11 @@ int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
 
 // ---------------------------------------------------------------------------------------------
 // the two halves of the set-share / column-sum calls (gk_calls.h)
-int gk_shares_enqueue(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
+int gk_shares_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32_t* ids, int32_t n_sets, int32_t c,
                       bool with_value, GkSumCall& call) {
   gk_bind(ctx);
-  GK_REQUIRE(ctx && ids && n_rows > 0 && ld >= n_rows && n_sets > 0, "bad fraction arguments");
+  const int64_t ld = L.ld;
+  GK_REQUIRE(ctx && L.d && ids && n_rows > 0 && ld >= n_rows && n_sets > 0, "bad fraction arguments");
   GK_REQUIRE(c >= 1 && c <= kMaxC, "copy number beyond supported set size");
   // Order the sets so that tiles of 32 share columns: the best sets pair a few strong alleles with
   // many partners, so sort by each set's ids taken rarest-first (partners adjacent, hubs shared).
@@ -890,12 +917,18 @@ int gk_shares_enqueue(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, cons
   call.temps.push_back(d_out);
   const dim3 grid((unsigned)n_tiles, (unsigned)dp.n_spans);
   const size_t lds = (size_t)max_dist * kFracLd * sizeof(double);   // <= 256 columns * 41 * 8 = 84 KB
-#define GK_FRAC_LAUNCH_V(C, V)                                                                                       \
-  if (lds > 48 * 1024)                                                                                               \
-    GK_HIP(hipFuncSetAttribute((const void*)fraction_chunks<C, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-  GK_PROF(ctx, GK_K_FRACTION,                                                                                        \
-          GK_KERNEL((fraction_chunks<C, V>), grid, dim3(kThreads), lds, st, gk_ptr<double>(d_L), ld, dp.ids,     \
-                             dp.ids + o_cols, dp.ids + o_local, dp.ids + o_perm, n_sets, dp.spans, dp.leaves, d_partial))
+#define GK_FRAC_GO(C, V, TL, VIEW)                                                                                   \
+  {                                                                                                                  \
+    if (lds > 48 * 1024)                                                                                             \
+      GK_HIP(hipFuncSetAttribute((const void*)fraction_chunks<C, V, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)lds));                                                                         \
+    GK_PROF(ctx, GK_K_FRACTION,                                                                                      \
+            GK_KERNEL((fraction_chunks<C, V, TL>), grid, dim3(kThreads), lds, st, VIEW, ld, dp.ids, dp.ids + o_cols, \
+                      dp.ids + o_local, dp.ids + o_perm, n_sets, dp.spans, dp.leaves, d_partial));                   \
+  }
+#define GK_FRAC_LAUNCH_V(C, V)                                                                          \
+  if (L.indexed()) GK_FRAC_GO(C, V, uint16_t, (TableView<uint16_t>{gk_ptr<uint16_t>(L.d), L.vals}))     \
+  else GK_FRAC_GO(C, V, double, (TableView<double>{gk_ptr<double>(L.d), nullptr}))
 #define GK_FRAC_LAUNCH(C)                 \
   if (with_value) { GK_FRAC_LAUNCH_V(C, true); } \
   else { GK_FRAC_LAUNCH_V(C, false); }
@@ -911,6 +944,7 @@ int gk_shares_enqueue(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, cons
   }
 #undef GK_FRAC_LAUNCH
 #undef GK_FRAC_LAUNCH_V
+#undef GK_FRAC_GO
   // with the value riding along the sums are handed back undivided (collect divides the shares by n_rows)
   GK_PROF(ctx, GK_K_COMBINE,
           GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st,
@@ -943,10 +977,11 @@ void gk_shares_collect(gk_ctx* ctx, GkSumCall& call, double* value_out, double* 
   gk_release(ctx, call.temps);
 }
 
-int gk_colsum_enqueue(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* cols, int32_t n_cols,
+int gk_colsum_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32_t* cols, int32_t n_cols,
                       GkSumCall& call) {
   gk_bind(ctx);
-  GK_REQUIRE(ctx && cols && n_rows > 0 && ld >= n_rows && n_cols > 0, "bad column-sum arguments");
+  const int64_t ld = L.ld;
+  GK_REQUIRE(ctx && L.d && cols && n_rows > 0 && ld >= n_rows && n_cols > 0, "bad column-sum arguments");
   DeviceProgram dp;
   int rc = upload_program(ctx, n_rows, nullptr, 0, cols, (size_t)n_cols, dp);
   if (rc) return rc;
@@ -957,9 +992,17 @@ int gk_colsum_enqueue(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, cons
   call.temps.push_back(d_partial);
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_cols * sizeof(double)));
   call.temps.push_back(d_out);
-  GK_PROF_EXACT(ctx, GK_K_MAXSUM,
-          GK_KERNEL(colsum_chunks, dim3((unsigned)((n_cols + kColsPerGroup - 1) / kColsPerGroup), (unsigned)dp.n_spans),
-                    dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld, dp.cols, n_cols, dp.spans, dp.leaves, d_partial));
+  const dim3 cgrid((unsigned)((n_cols + kColsPerGroup - 1) / kColsPerGroup), (unsigned)dp.n_spans);
+  if (L.indexed())
+    GK_PROF_EXACT(ctx, GK_K_MAXSUM,
+                  GK_KERNEL(colsum_chunks<uint16_t>, cgrid, dim3(kThreads), 0, st,
+                            TableView<uint16_t>{gk_ptr<uint16_t>(L.d), L.vals}, ld, dp.cols, n_cols, dp.spans, dp.leaves,
+                            d_partial));
+  else
+    GK_PROF_EXACT(ctx, GK_K_MAXSUM,
+                  GK_KERNEL(colsum_chunks<double>, cgrid, dim3(kThreads), 0, st,
+                            TableView<double>{gk_ptr<double>(L.d), nullptr}, ld, dp.cols, n_cols, dp.spans, dp.leaves,
+                            d_partial));
   GK_PROF(ctx, GK_K_COMBINE,
           GK_KERNEL(combine_chunks, dim3((unsigned)((n_cols + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st,
                              d_partial, (int64_t)n_cols, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, 0.0, d_out));
@@ -975,3 +1018,21 @@ void gk_colsum_collect(gk_ctx* ctx, GkSumCall& call, double* out) {
   if (out) std::copy(call.back.begin(), call.back.end(), out);
   gk_release(ctx, call.temps);
 }
+
+int gk_expand_table(gk_ctx* ctx, const GkTable& L, int64_t n_rows, int32_t n_allele, gk_dptr d_L, int64_t ld) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && L.d && L.indexed() && d_L && n_rows > 0 && n_allele > 0 && ld >= n_rows && L.ld >= n_rows,
+             "bad table expansion");
+  int64_t want = (n_rows + kThreads - 1) / kThreads;
+  GK_KERNEL(expand_index, dim3((unsigned)(want < 256 ? want : 256), (unsigned)n_allele), dim3(kThreads), 0, ctx->stream,
+            gk_ptr<uint16_t>(L.d), L.ld, n_rows, L.vals, gk_ptr<double>(d_L), ld);
+  GK_HIP(hipGetLastError());
+  return GK_OK;
+}
+
+extern "C" int gk_expand_index(gk_ctx* ctx, gk_lut* lut, gk_dptr d_lidx, int64_t ldi, int64_t n_rows, int32_t n_allele,
+                               gk_dptr d_L, int64_t ld) {
+  GK_REQUIRE(lut, "null value table");
+  return gk_expand_table(ctx, GkTable{d_lidx, ldi, lut->d_vals}, n_rows, n_allele, d_L, ld);
+}
+

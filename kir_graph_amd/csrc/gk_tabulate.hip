@@ -158,7 +158,7 @@ __device__ inline uint32_t hash64(uint64_t k) {
 
 struct NovelTable {
   uint64_t* keys;   // kEmpty when free
-  uint32_t* seq;    // min (mate * kMaxEv + event) over insertions
+  uint64_t* seq;    // min (mate << 16 | event) over insertions: the first appearance in read order
   uint32_t* rank;   // first-appearance rank (filled by rank kernel)
   uint32_t mask;
   int* flags;       // bit 3 is raised when a key finds no slot within kNovelProbes: the host retries with a larger table
@@ -166,13 +166,13 @@ struct NovelTable {
 constexpr uint32_t kNovelProbes = 2048;   // far beyond any chain at the load factor the host accepts (0.5)
 
 // returns the slot of the key; when the table is (nearly) full the search is cut short and reported
-__device__ inline uint32_t novel_insert(const NovelTable& t, uint64_t key, uint32_t seq) {
+__device__ inline uint32_t novel_insert(const NovelTable& t, uint64_t key, uint64_t seq) {
   uint32_t s = hash64(key) & t.mask;
   for (uint32_t probe = 0; probe <= min(t.mask, kNovelProbes); ++probe) {
     unsigned long long prev = atomicCAS((unsigned long long*)&t.keys[s], (unsigned long long)kEmpty,
                                         (unsigned long long)key);
     if (prev == kEmpty || prev == key) {
-      atomicMin(&t.seq[s], seq);
+      atomicMin((unsigned long long*)&t.seq[s], (unsigned long long)seq);
       return s;
     }
     s = (s + 1) & t.mask;
@@ -205,10 +205,10 @@ struct Walked {
 
 // ev_out (pass 1 only, may be null): the positive list of the mate as it will be emitted -- the ordinal of a
 // known variant, kEvNovel | slot of the novel table otherwise -- so that pass 2 need not walk again.
-// seq_stride: sequence numbers of novel variants are mate * seq_stride + event (first appearance = smallest);
+// sequence numbers of novel variants are mate << 16 | event (first appearance = smallest), whatever the record format;
 // the stride is the event capacity of the widest record format present in the sample.
 template <bool kEmit, typename View>
-__device__ inline void walk_mate(const View& r, const IndexView& ix, const NovelTable& nt, int64_t m, uint32_t seq_stride,
+__device__ inline void walk_mate(const View& r, const IndexView& ix, const NovelTable& nt, int64_t m,
                                  uint32_t* evw, uint32_t* ids, uint32_t o_pos, uint32_t o_pos_end, uint32_t* ev_out,
                                  Walked& wk) {
   wk.n = 0; wk.clipped = false; wk.overflow = false; wk.drop = false; wk.any_n = 0; wk.bad_window = false;
@@ -258,7 +258,7 @@ __device__ inline void walk_mate(const View& r, const IndexView& ix, const Novel
         ids[o_pos + wk.n] = known ? (uint32_t)i : (uint32_t)ix.n_var + novel_rank(nt, k);
     } else {
       uint32_t saved = (uint32_t)i;
-      if (!known) saved = kEvNovel | novel_insert(nt, k, (uint32_t)(m * seq_stride + wk.n));
+      if (!known) saved = kEvNovel | novel_insert(nt, k, ((uint64_t)m << 16) | (uint64_t)wk.n);
       if (ev_out) ev_out[wk.n] = saved;
     }
     last_pos = pos; last_len = len; last_novel = !known;
@@ -430,7 +430,7 @@ __device__ inline uint32_t window_negatives(const IndexView& ix, const uint32_t*
 // pass 1: validity, counts, novel registration.  One lane per mate; mates of a pair sit in
 // adjacent lanes so the pair verdict is one lane shuffle.
 __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int64_t n_mates, IndexView ix,
-                                                      NovelTable nt, uint32_t seq_stride, uint32_t* cnt /*[4*n_pairs+1]*/,
+                                                      NovelTable nt, uint32_t* cnt /*[4*n_pairs+1]*/,
                                                       uint32_t* valid /*[n_pairs]*/, int* err_flags,
                                                       uint32_t* ev_save /*[n_mates][kMaxEv]*/,
                                                       uint32_t* lo_save /*[n_mates]*/,
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
   wk.n = 0; wk.lo = wk.hi = 0; wk.right = 0; wk.any_n = 0;
   bool enumerate = false;
   if (pair_ok) {
-    walk_mate<false>(r, ix, nt, m, seq_stride, evw, nullptr, 0, 0, ev_save + m * kMaxEv, wk);
+    walk_mate<false>(r, ix, nt, m, evw, nullptr, 0, 0, ev_save + m * kMaxEv, wk);
     if (wk.overflow) atomicOr(err_flags, 2);
     if (wk.clipped) {
     } else if (wk.bad_window) {
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kExpandThreads) void tab_expand(int64_t n_mates, in
   if (m < n_mates) {
     const int64_t pair = m >> 1;
     const int side = (int)(m & 1);
-    if (valid[pair]) {
+    if (valid[pair] == 1u) {      // 2 = a pair of the wide format: pass 1 saved nothing for it, tab_emit_wide writes its lists
       const uint32_t o_pos = off[4 * pair + side], n_pos = off[4 * pair + side + 1] - o_pos;
       const uint32_t o_neg = off[4 * pair + 2 + side], n_neg = off[4 * pair + 2 + side + 1] - o_neg;
       for (uint32_t e = 0; e < n_pos; ++e) {
@@ -539,23 +539,65 @@ __global__ __launch_bounds__(kExpandThreads) void tab_expand(int64_t n_mates, in
   for (uint32_t i = lane; i < run1 - run0; i += 64) ids[run0 + i] = mine[i];
 }
 
-// novel ranking: mark first-appearance sequence numbers, prefix-popcount, assign ranks
-__global__ void novel_mark(NovelTable nt, uint32_t* bitmap) {
+// Novel ranking by first appearance (hisat2.py:597-602: ids nv0, nv1, ... in the order the walk meets them): a novel
+// variant's first appearance is (mate, event).  Every mate owns one word of event bits (a gk_mate has at most 22
+// events); a mate of the wide format (up to 384 events) owns kWideWords words in a second, small array, found through
+// the ascending list of wide pairs.  rank = first appearances in earlier mates (a scan over per-mate popcounts) +
+// earlier first appearances inside the mate.  No dense (mate x event capacity) numbering: the sample size is not
+// coupled to the widest record format present.
+constexpr int kWideWords = (GK_WIDE_EVENTS + 31) / 32;
+
+__device__ inline int64_t wide_index(const int64_t* spill_pair, int64_t n_spill, int64_t pair) {
+  int64_t lo = 0, hi = n_spill;       // first k with spill_pair[k] >= pair
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (spill_pair[mid] < pair) lo = mid + 1; else hi = mid;
+  }
+  return lo < n_spill && spill_pair[lo] == pair ? lo : -1;
+}
+
+__global__ void novel_mark(NovelTable nt, uint32_t* mate_bits, uint32_t* wide_bits, const int64_t* spill_pair,
+                           int64_t n_spill) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s > nt.mask) return;
-  if (nt.keys[s] != kEmpty) atomicOr(&bitmap[nt.seq[s] >> 5], 1u << (nt.seq[s] & 31));
+  if (nt.keys[s] == kEmpty) return;
+  const uint64_t q = nt.seq[s];
+  const int64_t m = (int64_t)(q >> 16);
+  const uint32_t e = (uint32_t)(q & 0xFFFFu);
+  const int64_t w = n_spill ? wide_index(spill_pair, n_spill, m >> 1) : -1;
+  if (w < 0) atomicOr(&mate_bits[m], 1u << (e & 31));      // a gk_mate: e < 22
+  else atomicOr(&wide_bits[(2 * w + (m & 1)) * kWideWords + (e >> 5)], 1u << (e & 31));
 }
-__global__ void bitmap_popc(const uint32_t* bitmap, uint32_t* cnt, int64_t n_words) {
+// cnt[m] = first appearances in mate m
+__global__ void novel_count(const uint32_t* mate_bits, uint32_t* cnt, int64_t n_mates) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_words) cnt[i] = __popc(bitmap[i]);
+  if (i < n_mates) cnt[i] = __popc(mate_bits[i]);
 }
-__global__ void novel_assign(NovelTable nt, const uint32_t* bitmap, const uint32_t* prefix, uint64_t* novel_key) {
+__global__ void novel_count_wide(const uint32_t* wide_bits, const int64_t* spill_pair, int64_t n_spill, uint32_t* cnt) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * n_spill) return;
+  uint32_t c = 0;
+  for (int w = 0; w < kWideWords; ++w) c += __popc(wide_bits[t * kWideWords + w]);
+  cnt[2 * spill_pair[t >> 1] + (t & 1)] = c;
+}
+__global__ void novel_assign(NovelTable nt, const uint32_t* mate_bits, const uint32_t* wide_bits,
+                             const int64_t* spill_pair, int64_t n_spill, const uint32_t* prefix, uint64_t* novel_key) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s > nt.mask) return;
   const uint64_t k = nt.keys[s];
   if (k == kEmpty) return;
-  const uint32_t q = nt.seq[s];
-  const uint32_t rank = prefix[q >> 5] + __popc(bitmap[q >> 5] & ((1u << (q & 31)) - 1u));
+  const uint64_t q = nt.seq[s];
+  const int64_t m = (int64_t)(q >> 16);
+  const uint32_t e = (uint32_t)(q & 0xFFFFu);
+  const int64_t w = n_spill ? wide_index(spill_pair, n_spill, m >> 1) : -1;
+  uint32_t rank = prefix[m];
+  if (w < 0) {
+    rank += __popc(mate_bits[m] & ((1u << (e & 31)) - 1u));
+  } else {
+    const uint32_t* bits = wide_bits + (2 * w + (m & 1)) * kWideWords;
+    for (uint32_t j = 0; j < (e >> 5); ++j) rank += __popc(bits[j]);
+    rank += __popc(bits[e >> 5] & ((1u << (e & 31)) - 1u));
+  }
   nt.rank[s] = rank;
   novel_key[rank] = k;
 }
@@ -581,7 +623,7 @@ __global__ __launch_bounds__(kThreads) void tab_emit(const gk_mate* mates, int64
   uint32_t* evw = evs + threadIdx.x * kEvLd;
   Walked wk;
   wk.n = 0; wk.lo = wk.hi = 0; wk.right = 0; wk.any_n = 0;
-  if (o_pos != o_pos_end || o_neg != o_neg_end) walk_mate<true>(r, ix, nt, m, 0u, evw, ids, o_pos, o_pos_end, nullptr, wk);
+  if (o_pos != o_pos_end || o_neg != o_neg_end) walk_mate<true>(r, ix, nt, m, evw, ids, o_pos, o_pos_end, nullptr, wk);
   const int wid = threadIdx.x >> 6;
   // a mate with an empty negative list has nothing to enumerate (its window may still be non-empty)
   cooperative_negatives<true>(wneg[wid], ix, evs + wid * 64 * kEvLd, o_neg != o_neg_end ? (uint32_t)(wk.hi - wk.lo) : 0u,
@@ -592,7 +634,7 @@ __global__ __launch_bounds__(kThreads) void tab_emit(const gk_mate* mates, int64
 // global memory, windows enumerated candidate by candidate: the same walk and the same rules as above, without the
 // staging -- there are a handful of such pairs in a sample, if any.
 __global__ __launch_bounds__(64) void tab_count_wide(const gk_mate_wide* wide, const int64_t* spill_pair, int64_t n_spill,
-                                                     IndexView ix, NovelTable nt, uint32_t seq_stride, uint32_t* cnt,
+                                                     IndexView ix, NovelTable nt, uint32_t* cnt,
                                                      uint32_t* valid, int* err_flags, uint32_t* evw_all) {
   const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool in = t < 2 * n_spill;
@@ -607,7 +649,7 @@ __global__ __launch_bounds__(64) void tab_count_wide(const gk_mate_wide* wide, c
   uint32_t n_pos = 0, n_neg = 0;
   if (pair_ok) {
     Walked wk;
-    walk_mate<false>(r, ix, nt, 2 * pair + side, seq_stride, evw, nullptr, 0, 0, nullptr, wk);
+    walk_mate<false>(r, ix, nt, 2 * pair + side, evw, nullptr, 0, 0, nullptr, wk);
     if (wk.overflow) atomicOr(err_flags, 2);
     if (wk.clipped) {
     } else if (wk.bad_window) {
@@ -620,7 +662,7 @@ __global__ __launch_bounds__(64) void tab_count_wide(const gk_mate_wide* wide, c
   }
   cnt[4 * pair + side] = n_pos;
   cnt[4 * pair + 2 + side] = n_neg;
-  if (side == 0) valid[pair] = pair_ok ? 1u : 0u;
+  if (side == 0) valid[pair] = pair_ok ? 2u : 0u;   // 2: a valid pair whose lists tab_emit_wide writes (tab_expand skips it)
 }
 
 __global__ __launch_bounds__(64) void tab_emit_wide(const gk_mate_wide* wide, const int64_t* spill_pair, int64_t n_spill,
@@ -637,7 +679,7 @@ __global__ __launch_bounds__(64) void tab_emit_wide(const gk_mate_wide* wide, co
   const WideView r{wide + t};
   uint32_t* evw = evw_all + t * GK_WIDE_EVENTS;
   Walked wk;
-  walk_mate<true>(r, ix, nt, 2 * pair + side, 0u, evw, ids, o_pos, o_pos_end, nullptr, wk);
+  walk_mate<true>(r, ix, nt, 2 * pair + side, evw, ids, o_pos, o_pos_end, nullptr, wk);
   uint32_t at = o_neg;
   for (int i = wk.lo; i < wk.hi && at < o_neg_end; ++i)
     if (negative_kept(ix.key[i], i, ix, evw, wk.n, wk.any_n, wk.right)) ids[at++] = (uint32_t)i;
@@ -802,10 +844,6 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
   for (int64_t k = 0; k < n_spill; ++k)
     GK_REQUIRE(spill_pair[k] >= 0 && spill_pair[k] < n_pairs && (k == 0 || spill_pair[k - 1] < spill_pair[k]),
                "wide pairs must name pairs of the sample, ascending");
-  // sequence numbers of novel variants are 32-bit: mate * (event capacity of the widest format present) + event
-  const uint32_t seq_stride = n_spill ? (uint32_t)GK_WIDE_EVENTS : (uint32_t)kMaxEv;
-  GK_REQUIRE((uint64_t)2 * (uint64_t)n_pairs * seq_stride < (1ull << 32),
-             "too many pairs for one call when some are in the wide format: split the sample");
   GK_REQUIRE((d_corr == 0) == (d_gene_pos0 == 0), "correction table and position offsets come together");
   GK_REQUIRE(n_pairs < (1ll << 26), "more than 2^26 pairs per call");
   const gk_mate* mates = gk_ptr<const gk_mate>(d_mates_p);
@@ -819,10 +857,10 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
   const size_t cap = 1ull << log2cap;
   nt.mask = (uint32_t)(cap - 1);
   GK_HIP(gk_pool_malloc(ctx, (void**)&nt.keys, cap * sizeof(uint64_t)));
-  GK_HIP(gk_pool_malloc(ctx, (void**)&nt.seq, cap * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&nt.seq, cap * sizeof(uint64_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&nt.rank, cap * sizeof(uint32_t)));
   GK_HIP(hipMemsetAsync(nt.keys, 0xFF, cap * sizeof(uint64_t), st));
-  GK_HIP(hipMemsetAsync(nt.seq, 0xFF, cap * sizeof(uint32_t), st));
+  GK_HIP(hipMemsetAsync(nt.seq, 0xFF, cap * sizeof(uint64_t), st));
 
   uint32_t *cnt = nullptr, *valid = nullptr, *ev_save = nullptr, *lo_save = nullptr, *mask_save = nullptr;
   int* d_err = nullptr;
@@ -840,7 +878,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
                      idx->d_gene_pbase, idx->d_snp_ord};
   if (n_mates) {
     GK_PROF(ctx, GK_K_TAB_COUNT, GK_KERNEL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
-                       nt, seq_stride, cnt, valid, d_err, ev_save, lo_save, mask_save));
+                       nt, cnt, valid, d_err, ev_save, lo_save, mask_save));
   }
   int64_t* d_spill_pair = nullptr;
   uint32_t* wide_ev = nullptr;
@@ -853,21 +891,25 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
     GK_HIP(hipStreamSynchronize(st));   // the caller's arrays are free again
     tab->n_spill = n_spill;
     GK_KERNEL(tab_count_wide, dim3(nblk(2 * n_spill, 64)), dim3(64), 0, st, tab->d_wide, d_spill_pair, n_spill, ix, nt,
-              seq_stride, cnt, valid, d_err, wide_ev);
+              cnt, valid, d_err, wide_ev);
   }
   // offsets over input pairs (invalid pairs contribute zeros)
   int rc = gk_scan_u32(ctx, cnt, 4 * n_pairs, cnt + 4 * n_pairs);
   if (rc) return rc;
 
-  // novel ranks
-  const int64_t n_seq = n_mates * (int64_t)seq_stride;
-  const int64_t n_words = (n_seq + 31) / 32 + 1;
-  uint32_t *bitmap = nullptr, *prefix = nullptr;
+  // novel ranks: event bits per mate (bitmap) + per wide mate (wide_bits), per-mate counts scanned into `prefix`
+  const int64_t n_words = n_mates + 1;
+  uint32_t *bitmap = nullptr, *prefix = nullptr, *wide_bits = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&bitmap, (size_t)n_words * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&prefix, (size_t)(n_words + 1) * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&wide_bits, (size_t)(2 * n_spill + 1) * kWideWords * sizeof(uint32_t)));
   GK_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_words * sizeof(uint32_t), st));
-  GK_PROF(ctx, GK_K_NOVEL, GK_KERNEL(novel_mark, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap));
-  GK_PROF(ctx, GK_K_NOVEL, GK_KERNEL(bitmap_popc, dim3(nblk(n_words)), dim3(kThreads), 0, st, bitmap, prefix, n_words));
+  GK_HIP(hipMemsetAsync(wide_bits, 0, (size_t)(2 * n_spill + 1) * kWideWords * sizeof(uint32_t), st));
+  GK_PROF(ctx, GK_K_NOVEL, GK_KERNEL(novel_mark, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap, wide_bits,
+                                     d_spill_pair, n_spill));
+  GK_PROF(ctx, GK_K_NOVEL, GK_KERNEL(novel_count, dim3(nblk(n_words)), dim3(kThreads), 0, st, bitmap, prefix, n_words));
+  if (n_spill)
+    GK_KERNEL(novel_count_wide, dim3(nblk(2 * n_spill)), dim3(kThreads), 0, st, wide_bits, d_spill_pair, n_spill, prefix);
   rc = gk_scan_u32(ctx, prefix, n_words, prefix + n_words);
   if (rc) return rc;
 
@@ -884,7 +926,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
     gk_set_error("novel variant table overflow (%d novel variants in %llu slots)", tab->n_novel, (unsigned long long)cap);
     *table_too_small = true;
     GK_HIP(hipStreamSynchronize(st));
-    gk_pool_free(ctx,cnt); gk_pool_free(ctx,valid); gk_pool_free(ctx,d_err); gk_pool_free(ctx,bitmap); gk_pool_free(ctx,prefix);
+    gk_pool_free(ctx,cnt); gk_pool_free(ctx,valid); gk_pool_free(ctx,d_err); gk_pool_free(ctx,bitmap); gk_pool_free(ctx,prefix); gk_pool_free(ctx,wide_bits);
     gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save);
     gk_pool_free(ctx,d_spill_pair); gk_pool_free(ctx,wide_ev);
     gk_pool_free(ctx,nt.keys); gk_pool_free(ctx,nt.seq); gk_pool_free(ctx,nt.rank);
@@ -893,23 +935,25 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
   }
 
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_novel_key, (size_t)(tab->n_novel + 1) * sizeof(uint64_t)));
-  GK_PROF(ctx, GK_K_NOVEL, GK_KERNEL(novel_assign, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap, prefix,
-                     tab->d_novel_key));
+  GK_PROF(ctx, GK_K_NOVEL, GK_KERNEL(novel_assign, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap, wide_bits,
+                     d_spill_pair, n_spill, prefix, tab->d_novel_key));
 
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_ids, (size_t)(tab->n_ids + 1) * sizeof(uint32_t)));
   if (n_mates) {
     // pass 2: from what pass 1 saved; the second walk only when some window did not fit the saved bits
     const bool two_walks = getenv("GK_TAB_TWO_WALKS") != nullptr;   // development / test switch
-    if ((err & 4) || two_walks || n_spill) {   // (tab_expand reads what pass 1 saved: nothing for wide pairs)
+    if ((err & 4) || two_walks) {
       GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix, nt,
                          cnt, valid, tab->d_ids));
-      if (n_spill)
-        GK_KERNEL(tab_emit_wide, dim3(nblk(2 * n_spill, 64)), dim3(64), 0, st, tab->d_wide, d_spill_pair, n_spill, ix, nt,
-                  cnt, valid, tab->d_ids, wide_ev);
     } else {
       GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_expand, dim3(nblk(n_mates, kExpandThreads)), dim3(kExpandThreads), 0, st, n_mates, idx->n_var,
                          nt.rank, cnt, valid, ev_save, lo_save, mask_save, tab->d_ids));
     }
+    // the pairs of the wide format, AFTER the kernel above (tab_expand copies a wavefront's whole run of lists out of LDS,
+    // the slots of a wide pair included; tab_emit leaves them alone): their lists overwrite whatever lies there
+    if (n_spill)
+      GK_KERNEL(tab_emit_wide, dim3(nblk(2 * n_spill, 64)), dim3(64), 0, st, tab->d_wide, d_spill_pair, n_spill, ix, nt,
+                cnt, valid, tab->d_ids, wide_ev);
   }
   // compact valid pairs (order preserving)
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_pair_src, (size_t)(n_pairs + 1) * sizeof(int32_t)));
@@ -922,7 +966,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
                      tab->n_valid, cnt, tab->d_off, tab->d_pair_gene, tab->d_pair_nh, (uint32_t)tab->n_ids));
   GK_HIP(hipGetLastError());
   GK_HIP(hipStreamSynchronize(st));
-  gk_pool_free(ctx,cnt); gk_pool_free(ctx,valid); gk_pool_free(ctx,d_err); gk_pool_free(ctx,bitmap); gk_pool_free(ctx,prefix);
+  gk_pool_free(ctx,cnt); gk_pool_free(ctx,valid); gk_pool_free(ctx,d_err); gk_pool_free(ctx,bitmap); gk_pool_free(ctx,prefix); gk_pool_free(ctx,wide_bits);
   gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save);
   gk_pool_free(ctx,d_spill_pair); gk_pool_free(ctx,wide_ev);
   gk_pool_free(ctx,nt.keys); gk_pool_free(ctx,nt.seq); gk_pool_free(ctx,nt.rank);

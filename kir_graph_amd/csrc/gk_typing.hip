@@ -8,11 +8,12 @@
 //                       (_log: with np.log10 of line 263 applied through the value table)
 //
 // Compatibility kernel: one wavefront per read pair, lanes = alleles (1-4 allele slots per lane,
-// up to 256 alleles per pass).  The pair's variant ordinals are wave-uniform, and the 64 alleles of a slot are
-// 64 consecutive bits of a variant's bit row: the two words of the row that cover the slot ARE the slot's lane
-// mask.  They are fetched with scalar loads (s_load_dwordx2/4/8, a few variants ahead) and select 0.999 / 0.001
-// with v_cndmask_b32 straight from the SGPR pair, multiplied in the reference's factor order (lpv, rpv, lnv, rnv),
-// so the double product is bit-identical to numpy's sequential multiply.reduce.
+// up to 256 alleles per pass).  The pair's variant ordinals are wave-uniform; the bit rows of a chunk of 64
+// ordinals are laid down in LDS ([variant][word], per wave) and every lane reads the word that holds its allele's bit,
+// turns the bit into a select mask and picks the halves of 0.999 / 0.001, multiplied in the reference's factor order
+// (lpv, rpv, lnv, rnv), so the double product is bit-identical to numpy's sequential multiply.reduce.
+// (Round 3 tried the lane masks in SGPR pairs through scalar loads -- 3 VALU per factor instead of 4 -- and lost to
+// the scalar cache's miss path: DESIGN.md section 8, profiles/r03_compat_variants.txt.)
 #include <algorithm>
 
 #include "gk_common.h"
@@ -189,213 +190,6 @@ constexpr int kCompatThreads = 64 * kCompatWaves;
 constexpr int kTileRows = 16;            // rows per output tile (2 per wave)
 constexpr int kTileLd = kTileRows + 1;   // padded LDS stride (doubles) of the transposed tile
 
-// The gene's bit matrix [variant][words] with a tail of zero words: one all-zero row for variants without alleles
-// (novel ones), and enough slack that a scalar load of 8 words starting at the last word of the last row stays inside
-// the block.
-constexpr int kMaskTail = 16;   // words after the zero row
-__global__ __launch_bounds__(kThreads) void pad_mask(const uint32_t* mask, int64_t n_mask, int64_t n_out, uint32_t* out) {
-  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i < n_out) out[i] = i < n_mask ? mask[i] : 0u;
-}
-
-// clear bit `t` of a wave-uniform bit set (one s_bitset0_b64 instead of the add / addc / and of x &= x - 1)
-__device__ __forceinline__ uint64_t clear_bit(uint64_t set, int t) {
-  asm("s_bitset0_b64 %0, %1" : "+s"(set) : "s"(t));
-  return set;
-}
-
-// One wavefront per read pair, lanes = alleles (kSlots allele slots per lane; a gene of <= 256
-// alleles is one pass, and the last pass of a wider gene only carries the slots it needs).  Per chunk
-// of 64 variant ordinals, lane k loads ordinal k and its drop flag; the kept variants of the chunk are a scalar
-// bit set walked in order (s_ff1 / s_bitset0).  For every kept variant the 2 * kSlots words of its bit row that
-// this pass needs come through the scalar cache (the row offset of lane t's ordinal is read with one v_readlane);
-// per slot the word pair is the lane mask of "the allele has the variant", so a factor costs two
-// v_cndmask_b32 (the halves of 0.999 / 0.001, mask in an SGPR pair) and one v_mul_f64: 3 VALU per factor and
-// slot, no LDS, nothing cross-lane.  Scalar loads return out of order, so they are waited for in batches: the
-// rows of the next kBatch variants are requested, the current batch is multiplied in, then ONE s_waitcnt.
-// Results of a 16-row tile are transposed through LDS so that the column-major [allele][row]
-// output is written as 128-byte runs instead of one 8-byte store per (allele, row).
-//
-// kLog: the tile is mapped through the log10 value table on its way out (typing_mulit_allele.py:263),
-// so the table of log-probabilities is the only thing written.  A value whose log10 the host has not
-// evaluated yet is inserted into the table and stored as NaN; the host sees the table grow, evaluates
-// numpy.log10 for the new values and runs the kernel once more.
-template <int kWords> struct __attribute__((packed, aligned(4))) RowWords { uint32_t w[kWords]; };
-
-template <bool kLog, int kSlots, bool kMiss>
-__global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* rows, int64_t n_rows, const uint32_t* off,
-                                                                const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
-                                                                const uint32_t* __restrict__ mask_rows, int words, int n_allele,
-                                                                int a_base, double* probs, uint8_t* miss_out,
-                                                                uint16_t* nvar_out, LutView lut, double empty_p,
-                                                                uint8_t* miss8, int64_t ldm, uint32_t* bound_flags) {
-  const int n_span = vend - vbeg;   // mask_rows: [n_span + 1][words] (row n_span is all zero) + slack, see pad_mask
-  constexpr int kPassAlleles = 64 * kSlots;
-  constexpr int kPassWords = 2 * kSlots;   // bit-row words covering one pass
-  constexpr int kBatch = kSlots <= 2 ? 4 : 3;   // variants whose rows are in flight together (SGPR budget: 2 batches)
-  using Row = RowWords<kPassWords>;
-  __shared__ double tile[kPassAlleles * kTileLd];
-  // 0.999 = 0x3FEFF7CED916872B, 0.001 = 0x3F50624DD2F1A9FC
-  constexpr int32_t kHi999 = 0x3FEFF7CE, kLo999 = (int32_t)0xD916872B, kHi001 = 0x3F50624D, kLo001 = (int32_t)0xD2F1A9FC;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int w_base = a_base >> 5;   // a_base is a multiple of 256 = 8 words
-  const uint32_t zero_row = (uint32_t)(n_span * words) * 4u;       // byte offset of the all-zero row
-  const char* const row_bytes = reinterpret_cast<const char*>(mask_rows + w_base);
-
-  int a[kSlots];
-  bool live[kSlots];
-#pragma unroll
-  for (int s = 0; s < kSlots; ++s) {
-    a[s] = a_base + lane + 64 * s;
-    live[s] = a[s] < n_allele;
-  }
-  const int n_pass = min(kPassAlleles, n_allele - a_base);
-  const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
-  for (int64_t tile_i = blockIdx.x; tile_i < n_tiles; tile_i += gridDim.x) {
-    const int64_t row0 = tile_i * kTileRows;
-    for (int q = 0; q < kTileRows / kCompatWaves; ++q) {
-      const int rt = wid * (kTileRows / kCompatWaves) + q;   // row inside the tile
-      const int64_t i = row0 + rt;
-      if (i >= n_rows) break;                                   // wave-uniform
-      const int64_t row = rows[i];
-      const uint32_t b = __builtin_amdgcn_readfirstlane(off[4 * row]);
-      const uint32_t mid = __builtin_amdgcn_readfirstlane(off[4 * row + 2]);
-      const uint32_t e = __builtin_amdgcn_readfirstlane(off[4 * row + 4]);
-      double p[kSlots];
-      uint32_t miss[kSlots];
-      uint32_t nvar = 0;
-#pragma unroll
-      for (int s = 0; s < kSlots; ++s) { p[s] = 1.0; miss[s] = 0; }
-      for (uint32_t base = b; base < e; base += 64) {
-        const uint32_t k = base + lane;
-        bool my_keep = false;
-        uint32_t my_row = zero_row;       // byte offset of this lane's variant row; novel variants carry no allele
-        if (k < e) {
-          const uint32_t v = ids[k];
-          const int local = (int)v - vbeg;
-          if ((int)v < vend && local >= 0) my_row = (uint32_t)(local * words) * 4u;
-          my_keep = !(vflag[v] & (k < mid ? 1 : 2));
-        }
-        // kept variants of the chunk as a scalar bit set, walked in order: the positive ones (ordinals
-        // below `mid`) come first, then the negative ones, whose factors are swapped
-        uint64_t todo = __ballot(my_keep);
-        nvar += (uint32_t)__builtin_popcountll(todo);
-        const int n_pos = mid > base ? (int)min(mid - base, 64u) : 0;
-        Row ra[kBatch], rb[kBatch];
-        uint32_t neg_a = 0, neg_b = 0;     // bit i: factor i of the batch is a negative one
-        int na = 0, nb = 0;
-        auto request = [&](Row (&r)[kBatch], uint32_t& neg, int& n) {
-          n = min((int)__builtin_popcountll(todo), kBatch);
-          neg = 0;
-#pragma unroll
-          for (int j = 0; j < kBatch; ++j)
-            if (j < n) {
-              const int t = __builtin_ctzll(todo);
-              todo = clear_bit(todo, t);
-              const uint32_t at = __builtin_amdgcn_readlane(my_row, t);
-              r[j] = *reinterpret_cast<const Row*>(row_bytes + at);
-              neg |= (t >= n_pos ? 1u : 0u) << j;
-            }
-        };
-        auto apply = [&](const Row (&r)[kBatch], uint32_t neg, int n) {
-#pragma unroll
-          for (int j = 0; j < kBatch; ++j)
-            if (j < n) {
-              const uint64_t flip = (neg >> j) & 1u ? ~0ull : 0ull;
-#pragma unroll
-              for (int s = 0; s < kSlots; ++s) {
-                // lane mask of "the factor is 0.999": the allele has the variant (positive) / has it not (negative)
-                const uint64_t m = (((uint64_t)r[j].w[2 * s + 1] << 32) | r[j].w[2 * s]) ^ flip;
-                const bool hit = __builtin_amdgcn_inverse_ballot_w64(m);
-                p[s] *= __hiloint2double(hit ? kHi999 : kHi001, hit ? kLo999 : kLo001);   // 1.0 * f == f
-                if (kMiss) miss[s] += hit ? 0u : 1u;
-              }
-            }
-        };
-        request(ra, neg_a, na);
-        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): scalar loads return out of order
-        while (na) {
-          request(rb, neg_b, nb);
-          apply(ra, neg_a, na);
-          __builtin_amdgcn_s_waitcnt(0xC07F);
-          if (!nb) break;
-          request(ra, neg_a, na);
-          apply(rb, neg_b, nb);
-          __builtin_amdgcn_s_waitcnt(0xC07F);
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < kSlots; ++s) {
-        if (live[s]) {
-          // a read without any kept variant: 1.0, or 0.999 for every allele when such reads stay in the
-          // model (no_empty=False, typing_mulit_allele.py:372-374)
-          tile[(lane + 64 * s) * kTileLd + rt] = nvar ? p[s] : empty_p;
-          if (kMiss && miss_out) miss_out[(int64_t)a[s] * n_rows + i] = (uint8_t)min(miss[s], 255u);
-        }
-      }
-      if (kMiss && nvar_out && lane == 0 && a_base == 0) nvar_out[i] = (uint16_t)min(nvar, 65535u);
-      // the count read back from the log-likelihood below (m = floor(-L / 3 + 1/4)) is exact only while
-      // 0.000434 (n - m) < 3/4 * 3, i.e. for rows of fewer than ~5000 factors: a longer row sends the gene to the
-      // exact search (wide records and windows beyond 256 variants can produce such rows)
-      if (kLog && miss8 && nvar >= 4096u && lane == 0) atomicOr(bound_flags, 1u);
-    }
-    __syncthreads();
-    if (probs) {
-      const int n_r = (int)min<int64_t>(kTileRows, n_rows - row0);
-      uint64_t key0 = kLutEmptyKey, key1 = kLutEmptyKey;   // the two most recent values of this thread's read
-      double val0 = 0.0, val1 = 0.0;
-      for (int idx = tid; idx < n_pass * kTileRows; idx += kCompatThreads) {
-        const int al = idx / kTileRows, r = idx % kTileRows;
-        const bool in = r < n_r;
-        if (!in && !(kLog && miss8)) continue;
-        double v = in ? tile[al * kTileLd + r] : 1.0;
-        if (kLog && in) {
-          // one read's alleles share a handful of values: most lookups end in these two registers
-          const uint64_t key = (uint64_t)__double_as_longlong(v);
-          if (key != key0) {
-            double val;
-            if (key == key1) {
-              val = val1;
-            } else {
-              bool found;
-              val = gk_lut_lookup(lut, key, &found);
-              if (!found) gk_lut_insert(lut, key);
-            }
-            key1 = key0; val1 = val0;
-            key0 = key; val0 = val;
-          }
-          v = val0;
-        }
-        if (in) probs[(int64_t)(a_base + al) * n_rows + row0 + r] = v;
-        if (kLog && miss8) {
-          // The mismatch count of (read, allele) read back from the log-likelihood: -L = 3 m + 0.000434 (n - m),
-          // so m = floor(-L / 3 + 1/4) for any list shorter than ~5000 ids.  u8 table [allele][ldm], four rows of
-          // a quad packed into one store; rows past the end hold 0 (they add nothing to any |a - b| sum).
-          // A count >= 100 (the product is about to leave the normal range / underflow, L = -inf) raises the
-          // flag that sends the gene to the exact search; NaN (log10 not defined yet) is rewritten by the next pass.
-          uint32_t m = 0;
-          if (in) {
-            const double t = __builtin_fma(v, -1.0 / 3.0, 0.25);
-            if (t < 100.0) m = (uint32_t)(int)t;
-            else { m = 255u; if (v == v) atomicOr(bound_flags, 1u); }
-          }
-          uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xF9, 0xF, 0xF, true);      // lane + 1 of the quad
-          uint32_t packed = m | (x << 8);
-          x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9, 0xF, 0xF, true);               // lane + 2
-          packed |= x << 16;
-          x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9, 0xF, 0xF, true);               // lane + 3
-          packed |= x << 24;
-          if ((r & 3) == 0)
-            *reinterpret_cast<uint32_t*>(miss8 + (int64_t)(a_base + al) * ldm + row0 + r) = packed;
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// ---- experimental A/B: the LDS form of round 2 (GK_COMPAT=lds | ldsvcc)
 // bit matrix [variant][words] -> [word][variant]: in the compatibility kernel lane k reads word w of the
 // k-th variant of a window, and windows are runs of consecutive ordinals, so the word-major copy turns
 // 64 strided row reads into one coalesced 256-byte read per word
@@ -406,13 +200,40 @@ __global__ __launch_bounds__(kThreads) void transpose_mask(const uint32_t* mask,
   out[i] = mask[(int64_t)v * words + w];
 }
 
-template <bool kLog, int kSlots, bool kMiss, bool kVcc>
-__global__ __launch_bounds__(kCompatThreads) void compat_kernel_lds(const int32_t* rows, int64_t n_rows, const uint32_t* off,
+// clear bit `t` of a wave-uniform bit set (one s_bitset0_b64 instead of the add / addc / and of x &= x - 1)
+__device__ __forceinline__ uint64_t clear_bit(uint64_t set, int t) {
+  asm("s_bitset0_b64 %0, %1" : "+s"(set) : "s"(t));
+  return set;
+}
+
+// One wavefront per read pair, lanes = alleles (kSlots allele slots per lane; a gene of <= 256
+// alleles is one pass, and the last pass of a wider gene only carries the slots it needs).  Per chunk
+// of 64 variant ordinals, lane k loads ordinal k, its drop flag and the 2*kSlots bit-row words of
+// that variant that this pass needs (windows are runs of consecutive ordinals, so these are coalesced row reads of the
+// L2-resident, word-major bit matrix) and lays them down in LDS.  The kept variants of the chunk are a scalar bit set
+// walked in order; per factor and slot a lane reads the word holding its allele's bit (the next variant's words are
+// already in flight), sign-extends the bit into a select mask (v_bfe_i32), picks the factor's halves (2 x v_bfi_b32)
+// and multiplies -- 0.999 / 0.001 in the reference's order.
+// Results of a 16-row tile are transposed through LDS so that the column-major [allele][row]
+// output is written as runs instead of one store per (allele, row).
+//
+// kLog: the tile is mapped through the log10 value table on its way out (typing_mulit_allele.py:263),
+// so the table of log-probabilities is the only thing written.  A value whose log10 the host has not
+// evaluated yet is inserted into the table and stored as NaN; the host sees the table grow, evaluates
+// numpy.log10 for the new values and runs the kernel once more.
+// kIdx (with kLog): the table holds, per (allele, read), the DENSE INDEX of the log-likelihood in the value table
+// (uint16 [allele][ldm] through `lidx`) instead of the float64 itself -- 2 bytes + the mismatch byte per entry
+// instead of 8 + 1; the reductions gather the float64 from the table's value array (gk_search.hip).  An index
+// beyond 65534 raises bit 1 of the flag word: the caller then takes the float64 form for this gene.
+constexpr uint16_t kNoIndex = 0xFFFFu;   // "log10 not defined yet" in the index table (rewritten by the next pass)
+
+template <bool kLog, int kSlots, bool kMiss, bool kIdx>
+__global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* rows, int64_t n_rows, const uint32_t* off,
                                                                 const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
                                                                 const uint32_t* mask_t, int words, int n_allele, int a_base,
                                                                 double* probs, uint8_t* miss_out, uint16_t* nvar_out,
                                                                 LutView lut, double empty_p, uint8_t* miss8, int64_t ldm,
-                                                                uint32_t* bound_flags) {
+                                                                uint32_t* bound_flags, uint16_t* lidx) {
   const int n_span = vend - vbeg;   // mask_t: [words][n_span], see transpose_mask
   constexpr int kPassAlleles = 64 * kSlots;
   constexpr int kPassWords = 2 * kSlots;   // bit-row words covering one pass
@@ -481,7 +302,6 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel_lds(const int32_
         __builtin_amdgcn_wave_barrier();   // LDS operations of a wave are executed in order
         const uint32_t* const my_words = wrows + (lane >> 5);
         const int my_bit = lane & 31;
-        const uint32_t my_mask = 1u << my_bit;
         // one variant's words for the lane's slots / the factor they select; the walk reads the words of the
         // next kept variant before it multiplies the current one in (two register sets, no copies)
         auto fetch = [&](int t, uint32_t (&w)[kSlots]) {
@@ -491,13 +311,6 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel_lds(const int32_
         auto apply = [&](const uint32_t (&w)[kSlots], bool positive) {
 #pragma unroll
           for (int s = 0; s < kSlots; ++s) {
-            if (kVcc) {     // bit -> VCC with two VOP2 operations, then the halves with v_cndmask_b32_e32
-              const bool has = (w[s] & my_mask) != 0u;
-              const bool hit = has == positive;
-              p[s] *= __hiloint2double(hit ? kHi999 : kHi001, hit ? kLo999 : kLo001);
-              if (kMiss) miss[s] += hit ? 0u : 1u;
-              continue;
-            }
             const int32_t m = __builtin_amdgcn_sbfe((int32_t)w[s], my_bit, 1);   // -1: the allele has the variant
             if (positive) {
               p[s] *= __hiloint2double((m & kHi999) | (~m & kHi001), (m & kLo999) | (~m & kLo001));   // 1.0 * f == f
@@ -541,12 +354,59 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel_lds(const int32_
         }
       }
       if (kMiss && nvar_out && lane == 0 && a_base == 0) nvar_out[i] = (uint16_t)min(nvar, 65535u);
-      // the count read back from the log-likelihood below (m = floor(-L / 3 + 1/4)) is exact only while
-      // 0.000434 (n - m) < 3/4 * 3, i.e. for rows of fewer than ~5000 factors: a longer row sends the gene to the
-      // exact search (wide records and windows beyond 256 variants can produce such rows)
+      // the mismatch count read back from the log-likelihood (m = floor(-L / 3 + 1/4), gk_miss_of_log) is exact only
+      // for rows of fewer than ~5000 factors: a longer row sends the gene to the exact search (wide records and
+      // windows beyond 256 variants can produce such rows)
       if (kLog && miss8 && nvar >= 4096u && lane == 0) atomicOr(bound_flags, 1u);
     }
     __syncthreads();
+    if (kIdx) {
+      // index form: (dense index, mismatch count) of every product from the value table; four rows of a quad packed
+      // into one 8-byte store of indices and one 4-byte store of counts; rows past the end hold index 0xFFFF / count 0
+      const int n_r = (int)min<int64_t>(kTileRows, n_rows - row0);
+      uint64_t key0 = kLutEmptyKey, key1 = kLutEmptyKey;   // the two most recent values of this thread's read
+      uint64_t inf0 = kLutNoInfo, inf1 = kLutNoInfo;
+      for (int idx = tid; idx < n_pass * kTileRows; idx += kCompatThreads) {
+        const int al = idx / kTileRows, r = idx % kTileRows;
+        const bool in = r < n_r;
+        uint32_t id16 = kNoIndex, m = 0;
+        if (in) {
+          const uint64_t key = (uint64_t)__double_as_longlong(tile[al * kTileLd + r]);
+          if (key != key0) {
+            uint64_t info;
+            if (key == key1) {
+              info = inf1;
+            } else {
+              info = gk_lut_info(lut, key);
+              if (info == kLutNoInfo) gk_lut_insert(lut, key);
+            }
+            key1 = key0; inf1 = inf0;
+            key0 = key; inf0 = info;
+          }
+          if (inf0 != kLutNoInfo) {
+            const uint32_t dense = (uint32_t)inf0;
+            m = (uint32_t)(inf0 >> 32) & 0xFFu;
+            if (dense >= kNoIndex) atomicOr(bound_flags, 2u);       // the value table outgrew 16-bit indices
+            else id16 = dense;
+            if (m == 255u) atomicOr(bound_flags, 1u);               // a count >= 100 / a product that left the normal range
+          }
+        }
+        uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xF9, 0xF, 0xF, true);      // lane + 1 of the quad
+        uint32_t packed = m | (x << 8);
+        x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9, 0xF, 0xF, true);               // lane + 2
+        packed |= x << 16;
+        x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9, 0xF, 0xF, true);               // lane + 3
+        packed |= x << 24;
+        const uint32_t i1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)id16, 0xF9, 0xF, 0xF, true);
+        const uint32_t i2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)i1, 0xF9, 0xF, 0xF, true);
+        const uint32_t i3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)i2, 0xF9, 0xF, 0xF, true);
+        if ((r & 3) == 0) {
+          const int64_t at = (int64_t)(a_base + al) * ldm + row0 + r;
+          *reinterpret_cast<uint32_t*>(miss8 + at) = packed;
+          *reinterpret_cast<uint2*>(lidx + at) = make_uint2(id16 | (i1 << 16), i2 | (i3 << 16));
+        }
+      }
+    } else
     if (probs) {
       const int n_r = (int)min<int64_t>(kTileRows, n_rows - row0);
       uint64_t key0 = kLutEmptyKey, key1 = kLutEmptyKey;   // the two most recent values of this thread's read
@@ -604,34 +464,27 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel_lds(const int32_
 template <bool kLog>
 int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int vbeg, int vend,
                   gk_dptr d_mask, int words, int n_allele, double* out, uint8_t* miss, uint16_t* nvar, LutView view,
-                  int keep_empty, uint8_t* miss8 = nullptr, int64_t ldm = 0, uint32_t* bound_flags = nullptr) {
+                  int keep_empty, uint8_t* miss8 = nullptr, int64_t ldm = 0, uint32_t* bound_flags = nullptr,
+                  uint16_t* lidx = nullptr) {
   const double empty_p = keep_empty ? 0.999 : 1.0;
   int64_t want = (n_rows + kTileRows - 1) / kTileRows;
   const dim3 grid((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048)), block(kCompatThreads);
-  static const int variant = [] {
-    const char* e = getenv("GK_COMPAT");
-    return !e ? 0 : !strcmp(e, "lds") ? 1 : !strcmp(e, "ldsvcc") ? 2 : 0;
-  }();
-  const int64_t n_mask = (int64_t)(vend - vbeg) * words, n_pad = n_mask + words + kMaskTail;
-  uint32_t* mask_t = nullptr;     // the bit rows + one zero row + slack for the scalar loads (pad_mask)
-  GK_HIP(gk_pool_malloc(ctx, (void**)&mask_t, (size_t)n_pad * sizeof(uint32_t)));
-  if (variant == 0)
-    GK_KERNEL(pad_mask, dim3((unsigned)((n_pad + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
-              gk_ptr<uint32_t>(d_mask), n_mask, n_pad, mask_t);
-  else if (n_mask > 0)
+  const int64_t n_mask = (int64_t)(vend - vbeg) * words;
+  uint32_t* mask_t = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&mask_t, (size_t)std::max<int64_t>(n_mask, 1) * sizeof(uint32_t)));
+  if (n_mask > 0)
     GK_KERNEL(transpose_mask, dim3((unsigned)((n_mask + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
               gk_ptr<uint32_t>(d_mask), vend - vbeg, words, mask_t);
   for (int a_base = 0; a_base < n_allele; a_base += 64 * kMaxSlots) {
     const int slots = std::min(kMaxSlots, (n_allele - a_base + 63) / 64);
-#define GK_COMPAT_GO(KERNEL)                                                                                          \
-  GK_KERNEL(KERNEL, grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows, tab->d_off, tab->d_ids,              \
-            gk_ptr<uint8_t>(d_vflag), vbeg, vend, mask_t, words, n_allele, a_base, out, miss, nvar, view, empty_p, miss8, \
-            ldm, bound_flags)
-#define GK_COMPAT_LAUNCH(S)                                                              \
-  GK_PROF(ctx, GK_K_COMPAT, {                                                            \
-    if (variant == 0) GK_COMPAT_GO((compat_kernel<kLog, S, !kLog>));                     \
-    else if (variant == 1) GK_COMPAT_GO((compat_kernel_lds<kLog, S, !kLog, false>));     \
-    else GK_COMPAT_GO((compat_kernel_lds<kLog, S, !kLog, true>));                        \
+#define GK_COMPAT_GO(S, IDX)                                                                                       \
+  GK_KERNEL((compat_kernel<kLog, S, !kLog, IDX>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows,    \
+            tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, mask_t, words, n_allele, a_base, out,    \
+            miss, nvar, view, empty_p, miss8, ldm, bound_flags, lidx)
+#define GK_COMPAT_LAUNCH(S)                               \
+  GK_PROF(ctx, GK_K_COMPAT, {                             \
+    if (kLog && lidx) GK_COMPAT_GO(S, (kLog && true));    \
+    else GK_COMPAT_GO(S, false);                          \
   })
     switch (slots) {
       case 1: GK_COMPAT_LAUNCH(1); break;
@@ -968,6 +821,26 @@ int gk_compat_log_miss(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows,
   return launch_compat<true>(ctx, tab, d_rows, n_rows, d_vflag, vbeg, vend, d_mask, words, n_allele,
                              gk_ptr<double>(d_log), nullptr, nullptr, gk_lut_view(lut), keep_empty,
                              gk_ptr<uint8_t>(d_miss8), ldm, gk_ptr<uint32_t>(d_flags));
+}
+
+/* The index form of gk_compat_log_miss: d_lidx uint16 [n_allele][ldm] receives, per (allele, read), the dense index of
+ * the log-likelihood in the value table (gk_lut: value = vals[index]; 0xFFFF while the log10 of a product is not defined
+ * yet -- resolve and call again, as for gk_compat_log), d_miss8 the mismatch counts.  *d_flags: bit 0 as for
+ * gk_compat_log_miss, bit 1 = the value table holds more than 65535 values (use the float64 form for this gene). */
+int gk_compat_index(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg, int32_t vend,
+                    gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty, gk_lut* lut, gk_dptr d_lidx,
+                    gk_dptr d_miss8, int64_t ldm, gk_dptr d_flags) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && tab && lut, "null pointer");
+  GK_REQUIRE(words >= 1 && n_allele >= 0 && n_allele <= words * 32 && vend >= vbeg, "bad mask geometry");
+  if (n_rows == 0 || n_allele == 0) return GK_OK;
+  GK_REQUIRE(d_lidx && d_miss8 && d_flags, "null output");
+  GK_REQUIRE(ldm >= n_rows && ldm % 64 == 0, "table stride must be a multiple of 64 rows");
+  GK_HIP(hipMemsetAsync(gk_ptr<void>(d_miss8), 0, (size_t)n_allele * (size_t)ldm, ctx->stream));
+  GK_HIP(hipMemsetAsync(gk_ptr<void>(d_flags), 0, sizeof(uint32_t), ctx->stream));
+  return launch_compat<true>(ctx, tab, d_rows, n_rows, d_vflag, vbeg, vend, d_mask, words, n_allele, nullptr, nullptr,
+                             nullptr, gk_lut_view(lut), keep_empty, gk_ptr<uint8_t>(d_miss8), ldm,
+                             gk_ptr<uint32_t>(d_flags), gk_ptr<uint16_t>(d_lidx));
 }
 
 }  // extern "C"

@@ -404,15 +404,19 @@ class DeviceModel:
 
     def __init__(self, tab: Tabulation, rows: DeviceBuffer, n_rows: int, vflag: DeviceBuffer,
                  vbeg: int, vend: int, mask: DeviceBuffer, words: int, n_allele: int, logs: LogTable,
-                 want_miss: bool = False, keep_empty: bool = False, launch: bool = True):
+                 want_miss: bool = False, keep_empty: bool = False, launch: bool = True, indexed: bool = False):
         """``keep_empty``: rows without any kept variant are part of the model and score 0.999 for every
         allele (``no_empty=False``, typing_mulit_allele.py:372-374).  ``launch=False``: the tables are only
-        allocated; ``gk_sample_search`` fills them together with those of the sample's other genes."""
+        allocated; ``gk_sample_search`` fills them together with those of the sample's other genes.
+        ``indexed`` (with ``launch=False`` and the integer bound): the table is kept as uint16 indices into the value
+        table (2 bytes per entry, ``lidx``); the float64 form ``L`` is made from it only when somebody reads it."""
         self.tab, self.dev = tab, tab.dev
         self._keep_empty = int(bool(keep_empty))
         self.rows, self.n_rows, self.n_allele = rows, n_rows, n_allele
         self.vflag = vflag
-        self.L = self.miss = self.nvar = None
+        self._L = self.miss = self.nvar = None
+        self.lidx = None               # uint16 [n_allele][ldm]: the index form (valid once gk_sample_search said so)
+        self._indexed = False
         self._probs = None
         self._logs = logs
         self._geom = (vbeg, vend, mask, words)
@@ -424,16 +428,34 @@ class DeviceModel:
         self._bound_ok: bool | None = None
         if n_rows == 0 or n_allele == 0:
             return
-        self.L = self.dev.alloc((n_allele, n_rows), np.float64)
+        want_index = bool(indexed and not launch and searchMode() == "bound" and n_rows < 16_000_000)
+        if not want_index:
+            self._L = self.dev.alloc((n_allele, n_rows), np.float64)
         if searchMode() == "bound" and n_rows < 16_000_000:
             self.ldm = (n_rows + 63) // 64 * 64
             self.miss8 = self.dev.alloc((n_allele, self.ldm), np.uint8)
             self.msum = self.dev.alloc(n_allele, np.uint32)
             self._bound_flags = self.dev.alloc(1, np.uint32)
+            if want_index:
+                self.lidx = self.dev.alloc((n_allele, self.ldm), np.uint16)
         if launch:
             self._launchLog()
         if want_miss:
             self._launchProbs()
+
+    @property
+    def L(self) -> DeviceBuffer | None:
+        """The float64 table [allele][read]; made from the index form on first use when that is what the model holds."""
+        if self._L is None and self.lidx is not None:
+            if self._indexed:
+                self._L = self.dev.alloc((self.n_allele, self.n_rows), np.float64)
+                check(lib().gk_expand_index(self.dev.ctx, self._logs.handle, self.lidx.ptr, self.ldm, self.n_rows,
+                                            self.n_allele, self._L.ptr, self.n_rows))
+            else:       # the library worked on a float64 table of its own (value table beyond 16-bit indices): write ours
+                self._L = self.dev.alloc((self.n_allele, self.n_rows), np.float64)
+                self._launchLog()
+                self.finishLog()
+        return self._L
 
     def _launchLog(self) -> None:
         vbeg, vend, mask, words = self._geom
@@ -466,14 +488,14 @@ class DeviceModel:
 
     @property
     def probs(self) -> DeviceBuffer | None:
-        if self._probs is None and self.L is not None:
+        if self._probs is None and self.n_rows and self.n_allele:
             self._launchProbs()
         return self._probs
 
     def finishLog(self) -> None:
         """Second half of construction: if the kernel met products whose log10 the table did not
         hold yet, the host evaluates them (numpy.log10) and the table is written once more."""
-        if self.L is None or self._known_at_launch < 0:
+        if self._L is None or self._known_at_launch < 0:
             return
         for _ in range(64):
             self.dev.sync()                     # this model's kernel has stored every key it claimed
@@ -579,12 +601,12 @@ class DeviceModel:
         return out
 
     def hostProbs(self) -> np.ndarray:
-        return self.probs.download().reshape(self.n_allele, self.n_rows).T if self.L else np.array([])
+        return self.probs.download().reshape(self.n_allele, self.n_rows).T if self.n_rows and self.n_allele else np.array([])
 
     def hostLogProbs(self) -> np.ndarray:
         return self.L.download().reshape(self.n_allele, self.n_rows).T if self.L else np.array([])
 
     def free(self) -> None:
-        for b in (self._probs, self.L, self.miss, self.nvar, self.miss8, self.msum, self._bound_flags):
+        for b in (self._probs, self._L, self.lidx, self.miss, self.nvar, self.miss8, self.msum, self._bound_flags):
             if b is not None:
                 b.free()

@@ -19,15 +19,40 @@ It is a (max,+) contraction: f64 VALU bound, the HBM figure is reported next to 
 
 ``minsum_sad`` (integer bound of the same step): u8 mismatch counts, 4 reads per v_sad_u8.
 ``compat_kernel``: 4 VALU lane-operations per (id, allele) -- VALU bound (65 % VALU-busy measured), HBM beside it.
+VALU peaks are priced per instruction at the issue cost measured on the device (``ISSUE_CYCLES``), with the guide's
+figure beside them (``GUIDE_CYCLES``).
 ``tab_count``: a byte stream, HBM bound by construction (divergent walk: far below the roof).
 """
 from __future__ import annotations
 
-F64_VALU_PEAK_OPS = 78.6e12 / 2   # v_max_f64 / v_add_f64 issue rate = half the FMA-counted 78.6 TFLOP/s
-# 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one VALU lane-operation per lane and clock
-VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9
 HBM_PEAK_GBS = 8000.0
 TILE = 32
+N_SIMD = 256 * 4
+NOMINAL_HZ = 2.4e9
+
+# Issue cost of the VALU instructions the hot kernels are made of, MEASURED on MI355X with tools/valu_rate.hip at 8 waves
+# per SIMD (profiles/r03_valu_rate.txt): cycles of a 2.4 GHz clock per wave64 instruction and SIMD.  (The shader clock
+# under that load read 2.21 - 2.23 GHz, so 4.5 of these "cycles" are ~4.1 real ones: every VOP3-encoded 32-bit
+# instruction measured costs what a float64 instruction costs; only plain VOP2 forms -- v_mul_f32 2.40, v_and_b32 2.83,
+# v_add_u32 3.02 -- come near the 2 cycles of the guide.)
+ISSUE_CYCLES = {"v_mul_f64": 4.50, "v_add_f64": 4.26, "v_max_f64": 4.19, "v_bfe_i32": 4.43, "v_bfi_b32": 4.56,
+                "v_sad_u8": 4.49}
+# MI355X_MICROARCH.md: "a wave issues each VALU instruction over 2 cycles (32 lanes/cycle x 2)" with >= 2 waves per
+# SIMD (157.3 TFLOP/s fp32 = 78.6 T lane-FMAs/s); float64 at half that rate (78.6 TFLOP/s = 39.3 T lane-FMAs/s)
+GUIDE_CYCLES = {"v_mul_f64": 4.0, "v_add_f64": 4.0, "v_max_f64": 4.0, "v_bfe_i32": 2.0, "v_bfi_b32": 2.0, "v_sad_u8": 2.0}
+# the instructions one algorithmic operation of a kernel cannot do without
+KERNEL_OPS = {
+    "compat_kernel": ("v_bfe_i32", "v_bfi_b32", "v_bfi_b32", "v_mul_f64"),   # per (id, allele): bit -> mask, two halves, product
+    "minsum_sad": ("v_sad_u8",),                                              # per 4 reads, set and allele
+    "maxsum_chunks": ("v_max_f64", "v_add_f64"),                              # per read, set and allele
+}
+
+
+def laneOpsPeak(kernel: str, table: dict[str, float] = ISSUE_CYCLES) -> float:
+    """Lane-operations per second of the whole GPU when the kernel's instruction mix issues back to back at the costs of
+    ``table``: (instructions x 64 lanes x 1024 SIMDs) / (sum of their issue cycles / 2.4 GHz)."""
+    ops = KERNEL_OPS[kernel]
+    return len(ops) * 64 * N_SIMD * NOMINAL_HZ / sum(table[o] for o in ops)
 
 
 def symmetricOutputs(n: int) -> int:
@@ -55,10 +80,11 @@ def minsumLaunch(n_rows: int, n_sets: int, n_cols: int, n_prev_cols: int, symmet
 
 
 def compatLaunch(n_rows: int, n_allele: int, n_ids: float, out_bytes: int = 8) -> tuple[float, float]:
-    """reads the rows' id lists (4 B per id, 16 B of offsets per row), writes the f64 (and u8) table; per id and
-    allele the floor of the per-lane formulation is 4 VALU lane-operations (bit -> mask, two half-word selects of
-    0.999 / 0.001, one f64 multiply: the ordered product cannot be reassociated)."""
-    return 4.0 * n_ids + 16.0 * n_rows + float(out_bytes) * n_rows * n_allele, 4.0 * n_ids * n_allele
+    """reads the rows' id lists (4 B per id, 16 B of offsets per row), writes the table (8 B per entry as float64, 2 B in
+    the index form) and the mismatch byte; per id and allele the floor of the per-lane formulation is 4 VALU
+    lane-operations (bit -> mask, two half-word selects of 0.999 / 0.001, one f64 multiply: the ordered product cannot
+    be reassociated)."""
+    return 4.0 * n_ids + 16.0 * n_rows + float(out_bytes + 1) * n_rows * n_allele, 4.0 * n_ids * n_allele
 
 
 def tabLaunch(n_pairs: int, n_valid: int, n_ids: int) -> tuple[float, float]:
@@ -81,13 +107,13 @@ def _priced(kernel: str, calls: list[tuple]) -> tuple[float, float, str, float]:
             if c[2] == 1 and c[3] == 0:      # column sums (colsum_chunks): one add per element, a pure HBM stream
                 o = 0.0
             else:
-                bound, peak = "valu", F64_VALU_PEAK_OPS
+                bound, peak = "valu", laneOpsPeak("maxsum_chunks")
         elif kernel == "minsum_sad":
             b, o = minsumLaunch(*c[1:6])
-            bound, peak = "valu", VALU_LANE_OPS
+            bound, peak = "valu", laneOpsPeak("minsum_sad")
         elif kernel == "compat_kernel":
             b, o = compatLaunch(*c[1:5])
-            bound, peak = "valu", VALU_LANE_OPS
+            bound, peak = "valu", laneOpsPeak("compat_kernel")
         elif kernel == "tab_count":
             b, o = tabLaunch(*c[1:4])
         elif kernel in ("fraction_chunks", "setsum_chunks"):
@@ -120,11 +146,18 @@ def summarise(call_log: list[tuple], kernel: str, total_ms: float, launches: int
         tops = ops / sec / 1e12
         unit = {"maxsum_chunks": "Tops/s f64 (max+add)", "minsum_sad": "T lane-ops/s (v_sad_u8, 4 reads each)",
                 "compat_kernel": "T lane-ops/s (4 VALU per id and allele)"}.get(kernel, "T lane-ops/s")
+        guide = laneOpsPeak(kernel, GUIDE_CYCLES)
         out.update({"bound": "valu", "achieved": tops, "peak": peak / 1e12, "unit": unit, "frac": ops / sec / peak,
+                    "peak_guide": guide / 1e12, "frac_guide": ops / sec / guide,
+                    "issue_cycles": {o: ISSUE_CYCLES[o] for o in KERNEL_OPS[kernel]},
                     "algorithmic_ops_per_launch": ops / max(launches, 1), "hbm": hbm,
-                    "note": "VALU-issue bound (ordered f64 products / a (max,+) or (min,+) contraction): priced against "
-                            "the vector issue rate, the HBM roof is shown beside it; symmetric launches are credited "
-                            "with the triangle of tiles they compute"})
+                    "note": "VALU-issue bound (ordered f64 products / a (max,+) or (min,+) contraction).  `peak` = the "
+                            "kernel's own instruction mix issued back to back at the MEASURED cost of each instruction "
+                            "(tools/valu_rate.hip at 8 waves per SIMD, profiles/r03_valu_rate.txt: cycles of a 2.4 GHz "
+                            "clock per wave64 instruction and SIMD in `issue_cycles`); `peak_guide` / `frac_guide` price "
+                            "the same mix at the guide's 2 cycles per 32-bit and 4 per float64 instruction.  The HBM "
+                            "roof is shown beside it; symmetric launches are credited with the triangle of tiles they "
+                            "compute"})
     else:
         out.update(hbm)
         out["bound"] = "hbm"

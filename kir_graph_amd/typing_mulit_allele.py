@@ -390,8 +390,10 @@ class AlleleTyping:
         words = max(1, (n_allele + 31) // 32)
         if _mask is None:
             _mask = self._dev.put(buildMask(variants[:n_span], names))
+        import os
         self._model = DeviceModel(tab, rows, n_rows, rs.vflag, _vbeg, _vbeg + n_span, _mask, words, n_allele,
-                                  self._logs, keep_empty=not no_empty, launch=not _defer_launch)
+                                  self._logs, keep_empty=not no_empty, launch=not _defer_launch,
+                                  indexed=_defer_launch and os.environ.get("GK_INDEX_TABLE", "0") == "1")
         self._colsum_all: np.ndarray | None = None
         self._pair_table: np.ndarray | None = None    # scores of all allele pairs (second step), when formed
         self._reads_cache = None
@@ -541,21 +543,23 @@ class AlleleTyping:
         homo = self._isHomozygous(cn) if self.force_homo is None else self.force_homo
         m = self._model
         vbeg, vend, mask, words = m._geom
-        job = GeneJob(d_rows=m.rows.ptr, n_rows=m.n_rows, d_mask=mask.ptr, d_L=m.L.ptr if m.L else 0,
+        job = GeneJob(d_rows=m.rows.ptr, n_rows=m.n_rows, d_mask=mask.ptr, d_L=m._L.ptr if m._L else 0,
                       d_miss8=m.miss8.ptr if m.miss8 else 0, ldm=m.ldm, d_msum=m.msum.ptr if m.msum else 0,
-                      d_flags=m._bound_flags.ptr if m._bound_flags else 0, vbeg=vbeg, vend=vend, words=words,
-                      n_allele=m.n_allele, n_steps=1 if homo else cn, top_n=self.top_n, bound_ok=0, passes=0)
+                      d_flags=m._bound_flags.ptr if m._bound_flags else 0, d_lidx=m.lidx.ptr if m.lidx else 0,
+                      vbeg=vbeg, vend=vend, words=words, n_allele=m.n_allele, n_steps=1 if homo else cn,
+                      top_n=self.top_n, bound_ok=0, passes=0, indexed=0, rsv=0)
         return job, homo
 
     def adoptJob(self, job, handle, cn: int, homo: bool) -> TypingResult:
         """What ``typing(cn)`` leaves behind, from the gene's part of ``gk_sample_search``."""
         m = self._model
         m._bound_ok = bool(job.bound_ok)
+        m._indexed = bool(job.indexed)
         m._known_at_launch = -1
         if m.dev.call_log is not None:
             per_row = m.tab.n_ids / max(m.tab.n_valid, 1)
             for _ in range(max(1, int(job.passes))):
-                m.dev.call_log.append(("compat_kernel", m.n_rows, m.n_allele, per_row * m.n_rows, 8))
+                m.dev.call_log.append(("compat_kernel", m.n_rows, m.n_allele, per_row * m.n_rows, 2 if m._indexed else 8))
         self.result = []
         self._adoptSearch(handle, 1 if homo else cn)
         if homo:

@@ -129,6 +129,9 @@ def _mem_available_gb() -> float:
     return 0.0
 
 
+_BIG = {}      # what test_a_wide_pair_in_a_sample_of_ten_million_pairs needs beside the fixture's tuple
+
+
 @pytest.fixture(scope="module")
 def big(device):
     if _mem_available_gb() < 32:
@@ -136,9 +139,14 @@ def big(device):
     sidx, gidx, sample, rec, table = bench.build_inputs(1031, N_PAIRS_BIG)
     dindex = DeviceIndex(device, gidx)
     mates = device.put(rec)
+    # a few pairs with mismatches, kept on the host for test_a_wide_pair_in_a_sample_of_ten_million_pairs
+    with_mm = np.flatnonzero((rec["n_mm"][0::2] > 0) & (rec["n_mm"][1::2] > 0) & ((rec["flag"][0::2] & 2) != 0))
+    picks = with_mm[[10, len(with_mm) // 2, len(with_mm) - 7]]
+    _BIG["wide_src"] = {int(k): rec[2 * k:2 * k + 2].copy() for k in picks}
     del rec
     tab = Tabulation(dindex, mates)
     data = SampleData(tab, gidx, None, ins_strings=table.strings)
+    _BIG["mates"], _BIG["dindex"] = mates, dindex
     yield sidx, gidx, sample, data
     tab.close()
     mates.free()
@@ -194,3 +202,55 @@ def test_config2_pv_at_20m_reads(big):
             got += sorted(c for c in calls if c.split("*")[0] == g.split("*")[0])
     assert got == [a for g in sample.gene_cn for a in sorted(sample.truth[g])]
     assert warn == []
+
+
+def _toWide(pair_rec):
+    """The two gk_mate records of a pair in the wide format (gk_mate_wide) + the marker records that stay behind."""
+    from kir_graph_amd import _lib
+    wide = np.zeros(2, dtype=_lib.MATE_WIDE_DTYPE)
+    head = np.zeros(2, dtype=_lib.MATE_DTYPE)
+    for side in range(2):
+        r, x = pair_rec[side], wide[side]
+        for f in ("pos0", "flag", "ref", "nh", "nm"):
+            x[f] = r[f]
+            head[side][f] = r[f]
+        x["n_cig"], x["n_mm"], x["n_ins"] = r["n_cig"], r["n_mm"], r["n_ins"]
+        for i in range(int(r["n_cig"])):
+            x["cig"][i] = int(r["cig"][i])                               # len << 4 | op in both formats
+        for i in range(int(r["n_mm"])):
+            x["mm"][i] = (int(r["mm"][i]["ref_off"]) << 8) | int(r["mm"][i]["base"])
+        for i in range(int(r["n_ins"])):
+            x["ins"][i] = int(r["ins"][i])
+        head[side]["n_cig"] = _lib.SPILLED
+    return wide, head
+
+
+def test_a_wide_pair_in_a_sample_of_ten_million_pairs(big, device):
+    """with ONE pair in the wide record format the sequence numbers of novel variants used a stride of
+    384 events per mate in 32 bits, which refused samples above 5.59 M pairs.  First appearances are now ranked from
+    (mate, event) directly: three pairs of this 10 M-pair sample go through the wide format (tab_count_wide /
+    tab_emit_wide) while all others keep the one-walk path (tab_expand), and lists, offsets and the order of the novel
+    variants must be exactly those of the all-narrow tabulation."""
+    sidx, gidx, sample, data = big
+    want_off, want_ids, want_novel = data.tab.offsets(), data.tab.ids(), data.tab.novelKeys()
+    assert data.tab.n_novel > 1000
+    pairs = sorted(_BIG["wide_src"])
+    wide = np.concatenate([_toWide(_BIG["wide_src"][k])[0] for k in pairs])
+    # the marker records replace the pairs' records on the device (a copy of the sample's records: the fixture's stay)
+    from kir_graph_amd._lib import check, lib
+    mates2 = device.alloc(_BIG["mates"].shape, _BIG["mates"].dtype)
+    check(lib().gk_d2d(device.ctx, mates2.ptr, _BIG["mates"].ptr, _BIG["mates"].nbytes))
+    for j, k in enumerate(pairs):
+        head = _toWide(_BIG["wide_src"][k])[1]
+        head["ins"][:, 0] = j                                             # place in the wide array
+        check(lib().gk_h2d(device.ctx, mates2.ptr + 2 * k * head.dtype.itemsize, head.ctypes.data, head.nbytes))
+    tab = Tabulation(_BIG["dindex"], mates2, spill=(wide, np.array(pairs, dtype=np.int64)))
+    try:
+        assert tab.n_valid == data.tab.n_valid and tab.n_ids == data.tab.n_ids and tab.n_novel == data.tab.n_novel
+        assert np.array_equal(tab.offsets(), want_off)
+        assert np.array_equal(tab.novelKeys(), want_novel)                # same novel variants in the same order
+        assert np.array_equal(tab.ids(), want_ids)
+    finally:
+        tab.close()
+        mates2.free()
+

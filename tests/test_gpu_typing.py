@@ -190,3 +190,59 @@ def test_mismatch_table_equals_counts_from_the_lists(device, small_case, monkeyp
         assert np.array_equal(got[:, :n_rows], want)
         assert not got[:, n_rows:].any()
         assert np.array_equal(a.msum.download(), want.sum(axis=1, dtype=np.uint32))
+
+
+def test_index_table_equals_the_float_table(device, small_case, monkeypatch):
+    """The index form of a gene's table (gk_compat_index: uint16 dense indices into the value table, 2 bytes per entry)
+    expands (gk_expand_index) to exactly the float64 table of gk_compat_log_miss, with the same mismatch bytes; a whole
+    sample typed on index tables (GK_INDEX_TABLE=1) gives the bits of the float64 tables (the default) in every field
+    of every copy-number step."""
+    import ctypes as C
+    from kir_graph_amd._lib import check, lib
+    from kir_graph_amd.engine import DeviceModel
+    from kir_graph_amd.hisat2 import extractVariant, pairLines
+    from kir_graph_amd.kir_typing import selectKirTypingModel
+    from kir_graph_amd.typing_mulit_allele import sharedLogTable
+    monkeypatch.setenv("GK_SEARCH", "bound")
+    sidx, gidx, sample = small_case
+    data = extractVariant(pairLines(synth.toSamLines(sample)), gidx, dev=device)
+    tab, logs = data.tab, sharedLogTable(device)
+    for g, t in enumerate(gidx.tables):
+        rows, n_rows = tab.selectGene(g, False)
+        if not n_rows:
+            continue
+        vflag = device.alloc(max(tab.n_var_total, 1), np.uint8).zero()
+        a = DeviceModel(tab, rows, n_rows, vflag, t.vbeg, t.vend, tab.dindex.masks[g], t.words, t.n_allele, logs)
+        a.finishLog()                                   # every value of the gene is defined from here on
+        lidx = device.alloc((t.n_allele, a.ldm), np.uint16)
+        miss8 = device.alloc((t.n_allele, a.ldm), np.uint8)
+        flags = device.alloc(1, np.uint32)
+        check(lib().gk_compat_index(device.ctx, tab.handle, rows.ptr, n_rows, vflag.ptr, t.vbeg, t.vend,
+                                    tab.dindex.masks[g].ptr, t.words, t.n_allele, 0, logs.handle, lidx.ptr, miss8.ptr,
+                                    a.ldm, flags.ptr))
+        back = device.alloc((t.n_allele, n_rows), np.float64)
+        check(lib().gk_expand_index(device.ctx, logs.handle, lidx.ptr, a.ldm, n_rows, t.n_allele, back.ptr, n_rows))
+        assert int(flags.download()[0]) == int(a._bound_flags.download()[0]) == 0
+        idx = lidx.download().reshape(t.n_allele, a.ldm)[:, :n_rows]
+        assert idx.max() < 0xFFFF                         # nothing undefined, nothing beyond 16 bits
+        assert np.array_equal(back.download(), a.L.download())
+        assert np.array_equal(miss8.download(), a.miss8.download())
+    gene_cn = {g: (k % 4) + 1 for k, g in enumerate(sidx.genes)}
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GK_INDEX_TABLE", mode)
+        typer = selectKirTypingModel("full", data, top_n=600, variant_correction=True)
+        calls = typer.typing(gene_cn)
+        results[mode] = (calls, typer._result, typer)
+    models = [steps[-1].allele_prob.parts[0][0] for steps in results["1"][1].values() if steps]
+    assert models and all(m._indexed and m._L is None for m in models)      # the index form really was what ran
+    assert results["1"][0] == results["0"][0]
+    for gene, want in results["0"][1].items():
+        for x, y in zip(results["1"][1][gene], want):
+            for f in ("value", "value_sum_indv", "allele_id", "fraction"):
+                assert np.array_equal(np.asarray(getattr(x, f)), np.asarray(getattr(y, f))), (gene, f)
+    # the float64 form is made on demand from the indices (allele_prob / log_probs readers)
+    m = models[0]
+    assert m.L is not None and np.array_equal(np.asarray(results["1"][1][next(iter(results["1"][1]))][-1].allele_prob),
+                                             np.asarray(results["0"][1][next(iter(results["0"][1]))][-1].allele_prob))
+

@@ -142,7 +142,6 @@ int main() {
     run<6>("v_mul_f32 (VOP2)", 8, w);
     run<13>("v_fma_f32 (VOP3)", 8, w);
     run<14>("v_and_b32 (VOP2)", 8, w);
-    run<15>("v_cndmask_b32 (VOP2, vcc)", 8, w);
     run<11>("v_add_u32", 8, w);
     run<7>("v_bfi_b32", 8, w);
     run<8>("v_bfe_i32", 8, w);
