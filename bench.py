@@ -363,7 +363,9 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
     serial = None
     if args.serial_steps > 0 and rank == 0:
         keep = os.environ.get("GK_THREADS")
+        keep_streams = os.environ.get("GK_SAMPLE_STREAMS")
         os.environ["GK_THREADS"] = "1"
+        os.environ["GK_SAMPLE_STREAMS"] = "1"       # one stream: the kernels of a sample run back to back
         try:
             run_steps(1, dev, dindex, gidx, inputs, args.method, depth=0)      # contexts of this mode warm
             profiled(True)
@@ -377,10 +379,11 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
             serial = {"prof": s_prof, "call_log": s_log, "steps": args.serial_steps,
                       "ms_per_step": 1e3 * s_elapsed / args.serial_steps}
         finally:
-            if keep is None:
-                del os.environ["GK_THREADS"]
-            else:
-                os.environ["GK_THREADS"] = keep
+            for name, val in (("GK_THREADS", keep), ("GK_SAMPLE_STREAMS", keep_streams)):
+                if val is None:
+                    os.environ.pop(name, None)
+                else:
+                    os.environ[name] = val
     from kir_graph_amd.typing_mulit_allele import SEARCH_STATS, sharedLogTable
     n_values = sharedLogTable(dev).known()      # distinct probabilities met so far = entries of the log10 value table
     return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm, "n_values": n_values,
@@ -558,8 +561,8 @@ def main():
                      for k, (n, ms) in sorted(s_prof.items(), key=lambda kv: -kv[1][1])}
             out["kernels_serial"] = {"ms_per_step_wall": serial["ms_per_step"],
                                      "kernel_ms_per_step": sum(v[1] for v in s_prof.values()) / steps,
-                                     "mode": "one process, one gene thread, no prefetch (GK_PROCS_PER_GPU=1 GK_THREADS=1 "
-                                             "GK_PREFETCH=0): kernels run back to back",
+                                     "mode": "one process, one sample at a time on one stream, no prefetch (GK_PROCS_PER_GPU=1 "
+                                             "GK_SAMPLE_LANES=1 GK_SAMPLE_STREAMS=1 GK_PREFETCH=0): kernels run back to back",
                                      "kernels": table}
             out["roofline"] = roofmodel.dominant(s_prof, serial["call_log"])
         else:

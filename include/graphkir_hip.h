@@ -305,7 +305,9 @@ int gk_search_run(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, int32_t 
  * typing_mulit_allele.py:340-381 for the table and 478-598 for the search).  The genes advance in lock-step on the
  * calling thread and the context's ONE stream: compatibility tables of every gene, one wait; column sums of every gene,
  * one wait; then step 2, 3, ... of every gene that has one -- bound, wait, exact sums of the selections, wait, ranking.
- * A sample costs about ten stream synchronisations whatever its number of genes, so one host thread feeds the GPU.
+ * A sample costs about ten waits whatever its number of genes, so one host thread feeds the GPU.  more_ctx (may be
+ * NULL): further contexts of the calling thread on the same GPU -- every gene queues its work on one of them, so the
+ * kernels of different genes overlap; a wait then covers all of them.
  * A job names the gene's rows (after error correction / empty-read removal: gk_sample_prepare), its variant span and
  * bit rows, and the tables the caller allocated: d_L double [n_allele][n_rows] -- or d_lidx for the index form
  * (2 bytes per entry instead of 8: the sums gather the float64 from the value table) --; optionally d_miss8 u8
@@ -328,8 +330,8 @@ typedef struct gk_gene_job {
   int32_t bound_ok, passes; /* out */
   int32_t indexed, rsv;     /* out: d_lidx holds the table (0: the value table outgrew 16-bit indices, the call worked on a float64 table of its own) */
 } gk_gene_job;
-int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_gene_job* jobs, int32_t n_jobs,
-                     gk_argsort_fn argsort, gk_log10_fn log10_fn, gk_search** out);
+int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut,
+                     gk_gene_job* jobs, int32_t n_jobs, gk_argsort_fn argsort, gk_log10_fn log10_fn, gk_search** out);
 int gk_search_steps(gk_search* s, int32_t* n_steps);
 int gk_search_info(gk_search* s, int32_t step, int32_t* n, int64_t* rows, int32_t* bounded);
 int gk_search_copy(gk_search* s, int32_t step, double* value, double* sum_indv, int32_t* ids, double* frac);

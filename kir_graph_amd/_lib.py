@@ -183,8 +183,8 @@ _SIGS = {
     "gk_search_run": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_int64,
                                 C.c_uint64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                 C.POINTER(C.c_void_p)]),
-    "gk_sample_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
-                                   C.c_void_p, C.c_void_p]),
+    "gk_sample_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gk_lut_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32)]),
     "gk_lut_known": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),

@@ -564,16 +564,24 @@ int gk_search_run(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, int32_t 
   return GK_OK;
 }
 
-/* The searches of ALL genes of a sample in lock-step on the calling thread and ONE stream: the compatibility tables,
+/* The searches of ALL genes of a sample in lock-step on the calling thread (one stream per context handed in): the compatibility tables,
  * then the column sums, then step 2, 3, ... of every gene that has one -- each phase is queued for every gene before
  * ONE wait, so a sample costs about ten stream synchronisations instead of several per gene and step, and one host
  * thread keeps the GPU fed (typing_mulit_allele.py:340-381 + 478-598 per gene; kir_typing.py:103-132 is the gene loop).
  * jobs[i] describes gene i (tables allocated by the caller); out[i] receives its search (gk_search_*), NULL for a
  * gene without rows.  `log10_fn` = numpy.log10 (value table, see gk_lut_resolve), `argsort` = numpy.argsort. */
-int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_gene_job* jobs, int32_t n_jobs,
-                     gk_argsort_fn argsort, gk_log10_fn log10_fn, gk_search** out) {
+int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut,
+                     gk_gene_job* jobs, int32_t n_jobs, gk_argsort_fn argsort, gk_log10_fn log10_fn, gk_search** out) {
   gk_bind(ctx);
   GK_REQUIRE(ctx && tab && lut && jobs && argsort && log10_fn && out && n_jobs >= 0, "null pointer");
+  GK_REQUIRE(n_more >= 0 && (n_more == 0 || more_ctx), "bad context list");
+  // the calling thread's contexts: gene i queues everything it does on ONE of them (its stream, its staging, its pool),
+  // so the kernels of different genes overlap on the GPU while the host still makes one pass and one wait per phase
+  std::vector<gk_ctx*> cx{ctx};
+  for (int k = 0; k < n_more; ++k) {
+    GK_REQUIRE(more_ctx[k] && more_ctx[k]->device == ctx->device, "contexts of one call share a device");
+    cx.push_back(more_ctx[k]);
+  }
   for (int i = 0; i < n_jobs; ++i) out[i] = nullptr;
   std::vector<int> live;
   for (int i = 0; i < n_jobs; ++i) {
@@ -591,6 +599,19 @@ int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_
   }
   if (live.empty()) return GK_OK;
   int rc = GK_OK;
+  std::vector<gk_ctx*> ctx_of((size_t)n_jobs, ctx);
+  {
+    std::vector<int> by_size(live);      // largest tables first, dealt round-robin: the streams carry similar loads
+    std::stable_sort(by_size.begin(), by_size.end(), [&](int x, int y) {
+      return jobs[x].n_rows * jobs[x].n_allele > jobs[y].n_rows * jobs[y].n_allele;
+    });
+    for (size_t k = 0; k < by_size.size(); ++k) ctx_of[by_size[k]] = cx[k % cx.size()];
+  }
+  auto wait_all = [&]() {
+    int worst = GK_OK;
+    for (gk_ctx* c : cx) { const int r = wait_stream(c); if (r) worst = r; }
+    return worst;
+  };
   // GK_SEARCH_TIMING=1: where the calling thread spends the call (host work between the waits / the waits themselves)
   static const bool timing = getenv("GK_SEARCH_TIMING") != nullptr;
   using clk = std::chrono::steady_clock;
@@ -617,23 +638,24 @@ int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_
     if (rc) return rc;
     for (int i : live) {
       gk_gene_job& j = jobs[i];
+      gk_ctx* const gc = ctx_of[i];
       j.passes++;
       if (j.d_lidx && !j.d_L) {
-        rc = gk_compat_index(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
+        rc = gk_compat_index(gc, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
                              j.d_lidx, j.d_miss8, j.ldm, j.d_flags);
-        if (rc == GK_OK) rc = gk_miss_colsum(ctx, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
-        if (rc == GK_OK && gk_fetch_queue(ctx, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
+        if (rc == GK_OK) rc = gk_miss_colsum(gc, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
+        if (rc == GK_OK && gk_fetch_queue(gc, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
       } else if (j.d_miss8) {
-        rc = gk_compat_log_miss(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
+        rc = gk_compat_log_miss(gc, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
                                 j.d_L, j.d_miss8, j.ldm, j.d_flags);
-        if (rc == GK_OK) rc = gk_miss_colsum(ctx, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
-        if (rc == GK_OK && gk_fetch_queue(ctx, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
+        if (rc == GK_OK) rc = gk_miss_colsum(gc, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
+        if (rc == GK_OK && gk_fetch_queue(gc, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
       } else {
-        rc = gk_compat_log(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut, j.d_L);
+        rc = gk_compat_log(gc, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut, j.d_L);
       }
       if (rc) return rc;
     }
-    lap(false); rc = wait_stream(ctx); lap(true);          // every key these kernels claimed is stored
+    lap(false); rc = wait_all(); lap(true);          // every key these kernels claimed is stored
     if (rc) return rc;
     int32_t n_new = 0, n_known = 0, n_undefined = 0;
     rc = gk_lut_resolve(lut, log10_fn, &n_new, &n_known, &n_undefined);
@@ -648,22 +670,23 @@ int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_
   std::vector<void*> own_L((size_t)n_jobs, nullptr);
   auto fail = [&](int code) {
     for (auto& g : gs) if (g) g->abandon();
-    for (void* p : own_L) gk_pool_free(ctx, p);
+    for (int i = 0; i < n_jobs; ++i) gk_pool_free(ctx_of[i], own_L[i]);
     return code;
   };
   for (int i : live) {
     gk_gene_job& j = jobs[i];
     j.indexed = (j.d_lidx && !j.d_L && !(flags[i] & 2u)) ? 1 : 0;
     if (j.d_lidx && !j.d_L && !j.indexed) {
-      if (gk_pool_malloc(ctx, &own_L[i], (size_t)j.n_allele * (size_t)j.n_rows * sizeof(double)) != hipSuccess) {
+      gk_ctx* const gc = ctx_of[i];
+      if (gk_pool_malloc(gc, &own_L[i], (size_t)j.n_allele * (size_t)j.n_rows * sizeof(double)) != hipSuccess) {
         gk_set_error("out of device memory for the float64 table of a gene");
         return fail(GK_ERR_HIP);
       }
-      rc = gk_compat_log_miss(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
+      rc = gk_compat_log_miss(gc, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
                               gk_addr(own_L[i]), j.d_miss8, j.ldm, j.d_flags);
-      if (rc == GK_OK) rc = gk_miss_colsum(ctx, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
-      if (rc == GK_OK && gk_fetch_queue(ctx, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
-      if (rc == GK_OK) rc = wait_stream(ctx);
+      if (rc == GK_OK) rc = gk_miss_colsum(gc, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
+      if (rc == GK_OK && gk_fetch_queue(gc, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
+      if (rc == GK_OK) rc = wait_stream(gc);
       if (rc) return fail(rc);
       j.passes++;
     }
@@ -677,12 +700,12 @@ int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_
     gs[i].reset(new GeneSearch());
     const gk_dptr d_L = own_L[i] ? gk_addr(own_L[i]) : j.d_L;
     const GkTable tbl = j.indexed ? GkTable{j.d_lidx, j.ldm, lut->d_vals} : GkTable{d_L, j.n_rows, nullptr};
-    rc = gs[i]->init(ctx, tbl, j.indexed ? 0 : d_L, j.n_rows, j.n_rows, j.n_allele, j.bound_ok ? j.d_miss8 : 0, j.ldm,
+    rc = gs[i]->init(ctx_of[i], tbl, j.indexed ? 0 : d_L, j.n_rows, j.n_rows, j.n_allele, j.bound_ok ? j.d_miss8 : 0, j.ldm,
                      j.bound_ok ? j.d_msum : 0, cols.data(), j.n_allele, j.n_steps, j.top_n, argsort);
     if (rc == GK_OK) rc = gs[i]->colsum_enqueue();
     if (rc) return fail(rc);
   }
-  lap(false); rc = wait_stream(ctx); lap(true);
+  lap(false); rc = wait_all(); lap(true);
   if (rc) return fail(rc);
   for (int i : live) {
     gs[i]->colsum_collect();
@@ -695,10 +718,10 @@ int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_
     for (int i : live) if (gs[i]->more()) todo.push_back(i);
     if (todo.empty()) break;
     for (int i : todo) { rc = gs[i]->step_begin(); if (rc) return fail(rc); }
-    lap(false); rc = wait_stream(ctx); lap(true);
+    lap(false); rc = wait_all(); lap(true);
     if (rc) return fail(rc);
     for (int i : todo) { rc = gs[i]->after_bound(); if (rc) return fail(rc); }
-    lap(false); rc = wait_stream(ctx); lap(true);
+    lap(false); rc = wait_all(); lap(true);
     if (rc) return fail(rc);
     for (int i : todo) { rc = gs[i]->after_sums(); if (rc) return fail(rc); }
     for (int i : todo) {
@@ -710,7 +733,7 @@ int gk_sample_search(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_
     gs[i]->finish();
     out[i] = gs[i]->S.release();
   }
-  for (void* p : own_L) gk_pool_free(ctx, p);
+  for (int i = 0; i < n_jobs; ++i) gk_pool_free(ctx_of[i], own_L[i]);
   lap(false);
   return GK_OK;
 }

@@ -50,9 +50,16 @@ static inline LutView gk_lut_view(const gk_lut* l) {
                  (uint32_t)((1ull << l->log2cap) - 1), (uint32_t)l->n_known};
 }
 
+// slot of a probability's bit pattern: the low mantissa word of a product of 0.999 / 0.001 factors is as good as random
+// already, so one 32-bit multiply mixes it (two 64-bit multiplies -- eight quarter-rate instructions -- per lookup were
+// a measurable part of the compatibility kernel's epilogue)
 __device__ inline uint32_t gk_hash64(uint64_t k) {
-  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-  return (uint32_t)k;
+  const uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+  uint32_t h = lo ^ (hi << 11) ^ (hi >> 7);
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
+  return h;
 }
 
 // insert `k` if absent (open addressing, first writer assigns the dense index)

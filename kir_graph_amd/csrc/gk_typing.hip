@@ -300,13 +300,16 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
 #pragma unroll
         for (int w = 0; w < kPassWords; ++w) wrows[lane * kPassWords + w] = mrow[w];
         __builtin_amdgcn_wave_barrier();   // LDS operations of a wave are executed in order
-        const uint32_t* const my_words = wrows + (lane >> 5);
+        // this lane's word of variant t and slot s: a 32-bit LDS index (wave's base + the lane's half) + a scalar t * stride
+        const int my_word0 = wid * (64 * kPassWords) + (lane >> 5);
         const int my_bit = lane & 31;
         // one variant's words for the lane's slots / the factor they select; the walk reads the words of the
         // next kept variant before it multiplies the current one in (two register sets, no copies)
         auto fetch = [&](int t, uint32_t (&w)[kSlots]) {
+          int t_off;      // t * words per variant, on the scalar unit (the compiler would otherwise spend a 64-bit VALU multiply-add on it)
+          asm("s_mul_i32 %0, %1, %2" : "=s"(t_off) : "s"(t), "n"(kPassWords));
 #pragma unroll
-          for (int s = 0; s < kSlots; ++s) w[s] = my_words[t * kPassWords + 2 * s];
+          for (int s = 0; s < kSlots; ++s) w[s] = (&wave_rows[0][0])[my_word0 + t_off + 2 * s];
         };
         auto apply = [&](const uint32_t (&w)[kSlots], bool positive) {
 #pragma unroll

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the round's evidence under gpurun_out/rNN (run on the GPU box through gpurun); the summaries that are
 # judged are then copied into profiles/ in the build container: bash tools/install_profiles.sh <tag>.
-#   bash tools/collect_profiles.sh [round tag, default r02]
+#   bash tools/collect_profiles.sh [round tag, default r03]
 set -e
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -14,7 +14,7 @@ echo "[collect] bench done"
 # 2. the roofline basis under rocprofv3: ONE process, ONE gene thread, no prefetch -- kernels back to back, the
 #    same mode as the bench's own serial pass (children are not allowed under the profiler on this pool)
 cd /tmp && export TMPDIR=/tmp
-export GK_PROCS_PER_GPU=1 GK_THREADS=1 GK_PREFETCH=0
+export GK_PROCS_PER_GPU=1 GK_THREADS=1 GK_PREFETCH=0 GK_SAMPLE_LANES=1 GK_SAMPLE_STREAMS=1
 SERIAL="python3 $R/bench.py --cpu-pairs 0 --steps 6 --warmup 2 --serial-steps 2"
 rocprofv3 --kernel-trace --stats -d $O/stats -o b --output-format csv -- $SERIAL > $O/bench_under_rocprof.json 2> $O/stats.err
 echo "[collect] kernel stats done"

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Copies the summaries that tools/collect_profiles.sh left under gpurun_out/<tag> (merged back by gpurun) into
-# profiles/ under the names DESIGN.md and profiles/README.md cite.   bash tools/install_profiles.sh [tag, default r02]
+# profiles/ under the names DESIGN.md and profiles/README.md cite.   bash tools/install_profiles.sh [tag, default r03]
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/$TAG
 cp $O/bench.json $R/profiles/${TAG}_bench.json
