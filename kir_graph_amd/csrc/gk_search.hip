@@ -376,18 +376,14 @@ __global__ __launch_bounds__(kThreads) void combine_chunks(const double* __restr
 // workgroup.  The host orders the sets so that neighbours share alleles and hands every tile of 32
 // sets the list of its distinct columns; the workgroup stages those columns through LDS in blocks
 // of 32 rows (coalesced 256-byte runs) instead of every set reading its own columns from L2.
-// A workgroup is ONE wavefront (8 sets): the kernel is bound by the latency of its staging loads (L2), and what hides it
-// is wavefronts in flight -- 32 per CU at ~3 KB of LDS each, none of them waiting at a workgroup barrier for the
-// slowest of four (the 256-thread form of round 2 ran at 12 - 16 wavefronts per CU with two barriers per 32 rows).
-constexpr int kFracThreads = 64;
-constexpr int kFracSets = kFracThreads / 8;   // sets per workgroup
+constexpr int kFracSets = kThreads / 8;   // sets per workgroup
 constexpr int kFracRows = 32;             // staged rows per block (4 row-steps of the 8 lanes)
 constexpr int kFracLd = kFracRows + 9;    // + up to 7 tail rows of the leaf, odd stride
 
 // kValue: the set's likelihood sum_r max_j L[r, ids[k][j]] (typing_mulit_allele.py:540-542 for ONE set) rides along as
 // one more accumulator -- same terms, same tree, hence the bits of maxsum_chunks -- and is stored after the shares.
 template <int kC, bool kValue, typename TL>
-__global__ __launch_bounds__(kFracThreads) void fraction_chunks(TableView<TL> L, int64_t ld,
+__global__ __launch_bounds__(kThreads) void fraction_chunks(TableView<TL> L, int64_t ld,
                                                             const int32_t* __restrict__ tile_col_off,
                                                             const int32_t* __restrict__ tile_cols,
                                                             const int32_t* __restrict__ local_idx,
@@ -445,12 +441,12 @@ __global__ __launch_bounds__(kFracThreads) void fraction_chunks(TableView<TL> L,
       const int rows_in = min(kFracRows, n8 - b0);          // <= 0 when the leaf is all tail
       const bool last = sb + 1 == n_blocks;
       __syncthreads();
-      for (int idx = tid; idx < n_dist * kFracRows; idx += kFracThreads) {
+      for (int idx = tid; idx < n_dist * kFracRows; idx += kThreads) {
         const int col = idx >> 5, r = idx & (kFracRows - 1);
         if (r < rows_in) fbuf[col * kFracLd + r] = L.at((int64_t)cols[col] * ld + r0 + b0 + r);
       }
       if (last) {   // sequential tail rows n8 .. len (all rows of a leaf shorter than 8)
-        for (int idx = tid; idx < n_dist * 8; idx += kFracThreads) {
+        for (int idx = tid; idx < n_dist * 8; idx += kThreads) {
           const int col = idx >> 3, r = n8 + (idx & 7);
           if (r < len) fbuf[col * kFracLd + kFracRows + (idx & 7)] = L.at((int64_t)cols[col] * ld + r0 + r);
         }
@@ -927,7 +923,7 @@ int gk_shares_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32
       GK_HIP(hipFuncSetAttribute((const void*)fraction_chunks<C, V, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  (int)lds));                                                                         \
     GK_PROF(ctx, GK_K_FRACTION,                                                                                      \
-            GK_KERNEL((fraction_chunks<C, V, TL>), grid, dim3(kFracThreads), lds, st, VIEW, ld, dp.ids, dp.ids + o_cols, \
+            GK_KERNEL((fraction_chunks<C, V, TL>), grid, dim3(kThreads), lds, st, VIEW, ld, dp.ids, dp.ids + o_cols, \
                       dp.ids + o_local, dp.ids + o_perm, n_sets, dp.spans, dp.leaves, d_partial));                   \
   }
 #define GK_FRAC_LAUNCH_V(C, V)                                                                          \
