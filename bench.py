@@ -80,6 +80,20 @@ def pin_rank(local_rank: int, k: int) -> list[int]:
     return sorted(set(mine))
 
 
+def pin_all_threads(cores) -> int:
+    """Apply the rank's core set to EVERY thread this process has by now: the HIP / ROCr runtime starts helper threads
+    (signal and event handling) that do not keep the mask they inherit -- without this a rank pinned to 2 cores showed
+    2.8 cores busy.  Called after the warm-up, when those threads exist.  Returns the number of threads bound."""
+    n = 0
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(tid), set(cores))
+            n += 1
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_seconds() -> float:
     """User + system time of this process (all its threads) so far."""
     import resource
@@ -320,6 +334,8 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
     n_valid = 0
     if args.warmup:
         n_valid = run_steps(args.warmup, dev, dindex, gidx, inputs, args.method)[2]
+    if getattr(args, "pinned_to", None):      # --cores-per-gpu: the runtime's own threads too (they exist by now)
+        pin_all_threads(args.pinned_to)
     if j == 0 and getattr(args, "profile_host", False):
         import cProfile
         import pstats
@@ -448,6 +464,7 @@ def main():
         sys.exit(2)
     cores_before = allowed_cores()
     pinned = pin_rank(local_rank, args.cores_per_gpu) if args.cores_per_gpu > 0 else None
+    args.pinned_to = pinned          # handed to the workers (vars(args)): they bind the runtime's threads after the warm-up
     # Worker processes of this rank on its GPU (see worker()): started first, before anything touches HIP.
     # A sample is typed by ONE host thread on one stream (gk_sample_search: all genes in lock-step, ~10 waits), two
     # samples at a time per process (GK_SAMPLE_LANES) plus the ingest thread; two such processes keep the GPU fed from

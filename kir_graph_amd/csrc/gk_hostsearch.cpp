@@ -630,8 +630,25 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
     const bool on; double& h; double& w; int& n; int jobs;
     ~Report() { if (on) fprintf(stderr, "[gk_sample_search] %d genes: host %.2f ms, waits %.2f ms in %d waits\n", jobs, h, w, n); }
   } report{timing, t_host, t_wait, n_wait, (int)live.size()};
-  // ---- phase 0: the compatibility tables (log-likelihoods through the value table + mismatch counts)
+  // ---- phase 0: the compatibility tables (log-likelihoods through the value table + mismatch counts); a float64 table's
+  // column sums are queued right behind the kernel that writes it -- the table is still in the Infinity Cache then, which
+  // it is not any more once the tables of all genes (1.3 GB for a configs[1] sample) have been written
   std::vector<uint32_t> flags((size_t)n_jobs, 0);
+  std::vector<std::unique_ptr<GeneSearch>> gs((size_t)n_jobs);
+  std::vector<char> sums_queued((size_t)n_jobs, 0);
+  auto start_search = [&](int i, gk_dptr d_L, bool indexed) {       // the gene's search object + its column sums, queued
+    gk_gene_job& j = jobs[i];
+    std::vector<int32_t> cols((size_t)j.n_allele);
+    std::iota(cols.begin(), cols.end(), 0);
+    if (gs[i]) gs[i]->abandon();                                    // a pass that is being repeated: its sums are void
+    gs[i].reset(new GeneSearch());
+    const GkTable tbl = indexed ? GkTable{j.d_lidx, j.ldm, lut->d_vals} : GkTable{d_L, j.n_rows, nullptr};
+    int r = gs[i]->init(ctx_of[i], tbl, indexed ? 0 : d_L, j.n_rows, j.n_rows, j.n_allele, j.d_miss8, j.ldm, j.d_msum,
+                        cols.data(), j.n_allele, j.n_steps, j.top_n, argsort);
+    if (r == GK_OK) r = gs[i]->colsum_enqueue();
+    sums_queued[i] = r == GK_OK;
+    return r;
+  };
   for (int pass = 0; pass < 64; ++pass) {
     int32_t known_at_launch = 0;
     rc = gk_lut_known(lut, &known_at_launch);
@@ -650,21 +667,26 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
                                 j.d_L, j.d_miss8, j.ldm, j.d_flags);
         if (rc == GK_OK) rc = gk_miss_colsum(gc, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
         if (rc == GK_OK && gk_fetch_queue(gc, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
+        if (rc == GK_OK) rc = start_search(i, j.d_L, false);
       } else {
         rc = gk_compat_log(gc, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut, j.d_L);
+        if (rc == GK_OK) rc = start_search(i, j.d_L, false);
       }
-      if (rc) return rc;
+      if (rc) { for (auto& g : gs) if (g) g->abandon(); return rc; }
     }
     lap(false); rc = wait_all(); lap(true);          // every key these kernels claimed is stored
-    if (rc) return rc;
+    if (rc) { for (auto& g : gs) if (g) g->abandon(); return rc; }
     int32_t n_new = 0, n_known = 0, n_undefined = 0;
     rc = gk_lut_resolve(lut, log10_fn, &n_new, &n_known, &n_undefined);
-    if (rc) return rc;
+    if (rc) { for (auto& g : gs) if (g) g->abandon(); return rc; }
     if (n_known > known_at_launch) continue;    // some values were undefined at launch: write the tables again
     if (n_undefined == 0) break;                // every value these launches met had its log10 in the table
-    if (pass == 63) { gk_set_error("log10 value table did not settle"); return GK_ERR_ASSERT; }
+    if (pass == 63) {
+      for (auto& g : gs) if (g) g->abandon();
+      gk_set_error("log10 value table did not settle");
+      return GK_ERR_ASSERT;
+    }
   }
-  std::vector<std::unique_ptr<GeneSearch>> gs((size_t)n_jobs);
   // a gene whose indices do not fit 16 bits (the value table holds more than 65535 values) takes the float64 form, in a
   // block of this call's own; every value is defined by now, so one pass writes it
   std::vector<void*> own_L((size_t)n_jobs, nullptr);
@@ -691,22 +713,22 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
       j.passes++;
     }
   }
-  // ---- phase 1: column sums of every gene, first step
+  // ---- phase 1: the column sums that are not queued yet (index tables, float64 tables of this call's own), first step
+  bool late = false;
   for (int i : live) {
     gk_gene_job& j = jobs[i];
     j.bound_ok = (j.d_miss8 && (flags[i] & 1u) == 0) ? 1 : 0;
-    std::vector<int32_t> cols((size_t)j.n_allele);
-    std::iota(cols.begin(), cols.end(), 0);
-    gs[i].reset(new GeneSearch());
-    const gk_dptr d_L = own_L[i] ? gk_addr(own_L[i]) : j.d_L;
-    const GkTable tbl = j.indexed ? GkTable{j.d_lidx, j.ldm, lut->d_vals} : GkTable{d_L, j.n_rows, nullptr};
-    rc = gs[i]->init(ctx_of[i], tbl, j.indexed ? 0 : d_L, j.n_rows, j.n_rows, j.n_allele, j.bound_ok ? j.d_miss8 : 0, j.ldm,
-                     j.bound_ok ? j.d_msum : 0, cols.data(), j.n_allele, j.n_steps, j.top_n, argsort);
-    if (rc == GK_OK) rc = gs[i]->colsum_enqueue();
+    if (!sums_queued[i]) {
+      rc = start_search(i, own_L[i] ? gk_addr(own_L[i]) : j.d_L, j.indexed != 0);
+      if (rc) return fail(rc);
+      late = true;
+    }
+    if (!j.bound_ok) gs[i]->bound = false;        // a mismatch count near the underflow range / a very long row: exact steps
+  }
+  if (late) {
+    lap(false); rc = wait_all(); lap(true);
     if (rc) return fail(rc);
   }
-  lap(false); rc = wait_all(); lap(true);
-  if (rc) return fail(rc);
   for (int i : live) {
     gs[i]->colsum_collect();
     rc = gs[i]->first_step();

@@ -121,7 +121,10 @@ def _mapLoop(names, prepare, ahead, gk, gene_len, dev, dindex, index_ref, exon_r
             # the reference also rewrites the filtered pairs as BAM (hisat2.py:936-940)
             saveReadsToBam(data, name, source)
             saveReadsToBam(data, name + ".no_multi", source, filter_multi_mapped=True)
-        else:   # compact hand-off instead: CSR + string table, no SAM text (hisat2.writeCompact)
+        elif os.environ.get("GK_HANDOFF", "always") != "lazy":
+            # compact hand-off instead: CSR + string table, no SAM text (hisat2.writeCompact).  GK_HANDOFF=lazy: only
+            # for a sample that has to leave HBM before it is typed (main(): the --cn-cohort retention budget) -- a
+            # cohort of 64 x 5 M reads would otherwise leave 42 GB of files that nothing reads
             writes.append(writeCompact(data, name + ".npz", index_ref=index_ref, background=writer))
         depth_name = name + ".no_multi"
         logger.info(f"[Graph] Calculate read depth to {depth_name}.depth.tsv")
@@ -327,7 +330,9 @@ def _runCohort(args, names, reads, cn_files, index, index_ref, cohort_name, comm
             size = 4 * (data.tab.n_ids + 4 * data.tab.n_valid) + 6 * data.tab.n_valid
             if not args.step_skip_typing and retained + size > budget:
                 if args.no_variant_json:
-                    parked = name + ".npz"          # already written by mapSamples
+                    parked = name + ".npz"          # already written by mapSamples, unless hand-off files are lazy
+                    if os.environ.get("GK_HANDOFF", "always") == "lazy":
+                        writeCompact(data, parked, index_ref=index_ref)
                 else:
                     parked = name + ".json"
                 data.tab.close()

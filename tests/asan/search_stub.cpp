@@ -87,8 +87,10 @@ void gk_bound_collect(gk_ctx*, GkBoundCall& call, uint32_t* hdr_out, int32_t* id
   std::copy(t_bound.mm.begin(), t_bound.mm.begin() + n, m_out);
 }
 
-int gk_shares_enqueue(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* ids, int32_t n_sets, int32_t c,
+int gk_shares_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32_t* ids, int32_t n_sets, int32_t c,
                       bool with_value, GkSumCall& call) {
+  const gk_dptr d_L = L.d;
+  const int64_t ld = L.ld;
   call.n_sets = n_sets; call.c = c; call.with_value = with_value;
   call.back.assign((size_t)n_sets * (c + 1), 0.0);          // [values | shares]
   double* value = call.back.data();
@@ -101,12 +103,14 @@ void gk_shares_collect(gk_ctx*, GkSumCall& call, double* value_out, double* frac
   if (frac_out) std::copy(call.back.begin() + call.n_sets, call.back.end(), frac_out);
 }
 
-int gk_colsum_enqueue(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_t* cols, int32_t n_cols,
+int gk_colsum_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32_t* cols, int32_t n_cols,
                       GkSumCall& call) {
   call.back.assign((size_t)n_cols, 0.0);
-  return gk_maxsum(ctx, d_L, n_rows, ld, nullptr, 1, 0, cols, n_cols, call.back.data());
+  return gk_maxsum(ctx, L.d, n_rows, L.ld, nullptr, 1, 0, cols, n_cols, call.back.data());
 }
 void gk_colsum_collect(gk_ctx*, GkSumCall& call, double* out) { std::copy(call.back.begin(), call.back.end(), out); }
+int gk_expand_table(gk_ctx*, const GkTable&, int64_t, int32_t, gk_dptr, int64_t) { return GK_ERR_NO_DEVICE; }   // index tables: device only
+hipError_t gk_pool_malloc(gk_ctx*, void**, size_t) { return hipErrorOutOfMemory; }
 
 // gk_sample_search's table phase has no CPU stand-in (it is the compatibility kernel): the entry points exist so that the
 // library loads, and fail when called
@@ -116,6 +120,8 @@ int gk_compat_log_miss(gk_ctx*, gk_tab*, gk_dptr, int64_t, gk_dptr, int32_t, int
 int gk_compat_log(gk_ctx*, gk_tab*, gk_dptr, int64_t, gk_dptr, int32_t, int32_t, gk_dptr, int32_t, int32_t, int32_t, gk_lut*,
                   gk_dptr) { gk_set_error("no device in the host-only build"); return GK_ERR_NO_DEVICE; }
 int gk_miss_colsum(gk_ctx*, gk_dptr, int64_t, int32_t, gk_dptr) { return GK_ERR_NO_DEVICE; }
+int gk_compat_index(gk_ctx*, gk_tab*, gk_dptr, int64_t, gk_dptr, int32_t, int32_t, gk_dptr, int32_t, int32_t, int32_t, gk_lut*,
+                    gk_dptr, gk_dptr, int64_t, gk_dptr) { return GK_ERR_NO_DEVICE; }
 int gk_lut_known(gk_lut*, int32_t* n) { *n = 0; return GK_OK; }
 int gk_lut_resolve(gk_lut*, gk_log10_fn, int32_t*, int32_t*, int32_t*) { return GK_ERR_NO_DEVICE; }
 }

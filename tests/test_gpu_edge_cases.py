@@ -137,3 +137,34 @@ def test_reads_without_information_stay_when_asked(device, one_gene, correction)
     for a, b in zip(gpu.result, cpu.result):
         same(a, b)
     assert got.selectBest() == oty.selectBest(want)
+
+
+def test_a_row_of_thousands_of_factors_takes_the_exact_search(device, monkeypatch):
+    """The mismatch bytes of the integer bound are read back from the log-likelihood (m = floor(-L / 3 + 1/4)), which is
+    exact only while a row lists fewer than ~5000 variants.  A row beyond 4096 factors (wide records and windows of
+    more than 256 variants can produce one) raises the gene's flag, so the search runs on float64 sums for every
+    candidate -- and still equals the oracle."""
+    from kir_graph_amd.msa2hisat import Variant
+    monkeypatch.setenv("GK_SEARCH", "bound")
+    rng = np.random.default_rng(3)
+    alleles = [f"KIRX*{k:03d}" for k in range(200)]
+    variants = []
+    for i in range(4300):       # every variant belongs to one allele: a long row then stays far below 100 mismatches per allele
+        v = Variant(pos=10 + 2 * i, typ="single", ref="KIRX*BACKBONE", val="ACGT"[i % 4], length=1)
+        v.id = f"hv{i}"
+        v.allele = [alleles[i % 200]]
+        variants.append(v)
+    ids = [str(v.id) for v in variants]
+    long_row = {"lpv": ids[:6], "rpv": ids[6:10], "lnv": ids[10:2100], "rnv": ids[2100:4200],
+                "multiple": 1, "backbone": "KIRX*BACKBONE"}
+    short = [{"lpv": [ids[int(k)] for k in rng.choice(4300, 3, replace=False)], "rpv": [],
+              "lnv": [ids[int(k)] for k in rng.choice(4300, 6, replace=False)], "rnv": [],
+              "multiple": 1, "backbone": "KIRX*BACKBONE"} for _ in range(300)]
+    reads = [long_row] + short
+    cpu = oty.GeneModel(copy.deepcopy(reads), variants, force_homo=False, top_n=20, variant_correction=False)
+    gpu = AlleleTyping(to_pairs(reads), variants, force_homo=False, top_n=20, variant_correction=False, device=device)
+    want, got = cpu.typing(2), gpu.typing(2)
+    assert gpu._model.miss8 is not None and not gpu._model.boundOk        # 4200 factors in one row: the flag is up
+    assert np.isfinite(np.asarray(want.value)).all()                       # ... not because a product underflowed
+    same(got, want)
+

@@ -162,8 +162,8 @@ def test_native_search_host_half_equals_the_oracle(host_search, bound):
     bounded_steps = exact_steps = 0
     for trial in range(40):
         n_rows = int(rng.choice([7, 64, 129, 500]))
-        n_allele = int(rng.choice([3, 9, 33, 70]))
-        top_n = int(rng.choice([2, 5, 17, 60]))
+        n_allele = int(rng.choice([3, 9, 33, 70, 130]))
+        top_n = int(rng.choice([2, 5, 17, 60, 200]))      # 200 >= alleles: the second step's bound runs on the upper triangle only
         cn = int(rng.integers(1, 5))
         tab = Table(rng, n_rows, n_allele)
         cols = np.arange(n_allele) if trial % 3 else np.sort(rng.choice(n_allele, size=max(1, n_allele // 2), replace=False))

@@ -74,7 +74,8 @@ def run_cli(folder, out, bams, ranks):
         cmd += ["--alignment", b]
     if ranks > 1:
         cmd += ["--ranks", str(ranks)]
-    env = dict(os.environ, PYTHONPATH=ROOT, GK_COMM_BACKEND="file")
+    # no hand-off files unless a sample has to leave HBM before the pooled fit (64 x 660 MB of .npz that nothing reads)
+    env = dict(os.environ, PYTHONPATH=ROOT, GK_COMM_BACKEND="file", GK_HANDOFF="lazy")
     watch = HbmWatch()
     watch.start()
     before = resource.getrusage(resource.RUSAGE_CHILDREN)
