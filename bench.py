@@ -257,6 +257,9 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
     (and every rank) is ready and ends when every worker's last sample is typed."""
     from types import SimpleNamespace
     args = SimpleNamespace(**opts)
+    # the host threads of a process (sample lanes, ingest) hold the interpreter lock only between library calls: a short
+    # switch interval keeps one lane's Python from delaying another lane's next launch by the default 5 ms
+    sys.setswitchinterval(float(os.environ.get("GK_SWITCH_INTERVAL", "0.0005")))
     if j and os.environ.get("GK_BENCH_KILL_WORKER") == str(j):   # test hook: this worker dies at once
         os._exit(3)
     from kir_graph_amd import _lib, comm as gk_comm
