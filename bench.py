@@ -171,15 +171,36 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
         method = "exonfirst_1"
     depth = int(os.environ.get("GK_PREFETCH", "1")) if depth is None else depth
     lanes = int(os.environ.get("GK_SAMPLE_LANES", "2"))   # samples typed at a time, each on a host thread and a stream of its own
-    ingest = dev.worker(lanes * hostThreads())   # a context of its own: the typing lanes use workers 0..lanes*n-1
+    # staging (copy + tabulation) has contexts of its own, one per staging thread: the typing lanes use workers 0..lanes*n-1
+    n_ingest = max(1, int(os.environ.get("GK_INGEST_THREADS", "2")))
+    ingest_of = {}
+    ingest_lock = threading.Lock()
+
+    def ingest_ctx():
+        me = threading.get_ident()
+        with ingest_lock:
+            if me not in ingest_of:
+                ingest_of[me] = dev.worker(lanes * hostThreads() + len(ingest_of) % n_ingest, urgent=True)
+            return ingest_of[me]
+
+    trace = os.environ.get("GK_BENCH_TRACE") == "1"      # a timeline of the host threads on stderr (tools/host_timeline.py)
+
+    def note(what, k, t0):
+        if trace:
+            log(f"[trace] {what} {k} {threading.get_native_id()} {t0:.6f} {time.perf_counter():.6f}")
 
     def stage(k):
+        t0 = time.perf_counter()
         pinned, table, gene_cn = inputs[k % len(inputs)]
+        ingest = ingest_ctx()
         mates = pinned.toDevice(ingest)
-        return Tabulation(dindex, mates, dev=ingest), table, gene_cn
+        tab = Tabulation(dindex, mates, dev=ingest)
+        note("stage", k, t0)
+        return tab, table, gene_cn, k
 
     def type_one(item, lane):
-        tab, table, gene_cn = item
+        t0 = time.perf_counter()
+        tab, table, gene_cn, k = item
         data = SampleData(tab, gidx, None, ins_strings=table.strings)
         typer = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
         typer.slot_base = lane * hostThreads()
@@ -187,6 +208,7 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
         n_valid = tab.n_valid
         tab.close()
         tab.mates.free()
+        note("type", k, t0)
         return calls, warn, n_valid, typer
 
     out = None
@@ -195,7 +217,10 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
         for k in items:
             out = type_one(stage(k), 0)
         return out
-    for out in overlapped(prefetched(items, stage, depth=depth), type_one, lanes=lanes):
+    # staging a sample takes 7 - 10 ms of wall time next to the typing kernels (its kernels queue behind theirs, and it
+    # waits for the device several times): two staging threads, or staging is what a worker process waits for
+    depth = max(depth, n_ingest)
+    for out in overlapped(prefetched(items, stage, depth=depth, workers=n_ingest), type_one, lanes=lanes):
         pass
     return out
 

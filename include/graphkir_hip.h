@@ -105,6 +105,11 @@ int gk_abi_version(void);
 const char* gk_last_error(void);
 int gk_device_count(int* n);
 int gk_ctx_create(int device, gk_ctx** out);
+/* The same with a stream priority: urgent != 0 asks for the device's highest stream priority -- for the short,
+ * latency-bound work of a sample (copy + tabulation of the next sample, the preamble of a gene loop), whose small
+ * kernels otherwise queue behind the workgroups of another sample's long kernels.  No reference counterpart (the
+ * reference is single-threaded numpy); the hot path it serves is hisat2.py:551-620 + kir_typing.py:103-132. */
+int gk_ctx_create_priority(int device, int urgent, gk_ctx** out);
 int gk_ctx_destroy(gk_ctx* ctx);
 int gk_sync(gk_ctx* ctx);
 int gk_malloc(gk_ctx* ctx, size_t bytes, gk_dptr* out);

@@ -78,6 +78,7 @@ _SIGS = {
     "gk_last_error": (C.c_char_p, []),
     "gk_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "gk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "gk_ctx_create_priority": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "gk_ctx_destroy": (C.c_int, [C.c_void_p]),
     "gk_sync": (C.c_int, [C.c_void_p]),
     "gk_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
@@ -346,26 +347,37 @@ class DeviceSlice(DeviceBuffer):
 class Device:
     """One HIP device context (one process drives one GPU)."""
 
-    def __init__(self, ordinal: int | None = None):
+    def __init__(self, ordinal: int | None = None, urgent: bool = False):
+        """``urgent``: a stream of the device's highest priority (short, latency-bound work next to long kernels)."""
         if ordinal is None:
             ordinal = int(os.environ.get("LOCAL_RANK", "0"))
             n = deviceCount()
             ordinal = ordinal % n if n else 0
         ctx = C.c_void_p()
-        check(lib().gk_ctx_create(ordinal, C.byref(ctx)))
+        urgent = urgent and os.environ.get("GK_STREAM_PRIORITY", "1") != "0"
+        check(lib().gk_ctx_create_priority(ordinal, int(urgent), C.byref(ctx)))
         self.ctx = ctx
         self.ordinal = ordinal
+        self._urgent: "Device | None" = None
         self.call_log: list[tuple] | None = None   # set to [] to record launch geometry (bench roofline)
         self._workers: list["Device"] = []
         Device.instances.append(self)
 
     instances: list["Device"] = []
 
-    def worker(self, k: int) -> "Device":
-        """k-th extra context (own stream + allocator) on the same GPU, for per-gene host threads."""
+    def worker(self, k: int, urgent: bool = False) -> "Device":
+        """k-th extra context (own stream + allocator) on the same GPU, for per-gene host threads (``urgent`` counts
+        when the context is made: see ``Device``)."""
         while len(self._workers) <= k:
-            self._workers.append(Device(self.ordinal))
+            self._workers.append(Device(self.ordinal, urgent=urgent and len(self._workers) == k))
         return self._workers[k]
+
+    def urgent(self) -> "Device":
+        """This context's high-priority sibling (made on first use): for the short preamble of a sample, whose small
+        kernels and waits would otherwise sit behind the long kernels of the samples typed next to it."""
+        if self._urgent is None:
+            self._urgent = Device(self.ordinal, urgent=True)
+        return self._urgent
 
     def alloc(self, shape, dtype) -> DeviceBuffer:
         return DeviceBuffer(self, shape, dtype)

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -40,15 +41,19 @@ struct gk_ctx {
   // small reusable device scratch (scan partials, counters)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
-  // pinned host staging: a ring for host -> device parameters (gk_send) and a bounce area for device -> host
-  // results (gk_fetch_*).  Copies to / from pageable memory go through a staging path inside the runtime that the
-  // host threads of a process share; with a dozen gene threads that path was the throughput limit of one process.
-  void* pinned = nullptr;
-  size_t pinned_bytes = 0, pinned_head = 0;
-  void* bounce = nullptr;
-  size_t bounce_bytes = 0, bounce_head = 0;
-  struct Pending { void* dst; size_t off, bytes; };
-  std::vector<Pending> fetches;
+  // pinned host staging: a ring for host -> device parameters (gk_send) and one for device -> host results
+  // (gk_fetch_*).  Copies to / from pageable memory go through a staging path inside the runtime that the host threads
+  // of a process share; with a dozen gene threads that path was the throughput limit of one process.  Both rings are
+  // addressed by byte counters that only grow (offset = counter % size); space comes back when a MARK -- an event
+  // recorded on the stream, gk_fetch_mark -- is known to have passed, or when the stream has been drained.
+  struct Ring { void* base = nullptr; size_t bytes = 0; uint64_t head = 0, tail = 0; };
+  Ring send_ring, fetch_ring;
+  struct Pending { void* dst; size_t off, bytes; uint64_t end; };
+  std::deque<Pending> fetches;
+  struct Mark { hipEvent_t ev; uint64_t id, send_head, fetch_head; };
+  std::deque<Mark> marks;
+  uint64_t mark_next = 1, mark_done = 0;      // ids handed out / the newest mark known to have passed
+  std::vector<hipEvent_t> mark_pool;
   // reduction-tree programs of gk_search.hip, one device block per row count (they depend on nothing else)
   std::map<int64_t, void*> tree_programs;
   struct TreeHead { size_t o_leaf, o_span, o_cs, o_co, o_top; int n_spans, n_chunks; };
@@ -102,10 +107,17 @@ int gk_ctx_scratch(gk_ctx* ctx, size_t bytes, void** out);
 // until the stream has passed it
 hipError_t gk_send(gk_ctx* ctx, void* dst_dev, const void* src, size_t bytes);
 size_t gk_stage_direct();
-// device -> host through the pinned bounce area: queue any number of copies, then wait once (stream synchronise)
-// and have them delivered to their destinations; gk_fetch = queue + wait
+// device -> host through the pinned ring: queue any number of copies, then wait once (stream synchronise) and have
+// them delivered to their destinations; gk_fetch = queue + wait.  `dst` must stay valid until the delivery.
 hipError_t gk_fetch_queue(gk_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
 hipError_t gk_fetch_wait(gk_ctx* ctx);
+// A mark is a point of the stream: gk_fetch_wait_mark returns when the stream has passed it, with every copy queued
+// before it delivered -- work queued after the mark keeps running, so a caller that drives several independent
+// sequences on one stream (the genes of a sample, gk_sample_search) waits for one without draining the others.
+hipError_t gk_fetch_mark(gk_ctx* ctx, uint64_t* mark);
+hipError_t gk_fetch_wait_mark(gk_ctx* ctx, uint64_t mark);
+// Drain the stream and DROP the copies still queued (their destinations are going away: an error path).
+void gk_fetch_cancel(gk_ctx* ctx);
 static inline hipError_t gk_fetch(gk_ctx* ctx, void* dst, const void* src_dev, size_t bytes) {
   hipError_t e = gk_fetch_queue(ctx, dst, src_dev, bytes);
   return e != hipSuccess ? e : gk_fetch_wait(ctx);

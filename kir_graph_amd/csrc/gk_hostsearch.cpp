@@ -21,6 +21,8 @@
 #include <unordered_map>
 #include <unordered_set>
 #include <chrono>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "gk_calls.h"
 #include "gk_lut.h"
@@ -523,6 +525,48 @@ int wait_stream(gk_ctx* ctx) {
   return GK_OK;
 }
 
+int wait_mark(gk_ctx* ctx, uint64_t mark) {
+  if (gk_fetch_wait_mark(ctx, mark) != hipSuccess) {
+    gk_set_error("search: waiting for a mark of the stream failed: %s", hipGetErrorString(hipGetLastError()));
+    return GK_ERR_HIP;
+  }
+  return GK_OK;
+}
+
+int set_mark(gk_ctx* ctx, uint64_t* mark) {
+  if (gk_fetch_mark(ctx, mark) != hipSuccess) {
+    gk_set_error("search: recording a mark on the stream failed: %s", hipGetErrorString(hipGetLastError()));
+    return GK_ERR_HIP;
+  }
+  return GK_OK;
+}
+
+// GK_SEARCH_TIMING=1: where the calling thread spends a gk_sample_search call (host work between the waits / the waits)
+struct SearchClock {
+  using clk = std::chrono::steady_clock;
+  const bool on;
+  const char* form;
+  int genes;
+  double host = 0, wait = 0;
+  int n_wait = 0;
+  clk::time_point mark = clk::now();
+  const clk::time_point begin = mark;
+  SearchClock(const char* f, int g) : on(getenv("GK_SEARCH_TIMING") != nullptr), form(f), genes(g) {}
+  void lap(bool waited) {
+    if (!on) return;
+    const auto now = clk::now();
+    (waited ? wait : host) += std::chrono::duration<double, std::milli>(now - mark).count();
+    n_wait += waited ? 1 : 0;
+    mark = now;
+  }
+  ~SearchClock() {
+    // begin / end on the monotonic clock (Python's time.perf_counter on Linux), for timelines across threads
+    if (on) fprintf(stderr, "[gk_sample_search %s] thread %ld, %d genes: host %.2f ms, waits %.2f ms in %d waits; from %.6f to %.6f s\n", form,
+                    (long)syscall(SYS_gettid), genes, host, wait, n_wait, std::chrono::duration<double>(begin.time_since_epoch()).count(),
+                    std::chrono::duration<double>(clk::now().time_since_epoch()).count());
+  }
+};
+
 }  // namespace
 
 extern "C" {
@@ -564,40 +608,16 @@ int gk_search_run(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, int32_t 
   return GK_OK;
 }
 
-/* The searches of ALL genes of a sample in lock-step on the calling thread (one stream per context handed in): the compatibility tables,
- * then the column sums, then step 2, 3, ... of every gene that has one -- each phase is queued for every gene before
- * ONE wait, so a sample costs about ten stream synchronisations instead of several per gene and step, and one host
- * thread keeps the GPU fed (typing_mulit_allele.py:340-381 + 478-598 per gene; kir_typing.py:103-132 is the gene loop).
- * jobs[i] describes gene i (tables allocated by the caller); out[i] receives its search (gk_search_*), NULL for a
- * gene without rows.  `log10_fn` = numpy.log10 (value table, see gk_lut_resolve), `argsort` = numpy.argsort. */
-int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut,
-                     gk_gene_job* jobs, int32_t n_jobs, gk_argsort_fn argsort, gk_log10_fn log10_fn, gk_search** out) {
-  gk_bind(ctx);
-  GK_REQUIRE(ctx && tab && lut && jobs && argsort && log10_fn && out && n_jobs >= 0, "null pointer");
-  GK_REQUIRE(n_more >= 0 && (n_more == 0 || more_ctx), "bad context list");
-  // the calling thread's contexts: gene i queues everything it does on ONE of them (its stream, its staging, its pool),
-  // so the kernels of different genes overlap on the GPU while the host still makes one pass and one wait per phase
-  std::vector<gk_ctx*> cx{ctx};
-  for (int k = 0; k < n_more; ++k) {
-    GK_REQUIRE(more_ctx[k] && more_ctx[k]->device == ctx->device, "contexts of one call share a device");
-    cx.push_back(more_ctx[k]);
-  }
-  for (int i = 0; i < n_jobs; ++i) out[i] = nullptr;
-  std::vector<int> live;
-  for (int i = 0; i < n_jobs; ++i) {
-    gk_gene_job& j = jobs[i];
-    j.bound_ok = 0;
-    j.passes = 0;
-    j.indexed = 0;
-    GK_REQUIRE(j.n_rows >= 0 && j.n_allele >= 0 && j.n_steps >= 1 && j.top_n >= 1, "bad gene job");
-    if (j.n_rows > 0 && j.n_allele > 0) {
-      GK_REQUIRE(j.d_rows && (j.d_L || j.d_lidx) && j.d_mask && j.words >= 1, "gene job without tables");
-      GK_REQUIRE(!j.d_miss8 || (j.d_msum && j.d_flags && j.ldm >= j.n_rows && j.ldm % 64 == 0), "bad mismatch table");
-      GK_REQUIRE(!j.d_lidx || j.d_miss8, "the index form comes with the mismatch table (same stride)");
-      live.push_back(i);
-    }
-  }
-  if (live.empty()) return GK_OK;
+}  // extern "C"
+
+namespace {
+
+/* All genes in LOCK-STEP: each phase is queued for every gene before ONE wait (about ten stream synchronisations per
+ * sample).  The form for several streams, for index tables, and the one that settles the value table (repeated passes
+ * while log10 values are being defined). */
+int sample_search_lockstep(gk_ctx* ctx, const std::vector<gk_ctx*>& cx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut,
+                           gk_gene_job* jobs, int32_t n_jobs, const std::vector<int>& live, gk_argsort_fn argsort,
+                           gk_log10_fn log10_fn, gk_search** out) {
   int rc = GK_OK;
   std::vector<gk_ctx*> ctx_of((size_t)n_jobs, ctx);
   {
@@ -612,24 +632,8 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
     for (gk_ctx* c : cx) { const int r = wait_stream(c); if (r) worst = r; }
     return worst;
   };
-  // GK_SEARCH_TIMING=1: where the calling thread spends the call (host work between the waits / the waits themselves)
-  static const bool timing = getenv("GK_SEARCH_TIMING") != nullptr;
-  using clk = std::chrono::steady_clock;
-  double t_host = 0, t_wait = 0;
-  int n_wait = 0;
-  auto t_mark = clk::now();
-  auto lap = [&](bool waited) {
-    if (!timing) return;
-    const auto now = clk::now();
-    const double ms = std::chrono::duration<double, std::milli>(now - t_mark).count();
-    (waited ? t_wait : t_host) += ms;
-    n_wait += waited ? 1 : 0;
-    t_mark = now;
-  };
-  struct Report {
-    const bool on; double& h; double& w; int& n; int jobs;
-    ~Report() { if (on) fprintf(stderr, "[gk_sample_search] %d genes: host %.2f ms, waits %.2f ms in %d waits\n", jobs, h, w, n); }
-  } report{timing, t_host, t_wait, n_wait, (int)live.size()};
+  SearchClock clock("lock-step", (int)live.size());
+  auto lap = [&](bool waited) { clock.lap(waited); };
   // ---- phase 0: the compatibility tables (log-likelihoods through the value table + mismatch counts); a float64 table's
   // column sums are queued right behind the kernel that writes it -- the table is still in the Infinity Cache then, which
   // it is not any more once the tables of all genes (1.3 GB for a configs[1] sample) have been written
@@ -649,10 +653,15 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
     sums_queued[i] = r == GK_OK;
     return r;
   };
+  auto quit = [&](int code) {
+    for (gk_ctx* c : cx) gk_fetch_cancel(c);
+    for (auto& g : gs) if (g) g->abandon();
+    return code;
+  };
   for (int pass = 0; pass < 64; ++pass) {
     int32_t known_at_launch = 0;
     rc = gk_lut_known(lut, &known_at_launch);
-    if (rc) return rc;
+    if (rc) return quit(rc);
     for (int i : live) {
       gk_gene_job& j = jobs[i];
       gk_ctx* const gc = ctx_of[i];
@@ -672,25 +681,25 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
         rc = gk_compat_log(gc, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut, j.d_L);
         if (rc == GK_OK) rc = start_search(i, j.d_L, false);
       }
-      if (rc) { for (auto& g : gs) if (g) g->abandon(); return rc; }
+      if (rc) return quit(rc);
     }
     lap(false); rc = wait_all(); lap(true);          // every key these kernels claimed is stored
-    if (rc) { for (auto& g : gs) if (g) g->abandon(); return rc; }
+    if (rc) return quit(rc);
     int32_t n_new = 0, n_known = 0, n_undefined = 0;
     rc = gk_lut_resolve(lut, log10_fn, &n_new, &n_known, &n_undefined);
-    if (rc) { for (auto& g : gs) if (g) g->abandon(); return rc; }
+    if (rc) return quit(rc);
     if (n_known > known_at_launch) continue;    // some values were undefined at launch: write the tables again
     if (n_undefined == 0) break;                // every value these launches met had its log10 in the table
     if (pass == 63) {
-      for (auto& g : gs) if (g) g->abandon();
       gk_set_error("log10 value table did not settle");
-      return GK_ERR_ASSERT;
+      return quit(GK_ERR_ASSERT);
     }
   }
   // a gene whose indices do not fit 16 bits (the value table holds more than 65535 values) takes the float64 form, in a
   // block of this call's own; every value is defined by now, so one pass writes it
   std::vector<void*> own_L((size_t)n_jobs, nullptr);
   auto fail = [&](int code) {
+    for (gk_ctx* c : cx) gk_fetch_cancel(c);        // copies still queued point into the searches that go away now
     for (auto& g : gs) if (g) g->abandon();
     for (int i = 0; i < n_jobs; ++i) gk_pool_free(ctx_of[i], own_L[i]);
     return code;
@@ -758,6 +767,178 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
   for (int i = 0; i < n_jobs; ++i) gk_pool_free(ctx_of[i], own_L[i]);
   lap(false);
   return GK_OK;
+}
+
+/* All genes PIPELINED on one stream: every gene is a sequence table -> [bound -> sums]* whose stages are cut where the
+ * host needs a result; a stage ends with a mark (gk_fetch_mark), and the host takes the stages in the order they were
+ * queued: waits for the mark, does the gene's host work, queues its next stage -- behind the stages of the other genes
+ * that are still running.  The stream therefore always holds about one stage of every gene, and the host work of a
+ * gene is hidden behind the kernels of the others (lock-step: the GPU idles while the host handles a phase of all
+ * genes, ~3 ms of a 9 ms sample).  Optimistic about the value table: the searches start on the tables of the first
+ * pass, and the table's entry count -- read on the stream behind the last compatibility kernel -- tells whether that
+ * pass met a value without a log10 yet; then `*redo` is set, nothing is returned, and the caller takes the lock-step
+ * form (after the first samples of a run the table does not grow any more). */
+int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_gene_job* jobs, int32_t n_jobs,
+                            const std::vector<int>& live, gk_argsort_fn argsort, gk_search** out, bool* redo) {
+  *redo = false;
+  SearchClock clock("pipelined", (int)live.size());
+  std::vector<uint32_t> flags((size_t)n_jobs, 0);
+  std::vector<std::unique_ptr<GeneSearch>> gs((size_t)n_jobs);
+  enum { kTable, kBound, kSums, kValues };
+  struct Item { int gene, stage; uint64_t mark; };
+  std::deque<Item> queue;
+  auto fail = [&](int code) {
+    gk_fetch_cancel(ctx);                        // copies still queued point into the searches that go away now
+    for (auto& g : gs) if (g) g->abandon();
+    return code;
+  };
+  auto push = [&](int gene, int stage) {
+    uint64_t m = 0;
+    const int r = set_mark(ctx, &m);
+    if (r == GK_OK) queue.push_back({gene, stage, m});
+    return r;
+  };
+  int32_t known_at_launch = 0;
+  int rc = gk_lut_known(lut, &known_at_launch);
+  if (rc) return rc;
+  for (int i : live) {
+    gk_gene_job& j = jobs[i];
+    j.passes++;
+    if (j.d_miss8) {
+      rc = gk_compat_log_miss(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
+                              j.d_L, j.d_miss8, j.ldm, j.d_flags);
+      if (rc == GK_OK) rc = gk_miss_colsum(ctx, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
+      if (rc == GK_OK && gk_fetch_queue(ctx, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
+    } else {
+      rc = gk_compat_log(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut, j.d_L);
+    }
+    if (rc) return fail(rc);
+    // the column sums right behind the kernel that wrote the table (still in the Infinity Cache)
+    std::vector<int32_t> cols((size_t)j.n_allele);
+    std::iota(cols.begin(), cols.end(), 0);
+    gs[i].reset(new GeneSearch());
+    rc = gs[i]->init(ctx, GkTable{j.d_L, j.n_rows, nullptr}, j.d_L, j.n_rows, j.n_rows, j.n_allele, j.d_miss8, j.ldm, j.d_msum,
+                     cols.data(), j.n_allele, j.n_steps, j.top_n, argsort);
+    if (rc == GK_OK) rc = gs[i]->colsum_enqueue();
+    if (rc == GK_OK) rc = push(i, kTable);
+    if (rc) return fail(rc);
+  }
+  uint32_t n_values = 0;       // entries of the value table once every kernel above has run
+  if (gk_fetch_queue(ctx, &n_values, lut->d_count, sizeof(uint32_t)) != hipSuccess) return fail(GK_ERR_HIP);
+  rc = push(-1, kValues);
+  if (rc) return fail(rc);
+
+  // gene i goes on until it has a stage in flight (queued here) or no step left
+  auto advance = [&](int i, bool at_step_start) -> int {
+    GeneSearch& g = *gs[i];
+    for (;;) {
+      if (at_step_start) {
+        if (!g.more()) return GK_OK;
+        const int r = g.step_begin();
+        if (r) return r;
+        if (g.bound_in_flight) return push(i, kBound);
+      }
+      if (!g.step_done) {          // the bound does not apply / could not settle the step: float64 sums of every candidate
+        const int r = g.exact_step();
+        if (r) return r;
+      }
+      g.step_end();
+      at_step_start = true;
+    }
+  };
+  while (!queue.empty()) {
+    const Item it = queue.front();
+    queue.pop_front();
+    clock.lap(false);
+    rc = wait_mark(ctx, it.mark);
+    clock.lap(true);
+    if (rc) return fail(rc);
+    if (it.stage == kValues) {
+      int32_t known_now = 0;
+      rc = gk_lut_known(lut, &known_now);
+      if (rc) return fail(rc);
+      if ((int64_t)n_values != (int64_t)known_at_launch || known_now != known_at_launch) {
+        *redo = true;              // some value had no log10 when a table was written: settle the table, write them again
+        return fail(GK_OK);
+      }
+      continue;
+    }
+    gk_gene_job& j = jobs[it.gene];
+    GeneSearch& g = *gs[it.gene];
+    switch (it.stage) {
+      case kTable:
+        j.bound_ok = (j.d_miss8 && (flags[it.gene] & 1u) == 0) ? 1 : 0;
+        if (!j.bound_ok) g.bound = false;      // a mismatch count near the underflow range / a very long row: exact steps
+        g.colsum_collect();
+        rc = g.first_step();
+        if (rc == GK_OK) rc = advance(it.gene, true);
+        break;
+      case kBound:
+        rc = g.after_bound();
+        if (rc == GK_OK) rc = g.sums_in_flight ? push(it.gene, kSums) : advance(it.gene, false);
+        break;
+      default:
+        rc = g.after_sums();
+        if (rc == GK_OK) rc = advance(it.gene, false);
+        break;
+    }
+    if (rc) return fail(rc);
+  }
+  for (int i : live) {
+    gs[i]->finish();
+    out[i] = gs[i]->S.release();
+  }
+  clock.lap(false);
+  return GK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* The searches of ALL genes of a sample on the calling thread: the compatibility tables, then the column sums, then
+ * step 2, 3, ... of every gene that has one -- pipelined on one stream (sample_search_pipelined; GK_SAMPLE_PIPELINE=0
+ * turns it off) or in lock-step (several streams, index tables, a value table that is still growing), so that one host
+ * thread keeps the GPU fed (typing_mulit_allele.py:340-381 + 478-598 per gene; kir_typing.py:103-132 is the gene loop).
+ * jobs[i] describes gene i (tables allocated by the caller); out[i] receives its search (gk_search_*), NULL for a
+ * gene without rows.  `log10_fn` = numpy.log10 (value table, see gk_lut_resolve), `argsort` = numpy.argsort. */
+int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut,
+                     gk_gene_job* jobs, int32_t n_jobs, gk_argsort_fn argsort, gk_log10_fn log10_fn, gk_search** out) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && tab && lut && jobs && argsort && log10_fn && out && n_jobs >= 0, "null pointer");
+  GK_REQUIRE(n_more >= 0 && (n_more == 0 || more_ctx), "bad context list");
+  // the calling thread's contexts: gene i queues everything it does on ONE of them (its stream, its staging, its pool),
+  // so the kernels of different genes overlap on the GPU while the host still makes one pass and one wait per phase
+  std::vector<gk_ctx*> cx{ctx};
+  for (int k = 0; k < n_more; ++k) {
+    GK_REQUIRE(more_ctx[k] && more_ctx[k]->device == ctx->device, "contexts of one call share a device");
+    cx.push_back(more_ctx[k]);
+  }
+  for (int i = 0; i < n_jobs; ++i) out[i] = nullptr;
+  std::vector<int> live;
+  for (int i = 0; i < n_jobs; ++i) {
+    gk_gene_job& j = jobs[i];
+    j.bound_ok = 0;
+    j.passes = 0;
+    j.indexed = 0;
+    GK_REQUIRE(j.n_rows >= 0 && j.n_allele >= 0 && j.n_steps >= 1 && j.top_n >= 1, "bad gene job");
+    if (j.n_rows > 0 && j.n_allele > 0) {
+      GK_REQUIRE(j.d_rows && (j.d_L || j.d_lidx) && j.d_mask && j.words >= 1, "gene job without tables");
+      GK_REQUIRE(!j.d_miss8 || (j.d_msum && j.d_flags && j.ldm >= j.n_rows && j.ldm % 64 == 0), "bad mismatch table");
+      GK_REQUIRE(!j.d_lidx || j.d_miss8, "the index form comes with the mismatch table (same stride)");
+      live.push_back(i);
+    }
+  }
+  if (live.empty()) return GK_OK;
+  static const bool pipeline = [] { const char* e = getenv("GK_SAMPLE_PIPELINE"); return !(e && !strcmp(e, "0")); }();
+  bool float_tables = true;
+  for (int i : live) float_tables = float_tables && jobs[i].d_L && !jobs[i].d_lidx;
+  if (pipeline && n_more == 0 && float_tables) {
+    bool redo = false;
+    const int rc = sample_search_pipelined(ctx, tab, d_vflag, lut, jobs, n_jobs, live, argsort, out, &redo);
+    if (rc || !redo) return rc;
+  }
+  return sample_search_lockstep(ctx, cx, tab, d_vflag, lut, jobs, n_jobs, live, argsort, log10_fn, out);
 }
 
 int gk_search_steps(gk_search* s, int32_t* n_steps) {

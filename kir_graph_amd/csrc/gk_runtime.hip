@@ -33,7 +33,9 @@ int gk_device_count(int* n) {
   return GK_OK;
 }
 
-int gk_ctx_create(int device, gk_ctx** out) {
+int gk_ctx_create(int device, gk_ctx** out) { return gk_ctx_create_priority(device, 0, out); }
+
+int gk_ctx_create_priority(int device, int urgent, gk_ctx** out) {
   GK_REQUIRE(out, "null pointer");
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) {
@@ -57,7 +59,13 @@ int gk_ctx_create(int device, gk_ctx** out) {
   }
   gk_ctx* ctx = new gk_ctx();
   ctx->device = device;
-  GK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  if (urgent) {
+    int least = 0, greatest = 0;           // numerically lower = more urgent
+    GK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    GK_HIP(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest));
+  } else {
+    GK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  }
   GK_HIP(hipEventCreate(&ctx->ev0));
   GK_HIP(hipEventCreate(&ctx->ev1));
   *out = ctx;
@@ -72,8 +80,10 @@ int gk_ctx_destroy(gk_ctx* ctx) {
   for (auto& kv : ctx->pool_free) hipFree(kv.second);
   for (auto& kv : ctx->pool_live) hipFree(kv.first);
   if (ctx->scratch) hipFree(ctx->scratch);
-  if (ctx->pinned) hipHostFree(ctx->pinned);
-  if (ctx->bounce) hipHostFree(ctx->bounce);
+  if (ctx->send_ring.base) hipHostFree(ctx->send_ring.base);
+  if (ctx->fetch_ring.base) hipHostFree(ctx->fetch_ring.base);
+  for (const auto& m : ctx->marks) hipEventDestroy(m.ev);
+  for (hipEvent_t ev : ctx->mark_pool) hipEventDestroy(ev);
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
   hipStreamDestroy(ctx->stream);
@@ -161,25 +171,90 @@ int gk_timer_stop_ms(gk_ctx* ctx, float* ms) {
 constexpr size_t kStageDirect = (size_t)4 << 20;   // larger transfers go straight to / from the caller's memory
 size_t gk_stage_direct() { return kStageDirect; }
 
+// ---- the two rings and the marks that give their space back
+namespace {
+
+bool wait_blocks() {        // GK_WAIT_POLICY=block: events that put the waiting thread to sleep
+  static const bool v = [] { const char* e = getenv("GK_WAIT_POLICY"); return e && !strcmp(e, "block"); }();
+  return v;
+}
+
+void deliver_upto(gk_ctx* ctx, uint64_t fetch_head) {
+  while (!ctx->fetches.empty() && ctx->fetches.front().end <= fetch_head) {
+    const auto& f = ctx->fetches.front();
+    memcpy(f.dst, (const char*)ctx->fetch_ring.base + f.off, f.bytes);
+    ctx->fetches.pop_front();
+  }
+  ctx->fetch_ring.tail = std::max(ctx->fetch_ring.tail, fetch_head);
+}
+
+// the oldest `n` marks are known to have passed
+void complete_marks(gk_ctx* ctx, size_t n) {
+  for (size_t k = 0; k < n && !ctx->marks.empty(); ++k) {
+    const gk_ctx::Mark m = ctx->marks.front();
+    ctx->marks.pop_front();
+    ctx->send_ring.tail = std::max(ctx->send_ring.tail, m.send_head);
+    deliver_upto(ctx, m.fetch_head);
+    ctx->mark_done = m.id;
+    ctx->mark_pool.push_back(m.ev);
+  }
+}
+
+hipError_t drain(gk_ctx* ctx, bool deliver) {
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (deliver) deliver_upto(ctx, ctx->fetch_ring.head);
+  ctx->fetches.clear();
+  ctx->fetch_ring.tail = ctx->fetch_ring.head;
+  ctx->send_ring.tail = ctx->send_ring.head;
+  for (const auto& m : ctx->marks) ctx->mark_pool.push_back(m.ev);
+  ctx->marks.clear();
+  ctx->mark_done = ctx->mark_next - 1;
+  return e;
+}
+
+// `need` contiguous bytes of a ring: waits for the oldest mark (or the whole stream) while the ring is full
+hipError_t ring_take(gk_ctx* ctx, gk_ctx::Ring& r, size_t need, size_t min_bytes, size_t* off) {
+  for (;;) {
+    if (r.bytes >= need) {
+      uint64_t head = r.head;
+      const size_t phys = (size_t)(head % r.bytes);
+      if (phys + need > r.bytes) head += r.bytes - phys;          // does not fit before the end: start over at 0
+      if (head + need - r.tail <= r.bytes) {
+        *off = (size_t)(head % r.bytes);
+        r.head = head + need;
+        return hipSuccess;
+      }
+    }
+    if (r.head != r.tail) {                 // something is in flight: let the oldest part of it pass
+      hipError_t e;
+      if (ctx->marks.empty()) {
+        e = drain(ctx, true);
+      } else {
+        e = hipEventSynchronize(ctx->marks.front().ev);
+        complete_marks(ctx, 1);
+      }
+      if (e != hipSuccess) return e;
+      continue;
+    }
+    // empty and too small: a larger area (nothing refers to the old one)
+    if (r.base) hipHostFree(r.base);
+    r.base = nullptr;
+    r.bytes = std::max<size_t>(need * 4, min_bytes);
+    r.head = r.tail = 0;
+    hipError_t e = hipHostMalloc(&r.base, r.bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { r.bytes = 0; return e; }
+  }
+}
+
+}  // namespace
+
 hipError_t gk_send(gk_ctx* ctx, void* dst_dev, const void* src, size_t bytes) {
   if (!bytes) return hipSuccess;
   if (bytes > kStageDirect) return hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, ctx->stream);
-  const size_t need = (bytes + 63) / 64 * 64;
-  if (ctx->pinned_bytes < need || ctx->pinned_head + need > ctx->pinned_bytes) {
-    // the ring is full (or too small): every copy queued from it has left once the stream has drained
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) return e;
-    if (ctx->pinned_bytes < need * 4) {
-      if (ctx->pinned) hipHostFree(ctx->pinned);
-      ctx->pinned = nullptr;
-      ctx->pinned_bytes = std::max<size_t>(need * 4, (size_t)1 << 20);
-      e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault);
-      if (e != hipSuccess) { ctx->pinned_bytes = 0; return e; }
-    }
-    ctx->pinned_head = 0;
-  }
-  char* slot = (char*)ctx->pinned + ctx->pinned_head;
-  ctx->pinned_head += need;
+  size_t off = 0;
+  hipError_t e = ring_take(ctx, ctx->send_ring, (bytes + 63) / 64 * 64, (size_t)8 << 20, &off);
+  if (e != hipSuccess) return e;
+  char* slot = (char*)ctx->send_ring.base + off;
   memcpy(slot, src, bytes);
   return hipMemcpyAsync(dst_dev, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
 }
@@ -187,30 +262,42 @@ hipError_t gk_send(gk_ctx* ctx, void* dst_dev, const void* src, size_t bytes) {
 hipError_t gk_fetch_queue(gk_ctx* ctx, void* dst, const void* src_dev, size_t bytes) {
   if (!bytes) return hipSuccess;
   if (bytes > kStageDirect) return hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
-  const size_t need = (bytes + 63) / 64 * 64;
-  if (ctx->bounce_head + need > ctx->bounce_bytes) {
-    hipError_t e = gk_fetch_wait(ctx);          // deliver what is queued, then the area is free
-    if (e != hipSuccess) return e;
-    if (ctx->bounce_bytes < need) {
-      if (ctx->bounce) hipHostFree(ctx->bounce);
-      ctx->bounce = nullptr;
-      ctx->bounce_bytes = std::max<size_t>(need * 2, (size_t)1 << 20);
-      e = hipHostMalloc(&ctx->bounce, ctx->bounce_bytes, hipHostMallocDefault);
-      if (e != hipSuccess) { ctx->bounce_bytes = 0; return e; }
-    }
-  }
-  const size_t off = ctx->bounce_head;
-  ctx->bounce_head += need;
-  ctx->fetches.push_back({dst, off, bytes});
-  return hipMemcpyAsync((char*)ctx->bounce + off, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  size_t off = 0;
+  hipError_t e = ring_take(ctx, ctx->fetch_ring, (bytes + 63) / 64 * 64, (size_t)8 << 20, &off);
+  if (e != hipSuccess) return e;
+  ctx->fetches.push_back({dst, off, bytes, ctx->fetch_ring.head});
+  return hipMemcpyAsync((char*)ctx->fetch_ring.base + off, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
 }
 
-hipError_t gk_fetch_wait(gk_ctx* ctx) {
-  hipError_t e = hipStreamSynchronize(ctx->stream);
-  for (const auto& f : ctx->fetches) memcpy(f.dst, (const char*)ctx->bounce + f.off, f.bytes);
-  ctx->fetches.clear();
-  ctx->bounce_head = 0;
-  return e;
+hipError_t gk_fetch_wait(gk_ctx* ctx) { return drain(ctx, true); }
+
+void gk_fetch_cancel(gk_ctx* ctx) { (void)drain(ctx, false); }
+
+hipError_t gk_fetch_mark(gk_ctx* ctx, uint64_t* mark) {
+  hipEvent_t ev = nullptr;
+  if (!ctx->mark_pool.empty()) {
+    ev = ctx->mark_pool.back();
+    ctx->mark_pool.pop_back();
+  } else {
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming | (wait_blocks() ? hipEventBlockingSync : 0));
+    if (e != hipSuccess) return e;
+  }
+  hipError_t e = hipEventRecord(ev, ctx->stream);
+  if (e != hipSuccess) { ctx->mark_pool.push_back(ev); return e; }
+  ctx->marks.push_back({ev, ctx->mark_next, ctx->send_ring.head, ctx->fetch_ring.head});
+  *mark = ctx->mark_next++;
+  return hipSuccess;
+}
+
+hipError_t gk_fetch_wait_mark(gk_ctx* ctx, uint64_t mark) {
+  if (mark <= ctx->mark_done) return hipSuccess;          // passed already (a wait for a later mark, or a drain)
+  size_t n = 0;
+  while (n < ctx->marks.size() && ctx->marks[n].id <= mark) ++n;
+  if (n == 0) return hipSuccess;
+  hipError_t e = hipEventSynchronize(ctx->marks[n - 1].ev);   // one stream: the earlier marks have passed too
+  if (e != hipSuccess) return e;
+  complete_marks(ctx, n);
+  return hipSuccess;
 }
 
 static size_t pool_class(size_t bytes) {

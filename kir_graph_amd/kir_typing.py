@@ -228,10 +228,16 @@ class TypingWithPosNegAllele(_GenesInParallel):
         import os
         from . import _lib
         from ._lib import check, lib
+        import time
+        trace = os.environ.get("GK_BENCH_TRACE") == "1"     # host timeline on stderr (tools/host_timeline.py)
+        t_in = time.perf_counter()
         tab, logs = self._context()
-        prep = tab.prepared(tab.dev, self._multiple)
+        # the sample-wide preamble (error correction, empty reads, tallies: small kernels and four waits) on the lane's
+        # high-priority stream: next to another sample's search it took 8 ms instead of 1.5 on a stream like any other
+        prep = tab.prepared(tab.dev.urgent() if os.environ.get("GK_URGENT_PREAMBLE", "1") != "0" else tab.dev, self._multiple)
         if prep is None:                 # not a gk_tabulate tabulation (host lists / compact files)
             return super().typing(gene_cn, min_reads_num)
+        t_prep = time.perf_counter()
         vflag, cnt, rows_all, off = prep[:4]
         todo = [(gene, int(cn)) for gene, cn in gene_cn.items() if cn]
         entries = []                     # (gene, cn, typ or None, job, homo)
@@ -264,6 +270,10 @@ class TypingWithPosNegAllele(_GenesInParallel):
             base_slot = self.slot_base + (getattr(self._local, "slot", None) or 0)
             extra = [self._data.tab.dev.worker(base_slot + k) for k in range(1, n_streams)]
             more = (C.c_void_p * max(len(extra), 1))(*[d.ctx for d in extra])
+            if trace:
+                import sys
+                import threading
+                print(f"[trace] pre {threading.get_native_id()} {t_in:.6f} {t_prep:.6f} {time.perf_counter():.6f}", file=sys.stderr, flush=True)
             check(lib().gk_sample_search(tab.dev.ctx, more, len(extra), tab.handle, vflag.ptr, logs.handle, jobs, len(live),
                                          _lib.NUMPY_ARGSORT, _lib.NUMPY_LOG10, handles))
             try:

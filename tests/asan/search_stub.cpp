@@ -66,6 +66,9 @@ int gk_bound_step(gk_ctx*, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, gk_dptr
 // ---- the two-phase forms (gk_calls.h) on the same callbacks
 hipError_t gk_fetch_wait(gk_ctx*) { return hipSuccess; }
 hipError_t gk_fetch_queue(gk_ctx*, void*, const void*, size_t) { return hipSuccess; }
+hipError_t gk_fetch_mark(gk_ctx*, uint64_t* mark) { *mark = 0; return hipSuccess; }
+hipError_t gk_fetch_wait_mark(gk_ctx*, uint64_t) { return hipSuccess; }
+void gk_fetch_cancel(gk_ctx*) {}
 void gk_pool_free(gk_ctx*, void*) {}
 
 struct StubBound { uint32_t hdr[4]; std::vector<int32_t> idx; std::vector<uint32_t> mm; };

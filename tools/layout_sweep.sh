@@ -17,12 +17,13 @@ run() {
     | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); d['label']='$label'; print(json.dumps({k: d[k] for k in ('label','ms_per_step','value','host','config','search_steps')}))" >> $O/layout_sweep.jsonl
   tail -1 $O/layout_sweep.jsonl | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['label'], '|', round(d['ms_per_step'],3), 'ms/step', round(d['host']['host_core_s_per_step']*1e3,2), 'core-ms/step', round(d['host']['cores_busy'],2), 'cores busy')"
 }
-for cfg in "$@"; do :; done
-run "2p x 2l block unpinned" GK_PROCS_PER_GPU=2 GK_SAMPLE_LANES=2 GK_WAIT_POLICY=block --
-run "3p x 2l block unpinned" GK_PROCS_PER_GPU=3 GK_SAMPLE_LANES=2 GK_WAIT_POLICY=block --
-run "2p x 3l block unpinned" GK_PROCS_PER_GPU=2 GK_SAMPLE_LANES=3 GK_WAIT_POLICY=block --
-run "2p x 2l spin unpinned" GK_PROCS_PER_GPU=2 GK_SAMPLE_LANES=2 --
-run "4p x 1l block unpinned" GK_PROCS_PER_GPU=4 GK_SAMPLE_LANES=1 GK_WAIT_POLICY=block --
-run "2p x 2l block 2 cores" GK_PROCS_PER_GPU=2 GK_SAMPLE_LANES=2 GK_WAIT_POLICY=block -- --cores-per-gpu 2
-run "1p x 3l block 2 cores" GK_PROCS_PER_GPU=1 GK_SAMPLE_LANES=3 GK_WAIT_POLICY=block -- --cores-per-gpu 2
-run "2p x 2l block 3 cores" GK_PROCS_PER_GPU=2 GK_SAMPLE_LANES=2 GK_WAIT_POLICY=block -- --cores-per-gpu 3
+export GK_INGEST_THREADS=${GK_INGEST_THREADS:-1}
+for PL in "1 3" "1 4" "2 2" "2 3" "3 2" "1 2" "2 1" "4 1"; do
+  set -- $PL
+  run "$1p x $2l unpinned" GK_PROCS_PER_GPU=$1 GK_SAMPLE_LANES=$2 --
+done
+run "1p x 3l 3 cores" GK_PROCS_PER_GPU=1 GK_SAMPLE_LANES=3 -- --cores-per-gpu 3
+run "1p x 3l 2 cores" GK_PROCS_PER_GPU=1 GK_SAMPLE_LANES=3 -- --cores-per-gpu 2
+run "1p x 4l 2 cores" GK_PROCS_PER_GPU=1 GK_SAMPLE_LANES=4 -- --cores-per-gpu 2
+run "2p x 2l 2 cores" GK_PROCS_PER_GPU=2 GK_SAMPLE_LANES=2 -- --cores-per-gpu 2
+run "2p x 2l 3 cores" GK_PROCS_PER_GPU=2 GK_SAMPLE_LANES=2 -- --cores-per-gpu 3
