@@ -172,7 +172,7 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
     depth = int(os.environ.get("GK_PREFETCH", "1")) if depth is None else depth
     lanes = int(os.environ.get("GK_SAMPLE_LANES", "2"))   # samples typed at a time, each on a host thread and a stream of its own
     # staging (copy + tabulation) has contexts of its own, one per staging thread: the typing lanes use workers 0..lanes*n-1
-    n_ingest = max(1, int(os.environ.get("GK_INGEST_THREADS", "2")))
+    n_ingest = max(1, int(os.environ.get("GK_INGEST_THREADS", "1")))
     ingest_of = {}
     ingest_lock = threading.Lock()
 
@@ -217,8 +217,9 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
         for k in items:
             out = type_one(stage(k), 0)
         return out
-    # staging a sample takes 7 - 10 ms of wall time next to the typing kernels (its kernels queue behind theirs, and it
-    # waits for the device several times): two staging threads, or staging is what a worker process waits for
+    # staging a sample takes 6 - 10 ms of wall time next to the typing kernels (it waits for the device several times,
+    # and its kernels run between theirs): it has a high-priority stream; a second staging thread (GK_INGEST_THREADS=2)
+    # measured slower
     depth = max(depth, n_ingest)
     for out in overlapped(prefetched(items, stage, depth=depth, workers=n_ingest), type_one, lanes=lanes):
         pass
@@ -501,6 +502,11 @@ def main():
     os.environ.setdefault("GK_WAIT_POLICY", "block")
     procs = max(1, int(os.environ.get("GK_PROCS_PER_GPU", "2")))
     procs = min(procs, max(1, args.steps))
+    # the sample preamble on a high-priority stream: what lets ONE process keep the GPU busy (8.9 against 10.2 ms per
+    # sample with three lanes); with two processes it takes CUs from the other process's search at the wrong moments
+    # (9.4 against 8.3 ms) -- profiles/r03_stream_priority.txt
+    os.environ.setdefault("GK_URGENT_PREAMBLE", "1" if procs == 1 else "0")
+    os.environ.setdefault("GK_SAMPLE_LANES", "3" if procs == 1 else "2")      # samples in flight per worker process
     own_threads = procs > 1 and "GK_THREADS" not in os.environ and os.environ.get("GK_SAMPLE_SEARCH") == "0"
     if own_threads:
         os.environ["GK_THREADS"] = "3"   # per-gene threads (the round-2 path): four processes of three shared the host cores
