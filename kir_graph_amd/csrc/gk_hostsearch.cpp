@@ -930,7 +930,8 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
     }
   }
   if (live.empty()) return GK_OK;
-  static const bool pipeline = [] { const char* e = getenv("GK_SAMPLE_PIPELINE"); return !(e && !strcmp(e, "0")); }();
+  const char* const form = getenv("GK_SAMPLE_PIPELINE");      // read per call: the tests compare both forms in one process
+  const bool pipeline = !(form && !strcmp(form, "0"));
   bool float_tables = true;
   for (int i : live) float_tables = float_tables && jobs[i].d_L && !jobs[i].d_lidx;
   if (pipeline && n_more == 0 && float_tables) {

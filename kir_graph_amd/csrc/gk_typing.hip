@@ -227,7 +227,14 @@ __device__ __forceinline__ uint64_t clear_bit(uint64_t set, int t) {
 // beyond 65534 raises bit 1 of the flag word: the caller then takes the float64 form for this gene.
 constexpr uint16_t kNoIndex = 0xFFFFu;   // "log10 not defined yet" in the index table (rewritten by the next pass)
 
-template <bool kLog, int kSlots, bool kMiss, bool kIdx>
+// kFma: the factor as 0.001 + b * 0.998 in ONE fused multiply-add (b = 1.0 where the allele agrees with the read: the
+// selected bit moved into the exponent field of a double whose low word stays 0): fl(0.001 + 0.998) == 0.999 exactly,
+// so the factors are the reference's two constants bit for bit.  v_bfe_i32 + v_and_b32 + v_fma_f64 + v_mul_f64 issue in
+// 16.05 cycles per factor and slot where the two v_bfi_b32 of the select form take 18.05 (profiles/r03_valu_rate.txt);
+// in the kernel the form measured no faster (3.18 - 3.21 against 3.15 ms per sample), it stays as an option.
+// The bit rows of the NEGATIVE variants are inverted when they are laid down in LDS (once per variant, not per factor
+// and slot), so that one walk in list order serves both signs.
+template <bool kLog, int kSlots, bool kMiss, bool kIdx, bool kFma = false>
 __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* rows, int64_t n_rows, const uint32_t* off,
                                                                 const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
                                                                 const uint32_t* mask_t, int words, int n_allele, int a_base,
@@ -264,11 +271,11 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
       const uint32_t b = __builtin_amdgcn_readfirstlane(off[4 * row]);
       const uint32_t mid = __builtin_amdgcn_readfirstlane(off[4 * row + 2]);
       const uint32_t e = __builtin_amdgcn_readfirstlane(off[4 * row + 4]);
-      double p[kSlots];
+      double p[kSlots], agree[kSlots];
       uint32_t miss[kSlots];
       uint32_t nvar = 0;
 #pragma unroll
-      for (int s = 0; s < kSlots; ++s) { p[s] = 1.0; miss[s] = 0; }
+      for (int s = 0; s < kSlots; ++s) { p[s] = 1.0; miss[s] = 0; agree[s] = 0.0; }
       for (uint32_t base = b; base < e; base += 64) {
         const uint32_t k = base + lane;
         bool my_keep = false;
@@ -285,6 +292,10 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
               if (w_base + w < words) mrow[w] = src[(int64_t)w * n_span];
           }
           my_keep = !(vflag[v] & (k < mid ? 1 : 2));
+          if (kFma && k >= mid) {
+#pragma unroll
+            for (int w = 0; w < kPassWords; ++w) mrow[w] = ~mrow[w];     // "the allele lacks it" = agreement with a negative id
+          }
         }
         // kept variants of the chunk as scalar bit sets, walked in order: the positive ones (ordinals
         // below `mid`) come first, then the negative ones, whose factors are swapped
@@ -315,7 +326,11 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
 #pragma unroll
           for (int s = 0; s < kSlots; ++s) {
             const int32_t m = __builtin_amdgcn_sbfe((int32_t)w[s], my_bit, 1);   // -1: the allele has the variant
-            if (positive) {
+            if (kFma) {
+              agree[s] = __hiloint2double(m & 0x3FF00000, __double2loint(agree[s]));   // 1.0 / 0.0: only the high word changes
+              p[s] *= __builtin_fma(agree[s], 0.998, 0.001);
+              if (kMiss) miss[s] += (uint32_t)(m + 1);
+            } else if (positive) {
               p[s] *= __hiloint2double((m & kHi999) | (~m & kHi001), (m & kLo999) | (~m & kLo001));   // 1.0 * f == f
               if (kMiss) miss[s] += (uint32_t)(m + 1);
             } else {
@@ -343,8 +358,12 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
             apply(wb, positive);
           }
         };
-        walk(kept & pos_lanes, true);
-        walk(kept & ~pos_lanes, false);
+        if (kFma) {
+          walk(kept, true);
+        } else {
+          walk(kept & pos_lanes, true);
+          walk(kept & ~pos_lanes, false);
+        }
         __builtin_amdgcn_wave_barrier();   // the next chunk overwrites the rows
       }
 #pragma unroll
@@ -412,16 +431,16 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
     } else
     if (probs) {
       const int n_r = (int)min<int64_t>(kTileRows, n_rows - row0);
-      uint64_t key0 = kLutEmptyKey, key1 = kLutEmptyKey;   // the two most recent values of this thread's read
-      double val0 = 0.0, val1 = 0.0;
-      for (int idx = tid; idx < n_pass * kTileRows; idx += kCompatThreads) {
-        const int al = idx / kTileRows, r = idx % kTileRows;
-        const bool in = r < n_r;
-        if (!in && !(kLog && miss8)) continue;
-        double v = in ? tile[al * kTileLd + r] : 1.0;
-        if (kLog && in) {
-          // one read's alleles share a handful of values: most lookups end in these two registers
-          const uint64_t key = (uint64_t)__double_as_longlong(v);
+      if (kLog) {
+        // Pass 1 of the way out: every product of the tile is replaced, in place, by its log10 from the value table.
+        // A thread keeps to ONE read (its alleles share a handful of values: most lookups end in the two registers).
+        uint64_t key0 = kLutEmptyKey, key1 = kLutEmptyKey;   // the two most recent values of this thread's read
+        double val0 = 0.0, val1 = 0.0;
+        for (int idx = tid; idx < n_pass * kTileRows; idx += kCompatThreads) {
+          const int al = idx / kTileRows, r = idx % kTileRows;
+          if (r >= n_r) continue;
+          double* const cell = &tile[al * kTileLd + r];
+          const uint64_t key = (uint64_t)__double_as_longlong(*cell);
           if (key != key0) {
             double val;
             if (key == key1) {
@@ -434,29 +453,47 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
             key1 = key0; val1 = val0;
             key0 = key; val0 = val;
           }
-          v = val0;
+          *cell = val0;
         }
-        if (in) probs[(int64_t)(a_base + al) * n_rows + row0 + r] = v;
-        if (kLog && miss8) {
-          // The mismatch count of (read, allele) read back from the log-likelihood: -L = 3 m + 0.000434 (n - m),
-          // so m = floor(-L / 3 + 1/4) for any list shorter than ~5000 ids.  u8 table [allele][ldm], four rows of
-          // a quad packed into one store; rows past the end hold 0 (they add nothing to any |a - b| sum).
-          // A count >= 100 (the product is about to leave the normal range / underflow, L = -inf) raises the
-          // flag that sends the gene to the exact search; NaN (log10 not defined yet) is rewritten by the next pass.
-          uint32_t m = 0;
-          if (in) {
-            const double t = __builtin_fma(v, -1.0 / 3.0, 0.25);
-            if (t < 100.0) m = (uint32_t)(int)t;
-            else { m = 255u; if (v == v) atomicOr(bound_flags, 1u); }
+        __syncthreads();
+      }
+      // Pass 2: a thread takes FOUR consecutive reads of one allele -- 32 bytes of the column-major table (four stores off
+      // one address) and, on the product path, their four mismatch bytes as one word.  The mismatch count of
+      // (read, allele) is read back from the log-likelihood: -L = 3 m + 0.000434 (n - m), so m = floor(-L / 3 + 1/4)
+      // for any list shorter than ~5000 ids.  u8 table [allele][ldm]; rows past the end hold 0 (they add nothing to any
+      // |a - b| sum).  A count >= 100 (the product is about to leave the normal range / underflow, L = -inf) raises the
+      // flag that sends the gene to the exact search; NaN (log10 not defined yet) is rewritten by the next pass.
+      constexpr int kQuads = kTileRows / 4;
+      for (int it = tid; it < n_pass * kQuads; it += kCompatThreads) {
+        const int al = it / kQuads, r0 = 4 * (it % kQuads);
+        const double* const cell = &tile[al * kTileLd + r0];
+        double v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = cell[j];
+        if (r0 < n_r) {
+          double* const dst = probs + (int64_t)(a_base + al) * n_rows + row0 + r0;
+          if (r0 + 4 <= n_r) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = v[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (r0 + j < n_r) dst[j] = v[j];
           }
-          uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xF9, 0xF, 0xF, true);      // lane + 1 of the quad
-          uint32_t packed = m | (x << 8);
-          x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9, 0xF, 0xF, true);               // lane + 2
-          packed |= x << 16;
-          x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9, 0xF, 0xF, true);               // lane + 3
-          packed |= x << 24;
-          if ((r & 3) == 0)
-            *reinterpret_cast<uint32_t*>(miss8 + (int64_t)(a_base + al) * ldm + row0 + r) = packed;
+        }
+        if (kLog && miss8) {
+          uint32_t packed = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (r0 + j < n_r) {
+              const double t = __builtin_fma(v[j], -1.0 / 3.0, 0.25);
+              uint32_t m;
+              if (t < 100.0) m = (uint32_t)(int)t;
+              else { m = 255u; if (v[j] == v[j]) atomicOr(bound_flags, 1u); }
+              packed |= m << (8 * j);
+            }
+          }
+          *reinterpret_cast<uint32_t*>(miss8 + (int64_t)(a_base + al) * ldm + row0 + r0) = packed;
         }
       }
     }
@@ -478,16 +515,21 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
   if (n_mask > 0)
     GK_KERNEL(transpose_mask, dim3((unsigned)((n_mask + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
               gk_ptr<uint32_t>(d_mask), vend - vbeg, words, mask_t);
+  // GK_COMPAT_FORM = select (default) | fma: how a factor is chosen, see compat_kernel (the fma form measured 1 - 2 %
+  // slower on the bench sample, profiles/r03_compat_variants.txt: the factor loop is 56 % of the kernel's VALU work)
+  const char* const form_env = getenv("GK_COMPAT_FORM");      // read per call: the tests compare both forms in one process
+  const bool fma_form = form_env && !strcmp(form_env, "fma");
   for (int a_base = 0; a_base < n_allele; a_base += 64 * kMaxSlots) {
     const int slots = std::min(kMaxSlots, (n_allele - a_base + 63) / 64);
-#define GK_COMPAT_GO(S, IDX)                                                                                       \
-  GK_KERNEL((compat_kernel<kLog, S, !kLog, IDX>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows,    \
-            tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, mask_t, words, n_allele, a_base, out,    \
+#define GK_COMPAT_GO(S, IDX, FMA)                                                                                     \
+  GK_KERNEL((compat_kernel<kLog, S, !kLog, IDX, FMA>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows,  \
+            tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, mask_t, words, n_allele, a_base, out,       \
             miss, nvar, view, empty_p, miss8, ldm, bound_flags, lidx)
-#define GK_COMPAT_LAUNCH(S)                               \
-  GK_PROF(ctx, GK_K_COMPAT, {                             \
-    if (kLog && lidx) GK_COMPAT_GO(S, (kLog && true));    \
-    else GK_COMPAT_GO(S, false);                          \
+#define GK_COMPAT_LAUNCH(S)                                       \
+  GK_PROF(ctx, GK_K_COMPAT, {                                     \
+    if (kLog && lidx) GK_COMPAT_GO(S, (kLog && true), false);     \
+    else if (kLog && fma_form) GK_COMPAT_GO(S, false, (kLog && true)); \
+    else GK_COMPAT_GO(S, false, false);                           \
   })
     switch (slots) {
       case 1: GK_COMPAT_LAUNCH(1); break;

@@ -246,3 +246,35 @@ def test_index_table_equals_the_float_table(device, small_case, monkeypatch):
     assert m.L is not None and np.array_equal(np.asarray(results["1"][1][next(iter(results["1"][1]))][-1].allele_prob),
                                              np.asarray(results["0"][1][next(iter(results["0"][1]))][-1].allele_prob))
 
+
+
+@pytest.mark.gpu
+def test_forms_of_the_sample_search_and_of_the_factor_agree(device, small_case, monkeypatch):
+    """A whole sample typed four ways gives the same bits in every field of every copy-number step: the gene loop
+    pipelined on one stream (marks; the default) or in lock-step (GK_SAMPLE_PIPELINE=0), the factor of the
+    compatibility kernel chosen by bit-field selects (default) or by one fused multiply-add (GK_COMPAT_FORM=fma), and
+    the sample preamble on the urgent stream or on the lane's own."""
+    from kir_graph_amd.hisat2 import extractVariant, pairLines
+    monkeypatch.setenv("GK_SEARCH", "bound")
+    sidx, gidx, sample = small_case
+    data = extractVariant(pairLines(synth.toSamLines(sample)), gidx, dev=device)
+    gene_cn = {g: (k % 4) + 1 for k, g in enumerate(sidx.genes)}
+    results = {}
+    for name, env in (("default", {}), ("lock-step", {"GK_SAMPLE_PIPELINE": "0"}), ("fma", {"GK_COMPAT_FORM": "fma"}),
+                      ("plain preamble", {"GK_URGENT_PREAMBLE": "0"})):
+        for k in ("GK_SAMPLE_PIPELINE", "GK_COMPAT_FORM", "GK_URGENT_PREAMBLE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        typer = selectKirTypingModel("full", data, top_n=600, variant_correction=True)
+        assert typer._wholeSample()
+        results[name] = (typer.typing(gene_cn), typer._result)
+    want_calls, want = results["default"]
+    assert any(len(steps) > 1 for steps in want.values())
+    for name, (calls, got) in results.items():
+        assert calls == want_calls, name
+        for gene, steps in want.items():
+            assert len(got[gene]) == len(steps), (name, gene)
+            for x, y in zip(got[gene], steps):
+                for f in ("value", "value_sum_indv", "allele_id", "fraction"):
+                    assert np.array_equal(np.asarray(getattr(x, f)), np.asarray(getattr(y, f))), (name, gene, f)
