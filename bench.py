@@ -171,17 +171,14 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
         method = "exonfirst_1"
     depth = int(os.environ.get("GK_PREFETCH", "1")) if depth is None else depth
     lanes = int(os.environ.get("GK_SAMPLE_LANES", "2"))   # samples typed at a time, each on a host thread and a stream of its own
-    # staging (copy + tabulation) has contexts of its own, one per staging thread: the typing lanes use workers 0..lanes*n-1
-    n_ingest = max(1, int(os.environ.get("GK_INGEST_THREADS", "1")))
-    ingest_of = {}
-    ingest_lock = threading.Lock()
-
-    def ingest_ctx():
-        me = threading.get_ident()
-        with ingest_lock:
-            if me not in ingest_of:
-                ingest_of[me] = dev.worker(lanes * hostThreads() + len(ingest_of) % n_ingest, urgent=True)
-            return ingest_of[me]
+    # Staging has contexts of its own (the typing lanes use workers 0..lanes*n-1): one for the copy of a sample's
+    # records into HBM, one -- with a high-priority stream -- for its tabulation.  The two are stages of a pipeline
+    # (GK_COPY_AHEAD=1, default): while sample k is typed, sample k+1 is tabulated and the records of k+2 are on their
+    # way, each stage on a thread of its own.  In one stage (GK_COPY_AHEAD=0) a sample's staging took 6 - 7 ms of wall time
+    # next to the typing kernels -- 80 % of a worker process's budget per sample.
+    ingest = dev.worker(lanes * hostThreads(), urgent=True)
+    copier = dev.worker(lanes * hostThreads() + 1)
+    copy_ahead = os.environ.get("GK_COPY_AHEAD", "1") != "0"
 
     trace = os.environ.get("GK_BENCH_TRACE") == "1"      # a timeline of the host threads on stderr (tools/host_timeline.py)
 
@@ -189,12 +186,25 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
         if trace:
             log(f"[trace] {what} {k} {threading.get_native_id()} {t0:.6f} {time.perf_counter():.6f}")
 
-    def stage(k):
+    def copy_in(k):
+        t0 = time.perf_counter()
+        mates = inputs[k % len(inputs)][0].toDevice(copier)
+        copier.sync()                       # the records are in HBM when the next stage takes them
+        note("copy", k, t0)
+        return k, mates
+
+    def tabulate(item):
+        t0 = time.perf_counter()
+        k, mates = item
+        _, table, gene_cn = inputs[k % len(inputs)]
+        tab = Tabulation(dindex, mates, dev=ingest)
+        note("stage", k, t0)
+        return tab, table, gene_cn, k
+
+    def stage(k):                           # both in one go: queued on one stream, one after the other
         t0 = time.perf_counter()
         pinned, table, gene_cn = inputs[k % len(inputs)]
-        ingest = ingest_ctx()
-        mates = pinned.toDevice(ingest)
-        tab = Tabulation(dindex, mates, dev=ingest)
+        tab = Tabulation(dindex, pinned.toDevice(ingest), dev=ingest)
         note("stage", k, t0)
         return tab, table, gene_cn, k
 
@@ -217,11 +227,9 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
         for k in items:
             out = type_one(stage(k), 0)
         return out
-    # staging a sample takes 6 - 10 ms of wall time next to the typing kernels (it waits for the device several times,
-    # and its kernels run between theirs): it has a high-priority stream; a second staging thread (GK_INGEST_THREADS=2)
-    # measured slower
-    depth = max(depth, n_ingest)
-    for out in overlapped(prefetched(items, stage, depth=depth, workers=n_ingest), type_one, lanes=lanes):
+    staged = prefetched(prefetched(items, copy_in, depth=depth), tabulate, depth=depth) if copy_ahead \
+        else prefetched(items, stage, depth=depth)
+    for out in overlapped(staged, type_one, lanes=lanes):
         pass
     return out
 
@@ -368,11 +376,14 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
     if j == 0 and getattr(args, "profile_host", False):
         import cProfile
         import pstats
+        n_prof = int(os.environ.get("GK_PROFILE_STEPS", "1"))     # with GK_SAMPLE_LANES=1 GK_PREFETCH=0 everything is on this thread
         pr = cProfile.Profile()
         pr.enable()
-        run_steps(1, dev, dindex, gidx, inputs, args.method)
+        run_steps(n_prof, dev, dindex, gidx, inputs, args.method)
         pr.disable()
+        log(f"[bench] host profile of {n_prof} step(s)")
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(45)
     # per-kernel events inside the timed region cost ~3 ms per step (a profiling signal per dispatch): only on request;
     # the roofline comes from the serial pass after the region
     in_region = bool(getattr(args, "verbose", False)) or os.environ.get("GK_BENCH_PROFILE") == "1"

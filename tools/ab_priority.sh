@@ -11,7 +11,6 @@ run() {
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1]); print('$label |', round(d['ms_per_step'],3), 'ms/step', round(d['host']['host_core_s_per_step']*1e3,1), 'core-ms/step', round(d['host']['cores_busy'],2), 'cores busy')"
 }
-export GK_INGEST_THREADS=${GK_INGEST_THREADS:-1}
 for rep in 1 2; do
   run "1 process x 3 lanes, staging + preamble urgent" GK_PROCS_PER_GPU=1 GK_SAMPLE_LANES=3
   run "1 process x 3 lanes, staging urgent" GK_PROCS_PER_GPU=1 GK_SAMPLE_LANES=3 GK_URGENT_PREAMBLE=0

@@ -24,11 +24,11 @@ run "default (2 procs x 2 lanes, block), unpinned" X=1 --
 for K in 16 8 4 3 2; do
   run "default (2 procs x 2 lanes, block), $K cores" X=1 -- --cores-per-gpu $K
 done
-run "one process x 3 lanes, block, unpinned" GK_PROCS_PER_GPU=1 GK_SAMPLE_LANES=3 --
-for K in 3 2; do
-  run "one process x 3 lanes, block, $K cores" GK_PROCS_PER_GPU=1 GK_SAMPLE_LANES=3 -- --cores-per-gpu $K
+run "one process x 3 lanes, block, unpinned" GK_PROCS_PER_GPU=1 --
+for K in 4 3 2; do
+  run "one process x 3 lanes, block, $K cores" GK_PROCS_PER_GPU=1 -- --cores-per-gpu $K
 done
-run "one process x 2 lanes, block, 2 cores" GK_PROCS_PER_GPU=1 GK_SAMPLE_LANES=2 -- --cores-per-gpu 2
+run "one process x 4 lanes, block, 2 cores" GK_PROCS_PER_GPU=1 GK_SAMPLE_LANES=4 -- --cores-per-gpu 2
 run "round-2 layout (per-gene threads, 4 procs x 3, spin), unpinned" GK_SAMPLE_SEARCH=0 GK_PROCS_PER_GPU=4 GK_WAIT_POLICY=spin --
 run "round-2 layout (per-gene threads, 4 procs x 3, spin), 4 cores" GK_SAMPLE_SEARCH=0 GK_PROCS_PER_GPU=4 GK_WAIT_POLICY=spin -- --cores-per-gpu 4
 run "round-2 layout (per-gene threads, 4 procs x 3, spin), 2 cores" GK_SAMPLE_SEARCH=0 GK_PROCS_PER_GPU=4 GK_WAIT_POLICY=spin -- --cores-per-gpu 2

@@ -17,7 +17,6 @@ run() {
     | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); d['label']='$label'; print(json.dumps({k: d[k] for k in ('label','ms_per_step','value','host','config','search_steps')}))" >> $O/layout_sweep.jsonl
   tail -1 $O/layout_sweep.jsonl | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['label'], '|', round(d['ms_per_step'],3), 'ms/step', round(d['host']['host_core_s_per_step']*1e3,2), 'core-ms/step', round(d['host']['cores_busy'],2), 'cores busy')"
 }
-export GK_INGEST_THREADS=${GK_INGEST_THREADS:-1}
 for PL in "1 3" "1 4" "2 2" "2 3" "3 2" "1 2" "2 1" "4 1"; do
   set -- $PL
   run "$1p x $2l unpinned" GK_PROCS_PER_GPU=$1 GK_SAMPLE_LANES=$2 --
