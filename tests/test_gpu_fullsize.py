@@ -90,6 +90,29 @@ def test_typing_recovers_the_planted_genotype_and_is_deterministic(full):
         assert np.array_equal(a.fraction, b.fraction)
 
 
+def test_forms_of_the_gene_loop_agree_at_full_size(full, monkeypatch):
+    """configs[1] typed with the genes of the sample pipelined on marks of one stream (the default; at this size the
+    staging rings go round while marks are outstanding), in lock-step (GK_SAMPLE_PIPELINE=0) and with a thread and a
+    stream per gene (GK_SAMPLE_SEARCH=0): the same bits in every field of every copy-number step of every gene."""
+    sidx, gidx, sample, rec, data = full
+    results = {}
+    for name, env in (("pipelined", {}), ("lock-step", {"GK_SAMPLE_PIPELINE": "0"}), ("per gene", {"GK_SAMPLE_SEARCH": "0"})):
+        for k in ("GK_SAMPLE_PIPELINE", "GK_SAMPLE_SEARCH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        typer, calls, _ = _type(data, sample)
+        results[name] = (calls, typer._result)
+    want_calls, want = results["pipelined"]
+    for name, (calls, got) in results.items():
+        assert calls == want_calls, name
+        for gene, steps in want.items():
+            assert len(got[gene]) == len(steps), (name, gene)
+            for x, y in zip(got[gene], steps):
+                for f in ("value", "value_sum_indv", "allele_id", "fraction"):
+                    assert np.array_equal(np.asarray(getattr(x, f)), np.asarray(getattr(y, f))), (name, gene, f)
+
+
 def test_other_strategies_agree_on_the_planted_genotype(full):
     sidx, gidx, sample, rec, data = full
     want = sorted(a for g in sample.gene_cn for a in sample.truth[g])

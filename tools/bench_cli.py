@@ -44,6 +44,15 @@ for b in bams:
     argv += ["--alignment", b]
 argv += ["--cn-provided"] + cns
 args = cli.createParser().parse_args(argv + extra)
+import resource
+
+
+def cpu_now():      # user, system seconds of this process (its ingest / typing threads included)
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    return ru.ru_utime, ru.ru_stime
+
+
+cpu0 = cpu_now()    # whatever writing the inputs cost is before this point
 t = time.time()
 if os.environ.get("GK_CLI_PROFILE") == "1":     # where does the main thread spend its time?
     import cProfile, pstats
@@ -55,10 +64,11 @@ if os.environ.get("GK_CLI_PROFILE") == "1":     # where does the main thread spe
 else:
     cli.main(args)
 dt = time.time() - t
-import resource
-ru = resource.getrusage(resource.RUSAGE_SELF)
-print(f"process CPU: {ru.ru_utime:.1f}s user + {ru.ru_stime:.1f}s system over {dt:.1f}s of wall = {(ru.ru_utime + ru.ru_stime) / dt:.1f} cores busy, "
-      f"{(ru.ru_utime + ru.ru_stime) / n_samples:.2f} core-s per sample (input generation included when this run made them)", file=sys.stderr)
+cpu1 = cpu_now()
+user, system = cpu1[0] - cpu0[0], cpu1[1] - cpu0[1]
+print(f"process CPU of the command line alone: {user:.1f}s user + {system:.1f}s system over {dt:.1f}s of wall = {(user + system) / dt:.1f} cores busy, "
+      f"{(user + system) / n_samples:.2f} core-s per sample of {2 * n_pairs} reads (ingest + typing + outputs; typing alone is "
+      f"~0.025 core-s per 2 M reads, bench.py host.host_core_s_per_step)", file=sys.stderr)
 if rank == 0:
   print(f"command line: {dt:.2f}s for {n_samples} samples = {dt / n_samples:.2f}s per sample of {2 * n_pairs} reads "
       f"({2 * n_pairs * n_samples / dt / 1e6:.2f} M reads/s end to end; flags {extra})")
