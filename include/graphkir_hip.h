@@ -355,6 +355,12 @@ int gk_site_verdict(const int64_t* pos, const int64_t* code, const uint8_t* nega
 int gk_site_verdict_tallies(const uint64_t* keys, int64_t n_keys, const int64_t* label_of_insert, int64_t n_insert,
                             const int32_t* ordinal, const uint32_t* positive, const uint32_t* negative, int64_t n,
                             int32_t cn, int32_t* homozygous);
+/* The same verdict for every gene of a sample in one call (the gene loop of kir_typing.py:103-132 asks it once per gene):
+ * the tallies are grouped by gene, group g = entries [bounds[g], bounds[g + 1]) with copy number cn[g];
+ * homozygous[g] = 0 for cn[g] <= 1 (isHomozygous is not asked then, typing_mulit_allele.py:386). */
+int gk_site_verdict_genes(const uint64_t* keys, int64_t n_keys, const int64_t* label_of_insert, int64_t n_insert,
+                          const int32_t* ordinal, const uint32_t* positive, const uint32_t* negative,
+                          const int64_t* bounds, int32_t n_groups, const int32_t* cn, int32_t* homozygous);
 
 /* ---- EM strategy: typing_em.py:68-188.
  * gk_em_sets: per-row candidate-allele bit sets (getCandidateAllelePerRead + getMostFreqAllele).

@@ -198,6 +198,8 @@ _SIGS = {
     "gk_search_destroy": (C.c_int, [C.c_void_p]),
     "gk_site_verdict_tallies": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.c_int32, C.POINTER(C.c_int32)]),
+    "gk_site_verdict_genes": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "gk_site_verdict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                   C.POINTER(C.c_int32)]),
     "gk_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),

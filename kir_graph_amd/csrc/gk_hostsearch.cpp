@@ -1068,4 +1068,20 @@ int gk_site_verdict_tallies(const uint64_t* keys, int64_t n_keys, const int64_t*
   return GK_OK;
 }
 
+int gk_site_verdict_genes(const uint64_t* keys, int64_t n_keys, const int64_t* label_of_insert, int64_t n_insert,
+                          const int32_t* ordinal, const uint32_t* positive, const uint32_t* negative,
+                          const int64_t* bounds, int32_t n_groups, const int32_t* cn, int32_t* homozygous) {
+  GK_REQUIRE(bounds && cn && homozygous && n_groups >= 0, "bad verdict arguments");
+  for (int32_t g = 0; g < n_groups; ++g) {
+    const int64_t a0 = bounds[g], n = bounds[g + 1] - a0;
+    GK_REQUIRE(a0 >= 0 && n >= 0, "tally groups must follow one another");
+    homozygous[g] = 0;
+    if (cn[g] <= 1) continue;
+    const int rc = gk_site_verdict_tallies(keys, n_keys, label_of_insert, n_insert, n ? ordinal + a0 : nullptr,
+                                           n ? positive + a0 : nullptr, n ? negative + a0 : nullptr, n, cn[g], &homozygous[g]);
+    if (rc) return rc;
+  }
+  return GK_OK;
+}
+
 }  // extern "C"

@@ -155,16 +155,22 @@ class Tabulation:
                 if len(o) and int(o[-1]) >= n_index:
                     novel = o >= n_index
                     gene_of[novel] = (self.novelKeys()[o[novel] - n_index] >> np.uint64(56)).astype(gene_of.dtype)
-                prep = store[bool(multiple)] = (vflag, cnt, rows, off, (o, p, q, gene_of))
+                # grouped by gene once (ordinals ascending inside a gene, as survivingCounts lists them): a gene's tallies
+                # are a slice, and the zygosity verdicts of all genes one native call (gk_site_verdict_genes)
+                order = np.argsort(gene_of, kind="stable")
+                bounds = np.searchsorted(gene_of[order], np.arange(len(self.dindex.host.genes) + 1)).astype(np.int64)
+                grouped = (np.ascontiguousarray(o[order], dtype=np.int32), np.ascontiguousarray(p[order], dtype=np.uint32),
+                           np.ascontiguousarray(q[order], dtype=np.uint32), bounds)
+                prep = store[bool(multiple)] = (vflag, cnt, rows, off, grouped)
         return prep
 
     @staticmethod
     def survivingOfGene(prep, g: int):
         """(ordinals, positive tally, negative tally) of gene ``g`` out of ``prepared()``'s sample-wide list: what
         ``survivingCounts(cnt, vflag, gene=(g, vbeg, vend))`` returns, without a device call."""
-        o, p, q, gene_of = prep[4]
-        mine = gene_of == g
-        return o[mine], p[mine], q[mine]
+        o, p, q, bounds = prep[4]
+        a, b = int(bounds[g]), int(bounds[g + 1])
+        return o[a:b], p[a:b], q[a:b]
 
     def on(self, dev: Device) -> "Tabulation":
         """The same tabulation driven from another context (stream) of the same GPU.

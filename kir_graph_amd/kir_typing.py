@@ -241,8 +241,9 @@ class TypingWithPosNegAllele(_GenesInParallel):
         vflag, cnt, rows_all, off = prep[:4]
         todo = [(gene, int(cn)) for gene, cn in gene_cn.items() if cn]
         entries = []                     # (gene, cn, typ or None, job, homo)
-        for gene, cn in todo:
-            view = _GeneView(self._data, gene, self._multiple, tab=tab)
+        views = [_GeneView(self._data, gene, self._multiple, tab=tab) for gene, _ in todo]
+        verdicts = self._zygosityVerdicts(tab, prep, [(v.g, cn) for v, (_, cn) in zip(views, todo)])
+        for (gene, cn), view in zip(todo, views):
             if view.g is None or not view.alleles:
                 entries.append((gene, cn, None, None, False))
                 continue
@@ -257,7 +258,7 @@ class TypingWithPosNegAllele(_GenesInParallel):
             if b - a == 0:
                 entries.append((gene, cn, typ, None, False))
                 continue
-            job, homo = typ.geneJob(cn)
+            job, homo = typ.geneJob(cn, verdicts.get(view.g) if cn > 1 else False)
             entries.append((gene, cn, typ, job, homo))
         live = [e for e in entries if e[3] is not None]
         if live:
@@ -299,6 +300,27 @@ class TypingWithPosNegAllele(_GenesInParallel):
             if reads_num < min_reads_num:
                 warning_genes.append(gene)
         return predict_alleles, warning_genes
+
+    @staticmethod
+    def _zygosityVerdicts(tab, prep, wanted: list[tuple[int | None, int]]) -> dict[int, bool]:
+        """isHomozygous (typing_mulit_allele.py:807-857) of every listed (backbone ordinal, cn) in ONE native call on the
+        sample's grouped tallies (``gk_site_verdict_genes``); a gene is asked once per sample."""
+        import ctypes as C
+        from ._lib import check, lib
+        o, p, q, bounds = prep[4]
+        tables = tab.labelTables()
+        if tables is None:
+            return {}
+        keys_all, ins_code = tables
+        cn = np.ones(len(bounds) - 1, dtype=np.int32)
+        for g, c in wanted:
+            if g is not None:
+                cn[g] = c
+        out = np.zeros(len(cn), dtype=np.int32)
+        check(lib().gk_site_verdict_genes(keys_all.ctypes.data, len(keys_all), ins_code.ctypes.data, len(ins_code),
+                                          o.ctypes.data, p.ctypes.data, q.ctypes.data, bounds.ctypes.data, len(cn),
+                                          cn.ctypes.data, out.ctypes.data))
+        return {g: bool(out[g]) for g, c in wanted if g is not None and c > 1}
 
     def typingPerGene(self, gene: str, cn: int) -> tuple[list[str], int]:
         logger.debug(f"[Allele] {gene=} {cn=}")

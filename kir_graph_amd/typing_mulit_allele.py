@@ -534,13 +534,17 @@ class AlleleTyping:
                 else:
                     m.dev.call_log.append(("fraction_chunks", a, b, c_, d))
 
-    def geneJob(self, cn: int):
+    def geneJob(self, cn: int, verdict: bool | None = None):
         """(``_lib.GeneJob`` for ``gk_sample_search``, homozygous?) of a model built with ``_defer_launch``: the
-        zygosity decision of ``typing`` (383-410) is taken here, the table and the search run in the library."""
+        zygosity decision of ``typing`` (383-410) is taken here, the table and the search run in the library.
+        ``verdict``: what ``_isHomozygous(cn)`` says, when the caller asked for all genes at once."""
         from ._lib import GeneJob
         if cn < 1:
             raise ValueError(f"CN should be >= 1, got {cn}")
-        homo = self._isHomozygous(cn) if self.force_homo is None else self.force_homo
+        if self.force_homo is not None:
+            homo = self.force_homo
+        else:
+            homo = self._isHomozygous(cn) if verdict is None else verdict
         m = self._model
         vbeg, vend, mask, words = m._geom
         job = GeneJob(d_rows=m.rows.ptr, n_rows=m.n_rows, d_mask=mask.ptr, d_L=m._L.ptr if m._L else 0,

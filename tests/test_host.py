@@ -994,6 +994,46 @@ def test_site_verdict_from_tallies_equals_reference_loop():
     assert verdicts == {True, False}
 
 
+def test_site_verdicts_of_all_genes_in_one_call():
+    """gk_site_verdict_genes over tallies grouped by gene = gk_site_verdict_tallies group by group (0 where cn <= 1,
+    where the question is not asked); empty groups included."""
+    import ctypes as C
+    from kir_graph_amd.index import packKey
+    rng = np.random.default_rng(5)
+    ins_code = np.array([65, 67, 258], dtype=np.int64)
+    seen = set()
+    for trial in range(60):
+        n_keys = int(rng.integers(20, 200))
+        keys = np.array([packKey(int(rng.integers(0, 6)), int(rng.integers(0, 12)), int(rng.choice([0, 1, 1, 2])),
+                                 int(rng.integers(0, 3))) for _ in range(n_keys)], dtype=np.uint64)
+        n_groups = int(rng.integers(1, 9))
+        sizes = rng.integers(0, 40, n_groups)
+        sizes[rng.integers(n_groups)] = 0
+        bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        n = int(bounds[-1])
+        ords = rng.integers(0, n_keys, n).astype(np.int32)
+        pcount = np.where(rng.random(n) < 0.7, rng.integers(1, 60, n), 0).astype(np.uint32)
+        ncount = np.where(rng.random(n) < 0.7, rng.integers(1, 60, n), 0).astype(np.uint32)
+        cn = rng.integers(0, 5, n_groups).astype(np.int32)
+        got = np.full(n_groups, -1, dtype=np.int32)
+        _lib.check(_lib.lib().gk_site_verdict_genes(keys.ctypes.data, n_keys, ins_code.ctypes.data, len(ins_code),
+                                                    ords.ctypes.data, pcount.ctypes.data, ncount.ctypes.data,
+                                                    bounds.ctypes.data, n_groups, cn.ctypes.data, got.ctypes.data))
+        for g in range(n_groups):
+            a, b = int(bounds[g]), int(bounds[g + 1])
+            want = 0
+            if cn[g] > 1:
+                v = C.c_int32()
+                o_, p_, q_ = (np.ascontiguousarray(x[a:b]) for x in (ords, pcount, ncount))
+                _lib.check(_lib.lib().gk_site_verdict_tallies(keys.ctypes.data, n_keys, ins_code.ctypes.data, len(ins_code),
+                                                              o_.ctypes.data, p_.ctypes.data, q_.ctypes.data, b - a,
+                                                              int(cn[g]), C.byref(v)))
+                want = v.value
+            assert got[g] == want, (trial, g)
+            seen.add((bool(cn[g] > 1), int(got[g])))
+    assert {(True, 0), (True, 1), (False, 0)} <= seen
+
+
 def test_name_collation_with_a_long_common_prefix(tmp_path):
     """Names of one sequencing run share instrument / run / flow cell / lane: the sort keys start after the prefix
     common to all names (cut back to the start of a digit run it would split), and the order is still the plain
