@@ -158,11 +158,12 @@ class PinnedRecords:
 
 
 # ------------------------------------------------------------------------------------------ steps
-def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None):
+def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None, resident=None):
     """Types the samples ``inputs[k % len(inputs)]`` for k in ``items``: pinned records -> HBM -> tabulation ->
     typing -> calls.  Like a cohort run the samples go through ``cohort.prefetched``: copy + tabulation of
     the next sample are issued (on their own stream) while the current one is typed.  Every copy,
-    tabulation and typing of the listed samples starts and ends inside this call."""
+    tabulation and typing of the listed samples starts and ends inside this call.  ``resident``: the records of the
+    distinct samples already in HBM (one device buffer per entry of ``inputs``) -- a step then starts at the tabulation."""
     from kir_graph_amd.cohort import overlapped, prefetched
     from kir_graph_amd.engine import Tabulation
     from kir_graph_amd.hisat2 import SampleData
@@ -208,6 +209,9 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
         note("stage", k, t0)
         return tab, table, gene_cn, k
 
+    def from_hbm(k):                        # the records are in HBM already: the step starts here
+        return tabulate((k, resident[k % len(inputs)]))
+
     def type_one(item, lane):
         t0 = time.perf_counter()
         tab, table, gene_cn, k = item
@@ -217,7 +221,8 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
         calls, warn = typer.typing(gene_cn)
         n_valid = tab.n_valid
         tab.close()
-        tab.mates.free()
+        if resident is None:
+            tab.mates.free()
         note("type", k, t0)
         return calls, warn, n_valid, typer
 
@@ -225,10 +230,14 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
     items = range(items) if isinstance(items, int) else items
     if depth <= 0:
         for k in items:
-            out = type_one(stage(k), 0)
+            out = type_one(from_hbm(k) if resident is not None else stage(k), 0)
         return out
-    staged = prefetched(prefetched(items, copy_in, depth=depth), tabulate, depth=depth) if copy_ahead \
-        else prefetched(items, stage, depth=depth)
+    if resident is not None:
+        staged = prefetched(items, from_hbm, depth=depth)
+    elif copy_ahead:
+        staged = prefetched(prefetched(items, copy_in, depth=depth), tabulate, depth=depth)
+    else:
+        staged = prefetched(items, stage, depth=depth)
     for out in overlapped(staged, type_one, lanes=lanes):
         pass
     return out
@@ -368,9 +377,19 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
             call_log += d.call_log or []
         return prof, call_log
 
+    # The records of the distinct samples in HBM before any clock starts (--inputs hbm, the default): `value` is measured
+    # with the inputs resident, a step = tabulation + typing + calls.  A second leg times the same steps with every
+    # sample's records starting in pinned host memory (the 256 MB copy inside the region): `pcie_inclusive`.
+    resident = None
+    if args.inputs == "hbm":
+        resident = [pinned.toDevice(dev) for pinned, _, _ in inputs]
+        dev.sync()
+    pcie_leg = resident is not None and args.pcie_leg
     n_valid = 0
     if args.warmup:
-        n_valid = run_steps(args.warmup, dev, dindex, gidx, inputs, args.method)[2]
+        n_valid = run_steps(args.warmup, dev, dindex, gidx, inputs, args.method, resident=resident)[2]
+        if pcie_leg:
+            run_steps(min(args.warmup, 4), dev, dindex, gidx, inputs, args.method)      # the copy path's contexts and pools
     if getattr(args, "pinned_to", None):      # --cores-per-gpu: the runtime's own threads too (they exist by now)
         pin_all_threads(args.pinned_to)
     if j == 0 and getattr(args, "profile_host", False):
@@ -379,7 +398,7 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
         n_prof = int(os.environ.get("GK_PROFILE_STEPS", "1"))     # with GK_SAMPLE_LANES=1 GK_PREFETCH=0 everything is on this thread
         pr = cProfile.Profile()
         pr.enable()
-        run_steps(n_prof, dev, dindex, gidx, inputs, args.method)
+        run_steps(n_prof, dev, dindex, gidx, inputs, args.method, resident=resident)
         pr.disable()
         log(f"[bench] host profile of {n_prof} step(s)")
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
@@ -387,33 +406,47 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
     # per-kernel events inside the timed region cost ~3 ms per step (a profiling signal per dispatch): only on request;
     # the roofline comes from the serial pass after the region
     in_region = bool(getattr(args, "verbose", False)) or os.environ.get("GK_BENCH_PROFILE") == "1"
+
+    def timed_leg(leg_resident):
+        """EXACTLY args.steps steps between a barrier + device synchronise on both sides; (seconds, host CPU seconds of
+        this worker, the last step's result)."""
+        if j == 0 and gang is not None:
+            gang["next"].value = 0          # nobody claims before the "go" barrier below
+        dev.sync()
+        gang_wait("ready")
+        if comm is not None:
+            comm.barrier()          # RCCL all-reduce + stream synchronise: every rank is ready
+        gang_wait("go")
+        t0 = time.perf_counter()
+        cpu0 = cpu_seconds()
+        last = run_steps(claims(), dev, dindex, gidx, inputs, args.method, resident=leg_resident)
+        for d in all_devices():
+            d.sync()
+        cpu = cpu_seconds() - cpu0          # this worker's host time for its share of the steps (waits that spin included)
+        gang_wait("done")
+        if comm is not None:
+            comm.barrier()
+        return time.perf_counter() - t0, cpu, last
+
     if in_region:
         profiled(True)
-    dev.sync()
-    gang_wait("ready")
-    if comm is not None:
-        comm.barrier()          # RCCL all-reduce + stream synchronise: every rank is ready
-    gang_wait("go")
-    t0 = time.perf_counter()
-    cpu0 = cpu_seconds()
-    last = run_steps(claims(), dev, dindex, gidx, inputs, args.method)
+    elapsed, cpu_s, last = timed_leg(resident)
     if last is not None:
         n_valid = last[2]
-    for d in all_devices():
-        d.sync()
-    cpu_s = cpu_seconds() - cpu0          # this worker's host time for its share of the steps (waits that spin included)
-    gang_wait("done")
-    if comm is not None:
-        comm.barrier()
-    elapsed = time.perf_counter() - t0
     prof, call_log = collect() if in_region else ({}, [])
     profiled(False)
+    pcie_elapsed, pcie_cpu_s = None, 0.0
+    if pcie_leg:
+        pcie_elapsed, pcie_cpu_s, _ = timed_leg(None)
     if j:
-        gang["results"].put({"prof": prof, "call_log": call_log, "cpu_s": cpu_s})
+        gang["results"].put({"prof": prof, "call_log": call_log, "cpu_s": cpu_s, "pcie_cpu_s": pcie_cpu_s})
         return None
     if comm is not None:
         elapsed = comm.maxF64(elapsed)
+        if pcie_elapsed is not None:
+            pcie_elapsed = comm.maxF64(pcie_elapsed)
     timing["elapsed"] = elapsed
+    timing["pcie_elapsed"] = pcie_elapsed
     others = helpers_done() if helpers_done is not None else []      # the other workers have left the GPU
     # ---- the roofline basis: the same step in ONE process, ONE gene thread, no prefetch (kernels back to back)
     serial = None
@@ -423,10 +456,10 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
         os.environ["GK_THREADS"] = "1"
         os.environ["GK_SAMPLE_STREAMS"] = "1"       # one stream: the kernels of a sample run back to back
         try:
-            run_steps(1, dev, dindex, gidx, inputs, args.method, depth=0)      # contexts of this mode warm
+            run_steps(1, dev, dindex, gidx, inputs, args.method, depth=0, resident=resident)      # contexts of this mode warm
             profiled(True)
             t1 = time.perf_counter()
-            run_steps(args.serial_steps, dev, dindex, gidx, inputs, args.method, depth=0)
+            run_steps(args.serial_steps, dev, dindex, gidx, inputs, args.method, depth=0, resident=resident)
             for d in all_devices():
                 d.sync()
             s_elapsed = time.perf_counter() - t1
@@ -443,7 +476,8 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
     from kir_graph_amd.typing_mulit_allele import SEARCH_STATS, sharedLogTable
     n_values = sharedLogTable(dev).known()      # distinct probabilities met so far = entries of the log10 value table
     return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm, "n_values": n_values,
-            "search_steps": dict(SEARCH_STATS), "others": others, "cpu_s": cpu_s + sum(o.get("cpu_s", 0.0) for o in others)}
+            "search_steps": dict(SEARCH_STATS), "others": others, "cpu_s": cpu_s + sum(o.get("cpu_s", 0.0) for o in others),
+            "pcie_cpu_s": pcie_cpu_s + sum(o.get("pcie_cpu_s", 0.0) for o in others)}
 
 
 # ------------------------------------------------------------------------------------------ launcher
@@ -486,6 +520,11 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs for the CPU baseline sample (0 = skip)")
     ap.add_argument("--serial-steps", type=int, default=2,
                     help="steps of the one-process serial pass after the timed region (roofline basis; 0 = skip)")
+    ap.add_argument("--inputs", choices=("hbm", "host"), default="hbm",
+                    help="where a sample's records are when its step starts: resident in HBM (the metric), or in pinned "
+                         "host memory (the 256 MB copy inside the step)")
+    ap.add_argument("--no-pcie-leg", dest="pcie_leg", action="store_false",
+                    help="skip the second timed leg (the same steps from pinned host memory, reported as pcie_inclusive)")
     ap.add_argument("--cores-per-gpu", type=int, default=0,
                     help="pin every rank (its worker processes and threads) to this many host cores of its own, "
                          "before anything touches HIP (0 = no pinning)")
@@ -605,8 +644,12 @@ def main():
                                    f"1 synthetic sample per step and GPU ({args.distinct} distinct samples in "
                                    f"rotation), {2 * args.pairs} 150 bp PE reads, synthetic example_index-shaped index "
                                    f"({sum(len(t.alleles) for t in gidx.tables)} alleles, 15 genes), "
-                                   f"--allele-strategy {args.method}, top_n 600; records start in pinned host memory "
-                                   "(H2D inside the timed region)",
+                                   f"--allele-strategy {args.method}, top_n 600; "
+                                   + ("a step starts with the sample's records resident in HBM (tabulation + typing + calls "
+                                      "inside the timed region); pcie_inclusive: the same steps from pinned host memory"
+                                      if args.inputs == "hbm" else
+                                      "records start in pinned host memory (H2D inside the timed region)"),
+                       "inputs": args.inputs,
                        "pairs_per_sample": args.pairs, "pairs_passing_filter": int(n_valid),
                        "parallelism": f"samples sharded over {world} GPU(s), no data-path collective; "
                                       f"{procs} worker process(es) per GPU, {os.environ.get('GK_SAMPLE_LANES', '2')} samples in flight "
@@ -643,6 +686,15 @@ def main():
                        "wait_policy": os.environ.get("GK_WAIT_POLICY", "runtime default"),
                        "note": "user + system time of rank 0's worker processes over the timed region (getrusage); "
                                "a host thread that spins on the GPU counts as busy"}
+        pcie_elapsed = timing.get("pcie_elapsed")
+        if pcie_elapsed:
+            out["pcie_inclusive"] = {
+                "value": reads_per_step / (pcie_elapsed / args.steps), "unit": "reads/s",
+                "ms_per_step": 1e3 * pcie_elapsed / args.steps,
+                "host_core_s_per_step": float(res.get("pcie_cpu_s", 0.0)) / args.steps,
+                "note": f"a second timed leg of the same {args.steps} steps with every sample's packed records starting in "
+                        f"pinned host memory: the {256 * args.pairs // 1_000_000} MB host-to-device copy of each sample is "
+                        "inside the timed region (staged two samples ahead of the typing)"}
         if args.cpu_pairs and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.method, args.cpu_pairs)
         print(json.dumps(out), flush=True)

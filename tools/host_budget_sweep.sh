@@ -16,7 +16,7 @@ run() {   # label, env assignments..., then -- bench flags
   local envs=()
   while [ "$1" != "--" ]; do envs+=("$1"); shift; done
   shift
-  env "${envs[@]}" python bench.py --steps $STEPS --warmup 8 --cpu-pairs 0 --serial-steps 0 "$@" 2>> $O/host_budget.err \
+  env "${envs[@]}" python bench.py --steps $STEPS --warmup 8 --cpu-pairs 0 --serial-steps 0 --no-pcie-leg "$@" 2>> $O/host_budget.err \
     | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); d['label']='$label'; print(json.dumps({k: d[k] for k in ('label','ms_per_step','value','host','config')}))" >> $O/host_budget.jsonl
   tail -1 $O/host_budget.jsonl | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-58s %7.3f ms/step %7.2f core-ms/step %5.2f cores busy' % (d['label'], d['ms_per_step'], d['host']['host_core_s_per_step']*1e3, d['host']['cores_busy']))"
 }
