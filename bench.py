@@ -545,12 +545,13 @@ def main():
     pinned = pin_rank(local_rank, args.cores_per_gpu) if args.cores_per_gpu > 0 else None
     args.pinned_to = pinned          # handed to the workers (vars(args)): they bind the runtime's threads after the warm-up
     # Worker processes of this rank on its GPU (see worker()): started first, before anything touches HIP.
-    # A sample is typed by ONE host thread on one stream (gk_sample_search: all genes in lock-step, ~10 waits), two
-    # samples at a time per process (GK_SAMPLE_LANES) plus the ingest thread; two such processes keep the GPU fed from
-    # two to three host cores (profiles/r03_host_budget.txt).  Waits block instead of spinning: a rank of an 8-GPU node
-    # has about two cores.
+    # A sample is typed by ONE host thread on one stream (gk_sample_search: its genes pipelined on marks of the stream),
+    # three samples at a time (GK_SAMPLE_LANES) plus the staging thread(s): ONE process keeps the GPU fed from two to
+    # three host cores (profiles/r03_host_budget.txt, profiles/r03_default_layout.txt); GK_PROCS_PER_GPU=2 adds a second
+    # worker process (the default until the end of round 3).  Waits block instead of spinning: a rank of an 8-GPU
+    # node may have about two cores.
     os.environ.setdefault("GK_WAIT_POLICY", "block")
-    procs = max(1, int(os.environ.get("GK_PROCS_PER_GPU", "2")))
+    procs = max(1, int(os.environ.get("GK_PROCS_PER_GPU", "1")))
     procs = min(procs, max(1, args.steps))
     # the sample preamble on a high-priority stream: what lets ONE process keep the GPU busy (8.9 against 10.2 ms per
     # sample with three lanes); with two processes it takes CUs from the other process's search at the wrong moments
