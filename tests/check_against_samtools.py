@@ -12,7 +12,7 @@ tools/check_against_samtools.sh; every check prints PASS / FAIL / SKIP and the f
   4. end to end       `python -m kir_graph_amd.main` on example/test00 + test01    vs  the reference CLI
                       (needs hisat2, the example_index and GK_REFERENCE_DIR=<clone of linnil1/KIR_graph>)
 
-    python tools/check_against_samtools.py [--bam aligned.bam --index-prefix <...leftalign.mut01>] [--example DIR]
+    python tests/check_against_samtools.py [--bam aligned.bam --index-prefix <...leftalign.mut01>] [--example DIR]
 
 Without --bam a synthetic sample is rendered (synth.py) and written as a coordinate-sorted BAM with the product's own
 writer -- the comparison then covers the readers, not the writer's view of real HISAT2 records; with the BAM of a real

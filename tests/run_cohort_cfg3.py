@@ -7,7 +7,7 @@ with a GPU per rank the same calls go over RCCL), compared with the single-proce
   * the CN column against the ORACLE's fit (oracle/cn.py) on the pooled depths of the depth files the run wrote;
   * a log line per run: samples/s, reads/s, peak host RSS over all ranks, peak HBM in use (rocm-smi, polled).
 
-    python tools/run_cohort_cfg3.py [--samples 64] [--pairs 2500000] [--ranks 6] [--distinct 8] [--out DIR]
+    python tests/run_cohort_cfg3.py [--samples 64] [--pairs 2500000] [--ranks 6] [--distinct 8] [--out DIR]
 
 BASELINE.json configs[3] = 64 samples x 5 M reads (2.5 M pairs) over 8 GPUs.  The GPU boxes of this pool allow at most
 6 processes on a card, hence `--ranks 6` by default here (8 ranks need 8 GPUs or a box without that guard).  Only

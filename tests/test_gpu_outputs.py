@@ -287,7 +287,7 @@ def test_ranks_flag_starts_the_ranks_itself(device, tmp_path):
 
 def test_configs3_in_small_sixteen_samples_over_five_ranks(device, tmp_path):
     """configs[3] reduced (BASELINE.json: 64 samples x 5 M reads, --cn-cohort, 8 GPUs; the full size is
-    tools/run_cohort_cfg3.py): 16 samples through ``python -m kir_graph_amd.main --cn-cohort --ranks 5`` on this GPU
+    tests/run_cohort_cfg3.py): 16 samples through ``python -m kir_graph_amd.main --cn-cohort --ranks 5`` on this GPU
     (file backend; the pool allows six processes on a card and this test process is one of them) -- every TSV equals the single-process run byte for byte,
     and the copy numbers equal the oracle's fit on the pooled depths (main.py:572-589, kir_cn.py:61, 167-186)."""
     import subprocess

@@ -9,4 +9,4 @@ if ! command -v samtools > /dev/null; then
   echo "[SKIP] samtools is not installed here; nothing was compared"
   exit 0
 fi
-exec python3 tools/check_against_samtools.py "$@"
+exec python3 tests/check_against_samtools.py "$@"
