@@ -40,6 +40,11 @@ ISSUE_CYCLES = {"v_mul_f64": 4.50, "v_add_f64": 4.26, "v_max_f64": 4.19, "v_bfe_
 # MI355X_MICROARCH.md: "a wave issues each VALU instruction over 2 cycles (32 lanes/cycle x 2)" with >= 2 waves per
 # SIMD (157.3 TFLOP/s fp32 = 78.6 T lane-FMAs/s); float64 at half that rate (78.6 TFLOP/s = 39.3 T lane-FMAs/s)
 GUIDE_CYCLES = {"v_mul_f64": 4.0, "v_add_f64": 4.0, "v_max_f64": 4.0, "v_bfe_i32": 2.0, "v_bfi_b32": 2.0, "v_sad_u8": 2.0}
+# The same instructions issued as the SEQUENCE the kernel runs (tools/valu_rate.hip "compat factor": v_bfe_i32 + 2 x v_bfi_b32
+# + v_mul_f64 on eight independent chains per wave, 8 waves per SIMD): 5.81 cycles per instruction -- any mix of these VOP3
+# and float64 instructions issues there, whatever the dependencies -- where the four cost 4.51 on average one kind at a
+# time.  Reported beside `peak` as `peak_sequence` (profiles/r03_valu_rate.txt).
+SEQUENCE_CYCLES = {"compat_kernel": 5.81}
 # the instructions one algorithmic operation of a kernel cannot do without
 KERNEL_OPS = {
     "compat_kernel": ("v_bfe_i32", "v_bfi_b32", "v_bfi_b32", "v_mul_f64"),   # per (id, allele): bit -> mask, two halves, product
@@ -158,6 +163,12 @@ def summarise(call_log: list[tuple], kernel: str, total_ms: float, launches: int
                             "the same mix at the guide's 2 cycles per 32-bit and 4 per float64 instruction.  The HBM "
                             "roof is shown beside it; symmetric launches are credited with the triangle of tiles they "
                             "compute"})
+        if kernel in SEQUENCE_CYCLES:
+            seq = 64 * N_SIMD * NOMINAL_HZ / SEQUENCE_CYCLES[kernel]
+            out["peak_sequence"] = seq / 1e12
+            out["frac_sequence"] = ops / sec / seq
+            out["note"] += (".  `peak_sequence` / `frac_sequence`: the same instructions at the rate measured for them "
+                            "as the sequence the kernel issues (eight independent chains per wave, 8 waves per SIMD)")
     else:
         out.update(hbm)
         out["bound"] = "hbm"
