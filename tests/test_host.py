@@ -1053,6 +1053,12 @@ def test_name_collation_with_a_long_common_prefix(tmp_path):
         "digits_at_the_cut": lambda i: f"run7_read10{int(rng.integers(0, 500000))}",        # common prefix ends inside a number
         "zeros_at_the_cut": lambda i: f"s00{int(rng.integers(0, 300000)):0{int(rng.integers(1, 8))}d}x",
         "one_is_the_prefix": lambda i: "frag" if i == 0 else f"frag{'' if i % 3 else '.'}{int(rng.integers(0, 900000))}",
+        # the buckets of the sample sort are ordered by radix passes over the first eight key bytes, then by the full
+        # comparison inside runs of equal first halves: long runs (two groups that share eight characters each) ...
+        "equal_first_halves": lambda i: f"{'aaaaaaaa' if i % 2 else 'bbbbbbbb'}{'x' * int(rng.integers(0, 3))}{int(rng.integers(0, 700000))}",
+        # ... and keys that stop before their eighth byte (a digit run too long for a key ends it): such buckets keep
+        # the comparison sort
+        "keys_that_stop_early": lambda i: f"{'q' * int(rng.integers(0, 4))}{int(rng.integers(10**10, 10**12))}_{int(rng.integers(0, 50))}",
     }
     for tag, make in families.items():
         names = []
