@@ -558,6 +558,11 @@ def main():
     # (9.4 against 8.3 ms) -- profiles/r03_stream_priority.txt
     os.environ.setdefault("GK_URGENT_PREAMBLE", "1" if procs == 1 else "0")
     os.environ.setdefault("GK_SAMPLE_LANES", "3" if procs == 1 else "2")      # samples in flight per worker process
+    # ... of which two at a time are in their search (the third has its preamble done and starts the moment a search
+    # ends): two searches fill the GPU, a third next to them lengthens all three and the tail of a short run
+    # (profiles/r03_search_slots.txt: 8.13 against 8.84 ms per sample on the driver's 20 steps, the same on 64)
+    if procs == 1:
+        os.environ.setdefault("GK_SEARCH_SLOTS", "2")
     own_threads = procs > 1 and "GK_THREADS" not in os.environ and os.environ.get("GK_SAMPLE_SEARCH") == "0"
     if own_threads:
         os.environ["GK_THREADS"] = "3"   # per-gene threads (the round-2 path): four processes of three shared the host cores

@@ -208,6 +208,13 @@ int gk_variant_surviving_gene(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d
  * unless `multiple`), gene_off_out int64 [n_gene + 1] their bounds.  Needs a tabulation made by gk_tabulate. */
 int gk_sample_prepare(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_vflag, gk_dptr d_cnt, gk_dptr d_rows,
                       int64_t* gene_off_out);
+/* gk_sample_prepare + gk_variant_surviving (every backbone) + the tabulation's novel keys in one call and two waits
+ * instead of six: the preamble of the gene loop (kir_typing.py:80-101 groups the reads, typing_mulit_allele.py:302-338,
+ * 274-281 and 807-834 per gene).  ord / pos / neg_out hold max_out entries (>= index + novel variants of the sample;
+ * GK_ERR_CAPACITY otherwise); novel_key_out [n_novel] may be NULL. */
+int gk_sample_prepare_all(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_vflag, gk_dptr d_cnt, gk_dptr d_rows,
+                          int64_t* gene_off_out, int64_t max_out, int32_t* ord_out, uint32_t* pos_out, uint32_t* neg_out,
+                          int64_t* n_out, uint64_t* novel_key_out);
 
 /* ---- compatibility: reads2AlleleProb (typing_mulit_allele.py:340-381).
  * d_mask uint32 [vend-vbeg][words]: allele bit rows of the gene's index variants.

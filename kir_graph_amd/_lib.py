@@ -115,6 +115,8 @@ _SIGS = {
     "gk_variant_surviving_gene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32,
                                             C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "gk_sample_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "gk_sample_prepare_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
+                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
     "gk_variant_correct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "gk_compat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_int32, C.c_int32,
                             C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]),

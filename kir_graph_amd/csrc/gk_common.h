@@ -188,6 +188,8 @@ static inline gk_dptr gk_addr(const void* p) { return static_cast<gk_dptr>(reint
 // exclusive scan of uint32 in place; total written to *d_total (device) if non-null
 int gk_scan_u32(gk_ctx* ctx, uint32_t* d_data, int64_t n, uint32_t* d_total);
 // stable compaction: out[k] = values[i] (or i when values == nullptr) for the k-th i with flag[i] != 0
+int gk_compact_enqueue(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int64_t n, int32_t* d_out,
+                       uint32_t** d_total_out, std::vector<void*>& temps);
 int gk_compact(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int64_t n, int32_t* d_out,
                int64_t* n_out);
 

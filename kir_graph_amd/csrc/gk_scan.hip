@@ -150,41 +150,55 @@ int gk_scan_u32(gk_ctx* ctx, uint32_t* d_data, int64_t n, uint32_t* d_total) {
   return rc;
 }
 
-int gk_compact(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int64_t n, int32_t* d_out,
-               int64_t* n_out) {
+// The compaction queued on the stream, its total left on the device (*d_total_out points into a temporary): nothing is
+// waited for.  `temps` are the pool blocks to give back once the stream has passed the compaction (stream-ordered reuse:
+// at once is fine too, as gk_compact does).
+int gk_compact_enqueue(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int64_t n, int32_t* d_out,
+                       uint32_t** d_total_out, std::vector<void*>& temps) {
   gk_bind(ctx);
-  if (n <= 0) {
-    if (n_out) *n_out = 0;
-    return GK_OK;
-  }
+  *d_total_out = nullptr;
+  if (n <= 0) return GK_OK;
   const int64_t blocks2 = (n + kCompactTile - 1) / kCompactTile;
   if (blocks2 <= kCompactMaxBlocks) {
     uint32_t* cnt = nullptr;
     GK_HIP(gk_pool_malloc(ctx, (void**)&cnt, (size_t)(blocks2 + 1) * sizeof(uint32_t)));
+    temps.push_back(cnt);
     GK_PROF(ctx, GK_K_SCAN, GK_KERNEL(compact_count, dim3((unsigned)blocks2), dim3(kThreads), 0, ctx->stream,
                                              d_flag, n, cnt));
     GK_PROF(ctx, GK_K_SCAN, GK_KERNEL(compact_scatter, dim3((unsigned)blocks2), dim3(kThreads), 0, ctx->stream,
                                              d_flag, d_values, n, cnt, d_out, cnt + blocks2));
     GK_HIP(hipGetLastError());
-    uint32_t total = 0;
-    GK_HIP(gk_fetch(ctx, &total, cnt + blocks2, sizeof(uint32_t)));
-    gk_pool_free(ctx, cnt);
-    if (n_out) *n_out = total;
+    *d_total_out = cnt + blocks2;
     return GK_OK;
   }
   uint32_t* pos = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&pos, (size_t)(n + 1) * sizeof(uint32_t)));
+  temps.push_back(pos);
   unsigned blocks = (unsigned)((n + kThreads - 1) / kThreads);
   GK_PROF(ctx, GK_K_SCAN, GK_KERNEL(flags_to_u32, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, n));
   int rc = gk_scan_u32(ctx, pos, n, pos + n);
-  if (rc) {
-    gk_pool_free(ctx,pos);
-    return rc;
-  }
+  if (rc) return rc;
   GK_PROF(ctx, GK_K_SCAN, GK_KERNEL(scatter_selected, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, d_values, n, d_out));
-  uint32_t total = 0;
-  GK_HIP(gk_fetch(ctx, &total, pos + n, sizeof(uint32_t)));
-  gk_pool_free(ctx, pos);
-  if (n_out) *n_out = total;
+  GK_HIP(hipGetLastError());
+  *d_total_out = pos + n;
   return GK_OK;
+}
+
+int gk_compact(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_values, int64_t n, int32_t* d_out,
+               int64_t* n_out) {
+  if (n <= 0) {
+    if (n_out) *n_out = 0;
+    return GK_OK;
+  }
+  std::vector<void*> temps;
+  uint32_t* d_total = nullptr;
+  int rc = gk_compact_enqueue(ctx, d_flag, d_values, n, d_out, &d_total, temps);
+  uint32_t total = 0;
+  if (rc == GK_OK && gk_fetch(ctx, &total, d_total, sizeof(uint32_t)) != hipSuccess) {
+    gk_set_error("compaction: fetching the count failed");
+    rc = GK_ERR_HIP;
+  }
+  for (void* t : temps) gk_pool_free(ctx, t);
+  if (rc == GK_OK && n_out) *n_out = total;
+  return rc;
 }

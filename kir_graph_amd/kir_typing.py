@@ -194,6 +194,26 @@ class _GenesInParallel(Typing):
         return 0 if g is None else self._data.index.tables[g].n_allele ** 2
 
 
+_SEARCH_SLOTS: dict = {}
+_SEARCH_SLOTS_LOCK = threading.Lock()
+
+
+def _searchSlot():
+    """Context manager that admits GK_SEARCH_SLOTS whole-sample searches of this process at a time (0 / unset: any
+    number).  Two searches fill the GPU; a third next to them only lengthens all three (and the tail of a short run),
+    while the preamble of the samples that wait is already done -- the next search starts the moment a slot is free."""
+    import contextlib
+    import os
+    n = int(os.environ.get("GK_SEARCH_SLOTS", "0") or 0)
+    if n <= 0:
+        return contextlib.nullcontext()
+    with _SEARCH_SLOTS_LOCK:
+        sem = _SEARCH_SLOTS.get(n)
+        if sem is None:
+            sem = _SEARCH_SLOTS[n] = threading.BoundedSemaphore(n)
+    return sem
+
+
 class TypingWithPosNegAllele(_GenesInParallel):
     """Likelihood typing with positive / negative variants (77-150)."""
 
@@ -275,8 +295,9 @@ class TypingWithPosNegAllele(_GenesInParallel):
                 import sys
                 import threading
                 print(f"[trace] pre {threading.get_native_id()} {t_in:.6f} {t_prep:.6f} {time.perf_counter():.6f}", file=sys.stderr, flush=True)
-            check(lib().gk_sample_search(tab.dev.ctx, more, len(extra), tab.handle, vflag.ptr, logs.handle, jobs, len(live),
-                                         _lib.NUMPY_ARGSORT, _lib.NUMPY_LOG10, handles))
+            with _searchSlot():
+                check(lib().gk_sample_search(tab.dev.ctx, more, len(extra), tab.handle, vflag.ptr, logs.handle, jobs, len(live),
+                                             _lib.NUMPY_ARGSORT, _lib.NUMPY_LOG10, handles))
             try:
                 for k, (gene, cn, typ, _, homo) in enumerate(live):
                     typ.adoptJob(jobs[k], C.c_void_p(handles[k]), cn, homo)
