@@ -240,7 +240,9 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
                                                                 const uint32_t* mask_t, int words, int n_allele, int a_base,
                                                                 double* probs, uint8_t* miss_out, uint16_t* nvar_out,
                                                                 LutView lut, double empty_p, uint8_t* miss8, int64_t ldm,
-                                                                uint32_t* bound_flags, uint16_t* lidx) {
+                                                                uint32_t* bound_flags, uint16_t* lidx, int probe) {
+  // probe (tools/compat_phases.sh, GK_COMPAT_PROBE): 1 = leave out the walk over the kept variants, 2 = leave out the way
+  // out of a tile, 3 = only its second pass (the stores), 4 = only its first (the value-table look-ups) -- WRONG results, for timing the two halves of the kernel only; 0 in every real launch
   const int n_span = vend - vbeg;   // mask_t: [words][n_span], see transpose_mask
   constexpr int kPassAlleles = 64 * kSlots;
   constexpr int kPassWords = 2 * kSlots;   // bit-row words covering one pass
@@ -358,7 +360,9 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
             apply(wb, positive);
           }
         };
-        if (kFma) {
+        if (probe == 1) {
+          // timing probe: no factors
+        } else if (kFma) {
           walk(kept, true);
         } else {
           walk(kept & pos_lanes, true);
@@ -429,9 +433,9 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
         }
       }
     } else
-    if (probs) {
+    if (probs && probe != 2) {
       const int n_r = (int)min<int64_t>(kTileRows, n_rows - row0);
-      if (kLog) {
+      if (kLog && probe != 4) {
         // Pass 1 of the way out: every product of the tile is replaced, in place, by its log10 from the value table.
         // A thread keeps to ONE read (its alleles share a handful of values: most lookups end in the two registers).
         uint64_t key0 = kLutEmptyKey, key1 = kLutEmptyKey;   // the two most recent values of this thread's read
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
       // |a - b| sum).  A count >= 100 (the product is about to leave the normal range / underflow, L = -inf) raises the
       // flag that sends the gene to the exact search; NaN (log10 not defined yet) is rewritten by the next pass.
       constexpr int kQuads = kTileRows / 4;
-      for (int it = tid; it < n_pass * kQuads; it += kCompatThreads) {
+      for (int it = tid; it < (probe == 3 ? 0 : n_pass * kQuads); it += kCompatThreads) {
         const int al = it / kQuads, r0 = 4 * (it % kQuads);
         const double* const cell = &tile[al * kTileLd + r0];
         double v[4];
@@ -517,6 +521,8 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
               gk_ptr<uint32_t>(d_mask), vend - vbeg, words, mask_t);
   // GK_COMPAT_FORM = select (default) | fma: how a factor is chosen, see compat_kernel (the fma form measured 1 - 2 %
   // slower on the bench sample, profiles/r03_compat_variants.txt: the factor loop is 56 % of the kernel's VALU work)
+  const char* const probe_env = getenv("GK_COMPAT_PROBE");
+  const int probe = probe_env ? atoi(probe_env) : 0;
   const char* const form_env = getenv("GK_COMPAT_FORM");      // read per call: the tests compare both forms in one process
   const bool fma_form = form_env && !strcmp(form_env, "fma");
   for (int a_base = 0; a_base < n_allele; a_base += 64 * kMaxSlots) {
@@ -524,7 +530,7 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
 #define GK_COMPAT_GO(S, IDX, FMA)                                                                                     \
   GK_KERNEL((compat_kernel<kLog, S, !kLog, IDX, FMA>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows,  \
             tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, mask_t, words, n_allele, a_base, out,       \
-            miss, nvar, view, empty_p, miss8, ldm, bound_flags, lidx)
+            miss, nvar, view, empty_p, miss8, ldm, bound_flags, lidx, probe)
 #define GK_COMPAT_LAUNCH(S)                                       \
   GK_PROF(ctx, GK_K_COMPAT, {                                     \
     if (kLog && lidx) GK_COMPAT_GO(S, (kLog && true), false);     \
