@@ -521,8 +521,17 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
               gk_ptr<uint32_t>(d_mask), vend - vbeg, words, mask_t);
   // GK_COMPAT_FORM = select (default) | fma: how a factor is chosen, see compat_kernel (the fma form measured 1 - 2 %
   // slower on the bench sample, profiles/r03_compat_variants.txt: the factor loop is 56 % of the kernel's VALU work)
+  // timing probe (tools/compat_phases.sh): honoured only together with GK_TIMING_PROBES=1, and never quietly
   const char* const probe_env = getenv("GK_COMPAT_PROBE");
-  const int probe = probe_env ? atoi(probe_env) : 0;
+  const char* const probes_on = getenv("GK_TIMING_PROBES");
+  const int probe = (probe_env && probes_on && !strcmp(probes_on, "1")) ? atoi(probe_env) : 0;
+  if (probe) {
+    static std::once_flag warned;
+    std::call_once(warned, [&] {
+      fprintf(stderr, "[graphkir_hip] GK_COMPAT_PROBE=%d: parts of the compatibility kernel are left out -- the tables are "
+                      "WRONG, this run is good for timing only\n", probe);
+    });
+  }
   const char* const form_env = getenv("GK_COMPAT_FORM");      // read per call: the tests compare both forms in one process
   const bool fma_form = form_env && !strcmp(form_env, "fma");
   for (int a_base = 0; a_base < n_allele; a_base += 64 * kMaxSlots) {

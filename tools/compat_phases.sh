@@ -6,6 +6,6 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 for rep in 1 2; do
   for p in 0 1 2 3 4; do
-    GK_COMPAT_PROBE=$p timeout -k 10 200 python tools/bench_compat.py 2>&1 | grep -m1 "compat_kernel" | sed "s/^/probe $p: /"
+    GK_TIMING_PROBES=1 GK_COMPAT_PROBE=$p timeout -k 10 200 python tools/bench_compat.py 2>&1 | grep -m1 "compat_kernel" | sed "s/^/probe $p: /"
   done
 done
