@@ -1,0 +1,56 @@
+"""bench.py run the way the driver runs it (a child process, small sample): the one JSON line and its contract -- the
+metric of BASELINE.json, whole-job throughput from records resident in HBM, the second leg from host memory, the roofline
+of the dominant kernel measured in the same run, the host budget -- and the multi-rank form on one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=600):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=timeout, env=dict(os.environ, **(env or {})), cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [x for x in res.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]          # ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_one_gpu_line_keeps_the_contract(device):
+    d = _run(["--gpus", "1", "--steps", "6", "--warmup", "2", "--pairs", "20000", "--cpu-pairs", "0", "--serial-steps", "1"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "host", "pcie_inclusive"):
+        assert key in d, key
+    assert d["unit"] == "reads/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["inputs"] == "hbm" and d["config"]["pairs_per_sample"] == 20000
+    assert abs(d["value"] - 2 * 20000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9      # whole-job reads per second
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "valu") and r["unit"] and r["peak"] > 0 and r["achieved"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "traffic" in r and "kernel" in r and r["avg_launch_ms"] > 0
+    h = d["host"]
+    assert h["host_core_s_per_step"] > 0 and h["worker_processes"] == 1 and h["sample_lanes"] == 3
+    p = d["pcie_inclusive"]
+    assert p["unit"] == "reads/s" and p["value"] > 0 and p["ms_per_step"] > 0
+    assert d["search_steps"]["bounded"] > 0
+
+
+def test_steps_from_host_memory_and_two_worker_processes(device):
+    d = _run(["--steps", "4", "--warmup", "2", "--pairs", "20000", "--cpu-pairs", "0", "--serial-steps", "0", "--inputs", "host"],
+             env={"GK_PROCS_PER_GPU": "2"})
+    assert d["config"]["inputs"] == "host" and "pcie_inclusive" not in d
+    assert d["host"]["worker_processes"] == 2 and d["host"]["sample_lanes"] == 2 and d["value"] > 0
+
+
+def test_two_ranks_on_one_gpu_through_the_file_backend(device):
+    d = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--pairs", "20000", "--cpu-pairs", "0", "--serial-steps", "0",
+              "--no-pcie-leg"], env={"GK_BENCH_BACKEND": "file"})
+    assert d["n_gpus"] == 2 and d["config"]["rank_barrier"] == "file" and "pcie_inclusive" not in d
+    assert abs(d["value"] - 2 * 2 * 20000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9       # both ranks' reads / the slower rank's time
