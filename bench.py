@@ -94,6 +94,22 @@ def pin_all_threads(cores) -> int:
     return n
 
 
+def thread_cpu_table() -> list[tuple[str, int, float]]:
+    """(name, thread id, user + system seconds so far) of every thread of this process, from /proc/self/task."""
+    out = []
+    tick = os.sysconf("SC_CLK_TCK")
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            with open(f"/proc/self/task/{tid}/stat") as f:
+                text = f.read()
+        except OSError:
+            continue
+        name = text[text.index("(") + 1:text.rindex(")")]
+        rest = text[text.rindex(")") + 2:].split()
+        out.append((name, int(tid), (int(rest[11]) + int(rest[12])) / tick))
+    return out
+
+
 def cpu_seconds() -> float:
     """User + system time of this process (all its threads) so far."""
     import resource
@@ -419,10 +435,15 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
         gang_wait("go")
         t0 = time.perf_counter()
         cpu0 = cpu_seconds()
+        by_thread0 = {tid: c for _, tid, c in thread_cpu_table()} if os.environ.get("GK_BENCH_TRACE") == "1" else None
         last = run_steps(claims(), dev, dindex, gidx, inputs, args.method, resident=leg_resident)
         for d in all_devices():
             d.sync()
         cpu = cpu_seconds() - cpu0          # this worker's host time for its share of the steps (waits that spin included)
+        if by_thread0 is not None:          # GK_BENCH_TRACE=1: which threads the host time of the leg went to
+            rows = sorted(((c - by_thread0.get(tid, 0.0), name, tid) for name, tid, c in thread_cpu_table()), reverse=True)
+            log("[trace] host CPU of the leg by thread (ms per step): " +
+                ", ".join(f"{name}/{tid} {1e3 * c / max(args.steps, 1):.2f}" for c, name, tid in rows if c > 0))
         gang_wait("done")
         if comm is not None:
             comm.barrier()
