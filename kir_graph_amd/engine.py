@@ -152,13 +152,13 @@ class Tabulation:
                     o, p, q = (np.empty(nv, dtype=t) for t in (np.int32, np.uint32, np.uint32))
                     n_surv = C.c_int64()
                     want_novel = self._novel_keys is None and self.n_novel > 0
-                    novel = np.empty(self.n_novel, dtype=np.uint64) if want_novel else None
+                    novel_keys = np.empty(self.n_novel, dtype=np.uint64) if want_novel else None
                     check(lib().gk_sample_prepare_all(dev.ctx, self.handle, int(multiple), vflag.ptr, cnt.ptr, rows.ptr,
                                                       off.ctypes.data, nv, o.ctypes.data, p.ctypes.data, q.ctypes.data,
-                                                      C.byref(n_surv), novel.ctypes.data if want_novel else None))
+                                                      C.byref(n_surv), novel_keys.ctypes.data if want_novel else None))
                     o, p, q = o[:n_surv.value], p[:n_surv.value], q[:n_surv.value]
                     if want_novel:
-                        self._novel_keys = root._novel_keys = novel
+                        self._novel_keys = root._novel_keys = novel_keys
                 else:      # the three calls one after the other (six waits): kept for comparison
                     check(lib().gk_sample_prepare(dev.ctx, self.handle, int(multiple), vflag.ptr, cnt.ptr, rows.ptr,
                                                   off.ctypes.data))
@@ -167,8 +167,8 @@ class Tabulation:
                 n_index = self.dindex.host.n_variant
                 gene_of = np.searchsorted(self.dindex.host.gene_vbeg, o, side="right") - 1
                 if len(o) and int(o[-1]) >= n_index:
-                    novel = o >= n_index
-                    gene_of[novel] = (self.novelKeys()[o[novel] - n_index] >> np.uint64(56)).astype(gene_of.dtype)
+                    is_novel = o >= n_index
+                    gene_of[is_novel] = (self.novelKeys()[o[is_novel] - n_index] >> np.uint64(56)).astype(gene_of.dtype)
                 # grouped by gene once (ordinals ascending inside a gene, as survivingCounts lists them): a gene's tallies
                 # are a slice, and the zygosity verdicts of all genes one native call (gk_site_verdict_genes)
                 order = np.argsort(gene_of, kind="stable")
