@@ -2,14 +2,22 @@
 """
 bench.py -- typed 150 bp PE reads/s of the Graph-KIR hot path on MI355X.
 
-One "step" = one synthetic sample (BASELINE.json configs[1]: 2 M reads = 1 M pairs, ~2 k alleles in
-15 genes, --allele-strategy pv == full, top_n 600, variant correction on) taken from packed alignment
-records in PINNED HOST MEMORY to per-gene allele calls on the host: the
-host-to-device copy of the records (256 MB), the tabulation (gk_tabulate), per gene the error
-correction, compatibility table, log table and greedy multi-allele likelihood search, and the allele
-selection all lie inside the timed region.  Consecutive steps take DIFFERENT samples (three distinct
-ones per rank, in rotation) and are pipelined like the samples of a cohort: the copy + tabulation of the
-next sample runs while the current one is typed.
+One "step" = one synthetic sample (BASELINE.json configs[1]: 2 M reads = 1 M pairs, ~2 k alleles in 15 genes,
+--allele-strategy pv == full, top_n 600, variant correction on) taken from packed alignment records to per-gene allele
+calls on the host: the tabulation (gk_tabulate), the sample preamble (error correction, empty reads, zygosity tallies),
+per gene the compatibility table through the log10 value table and the greedy multi-allele likelihood search
+(gk_sample_search), and the allele selection.  The steps run through the package's own sample pipeline
+(kir_graph_amd.cohort: stagedSamples -> typeSamples), the one `python -m kir_graph_amd.main` types a cohort with.
+
+Two kinds of timed leg over the same K steps, each bracketed by a barrier + device synchronise on both sides, each kind
+timed `--legs` times (default 3) with the MEDIAN leg reported:
+  host  (`value`)         a sample's records start in PINNED HOST MEMORY: the 256 MB host-to-device copy is inside the
+                          region (SURVEY.md section 8(d)), staged two samples ahead of the typing;
+  hbm   (`hbm_resident`)  the records of the distinct samples are resident in HBM before the clock starts.
+`--inputs hbm` swaps the two (`value` from resident records, `pcie_inclusive` beside it).
+Consecutive steps take DIFFERENT samples: `--distinct N` (default 8) distinct ones per rank in rotation, seeds
+1031 + 7 rank + i.  With N >= steps + warmup the first leg types only samples nobody has typed before -- `legs[0]`
+then says what a NEW sample costs (value_table_new_per_sample, samples_repeated_pass), the later legs what a repeated one.
 
 ``--gpus N``: N ranks, one per GPU, every rank types its own samples (cohort sharding: weak scaling, no
 data-path collective); value = reads of all ranks / max-over-ranks time.  Started without a launcher
@@ -18,15 +26,16 @@ anything here touches the GPU -- and relays rank 0's line; under `torchrun` (RAN
 is one of the ranks.  Ranks meet through kir_graph_amd/comm.py (RCCL: barrier + max of the times).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline        the dominant kernel of the step, from a ONE-PROCESS, SERIAL pass (one gene thread, no
-                  prefetch) run right after the timed region: HIP-event time per launch, algorithmic
-                  bytes / operations per launch (kir_graph_amd/roofmodel.py)
-  kernels_serial  per-kernel launches and time per step of that pass (the basis rocprofv3 reproduces:
-                  GK_PROCS_PER_GPU=1 GK_THREADS=1 GK_PREFETCH=0, profiles/)
+  roofline        the dominant kernel of the step, from a ONE-PROCESS, SERIAL pass (one sample at a time on one
+                  stream, no prefetch) run right after the timed legs: HIP-event time per launch, algorithmic
+                  bytes / operations per launch (kir_graph_amd/roofmodel.py); `roofline.step` =
+                  the algorithmic bytes of ALL launches of a step over the reported ms_per_step against 8 TB/s
+  kernels_serial  per-kernel launches and time per step of that pass (the basis rocprofv3 reproduces, profiles/)
+  legs            every timed leg of the headline kind in the order they ran
   cpu_baseline    the oracle (CPU restatement of the reference) on a bounded sample of the same
                   workload, one core and N-way over the host's cores
   host            what the step costs on the host: core-seconds per step (user + system time of every worker
-                  process of rank 0 over the timed region, getrusage), cores busy on average, the cores the rank was
+                  process of rank 0 over the reported leg, getrusage), cores busy on average, the cores the rank was
                   allowed (``--cores-per-gpu K`` pins every rank and its workers to K cores of its own before
                   anything touches HIP: the budget an 8-GPU node leaves each rank)
 """
@@ -45,7 +54,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-N_DISTINCT = 3          # distinct samples a rank rotates through
+N_DISTINCT = 8          # distinct samples a rank rotates through (--distinct)
 
 
 def log(*a):
@@ -174,29 +183,19 @@ class PinnedRecords:
 
 
 # ------------------------------------------------------------------------------------------ steps
-def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None, resident=None):
+def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None, resident=None, stats=None):
     """Types the samples ``inputs[k % len(inputs)]`` for k in ``items``: pinned records -> HBM -> tabulation ->
-    typing -> calls.  Like a cohort run the samples go through ``cohort.prefetched``: copy + tabulation of
-    the next sample are issued (on their own stream) while the current one is typed.  Every copy,
-    tabulation and typing of the listed samples starts and ends inside this call.  ``resident``: the records of the
-    distinct samples already in HBM (one device buffer per entry of ``inputs``) -- a step then starts at the tabulation."""
-    from kir_graph_amd.cohort import overlapped, prefetched
+    typing -> calls, through the package's sample pipeline -- ``cohort.stagedSamples`` (copy and tabulation of the next
+    samples on their own contexts while the current ones are typed) feeding ``cohort.typeSamples`` (the typing lanes),
+    the same two calls ``kir_graph_amd.main`` makes for the samples of a cohort.  Every copy, tabulation and typing of
+    the listed samples starts and ends inside this call.  ``resident``: the records of the distinct samples already in
+    HBM (one device buffer per entry of ``inputs``) -- a step then starts at the tabulation.  ``stats`` (a dict):
+    receives what the value table and the searches did over these samples."""
+    from kir_graph_amd import cohort
     from kir_graph_amd.engine import Tabulation
     from kir_graph_amd.hisat2 import SampleData
-    from kir_graph_amd.kir_typing import hostThreads, selectKirTypingModel
-    if method == "exonfirst":      # the command line types `--allele-strategy exonfirst` as exonfirst_1 (main.py:186-187)
-        method = "exonfirst_1"
-    depth = int(os.environ.get("GK_PREFETCH", "1")) if depth is None else depth
-    lanes = int(os.environ.get("GK_SAMPLE_LANES", "2"))   # samples typed at a time, each on a host thread and a stream of its own
-    # Staging has contexts of its own (the typing lanes use workers 0..lanes*n-1): one for the copy of a sample's
-    # records into HBM, one -- with a high-priority stream -- for its tabulation.  The two are stages of a pipeline
-    # (GK_COPY_AHEAD=1, default): while sample k is typed, sample k+1 is tabulated and the records of k+2 are on their
-    # way, each stage on a thread of its own.  In one stage (GK_COPY_AHEAD=0) a sample's staging took 6 - 7 ms of wall time
-    # next to the typing kernels -- 80 % of a worker process's budget per sample.
-    ingest = dev.worker(lanes * hostThreads(), urgent=True)
-    copier = dev.worker(lanes * hostThreads() + 1)
-    copy_ahead = os.environ.get("GK_COPY_AHEAD", "1") != "0"
-
+    lanes = cohort.sampleLanes() if depth is None or depth > 0 else 1
+    copier, ingest = cohort.stagingContexts(dev, cohort.sampleLanes())
     trace = os.environ.get("GK_BENCH_TRACE") == "1"      # a timeline of the host threads on stderr (tools/host_timeline.py)
 
     def note(what, k, t0):
@@ -212,51 +211,69 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
 
     def tabulate(item):
         t0 = time.perf_counter()
-        k, mates = item
+        k, mates = item if isinstance(item, tuple) else (item, resident[item % len(inputs)])
         _, table, gene_cn = inputs[k % len(inputs)]
         tab = Tabulation(dindex, mates, dev=ingest)
         note("stage", k, t0)
-        return tab, table, gene_cn, k
+        return SampleData(tab, gidx, None, ins_strings=table.strings), gene_cn, (k, time.perf_counter())
 
-    def stage(k):                           # both in one go: queued on one stream, one after the other
-        t0 = time.perf_counter()
-        pinned, table, gene_cn = inputs[k % len(inputs)]
-        tab = Tabulation(dindex, pinned.toDevice(ingest), dev=ingest)
-        note("stage", k, t0)
-        return tab, table, gene_cn, k
-
-    def from_hbm(k):                        # the records are in HBM already: the step starts here
-        return tabulate((k, resident[k % len(inputs)]))
-
-    def type_one(item, lane):
-        t0 = time.perf_counter()
-        tab, table, gene_cn, k = item
-        data = SampleData(tab, gidx, None, ins_strings=table.strings)
-        typer = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
-        typer.slot_base = lane * hostThreads()
-        calls, warn = typer.typing(gene_cn)
+    def finish(typer, calls, warn, item):
+        k, t0 = item
+        tab = typer._data.tab
         n_valid = tab.n_valid
         tab.close()
         if resident is None:
             tab.mates.free()
         note("type", k, t0)
+        if stats is not None:
+            stats["samples"] = stats.get("samples", 0) + 1
+            stats["samples_repeated_pass"] = stats.get("samples_repeated_pass", 0) + (1 if getattr(typer, "tables_rewritten", 0) else 0)
+            stats["tables_rewritten"] = stats.get("tables_rewritten", 0) + getattr(typer, "tables_rewritten", 0)
         return calls, warn, n_valid, typer
 
-    out = None
     items = range(items) if isinstance(items, int) else items
-    if depth <= 0:
-        for k in items:
-            out = type_one(from_hbm(k) if resident is not None else stage(k), 0)
-        return out
-    if resident is not None:
-        staged = prefetched(items, from_hbm, depth=depth)
-    elif copy_ahead:
-        staged = prefetched(prefetched(items, copy_in, depth=depth), tabulate, depth=depth)
-    else:
-        staged = prefetched(items, stage, depth=depth)
-    for out in overlapped(staged, type_one, lanes=lanes):
+    staged = cohort.stagedSamples(items, None if resident is not None else copy_in, tabulate, depth=depth)
+    out = None
+    for out in cohort.typeSamples(staged, method, lanes=lanes, finish=finish):
         pass
     return out
+
+
+def cli_typing_stage(n, dev, dindex, gidx, inputs, resident, method):
+    """The typing stage of the COMMAND LINE (`kir_graph_amd.main.alleleTyping`, main.py:171-220 of the reference) on `n`
+    tabulated samples, timed: copy-number files read, every sample typed through the process's typing lanes, its
+    `.tsv` / `.possible.tsv` written, its tabulation released.  The samples are tabulated (and their copy-number files
+    written) before the clock starts -- `main` does that in its mapping stage -- so the figure compares with a bench step
+    minus its tabulation.  Same lanes, slots, streams and waits as the timed legs: one code path (cohort.SampleTyper)."""
+    import shutil
+    from kir_graph_amd import cohort, main as gk_main
+    from kir_graph_amd.engine import Tabulation
+    from kir_graph_amd.hisat2 import SampleData
+    _, ingest = cohort.stagingContexts(dev, cohort.sampleLanes())
+    tmp = tempfile.mkdtemp(prefix="gk_bench_cli_")
+    try:
+        processed, cn_files = [], []
+        for k in range(n):
+            _, table, gene_cn = inputs[k % len(inputs)]
+            tab = Tabulation(dindex, resident[k % len(inputs)], dev=ingest)
+            name = os.path.join(tmp, f"s{k:03d}.variant")
+            cn_file = name + ".no_multi.depth.p75.LCND.tsv"
+            with open(cn_file, "w") as f:
+                f.write("gene\tcn\tdepth\n" + "".join(f"{g}\t{c}\t{30.0 * c}\n" for g, c in gene_cn.items()))
+            processed.append((name, SampleData(tab, gidx, None, ins_strings=table.strings)))
+            cn_files.append(cn_file)
+        ingest.sync()
+        cpu0, t0 = cpu_seconds(), time.perf_counter()
+        files = gk_main.alleleTyping(processed, cn_files, method="full" if method in ("pv", "full") else method, release=True)
+        for d in list(type(dev).instances):
+            d.sync()
+        elapsed, cpu = time.perf_counter() - t0, cpu_seconds() - cpu0
+        assert len(files) == n and all(os.path.getsize(f) > 0 for f in files)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"samples": n, "ms_per_sample": 1e3 * elapsed / n, "host_core_s_per_sample": cpu / n,
+            "what": "kir_graph_amd.main.alleleTyping on tabulated samples (copy-number files read, typing lanes, .tsv + "
+                    ".possible.tsv written, tabulations released): the command line's typing stage, timed in this process"}
 
 
 def _oracle_leg(job):
@@ -393,19 +410,17 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
             call_log += d.call_log or []
         return prof, call_log
 
-    # The records of the distinct samples in HBM before any clock starts (--inputs hbm, the default): `value` is measured
-    # with the inputs resident, a step = tabulation + typing + calls.  A second leg times the same steps with every
-    # sample's records starting in pinned host memory (the 256 MB copy inside the region): `pcie_inclusive`.
-    resident = None
-    if args.inputs == "hbm":
-        resident = [pinned.toDevice(dev) for pinned, _, _ in inputs]
-        dev.sync()
-    pcie_leg = resident is not None and args.pcie_leg
+    # Two kinds of timed leg over the same steps.  "host": every sample's packed records start in pinned host memory, the
+    # 256 MB host-to-device copy is inside the region (the metric) -- `value`.  "hbm": the records
+    # of the distinct samples are resident in HBM before any clock starts, a step = tabulation + typing + calls --
+    # `hbm_resident`.  Each kind is timed `--legs` times (alternating), the median leg is reported.
+    from kir_graph_amd.typing_mulit_allele import sharedLogTable
+    resident = [pinned.toDevice(dev) for pinned, _, _ in inputs]
+    dev.sync()
     n_valid = 0
     if args.warmup:
         n_valid = run_steps(args.warmup, dev, dindex, gidx, inputs, args.method, resident=resident)[2]
-        if pcie_leg:
-            run_steps(min(args.warmup, 4), dev, dindex, gidx, inputs, args.method)      # the copy path's contexts and pools
+        run_steps(min(args.warmup, 4), dev, dindex, gidx, inputs, args.method)      # the copy path's contexts and pools
     if getattr(args, "pinned_to", None):      # --cores-per-gpu: the runtime's own threads too (they exist by now)
         pin_all_threads(args.pinned_to)
     if j == 0 and getattr(args, "profile_host", False):
@@ -425,7 +440,7 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
 
     def timed_leg(leg_resident):
         """EXACTLY args.steps steps between a barrier + device synchronise on both sides; (seconds, host CPU seconds of
-        this worker, the last step's result)."""
+        this worker, the last step's result, what the value table and the searches did)."""
         if j == 0 and gang is not None:
             gang["next"].value = 0          # nobody claims before the "go" barrier below
         dev.sync()
@@ -433,10 +448,11 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
         if comm is not None:
             comm.barrier()          # RCCL all-reduce + stream synchronise: every rank is ready
         gang_wait("go")
+        stats = {"value_table_at_start": sharedLogTable(dev).known()}
         t0 = time.perf_counter()
         cpu0 = cpu_seconds()
         by_thread0 = {tid: c for _, tid, c in thread_cpu_table()} if os.environ.get("GK_BENCH_TRACE") == "1" else None
-        last = run_steps(claims(), dev, dindex, gidx, inputs, args.method, resident=leg_resident)
+        last = run_steps(claims(), dev, dindex, gidx, inputs, args.method, resident=leg_resident, stats=stats)
         for d in all_devices():
             d.sync()
         cpu = cpu_seconds() - cpu0          # this worker's host time for its share of the steps (waits that spin included)
@@ -447,28 +463,36 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
         gang_wait("done")
         if comm is not None:
             comm.barrier()
-        return time.perf_counter() - t0, cpu, last
+        elapsed = time.perf_counter() - t0
+        stats["value_table_new"] = sharedLogTable(dev).known() - stats.pop("value_table_at_start")
+        return elapsed, cpu, last, stats
 
-    if in_region:
-        profiled(True)
-    elapsed, cpu_s, last = timed_leg(resident)
-    if last is not None:
-        n_valid = last[2]
-    prof, call_log = collect() if in_region else ({}, [])
-    profiled(False)
-    pcie_elapsed, pcie_cpu_s = None, 0.0
-    if pcie_leg:
-        pcie_elapsed, pcie_cpu_s, _ = timed_leg(None)
+    kinds = [k for k in ("host", "hbm") if k == args.inputs or args.both_legs]
+    kinds.sort(key=lambda k: k != args.inputs)          # the headline's kind first: its first leg meets the new samples
+    legs = {k: [] for k in kinds}
+    prof, call_log = {}, []
+    for n in range(max(1, args.legs)):
+        for kind in kinds:
+            profile_this = in_region and n == 0 and kind == args.inputs
+            if profile_this:
+                profiled(True)
+            elapsed, cpu_s, last, stats = timed_leg(resident if kind == "hbm" else None)
+            if profile_this:
+                prof, call_log = collect()
+                profiled(False)
+            if last is not None:
+                n_valid = last[2]
+            if comm is not None:
+                elapsed = comm.maxF64(elapsed)
+            legs[kind].append(dict(stats, elapsed=elapsed, cpu_s=cpu_s))
     if j:
-        gang["results"].put({"prof": prof, "call_log": call_log, "cpu_s": cpu_s, "pcie_cpu_s": pcie_cpu_s})
+        gang["results"].put({"prof": prof, "call_log": call_log, "legs": legs})
         return None
-    if comm is not None:
-        elapsed = comm.maxF64(elapsed)
-        if pcie_elapsed is not None:
-            pcie_elapsed = comm.maxF64(pcie_elapsed)
-    timing["elapsed"] = elapsed
-    timing["pcie_elapsed"] = pcie_elapsed
+    timing["legs"] = legs
     others = helpers_done() if helpers_done is not None else []      # the other workers have left the GPU
+    cli_stage = None
+    if args.cli_samples > 0 and rank == 0 and world == 1:
+        cli_stage = cli_typing_stage(args.cli_samples, dev, dindex, gidx, inputs, resident, args.method)
     # ---- the roofline basis: the same step in ONE process, ONE gene thread, no prefetch (kernels back to back)
     serial = None
     if args.serial_steps > 0 and rank == 0:
@@ -494,11 +518,16 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
                     os.environ.pop(name, None)
                 else:
                     os.environ[name] = val
-    from kir_graph_amd.typing_mulit_allele import SEARCH_STATS, sharedLogTable
+    from kir_graph_amd.typing_mulit_allele import SEARCH_STATS
     n_values = sharedLogTable(dev).known()      # distinct probabilities met so far = entries of the log10 value table
+    for other in others:                        # the other worker processes of this rank: their host time counts too
+        for kind, rows in other.get("legs", {}).items():
+            for mine, theirs in zip(legs.get(kind, []), rows):
+                mine["cpu_s"] += theirs["cpu_s"]
+                for key in ("samples", "samples_repeated_pass", "tables_rewritten", "value_table_new"):
+                    mine[key] = mine.get(key, 0) + theirs.get(key, 0)
     return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm, "n_values": n_values,
-            "search_steps": dict(SEARCH_STATS), "others": others, "cpu_s": cpu_s + sum(o.get("cpu_s", 0.0) for o in others),
-            "pcie_cpu_s": pcie_cpu_s + sum(o.get("pcie_cpu_s", 0.0) for o in others)}
+            "search_steps": dict(SEARCH_STATS), "others": others, "cli_stage": cli_stage}
 
 
 # ------------------------------------------------------------------------------------------ launcher
@@ -537,15 +566,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per sample (config 2: 1e6)")
     ap.add_argument("--method", default="pv")
-    ap.add_argument("--distinct", type=int, default=N_DISTINCT, help="distinct samples a rank rotates through")
+    ap.add_argument("--distinct", type=int, default=N_DISTINCT,
+                    help="distinct samples a rank rotates through (a cohort types every sample once: with N >= steps + "
+                         "warmup the first leg only meets samples nobody has typed before; 3.4 s of generation each)")
+    ap.add_argument("--legs", type=int, default=3, help="timed legs per kind of input; the median leg is reported")
     ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs for the CPU baseline sample (0 = skip)")
     ap.add_argument("--serial-steps", type=int, default=2,
                     help="steps of the one-process serial pass after the timed region (roofline basis; 0 = skip)")
-    ap.add_argument("--inputs", choices=("hbm", "host"), default="hbm",
-                    help="where a sample's records are when its step starts: resident in HBM (the metric), or in pinned "
-                         "host memory (the 256 MB copy inside the step)")
-    ap.add_argument("--no-pcie-leg", dest="pcie_leg", action="store_false",
-                    help="skip the second timed leg (the same steps from pinned host memory, reported as pcie_inclusive)")
+    ap.add_argument("--inputs", choices=("host", "hbm"), default="host",
+                    help="where a sample's records are when its step starts -- what `value` is measured on: pinned host "
+                         "memory (the 256 MB copy inside the step: SURVEY.md section 8(d), the metric), or resident in "
+                         "HBM (a step = tabulation + typing + calls).  The other kind is timed too and reported beside it")
+    ap.add_argument("--one-kind", "--no-pcie-leg", dest="both_legs", action="store_false",
+                    help="time only the kind of leg --inputs names (no second object in the JSON line)")
+    ap.add_argument("--cli-samples", type=int, default=12,
+                    help="samples for the command line's typing stage (main.alleleTyping), timed after the legs as "
+                         "`cli_typing_stage` (rank 0 of the one-GPU run only; 0 = skip)")
     ap.add_argument("--cores-per-gpu", type=int, default=0,
                     help="pin every rank (its worker processes and threads) to this many host cores of its own, "
                          "before anything touches HIP (0 = no pinning)")
@@ -571,19 +607,12 @@ def main():
     # three host cores (profiles/r03_host_budget.txt, profiles/r03_default_layout.txt); GK_PROCS_PER_GPU=2 adds a second
     # worker process (the default until the end of round 3).  Waits block instead of spinning: a rank of an 8-GPU
     # node may have about two cores.
-    os.environ.setdefault("GK_WAIT_POLICY", "block")
     procs = max(1, int(os.environ.get("GK_PROCS_PER_GPU", "1")))
     procs = min(procs, max(1, args.steps))
-    # the sample preamble on a high-priority stream: what lets ONE process keep the GPU busy (8.9 against 10.2 ms per
-    # sample with three lanes); with two processes it takes CUs from the other process's search at the wrong moments
-    # (9.4 against 8.3 ms) -- profiles/r03_stream_priority.txt
-    os.environ.setdefault("GK_URGENT_PREAMBLE", "1" if procs == 1 else "0")
-    os.environ.setdefault("GK_SAMPLE_LANES", "3" if procs == 1 else "2")      # samples in flight per worker process
-    # ... of which two at a time are in their search (the third has its preamble done and starts the moment a search
-    # ends): two searches fill the GPU, a third next to them lengthens all three and the tail of a short run
-    # (profiles/r03_search_slots.txt: 8.13 against 8.84 ms per sample on the driver's 20 steps, the same on 64)
-    if procs == 1:
-        os.environ.setdefault("GK_SEARCH_SLOTS", "2")
+    # blocking waits, three sample lanes, two search slots, the preamble on a high-priority stream: the package's own
+    # defaults for a process that types a cohort (kir_graph_amd.main sets the same ones)
+    from kir_graph_amd import cohort
+    cohort.pipelineDefaults(procs)
     own_threads = procs > 1 and "GK_THREADS" not in os.environ and os.environ.get("GK_SAMPLE_SEARCH") == "0"
     if own_threads:
         os.environ["GK_THREADS"] = "3"   # per-gene threads (the round-2 path): four processes of three shared the host cores
@@ -641,7 +670,15 @@ def main():
         if own_threads:
             del os.environ["GK_THREADS"]
         res = worker(0, 1, vars(args), rank, local_rank, None, timing=timing)
-    elapsed = timing["elapsed"]
+    legs = timing["legs"]
+
+    def median_leg(kind):
+        """The leg of ``kind`` with the median time (the slower of the middle two for an even count)."""
+        rows = sorted(legs[kind], key=lambda r: r["elapsed"])
+        return rows[len(rows) // 2]
+
+    head = median_leg(args.inputs)
+    elapsed = head["elapsed"]
     prof, call_log, n_valid, gidx = res["prof"], res["call_log"], res["n_valid"], res["gidx"]
     for other in res.get("others", []):
         for k, (n, ms) in other["prof"].items():
@@ -672,10 +709,13 @@ def main():
                                    f"rotation), {2 * args.pairs} 150 bp PE reads, synthetic example_index-shaped index "
                                    f"({sum(len(t.alleles) for t in gidx.tables)} alleles, 15 genes), "
                                    f"--allele-strategy {args.method}, top_n 600; "
-                                   + ("a step starts with the sample's records resident in HBM (tabulation + typing + calls "
-                                      "inside the timed region); pcie_inclusive: the same steps from pinned host memory"
-                                      if args.inputs == "hbm" else
-                                      "records start in pinned host memory (H2D inside the timed region)"),
+                                   + ("a step starts with the sample's packed records in pinned host memory: host-to-device "
+                                      "copy + tabulation + typing + calls inside the timed region (SURVEY.md 8(d)); "
+                                      "hbm_resident: the same steps with the records resident in HBM"
+                                      if args.inputs == "host" else
+                                      "a step starts with the sample's records resident in HBM (tabulation + typing + calls "
+                                      "inside the timed region); pcie_inclusive: the same steps from pinned host memory")
+                                   + f"; median of {len(legs[args.inputs])} timed legs of {args.steps} steps",
                        "inputs": args.inputs,
                        "pairs_per_sample": args.pairs, "pairs_passing_filter": int(n_valid),
                        "parallelism": f"samples sharded over {world} GPU(s), no data-path collective; "
@@ -705,23 +745,47 @@ def main():
             out["kernel_ms_per_step"] = {k: v[1] / args.steps for k, v in prof.items()}
         out["search_steps"] = res.get("search_steps")    # worker 0: steps bounded by integers / redone with f64 only
         out["value_table_entries"] = res.get("n_values")  # worker 0: distinct probabilities = log10 evaluations on the host
-        cpu_s = float(res.get("cpu_s", 0.0))
+        cpu_s = float(head["cpu_s"])
         out["host"] = {"host_core_s_per_step": cpu_s / args.steps, "cores_busy": cpu_s / elapsed if elapsed else None,
                        "cores_per_gpu": args.cores_per_gpu or None, "pinned_to": pinned,
                        "cores_allowed": len(cores_before), "cgroup_quota_cores": cgroup_cores(),
                        "worker_processes": procs, "sample_lanes": int(os.environ.get("GK_SAMPLE_LANES", "2")),
                        "wait_policy": os.environ.get("GK_WAIT_POLICY", "runtime default"),
-                       "note": "user + system time of rank 0's worker processes over the timed region (getrusage); "
+                       "note": "user + system time of rank 0's worker processes over the reported leg (getrusage); "
                                "a host thread that spins on the GPU counts as busy"}
-        pcie_elapsed = timing.get("pcie_elapsed")
-        if pcie_elapsed:
-            out["pcie_inclusive"] = {
-                "value": reads_per_step / (pcie_elapsed / args.steps), "unit": "reads/s",
-                "ms_per_step": 1e3 * pcie_elapsed / args.steps,
-                "host_core_s_per_step": float(res.get("pcie_cpu_s", 0.0)) / args.steps,
-                "note": f"a second timed leg of the same {args.steps} steps with every sample's packed records starting in "
-                        f"pinned host memory: the {256 * args.pairs // 1_000_000} MB host-to-device copy of each sample is "
-                        "inside the timed region (staged two samples ahead of the typing)"}
+
+        def leg_rows(kind):
+            """Every timed leg of a kind, in the order they ran: what a NEW sample costs shows in the first leg of a run
+            with --distinct >= steps + warmup (value_table_new > 0 there, 0 in the later legs, which meet the same samples
+            again); samples_repeated_pass = samples of the leg that had a compatibility table written twice because
+            they brought a product without a log10, tables_rewritten = how many tables that was."""
+            return [{"ms_per_step": 1e3 * r["elapsed"] / args.steps, "value_table_new": r.get("value_table_new", 0),
+                     "value_table_new_per_sample": r.get("value_table_new", 0) / max(args.steps, 1),
+                     "samples_repeated_pass": r.get("samples_repeated_pass", 0),
+                     "tables_rewritten": r.get("tables_rewritten", 0)} for r in legs[kind]]
+
+        out["legs"] = leg_rows(args.inputs)
+        first = legs[args.inputs][0]
+        out["value_table_new_per_sample"] = first.get("value_table_new", 0) / max(args.steps, 1)
+        out["samples_repeated_pass"] = first.get("samples_repeated_pass", 0)
+        out["distinct_samples"] = args.distinct
+        other_kind = [k for k in legs if k != args.inputs]
+        if other_kind:
+            kind = other_kind[0]
+            o = median_leg(kind)
+            name = "pcie_inclusive" if kind == "host" else "hbm_resident"
+            out[name] = {
+                "value": reads_per_step / (o["elapsed"] / args.steps), "unit": "reads/s",
+                "ms_per_step": 1e3 * o["elapsed"] / args.steps,
+                "host_core_s_per_step": float(o["cpu_s"]) / args.steps,
+                "legs": leg_rows(kind),
+                "note": (f"the same {args.steps} steps with every sample's packed records starting in pinned host memory: "
+                         f"the {256 * args.pairs // 1_000_000} MB host-to-device copy of each sample is inside the timed "
+                         "region (staged two samples ahead of the typing)" if kind == "host" else
+                         f"the same {args.steps} steps with the records of the distinct samples resident in HBM before the "
+                         "clock starts (a step = tabulation + typing + calls)") + f"; median of {len(legs[kind])} legs"}
+        if res.get("cli_stage"):
+            out["cli_typing_stage"] = dict(res["cli_stage"], vs_bench_step=res["cli_stage"]["ms_per_sample"] / ms_per_step)
         if args.cpu_pairs and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.method, args.cpu_pairs)
         print(json.dumps(out), flush=True)

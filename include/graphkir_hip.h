@@ -243,6 +243,10 @@ int gk_lut_apply(gk_lut* lut, gk_dptr d_in, gk_dptr d_out, int64_t n);
  * values newly defined, values defined in all, entries claimed by kernels still running elsewhere. */
 typedef int (*gk_log10_fn)(const double* values, int64_t n, double* out);
 int gk_lut_resolve(gk_lut* lut, gk_log10_fn log10_fn, int32_t* n_new, int32_t* n_known, int32_t* n_undefined);
+/* The same without draining the device: for a caller whose own kernels have completed (it waited for them) while other
+ * streams keep running; entries a running kernel has claimed but not stored yet stay undefined (n_undefined), the values
+ * this caller's kernels stored before them are defined (typing_mulit_allele.py:263). */
+int gk_lut_resolve_stored(gk_lut* lut, gk_log10_fn log10_fn, int32_t* n_new, int32_t* n_known, int32_t* n_undefined);
 int gk_lut_known(gk_lut* lut, int32_t* n_known);
 /* reads2AlleleProb and np.log10 in one pass (typing_mulit_allele.py:257-263): gk_compat's product,
  * mapped through the value table as it is written; d_log is column-major double [allele][row].
@@ -271,7 +275,8 @@ int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
  * gk_compat_log_miss = gk_compat_log that also writes the mismatch counts miss[r, a] as a u8 table
  *   d_miss8 [n_allele][ldm] (ldm a multiple of 64 >= n_rows, rows past the end zero), derived from the
  *   log-likelihoods; *d_flags (uint32) gets bit 0 when some count is >= 100 (products near underflow: the caller
- *   must then use gk_maxsum for this gene).
+ *   must then use gk_maxsum for this gene) and bit 2 when some product had no log10 in the value table yet (NaN was
+ *   stored for it: resolve the table and write this gene's table again -- the other genes' tables are not concerned).
  * gk_miss_colsum: d_msum uint32 [n_cols] = column sums of that table.
  * gk_bound_step: M[t, j] = sum_r min(miss[r, cols[j]], min_k miss[r, ids[t*c_prev + k]]) for every candidate,
  *   restricted to first[t*n_cols + j] != 0 (first occurrences of an allele multiset, uniqueAllele 456-476);

@@ -190,6 +190,8 @@ _SIGS = {
                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gk_lut_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32)]),
+    "gk_lut_resolve_stored": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32)]),
     "gk_lut_known": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "gk_search_steps": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "gk_search_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64),

@@ -70,6 +70,152 @@ def overlapped(items, work, lanes: int = 2):
             yield pending.pop(0).result()
 
 
+def pipelineDefaults(procs: int = 1) -> None:
+    """Environment defaults of the sample pipeline, set before the first HIP call of the process (the wait policy is
+    read when a context is made).  ``main._runCohort`` and ``bench.py`` both call this: ONE worker process per GPU types
+    three samples at a time (``GK_SAMPLE_LANES``), two of them inside their search (``GK_SEARCH_SLOTS``), the sample
+    preamble on a high-priority stream, waits that put the thread to sleep (a rank of an 8-GPU node has about two
+    cores).  With several worker processes on a GPU (``procs`` > 1) two lanes each and a plain preamble measured
+    better (profiles/r03_stream_priority.txt, r03_search_slots.txt).  Anything the user set stays."""
+    os.environ.setdefault("GK_WAIT_POLICY", "block")
+    os.environ.setdefault("GK_URGENT_PREAMBLE", "1" if procs == 1 else "0")
+    os.environ.setdefault("GK_SAMPLE_LANES", "3" if procs == 1 else "2")
+    if procs == 1:
+        os.environ.setdefault("GK_SEARCH_SLOTS", "2")
+
+
+def sampleLanes() -> int:
+    """Samples typed at a time by this process, each on a host thread and a block of device contexts of its own."""
+    return max(1, int(os.environ.get("GK_SAMPLE_LANES", "3")))
+
+
+def stagingContexts(dev, lanes: int | None = None):
+    """(copier, ingest): the two device contexts of the staging stages, beyond the blocks of the typing lanes
+    (workers 0 .. lanes * hostThreads() - 1 belong to those): one stream for the copy of a sample's records into
+    HBM, one -- of the device's highest priority -- for its tabulation, whose short kernels would otherwise sit behind
+    the long kernels of the samples being typed."""
+    from .kir_typing import hostThreads
+    lanes = sampleLanes() if lanes is None else lanes
+    base = lanes * hostThreads()
+    ingest = dev.worker(base, urgent=True)       # made first: a context's priority is fixed when it is made
+    return dev.worker(base + 1), ingest
+
+
+def stagedSamples(items, copy_in, tabulate, depth: int | None = None, copy_ahead: bool | None = None):
+    """Yield ``tabulate(copy_in(item))`` for every item, in order, staged ahead of the consumer as a two-stage
+    pipeline: while sample k is typed, sample k + 1 is tabulated and the records of k + 2 are on their way to HBM,
+    each stage on a thread (and a device context, ``stagingContexts``) of its own.  ``copy_ahead=False``
+    (GK_COPY_AHEAD=0): both stages in one (6 - 7 ms of wall time per configs[1] sample next to the typing kernels, 80 % of
+    a process's budget).  ``copy_in=None``: the records are in HBM already, one stage.  ``depth`` <= 0 (GK_PREFETCH=0):
+    nothing ahead, everything on the calling thread."""
+    depth = int(os.environ.get("GK_PREFETCH", "1")) if depth is None else depth
+    if copy_ahead is None:
+        copy_ahead = os.environ.get("GK_COPY_AHEAD", "1") != "0"
+    if depth <= 0:
+        for item in items:
+            yield tabulate(item if copy_in is None else copy_in(item))
+        return
+    if copy_in is None:
+        yield from prefetched(items, tabulate, depth=depth)
+    elif copy_ahead:
+        yield from prefetched(prefetched(items, copy_in, depth=depth), tabulate, depth=depth)
+    else:
+        yield from prefetched(items, lambda item: tabulate(copy_in(item)), depth=depth)
+
+
+class SampleTyper:
+    """The typing stage of one process: ``submit`` hands a tabulated sample to one of ``lanes`` host threads (each
+    with its own block of device contexts: ``typer.slot_base``), results come back in submission order.
+
+    This is the one code path behind ``main.alleleTyping`` / ``main._runCohort`` (the command line) and ``bench.py``
+    (the measurement): a sample is typed by ONE host thread on one stream (``gk_sample_search``), up to ``lanes``
+    samples at a time, at most GK_SEARCH_SLOTS of them inside their search (``kir_typing._searchSlot``), the
+    preamble of a sample on the lane's high-priority stream (GK_URGENT_PREAMBLE), waits that block.
+
+    ``finish(typer, calls, warnings, item)`` runs on the lane's thread once the sample is typed (write its files,
+    release its HBM); its return value is the sample's result."""
+
+    def __init__(self, method: str, lanes: int | None = None, top_n: int = 600, variant_correction: bool = True,
+                 finish=None):
+        from concurrent.futures import ThreadPoolExecutor
+        import queue
+        self.method = "exonfirst_1" if method == "exonfirst" else method     # main.py:186-187
+        self.lanes = sampleLanes() if lanes is None else max(1, lanes)
+        self.top_n, self.variant_correction = top_n, variant_correction
+        self.finish = finish
+        self._pool = ThreadPoolExecutor(max_workers=self.lanes, thread_name_prefix="gk-sample") if self.lanes > 1 else None
+        self._free = queue.SimpleQueue()
+        for lane in range(self.lanes):
+            self._free.put(lane)
+        self._pending: list = []
+
+    def typeOne(self, data, gene_cn, item=None, lane: int = 0):
+        """One sample on the calling thread, on lane ``lane``'s contexts."""
+        from .kir_typing import hostThreads, selectKirTypingModel
+        typer = selectKirTypingModel(self.method, data, top_n=self.top_n, variant_correction=self.variant_correction)
+        typer.slot_base = lane * hostThreads()
+        calls, warnings = typer.typing(gene_cn() if callable(gene_cn) else gene_cn)
+        if self.finish is not None:
+            return self.finish(typer, calls, warnings, item)
+        return calls, warnings, typer
+
+    def _run(self, data, gene_cn, item):
+        lane = self._free.get()
+        try:
+            return self.typeOne(data, gene_cn, item, lane)
+        finally:
+            self._free.put(lane)
+
+    def submit(self, data, gene_cn, item=None) -> None:
+        """Queue a sample (``gene_cn``: the copy numbers, or a callable that returns them on the lane's thread)."""
+        if self._pool is None:
+            self._pending.append(_Done(self.typeOne(data, gene_cn, item, 0)))
+        else:
+            self._pending.append(self._pool.submit(self._run, data, gene_cn, item))
+
+    def inFlight(self) -> int:
+        return len(self._pending)
+
+    def next(self):
+        """The oldest sample's result (waits for it); an exception of its typing is raised here."""
+        return self._pending.pop(0).result()
+
+    def drain(self):
+        while self._pending:
+            yield self.next()
+
+    def close(self) -> None:
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class _Done:
+    def __init__(self, value):
+        self._value = value
+
+    def result(self):
+        return self._value
+
+
+def typeSamples(samples, method: str, lanes: int | None = None, finish=None, top_n: int = 600,
+                variant_correction: bool = True):
+    """Type every ``(SampleData, gene_cn, item)`` of ``samples`` -- an iterable that may stage its samples ahead
+    (``stagedSamples``) -- and yield the results in order, with up to ``lanes`` samples in flight (``SampleTyper``)."""
+    with SampleTyper(method, lanes=lanes, top_n=top_n, variant_correction=variant_correction, finish=finish) as typer:
+        for data, gene_cn, item in samples:
+            typer.submit(data, gene_cn, item)
+            if typer.inFlight() >= typer.lanes:
+                yield typer.next()
+        yield from typer.drain()
+
+
 def shardSamples(n_samples: int, world: int, weights=None) -> list[list[int]]:
     """Assignment of sample indices to ranks, deterministic and known to every rank.
 

@@ -284,12 +284,15 @@ struct GeneSearch {
     std::vector<int64_t> order((size_t)A);
     // numpy.argsort is an unstable sort: its order among EQUAL values is numpy's own, so it is asked (a call back
     // into the host language, which may have to wait for the interpreter lock) only when equal values exist;
-    // distinct values have one ascending order, whoever sorts them
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return score[x] != score[y] ? score[x] < score[y] : x < y; });
+    // distinct values have one ascending order, whoever sorts them.  NaN (a table read before its last pass) never
+    // reaches std::sort: `<` is no strict weak order with it
     bool plain = true;
-    for (int a = 0; a < A && plain; ++a)
-      plain = score[a] == score[a] && (a == 0 || score[order[a - 1]] != score[order[a]]);   // no NaN, no tie
+    for (int a = 0; a < A && plain; ++a) plain = score[a] == score[a];
+    if (plain) {
+      std::iota(order.begin(), order.end(), 0);
+      std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return score[x] != score[y] ? score[x] < score[y] : x < y; });
+      for (int a = 1; a < A && plain; ++a) plain = score[order[a - 1]] != score[order[a]];   // no tie
+    }
     if (!plain) GK_REQUIRE(argsort(score.data(), A, order.data()) == 0, "host argsort failed");
     Step s1;
     s1.n = 1;
@@ -373,6 +376,8 @@ struct GeneSearch {
     bool ok = true;
     std::vector<int64_t> head;
     const int64_t n_top = std::min<int64_t>(std::max<int64_t>(T, N / 5), N);
+    for (double v : value)
+      if (v != v) return GK_OK;          // a NaN sum (cannot happen on a settled table): the exact step, which asks numpy
     if (N > T) {
       std::vector<double> tmp(value);
       std::nth_element(tmp.begin(), tmp.begin() + (T - 1), tmp.end(), [](double x, double y) { return x > y; });
@@ -658,11 +663,16 @@ int sample_search_lockstep(gk_ctx* ctx, const std::vector<gk_ctx*>& cx, gk_tab* 
     for (auto& g : gs) if (g) g->abandon();
     return code;
   };
-  for (int pass = 0; pass < 64; ++pass) {
+  // The tables are written until every product met had its log10 in the value table.  A kernel that stored NaN for a
+  // product says so in its gene's flag word (bit 2), so only THAT gene's table is written again; a job without a flag
+  // word (no mismatch table) is judged by the table's growth since its launch, as before.
+  std::vector<int> dirty(live);
+  bool settled = false;
+  for (int pass = 0; pass < 64 && !settled; ++pass) {
     int32_t known_at_launch = 0;
     rc = gk_lut_known(lut, &known_at_launch);
     if (rc) return quit(rc);
-    for (int i : live) {
+    for (int i : dirty) {
       gk_gene_job& j = jobs[i];
       gk_ctx* const gc = ctx_of[i];
       j.passes++;
@@ -688,12 +698,21 @@ int sample_search_lockstep(gk_ctx* ctx, const std::vector<gk_ctx*>& cx, gk_tab* 
     int32_t n_new = 0, n_known = 0, n_undefined = 0;
     rc = gk_lut_resolve(lut, log10_fn, &n_new, &n_known, &n_undefined);
     if (rc) return quit(rc);
-    if (n_known > known_at_launch) continue;    // some values were undefined at launch: write the tables again
-    if (n_undefined == 0) break;                // every value these launches met had its log10 in the table
-    if (pass == 63) {
-      gk_set_error("log10 value table did not settle");
-      return quit(GK_ERR_ASSERT);
+    std::vector<int> again;
+    bool unflagged = false;
+    for (int i : dirty) {
+      if (jobs[i].d_flags) { if (flags[i] & 4u) again.push_back(i); }
+      else unflagged = true;
     }
+    if (unflagged && (n_known > known_at_launch || n_undefined != 0))
+      for (int i : dirty) if (!jobs[i].d_flags) again.push_back(i);
+    std::sort(again.begin(), again.end());
+    settled = again.empty();
+    dirty.swap(again);
+  }
+  if (!settled) {
+    gk_set_error("log10 value table did not settle");
+    return quit(GK_ERR_ASSERT);
   }
   // a gene whose indices do not fit 16 bits (the value table holds more than 65535 values) takes the float64 form, in a
   // block of this call's own; every value is defined by now, so one pass writes it
@@ -774,17 +793,16 @@ int sample_search_lockstep(gk_ctx* ctx, const std::vector<gk_ctx*>& cx, gk_tab* 
  * queued: waits for the mark, does the gene's host work, queues its next stage -- behind the stages of the other genes
  * that are still running.  The stream therefore always holds about one stage of every gene, and the host work of a
  * gene is hidden behind the kernels of the others (lock-step: the GPU idles while the host handles a phase of all
- * genes, ~3 ms of a 9 ms sample).  Optimistic about the value table: the searches start on the tables of the first
- * pass, and the table's entry count -- read on the stream behind the last compatibility kernel -- tells whether that
- * pass met a value without a log10 yet; then `*redo` is set, nothing is returned, and the caller takes the lock-step
- * form (after the first samples of a run the table does not grow any more). */
+ * genes, ~3 ms of a 9 ms sample).  The value table settles PER GENE: a compatibility kernel that stored NaN for a product
+ * without a log10 raises bit 2 of its gene's flag word, which comes back with the table's mark -- before any host sort
+ * sees the column sums; that gene's table is written again after the new values are defined, the searches of the other
+ * genes are not touched (a sample that brings one new value pays one more kernel of one gene). */
 int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut, gk_gene_job* jobs, int32_t n_jobs,
-                            const std::vector<int>& live, gk_argsort_fn argsort, gk_search** out, bool* redo) {
-  *redo = false;
+                            const std::vector<int>& live, gk_argsort_fn argsort, gk_log10_fn log10_fn, gk_search** out) {
   SearchClock clock("pipelined", (int)live.size());
   std::vector<uint32_t> flags((size_t)n_jobs, 0);
   std::vector<std::unique_ptr<GeneSearch>> gs((size_t)n_jobs);
-  enum { kTable, kBound, kSums, kValues };
+  enum { kTable, kBound, kSums };
   struct Item { int gene, stage; uint64_t mark; };
   std::deque<Item> queue;
   auto fail = [&](int code) {
@@ -798,35 +816,31 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
     if (r == GK_OK) queue.push_back({gene, stage, m});
     return r;
   };
-  int32_t known_at_launch = 0;
-  int rc = gk_lut_known(lut, &known_at_launch);
-  if (rc) return rc;
-  for (int i : live) {
+  // gene i's table, mismatch sums, flag word and column sums (right behind the kernel that wrote the table: it is still
+  // in the Infinity Cache), then a mark
+  auto write_table = [&](int i) -> int {
     gk_gene_job& j = jobs[i];
     j.passes++;
-    if (j.d_miss8) {
-      rc = gk_compat_log_miss(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
-                              j.d_L, j.d_miss8, j.ldm, j.d_flags);
-      if (rc == GK_OK) rc = gk_miss_colsum(ctx, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
-      if (rc == GK_OK && gk_fetch_queue(ctx, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
-    } else {
-      rc = gk_compat_log(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut, j.d_L);
-    }
-    if (rc) return fail(rc);
-    // the column sums right behind the kernel that wrote the table (still in the Infinity Cache)
+    int rc = gk_compat_log_miss(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
+                                j.d_L, j.d_miss8, j.ldm, j.d_flags);
+    if (rc == GK_OK) rc = gk_miss_colsum(ctx, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
+    if (rc == GK_OK && gk_fetch_queue(ctx, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
+    if (rc) return rc;
     std::vector<int32_t> cols((size_t)j.n_allele);
     std::iota(cols.begin(), cols.end(), 0);
+    if (gs[i]) gs[i]->abandon();                 // the pass before this one: its column sums are void
     gs[i].reset(new GeneSearch());
     rc = gs[i]->init(ctx, GkTable{j.d_L, j.n_rows, nullptr}, j.d_L, j.n_rows, j.n_rows, j.n_allele, j.d_miss8, j.ldm, j.d_msum,
                      cols.data(), j.n_allele, j.n_steps, j.top_n, argsort);
     if (rc == GK_OK) rc = gs[i]->colsum_enqueue();
     if (rc == GK_OK) rc = push(i, kTable);
+    return rc;
+  };
+  int rc = GK_OK;
+  for (int i : live) {
+    rc = write_table(i);
     if (rc) return fail(rc);
   }
-  uint32_t n_values = 0;       // entries of the value table once every kernel above has run
-  if (gk_fetch_queue(ctx, &n_values, lut->d_count, sizeof(uint32_t)) != hipSuccess) return fail(GK_ERR_HIP);
-  rc = push(-1, kValues);
-  if (rc) return fail(rc);
 
   // gene i goes on until it has a stage in flight (queued here) or no step left
   auto advance = [&](int i, bool at_step_start) -> int {
@@ -853,21 +867,25 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
     rc = wait_mark(ctx, it.mark);
     clock.lap(true);
     if (rc) return fail(rc);
-    if (it.stage == kValues) {
-      int32_t known_now = 0;
-      rc = gk_lut_known(lut, &known_now);
-      if (rc) return fail(rc);
-      if ((int64_t)n_values != (int64_t)known_at_launch || known_now != known_at_launch) {
-        *redo = true;              // some value had no log10 when a table was written: settle the table, write them again
-        return fail(GK_OK);
-      }
-      continue;
-    }
     gk_gene_job& j = jobs[it.gene];
     GeneSearch& g = *gs[it.gene];
     switch (it.stage) {
       case kTable:
-        j.bound_ok = (j.d_miss8 && (flags[it.gene] & 1u) == 0) ? 1 : 0;
+        if (flags[it.gene] & 4u) {
+          // the kernel met a product without a log10 and stored NaN for it (a sample that brings new values): define what
+          // is stored by now -- this gene's kernel has completed, so its own keys are -- and write THIS gene's table again,
+          // behind the stages of the other genes, whose searches go on.  A key that a kernel still running on another
+          // stream has claimed but not stored ends the resolver's batch; after a few fruitless passes the device is drained.
+          if (j.passes >= 64) {
+            gk_set_error("log10 value table did not settle");
+            rc = GK_ERR_ASSERT;
+            break;
+          }
+          rc = (j.passes < 4 ? gk_lut_resolve_stored : gk_lut_resolve)(lut, log10_fn, nullptr, nullptr, nullptr);
+          if (rc == GK_OK) rc = write_table(it.gene);
+          break;
+        }
+        j.bound_ok = (flags[it.gene] & 1u) == 0 ? 1 : 0;
         if (!j.bound_ok) g.bound = false;      // a mismatch count near the underflow range / a very long row: exact steps
         g.colsum_collect();
         rc = g.first_step();
@@ -934,11 +952,10 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
   const bool pipeline = !(form && !strcmp(form, "0"));
   bool float_tables = true;
   for (int i : live) float_tables = float_tables && jobs[i].d_L && !jobs[i].d_lidx;
-  if (pipeline && n_more == 0 && float_tables) {
-    bool redo = false;
-    const int rc = sample_search_pipelined(ctx, tab, d_vflag, lut, jobs, n_jobs, live, argsort, out, &redo);
-    if (rc || !redo) return rc;
-  }
+  bool flagged = true;               // every table comes with the flag word that reports products without a log10
+  for (int i : live) flagged = flagged && jobs[i].d_miss8 && jobs[i].d_flags;
+  if (pipeline && n_more == 0 && float_tables && flagged)
+    return sample_search_pipelined(ctx, tab, d_vflag, lut, jobs, n_jobs, live, argsort, log10_fn, out);
   return sample_search_lockstep(ctx, cx, tab, d_vflag, lut, jobs, n_jobs, live, argsort, log10_fn, out);
 }
 

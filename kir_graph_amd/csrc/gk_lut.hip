@@ -139,13 +139,14 @@ int gk_lut_collect(gk_lut* l, gk_dptr d_vals, int64_t n) {
   return GK_OK;
 }
 
-int gk_lut_pending(gk_lut* l, int32_t* n_total, int32_t* n_known) {
+// entries claimed so far / defined so far; `drain`: when the table grew, let every stream of the device finish first, so
+// that every claimed entry is stored (the resolver then never meets a claimed-but-unstored key)
+static int lut_pending(gk_lut* l, bool drain, int32_t* n_total, int32_t* n_known) {
   gk_bind(l ? l->ctx : nullptr);
   GK_REQUIRE(l && n_total && n_known, "null pointer");
   uint32_t c = 0;
   GK_HIP(gk_fetch(l->ctx, &c, l->d_count, sizeof(uint32_t)));
-  if ((int64_t)c > (int64_t)l->n_known) {
-    // new values: let every stream of the device finish, so that all claimed entries are written
+  if (drain && (int64_t)c > (int64_t)l->n_known) {
     GK_HIP(hipDeviceSynchronize());
     GK_HIP(gk_fetch(l->ctx, &c, l->d_count, sizeof(uint32_t)));
   }
@@ -157,6 +158,8 @@ int gk_lut_pending(gk_lut* l, int32_t* n_total, int32_t* n_known) {
   *n_known = l->n_known;
   return GK_OK;
 }
+
+int gk_lut_pending(gk_lut* l, int32_t* n_total, int32_t* n_known) { return lut_pending(l, true, n_total, n_known); }
 
 int gk_lut_export(gk_lut* l, int32_t first, int32_t count, double* keys_out) {
   gk_bind(l ? l->ctx : nullptr);
@@ -184,11 +187,12 @@ int gk_lut_define(gk_lut* l, int32_t first, int32_t count, const double* log_val
  * reference's on the machine at hand) for the values first seen since the last call, define them.  One resolver at a
  * time.  The caller's own kernels must have completed.  Kernels of other streams may still be inserting: an entry that is
  * claimed but not stored yet ends the batch (n_undefined > 0) -- whoever launched that kernel resolves it. */
-int gk_lut_resolve(gk_lut* l, gk_log10_fn log10_fn, int32_t* n_new_out, int32_t* n_known_out, int32_t* n_undefined_out) {
+static int lut_resolve(gk_lut* l, gk_log10_fn log10_fn, bool drain, int32_t* n_new_out, int32_t* n_known_out,
+                       int32_t* n_undefined_out) {
   GK_REQUIRE(l && log10_fn, "null pointer");
   std::lock_guard<std::mutex> lock(l->resolve_mutex);
   int32_t tot = 0, known = 0;
-  int rc = gk_lut_pending(l, &tot, &known);
+  int rc = lut_pending(l, drain, &tot, &known);
   if (rc) return rc;
   int32_t fresh = tot - known;
   if (fresh > 0) {
@@ -213,6 +217,17 @@ int gk_lut_resolve(gk_lut* l, gk_log10_fn log10_fn, int32_t* n_new_out, int32_t*
   if (n_known_out) *n_known_out = l->n_known;
   if (n_undefined_out) *n_undefined_out = l->n_undefined;
   return GK_OK;
+}
+
+int gk_lut_resolve(gk_lut* l, gk_log10_fn log10_fn, int32_t* n_new_out, int32_t* n_known_out, int32_t* n_undefined_out) {
+  return lut_resolve(l, log10_fn, true, n_new_out, n_known_out, n_undefined_out);
+}
+
+/* gk_lut_resolve for a caller whose OWN kernels have completed and who does not want the other streams of the device
+ * drained: defines the stored entries up to the first one that a kernel still running elsewhere has claimed but not
+ * stored (n_undefined counts what is left; whoever launched that kernel resolves it, or this caller asks again). */
+int gk_lut_resolve_stored(gk_lut* l, gk_log10_fn log10_fn, int32_t* n_new_out, int32_t* n_known_out, int32_t* n_undefined_out) {
+  return lut_resolve(l, log10_fn, false, n_new_out, n_known_out, n_undefined_out);
 }
 
 int gk_lut_known(gk_lut* l, int32_t* n_known) {

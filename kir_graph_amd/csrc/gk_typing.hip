@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
               info = inf1;
             } else {
               info = gk_lut_info(lut, key);
-              if (info == kLutNoInfo) gk_lut_insert(lut, key);
+              if (info == kLutNoInfo) { gk_lut_insert(lut, key); atomicOr(bound_flags, 4u); }   // no log10 yet: this table is written again
             }
             key1 = key0; inf1 = inf0;
             key0 = key; inf0 = info;
@@ -452,7 +452,10 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
             } else {
               bool found;
               val = gk_lut_lookup(lut, key, &found);
-              if (!found) gk_lut_insert(lut, key);
+              if (!found) {
+                gk_lut_insert(lut, key);
+                if (bound_flags) atomicOr(bound_flags, 4u);      // no log10 yet (NaN stored): this table is written again
+              }
             }
             key1 = key0; val1 = val0;
             key0 = key; val0 = val;

@@ -519,6 +519,15 @@ class DeviceModel:
             return
         for _ in range(64):
             self.dev.sync()                     # this model's kernel has stored every key it claimed
+            if self._bound_flags is not None:
+                # the kernel itself says whether it stored NaN for a product without a log10 (bit 2 of the flag word)
+                flags = int(self._bound_flags.download()[0])
+                if not flags & 4:
+                    self._bound_ok = (flags & 3) == 0
+                    break
+                self._logs.resolve()
+                self._launchLog()
+                continue
             self._logs.resolve()
             if self._logs.n_known > self._known_at_launch:
                 self._launchLog()               # some values were undefined at launch: write the table again
@@ -535,7 +544,7 @@ class DeviceModel:
         if self.miss8 is None:
             return False
         if self._bound_ok is None:
-            self._bound_ok = int(self._bound_flags.download()[0]) == 0
+            self._bound_ok = (int(self._bound_flags.download()[0]) & 3) == 0
         return self._bound_ok
 
     def boundStep(self, prev_ids: np.ndarray, cols: np.ndarray, first: np.ndarray, top_n: int, cap: int):

@@ -370,9 +370,10 @@ def packAlignments(source, index: GkIndex, keep_text: bool = True) -> dict:
 
 
 def extractVariantFromPacked(pack: dict, index: GkIndex, dev: Device | None = None,
-                             dindex: DeviceIndex | None = None, correction=None) -> SampleData:
+                             dindex: DeviceIndex | None = None, correction=None, mates=None) -> SampleData:
     """Device half: packed records -> tabulated sample (novel ids continue the process-wide counter).
-    ``correction``: see ``Tabulation`` (pileup error correction, hisat2.py:609-654)."""
+    ``correction``: see ``Tabulation`` (pileup error correction, hisat2.py:609-654).  ``mates``: the records already in
+    HBM (a device buffer: the pipeline copies them on a stream of its own), else they are uploaded here."""
     dev = dev or Device()
     dindex = dindex or DeviceIndex(dev, index)
     logger.info(f"[Graph] Reads: {pack['counts']['reads']} Pairs: {pack['counts']['pairs']}")
@@ -380,7 +381,8 @@ def extractVariantFromPacked(pack: dict, index: GkIndex, dev: Device | None = No
     spill = pack["counts"].get("spill")
     if spill is not None:
         logger.info(f"[Graph] Pairs beyond the 128-byte record, kept in the wide format: {len(spill[1])}")
-    tab = Tabulation(dindex, pack["records"], novel_base=base, correction=correction, spill=spill)
+    tab = Tabulation(dindex, pack["records"] if mates is None else mates, novel_base=base, dev=dev, correction=correction,
+                     spill=spill)
     Variant.novel_id = base + tab.n_novel
     logger.info(f"[Graph] Filterd pairs: {tab.n_valid}")
     return SampleData(tab, index, None, pairs_text=pack["pairs_text"], ins_strings=pack["strings"])

@@ -145,7 +145,8 @@ class _GenesInParallel(Typing):
     def __init__(self) -> None:
         super().__init__()
         self._local = threading.local()
-        self.slot_base = 0     # first worker context of this typer (cohort.overlapped gives every lane its own block)
+        self.slot_base = 0     # first worker context of this typer (cohort.SampleTyper gives every lane its own block)
+        self.tables_rewritten = 0   # compatibility tables written again because the sample brought products without a log10
 
     def _context(self):
         """(tabulation bound to this thread's context, its log table)."""
@@ -298,6 +299,7 @@ class TypingWithPosNegAllele(_GenesInParallel):
             with _searchSlot():
                 check(lib().gk_sample_search(tab.dev.ctx, more, len(extra), tab.handle, vflag.ptr, logs.handle, jobs, len(live),
                                              _lib.NUMPY_ARGSORT, _lib.NUMPY_LOG10, handles))
+            self.tables_rewritten = sum(max(0, int(jobs[k].passes) - 1) for k in range(len(live)))
             try:
                 for k, (gene, cn, typ, _, homo) in enumerate(live):
                     typ.adoptJob(jobs[k], C.c_void_p(handles[k]), cn, homo)

@@ -76,6 +76,10 @@ def mapSamples(names, reads, index, index_ref, exon_region_only=False, alignment
     dev = defaultDevice()
     from .engine import DeviceIndex
     dindex = DeviceIndex(dev, gk)
+    # the staging contexts of the sample pipeline (cohort.stagingContexts, the ones bench.py stages with): the records go
+    # to HBM on the copier's stream, the tabulation and the depth run on a high-priority stream of their own -- beside the
+    # typing lanes (cohort.SampleTyper), which are typing the samples before this one
+    copier, ingest = cohort.stagingContexts(dev)
 
     def prepare(k: int):
         """External mapping (when needed) + native packing of sample k: host work, off the GPU's path."""
@@ -99,20 +103,22 @@ def mapSamples(names, reads, index, index_ref, exon_region_only=False, alignment
     writer = ThreadPoolExecutor(max_workers=2, thread_name_prefix="gk-write")   # compact hand-off files, off this thread
     writes = []
     try:
-        yield from _mapLoop(names, prepare, ahead, gk, gene_len, dev, dindex, index_ref, exon_region_only, write_json,
-                            writer, writes)
+        yield from _mapLoop(names, prepare, ahead, gk, gene_len, (copier, ingest), dindex, index_ref, exon_region_only,
+                            write_json, writer, writes)
     finally:
         for w in writes:
             w.result()          # every hand-off file is complete (and any write error surfaces) before we return
         writer.shutdown()
 
 
-def _mapLoop(names, prepare, ahead, gk, gene_len, dev, dindex, index_ref, exon_region_only, write_json, writer, writes):
+def _mapLoop(names, prepare, ahead, gk, gene_len, staging, dindex, index_ref, exon_region_only, write_json, writer, writes):
+    copier, dev = staging
     for name, source, pack in cohort.prefetched(range(len(names)), prepare, depth=ahead, workers=ahead):
         name += ".variant"
         logger.info(f"[Graph] Filter mapping ({name})")
         if pack is not None:
-            data = extractVariantFromPacked(pack, gk, dev=dev, dindex=dindex)
+            mates = copier.put(pack["records"])      # pinned records -> HBM on the copier's stream (gk_h2d waits for it)
+            data = extractVariantFromPacked(pack, gk, dev=dev, dindex=dindex, mates=mates)
         else:   # BAM name-collated through samtools like the reference (hisat2.readBam)
             data = extractVariant(readPair(source), gk, dev=dev, dindex=dindex)
         del pack
@@ -160,34 +166,55 @@ def readMapping(names, reads, index, index_ref, exon_region_only=False, alignmen
     return bam_files, processed, depth_files
 
 
+def typingSuffix(name: str, cn_file: str, method: str) -> str:
+    """``.cn<what the CN file's name adds to the sample's>.<method>`` (main.py:182-187)."""
+    if method == "exonfirst":
+        method += "_1"
+    return ".cn" + cn_file[len(getCommonName(name, cn_file)):].replace("/", "_").replace(".", "_") + "." + method
+
+
+def writeTyping(name: str, typer, called_alleles: list[str], warning_genes: list[str]) -> str:
+    """``{name}.tsv`` (name, alleles, warnings) and ``{name}.possible.tsv`` of one typed sample (main.py:203-219)."""
+    pd.DataFrame({"name": [name], "alleles": ["_".join(called_alleles)],
+                  "warnings": ["_".join(warning_genes)]}).to_csv(name + ".tsv", sep="\t", index=False)
+    try:
+        possible = typer.getAllPossibleTyping()       # reads the ranked results on the host only
+    except NotImplementedError:      # EM strategy has no possible-set table (kir_typing.py:63-68)
+        possible = []
+    pd.DataFrame(possible).fillna("").to_csv(name + ".possible.tsv", index=False, sep="\t")
+    return name + ".tsv"
+
+
+def sampleTyper(method: str, release: bool = True) -> "cohort.SampleTyper":
+    """The typing stage of this process (``cohort.SampleTyper``: the sample lanes, search slots, urgent preamble and
+    blocking waits that ``bench.py`` measures), finishing every sample the reference's way: its two files written, its
+    tabulation released.  Submit ``(SampleData or hand-off file, copy numbers, (name, cn_file))``."""
+    def finish(typer, called_alleles, warning_genes, item):
+        name, cn_file, source = item
+        if release or not isinstance(source, SampleData):      # done with this sample: free its HBM
+            typer._data.tab.close()
+        logger.info(f"[Allele] {called_alleles} ({name})")
+        return writeTyping(name + typingSuffix(name, cn_file, method), typer, called_alleles, warning_genes)
+
+    return cohort.SampleTyper(method, finish=finish)
+
+
 def alleleTyping(processed_bam, cn_files: list[str], method: str = "full", release: bool = False) -> list[str]:
     """Allele typing of every sample; writes ``{name}{suffix}.tsv`` and ``.possible.tsv`` (171-220).
 
     ``processed_bam`` entries are names (the ``.json`` next to them is loaded) or (name, SampleData);
-    ``release``: close every SampleData's tabulation once its results are taken (the pipeline does)."""
+    ``release``: close every SampleData's tabulation once its results are taken (the pipeline does).
+    The samples go through the process's typing lanes (``sampleTyper``): up to GK_SAMPLE_LANES at a time, results in
+    order -- the reference types them one after the other (main.py:178-220), the files are the same."""
     allele_files = []
-    for entry, cn_file in zip(processed_bam, cn_files):
-        name, source = entry if isinstance(entry, tuple) else (entry, entry + ".json")
-        logger.debug(f"[Allele] Allele typing ({method}) with CN {cn_file} ({name})")
-        suffix = ".cn" + cn_file[len(getCommonName(name, cn_file)):].replace("/", "_").replace(".", "_") + "."
-        if method == "exonfirst":
-            method += "_1"
-        suffix += method
-        t = selectKirTypingModel(method, source, top_n=600, variant_correction=True)
-        cn = loadCN(cn_file)
-        called_alleles, warning_genes = t.typing(cn)
-        if release and isinstance(source, SampleData):      # the caller is done with this sample: free its HBM
-            source.tab.close()
-        logger.info(f"[Allele] {called_alleles} ({name})")
-        name += suffix
-        pd.DataFrame({"name": [name], "alleles": ["_".join(called_alleles)],
-                      "warnings": ["_".join(warning_genes)]}).to_csv(name + ".tsv", sep="\t", index=False)
-        allele_files.append(name + ".tsv")
-        try:
-            possible = t.getAllPossibleTyping()       # reads the ranked results on the host only
-        except NotImplementedError:      # EM strategy has no possible-set table (kir_typing.py:63-68)
-            possible = []
-        pd.DataFrame(possible).fillna("").to_csv(name + ".possible.tsv", index=False, sep="\t")
+    with sampleTyper(method, release=release) as lanes:
+        for entry, cn_file in zip(processed_bam, cn_files):
+            name, source = entry if isinstance(entry, tuple) else (entry, entry + ".json")
+            logger.debug(f"[Allele] Allele typing ({method}) with CN {cn_file} ({name})")
+            lanes.submit(source, (lambda f=cn_file: loadCN(f)), (name, cn_file, source))
+            if lanes.inFlight() >= lanes.lanes:
+                allele_files.append(lanes.next())
+        allele_files.extend(lanes.drain())
     return allele_files
 
 
@@ -236,6 +263,7 @@ def createParser() -> argparse.ArgumentParser:
 
 
 def main(args: argparse.Namespace) -> None:
+    cohort.pipelineDefaults()       # before the first HIP call: blocking waits, sample lanes, search slots (as bench.py)
     setThreads(args.thread)
     setEngine(args.engine)
     logger.setLevel(args.log_level)
@@ -314,12 +342,24 @@ def _runCohort(args, names, reads, cn_files, index, index_ref, cohort_name, comm
     kwargs = {"base_dev": float(args.cn_dist_dev), "start_base": 2}
     method = {"pv": "full", "report": "em"}.get(args.allele_strategy, args.allele_strategy)
     pooled_fit = args.cn_cohort and not all(cn_files)
+    lanes = sampleTyper(method)
+    try:
+        allele_files, my_cn = _typeShare(args, lanes, pick(names), pick(reads), my_cn, pick, index, index_ref, cohort_name,
+                                         comm, kwargs, pooled_fit)
+    finally:
+        lanes.close()
+    _mergeShare(my_cn, allele_files, cohort_name, comm)
+
+
+def _typeShare(args, lanes, names, reads, my_cn, pick, index, index_ref, cohort_name, comm, kwargs, pooled_fit):
+    """Tabulation, depth, copy numbers of this rank's samples, each handed to the typing lanes as soon as its copy
+    numbers are known; returns (allele files, CN files) in the rank's sample order."""
     allele_files: list[str] = []
     waiting: list[tuple[str, object]] = []      # samples that wait for the pooled copy-number fit
     depth_files: list[str] = []
     retained = 0
     budget = int(float(os.environ.get("GK_RETAIN_GB", "64")) * 2**30)   # tabulations kept in HBM until the pooled fit
-    samples = mapSamples(pick(names), pick(reads), index, index_ref, exon_region_only=args.cn_exon,
+    samples = mapSamples(names, reads, index, index_ref, exon_region_only=args.cn_exon,
                          alignments=pick(args.alignment) if args.alignment else None,
                          write_json=not args.no_variant_json)
     for i, (_, name, data, depth_file) in enumerate(samples):
@@ -348,9 +388,12 @@ def _runCohort(args, names, reads, cn_files, index, index_ref, cohort_name, comm
                              cluster_method_kwargs=kwargs, assume_3DL3_diploid=not args.cn_3dl3_not_diploid,
                              save_cn_model_path=cn_name + ".json", select_mode=args.cn_select)
             my_cn[i] = cn_name + ".tsv"
-        # copy numbers known: type the sample now and release it (memory does not grow with the cohort)
+        # copy numbers known: hand the sample to the typing lanes and go on with the next one's tabulation; a lane
+        # releases the sample when it is typed (at most GK_SAMPLE_LANES tabulations wait in HBM)
         if not args.step_skip_typing:
-            allele_files += alleleTyping([(name, data)], [my_cn[i]], method=method, release=True)
+            lanes.submit(data, (lambda f=my_cn[i]: loadCN(f)), (name, my_cn[i], data))
+            if lanes.inFlight() >= lanes.lanes:
+                allele_files.append(lanes.next())
         else:
             data.tab.close()
     if pooled_fit:
@@ -364,9 +407,14 @@ def _runCohort(args, names, reads, cn_files, index, index_ref, cohort_name, comm
                 if isinstance(source, SampleData):
                     source.tab.close()
                 continue
-            entry = (name, source) if isinstance(source, SampleData) or source.endswith(".npz") else name
-            allele_files += alleleTyping([entry], [cn_file], method=method, release=True)
+            lanes.submit(source, (lambda f=cn_file: loadCN(f)), (name, cn_file, source))
+            if lanes.inFlight() >= lanes.lanes:
+                allele_files.append(lanes.next())
+    allele_files.extend(lanes.drain())
+    return allele_files, my_cn
 
+
+def _mergeShare(my_cn, allele_files, cohort_name, comm) -> None:
     # merge on rank 0, in cohort order
     if comm is not None:
         cn_sorted = comm.gatherInCohortOrder(my_cn)

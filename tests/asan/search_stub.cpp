@@ -127,4 +127,5 @@ int gk_compat_index(gk_ctx*, gk_tab*, gk_dptr, int64_t, gk_dptr, int32_t, int32_
                     gk_dptr, gk_dptr, int64_t, gk_dptr) { return GK_ERR_NO_DEVICE; }
 int gk_lut_known(gk_lut*, int32_t* n) { *n = 0; return GK_OK; }
 int gk_lut_resolve(gk_lut*, gk_log10_fn, int32_t*, int32_t*, int32_t*) { return GK_ERR_NO_DEVICE; }
+int gk_lut_resolve_stored(gk_lut*, gk_log10_fn, int32_t*, int32_t*, int32_t*) { return GK_ERR_NO_DEVICE; }
 }

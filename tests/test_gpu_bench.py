@@ -1,6 +1,7 @@
 """bench.py run the way the driver runs it (a child process, small sample): the one JSON line and its contract -- the
-metric of BASELINE.json, whole-job throughput from records resident in HBM, the second leg from host memory, the roofline
-of the dominant kernel measured in the same run, the host budget -- and the multi-rank form on one GPU."""
+metric of BASELINE.json, whole-job throughput from records in pinned host memory, the legs from records
+resident in HBM beside it, the median of the timed legs, the roofline of the dominant kernel measured in the same run, the
+host budget, what the value table did -- and the multi-rank form on one GPU."""
 import json
 import os
 import subprocess
@@ -24,33 +25,50 @@ def _run(args, env=None, timeout=600):
 def test_one_gpu_line_keeps_the_contract(device):
     d = _run(["--gpus", "1", "--steps", "6", "--warmup", "2", "--pairs", "20000", "--cpu-pairs", "0", "--serial-steps", "1"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "host", "pcie_inclusive"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "host", "hbm_resident", "legs",
+                "value_table_new_per_sample", "samples_repeated_pass", "search_steps"):
         assert key in d, key
     assert d["unit"] == "reads/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
-    assert d["config"]["inputs"] == "hbm" and d["config"]["pairs_per_sample"] == 20000
+    assert d["config"]["inputs"] == "host" and d["config"]["pairs_per_sample"] == 20000
     assert abs(d["value"] - 2 * 20000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9      # whole-job reads per second
+    # three timed legs, the median one is the line's
+    assert len(d["legs"]) == 3 and sorted(x["ms_per_step"] for x in d["legs"])[1] == pytest.approx(d["ms_per_step"])
+    # 8 distinct samples, 2 of them warmed up: the first leg meets 4 new ones, the later legs none
+    assert d["distinct_samples"] == 8 and d["legs"][0]["value_table_new"] >= 0 and d["legs"][2]["value_table_new"] == 0
+    assert d["legs"][2]["samples_repeated_pass"] == 0
     r = d["roofline"]
     assert r["bound"] in ("hbm", "valu") and r["unit"] and r["peak"] > 0 and r["achieved"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert "traffic" in r and "kernel" in r and r["avg_launch_ms"] > 0
     h = d["host"]
     assert h["host_core_s_per_step"] > 0 and h["worker_processes"] == 1 and h["sample_lanes"] == 3
-    p = d["pcie_inclusive"]
-    assert p["unit"] == "reads/s" and p["value"] > 0 and p["ms_per_step"] > 0
+    p = d["hbm_resident"]
+    assert p["unit"] == "reads/s" and p["value"] > 0 and p["ms_per_step"] > 0 and len(p["legs"]) == 3
     assert d["search_steps"]["bounded"] > 0
 
 
-def test_steps_from_host_memory_and_two_worker_processes(device):
-    d = _run(["--steps", "4", "--warmup", "2", "--pairs", "20000", "--cpu-pairs", "0", "--serial-steps", "0", "--inputs", "host"],
-             env={"GK_PROCS_PER_GPU": "2"})
-    assert d["config"]["inputs"] == "host" and "pcie_inclusive" not in d
+def test_steps_from_hbm_and_two_worker_processes(device):
+    d = _run(["--steps", "4", "--warmup", "2", "--pairs", "20000", "--cpu-pairs", "0", "--serial-steps", "0", "--inputs", "hbm",
+              "--one-kind", "--legs", "1"], env={"GK_PROCS_PER_GPU": "2"})
+    assert d["config"]["inputs"] == "hbm" and "pcie_inclusive" not in d and "hbm_resident" not in d and len(d["legs"]) == 1
     assert d["host"]["worker_processes"] == 2 and d["host"]["sample_lanes"] == 2 and d["value"] > 0
 
 
 def test_two_ranks_on_one_gpu_through_the_file_backend(device):
     d = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--pairs", "20000", "--cpu-pairs", "0", "--serial-steps", "0",
-              "--no-pcie-leg"], env={"GK_BENCH_BACKEND": "file"})
-    assert d["n_gpus"] == 2 and d["config"]["rank_barrier"] == "file" and "pcie_inclusive" not in d
+              "--one-kind"], env={"GK_BENCH_BACKEND": "file"})
+    assert d["n_gpus"] == 2 and d["config"]["rank_barrier"] == "file" and "hbm_resident" not in d
     assert abs(d["value"] - 2 * 2 * 20000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9       # both ranks' reads / the slower rank's time
+
+
+def test_cli_typing_stage_keeps_pace_with_the_bench(device):
+    """The command line's typing stage (main.alleleTyping: copy-number files, typing lanes, the two files per sample) on 12
+    configs[1] samples against the bench's step on the same samples in the same process: one code path
+    (cohort.SampleTyper), so the CLI may cost at most 1.3 x the measured step."""
+    d = _run(["--steps", "12", "--warmup", "4", "--distinct", "4", "--cpu-pairs", "0", "--serial-steps", "0", "--legs", "1",
+              "--cli-samples", "12"], timeout=900)
+    c = d["cli_typing_stage"]
+    assert c["samples"] == 12 and c["ms_per_sample"] > 0
+    assert c["ms_per_sample"] <= 1.3 * d["ms_per_step"], (c["ms_per_sample"], d["ms_per_step"])

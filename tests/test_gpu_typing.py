@@ -278,3 +278,36 @@ def test_forms_of_the_sample_search_and_of_the_factor_agree(device, small_case, 
             for x, y in zip(got[gene], steps):
                 for f in ("value", "value_sum_indv", "allele_id", "fraction"):
                     assert np.array_equal(np.asarray(getattr(x, f)), np.asarray(getattr(y, f))), (name, gene, f)
+
+
+@pytest.mark.gpu
+def test_new_values_settle_per_gene_and_give_the_same_bits(device, small_case, monkeypatch):
+    """A cohort of DISTINCT samples: every sample may bring products the log10 value table has not seen.  The pipelined
+    gene loop settles them per gene -- a compatibility kernel that stored NaN says so in its gene's flag word, only that
+    gene's table is written again (`tables_rewritten`) -- and every field of every copy-number step equals the lock-step
+    form's and the oracle's.  The samples grow (more pairs, more errors), so later ones do bring new products."""
+    from kir_graph_amd.hisat2 import extractVariant, pairLines
+    monkeypatch.setenv("GK_SEARCH", "bound")
+    monkeypatch.delenv("GK_SAMPLE_PIPELINE", raising=False)
+    sidx, gidx, _ = small_case
+    rewritten, n_genes = [], []
+    for k, (pairs, err) in enumerate(((1500, 0.0), (2500, 0.001), (4000, 0.004), (4000, 0.004), (6000, 0.01))):
+        sample = synth.makeSample(sidx, seed=4000 + (k if k != 3 else 2), n_pairs=pairs, err_rate=err)
+        lines = synth.toSamLines(sample)
+        data = extractVariant(pairLines(lines), gidx, dev=device)
+        gene_cn = {g: ((k + i) % 3) + 1 for i, g in enumerate(sidx.genes)}
+        typer = selectKirTypingModel("full", data, top_n=600, variant_correction=True)
+        assert typer._wholeSample()
+        calls = typer.typing(gene_cn)
+        rewritten.append(typer.tables_rewritten)
+        n_genes.append(sum(1 for steps in typer._result.values() if steps))
+        cpu = oty.makeTyper("full", ot.tabulateLines(lines, gidx.variants), top_n=600, variant_correction=True)
+        assert calls == cpu.typing(gene_cn), k
+        for gene, steps in cpu.results.items():
+            assert len(typer._result[gene]) == len(steps), (k, gene)
+            for a, b in zip(typer._result[gene], steps):
+                same_result(a, b)
+        data.tab.close()
+    # sample 3 repeats sample 2: nothing new, no table written twice; no sample rewrites a table more than a few times
+    assert rewritten[3] == 0, rewritten
+    assert all(r <= 3 * g for r, g in zip(rewritten, n_genes)), (rewritten, n_genes)
