@@ -227,8 +227,10 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
         note("type", k, t0)
         if stats is not None:
             stats["samples"] = stats.get("samples", 0) + 1
-            stats["samples_repeated_pass"] = stats.get("samples_repeated_pass", 0) + (1 if getattr(typer, "tables_rewritten", 0) else 0)
+            again = getattr(typer, "tables_rewritten", 0) + getattr(typer, "tables_patched", 0)
+            stats["samples_repeated_pass"] = stats.get("samples_repeated_pass", 0) + (1 if again else 0)
             stats["tables_rewritten"] = stats.get("tables_rewritten", 0) + getattr(typer, "tables_rewritten", 0)
+            stats["tables_patched"] = stats.get("tables_patched", 0) + getattr(typer, "tables_patched", 0)
         return calls, warn, n_valid, typer
 
     items = range(items) if isinstance(items, int) else items
@@ -524,7 +526,7 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
         for kind, rows in other.get("legs", {}).items():
             for mine, theirs in zip(legs.get(kind, []), rows):
                 mine["cpu_s"] += theirs["cpu_s"]
-                for key in ("samples", "samples_repeated_pass", "tables_rewritten", "value_table_new"):
+                for key in ("samples", "samples_repeated_pass", "tables_rewritten", "tables_patched", "value_table_new"):
                     mine[key] = mine.get(key, 0) + theirs.get(key, 0)
     return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm, "n_values": n_values,
             "search_steps": dict(SEARCH_STATS), "others": others, "cli_stage": cli_stage}
@@ -737,6 +739,7 @@ def main():
                                              "GK_SAMPLE_LANES=1 GK_SAMPLE_STREAMS=1 GK_PREFETCH=0): kernels run back to back",
                                      "kernels": table}
             out["roofline"] = roofmodel.dominant(s_prof, serial["call_log"])
+            out["roofline"]["step"] = roofmodel.stepRoofline(serial["call_log"], steps, ms_per_step)
         else:
             out["roofline"] = roofmodel.dominant(prof, call_log)
             out["roofline"]["note_basis"] = "launch times taken inside the timed region (other workers share the GPU)"
@@ -757,12 +760,14 @@ def main():
         def leg_rows(kind):
             """Every timed leg of a kind, in the order they ran: what a NEW sample costs shows in the first leg of a run
             with --distinct >= steps + warmup (value_table_new > 0 there, 0 in the later legs, which meet the same samples
-            again); samples_repeated_pass = samples of the leg that had a compatibility table written twice because
-            they brought a product without a log10, tables_rewritten = how many tables that was."""
+            again); samples_repeated_pass = samples of the leg that brought a product without a log10, tables_patched = the
+            gene tables that got those values patched in (gk_compat_patch: one pass over the table), tables_rewritten = the
+            ones written again by the compatibility kernel."""
             return [{"ms_per_step": 1e3 * r["elapsed"] / args.steps, "value_table_new": r.get("value_table_new", 0),
                      "value_table_new_per_sample": r.get("value_table_new", 0) / max(args.steps, 1),
                      "samples_repeated_pass": r.get("samples_repeated_pass", 0),
-                     "tables_rewritten": r.get("tables_rewritten", 0)} for r in legs[kind]]
+                     "tables_rewritten": r.get("tables_rewritten", 0),
+                     "tables_patched": r.get("tables_patched", 0)} for r in legs[kind]]
 
         out["legs"] = leg_rows(args.inputs)
         first = legs[args.inputs][0]

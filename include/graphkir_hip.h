@@ -275,8 +275,7 @@ int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
  * gk_compat_log_miss = gk_compat_log that also writes the mismatch counts miss[r, a] as a u8 table
  *   d_miss8 [n_allele][ldm] (ldm a multiple of 64 >= n_rows, rows past the end zero), derived from the
  *   log-likelihoods; *d_flags (uint32) gets bit 0 when some count is >= 100 (products near underflow: the caller
- *   must then use gk_maxsum for this gene) and bit 2 when some product had no log10 in the value table yet (NaN was
- *   stored for it: resolve the table and write this gene's table again -- the other genes' tables are not concerned).
+ *   must then use gk_maxsum for this gene); bits 2 and 3: see gk_compat_patch.
  * gk_miss_colsum: d_msum uint32 [n_cols] = column sums of that table.
  * gk_bound_step: M[t, j] = sum_r min(miss[r, cols[j]], min_k miss[r, ids[t*c_prev + k]]) for every candidate,
  *   restricted to first[t*n_cols + j] != 0 (first occurrences of an allele multiset, uniqueAllele 456-476);
@@ -290,6 +289,14 @@ int gk_compat_log_miss(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows,
                        int32_t vbeg, int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele,
                        int32_t keep_empty, gk_lut* lut, gk_dptr d_log, gk_dptr d_miss8, int64_t ldm, gk_dptr d_flags);
 int gk_miss_colsum(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int32_t n_cols, gk_dptr d_msum);
+/* Bits 2 and 3 of *d_flags after gk_compat_log_miss: bit 2 = some product had no log10 in the value table yet; its entry
+ * of d_log holds the PRODUCT itself (strictly positive, which no log10 of a probability is) until gk_compat_patch, after
+ * the table has been resolved (gk_lut_resolve*), puts the log10 and the mismatch byte there -- one pass over this gene's
+ * table instead of the kernel that made it, the tables of the other genes are not concerned.  Bit 3 = such a product was
+ * +0.0 and could not mark itself (NaN stored): write the table again.  gk_compat_patch clears *d_flags first; bit 2
+ * comes back when some value is still undefined, bit 0 as above (typing_mulit_allele.py:263, 340-381). */
+int gk_compat_patch(gk_ctx* ctx, gk_lut* lut, gk_dptr d_log, int64_t n_rows, int32_t n_allele, gk_dptr d_miss8,
+                    int64_t ldm, gk_dptr d_flags);
 /* The index form of gk_compat_log_miss (typing_mulit_allele.py:263, 340-381): d_lidx uint16 [n_allele][ldm] = dense index
  * of every log-likelihood in the value table (0xFFFF while a product's log10 is undefined: resolve and call again);
  * *d_flags bit 1 = the table holds more than 65535 values (use gk_compat_log_miss).  gk_expand_index writes the float64
@@ -345,7 +352,7 @@ typedef struct gk_gene_job {
   int32_t words, n_allele;
   int32_t n_steps, top_n;
   int32_t bound_ok, passes; /* out */
-  int32_t indexed, rsv;     /* out: d_lidx holds the table (0: the value table outgrew 16-bit indices, the call worked on a float64 table of its own) */
+  int32_t indexed, patches; /* out: d_lidx holds the table (0: the value table outgrew 16-bit indices, the call worked on a float64 table of its own); how often the table was patched (gk_compat_patch) */
 } gk_gene_job;
 int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut,
                      gk_gene_job* jobs, int32_t n_jobs, gk_argsort_fn argsort, gk_log10_fn log10_fn, gk_search** out);

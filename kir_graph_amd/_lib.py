@@ -56,7 +56,7 @@ class GeneJob(C.Structure):
         ("d_lidx", C.c_uint64),
         ("vbeg", C.c_int32), ("vend", C.c_int32), ("words", C.c_int32), ("n_allele", C.c_int32),
         ("n_steps", C.c_int32), ("top_n", C.c_int32), ("bound_ok", C.c_int32), ("passes", C.c_int32),
-        ("indexed", C.c_int32), ("rsv", C.c_int32),
+        ("indexed", C.c_int32), ("patches", C.c_int32),
     ]
 
 
@@ -190,6 +190,7 @@ _SIGS = {
                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gk_lut_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32)]),
+    "gk_compat_patch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_uint64, C.c_int64, C.c_uint64]),
     "gk_lut_resolve_stored": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32)]),
     "gk_lut_known": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),

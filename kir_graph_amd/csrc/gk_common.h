@@ -56,7 +56,10 @@ struct gk_ctx {
   std::vector<hipEvent_t> mark_pool;
   // reduction-tree programs of gk_search.hip, one device block per row count (they depend on nothing else)
   std::map<int64_t, void*> tree_programs;
-  struct TreeHead { size_t o_leaf, o_span, o_cs, o_co, o_top; int n_spans, n_chunks; };
+  struct TreeHead {
+    size_t o_leaf, o_span, o_cs, o_co, o_top, o_flat, o_cl, o_clo, o_lops, o_unit, o_zero;
+    int n_spans, n_chunks, n_leaves, max_chunk_leaves;
+  };
   std::map<int64_t, TreeHead> tree_heads;
   // caching allocator state (gk_pool_*)
   std::mutex pool_mutex;   // frees may come from another host thread (Python GC)
@@ -74,7 +77,7 @@ struct gk_ctx {
 enum {
   GK_K_TAB_COUNT = 0, GK_K_TAB_EMIT, GK_K_SCAN, GK_K_NOVEL, GK_K_COUNT_IDS, GK_K_SELECT, GK_K_COMPAT,
   GK_K_LUT_COLLECT, GK_K_LUT_APPLY, GK_K_MAXSUM, GK_K_COMBINE, GK_K_FRACTION, GK_K_SETMAX, GK_K_EM_SETS,
-  GK_K_EM_RUN, GK_K_SETMIN, GK_K_MINSUM, GK_K_SELECT_CUT, GK_K_N
+  GK_K_EM_RUN, GK_K_SETMIN, GK_K_MINSUM, GK_K_SELECT_CUT, GK_K_COMPAT_PATCH, GK_K_N
 };
 // Per-kernel timing.  GK_PROF brackets a launch with two events recorded on the stream (cheap; under
 // multi-stream load the span also counts the time the kernel waits for CUs that other streams are using).

@@ -211,6 +211,8 @@ int gk_compat_log(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
                   int32_t vend, gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty, gk_lut* lut,
                   gk_dptr d_log);
 int gk_miss_colsum(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int32_t n_cols, gk_dptr d_msum);
+int gk_compat_patch(gk_ctx* ctx, gk_lut* lut, gk_dptr d_log, int64_t n_rows, int32_t n_allele, gk_dptr d_miss8, int64_t ldm,
+                    gk_dptr d_flags);
 int gk_compat_index(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_dptr d_vflag, int32_t vbeg, int32_t vend,
                     gk_dptr d_mask, int32_t words, int32_t n_allele, int32_t keep_empty, gk_lut* lut, gk_dptr d_lidx,
                     gk_dptr d_miss8, int64_t ldm, gk_dptr d_flags);
@@ -667,6 +669,7 @@ int sample_search_lockstep(gk_ctx* ctx, const std::vector<gk_ctx*>& cx, gk_tab* 
   // product says so in its gene's flag word (bit 2), so only THAT gene's table is written again; a job without a flag
   // word (no mismatch table) is judged by the table's growth since its launch, as before.
   std::vector<int> dirty(live);
+  std::vector<uint32_t> sticky((size_t)n_jobs, 0);      // bit 0 of a gene's flag word survives its patches
   bool settled = false;
   for (int pass = 0; pass < 64 && !settled; ++pass) {
     int32_t known_at_launch = 0;
@@ -675,7 +678,19 @@ int sample_search_lockstep(gk_ctx* ctx, const std::vector<gk_ctx*>& cx, gk_tab* 
     for (int i : dirty) {
       gk_gene_job& j = jobs[i];
       gk_ctx* const gc = ctx_of[i];
+      if (pass > 0 && j.d_L && j.d_miss8 && j.d_flags && (flags[i] & 12u) == 4u) {
+        // the entries that hold their product get their log10 (gk_compat_patch); everything else of the table stands
+        j.patches++;
+        sticky[i] |= flags[i] & 1u;
+        rc = gk_compat_patch(gc, lut, j.d_L, j.n_rows, j.n_allele, j.d_miss8, j.ldm, j.d_flags);
+        if (rc == GK_OK) rc = gk_miss_colsum(gc, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
+        if (rc == GK_OK && gk_fetch_queue(gc, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
+        if (rc == GK_OK) rc = start_search(i, j.d_L, false);
+        if (rc) return quit(rc);
+        continue;
+      }
       j.passes++;
+      sticky[i] = 0;
       if (j.d_lidx && !j.d_L) {
         rc = gk_compat_index(gc, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
                              j.d_lidx, j.d_miss8, j.ldm, j.d_flags);
@@ -745,7 +760,7 @@ int sample_search_lockstep(gk_ctx* ctx, const std::vector<gk_ctx*>& cx, gk_tab* 
   bool late = false;
   for (int i : live) {
     gk_gene_job& j = jobs[i];
-    j.bound_ok = (j.d_miss8 && (flags[i] & 1u) == 0) ? 1 : 0;
+    j.bound_ok = (j.d_miss8 && ((flags[i] | sticky[i]) & 1u) == 0) ? 1 : 0;
     if (!sums_queued[i]) {
       rc = start_search(i, own_L[i] ? gk_addr(own_L[i]) : j.d_L, j.indexed != 0);
       if (rc) return fail(rc);
@@ -818,11 +833,20 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
   };
   // gene i's table, mismatch sums, flag word and column sums (right behind the kernel that wrote the table: it is still
   // in the Infinity Cache), then a mark
-  auto write_table = [&](int i) -> int {
+  std::vector<uint32_t> sticky((size_t)n_jobs, 0);      // bit 0 of a gene's flag word survives its patches
+  auto write_table = [&](int i, bool patch) -> int {
     gk_gene_job& j = jobs[i];
-    j.passes++;
-    int rc = gk_compat_log_miss(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
-                                j.d_L, j.d_miss8, j.ldm, j.d_flags);
+    int rc;
+    if (patch) {      // only the entries that hold their product are touched (gk_compat_patch)
+      j.patches++;
+      sticky[i] |= flags[i] & 1u;
+      rc = gk_compat_patch(ctx, lut, j.d_L, j.n_rows, j.n_allele, j.d_miss8, j.ldm, j.d_flags);
+    } else {
+      j.passes++;
+      sticky[i] = 0;
+      rc = gk_compat_log_miss(ctx, tab, j.d_rows, j.n_rows, d_vflag, j.vbeg, j.vend, j.d_mask, j.words, j.n_allele, 0, lut,
+                              j.d_L, j.d_miss8, j.ldm, j.d_flags);
+    }
     if (rc == GK_OK) rc = gk_miss_colsum(ctx, j.d_miss8, j.ldm, j.n_allele, j.d_msum);
     if (rc == GK_OK && gk_fetch_queue(ctx, &flags[i], gk_ptr<void>(j.d_flags), sizeof(uint32_t)) != hipSuccess) rc = GK_ERR_HIP;
     if (rc) return rc;
@@ -838,7 +862,7 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
   };
   int rc = GK_OK;
   for (int i : live) {
-    rc = write_table(i);
+    rc = write_table(i, false);
     if (rc) return fail(rc);
   }
 
@@ -872,20 +896,21 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
     switch (it.stage) {
       case kTable:
         if (flags[it.gene] & 4u) {
-          // the kernel met a product without a log10 and stored NaN for it (a sample that brings new values): define what
-          // is stored by now -- this gene's kernel has completed, so its own keys are -- and write THIS gene's table again,
-          // behind the stages of the other genes, whose searches go on.  A key that a kernel still running on another
+          // the kernel met a product without a log10 and left the product in its place (a sample that brings new values):
+          // define what is stored by now -- this gene's kernel has completed, so its own keys are -- and patch THIS gene's
+          // table (gk_compat_patch: one pass over it; the whole kernel again only for a product that could not mark
+          // itself), behind the stages of the other genes, whose searches go on.  A key that a kernel still running on another
           // stream has claimed but not stored ends the resolver's batch; after a few fruitless passes the device is drained.
-          if (j.passes >= 64) {
+          if (j.passes + j.patches >= 64) {
             gk_set_error("log10 value table did not settle");
             rc = GK_ERR_ASSERT;
             break;
           }
-          rc = (j.passes < 4 ? gk_lut_resolve_stored : gk_lut_resolve)(lut, log10_fn, nullptr, nullptr, nullptr);
-          if (rc == GK_OK) rc = write_table(it.gene);
+          rc = (j.passes + j.patches < 4 ? gk_lut_resolve_stored : gk_lut_resolve)(lut, log10_fn, nullptr, nullptr, nullptr);
+          if (rc == GK_OK) rc = write_table(it.gene, (flags[it.gene] & 8u) == 0);
           break;
         }
-        j.bound_ok = (flags[it.gene] & 1u) == 0 ? 1 : 0;
+        j.bound_ok = ((flags[it.gene] | sticky[it.gene]) & 1u) == 0 ? 1 : 0;
         if (!j.bound_ok) g.bound = false;      // a mismatch count near the underflow range / a very long row: exact steps
         g.colsum_collect();
         rc = g.first_step();
@@ -939,6 +964,7 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
     j.bound_ok = 0;
     j.passes = 0;
     j.indexed = 0;
+    j.patches = 0;
     GK_REQUIRE(j.n_rows >= 0 && j.n_allele >= 0 && j.n_steps >= 1 && j.top_n >= 1, "bad gene job");
     if (j.n_rows > 0 && j.n_allele > 0) {
       GK_REQUIRE(j.d_rows && (j.d_L || j.d_lidx) && j.d_mask && j.words >= 1, "gene job without tables");

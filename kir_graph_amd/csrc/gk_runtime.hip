@@ -382,7 +382,7 @@ void gk_prof_end(gk_ctx* ctx) {
 static const char* kKernelNames[GK_K_N] = {
     "tab_count", "tab_emit", "scan", "novel_rank", "count_ids", "select", "compat_kernel", "lut_collect",
     "lut_apply", "maxsum_chunks", "combine_chunks", "fraction_chunks", "setmax_kernel", "em_sets_kernel", "em_kernel",
-    "setmin_u8", "minsum_sad", "select_cut"};
+    "setmin_u8", "minsum_sad", "select_cut", "patch_pending"};
 
 extern "C" int gk_prof_enable(gk_ctx* ctx, int on) {
   gk_bind(ctx);

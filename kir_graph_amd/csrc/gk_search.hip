@@ -492,6 +492,151 @@ __global__ __launch_bounds__(kThreads) void fraction_chunks(TableView<TL> L, int
   }
 }
 
+// ---- the same sums LEAF BY LEAF (typing_mulit_allele.py:540-542 for one set, 575-580): every column through LDS once.
+// fraction_chunks gives a workgroup 32 sets and stages THEIR columns; the ~600 sets a step selects touch every allele of
+// the gene, so the table was read 2.85 times through L2 (6.2 GB per configs[1] sample).  Here a workgroup of 1024 threads
+// owns ONE leaf of numpy's tree (<= 128 consecutive reads) and ALL sets: the leaf's rows of every column are staged
+// through LDS in blocks of 32 rows (the next block's loads are in flight while the current one is summed), each of the
+// 128 eight-lane groups carries the accumulators of ~5 sets (lane j = numpy's strided accumulator j), and the leaf's
+// sums go to `partial[leaf][set][share..., value]`.  fold_leaves then adds the leaves of a chunk in the order of numpy's
+// pairwise recursion and combine_chunks the chunks in sequence -- the same tree as fraction_chunks walks on its lane
+// stack, so the same bits.  HBM traffic = the table once.
+struct LeafAbs { int64_t row0; int32_t len, chunk; };
+constexpr int kLeafThreads = 1024;
+constexpr int kLeafGroups = kLeafThreads / 8;        // 128 lane groups = sets in flight per "slot"
+constexpr int kLeafSlots = 6;                        // sets per lane group at most: up to 768 sets per launch
+constexpr int kStageRows = 32;
+constexpr int kStageLd = kStageRows + 1;             // odd stride: the 8 groups of a wavefront read different banks
+constexpr int kStagePrefetch = 8;                    // staged values a thread carries in registers: <= 256 columns
+constexpr int kFoldOut = 64;                         // outputs per workgroup of fold_leaves
+constexpr int kMaxChunkLeaves = kChunkRows / 64;     // a leaf of a split node has >= 64 rows
+
+template <int kC, int kS>
+__global__ __launch_bounds__(kLeafThreads) void setsum_leaves(const double* __restrict__ L, int64_t ld, int n_cols,
+                                                              const int32_t* __restrict__ ids, int n_sets,
+                                                              int n_sets_all, const LeafAbs* __restrict__ leaves,
+                                                              double* __restrict__ partial) {
+  // ids / n_sets: this launch's batch of sets (partial already points at its first set); n_sets_all: sets per leaf row
+  extern __shared__ double sbuf[];   // [n_cols][kStageLd]
+  constexpr int kO = kC + 1;
+  const int tid = threadIdx.x, j = tid & 7, g = tid >> 3;
+  int loc[kS][kC];
+  double acc[kS][kO];
+#pragma unroll
+  for (int s = 0; s < kS; ++s) {
+    const int k = g + kLeafGroups * s;
+#pragma unroll
+    for (int q = 0; q < kC; ++q) loc[s][q] = (k < n_sets ? ids[k * kC + q] : 0) * kStageLd;
+#pragma unroll
+    for (int q = 0; q < kO; ++q) acc[s][q] = 0.0;
+  }
+  const LeafAbs leaf = leaves[blockIdx.x];
+  const int len = leaf.len;
+  const int n8 = len < 8 ? 0 : len - (len & 7);      // rows summed by the 8 strided accumulators
+  const double* const base = L + leaf.row0;
+  const int n_elem = n_cols * kStageRows;
+  const bool carried = n_elem <= kStagePrefetch * kLeafThreads;   // the next block rides in registers
+
+  // set s at staged row r: shares of the row's maximum (1 / number of alleles that reach it) + the maximum itself
+  auto add_terms = [&](int r) {
+#pragma unroll
+    for (int s = 0; s < kS; ++s) {
+      double v[kC];
+      double best = -__builtin_huge_val();
+#pragma unroll
+      for (int q = 0; q < kC; ++q) {
+        v[q] = sbuf[loc[s][q] + r];
+        best = vmax(best, v[q]);
+      }
+      int cnt = 0;
+#pragma unroll
+      for (int q = 0; q < kC; ++q) cnt += v[q] == best ? 1 : 0;
+      double share = 1.0;   // exact IEEE quotients, as numpy's bool / int
+#pragma unroll
+      for (int q = 2; q <= kC; ++q) share = cnt == q ? (1.0 / (double)q) : share;
+#pragma unroll
+      for (int q = 0; q < kC; ++q) acc[s][q] += v[q] == best ? share : 0.0;   // 0.0 + x == x: first term exact
+      acc[s][kC] += best;
+    }
+  };
+
+  double pre[kStagePrefetch];
+  auto fetch = [&](int b0, int rows_in) {
+#pragma unroll
+    for (int u = 0; u < kStagePrefetch; ++u) {
+      const int idx = tid + u * kLeafThreads;
+      const int col = idx >> 5, r = idx & (kStageRows - 1);
+      pre[u] = (idx < n_elem && r < rows_in) ? base[(int64_t)col * ld + b0 + r] : 0.0;
+    }
+  };
+  const int n_stage = (n8 + kStageRows - 1) / kStageRows;
+  if (carried && n_stage) fetch(0, min(kStageRows, n8));
+  for (int sb = 0; sb < n_stage; ++sb) {
+    const int b0 = sb * kStageRows;
+    const int rows_in = min(kStageRows, n8 - b0);
+    __syncthreads();                       // the readers of the block before this one are done
+    if (carried) {
+#pragma unroll
+      for (int u = 0; u < kStagePrefetch; ++u) {
+        const int idx = tid + u * kLeafThreads;
+        if (idx < n_elem) sbuf[(idx >> 5) * kStageLd + (idx & (kStageRows - 1))] = pre[u];
+      }
+    } else {
+      for (int idx = tid; idx < n_elem; idx += kLeafThreads) {
+        const int col = idx >> 5, r = idx & (kStageRows - 1);
+        if (r < rows_in) sbuf[col * kStageLd + r] = base[(int64_t)col * ld + b0 + r];
+      }
+    }
+    __syncthreads();
+    if (carried && sb + 1 < n_stage) fetch(b0 + kStageRows, min(kStageRows, n8 - b0 - kStageRows));
+    for (int r = j; r < rows_in; r += 8) add_terms(r);
+  }
+  if (n8) {
+#pragma unroll
+    for (int s = 0; s < kS; ++s)
+#pragma unroll
+      for (int q = 0; q < kO; ++q) acc[s][q] = group_sum8(acc[s][q]);
+  }
+  if (len > n8) {                          // sequential tail rows n8 .. len (all rows of a leaf shorter than 8)
+    __syncthreads();
+    for (int idx = tid; idx < n_cols * 8; idx += kLeafThreads) {
+      const int col = idx >> 3, t = idx & 7;
+      if (n8 + t < len) sbuf[col * kStageLd + t] = base[(int64_t)col * ld + n8 + t];
+    }
+    __syncthreads();
+    for (int r = 0; r < len - n8; ++r) add_terms(r);   // same in every lane
+  }
+  if (j == 0) {
+#pragma unroll
+    for (int s = 0; s < kS; ++s) {
+      const int k = g + kLeafGroups * s;
+      if (k < n_sets) {
+        double* const dst = partial + ((int64_t)blockIdx.x * n_sets_all + k) * kO;
+#pragma unroll
+        for (int q = 0; q < kO; ++q) dst[q] = acc[s][q];
+      }
+    }
+  }
+}
+
+// the leaves of chunk blockIdx.y, added up in the order of numpy's pairwise recursion (lops: dst += src over the
+// chunk's leaves, post-order); a thread owns one output, its leaf sums sit in its own LDS column (all loads in flight)
+__global__ __launch_bounds__(kFoldOut) void fold_leaves(const double* __restrict__ partial, int64_t n_out,
+                                                        const int32_t* __restrict__ chunk_leaf0,
+                                                        const int32_t* __restrict__ chunk_lop0,
+                                                        const TopOp* __restrict__ lops, double* __restrict__ chunk_sums) {
+  extern __shared__ double lsum[];   // [leaf of the chunk][kFoldOut]
+  const int t = threadIdx.x, q = blockIdx.y;
+  const int64_t o = (int64_t)blockIdx.x * kFoldOut + t;
+  const int l0 = chunk_leaf0[q], n_l = chunk_leaf0[q + 1] - l0;
+  if (o < n_out) {
+#pragma unroll 8
+    for (int l = 0; l < n_l; ++l) lsum[l * kFoldOut + t] = partial[(int64_t)(l0 + l) * n_out + o];
+  }
+  for (int k = chunk_lop0[q]; k < chunk_lop0[q + 1]; ++k) lsum[lops[k].dst * kFoldOut + t] += lsum[lops[k].src * kFoldOut + t];
+  if (o < n_out) chunk_sums[(int64_t)q * n_out + o] = lsum[t];
+}
+
 // Column sums log_probs[:, cols].sum(axis=0) (typing_mulit_allele.py:514) with numpy's tree.  An 8-lane group
 // owns one column over one span (lane j = numpy's strided accumulator j, stack slot j), so a workgroup of 256 threads
 // sums 32 columns.  No LDS staging: every element is read exactly once, straight from HBM -- the 8 lanes of a group
@@ -566,7 +711,27 @@ struct Program {
   std::vector<Span> spans;
   std::vector<int32_t> chunk_span0, chunk_op0;
   std::vector<TopOp> top;
+  // the same tree leaf by leaf (setsum_leaves / fold_leaves): every leaf with its first row, the leaves of a chunk,
+  // and per chunk the additions "leaf dst += leaf src" (chunk-relative) in post-order
+  std::vector<LeafAbs> flat;
+  std::vector<int32_t> chunk_leaf0, chunk_lop0;
+  std::vector<TopOp> lops;
+  std::vector<int32_t> unit0, zero0;      // combine_chunks over one sum per chunk: [0, 1, 2, ...] and all zeros
 };
+
+// returns the (chunk-relative) leaf that holds the node's sum
+int fold_nodes(Program& p, int chunk, int64_t chunk_row0, int start, int n, int first_leaf) {
+  if (n <= kBlockRows) {
+    p.flat.push_back(LeafAbs{chunk_row0 + start, n, chunk});
+    return (int)p.flat.size() - 1 - first_leaf;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  const int a = fold_nodes(p, chunk, chunk_row0, start, n2, first_leaf);
+  const int b = fold_nodes(p, chunk, chunk_row0, start + n2, n - n2, first_leaf);
+  p.lops.push_back(TopOp{a, b});
+  return a;
+}
 
 // leaves of a span in post-order; a leaf that completes right sub-trees folds them immediately
 void span_leaves(int start, int n, int slot, std::vector<Leaf>& out) {
@@ -619,9 +784,18 @@ void build_program(int64_t n_rows, Program& p) {
     p.chunk_span0.push_back((int32_t)p.spans.size());
     p.chunk_op0.push_back((int32_t)p.top.size());
     chunk_nodes(p, q, row0, 0, n, (int)p.spans.size());
+    p.chunk_leaf0.push_back((int32_t)p.flat.size());
+    p.chunk_lop0.push_back((int32_t)p.lops.size());
+    fold_nodes(p, q, row0, 0, n, (int)p.flat.size());
+    p.unit0.push_back(q);
+    p.zero0.push_back(0);
   }
   p.chunk_span0.push_back((int32_t)p.spans.size());
   p.chunk_op0.push_back((int32_t)p.top.size());
+  p.chunk_leaf0.push_back((int32_t)p.flat.size());
+  p.chunk_lop0.push_back((int32_t)p.lops.size());
+  p.unit0.push_back(n_chunks);
+  p.zero0.push_back(0);
 }
 
 struct DeviceProgram {
@@ -632,6 +806,10 @@ struct DeviceProgram {
   TopOp* top = nullptr;
   int32_t *ids = nullptr, *cols = nullptr;
   int n_spans = 0, n_chunks = 0;
+  LeafAbs* flat = nullptr;
+  int32_t *chunk_leaf0 = nullptr, *chunk_lop0 = nullptr, *unit0 = nullptr, *zero0 = nullptr;
+  TopOp* lops = nullptr;
+  int n_leaves = 0, max_chunk_leaves = 0;
 };
 
 template <typename T>
@@ -668,6 +846,17 @@ int upload_program(gk_ctx* ctx, int64_t n_rows, const int32_t* ids, size_t n_ids
     head.o_cs = put(buf, p.chunk_span0.data(), p.chunk_span0.size());
     head.o_co = put(buf, p.chunk_op0.data(), p.chunk_op0.size());
     head.o_top = put(buf, p.top.data(), p.top.size());
+    head.o_flat = put(buf, p.flat.data(), p.flat.size());
+    head.o_cl = put(buf, p.chunk_leaf0.data(), p.chunk_leaf0.size());
+    head.o_clo = put(buf, p.chunk_lop0.data(), p.chunk_lop0.size());
+    head.o_lops = put(buf, p.lops.data(), p.lops.size());
+    head.o_unit = put(buf, p.unit0.data(), p.unit0.size());
+    head.o_zero = put(buf, p.zero0.data(), p.zero0.size());
+    head.n_leaves = (int)p.flat.size();
+    head.max_chunk_leaves = 1;
+    for (size_t q = 0; q + 1 < p.chunk_leaf0.size(); ++q)
+      head.max_chunk_leaves = std::max(head.max_chunk_leaves, p.chunk_leaf0[q + 1] - p.chunk_leaf0[q]);
+    GK_REQUIRE(head.max_chunk_leaves <= kMaxChunkLeaves, "too many leaves in a chunk");
     head.n_spans = (int)p.spans.size();
     head.n_chunks = (int)p.chunk_span0.size() - 1;
     if (ctx->tree_programs.size() >= kMaxCachedPrograms) {   // every earlier call has synchronised: nothing is in flight
@@ -688,6 +877,14 @@ int upload_program(gk_ctx* ctx, int64_t n_rows, const int32_t* ids, size_t n_ids
   d.chunk_span0 = (int32_t*)(prog + head.o_cs);
   d.chunk_op0 = (int32_t*)(prog + head.o_co);
   d.top = (TopOp*)(prog + head.o_top);
+  d.flat = (LeafAbs*)(prog + head.o_flat);
+  d.chunk_leaf0 = (int32_t*)(prog + head.o_cl);
+  d.chunk_lop0 = (int32_t*)(prog + head.o_clo);
+  d.lops = (TopOp*)(prog + head.o_lops);
+  d.unit0 = (int32_t*)(prog + head.o_unit);
+  d.zero0 = (int32_t*)(prog + head.o_zero);
+  d.n_leaves = head.n_leaves;
+  d.max_chunk_leaves = head.max_chunk_leaves;
   d.n_spans = head.n_spans;
   d.n_chunks = head.n_chunks;
   // per-call parameters
@@ -847,19 +1044,104 @@ int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
 
 // ---------------------------------------------------------------------------------------------
 // the two halves of the set-share / column-sum calls (gk_calls.h)
+static int shares_leafwise(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32_t* ids, int32_t n_sets, int32_t c,
+                           int n_cols, size_t lds, GkSumCall& call) {
+  DeviceProgram dp;
+  int rc = upload_program(ctx, n_rows, ids, (size_t)n_sets * c, nullptr, 0, dp);
+  if (rc) return rc;
+  call.temps.push_back(dp.base);
+  hipStream_t st = ctx->stream;
+  const int per_set = c + 1;
+  const int64_t n_out = (int64_t)n_sets * per_set;
+  double *d_partial = nullptr, *d_chunk = nullptr, *d_out = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * dp.n_leaves * sizeof(double)));
+  call.temps.push_back(d_partial);
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_chunk, (size_t)n_out * dp.n_chunks * sizeof(double)));
+  call.temps.push_back(d_chunk);
+  GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_out * sizeof(double)));
+  call.temps.push_back(d_out);
+  // accumulators per lane group: (c + 1) float64 per set within 128 VGPRs -- 6 sets of 2 alleles, 4 of 3, 3 of 4; a
+  // selection beyond 128 x that many sets goes in batches (each batch streams the table once more)
+  const int max_slots = c == 2 ? 6 : c == 3 ? 4 : 3;
+  const dim3 grid((unsigned)dp.n_leaves);
+  for (int set0 = 0; set0 < n_sets; set0 += kLeafGroups * max_slots) {
+    const int n_here = std::min(n_sets - set0, kLeafGroups * max_slots);
+    const int slots = (n_here + kLeafGroups - 1) / kLeafGroups;
+#define GK_LEAF_GO(C, S)                                                                                                  \
+  {                                                                                                                       \
+    if (lds > 48 * 1024)                                                                                                  \
+      GK_HIP(hipFuncSetAttribute((const void*)setsum_leaves<C, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    GK_PROF(ctx, GK_K_FRACTION,                                                                                           \
+            GK_KERNEL((setsum_leaves<C, S>), grid, dim3(kLeafThreads), lds, st, gk_ptr<double>(L.d), L.ld, n_cols,         \
+                      dp.ids + (size_t)set0 * C, n_here, n_sets, dp.flat, d_partial + (size_t)set0 * (C + 1)));           \
+  }
+    if (c == 2) {
+      switch (slots) {
+        case 1: GK_LEAF_GO(2, 1); break;
+        case 2: GK_LEAF_GO(2, 2); break;
+        case 3: GK_LEAF_GO(2, 3); break;
+        case 4: GK_LEAF_GO(2, 4); break;
+        case 5: GK_LEAF_GO(2, 5); break;
+        default: GK_LEAF_GO(2, 6); break;
+      }
+    } else if (c == 3) {
+      switch (slots) {
+        case 1: GK_LEAF_GO(3, 1); break;
+        case 2: GK_LEAF_GO(3, 2); break;
+        case 3: GK_LEAF_GO(3, 3); break;
+        default: GK_LEAF_GO(3, 4); break;
+      }
+    } else {
+      switch (slots) {
+        case 1: GK_LEAF_GO(4, 1); break;
+        case 2: GK_LEAF_GO(4, 2); break;
+        default: GK_LEAF_GO(4, 3); break;
+      }
+    }
+#undef GK_LEAF_GO
+  }
+  const size_t fold_lds = (size_t)dp.max_chunk_leaves * kFoldOut * sizeof(double);
+  if (fold_lds > 48 * 1024)
+    GK_HIP(hipFuncSetAttribute((const void*)fold_leaves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds));
+  GK_PROF(ctx, GK_K_COMBINE,
+          GK_KERNEL(fold_leaves, dim3((unsigned)((n_out + kFoldOut - 1) / kFoldOut), (unsigned)dp.n_chunks), dim3(kFoldOut),
+                    fold_lds, st, d_partial, n_out, dp.chunk_leaf0, dp.chunk_lop0, dp.lops, d_chunk));
+  // the chunk sums in sequence (numpy's outer reduce loop); the shares are handed back undivided (collect divides)
+  GK_PROF(ctx, GK_K_COMBINE,
+          GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st, d_chunk,
+                    n_out, dp.n_chunks, dp.unit0, dp.zero0, dp.top, 0.0, d_out));
+  GK_HIP(hipGetLastError());
+  call.n_rows = n_rows;
+  call.n_sets = n_sets;
+  call.c = c;
+  call.with_value = true;
+  call.back.resize((size_t)n_out);
+  GK_HIP(gk_fetch_queue(ctx, call.back.data(), d_out, (size_t)n_out * sizeof(double)));
+  return GK_OK;
+}
+
 int gk_shares_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32_t* ids, int32_t n_sets, int32_t c,
                       bool with_value, GkSumCall& call) {
   gk_bind(ctx);
   const int64_t ld = L.ld;
   GK_REQUIRE(ctx && L.d && ids && n_rows > 0 && ld >= n_rows && n_sets > 0, "bad fraction arguments");
   GK_REQUIRE(c >= 1 && c <= kMaxC, "copy number beyond supported set size");
-  // Order the sets so that tiles of 32 share columns: the best sets pair a few strong alleles with
-  // many partners, so sort by each set's ids taken rarest-first (partners adjacent, hubs shared).
   int32_t max_id = 0;
   for (int64_t i = 0; i < (int64_t)n_sets * c; ++i) {
     GK_REQUIRE(ids[i] >= 0, "negative allele id");
     max_id = std::max(max_id, ids[i]);
   }
+  // value + shares of a step's selection, leaf by leaf: every column of the table through LDS once (setsum_leaves)
+  {
+    const char* const form = getenv("GK_SETSUM");        // read per call: the tests compare both forms in one process
+    const int n_cols = max_id + 1;
+    const size_t lds = (size_t)n_cols * kStageLd * sizeof(double);
+    if (with_value && !L.indexed() && c >= 2 && c <= 4 && n_sets <= 4 * kLeafGroups * kLeafSlots && lds <= 158 * 1024 &&
+        !(form && !strcmp(form, "tiles")))
+      return shares_leafwise(ctx, L, n_rows, ids, n_sets, c, n_cols, lds, call);
+  }
+  // Order the sets so that tiles of 32 share columns: the best sets pair a few strong alleles with
+  // many partners, so sort by each set's ids taken rarest-first (partners adjacent, hubs shared).
   std::vector<int32_t> freq((size_t)max_id + 1, 0);
   for (int64_t i = 0; i < (int64_t)n_sets * c; ++i) freq[ids[i]]++;
   std::vector<int32_t> key((size_t)n_sets * c), perm((size_t)n_sets);

@@ -453,8 +453,15 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
               bool found;
               val = gk_lut_lookup(lut, key, &found);
               if (!found) {
+                // no log10 yet.  With a flag word the PRODUCT itself is stored in the entry's place -- a strictly positive
+                // double, which no log10 of a probability is -- and bit 2 is raised: patch_pending puts the log10 there
+                // once the host has defined it (bit 3: the product is +0.0, which cannot mark itself: write the table again)
                 gk_lut_insert(lut, key);
-                if (bound_flags) atomicOr(bound_flags, 4u);      // no log10 yet (NaN stored): this table is written again
+                if (bound_flags) {
+                  const bool marks = (int64_t)key > 0;
+                  atomicOr(bound_flags, marks ? 4u : 12u);
+                  if (marks) val = __longlong_as_double((long long)key);
+                }
               }
             }
             key1 = key0; val1 = val0;
@@ -505,6 +512,35 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
       }
     }
     __syncthreads();
+  }
+}
+
+// Entries of a log-likelihood table that still hold their PRODUCT (a strictly positive double: the compatibility kernel
+// met it before the host had evaluated its log10, typing_mulit_allele.py:263) get the log10 from the value table, and
+// their byte of the mismatch table is set from it; an entry whose value is still undefined stays and raises bit 2 again.
+// One pass over the table (8 bytes per entry read, the few patched ones written) instead of the kernel that made it.
+__global__ __launch_bounds__(kThreads) void patch_pending(double* __restrict__ L, int64_t n_rows, int n_allele,
+                                                          LutView lut, uint8_t* __restrict__ miss8, int64_t ldm,
+                                                          uint32_t* __restrict__ flags) {
+  const int64_t n = n_rows * (int64_t)n_allele;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  uint64_t key0 = kLutEmptyKey;
+  double val0 = 0.0;
+  bool ok0 = false;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    const double v = L[i];
+    if (!(v > 0.0)) continue;
+    const uint64_t key = (uint64_t)__double_as_longlong(v);
+    if (key != key0) {
+      key0 = key;
+      val0 = gk_lut_lookup(lut, key, &ok0);
+    }
+    if (!ok0) { atomicOr(flags, 4u); continue; }
+    L[i] = val0;
+    const uint32_t m = gk_miss_of_log(val0);
+    if (m == 255u && val0 == val0) atomicOr(flags, 1u);
+    const int64_t a = i / n_rows, r = i - a * n_rows;
+    miss8[a * ldm + r] = (uint8_t)m;
   }
 }
 
@@ -980,6 +1016,26 @@ int gk_compat_log_miss(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows,
   return launch_compat<true>(ctx, tab, d_rows, n_rows, d_vflag, vbeg, vend, d_mask, words, n_allele,
                              gk_ptr<double>(d_log), nullptr, nullptr, gk_lut_view(lut), keep_empty,
                              gk_ptr<uint8_t>(d_miss8), ldm, gk_ptr<uint32_t>(d_flags));
+}
+
+/* After gk_compat_log_miss raised bit 2 of *d_flags (and not bit 3) and the value table has been resolved: the entries
+ * that hold their product instead of its log10 are patched in place, with their mismatch bytes (d_miss8 then needs its
+ * column sums again: gk_miss_colsum).  *d_flags is cleared first; bit 2 comes back if some value is still undefined,
+ * bit 0 as for gk_compat_log_miss (typing_mulit_allele.py:263). */
+int gk_compat_patch(gk_ctx* ctx, gk_lut* lut, gk_dptr d_log, int64_t n_rows, int32_t n_allele, gk_dptr d_miss8, int64_t ldm,
+                    gk_dptr d_flags) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && lut && d_log && d_miss8 && d_flags && n_rows >= 0 && n_allele >= 0 && ldm >= n_rows, "bad patch arguments");
+  GK_HIP(hipMemsetAsync(gk_ptr<void>(d_flags), 0, sizeof(uint32_t), ctx->stream));
+  if (n_rows == 0 || n_allele == 0) return GK_OK;
+  const int64_t n = n_rows * (int64_t)n_allele;
+  const int64_t want = (n + kThreads - 1) / kThreads;
+  GK_PROF(ctx, GK_K_COMPAT_PATCH,
+          GK_KERNEL(patch_pending, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(kThreads), 0, ctx->stream,
+                    gk_ptr<double>(d_log), n_rows, n_allele, gk_lut_view(lut), gk_ptr<uint8_t>(d_miss8), ldm,
+                    gk_ptr<uint32_t>(d_flags)));
+  GK_HIP(hipGetLastError());
+  return GK_OK;
 }
 
 /* The index form of gk_compat_log_miss: d_lidx uint16 [n_allele][ldm] receives, per (allele, read), the dense index of

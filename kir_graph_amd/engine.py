@@ -517,16 +517,24 @@ class DeviceModel:
         hold yet, the host evaluates them (numpy.log10) and the table is written once more."""
         if self._L is None or self._known_at_launch < 0:
             return
+        sticky = 0                              # bit 0 of the flag word survives a patch
         for _ in range(64):
             self.dev.sync()                     # this model's kernel has stored every key it claimed
             if self._bound_flags is not None:
                 # the kernel itself says whether it stored NaN for a product without a log10 (bit 2 of the flag word)
-                flags = int(self._bound_flags.download()[0])
+                flags = int(self._bound_flags.download()[0]) | sticky
                 if not flags & 4:
                     self._bound_ok = (flags & 3) == 0
                     break
                 self._logs.resolve()
-                self._launchLog()
+                if flags & 8:                   # a product that could not mark itself: the whole table again
+                    sticky = 0
+                    self._launchLog()
+                else:                           # the entries that hold their product get their log10, nothing else moves
+                    sticky = flags & 1
+                    check(lib().gk_compat_patch(self.dev.ctx, self._logs.handle, self._L.ptr, self.n_rows, self.n_allele,
+                                                self.miss8.ptr, self.ldm, self._bound_flags.ptr))
+                    check(lib().gk_miss_colsum(self.dev.ctx, self.miss8.ptr, self.ldm, self.n_allele, self.msum.ptr))
                 continue
             self._logs.resolve()
             if self._logs.n_known > self._known_at_launch:

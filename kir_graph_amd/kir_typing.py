@@ -147,6 +147,7 @@ class _GenesInParallel(Typing):
         self._local = threading.local()
         self.slot_base = 0     # first worker context of this typer (cohort.SampleTyper gives every lane its own block)
         self.tables_rewritten = 0   # compatibility tables written again because the sample brought products without a log10
+        self.tables_patched = 0     # ... and tables whose new products were patched in place (gk_compat_patch)
 
     def _context(self):
         """(tabulation bound to this thread's context, its log table)."""
@@ -300,6 +301,7 @@ class TypingWithPosNegAllele(_GenesInParallel):
                 check(lib().gk_sample_search(tab.dev.ctx, more, len(extra), tab.handle, vflag.ptr, logs.handle, jobs, len(live),
                                              _lib.NUMPY_ARGSORT, _lib.NUMPY_LOG10, handles))
             self.tables_rewritten = sum(max(0, int(jobs[k].passes) - 1) for k in range(len(live)))
+            self.tables_patched = sum(int(jobs[k].patches) for k in range(len(live)))
             try:
                 for k, (gene, cn, typ, _, homo) in enumerate(live):
                     typ.adoptJob(jobs[k], C.c_void_p(handles[k]), cn, homo)

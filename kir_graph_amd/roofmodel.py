@@ -193,3 +193,38 @@ def dominant(prof: dict[str, tuple[int, float]], call_log: list[tuple]) -> dict:
     if others:
         out["other_kernels"] = others
     return out
+
+
+def stepRoofline(call_log: list[tuple], steps: int, ms_per_step: float) -> dict:
+    """The whole step against the roofs: the algorithmic bytes of EVERY priced launch of a step (tabulation, compatibility
+    tables, bounds, exact sums, column sums) over the step's measured wall time against the HBM peak -- the metric's
+    "achieved HBM GB/s vs roofline" as one number -- and, beside it, how much of the step the VALU-bound kernels' own
+    floors take (algorithmic lane-operations at the measured issue peak of each kernel's instruction mix).
+    ``call_log`` covers ``steps`` steps (the serial pass); ``ms_per_step`` is the reported one (pipelined legs)."""
+    kernels = sorted({c[0] for c in call_log})
+    total_bytes = hbm_floor = valu_floor = valu_floor_guide = 0.0
+    per_kernel = {}
+    for k in kernels:
+        calls = [c for c in call_log if c[0] == k]
+        by, ops, bound, peak = _priced(k, calls)
+        if by <= 0:
+            continue
+        total_bytes += by
+        hbm_floor += by / (HBM_PEAK_GBS * 1e9)
+        if bound == "valu" and peak > 0:
+            valu_floor += ops / peak
+            valu_floor_guide += ops / laneOpsPeak(k, GUIDE_CYCLES)
+        per_kernel[k] = {"bytes_per_step": by / max(steps, 1), "ops_per_step": ops / max(steps, 1), "bound": bound}
+    steps = max(steps, 1)
+    sec = ms_per_step / 1e3
+    gbs = total_bytes / steps / sec / 1e9 if sec > 0 else None
+    return {"algorithmic_bytes_per_step": total_bytes / steps, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS if gbs is not None else None,
+            "hbm_floor_ms_per_step": 1e3 * hbm_floor / steps,
+            "valu_floor_ms_per_step": 1e3 * valu_floor / steps,
+            "valu_share_of_step": (1e3 * valu_floor / steps) / ms_per_step if ms_per_step > 0 else None,
+            "valu_floor_ms_per_step_guide": 1e3 * valu_floor_guide / steps,
+            "kernels": per_kernel,
+            "note": "sum over all priced launches of one step (serial pass geometries) / the reported ms_per_step; the "
+                    "step is VALU-issue bound, not HBM bound: valu_floor = the VALU-bound kernels' algorithmic "
+                    "lane-operations at the measured issue peak of their instruction mix (…_guide: at the guide's price)"}

@@ -551,7 +551,7 @@ class AlleleTyping:
                       d_miss8=m.miss8.ptr if m.miss8 else 0, ldm=m.ldm, d_msum=m.msum.ptr if m.msum else 0,
                       d_flags=m._bound_flags.ptr if m._bound_flags else 0, d_lidx=m.lidx.ptr if m.lidx else 0,
                       vbeg=vbeg, vend=vend, words=words, n_allele=m.n_allele, n_steps=1 if homo else cn,
-                      top_n=self.top_n, bound_ok=0, passes=0, indexed=0, rsv=0)
+                      top_n=self.top_n, bound_ok=0, passes=0, indexed=0, patches=0)
         return job, homo
 
     def adoptJob(self, job, handle, cn: int, homo: bool) -> TypingResult:

@@ -125,6 +125,7 @@ int gk_compat_log(gk_ctx*, gk_tab*, gk_dptr, int64_t, gk_dptr, int32_t, int32_t,
 int gk_miss_colsum(gk_ctx*, gk_dptr, int64_t, int32_t, gk_dptr) { return GK_ERR_NO_DEVICE; }
 int gk_compat_index(gk_ctx*, gk_tab*, gk_dptr, int64_t, gk_dptr, int32_t, int32_t, gk_dptr, int32_t, int32_t, int32_t, gk_lut*,
                     gk_dptr, gk_dptr, int64_t, gk_dptr) { return GK_ERR_NO_DEVICE; }
+int gk_compat_patch(gk_ctx*, gk_lut*, gk_dptr, int64_t, int32_t, gk_dptr, int64_t, gk_dptr) { gk_set_error("no device in the host-only build"); return GK_ERR_NO_DEVICE; }
 int gk_lut_known(gk_lut*, int32_t* n) { *n = 0; return GK_OK; }
 int gk_lut_resolve(gk_lut*, gk_log10_fn, int32_t*, int32_t*, int32_t*) { return GK_ERR_NO_DEVICE; }
 int gk_lut_resolve_stored(gk_lut*, gk_log10_fn, int32_t*, int32_t*, int32_t*) { return GK_ERR_NO_DEVICE; }

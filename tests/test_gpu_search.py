@@ -148,3 +148,41 @@ def test_setsum_gives_the_bits_of_maxsum_and_fraction(device, n_rows, c):
                               n_allele, out.ctypes.data))
         assert np.array_equal(value, out[np.arange(n_sets), ids[:, c - 1]])
     dL.free()
+
+
+@pytest.mark.parametrize("n_rows,n_allele,n_sets,c", [
+    (3, 11, 5, 2),            # a leaf shorter than 8 rows: all tail
+    (135, 40, 130, 2),        # two leaves (64 + 71) and a tail, two sets per lane group
+    (8192, 70, 600, 2),       # one full chunk, the shape of a search step
+    (8199, 70, 700, 3),       # a second chunk of 7 rows
+    (20011, 230, 650, 2),     # chunks with uneven last leaves; 230 columns staged
+    (20011, 300, 300, 4),     # more columns than ride in registers (the direct staging loop)
+    (9001, 64, 1000, 2),      # more sets than one launch carries: two batches
+    (9001, 64, 600, 3),       # three alleles: two batches of 4 sets per lane group
+    (5000, 50, 500, 4),       # four alleles: two batches of 3
+])
+def test_leafwise_setsum_equals_the_tiled_form_and_numpy(device, monkeypatch, n_rows, n_allele, n_sets, c):
+    """gk_setsum through setsum_leaves / fold_leaves (every column through LDS once, numpy's tree folded leaf by leaf) gives
+    the bits of the tiled kernel (fraction_chunks with the value riding along) and of numpy."""
+    rng = np.random.default_rng(n_rows * 7 + n_sets + c)
+    L = table(rng, n_rows, n_allele)
+    dL = device.put(np.ascontiguousarray(L.T))
+    ids = np.ascontiguousarray(rng.integers(0, n_allele, (n_sets, c)), dtype=np.int32)
+    ids[:40, 0] = 3
+    ids[-1, :] = n_allele - 1                         # the last column is used
+    got = {}
+    for form in ("leaves", "tiles"):
+        monkeypatch.setenv("GK_SETSUM", form)
+        value, frac = np.empty(n_sets), np.empty((n_sets, c))
+        check(lib().gk_setsum(device.ctx, dL.ptr, n_rows, n_rows, ids.ctypes.data, n_sets, c, value.ctypes.data,
+                              frac.ctypes.data))
+        got[form] = (value, frac)
+    assert np.array_equal(got["leaves"][0], got["tiles"][0])
+    assert np.array_equal(got["leaves"][1], got["tiles"][1])
+    gathered = L[:, ids]
+    best = np.asfortranarray(gathered.max(axis=2))
+    assert np.array_equal(got["leaves"][0], best.sum(axis=0))
+    owns = np.equal(gathered, gathered.max(axis=2)[:, :, None])
+    want = (owns / owns.sum(axis=2)[:, :, None]).sum(axis=0) / n_rows
+    assert np.array_equal(got["leaves"][1], want)
+    dL.free()
