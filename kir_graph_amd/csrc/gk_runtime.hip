@@ -171,6 +171,38 @@ int gk_timer_stop_ms(gk_ctx* ctx, float* ms) {
 constexpr size_t kStageDirect = (size_t)4 << 20;   // larger transfers go straight to / from the caller's memory
 size_t gk_stage_direct() { return kStageDirect; }
 
+// A bulk host-to-device copy done by a KERNEL that reads the pinned host block over PCIe (hipHostMalloc memory is mapped
+// into the device's address space) instead of by the runtime's DMA path: the DMA queues then stay free for the small
+// parameter / result copies of the samples being typed, which otherwise wait behind a 256 MB transfer (the copy of a
+// sample's packed records runs next to two searches that each make ~45 small round trips).  A few workgroups with many
+// 16-byte loads in flight fill the link; their waves mostly wait, so they take wave slots, hardly any issue cycles.
+namespace {
+constexpr int kCopyBlocks = 64, kCopyThreads = 256, kCopyUnroll = 8;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kCopyThreads) void copy_from_host(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int64_t n16,
+                                                               uint8_t* dst_tail, const uint8_t* src_tail, int n_tail) {
+  const int64_t stride = (int64_t)gridDim.x * kCopyThreads;
+  int64_t i = (int64_t)blockIdx.x * kCopyThreads + threadIdx.x;
+  for (; i + (kCopyUnroll - 1) * stride < n16; i += kCopyUnroll * stride) {
+    u32x4 v[kCopyUnroll];
+#pragma unroll
+    for (int u = 0; u < kCopyUnroll; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < kCopyUnroll; ++u) dst[i + u * stride] = v[u];
+  }
+  for (; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+}  // namespace
+
+hipError_t gk_copy_from_host(gk_ctx* ctx, void* dst_dev, const void* src_pinned, size_t bytes) {
+  const int64_t n16 = (int64_t)(bytes / 16);
+  const int n_tail = (int)(bytes % 16);
+  hipLaunchKernelGGL(copy_from_host, dim3(kCopyBlocks), dim3(kCopyThreads), 0, ctx->stream, (u32x4*)dst_dev,
+                     (const u32x4*)src_pinned, n16, (uint8_t*)dst_dev + 16 * n16, (const uint8_t*)src_pinned + 16 * n16, n_tail);
+  return hipGetLastError();
+}
+
 // ---- the two rings and the marks that give their space back
 namespace {
 

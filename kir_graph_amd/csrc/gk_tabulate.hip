@@ -65,6 +65,34 @@ struct MateView {
   __device__ bool passes() const { return (flag() & 2u) && nm() != GK_NM_ABSENT && nm() <= 4u; }
 };
 
+// a record whose first kHeadWords words are staged in LDS and whose rest is read where it lies in global memory: the
+// header, all 14 CIGAR operations and the first 6 mismatches are in the head -- a 150-base read that passes the NM <= 4
+// filter rarely has more events -- so pass 1 stages 64 bytes per mate instead of 128 (8 waves per SIMD fit)
+constexpr int kHeadWords = 16;
+constexpr int kHeadLd = kHeadWords + 1;
+struct HeadView {
+  static constexpr int kCapCig = GK_MAX_CIG, kCapMm = GK_MAX_MM, kCapIns = GK_MAX_INS, kCapEv = kMaxEv;
+  const uint32_t* w;      // LDS: words [0, kHeadWords)
+  const uint32_t* g;      // the whole record in global memory
+  __device__ uint32_t word(int i) const { return i < kHeadWords ? w[i] : g[i]; }
+  __device__ bool spilled() const { return n_cig() == GK_SPILLED; }
+  __device__ uint32_t pos0() const { return w[0]; }
+  __device__ uint32_t flag() const { return w[1] & 0xFFFFu; }
+  __device__ uint32_t ref() const { return (w[1] >> 16) & 0xFFu; }
+  __device__ uint32_t nm() const { return w[2] & 0xFFu; }
+  __device__ uint32_t n_cig() const { return (w[2] >> 8) & 0xFFu; }
+  __device__ uint32_t n_mm() const { return (w[2] >> 16) & 0xFFu; }
+  __device__ uint32_t cig(int i) const {
+    const uint32_t x = w[kCigWord + (i >> 1)];      // words 3 .. 9: always in the head
+    return (i & 1) ? (x >> 16) : (x & 0xFFFFu);
+  }
+  __device__ uint32_t mm_off(int i) const { return word(kMmWord + i) & 0xFFFFu; }
+  __device__ uint32_t mm_base(int i) const { return (word(kMmWord + i) >> 16) & 0xFFu; }
+  __device__ uint32_t ins(int i) const { return g[kInsWord + i]; }
+  __device__ bool passes() const { return (flag() & 2u) && nm() != GK_NM_ABSENT && nm() <= 4u; }
+};
+static_assert(kCigWord + GK_MAX_CIG / 2 <= kHeadWords, "the CIGAR lies in the staged head");
+
 // a record of the wide format (gk_mate_wide), read where it lies in global memory: such pairs are rare
 struct WideView {
   static constexpr int kCapCig = GK_WIDE_CIG, kCapMm = GK_WIDE_MM, kCapIns = GK_WIDE_INS, kCapEv = GK_WIDE_EVENTS;
@@ -82,6 +110,22 @@ struct WideView {
   __device__ bool passes() const { return (flag() & 2u) && nm() != GK_NM_ABSENT && nm() <= 4u; }
 };
 static_assert(sizeof(gk_mate_wide) == 2048, "gk_mate_wide layout");
+
+// the heads (first 64 bytes) of the workgroup's records [m0, m0 + 256) -> LDS: 4 lanes per record, 16 bytes each
+__device__ inline void stage_heads(const gk_mate* mates, int64_t m0, int64_t n_mates, uint32_t* rec) {
+  const int n_rec = (int)min<int64_t>(kThreads, n_mates - m0);
+#pragma unroll
+  for (int k = 0; k < kHeadWords / 4; ++k) {
+    const int idx = threadIdx.x + kThreads * k;        // (record, quarter of its head)
+    const int rcd = idx >> 2, part = idx & 3;
+    if (rcd < n_rec) {
+      const uint4 v = reinterpret_cast<const uint4*>(mates + m0 + rcd)[part];
+      uint32_t* d = rec + rcd * kHeadLd + part * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
+  __syncthreads();
+}
 
 // the workgroup's records [m0, m0 + 256) -> LDS, coalesced
 __device__ inline void stage_mates(const gk_mate* mates, int64_t m0, int64_t n_mates, uint32_t* rec) {
@@ -387,43 +431,56 @@ __device__ inline uint32_t cooperative_negatives(WaveNeg& wv, const IndexView& i
 // candidate-by-candidate loop.  The kept bits land in `words` (LDS, kMaskWords per lane); returns the kept count.
 __device__ inline uint32_t window_negatives(const IndexView& ix, const uint32_t* evw, int n_ev, uint32_t any_n,
                                             uint32_t right, uint32_t lo, uint32_t len, uint32_t* words) {
-#pragma unroll
-  for (int w = 0; w < kMaskWords; ++w) words[w] = 0;
+  // `evw` (the mate's event words) and `words` (its kMaskWords words of kept bits) are per-mate rows in GLOBAL memory:
+  // a word is built in a register and stored once, the events are few and read back from L2 -- the 33 KB of LDS the
+  // two arrays took per workgroup halved the kernel's occupancy (2 waves per SIMD)
   if (len == 0) return 0;
   if (any_n || len > 32u * kMaskWords) {
-    uint32_t kept = 0;
+    uint32_t kept = 0, cur = 0;
     for (uint32_t c = 0; c < len; ++c) {
       const uint32_t i = lo + c;
       if (negative_kept(ix.key[i], (int)i, ix, evw, n_ev, any_n, right)) {
         ++kept;
-        if (c < 32u * kMaskWords) words[c >> 5] |= 1u << (c & 31u);
+        cur |= 1u << (c & 31u);
+      }
+      if ((c & 31u) == 31u || c + 1 == len) {
+        if (c < 32u * kMaskWords) words[c >> 5] = cur;
+        cur = 0;
       }
     }
     return kept;
   }
+  // the first events relative to the window, in registers (novel events carry bit 31: far outside any window)
+  uint32_t rel4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) rel4[q] = q < n_ev ? (evw[q] & ~kEvIsN) - lo : 0xFFFFFFFFu;
   const uint32_t n_words = (len + 31u) >> 5;
+  uint32_t kept = 0;
   for (uint32_t w = 0; w < n_words; ++w) {
     const uint32_t left = len - 32u * w;
-    words[w] = left >= 32u ? ~0u : ((1u << left) - 1u);
-  }
-  for (int e = 0; e < n_ev; ++e) {                       // a positive of this mate is not a negative
-    const uint32_t word = evw[e] & ~kEvIsN;
-    const uint32_t rel = word - lo;                       // novel events carry bit 31: far outside any window
-    if (rel < len) words[rel >> 5] &= ~(1u << (rel & 31u));
-  }
-  for (uint32_t w = 0; w < n_words; ++w) {               // deletions reaching within 10 bases of the right edge
+    uint32_t word = left >= 32u ? ~0u : ((1u << left) - 1u);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                          // a positive of this mate is not a negative
+      const uint32_t rel = rel4[q] - 32u * w;
+      if (rel < 32u) word &= ~(1u << rel);
+    }
+    for (int e = 4; e < n_ev; ++e) {
+      const uint32_t rel = (evw[e] & ~kEvIsN) - lo - 32u * w;
+      if (rel < 32u) word &= ~(1u << rel);
+    }
+    // deletions reaching within 10 bases of the right edge
     const uint32_t first = lo + 32u * w, sh = first & 31u;
     const uint32_t a = ix.del_bits[first >> 5], b = ix.del_bits[(first >> 5) + 1];
-    uint32_t dels = (sh ? (a >> sh) | (b << (32u - sh)) : a) & words[w];
+    uint32_t dels = (sh ? (a >> sh) | (b << (32u - sh)) : a) & word;
     while (dels) {
       const int bit = __ffs(dels) - 1;
       dels &= dels - 1;
       const uint64_t k = ix.key[first + (uint32_t)bit];
-      if (gk_key_pos(k) + gk_key_val(k) + 10u >= right) words[w] &= ~(1u << bit);
+      if (gk_key_pos(k) + gk_key_val(k) + 10u >= right) word &= ~(1u << bit);
     }
+    kept += (uint32_t)__popc(word);
+    words[w] = word;
   }
-  uint32_t kept = 0;
-  for (uint32_t w = 0; w < n_words; ++w) kept += (uint32_t)__popc(words[w]);
   return kept;
 }
 
@@ -434,16 +491,17 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
                                                       uint32_t* valid /*[n_pairs]*/, int* err_flags,
                                                       uint32_t* ev_save /*[n_mates][kMaxEv]*/,
                                                       uint32_t* lo_save /*[n_mates]*/,
-                                                      uint32_t* mask_save /*[n_mates][kMaskWords]*/) {
-  __shared__ uint32_t rec[kThreads * kRecLd];
-  __shared__ uint32_t evs[kThreads * kEvLd];
-  __shared__ uint32_t wmask[kThreads * (kMaskWords + 1)];   // kept bits of the lane's window (odd stride)
+                                                      uint32_t* mask_save /*[n_mates][kMaskWords]*/,
+                                                      uint32_t* ev_words /*[n_mates][kMaxEv]: the walk's event words*/) {
+  // LDS holds the heads of the staged records only (17 KB per workgroup); a mate's event words and the kept bits of
+  // its window live in its rows of `ev_words` / `mask_save`
+  __shared__ uint32_t rec[kThreads * kHeadLd];
   const int64_t m0 = (int64_t)blockIdx.x * kThreads;
-  stage_mates(mates, m0, n_mates, rec);
+  stage_heads(mates, m0, n_mates, rec);
   const int64_t m = m0 + threadIdx.x;
   const bool in = m < n_mates;
-  const MateView r{rec + threadIdx.x * kRecLd};
-  uint32_t* evw = evs + threadIdx.x * kEvLd;
+  const HeadView r{rec + threadIdx.x * kHeadLd, reinterpret_cast<const uint32_t*>(mates + (in ? m : 0))};
+  uint32_t* evw = ev_words + (in ? m : 0) * kMaxEv;
   const bool ok = in && r.passes() && !r.spilled();   // wide pairs: tab_count_wide writes their counts afterwards
   const bool ok_other = __shfl_xor((int)ok, 1, 64) != 0;
   const bool pair_ok = ok && ok_other;
@@ -464,21 +522,19 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
       enumerate = true;
     }
   }
-  uint32_t* const my_words = wmask + threadIdx.x * (kMaskWords + 1);
+  // the kept bits of the window go straight to the mate's row of mask_save (what pass 2 needs to write the negative
+  // list without enumerating the window again)
   const uint32_t n_neg = enumerate ? window_negatives(ix, evw, wk.n, wk.any_n, wk.right, (uint32_t)wk.lo,
-                                                      (uint32_t)(wk.hi - wk.lo), my_words)
+                                                      (uint32_t)(wk.hi - wk.lo), mask_save + m * kMaskWords)
                                    : 0u;
   if (!in) return;
   cnt[4 * pair + side] = n_pos;
   cnt[4 * pair + 2 + side] = n_neg;
   if (side == 0) valid[pair] = pair_ok ? 1u : 0u;
-  // what pass 2 needs to write the negative list without enumerating the window again
   if (enumerate) {
     const uint32_t len = (uint32_t)(wk.hi - wk.lo);
     if (len > 32u * kMaskWords) atomicOr(err_flags, 4);   // does not fit the saved bits: the host takes the two-walk path
     lo_save[m] = (uint32_t)wk.lo;
-    const uint32_t n_words = min((len + 31u) >> 5, (uint32_t)kMaskWords);
-    for (uint32_t w = 0; w < n_words; ++w) mask_save[m * kMaskWords + w] = my_words[w];
   }
 }
 
@@ -862,9 +918,10 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
   GK_HIP(hipMemsetAsync(nt.keys, 0xFF, cap * sizeof(uint64_t), st));
   GK_HIP(hipMemsetAsync(nt.seq, 0xFF, cap * sizeof(uint64_t), st));
 
-  uint32_t *cnt = nullptr, *valid = nullptr, *ev_save = nullptr, *lo_save = nullptr, *mask_save = nullptr;
+  uint32_t *cnt = nullptr, *valid = nullptr, *ev_save = nullptr, *lo_save = nullptr, *mask_save = nullptr, *ev_words = nullptr;
   int* d_err = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&ev_save, (size_t)(n_mates + 1) * kMaxEv * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&ev_words, (size_t)(n_mates + 1) * kMaxEv * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&lo_save, (size_t)(n_mates + 1) * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&mask_save, (size_t)(n_mates + 1) * kMaskWords * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&cnt, (size_t)(4 * n_pairs + 2) * sizeof(uint32_t)));
@@ -878,7 +935,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
                      idx->d_gene_pbase, idx->d_snp_ord};
   if (n_mates) {
     GK_PROF(ctx, GK_K_TAB_COUNT, GK_KERNEL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
-                       nt, cnt, valid, d_err, ev_save, lo_save, mask_save));
+                       nt, cnt, valid, d_err, ev_save, lo_save, mask_save, ev_words));
   }
   int64_t* d_spill_pair = nullptr;
   uint32_t* wide_ev = nullptr;
@@ -927,7 +984,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
     *table_too_small = true;
     GK_HIP(hipStreamSynchronize(st));
     gk_pool_free(ctx,cnt); gk_pool_free(ctx,valid); gk_pool_free(ctx,d_err); gk_pool_free(ctx,bitmap); gk_pool_free(ctx,prefix); gk_pool_free(ctx,wide_bits);
-    gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save);
+    gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save); gk_pool_free(ctx,ev_words);
     gk_pool_free(ctx,d_spill_pair); gk_pool_free(ctx,wide_ev);
     gk_pool_free(ctx,nt.keys); gk_pool_free(ctx,nt.seq); gk_pool_free(ctx,nt.rank);
     gk_tab_destroy(tab);
@@ -967,7 +1024,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
   GK_HIP(hipGetLastError());
   GK_HIP(hipStreamSynchronize(st));
   gk_pool_free(ctx,cnt); gk_pool_free(ctx,valid); gk_pool_free(ctx,d_err); gk_pool_free(ctx,bitmap); gk_pool_free(ctx,prefix); gk_pool_free(ctx,wide_bits);
-  gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save);
+  gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save); gk_pool_free(ctx,ev_words);
   gk_pool_free(ctx,d_spill_pair); gk_pool_free(ctx,wide_ev);
   gk_pool_free(ctx,nt.keys); gk_pool_free(ctx,nt.seq); gk_pool_free(ctx,nt.rank);
   if (err & 2) {

@@ -240,7 +240,8 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
                                                                 const uint32_t* mask_t, int words, int n_allele, int a_base,
                                                                 double* probs, uint8_t* miss_out, uint16_t* nvar_out,
                                                                 LutView lut, double empty_p, uint8_t* miss8, int64_t ldm,
-                                                                uint32_t* bound_flags, uint16_t* lidx, int probe) {
+                                                                uint32_t* bound_flags, uint16_t* lidx, int probe,
+                                                                int uniform_cut) {
   // probe (tools/compat_phases.sh, GK_COMPAT_PROBE): 1 = leave out the walk over the kept variants, 2 = leave out the way
   // out of a tile, 3 = only its second pass (the stores), 4 = only its first (the value-table look-ups) -- WRONG results, for timing the two halves of the kernel only; 0 in every real launch
   const int n_span = vend - vbeg;   // mask_t: [words][n_span], see transpose_mask
@@ -299,6 +300,15 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
             for (int w = 0; w < kPassWords; ++w) mrow[w] = ~mrow[w];     // "the allele lacks it" = agreement with a negative id
           }
         }
+        // A variant that NO allele of a slot carries gives every lane of that slot the same factor (0.001 for a positive
+        // id, 0.999 for a negative one): one multiply by a constant instead of word read + bit test + two selects +
+        // multiply.  36 % of the (variant, slot) pairs of the bench index are such, and nearly all of a last slot that
+        // holds a few alleles only -- the padding lanes of a gene cost a quarter this way.  nz[s] = variants of the
+        // chunk with at least one allele in slot s, as a scalar bit set (all ones when the short cut is off).
+        uint64_t nz[kSlots];
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s)
+          nz[s] = (kFma || !uniform_cut) ? ~0ull : __ballot((mrow[2 * s] | mrow[2 * s + 1]) != 0u);
         // kept variants of the chunk as scalar bit sets, walked in order: the positive ones (ordinals
         // below `mid`) come first, then the negative ones, whose factors are swapped
         const uint64_t kept = __ballot(my_keep);
@@ -324,9 +334,14 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
 #pragma unroll
           for (int s = 0; s < kSlots; ++s) w[s] = (&wave_rows[0][0])[my_word0 + t_off + 2 * s];
         };
-        auto apply = [&](const uint32_t (&w)[kSlots], bool positive) {
+        auto apply = [&](const uint32_t (&w)[kSlots], int t, bool positive) {
 #pragma unroll
           for (int s = 0; s < kSlots; ++s) {
+            if (!((nz[s] >> t) & 1ull)) {      // wave-uniform: nobody in this slot has variant t
+              p[s] *= positive ? 0.001 : 0.999;
+              if (kMiss && positive) miss[s] += 1u;
+              continue;
+            }
             const int32_t m = __builtin_amdgcn_sbfe((int32_t)w[s], my_bit, 1);   // -1: the allele has the variant
             if (kFma) {
               agree[s] = __hiloint2double(m & 0x3FF00000, __double2loint(agree[s]));   // 1.0 / 0.0: only the high word changes
@@ -344,20 +359,20 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
         auto walk = [&](uint64_t todo, bool positive) {
           if (!todo) return;
           uint32_t wa[kSlots], wb[kSlots];
-          int t = __builtin_ctzll(todo);
-          todo = clear_bit(todo, t);
-          fetch(t, wa);
+          int ta = __builtin_ctzll(todo), tb;
+          todo = clear_bit(todo, ta);
+          fetch(ta, wa);
           for (;;) {
-            if (!todo) { apply(wa, positive); break; }
-            t = __builtin_ctzll(todo);
-            todo = clear_bit(todo, t);
-            fetch(t, wb);
-            apply(wa, positive);
-            if (!todo) { apply(wb, positive); break; }
-            t = __builtin_ctzll(todo);
-            todo = clear_bit(todo, t);
-            fetch(t, wa);
-            apply(wb, positive);
+            if (!todo) { apply(wa, ta, positive); break; }
+            tb = __builtin_ctzll(todo);
+            todo = clear_bit(todo, tb);
+            fetch(tb, wb);
+            apply(wa, ta, positive);
+            if (!todo) { apply(wb, tb, positive); break; }
+            ta = __builtin_ctzll(todo);
+            todo = clear_bit(todo, ta);
+            fetch(ta, wa);
+            apply(wb, tb, positive);
           }
         };
         if (probe == 1) {
@@ -571,6 +586,8 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
                       "WRONG, this run is good for timing only\n", probe);
     });
   }
+  const char* const cut_env = getenv("GK_COMPAT_UNIFORM");     // 0: every factor through the bit test (for comparisons)
+  const int uniform_cut = !(cut_env && !strcmp(cut_env, "0"));
   const char* const form_env = getenv("GK_COMPAT_FORM");      // read per call: the tests compare both forms in one process
   const bool fma_form = form_env && !strcmp(form_env, "fma");
   for (int a_base = 0; a_base < n_allele; a_base += 64 * kMaxSlots) {
@@ -578,7 +595,7 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
 #define GK_COMPAT_GO(S, IDX, FMA)                                                                                     \
   GK_KERNEL((compat_kernel<kLog, S, !kLog, IDX, FMA>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows,  \
             tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, mask_t, words, n_allele, a_base, out,       \
-            miss, nvar, view, empty_p, miss8, ldm, bound_flags, lidx, probe)
+            miss, nvar, view, empty_p, miss8, ldm, bound_flags, lidx, probe, uniform_cut)
 #define GK_COMPAT_LAUNCH(S)                                       \
   GK_PROF(ctx, GK_K_COMPAT, {                                     \
     if (kLog && lidx) GK_COMPAT_GO(S, (kLog && true), false);     \
