@@ -491,6 +491,15 @@ int gk_allgather_f64(gk_comm* comm, const double* send, double* recv, int64_t n)
 int gk_allreduce_max_f64(gk_comm* comm, double* inout, int64_t n);
 int gk_comm_barrier(gk_comm* comm);
 
+/* ---- the packed records of a sample in a compact form, for the time between its depth and its typing: with --cn-cohort a
+ * sample is typed only after the pooled copy-number fit of the whole cohort (main.py:572-589, kir_cn.py:167-186), and what
+ * waits in HBM meanwhile is this -- per mate the words it uses (header, CIGAR operations, mismatches, inserted-string
+ * ids: hisat2.py:228-276 is what a record holds) behind uint32 word offsets [n_mates + 1], ~30 bytes per mate instead of
+ * 128 -- not the tabulation (~1 GB per 5 M reads).  *d_compact_out: a block of the context's pool (gk_free), *bytes_out
+ * its size.  gk_mates_expand writes the records back (unused parts zero); gk_tabulate on them gives the same lists. */
+int gk_mates_compact(gk_ctx* ctx, gk_dptr d_mates, int64_t n_mates, gk_dptr* d_compact_out, int64_t* bytes_out);
+int gk_mates_expand(gk_ctx* ctx, gk_dptr d_compact, int64_t n_mates, gk_dptr d_mates_out);
+
 /* ---- pinned host memory for the packed records of a sample (the packer's output on its way to HBM) and a
  * host-to-device copy that is only queued on the context's stream (gk_h2d waits for it). */
 int gk_host_alloc(size_t bytes, void** out);

@@ -184,13 +184,6 @@ int gk_h2d_async(gk_ctx* ctx, gk_dptr dst, const void* src, size_t bytes) {
   gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   if (!bytes) return GK_OK;
-  // GK_H2D = kernel: the block (gk_host_alloc memory, 16-byte aligned) is read over PCIe by a copy kernel on the stream,
-  // the runtime's DMA queues stay free for the small copies of the typing lanes; dma (default): hipMemcpyAsync
-  static const bool by_kernel = [] { const char* e = getenv("GK_H2D"); return e && !strcmp(e, "kernel"); }();
-  if (by_kernel && bytes >= (1u << 20) && ((uintptr_t)src & 15u) == 0 && (dst & 15u) == 0) {
-    GK_HIP(gk_copy_from_host(ctx, gk_ptr<void>(dst), src, bytes));
-    return GK_OK;
-  }
   GK_HIP(hipMemcpyAsync(gk_ptr<void>(dst), src, bytes, hipMemcpyHostToDevice, ctx->stream));
   return GK_OK;
 }

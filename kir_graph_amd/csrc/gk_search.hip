@@ -522,6 +522,10 @@ __global__ __launch_bounds__(kLeafThreads) void setsum_leaves(const double* __re
   const int tid = threadIdx.x, j = tid & 7, g = tid >> 3;
   int loc[kS][kC];
   double acc[kS][kO];
+  // two alleles: a row's shares are 1 / 0, 0 / 1 or 1/2 / 1/2 -- multiples of 1/2, whose sums are exact in float64 in
+  // any order -- so the lanes COUNT the rows an allele reaches the maximum on (one compare + add-with-carry each) and the
+  // leaf's shares are formed from the counts at the end: n_q - tied / 2, tied = n_0 + n_1 - rows.  The value keeps its tree.
+  uint32_t hits[kS][2];
 #pragma unroll
   for (int s = 0; s < kS; ++s) {
     const int k = g + kLeafGroups * s;
@@ -529,18 +533,27 @@ __global__ __launch_bounds__(kLeafThreads) void setsum_leaves(const double* __re
     for (int q = 0; q < kC; ++q) loc[s][q] = (k < n_sets ? ids[k * kC + q] : 0) * kStageLd;
 #pragma unroll
     for (int q = 0; q < kO; ++q) acc[s][q] = 0.0;
+    hits[s][0] = hits[s][1] = 0u;
   }
   const LeafAbs leaf = leaves[blockIdx.x];
   const int len = leaf.len;
   const int n8 = len < 8 ? 0 : len - (len & 7);      // rows summed by the 8 strided accumulators
   const double* const base = L + leaf.row0;
   const int n_elem = n_cols * kStageRows;
-  const bool carried = n_elem <= kStagePrefetch * kLeafThreads;   // the next block rides in registers
+  // the next block rides in registers (and a column's lane offset fits 32 bits: 31 columns of ld rows)
+  const bool carried = n_elem <= kStagePrefetch * kLeafThreads && (uint64_t)ld * 32u * sizeof(double) < (1ull << 32);
 
   // set s at staged row r: shares of the row's maximum (1 / number of alleles that reach it) + the maximum itself
   auto add_terms = [&](int r) {
 #pragma unroll
     for (int s = 0; s < kS; ++s) {
+      if (kC == 2) {
+        const double v0 = sbuf[loc[s][0] + r], v1 = sbuf[loc[s][1] + r];
+        acc[s][kC] += vmax(v0, v1);
+        hits[s][0] += v0 >= v1 ? 1u : 0u;
+        hits[s][1] += v1 >= v0 ? 1u : 0u;
+        continue;
+      }
       double v[kC];
       double best = -__builtin_huge_val();
 #pragma unroll
@@ -561,12 +574,17 @@ __global__ __launch_bounds__(kLeafThreads) void setsum_leaves(const double* __re
   };
 
   double pre[kStagePrefetch];
+  // thread tid stages row (tid & 31) of columns (tid >> 5) + 32 u: one 32-bit lane offset, the rest of the address is
+  // wave-uniform (a scalar base per u and block)
+  const uint32_t lane_off = ((uint32_t)(tid >> 5) * (uint32_t)ld + (uint32_t)(tid & (kStageRows - 1))) * (uint32_t)sizeof(double);
+  const size_t col_step = (size_t)(kLeafThreads / kStageRows) * (size_t)ld * sizeof(double);
   auto fetch = [&](int b0, int rows_in) {
+    const char* const block = reinterpret_cast<const char*>(base + b0);
 #pragma unroll
     for (int u = 0; u < kStagePrefetch; ++u) {
       const int idx = tid + u * kLeafThreads;
-      const int col = idx >> 5, r = idx & (kStageRows - 1);
-      pre[u] = (idx < n_elem && r < rows_in) ? base[(int64_t)col * ld + b0 + r] : 0.0;
+      const int r = idx & (kStageRows - 1);
+      pre[u] = (idx < n_elem && r < rows_in) ? *reinterpret_cast<const double*>(block + (size_t)u * col_step + lane_off) : 0.0;
     }
   };
   const int n_stage = (n8 + kStageRows - 1) / kStageRows;
@@ -593,9 +611,20 @@ __global__ __launch_bounds__(kLeafThreads) void setsum_leaves(const double* __re
   }
   if (n8) {
 #pragma unroll
-    for (int s = 0; s < kS; ++s)
+    for (int s = 0; s < kS; ++s) {
 #pragma unroll
-      for (int q = 0; q < kO; ++q) acc[s][q] = group_sum8(acc[s][q]);
+      for (int q = (kC == 2 ? kC : 0); q < kO; ++q) acc[s][q] = group_sum8(acc[s][q]);
+      if (kC == 2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {      // the counts of the group's 8 lanes (integers: any order), in every lane
+          uint32_t h = hits[s][q];
+          h += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, kDppSwap1, 0xF, 0xF, true);
+          h += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, kDppSwap2, 0xF, 0xF, true);
+          h += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, kDppHalfMirror, 0xF, 0xF, true);
+          hits[s][q] = h;
+        }
+      }
+    }
   }
   if (len > n8) {                          // sequential tail rows n8 .. len (all rows of a leaf shorter than 8)
     __syncthreads();
@@ -605,6 +634,14 @@ __global__ __launch_bounds__(kLeafThreads) void setsum_leaves(const double* __re
     }
     __syncthreads();
     for (int r = 0; r < len - n8; ++r) add_terms(r);   // same in every lane
+  }
+  if (kC == 2) {
+#pragma unroll
+    for (int s = 0; s < kS; ++s) {
+      const double tied = (double)(hits[s][0] + hits[s][1] - (uint32_t)len);
+      acc[s][0] = (double)hits[s][0] - 0.5 * tied;      // exact: integers and halves
+      acc[s][1] = (double)hits[s][1] - 0.5 * tied;
+    }
   }
   if (j == 0) {
 #pragma unroll

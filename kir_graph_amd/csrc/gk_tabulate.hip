@@ -758,6 +758,69 @@ __global__ __launch_bounds__(kThreads) void gather_pairs(const gk_mate* mates, c
   nh[i] = (uint8_t)(w1 >> 24);
 }
 
+// ---- the records of a sample in a compact form (gk_mates_compact / gk_mates_expand): per mate only the words it uses
+// -- the 12-byte header, its CIGAR operations, its mismatches, its inserted-string ids -- behind a table of word offsets.
+// A 150-base mate with one CIGAR operation and three mismatches takes 7 words + its offset instead of 32.
+__device__ inline int mate_used_words(const uint32_t* w, int* n_cw, int* n_mm, int* n_ins) {
+  const uint32_t h = w[2];
+  const int n_cig = (int)((h >> 8) & 0xFFu);
+  const bool spilled = n_cig == GK_SPILLED;       // header + ins[0] = the pair's place in the wide array
+  *n_cw = spilled ? 0 : (min(n_cig, GK_MAX_CIG) + 1) / 2;
+  *n_mm = spilled ? 0 : min((int)((h >> 16) & 0xFFu), GK_MAX_MM);
+  *n_ins = spilled ? 1 : min((int)(h >> 24), GK_MAX_INS);
+  return 3 + *n_cw + *n_mm + *n_ins;
+}
+
+__global__ __launch_bounds__(kThreads) void mates_count_words(const gk_mate* mates, int64_t n, uint32_t* cnt) {
+  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (m >= n) return;
+  int a, b, c;
+  cnt[m] = (uint32_t)mate_used_words(reinterpret_cast<const uint32_t*>(mates + m), &a, &b, &c);
+}
+
+__global__ __launch_bounds__(kThreads) void mates_pack_words(const gk_mate* mates, int64_t n, const uint32_t* off,
+                                                             uint32_t* off_out, uint32_t* words, uint32_t total) {
+  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (m > n) return;
+  if (m == n) { off_out[n] = total; return; }
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(mates + m);
+  int n_cw, n_mm, n_ins;
+  mate_used_words(w, &n_cw, &n_mm, &n_ins);
+  uint32_t* d = words + off[m];
+  off_out[m] = off[m];
+  d[0] = w[0]; d[1] = w[1]; d[2] = w[2];
+  d += 3;
+  for (int i = 0; i < n_cw; ++i) d[i] = w[kCigWord + i];
+  d += n_cw;
+  for (int i = 0; i < n_mm; ++i) d[i] = w[kMmWord + i];
+  d += n_mm;
+  for (int i = 0; i < n_ins; ++i) d[i] = w[kInsWord + i];
+}
+
+__global__ __launch_bounds__(kThreads) void mates_unpack_words(const uint32_t* off, const uint32_t* words, int64_t n,
+                                                               gk_mate* mates) {
+  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (m >= n) return;
+  const uint32_t* s = words + off[m];
+  uint32_t rec[kMateWords];
+#pragma unroll
+  for (int i = 0; i < kMateWords; ++i) rec[i] = 0u;
+  rec[0] = s[0]; rec[1] = s[1]; rec[2] = s[2];
+  int n_cw, n_mm, n_ins;
+  mate_used_words(rec, &n_cw, &n_mm, &n_ins);
+  uint32_t* d = reinterpret_cast<uint32_t*>(mates + m);
+  uint4* d4 = reinterpret_cast<uint4*>(d);
+#pragma unroll
+  for (int i = 0; i < kMateWords / 4; ++i) d4[i] = make_uint4(0u, 0u, 0u, 0u);
+  d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+  s += 3;
+  for (int i = 0; i < n_cw; ++i) d[kCigWord + i] = s[i];
+  s += n_cw;
+  for (int i = 0; i < n_mm; ++i) d[kMmWord + i] = s[i];
+  s += n_mm;
+  for (int i = 0; i < n_ins; ++i) d[kInsWord + i] = s[i];
+}
+
 inline unsigned nblk(int64_t n, int t = kThreads) { return (unsigned)((n + t - 1) / t); }
 
 }  // namespace
@@ -1084,6 +1147,49 @@ int gk_tab_destroy(gk_tab* tab) {
   for (auto& part : tab->part)
     if (part.d_rows) gk_pool_free(part.owner, part.d_rows);
   delete tab;
+  return GK_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+/* The packed records of a sample in a compact form for the time between its depth and its typing (--cn-cohort types a
+ * sample only after the pooled fit of the whole cohort, main.py:572-589; hisat2.py:228-276 is what the records hold):
+ * uint32 offsets [n_mates + 1] followed by the words the mates use.  *d_compact_out is a block of the context's pool
+ * (gk_free), *bytes_out its size.  gk_mates_expand writes the 128-byte records back (unused parts zero). */
+int gk_mates_compact(gk_ctx* ctx, gk_dptr d_mates, int64_t n_mates, gk_dptr* d_compact_out, int64_t* bytes_out) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && d_compact_out && bytes_out && n_mates >= 0 && (n_mates == 0 || d_mates), "bad compaction arguments");
+  GK_REQUIRE(n_mates < (1ll << 27), "more than 2^26 pairs per call");
+  hipStream_t st = ctx->stream;
+  const gk_mate* mates = gk_ptr<const gk_mate>(d_mates);
+  uint32_t* cnt = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&cnt, (size_t)(n_mates + 2) * sizeof(uint32_t)));
+  if (n_mates) GK_KERNEL(mates_count_words, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, cnt);
+  int rc = gk_scan_u32(ctx, cnt, n_mates, cnt + n_mates);
+  if (rc) { gk_pool_free(ctx, cnt); return rc; }
+  uint32_t total = 0;
+  GK_HIP(gk_fetch(ctx, &total, cnt + n_mates, sizeof(uint32_t)));
+  const size_t bytes = ((size_t)(n_mates + 1) + (size_t)total) * sizeof(uint32_t);
+  uint32_t* out = nullptr;
+  GK_HIP(gk_pool_malloc(ctx, (void**)&out, bytes));
+  GK_KERNEL(mates_pack_words, dim3(nblk(n_mates + 1)), dim3(kThreads), 0, st, mates, n_mates, cnt, out, out + n_mates + 1, total);
+  GK_HIP(hipGetLastError());
+  gk_pool_free(ctx, cnt);      // stream-ordered reuse
+  *d_compact_out = gk_addr(out);
+  *bytes_out = (int64_t)bytes;
+  return GK_OK;
+}
+
+int gk_mates_expand(gk_ctx* ctx, gk_dptr d_compact, int64_t n_mates, gk_dptr d_mates_out) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && n_mates >= 0 && (n_mates == 0 || (d_compact && d_mates_out)), "bad expansion arguments");
+  if (!n_mates) return GK_OK;
+  const uint32_t* off = gk_ptr<const uint32_t>(d_compact);
+  GK_KERNEL(mates_unpack_words, dim3(nblk(n_mates)), dim3(kThreads), 0, ctx->stream, off, off + n_mates + 1, n_mates,
+            gk_ptr<gk_mate>(d_mates_out));
+  GK_HIP(hipGetLastError());
   return GK_OK;
 }
 

@@ -338,7 +338,10 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
 #pragma unroll
           for (int s = 0; s < kSlots; ++s) {
             if (!((nz[s] >> t) & 1ull)) {      // wave-uniform: nobody in this slot has variant t
-              p[s] *= positive ? 0.001 : 0.999;
+              // ONE multiply by a scalar constant, issued here (written as an instruction so that the compiler does not
+              // turn it into "move the constant, join the other path's multiply": two VALU operations)
+              const double c = positive ? 0.001 : 0.999;
+              asm volatile("v_mul_f64 %0, %0, %1" : "+v"(p[s]) : "s"(c));
               if (kMiss && positive) miss[s] += 1u;
               continue;
             }

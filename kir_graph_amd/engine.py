@@ -74,6 +74,7 @@ class Tabulation:
         ``spill``: (records of the pairs that do not fit ``gk_mate``, in the wide format, 2 per pair; the pairs they
         stand for, ascending) as the packer hands them out -- None when every pair fits."""
         self.dev, self.dindex = dev or dindex.dev, dindex
+        self._spill, self._correction = spill, correction      # host arrays, kept for a second tabulation (ParkedRecords)
         if isinstance(mates, np.ndarray):
             assert mates.dtype == _lib.MATE_DTYPE
             self.mates = self.dev.put(mates)

@@ -247,6 +247,58 @@ class SampleData:
         return self
 
 
+class ParkedRecords:
+    """A sample between its depth and its typing, when the two are a cohort apart (``--cn-cohort``: the copy numbers come
+    from ONE fit on the depths of all samples, main.py:572-589, so no sample can be typed before the last one is read).
+
+    What waits in HBM is the sample's packed records in compact form (``gk_mates_compact``: ~30 bytes per mate, ~150 MB
+    per 5 M reads) instead of its tabulation (~1 GB): the lists are made again from them when the sample's turn comes
+    (``restore``: expansion + ``gk_tabulate``, a millisecond or two) -- same records, same index, same first novel id, so
+    the same lists and the same ``nv`` ids."""
+
+    def __init__(self, data: "SampleData"):
+        import ctypes as C
+        tab = data.tab
+        if tab.mates is None:
+            raise ValueError("the packed records of the sample have been released already")
+        self.dev, self.dindex, self.index = tab.dev, tab.dindex, data.index
+        self.ins_strings = data.ins_strings
+        self.n_pairs, self.novel_base = tab.n_pairs, tab.novel_base
+        self.expect = (tab.n_valid, tab.n_ids, tab.n_novel)
+        self.spill, self.correction = getattr(tab, "_spill", None), getattr(tab, "_correction", None)
+        ptr, nbytes = C.c_uint64(), C.c_int64()
+        check(lib().gk_mates_compact(self.dev.ctx, tab.mates.ptr, 2 * self.n_pairs, C.byref(ptr), C.byref(nbytes)))
+        self.ptr, self.nbytes = ptr.value, int(nbytes.value)
+        tab.mates.free()
+        tab.mates = None
+        tab.close()
+
+    def restore(self) -> "SampleData":
+        """The tabulated sample again (its compact records are released)."""
+        if not self.ptr:
+            raise ValueError("restored already")
+        mates = self.dev.alloc(2 * self.n_pairs, _lib.MATE_DTYPE)
+        check(lib().gk_mates_expand(self.dev.ctx, self.ptr, 2 * self.n_pairs, mates.ptr))
+        self.release()                      # stream-ordered: the expansion is queued before the block is reused
+        tab = Tabulation(self.dindex, mates, novel_base=self.novel_base, dev=self.dev, spill=self.spill,
+                         correction=self.correction)
+        if (tab.n_valid, tab.n_ids, tab.n_novel) != self.expect:
+            raise AssertionError(f"second tabulation differs from the first: {(tab.n_valid, tab.n_ids, tab.n_novel)} "
+                                 f"!= {self.expect}")
+        return SampleData(tab, self.index, None, ins_strings=self.ins_strings)
+
+    def release(self) -> None:
+        if self.ptr:
+            lib().gk_free(self.dev.ctx, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 COMPACT_FORMAT = "graphkir-variant-csr-1"
 
 

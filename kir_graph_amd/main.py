@@ -28,7 +28,7 @@ import pandas as pd
 
 from . import cohort
 from .external_tools import setEngine
-from .hisat2 import (SampleData, extractVariant, extractVariantFromPacked, extractVariantFromText,  # noqa: F401
+from .hisat2 import (ParkedRecords, SampleData, extractVariant, extractVariantFromPacked, extractVariantFromText,  # noqa: F401
                      packAlignments, readExons, readPair,
                      saveReadsToBam, writeCompact,
                      writeReadsAndVariantsData, writeSampleJson)
@@ -64,13 +64,15 @@ def hisatMap(index: str, f1: str, f2: str, output_file: str, threads: int = 1) -
     runTool("samtools", ["samtools", "index", f"-@{threads}", f"{name}.bam"])
 
 
-def mapSamples(names, reads, index, index_ref, exon_region_only=False, alignments=None, write_json=True):
+def mapSamples(names, reads, index, index_ref, exon_region_only=False, alignments=None, write_json=True,
+               keep_records=False):
     """Graph mapping (external) -> tabulation (GPU) -> depth (GPU), one sample at a time (main.py:124-168).
 
     Yields ``(alignment file, "{name}.variant", SampleData, depth file)`` per sample, in order.  When a sample
     is yielded its by-products are on disk and its depth is computed, so what only they needed -- the SAM
     text of the pairs and the packed records in HBM -- has been released: the consumer holds the CSR of the
-    tabulation only (and closes it after typing), whatever the size of the cohort."""
+    tabulation only (and closes it after typing), whatever the size of the cohort.  ``keep_records``: the packed
+    records stay in HBM with the sample (``--cn-cohort`` parks a sample as its compact records, ``ParkedRecords``)."""
     gk = GkIndex.load(index_ref)
     gene_len = readLocusLengths(index_ref)
     dev = defaultDevice()
@@ -104,14 +106,15 @@ def mapSamples(names, reads, index, index_ref, exon_region_only=False, alignment
     writes = []
     try:
         yield from _mapLoop(names, prepare, ahead, gk, gene_len, (copier, ingest), dindex, index_ref, exon_region_only,
-                            write_json, writer, writes)
+                            write_json, writer, writes, keep_records)
     finally:
         for w in writes:
             w.result()          # every hand-off file is complete (and any write error surfaces) before we return
         writer.shutdown()
 
 
-def _mapLoop(names, prepare, ahead, gk, gene_len, staging, dindex, index_ref, exon_region_only, write_json, writer, writes):
+def _mapLoop(names, prepare, ahead, gk, gene_len, staging, dindex, index_ref, exon_region_only, write_json, writer, writes,
+             keep_records=False):
     copier, dev = staging
     for name, source, pack in cohort.prefetched(range(len(names)), prepare, depth=ahead, workers=ahead):
         name += ".variant"
@@ -140,17 +143,17 @@ def _mapLoop(names, prepare, ahead, gk, gene_len, staging, dindex, index_ref, ex
             logger.info(f"[Graph] Filter exon read to {depth_name}.exon.tsv")
             filterDepth(depth_name + ".tsv", depth_name + ".exon.tsv", readExons(index_ref))
             depth_name += ".exon"
-        releaseInputs(data)
+        releaseInputs(data, keep_records)
         yield source, name, data, depth_name + ".tsv"
 
 
-def releaseInputs(data: SampleData) -> None:
+def releaseInputs(data: SampleData, keep_records: bool = False) -> None:
     """Drop what only the by-products and the depth needed: the SAM text of the pairs (host) and the packed
-    records (HBM, 256 B per pair).  The tabulation's lists stay for typing."""
+    records (HBM, 256 B per pair; unless ``keep_records``).  The tabulation's lists stay for typing."""
     data.pairs_text = None
     data._reads = None
     mates = getattr(data.tab, "mates", None)
-    if mates is not None:
+    if mates is not None and not keep_records:
         mates.free()
         data.tab.mates = None
 
@@ -192,7 +195,12 @@ def sampleTyper(method: str, release: bool = True) -> "cohort.SampleTyper":
     def finish(typer, called_alleles, warning_genes, item):
         name, cn_file, source = item
         if release or not isinstance(source, SampleData):      # done with this sample: free its HBM
-            typer._data.tab.close()
+            tab = typer._data.tab
+            mates = getattr(tab, "mates", None)
+            if mates is not None:
+                mates.free()
+                tab.mates = None
+            tab.close()
         logger.info(f"[Allele] {called_alleles} ({name})")
         return writeTyping(name + typingSuffix(name, cn_file, method), typer, called_alleles, warning_genes)
 
@@ -361,25 +369,34 @@ def _typeShare(args, lanes, names, reads, my_cn, pick, index, index_ref, cohort_
     budget = int(float(os.environ.get("GK_RETAIN_GB", "64")) * 2**30)   # tabulations kept in HBM until the pooled fit
     samples = mapSamples(names, reads, index, index_ref, exon_region_only=args.cn_exon,
                          alignments=pick(args.alignment) if args.alignment else None,
-                         write_json=not args.no_variant_json)
+                         write_json=not args.no_variant_json, keep_records=pooled_fit and not args.step_skip_typing)
     for i, (_, name, data, depth_file) in enumerate(samples):
         depth_files.append(depth_file)
         if pooled_fit:
-            # every sample's depth is needed before any can be typed: keep the tabulation on the device while it
-            # fits the budget, else park it in the compact side-format and reload it for typing
-            size = 4 * (data.tab.n_ids + 4 * data.tab.n_valid) + 6 * data.tab.n_valid
-            if not args.step_skip_typing and retained + size > budget:
+            # every sample's depth is needed before any can be typed.  What waits in HBM is the sample's packed records in
+            # compact form (ParkedRecords: ~150 MB per 5 M reads), not its tabulation (~1 GB): the lists are made again when
+            # its turn comes.  Beyond the budget a sample is parked in a hand-off file and reloaded for typing.
+            if args.step_skip_typing:
+                data.tab.close()
+                waiting.append((name, None))
+                continue
+            size = int(0.12 * 256 * data.tab.n_pairs) + (1 << 20)      # what the compact records will take, roughly
+            if retained + size > budget or data.tab.mates is None:
                 if args.no_variant_json:
                     parked = name + ".npz"          # already written by mapSamples, unless hand-off files are lazy
                     if os.environ.get("GK_HANDOFF", "always") == "lazy":
                         writeCompact(data, parked, index_ref=index_ref)
                 else:
                     parked = name + ".json"
+                if data.tab.mates is not None:
+                    data.tab.mates.free()
+                    data.tab.mates = None
                 data.tab.close()
                 waiting.append((name, parked))
             else:
-                retained += size
-                waiting.append((name, data))
+                parked = ParkedRecords(data)        # compacts the records, releases them and the tabulation
+                retained += parked.nbytes
+                waiting.append((name, parked))
             continue
         if not my_cn[i]:
             cn_name = str(Path(depth_file).with_suffix(f".{args.cn_select}.{args.cn_algorithm}"))
@@ -404,9 +421,9 @@ def _typeShare(args, lanes, names, reads, my_cn, pick, index, index_ref, cohort_
                          save_cn_model_path=cohort_name + suffix + ".json", select_mode=args.cn_select, comm=comm)
         for (name, source), cn_file in zip(waiting, my_cn):
             if args.step_skip_typing:
-                if isinstance(source, SampleData):
-                    source.tab.close()
                 continue
+            if isinstance(source, ParkedRecords):
+                source = source.restore()           # expansion + tabulation, while the lanes type the samples before it
             lanes.submit(source, (lambda f=cn_file: loadCN(f)), (name, cn_file, source))
             if lanes.inFlight() >= lanes.lanes:
                 allele_files.append(lanes.next())

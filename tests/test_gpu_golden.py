@@ -130,3 +130,48 @@ def test_reads_beyond_the_128_byte_record_equal_the_reference(device, tmp_path, 
     novel = [[v.id, v.typ, v.pos, v.val, v.length, v.ref] for v in data.variants if str(v.id).startswith("nv")]
     assert novel == t12["novel"]
     data.tab.close()
+
+
+def test_a_parked_sample_comes_back_with_the_reference_lists(device, tmp_path):
+    """--cn-cohort keeps a sample between its depth and its typing as its packed records in compact form
+    (ParkedRecords: gk_mates_compact); expanded and tabulated again they give the reference's lists and novel ids of
+    fixture T12 -- pairs of the wide format, inserted strings and a first novel id that is not 0 included -- and the records
+    themselves come back word for word where they were used."""
+    import ctypes as C
+    from kir_graph_amd import _lib
+    from kir_graph_amd._lib import check, lib
+    from kir_graph_amd.hisat2 import ParkedRecords
+    t12 = load("t12_wide.json.gz")
+    gidx = index_from(t12["index"], tmp_path)
+    Variant.novel_id = 0
+    data = extractVariant(pairLines(t12["lines"]), gidx, dev=device)
+    before = data.tab.mates.download()
+    n_mates = len(before)
+    off0, ids0 = data.tab.offsets().copy(), data.tab.ids().copy()
+    parked = ParkedRecords(data)
+    assert parked.nbytes < before.nbytes // 2 and data.tab.handle is None and data.tab.mates is None
+    # the records, expanded: every field a kernel reads is back (unused array entries are zero now)
+    again = device.alloc(n_mates, _lib.MATE_DTYPE)
+    check(lib().gk_mates_expand(device.ctx, parked.ptr, n_mates, again.ptr))
+    after = again.download()
+    for f in ("pos0", "flag", "ref", "nh", "nm", "n_cig", "n_mm", "n_ins"):
+        assert np.array_equal(before[f], after[f]), f
+    for m in range(n_mates):
+        r, q = before[m], after[m]
+        if r["n_cig"] == 0xFF:
+            assert r["ins"][0] == q["ins"][0]
+            continue
+        assert np.array_equal(r["cig"][:r["n_cig"]], q["cig"][:r["n_cig"]])
+        assert np.array_equal(r["mm"][:r["n_mm"]], q["mm"][:r["n_mm"]])
+        assert np.array_equal(r["ins"][:r["n_ins"]], q["ins"][:r["n_ins"]])
+    again.free()
+    back = parked.restore()
+    assert parked.ptr == 0
+    assert np.array_equal(back.tab.offsets(), off0) and np.array_equal(back.tab.ids(), ids0)
+    reads = back.reads()
+    assert len(reads) == len(t12["reads"])
+    for got, want in zip(reads, t12["reads"]):
+        assert (got.lpv, got.lnv, got.rpv, got.rnv) == (want["lpv"], want["lnv"], want["rpv"], want["rnv"])
+    novel = [[v.id, v.typ, v.pos, v.val, v.length, v.ref] for v in back.variants if str(v.id).startswith("nv")]
+    assert novel == t12["novel"]
+    back.tab.close()
