@@ -11,8 +11,9 @@ per gene the compatibility table through the log10 value table and the greedy mu
 
 Two kinds of timed leg over the same K steps, each bracketed by a barrier + device synchronise on both sides, each kind
 timed `--legs` times (default 3) with the MEDIAN leg reported:
-  host  (`value`)         a sample's records start in PINNED HOST MEMORY: the 256 MB host-to-device copy is inside the
-                          region (SURVEY.md section 8(d)), staged two samples ahead of the typing;
+  host  (`value`)         a sample's records start in PINNED HOST MEMORY, in the compact form they cross PCIe in (~30 bytes
+                          per mate: packed.CompactMates): the host-to-device copy and the expansion into 128-byte
+                          records are inside the region (SURVEY.md section 8(d)), staged two samples ahead of the typing;
   hbm   (`hbm_resident`)  the records of the distinct samples are resident in HBM before the clock starts.
 `--inputs hbm` swaps the two (`value` from resident records, `pcie_inclusive` beside it).
 Consecutive steps take DIFFERENT samples: `--distinct N` (default 8) distinct ones per rank in rotation, seeds
@@ -156,30 +157,22 @@ def build_inputs(seed: int, n_pairs: int, index_seed: int = 2022):
 
 
 class PinnedRecords:
-    """The packed records of a sample in pinned host memory (gk_host_alloc): the start of a step."""
+    """The packed records of a sample in pinned host memory, in the compact form they cross PCIe in
+    (``packed.CompactMates``: ~30 bytes per mate instead of 128): the start of a step."""
 
     def __init__(self, rec):
-        import numpy as np
-        from kir_graph_amd._lib import check, lib
-        self.nbytes, self.count, self.dtype = rec.nbytes, len(rec), rec.dtype
-        p = C.c_void_p()
-        check(lib().gk_host_alloc(self.nbytes, C.byref(p)))
-        self.ptr = p.value
-        view = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self.ptr))
-        view[:] = rec.view(np.uint8).reshape(-1)
+        from kir_graph_amd.packed import CompactMates
+        self.compact = CompactMates(rec, threads=4)
+        self.nbytes, self.count, self.dtype = self.compact.nbytes, len(rec), rec.dtype
+        self.record_bytes = rec.nbytes
 
     def toDevice(self, dev):
-        """Queue the copy on ``dev``'s stream; kernels launched on that stream afterwards see the records."""
-        from kir_graph_amd._lib import check, lib
-        buf = dev.alloc(self.count, self.dtype)
-        check(lib().gk_h2d_async(dev.ctx, buf.ptr, C.c_void_p(self.ptr), self.nbytes))
-        return buf
+        """Queue the copy and the expansion into 128-byte records on ``dev``'s stream; kernels launched on that stream
+        afterwards see the records."""
+        return self.compact.toDevice(dev)
 
     def free(self):
-        from kir_graph_amd._lib import lib
-        if self.ptr:
-            lib().gk_host_free(C.c_void_p(self.ptr))
-            self.ptr = 0
+        self.compact = None
 
 
 # ------------------------------------------------------------------------------------------ steps
@@ -360,8 +353,9 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
         inputs.append((PinnedRecords(rec), table, sample.gene_cn))
         samples.append(sample)
         del rec
-    log(f"[bench] rank {rank} worker {j}: {len(inputs)} samples of {args.pairs} pairs in pinned memory "
-        f"({time.time() - t_in:.1f}s)")
+    log(f"[bench] rank {rank} worker {j}: {len(inputs)} samples of {args.pairs} pairs in pinned memory, "
+        f"{inputs[0][0].nbytes / 1e6:.0f} MB each in compact form ({inputs[0][0].record_bytes / 1e6:.0f} MB as 128-byte records; "
+        f"{time.time() - t_in:.1f}s)")
     dindex = DeviceIndex(dev, gidx)
     dev.sync()
     comm = None
@@ -413,7 +407,7 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
         return prof, call_log
 
     # Two kinds of timed leg over the same steps.  "host": every sample's packed records start in pinned host memory, the
-    # 256 MB host-to-device copy is inside the region (the metric) -- `value`.  "hbm": the records
+    # host-to-device copy (compact records) + expansion are inside the region (the metric) -- `value`.  "hbm": the records
     # of the distinct samples are resident in HBM before any clock starts, a step = tabulation + typing + calls --
     # `hbm_resident`.  Each kind is timed `--legs` times (alternating), the median leg is reported.
     from kir_graph_amd.typing_mulit_allele import sharedLogTable
@@ -529,7 +523,8 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
                 for key in ("samples", "samples_repeated_pass", "tables_rewritten", "tables_patched", "value_table_new"):
                     mine[key] = mine.get(key, 0) + theirs.get(key, 0)
     return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm, "n_values": n_values,
-            "search_steps": dict(SEARCH_STATS), "others": others, "cli_stage": cli_stage}
+            "search_steps": dict(SEARCH_STATS), "others": others, "cli_stage": cli_stage,
+            "h2d_bytes": inputs[0][0].nbytes, "record_bytes": inputs[0][0].record_bytes}
 
 
 # ------------------------------------------------------------------------------------------ launcher
@@ -577,7 +572,7 @@ def main():
                     help="steps of the one-process serial pass after the timed region (roofline basis; 0 = skip)")
     ap.add_argument("--inputs", choices=("host", "hbm"), default="host",
                     help="where a sample's records are when its step starts -- what `value` is measured on: pinned host "
-                         "memory (the 256 MB copy inside the step: SURVEY.md section 8(d), the metric), or resident in "
+                         "memory (the copy inside the step: SURVEY.md section 8(d), the metric), or resident in "
                          "HBM (a step = tabulation + typing + calls).  The other kind is timed too and reported beside it")
     ap.add_argument("--one-kind", "--no-pcie-leg", dest="both_legs", action="store_false",
                     help="time only the kind of leg --inputs names (no second object in the JSON line)")
@@ -719,6 +714,7 @@ def main():
                                       "inside the timed region); pcie_inclusive: the same steps from pinned host memory")
                                    + f"; median of {len(legs[args.inputs])} timed legs of {args.steps} steps",
                        "inputs": args.inputs,
+                       "h2d_bytes_per_sample": res.get("h2d_bytes"), "record_bytes_per_sample": res.get("record_bytes"),
                        "pairs_per_sample": args.pairs, "pairs_passing_filter": int(n_valid),
                        "parallelism": f"samples sharded over {world} GPU(s), no data-path collective; "
                                       f"{procs} worker process(es) per GPU, {os.environ.get('GK_SAMPLE_LANES', '2')} samples in flight "
@@ -785,7 +781,7 @@ def main():
                 "host_core_s_per_step": float(o["cpu_s"]) / args.steps,
                 "legs": leg_rows(kind),
                 "note": (f"the same {args.steps} steps with every sample's packed records starting in pinned host memory: "
-                         f"the {256 * args.pairs // 1_000_000} MB host-to-device copy of each sample is inside the timed "
+                         "the host-to-device copy of each sample (compact records) and their expansion are inside the timed "
                          "region (staged two samples ahead of the typing)" if kind == "host" else
                          f"the same {args.steps} steps with the records of the distinct samples resident in HBM before the "
                          "clock starts (a step = tabulation + typing + calls)") + f"; median of {len(legs[kind])} legs"}

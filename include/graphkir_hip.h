@@ -499,6 +499,12 @@ int gk_comm_barrier(gk_comm* comm);
  * its size.  gk_mates_expand writes the records back (unused parts zero); gk_tabulate on them gives the same lists. */
 int gk_mates_compact(gk_ctx* ctx, gk_dptr d_mates, int64_t n_mates, gk_dptr* d_compact_out, int64_t* bytes_out);
 int gk_mates_expand(gk_ctx* ctx, gk_dptr d_compact, int64_t n_mates, gk_dptr d_mates_out);
+/* The same compact form made on the HOST (no device needed): what crosses PCIe for a sample is then ~30 bytes per mate
+ * instead of 128, and gk_mates_expand writes the 128-byte records where the tabulation reads them.  gk_mates_compact_size:
+ * the words the mates take (offsets not counted); gk_mates_compact_host: `out` = uint32 [n_mates + 1 + words], the layout
+ * of gk_mates_compact.  n_threads: host threads for the two passes over the records. */
+int gk_mates_compact_size(const gk_mate* mates, int64_t n_mates, int32_t n_threads, int64_t* n_words_out);
+int gk_mates_compact_host(const gk_mate* mates, int64_t n_mates, int32_t n_threads, uint32_t* out, int64_t capacity_words);
 
 /* ---- pinned host memory for the packed records of a sample (the packer's output on its way to HBM) and a
  * host-to-device copy that is only queued on the context's stream (gk_h2d waits for it). */

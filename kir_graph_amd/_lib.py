@@ -192,6 +192,8 @@ _SIGS = {
                                  C.POINTER(C.c_int32)]),
     "gk_mates_compact": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]),
     "gk_mates_expand": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64]),
+    "gk_mates_compact_size": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
+    "gk_mates_compact_host": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64]),
     "gk_compat_patch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_uint64, C.c_int64, C.c_uint64]),
     "gk_lut_resolve_stored": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32)]),

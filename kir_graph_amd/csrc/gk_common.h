@@ -110,8 +110,6 @@ int gk_ctx_scratch(gk_ctx* ctx, size_t bytes, void** out);
 // until the stream has passed it
 hipError_t gk_send(gk_ctx* ctx, void* dst_dev, const void* src, size_t bytes);
 size_t gk_stage_direct();
-// copy from a pinned, device-mapped host block (the send ring) by a kernel on the context's stream, 16-byte aligned
-hipError_t gk_copy_from_host(gk_ctx* ctx, void* dst_dev, const void* src_pinned, size_t bytes);
 // device -> host through the pinned ring: queue any number of copies, then wait once (stream synchronise) and have
 // them delivered to their destinations; gk_fetch = queue + wait.  `dst` must stay valid until the delivery.
 hipError_t gk_fetch_queue(gk_ctx* ctx, void* dst, const void* src_dev, size_t bytes);

@@ -171,39 +171,6 @@ int gk_timer_stop_ms(gk_ctx* ctx, float* ms) {
 constexpr size_t kStageDirect = (size_t)4 << 20;   // larger transfers go straight to / from the caller's memory
 size_t gk_stage_direct() { return kStageDirect; }
 
-// A small host-to-device copy done by a KERNEL that reads the context's pinned ring over PCIe (hipHostMalloc memory is
-// mapped into the device's address space) instead of by the runtime's DMA path: the parameter blocks of the search
-// stages (5 - 125 KB, ~45 per sample) then do not queue behind the 256 MB transfer of the sample being staged on the one
-// DMA engine that serves host-to-device copies.  (The BULK copy by such a kernel was measured and lost: 12.3 against
-// 9.2 ms per sample -- 64 workgroups of loads over PCIe hold wave slots for milliseconds.)
-namespace {
-constexpr int kCopyThreads = 256, kCopyUnroll = 4;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(kCopyThreads) void copy_from_host(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int64_t n16,
-                                                               uint8_t* dst_tail, const uint8_t* src_tail, int n_tail) {
-  const int64_t stride = (int64_t)gridDim.x * kCopyThreads;
-  int64_t i = (int64_t)blockIdx.x * kCopyThreads + threadIdx.x;
-  for (; i + (kCopyUnroll - 1) * stride < n16; i += kCopyUnroll * stride) {
-    u32x4 v[kCopyUnroll];
-#pragma unroll
-    for (int u = 0; u < kCopyUnroll; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
-#pragma unroll
-    for (int u = 0; u < kCopyUnroll; ++u) dst[i + u * stride] = v[u];
-  }
-  for (; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
-  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
-}
-}  // namespace
-
-hipError_t gk_copy_from_host(gk_ctx* ctx, void* dst_dev, const void* src_pinned, size_t bytes) {
-  const int64_t n16 = (int64_t)(bytes / 16);
-  const int n_tail = (int)(bytes % 16);
-  const int64_t want = (n16 + kCopyThreads * kCopyUnroll - 1) / (kCopyThreads * kCopyUnroll);
-  hipLaunchKernelGGL(copy_from_host, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, 32))), dim3(kCopyThreads), 0,
-                     ctx->stream, (u32x4*)dst_dev, (const u32x4*)src_pinned, n16, (uint8_t*)dst_dev + 16 * n16,
-                     (const uint8_t*)src_pinned + 16 * n16, n_tail);
-  return hipGetLastError();
-}
 
 // ---- the two rings and the marks that give their space back
 namespace {
@@ -290,10 +257,6 @@ hipError_t gk_send(gk_ctx* ctx, void* dst_dev, const void* src, size_t bytes) {
   if (e != hipSuccess) return e;
   char* slot = (char*)ctx->send_ring.base + off;
   memcpy(slot, src, bytes);
-  // GK_SEND=kernel: the block is read out of the ring by a copy kernel on the stream (slots are 64-byte aligned)
-  static const bool by_kernel = [] { const char* e = getenv("GK_SEND"); return e && !strcmp(e, "kernel"); }();
-  if (by_kernel && bytes <= ((size_t)1 << 20) && ((uintptr_t)dst_dev & 15u) == 0)
-    return gk_copy_from_host(ctx, dst_dev, slot, bytes);
   return hipMemcpyAsync(dst_dev, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
 }
 

@@ -78,6 +78,8 @@ class Tabulation:
         if isinstance(mates, np.ndarray):
             assert mates.dtype == _lib.MATE_DTYPE
             self.mates = self.dev.put(mates)
+        elif hasattr(mates, "toDevice"):      # packed.CompactMates: copied compact, expanded in HBM
+            self.mates = mates.toDevice(self.dev)
         else:
             self.mates = mates
         self.n_pairs = self.mates.size // 2

@@ -96,6 +96,10 @@ def mapSamples(names, reads, index, index_ref, exon_region_only=False, alignment
         if source.endswith((".sam", ".sam.gz")) or os.environ.get("GK_BAM_READER", "native") != "samtools":
             # SAM text, or BAM decoded + name-collated natively (packed.bamChunks / packBam), packed natively
             pack = packAlignments(source, gk, keep_text=write_json)
+            if os.environ.get("GK_COMPACT_H2D", "1") != "0":
+                # the records cross PCIe in compact form (~30 bytes per mate instead of 128), like the bench's steps
+                from .packed import CompactMates
+                pack["compact"] = CompactMates(pack["records"], threads=2)
         return name, source, pack
 
     # the next sample is mapped / packed on a helper thread while this one is tabulated and written out
@@ -120,7 +124,9 @@ def _mapLoop(names, prepare, ahead, gk, gene_len, staging, dindex, index_ref, ex
         name += ".variant"
         logger.info(f"[Graph] Filter mapping ({name})")
         if pack is not None:
-            mates = copier.put(pack["records"])      # pinned records -> HBM on the copier's stream (gk_h2d waits for it)
+            # pinned records -> HBM on the copier's stream: compact words copied and expanded there, or the 128-byte records
+            compact = pack.pop("compact", None)
+            mates = compact.toDevice(copier, wait=True) if compact is not None else copier.put(pack["records"])
             data = extractVariantFromPacked(pack, gk, dev=dev, dindex=dindex, mates=mates)
         else:   # BAM name-collated through samtools like the reference (hisat2.readBam)
             data = extractVariant(readPair(source), gk, dev=dev, dindex=dindex)

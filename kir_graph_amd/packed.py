@@ -537,3 +537,38 @@ def _rankWithin(group: np.ndarray, sel: np.ndarray) -> np.ndarray:
     start[1:] = group[1:] != group[:-1]
     first = np.maximum.accumulate(np.where(start, np.arange(n), 0))
     return (before - before[first]).astype(np.int64)
+
+
+class CompactMates:
+    """Packed records in compact form on the host (``gk_mates_compact_host``): uint32 word offsets ``[n_mates + 1]``
+    followed by the words the mates use -- ~30 bytes per mate instead of 128.  This is what crosses PCIe for a sample;
+    ``toDevice`` queues the copy and the expansion into 128-byte records (``gk_mates_expand``) on a context's stream."""
+
+    def __init__(self, records: np.ndarray, threads: int = 4):
+        import ctypes as C
+        from ._lib import MATE_DTYPE, check, lib, pinnedEmpty
+        assert records.dtype == MATE_DTYPE
+        records = np.ascontiguousarray(records)
+        self.n_mates = len(records)
+        n_words = C.c_int64()
+        check(lib().gk_mates_compact_size(records.ctypes.data, self.n_mates, threads, C.byref(n_words)))
+        self.words = pinnedEmpty(self.n_mates + 1 + n_words.value, np.uint32)
+        check(lib().gk_mates_compact_host(records.ctypes.data, self.n_mates, threads, self.words.ctypes.data, len(self.words)))
+
+    @property
+    def nbytes(self) -> int:
+        return int(self.words.nbytes)
+
+    def toDevice(self, dev, wait: bool = False):
+        """The 128-byte records in HBM (a device buffer of ``MATE_DTYPE``): compact words copied (queued on ``dev``'s
+        stream; ``wait``: synchronised) and expanded there."""
+        import ctypes as C
+        from ._lib import MATE_DTYPE, check, lib
+        compact = dev.alloc(len(self.words), np.uint32)
+        check(lib().gk_h2d_async(dev.ctx, compact.ptr, C.c_void_p(self.words.ctypes.data), self.words.nbytes))
+        mates = dev.alloc(self.n_mates, MATE_DTYPE)
+        check(lib().gk_mates_expand(dev.ctx, compact.ptr, self.n_mates, mates.ptr))
+        compact.free()          # the pool reuses the block in stream order: after the expansion
+        if wait:
+            dev.sync()
+        return mates

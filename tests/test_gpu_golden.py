@@ -148,8 +148,12 @@ def test_a_parked_sample_comes_back_with_the_reference_lists(device, tmp_path):
     before = data.tab.mates.download()
     n_mates = len(before)
     off0, ids0 = data.tab.offsets().copy(), data.tab.ids().copy()
+    from kir_graph_amd.packed import CompactMates
+    on_host = CompactMates(before, threads=2)      # the same compact form made by the host packer's side
     parked = ParkedRecords(data)
     assert parked.nbytes < before.nbytes // 2 and data.tab.handle is None and data.tab.mates is None
+    assert parked.nbytes == on_host.nbytes
+    assert np.array_equal(device.view(parked.ptr, len(on_host.words), np.uint32), on_host.words)
     # the records, expanded: every field a kernel reads is back (unused array entries are zero now)
     again = device.alloc(n_mates, _lib.MATE_DTYPE)
     check(lib().gk_mates_expand(device.ctx, parked.ptr, n_mates, again.ptr))

@@ -1079,3 +1079,31 @@ def test_name_collation_with_a_long_common_prefix(tmp_path):
         samToBam(header + lines, path, block=20000)
         got = b"".join(packed.bamChunks(path, chunk_bytes=1 << 15)).decode().split("\n")[:-1]
         assert got == sorted(lines, key=functools.cmp_to_key(order)), tag
+
+
+def test_compact_records_on_the_host_hold_exactly_the_used_words():
+    """gk_mates_compact_host (what crosses PCIe for a sample: ~24 bytes per mate instead of 128): word offsets + the
+    header, CIGAR, mismatch and inserted-string words each mate uses, in record order, whatever the thread count."""
+    import numpy as np
+    from kir_graph_amd import packed, synth
+    from kir_graph_amd.index import GkIndex
+    sidx = synth.makeIndex(seed=2022, n_genes=3, var_range=(200, 300), allele_range=(12, 24))
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    sample = synth.makeSample(sidx, seed=1031, n_pairs=3000)
+    rec, _ = packed.packSample(sample, gidx)
+    w = rec.view(np.uint32).reshape(len(rec), 32)
+    want, offsets = [], [0]
+    for m in range(len(rec)):
+        h = int(w[m, 2])
+        n_cig, n_mm, n_ins = (h >> 8) & 255, (h >> 16) & 255, h >> 24
+        used = np.concatenate([w[m, :3], w[m, 3:3 + (min(n_cig, 14) + 1) // 2], w[m, 10:10 + min(n_mm, 16)],
+                               w[m, 26:26 + min(n_ins, 6)]])
+        want.append(used)
+        offsets.append(offsets[-1] + len(used))
+    want = np.concatenate(want)
+    assert int(rec["n_ins"].sum()) > 0 and int(rec["n_mm"].max()) > 1      # the case has insertions and mismatches
+    for threads in (1, 3, 8):
+        cm = packed.CompactMates(rec, threads=threads)
+        assert np.array_equal(cm.words[:len(rec) + 1], np.array(offsets, dtype=np.uint32))
+        assert np.array_equal(cm.words[len(rec) + 1:], want)
+        assert cm.nbytes * 4 < rec.nbytes
