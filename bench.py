@@ -251,6 +251,7 @@ def cli_typing_stage(n, dev, dindex, gidx, inputs, resident, method):
         for k in range(n):
             _, table, gene_cn = inputs[k % len(inputs)]
             tab = Tabulation(dindex, resident[k % len(inputs)], dev=ingest)
+            tab.mates = None        # the records are the bench's resident inputs: not this tabulation's to release
             name = os.path.join(tmp, f"s{k:03d}.variant")
             cn_file = name + ".no_multi.depth.p75.LCND.tsv"
             with open(cn_file, "w") as f:
