@@ -27,6 +27,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import re
 import shutil
 import time
 
@@ -120,26 +121,58 @@ class FileStore:
         except OSError:
             pass
 
+    # every key of this package is "<token>.<key>" (or ".<token>.<key>.<pid>.tmp" while it is written); a launch marks
+    # itself alive with "<token>.owner" = the pid of its rank 0 on this node
+    _KEY = re.compile(r"^\.?(?P<token>[0-9A-Za-z_-]+)\.(?:x\d+\.r\d+|bye\.r\d+|rccl_ok\.r\d+|rccl_id|abort|owner)(?:\.\d+\.tmp)?$")
+
+    def claim(self) -> None:
+        """Rank 0: record the pid that owns this launch's keys (what ``purgeOthers`` of a later launch looks at)."""
+        self.set("owner", str(os.getpid()).encode())
+
     def purgeOthers(self, older_than: float = 600.0) -> int:
-        """Remove the keys of other launches that nobody can still be waiting for (older than the ``get`` timeout:
-        what a crashed run left behind); returns how many.  Hygiene only -- such keys are never read."""
+        """Remove the keys a DEAD launch left behind in a shared rendezvous directory; returns how many.  Hygiene only
+        -- keys of other tokens are never read.  Only files that look like this package's keys are touched, and only
+        those of a token whose owner (the pid in its ``owner`` key) no longer exists; a token without an owner key is
+        left alone unless all its files are older than ``older_than`` AND that is more than its ``get`` timeout --
+        a live launch may hold a key for as long as a peer types (a rank parked in a round while another works)."""
         n = 0
-        prefix = self.token + "."
         now = time.time()
         try:
             names = os.listdir(self.path)
         except OSError:
             return 0
+        by_token: dict[str, list[str]] = {}
         for name in names:
-            if name.startswith(prefix) or name.startswith("." + prefix):
-                continue
-            full = os.path.join(self.path, name)
+            m = self._KEY.match(name)
+            if m and m.group("token") != self.token:
+                by_token.setdefault(m.group("token"), []).append(name)
+        for token, files in by_token.items():
+            owner = os.path.join(self.path, f"{token}.owner")
             try:
-                if now - os.path.getmtime(full) >= older_than:
-                    os.remove(full)
+                pid = int(open(owner, "rb").read().decode() or "0")
+            except (OSError, ValueError):
+                pid = 0
+            if pid > 0:
+                try:
+                    os.kill(pid, 0)
+                    continue                      # the launch is alive (or the pid was reused: leave it alone)
+                except ProcessLookupError:
+                    pass
+                except OSError:
+                    continue
+            else:
+                try:
+                    newest = max(os.path.getmtime(os.path.join(self.path, f)) for f in files)
+                except OSError:
+                    continue
+                if now - newest < max(older_than, 2 * self.timeout):
+                    continue
+            for f in files:
+                try:
+                    os.remove(os.path.join(self.path, f))
                     n += 1
-            except OSError:
-                pass
+                except OSError:
+                    pass
         return n
 
 
@@ -158,26 +191,41 @@ class Comm:
         self._dev = dev
         self._cdev = None
         if rank == 0:
+            store.claim()
             store.purgeOthers()
-        if backend == "rccl":
-            from ._lib import Device, check, lib
-            if dev is None:
-                raise CommError("the rccl backend needs the rank's device context")
-            # a context (stream, staging) of its own on the rank's GPU: collectives never queue behind, or in front
-            # of, the typing kernels, and a collective that cannot complete cannot block the compute stream
-            self._cdev = Device(dev.ordinal)
-            if rank == 0:
-                uid = C.create_string_buffer(128)
-                check(lib().gk_comm_unique_id(uid, 128))
-                store.set("rccl_id", uid.raw)
-            uid = store.get("rccl_id")
-            h = C.c_void_p()
-            check(lib().gk_comm_create(self._cdev.ctx, uid, len(uid), rank, world, C.byref(h)))
-            if abandoned is not None and abandoned.is_set():
-                lib().gk_comm_destroy(h)
-                raise CommError("RCCL communicator came up after its deadline; destroyed unused")
-            self._handle = h
-        self.barrier()      # everyone is here (and, with rccl, the communicator works) before anything is removed
+        try:
+            if backend == "rccl":
+                from ._lib import Device, check, lib
+                if dev is None:
+                    raise CommError("the rccl backend needs the rank's device context")
+                # a context (stream, staging) of its own on the rank's GPU: collectives never queue behind, or in front
+                # of, the typing kernels, and a collective that cannot complete cannot block the compute stream
+                self._cdev = Device(dev.ordinal)
+                if rank == 0:
+                    uid = C.create_string_buffer(128)
+                    check(lib().gk_comm_unique_id(uid, 128))
+                    store.set("rccl_id", uid.raw)
+                uid = store.get("rccl_id")
+                h = C.c_void_p()
+                check(lib().gk_comm_create(self._cdev.ctx, uid, len(uid), rank, world, C.byref(h)))
+                if abandoned is not None and abandoned.is_set():
+                    lib().gk_comm_destroy(h)
+                    raise CommError("RCCL communicator came up after its deadline; destroyed unused")
+                self._handle = h
+            self.barrier()      # everyone is here (and, with rccl, the communicator works) before anything is removed
+        except BaseException:
+            self._teardown()    # the private context (stream, pinned rings, pool) does not outlive a failed set-up
+            raise
+
+    def _teardown(self) -> None:
+        """Destroy the communicator and the context it lives on (idempotent; the store is left alone)."""
+        if self._handle is not None:
+            from ._lib import lib
+            lib().gk_comm_destroy(self._handle)
+            self._handle = None
+        if self._cdev is not None:
+            self._cdev.close()
+            self._cdev = None
 
     # ---- host-side exchange through the store (every rank writes one key per round, reads all)
     def _round(self, payload: bytes) -> list[bytes]:
@@ -231,13 +279,7 @@ class Comm:
         if self.store is None:
             return
         self._round(b"")
-        if self._handle is not None:
-            from ._lib import lib
-            lib().gk_comm_destroy(self._handle)
-            self._handle = None
-        if self._cdev is not None:
-            self._cdev.close()
-            self._cdev = None
+        self._teardown()
         # rank 0 removes the directory once every other rank has said it will not read from it again
         if self.rank:
             self.store.set(f"bye.r{self.rank}", b"")
@@ -344,19 +386,15 @@ def initFromEnv(dev=None, backend: str | None = None, fallback: bool = True) -> 
     if all(everyone):
         return made
     if not fallback:
-        if made is not None and made._handle is not None:
-            from ._lib import lib
-            lib().gk_comm_destroy(made._handle)
-            made._handle = None
+        if made is not None:
+            made._teardown()
         raise CommError("RCCL communicator failed on ranks " + str([r for r, ok in enumerate(everyone) if not ok])
                         + (f" (this rank: {why})" if why else ""))
     import sys
     print(f"[comm] rank {rank}: RCCL communicator unavailable ({why or 'another rank failed'}); "
           "control messages go through the rendezvous directory", file=sys.stderr, flush=True)
-    if made is not None and made._handle is not None:
-        from ._lib import lib
-        lib().gk_comm_destroy(made._handle)
-        made._handle = None
+    if made is not None:
+        made._teardown()
     other = Comm.__new__(Comm)
     other.rank, other.world, other.store, other.backend = rank, world, store, "file"
     other._seq, other._handle, other._dev, other._cdev = 0, None, dev, None     # no rank has used the store's rounds yet

@@ -285,3 +285,33 @@ def test_a_communicator_that_comes_up_after_its_deadline_is_destroyed_unused(tmp
     assert not th.is_alive()
     assert "after its deadline" in box.get("error", "")
     assert calls == ["create", "destroy"]     # no barrier, no leak
+
+
+def test_purge_only_removes_the_keys_of_dead_launches(tmp_path):
+    """A shared rendezvous directory: rank 0 of a new launch removes what a DEAD launch left (its owner pid is gone),
+    never the keys of a launch whose owner is alive -- however old they are: a rank parked in a round while a peer types
+    for more than ten minutes holds an old key -- and never files that are not this package's keys."""
+    import time
+    from kir_graph_amd import comm
+    d = tmp_path / "rdzv"
+    alive = comm.FileStore(str(d), token="alive1")
+    alive.claim()                                   # this process: alive
+    alive.set("x3.r1", b"payload")
+    alive.set("rccl_ok.r0", b"1")
+    gone = subprocess.Popen([sys.executable, "-c", "pass"])
+    gone.wait()
+    dead = comm.FileStore(str(d), token="dead22")
+    dead.set("owner", str(gone.pid).encode())       # a launch whose rank 0 has exited
+    dead.set("x0.r0", b"old")
+    dead.set("abort", b"why")
+    (d / "notes.txt").write_text("not a key of this package")
+    (d / "orphan9.x1.r0").write_bytes(b"no owner key, fresh")
+    old = time.time() - 3600
+    for name in ("alive1.x3.r1", "alive1.rccl_ok.r0", "alive1.owner"):
+        os.utime(d / name, (old, old))              # old, but its launch lives
+    mine = comm.FileStore(str(d), token="mine33")
+    removed = mine.purgeOthers()
+    left = sorted(p.name for p in d.iterdir())
+    assert removed == 3 and not any(n.startswith("dead22.") for n in left)
+    assert {"alive1.x3.r1", "alive1.rccl_ok.r0", "alive1.owner", "notes.txt", "orphan9.x1.r0"} <= set(left)
+    assert alive.get("x3.r1") == b"payload"
