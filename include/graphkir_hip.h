@@ -393,6 +393,23 @@ int gk_em_distinct(gk_ctx* ctx, gk_dptr d_sets, int64_t n_rows, int32_t words, i
 int gk_em_run(gk_ctx* ctx, const uint32_t* sets, const double* weight, int32_t n_sets, int32_t words,
               int32_t n_allele, int32_t iter_max, double diff_threshold, double* prob_out,
               int32_t* iters_out);
+/* The EM strategy for ALL genes of a sample in one call on one host thread and one stream (kir_typing.py:163-195 is the
+ * reference's gene loop; typing_em.py:68-188 per gene): candidate sets and distinct sets of every gene queued together,
+ * the host half (numpy.unique's ascending order of the sets, the reads naming each allele, the empty set dropped) in the
+ * library, the SQUAREM loops of all genes in ONE launch -- a workgroup per gene.  A job names a gene's rows (the NH == 1
+ * pairs, gk_select_gene), its variant span and bit rows; prob_out / count_out hold n_allele entries per job, one job after
+ * the other.  Out per job: the number of distinct candidate sets and the SQUAREM steps taken (< iter_max: stopped on
+ * diff_threshold).  GK_ERR_CAPACITY when a gene has more than 2^18 distinct sets (use the per-gene calls). */
+typedef struct gk_em_job {
+  gk_dptr d_rows;
+  int64_t n_rows;
+  gk_dptr d_mask;
+  int32_t vbeg, vend;
+  int32_t words, n_allele;
+  int32_t n_distinct, iterations; /* out */
+} gk_em_job;
+int gk_sample_em(gk_ctx* ctx, gk_tab* tab, gk_em_job* jobs, int32_t n_jobs, int32_t iter_max, double diff_threshold,
+                 double* prob_out, int64_t* count_out);
 
 /* ---- host ingest (no GPU): name-collated SAM text -> gk_mate records.
  * Native form of readPair (hisat2.py:228-276), of the field reads of filterRead / getNH (551-569,

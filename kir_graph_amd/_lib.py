@@ -60,6 +60,15 @@ class GeneJob(C.Structure):
     ]
 
 
+class EmJob(C.Structure):
+    """``gk_em_job`` (include/graphkir_hip.h): one gene of ``gk_sample_em``."""
+    _fields_ = [
+        ("d_rows", C.c_uint64), ("n_rows", C.c_int64), ("d_mask", C.c_uint64),
+        ("vbeg", C.c_int32), ("vend", C.c_int32), ("words", C.c_int32), ("n_allele", C.c_int32),
+        ("n_distinct", C.c_int32), ("iterations", C.c_int32),
+    ]
+
+
 class TabInfo(C.Structure):
     _fields_ = [
         ("n_pairs", C.c_int64), ("n_valid", C.c_int64), ("n_ids", C.c_int64),
@@ -190,6 +199,7 @@ _SIGS = {
                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gk_lut_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32)]),
+    "gk_sample_em": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
     "gk_mates_compact": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]),
     "gk_mates_expand": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64]),
     "gk_mates_compact_size": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),

@@ -408,10 +408,53 @@ class TypingWithReport(_GenesInParallel):
         self._data = _sample(filename_variant_json, device)
         self.em_info: dict[str, dict] = {}      # per gene: iterations used, distinct candidate sets
 
+    def typing(self, gene_cn: dict[str, int], min_reads_num: int = 100) -> tuple[list[str], list[str]]:
+        """All genes of the sample through ``gk_sample_em``: candidate sets, distinct sets and the SQUAREM loops of every
+        gene in ONE library call on one host thread and one stream (a workgroup per gene solves its EM), instead of a
+        thread and a stream per gene with three waits each.  GK_SAMPLE_EM=0 (or a gene with more than 2^18 distinct
+        candidate sets) keeps the per-gene calls.  Same reports either way (kir_typing.py:163-195)."""
+        import ctypes as C
+        import os
+        from . import _lib
+        from ._lib import lib
+        if os.environ.get("GK_SAMPLE_EM", "1") == "0":
+            return super().typing(gene_cn, min_reads_num)
+        tab, _ = self._context()
+        todo = [(gene, int(cn)) for gene, cn in gene_cn.items() if cn]
+        views = [_GeneView(self._data, gene, multiple=False, tab=tab) for gene, _ in todo]
+        live = [k for k, v in enumerate(views) if v.g is not None and v.alleles and v.n_rows]
+        reports: dict[int, list[Hisat2AlleleResult]] = {}
+        if live:
+            jobs = (_lib.EmJob * len(live))()
+            for q, k in enumerate(live):
+                v, t = views[k], self._data.index.tables[views[k].g]
+                jobs[q] = _lib.EmJob(d_rows=v.rows.ptr, n_rows=v.n_rows, d_mask=v.mask.ptr, vbeg=v.vbeg,
+                                     vend=v.vbeg + v.n_span, words=t.words, n_allele=len(v.alleles), n_distinct=0, iterations=0)
+            total = sum(len(views[k].alleles) for k in live)
+            prob, count = np.zeros(total, dtype=np.float64), np.zeros(total, dtype=np.int64)
+            rc = lib().gk_sample_em(tab.dev.ctx, tab.handle, jobs, len(live), 300, 0.0001, prob.ctypes.data, count.ctypes.data)
+            if rc == -5:                    # GK_ERR_CAPACITY: a gene with a flood of distinct sets -- the per-gene calls size for it
+                return super().typing(gene_cn, min_reads_num)
+            _lib.check(rc)
+            at = 0
+            for q, k in enumerate(live):
+                names = views[k].alleles
+                p, c = prob[at:at + len(names)], count[at:at + len(names)]
+                at += len(names)
+                reports[k] = [Hisat2AlleleResult(allele=names[a], count=int(c[a]), prob=float(p[a])) for a in np.nonzero(c)[0]]
+                self.em_info[todo[k][0]] = {"iterations": int(jobs[q].iterations), "distinct_sets": int(jobs[q].n_distinct)}
+        predict_alleles, warning_genes = [], []
+        self._result = {}
+        for k, (gene, cn) in enumerate(todo):
+            alleles, reads_num = self._callsOfReport(gene, cn, reports.get(k, []), views[k].n_rows if views[k].g is not None else 0)
+            predict_alleles.extend(alleles)
+            if reads_num < min_reads_num:
+                warning_genes.append(gene)
+        return predict_alleles, warning_genes
+
     def typingPerGene(self, gene: str, cn: int) -> tuple[list[str], int]:
         tab, _ = self._context()
         view = _GeneView(self._data, gene, multiple=False, tab=tab)
-        pure_gene = gene.split("*")[0]
         report: list[Hisat2AlleleResult] = []
         if view.g is not None and view.alleles and view.n_rows:
             t = self._data.index.tables[view.g]
@@ -419,11 +462,16 @@ class TypingWithReport(_GenesInParallel):
             report = hisat2TypingPerGene(tab, view.rows, view.n_rows, view.vbeg, view.vbeg + view.n_span,
                                          view.mask, t.words, view.alleles, info=info)
             self.em_info[gene] = info
+        return self._callsOfReport(gene, cn, report, view.n_rows)
+
+    def _callsOfReport(self, gene: str, cn: int, report: list, n_rows: int) -> tuple[list[str], int]:
+        """Abundances -> calls (kir_typing.py:181-192): the copy numbers go to the alleles in descending abundance."""
+        pure_gene = gene.split("*")[0]
         # descending abundance; ties by allele name (the reference leaves them to set order)
         report.sort(key=lambda r: (-r.prob, r.allele))
         if not report:
             self._result[gene] = report
-            return [f"{pure_gene}*"] * cn, view.n_rows   # the reference raises AxisError here
+            return [f"{pure_gene}*"] * cn, n_rows   # the reference raises AxisError here
         est_prob = 1 / cn
         called = []
         for rec in report:
@@ -434,7 +482,7 @@ class TypingWithReport(_GenesInParallel):
             if cn <= 0:
                 break
         self._result[gene] = report
-        return called, view.n_rows
+        return called, n_rows
 
     def getAllPossibleTyping(self) -> list[dict[Any, Any]]:
         raise NotImplementedError

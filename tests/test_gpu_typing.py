@@ -312,3 +312,22 @@ def test_new_values_settle_per_gene_and_give_the_same_bits(device, small_case, m
     # sample 3 repeats sample 2: nothing new, no table written twice; no sample rewrites a table more than a few times
     assert rewritten[3] == 0, rewritten
     assert all(r <= 3 * g for r, g in zip(rewritten, n_genes)), (rewritten, n_genes)
+
+
+@pytest.mark.gpu
+def test_em_of_all_genes_in_one_call_equals_the_per_gene_calls(tabulated, monkeypatch):
+    """gk_sample_em (candidate sets, distinct sets and the SQUAREM loops of every gene in one library call, a workgroup
+    per gene) gives the reports of the per-gene path -- abundances bit for bit (same sets in the same order through the
+    same loop), read counts, iterations, distinct sets -- and the same calls and warnings."""
+    data, ref, sample = tabulated
+    got = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("GK_SAMPLE_EM", form)
+        typer = selectKirTypingModel("em", data)
+        calls = typer.typing(sample.gene_cn)
+        got[form] = (calls, {g: [(r.allele, r.count, r.prob, r.cn) for r in rep] for g, rep in typer._result.items()},
+                     dict(typer.em_info))
+    assert got["1"][0] == got["0"][0]
+    assert list(got["1"][1]) == list(got["0"][1])
+    assert got["1"][1] == got["0"][1]
+    assert got["1"][2] == got["0"][2] and any(v["iterations"] > 0 for v in got["1"][2].values())
