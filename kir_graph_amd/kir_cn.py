@@ -176,5 +176,27 @@ def _predictPerGene(tables: list[pd.DataFrame], samples_depth_tsv: list[str], cl
 
 
 def loadCN(filename_cn: str) -> dict[str, int]:
+    """gene -> copy number of a CN file (``gene\\tcn[\\tdepth]``, kir_cn.py:234-243).  A plain file -- a header with a
+    ``cn`` column, integer cells, no quotes -- is read directly (pandas' reader costs a millisecond of interpreter time
+    per sample, which the typing lanes share); anything else goes through pandas like the reference."""
+    try:
+        with open(filename_cn) as f:
+            text = f.read()
+        if '"' not in text and "\r" not in text:
+            lines = text.split("\n")
+            if lines and lines[-1] == "":
+                lines.pop()
+            header = lines[0].split("\t")
+            at = header.index("cn")
+            out: dict[str, int] = {}
+            for line in lines[1:]:
+                cells = line.split("\t")
+                if len(cells) != len(header) or not cells[0] or cells[0] in out:
+                    raise ValueError
+                out[cells[0]] = int(cells[at])
+            if at > 0 and len(lines) > 1:
+                return out
+    except (ValueError, IndexError):
+        pass
     data = pd.read_csv(filename_cn, sep="\t", index_col=[0])
     return dict(data.to_dict()["cn"])
