@@ -38,6 +38,8 @@ KERNEL_SOURCES = {
     "select_cut": ["gk_bound.hip", "gk_common.h"],
     "setmin_u8": ["gk_bound.hip", "gk_common.h"],
     "fraction_chunks": ["gk_search.hip", "gk_common.h"],
+    "setsum_leaves": ["gk_search.hip", "gk_common.h"],
+    "patch_pending": ["gk_typing.hip", "gk_lut.h", "gk_common.h"],
     "maxsum_chunks": ["gk_search.hip", "gk_common.h"],
     "combine_chunks": ["gk_search.hip", "gk_common.h"],
 }
