@@ -308,19 +308,29 @@ static size_t pool_class(size_t bytes) {
     while (c < bytes) c <<= 1;
     return c;
   }
-  const size_t step = 1u << 20;  // then multiples of 1 MiB
+  // then multiples of 1 MiB up to 64 MiB, beyond that of 1/16 of the size's power of two (<= 6 % over): the tables of a
+  // sample are sized by its read counts, which differ from sample to sample -- coarse classes let the next sample's
+  // tables land in this sample's blocks instead of in fresh hipMalloc's (a 1 GB allocation costs milliseconds)
+  size_t step = 1u << 20;
+  if (bytes > ((size_t)64 << 20)) {
+    size_t p2 = (size_t)1 << 26;
+    while ((p2 << 1) <= bytes) p2 <<= 1;
+    step = p2 >> 4;
+  }
   return (bytes + step - 1) / step * step;
 }
 
 hipError_t gk_pool_malloc(gk_ctx* ctx, void** out, size_t bytes) {
   std::lock_guard<std::mutex> lock(ctx->pool_mutex);
   const size_t cls = pool_class(bytes);
-  auto it = ctx->pool_free.find(cls);
-  if (it != ctx->pool_free.end()) {
+  // the smallest cached block that holds the request, if it is not more than a quarter too large
+  auto it = ctx->pool_free.lower_bound(cls);
+  if (it != ctx->pool_free.end() && it->first <= cls + cls / 4) {
+    const size_t have = it->first;
     *out = it->second;
     ctx->pool_free.erase(it);
-    ctx->pool_cached_bytes -= cls;
-    ctx->pool_live[*out] = cls;
+    ctx->pool_cached_bytes -= have;
+    ctx->pool_live[*out] = have;
     return hipSuccess;
   }
   hipError_t e = hipMalloc(out, cls);

@@ -46,6 +46,9 @@ def nativeSearch() -> bool:
     return os.environ.get("GK_NATIVE_SEARCH", "1") != "0"
 
 
+_GROUP_CACHE_LOCK = threading.Lock()      # guards the per-gene exon-group caches (AlleleTypingExonFirst)
+
+
 def sharedLogTable(dev: Device) -> LogTable:
     """One log10 value table per GPU, shared by all its contexts (values recur across genes, samples
     and host threads, so every value is evaluated by numpy once per process)."""
@@ -966,23 +969,24 @@ class AlleleTypingExonFirst(AlleleTyping):
 
         # alleles sharing one exon-variant set become one group (649-659)
         cache = _group_cache if _group_cache is not None else {}
-        if "grouped" not in cache:
-            exon_variants = [v for v in variants if v.in_exon]
-            groups = self.aggrVariantsByAllele(exon_variants)
-            rest = self.collectAlleleNames(variants) - self.collectAlleleNames(exon_variants)
-            if rest:
-                groups[tuple()] = sorted(rest)
-            cache["allele_group"] = {"|".join(a): a for a in groups.values()}
-            inverse = self.createInverseMapping(cache["allele_group"])
-            cache["grouped"] = self.removeDuplicateAllele(variants, inverse)
-            cache["group_names"] = sorted(self.collectAlleleNames(cache["grouped"]))
-            cache["mask"] = buildMask(cache["grouped"][:n_span], cache["group_names"])
-            cache["device_mask"] = {}
-        self.allele_group = cache["allele_group"]
-        grouped, group_names = cache["grouped"], cache["group_names"]
-        exon_mask = cache["device_mask"].get(dev.ordinal)
-        if exon_mask is None:
-            exon_mask = cache["device_mask"][dev.ordinal] = dev.put(cache["mask"])
+        with _GROUP_CACHE_LOCK:       # the lanes of a process type the same gene of different samples at the same time
+            if "device_mask" not in cache:
+                exon_variants = [v for v in variants if v.in_exon]
+                groups = self.aggrVariantsByAllele(exon_variants)
+                rest = self.collectAlleleNames(variants) - self.collectAlleleNames(exon_variants)
+                if rest:
+                    groups[tuple()] = sorted(rest)
+                cache["allele_group"] = {"|".join(a): a for a in groups.values()}
+                inverse = self.createInverseMapping(cache["allele_group"])
+                cache["grouped"] = self.removeDuplicateAllele(variants, inverse)
+                cache["group_names"] = sorted(self.collectAlleleNames(cache["grouped"]))
+                cache["mask"] = buildMask(cache["grouped"][:n_span], cache["group_names"])
+                cache["device_mask"] = {}
+            self.allele_group = cache["allele_group"]
+            grouped, group_names = cache["grouped"], cache["group_names"]
+            exon_mask = cache["device_mask"].get(dev.ordinal)
+            if exon_mask is None:
+                exon_mask = cache["device_mask"][dev.ordinal] = dev.put(cache["mask"])
         # the base class runs errorCorrection once more on the exon lists (line 664: default True)
         super().__init__(exon_set, grouped, force_homo=force_homo, top_n=top_n, logs=logs,
                          _vbeg=_vbeg, _n_span=n_span, _mask=exon_mask, _alleles=group_names, _defer_log=True, _novel=_novel)
