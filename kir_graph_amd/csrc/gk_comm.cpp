@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include "gk_common.h"
@@ -184,7 +185,23 @@ int gk_h2d_async(gk_ctx* ctx, gk_dptr dst, const void* src, size_t bytes) {
   gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   if (!bytes) return GK_OK;
-  GK_HIP(hipMemcpyAsync(gk_ptr<void>(dst), src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // A bulk copy goes out in pieces (GK_H2D_CHUNK_MB, default 8; 0 = one call): the DMA engine that serves host-to-device
+  // copies also carries the small parameter blocks of the samples being typed, and it arbitrates between queues at
+  // command boundaries -- behind ONE 700 MB command (a configs[2] sample) every search stage of the other lanes waited
+  // for the whole transfer.
+  static const size_t chunk = [] {
+    const char* e = getenv("GK_H2D_CHUNK_MB");
+    const long mb = e ? atol(e) : 8;
+    return mb > 0 ? (size_t)mb << 20 : (size_t)0;
+  }();
+  if (!chunk || bytes <= chunk) {
+    GK_HIP(hipMemcpyAsync(gk_ptr<void>(dst), src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return GK_OK;
+  }
+  for (size_t at = 0; at < bytes; at += chunk) {
+    const size_t n = std::min(chunk, bytes - at);
+    GK_HIP(hipMemcpyAsync(gk_ptr<char>(dst) + at, (const char*)src + at, n, hipMemcpyHostToDevice, ctx->stream));
+  }
   return GK_OK;
 }
 

@@ -1,5 +1,8 @@
 // Runtime plumbing of the C ABI: context, memory, timing, errors.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <mutex>
 #include <cstring>
@@ -333,8 +336,16 @@ hipError_t gk_pool_malloc(gk_ctx* ctx, void** out, size_t bytes) {
     ctx->pool_live[*out] = have;
     return hipSuccess;
   }
+  static const bool trace = getenv("GK_POOL_TRACE") != nullptr;      // dev: every large pool miss and what it costs
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(out, cls);
+  if (trace && cls >= ((size_t)32 << 20))
+    fprintf(stderr, "[gk_pool] ctx %p: hipMalloc of %zu MB took %.0f us (cached %zu MB in %zu blocks)\n", (void*)ctx, cls >> 20,
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(),
+            ctx->pool_cached_bytes >> 20, ctx->pool_free.size());
   if (e != hipSuccess && ctx->pool_cached_bytes) {   // give the cache back and retry once
+    if (trace) fprintf(stderr, "[gk_pool] ctx %p: hipMalloc of %zu MB FAILED, flushing %zu MB of cached blocks\n", (void*)ctx,
+                       cls >> 20, ctx->pool_cached_bytes >> 20);
     hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->pool_free) hipFree(kv.second);
     ctx->pool_free.clear();
