@@ -215,6 +215,13 @@ int gk_sample_prepare(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_vfla
 int gk_sample_prepare_all(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_vflag, gk_dptr d_cnt, gk_dptr d_rows,
                           int64_t* gene_off_out, int64_t max_out, int32_t* ord_out, uint32_t* pos_out, uint32_t* neg_out,
                           int64_t* n_out, uint64_t* novel_key_out);
+/* The same preamble for the EXON model of every gene (AlleleTypingExonFirst.__init__, typing_mulit_allele.py:640-664):
+ * d_vflag comes in holding 3 for every variant outside the exons (removeIntronVariant 703-714) and is corrected TWICE
+ * (644-645 and again inside the base class, 664); rows without a surviving id are removed, the surviving tallies come back
+ * as for gk_sample_prepare_all. */
+int gk_sample_prepare_exon(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_vflag, gk_dptr d_cnt, gk_dptr d_rows,
+                           int64_t* gene_off_out, int64_t max_out, int32_t* ord_out, uint32_t* pos_out, uint32_t* neg_out,
+                           int64_t* n_out);
 
 /* ---- compatibility: reads2AlleleProb (typing_mulit_allele.py:340-381).
  * d_mask uint32 [vend-vbeg][words]: allele bit rows of the gene's index variants.
@@ -353,6 +360,14 @@ typedef struct gk_gene_job {
   int32_t n_steps, top_n;
   int32_t bound_ok, passes; /* out */
   int32_t indexed, patches; /* out: d_lidx holds the table (0: the value table outgrew 16-bit indices, the call worked on a float64 table of its own); how often the table was patched (gk_compat_patch) */
+  /* Exon-first (typing_mulit_allele.py:740-746: for every exon candidate, addCandidate(alleles of its k-th group) per copy):
+   * table_of >= 0: this job is a SEARCH on the table that job `table_of` writes (that job may have n_steps == 0: table and
+   * column sums only); -1: the job writes its own table.  n_step_cols > 0: step k of the search offers the alleles
+   * step_cols[step_cols_off[k] .. step_cols_off[k + 1]) (host arrays; the last list serves any further step) instead of
+   * every allele.  Both need the pipelined form (float64 + mismatch tables, one stream). */
+  int32_t table_of, n_step_cols;
+  const int32_t* step_cols;
+  const int32_t* step_cols_off;
 } gk_gene_job;
 int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab, gk_dptr d_vflag, gk_lut* lut,
                      gk_gene_job* jobs, int32_t n_jobs, gk_argsort_fn argsort, gk_log10_fn log10_fn, gk_search** out);

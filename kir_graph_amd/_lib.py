@@ -57,6 +57,7 @@ class GeneJob(C.Structure):
         ("vbeg", C.c_int32), ("vend", C.c_int32), ("words", C.c_int32), ("n_allele", C.c_int32),
         ("n_steps", C.c_int32), ("top_n", C.c_int32), ("bound_ok", C.c_int32), ("passes", C.c_int32),
         ("indexed", C.c_int32), ("patches", C.c_int32),
+        ("table_of", C.c_int32), ("n_step_cols", C.c_int32), ("step_cols", C.c_void_p), ("step_cols_off", C.c_void_p),
     ]
 
 
@@ -199,6 +200,8 @@ _SIGS = {
                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gk_lut_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32)]),
+    "gk_sample_prepare_exon": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
+                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "gk_sample_em": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
     "gk_mates_compact": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]),
     "gk_mates_expand": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64]),

@@ -235,7 +235,10 @@ struct GeneSearch {
   gk_dptr d_miss8 = 0, d_msum = 0;
   int64_t n_rows = 0, ld = 0, ldm = 0;
   int n_allele = 0, n_steps = 0, T = 0, A = 0;
-  std::vector<int32_t> cols;
+  std::vector<int32_t> cols;    // the alleles offered at the step in hand
+  // exon-first (typing_mulit_allele.py:740-746): every step of a candidate search offers the alleles of ONE exon group;
+  // empty = every step offers `cols` as given to init
+  std::vector<std::vector<int32_t>> step_cols;
   gk_argsort_fn argsort = nullptr;
   bool bound = false, unique_cols = true;
   std::unique_ptr<gk_search> S;
@@ -252,7 +255,7 @@ struct GeneSearch {
            gk_dptr msum, const int32_t* cols_, int32_t n_cols, int32_t n_steps_, int32_t top_n, gk_argsort_fn fn) {
     GK_REQUIRE(c && tbl.d && (L || tbl.indexed()) && cols_ && fn, "null pointer");
     table = tbl;
-    GK_REQUIRE(rows > 0 && ld_ >= rows && n_allele_ > 0 && n_cols > 0 && n_steps_ >= 1 && n_steps_ <= 8 && top_n >= 1,
+    GK_REQUIRE(rows > 0 && ld_ >= rows && n_allele_ > 0 && n_cols > 0 && n_steps_ >= 0 && n_steps_ <= 8 && top_n >= 1,
                "bad search arguments");
     for (int a = 0; a < n_cols; ++a) GK_REQUIRE(cols_[a] >= 0 && cols_[a] < n_allele_, "candidate allele out of range");
     ctx = c; d_L = L; n_rows = rows; ld = ld_; n_allele = n_allele_; d_miss8 = miss8; ldm = ldm_; d_msum = msum;
@@ -264,6 +267,23 @@ struct GeneSearch {
     S->colsum.resize((size_t)n_allele);
     std::vector<char> seen((size_t)n_allele, 0);
     for (int a = 0; a < A && unique_cols; ++a) { if (seen[cols[a]]) unique_cols = false; seen[cols[a]] = 1; }
+    return GK_OK;
+  }
+
+  // the columns of step `s` (0-based) become the ones in hand
+  int use_step(int s) {
+    if (step_cols.empty()) return GK_OK;
+    const std::vector<int32_t>& c = step_cols[std::min<size_t>((size_t)s, step_cols.size() - 1)];
+    GK_REQUIRE(!c.empty(), "a search step without candidate alleles");
+    cols = c;
+    A = (int)cols.size();
+    unique_cols = true;
+    std::vector<char> seen((size_t)n_allele, 0);
+    for (int a = 0; a < A; ++a) {
+      GK_REQUIRE(cols[a] >= 0 && cols[a] < n_allele, "candidate allele out of range");
+      if (seen[cols[a]]) unique_cols = false;
+      seen[cols[a]] = 1;
+    }
     return GK_OK;
   }
 
@@ -280,6 +300,7 @@ struct GeneSearch {
 
   // ---- first allele (512-532): argsort(score)[::-1][:top_n]
   int first_step() {
+    { const int r = use_step(0); if (r) return r; }
     const double* colsum = S->colsum.data();
     std::vector<double> score((size_t)A);
     for (int a = 0; a < A; ++a) score[a] = colsum[cols[a]];
@@ -315,6 +336,7 @@ struct GeneSearch {
 
   // ---- a further step: first occurrences, then the integer bound when it applies
   int step_begin() {
+    { const int r = use_step((int)S->steps.size()); if (r) return r; }
     const Step& prev = S->steps.back();
     const int k = prev.n;
     const int Tp = (int)prev.rows();
@@ -860,8 +882,14 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
     if (rc == GK_OK) rc = push(i, kTable);
     return rc;
   };
+  // searches that read another job's table (exon-first: the candidate searches of a gene on its full table) start when
+  // that table is final
+  std::vector<std::vector<int>> dependents((size_t)n_jobs);
+  for (int i : live)
+    if (jobs[i].table_of >= 0) dependents[(size_t)jobs[i].table_of].push_back(i);
   int rc = GK_OK;
   for (int i : live) {
+    if (jobs[i].table_of >= 0) continue;
     rc = write_table(i, false);
     if (rc) return fail(rc);
   }
@@ -913,8 +941,32 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
         j.bound_ok = ((flags[it.gene] | sticky[it.gene]) & 1u) == 0 ? 1 : 0;
         if (!j.bound_ok) g.bound = false;      // a mismatch count near the underflow range / a very long row: exact steps
         g.colsum_collect();
-        rc = g.first_step();
-        if (rc == GK_OK) rc = advance(it.gene, true);
+        if (j.n_steps > 0) {
+          rc = g.first_step();
+          if (rc == GK_OK) rc = advance(it.gene, true);
+        }
+        for (int d : dependents[(size_t)it.gene]) {      // the table is final: the searches that read it begin
+          if (rc) break;
+          gk_gene_job& jd = jobs[d];
+          jd.bound_ok = j.bound_ok;
+          gs[d].reset(new GeneSearch());
+          std::vector<int32_t> every((size_t)j.n_allele);
+          std::iota(every.begin(), every.end(), 0);
+          rc = gs[d]->init(ctx, GkTable{j.d_L, j.n_rows, nullptr}, j.d_L, j.n_rows, j.n_rows, j.n_allele, j.d_miss8, j.ldm, j.d_msum,
+                           every.data(), j.n_allele, jd.n_steps, jd.top_n, argsort);
+          if (rc) break;
+          if (!j.bound_ok) gs[d]->bound = false;
+          gs[d]->S->colsum = g.S->colsum;
+          if (jd.n_step_cols > 0) {
+            gs[d]->step_cols.resize((size_t)jd.n_step_cols);
+            for (int q = 0; q < jd.n_step_cols; ++q)
+              gs[d]->step_cols[(size_t)q].assign(jd.step_cols + jd.step_cols_off[q], jd.step_cols + jd.step_cols_off[q + 1]);
+          }
+          if (jd.n_steps > 0) {
+            rc = gs[d]->first_step();
+            if (rc == GK_OK) rc = advance(d, true);
+          }
+        }
         break;
       case kBound:
         rc = g.after_bound();
@@ -959,13 +1011,24 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
   }
   for (int i = 0; i < n_jobs; ++i) out[i] = nullptr;
   std::vector<int> live;
+  bool any_special = false;      // table-only jobs, searches on another job's table, columns per step: pipelined form only
   for (int i = 0; i < n_jobs; ++i) {
     gk_gene_job& j = jobs[i];
     j.bound_ok = 0;
     j.passes = 0;
     j.indexed = 0;
     j.patches = 0;
-    GK_REQUIRE(j.n_rows >= 0 && j.n_allele >= 0 && j.n_steps >= 1 && j.top_n >= 1, "bad gene job");
+    GK_REQUIRE(j.n_rows >= 0 && j.n_allele >= 0 && j.n_steps >= 0 && j.top_n >= 1, "bad gene job");
+    GK_REQUIRE(j.table_of >= -1 && j.table_of < n_jobs && j.table_of != i, "bad table reference");
+    GK_REQUIRE(j.n_step_cols >= 0 && (j.n_step_cols == 0 || (j.step_cols && j.step_cols_off)), "bad step columns");
+    if (j.table_of >= 0) {       // a search on another job's table: that job writes it
+      const gk_gene_job& o = jobs[j.table_of];
+      GK_REQUIRE(o.table_of < 0, "a table reference must name a job that writes its own table");
+      GK_REQUIRE(j.n_steps >= 1, "a search on another job's table needs steps");
+      if (o.n_rows > 0 && o.n_allele > 0) { live.push_back(i); any_special = true; }
+      continue;
+    }
+    if (j.n_steps == 0 || j.n_step_cols > 0) any_special = true;
     if (j.n_rows > 0 && j.n_allele > 0) {
       GK_REQUIRE(j.d_rows && (j.d_L || j.d_lidx) && j.d_mask && j.words >= 1, "gene job without tables");
       GK_REQUIRE(!j.d_miss8 || (j.d_msum && j.d_flags && j.ldm >= j.n_rows && j.ldm % 64 == 0), "bad mismatch table");
@@ -977,11 +1040,13 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
   const char* const form = getenv("GK_SAMPLE_PIPELINE");      // read per call: the tests compare both forms in one process
   const bool pipeline = !(form && !strcmp(form, "0"));
   bool float_tables = true;
-  for (int i : live) float_tables = float_tables && jobs[i].d_L && !jobs[i].d_lidx;
+  for (int i : live) if (jobs[i].table_of < 0) float_tables = float_tables && jobs[i].d_L && !jobs[i].d_lidx;
   bool flagged = true;               // every table comes with the flag word that reports products without a log10
-  for (int i : live) flagged = flagged && jobs[i].d_miss8 && jobs[i].d_flags;
-  if (pipeline && n_more == 0 && float_tables && flagged)
+  for (int i : live) if (jobs[i].table_of < 0) flagged = flagged && jobs[i].d_miss8 && jobs[i].d_flags;
+  if ((pipeline || any_special) && n_more == 0 && float_tables && flagged)
     return sample_search_pipelined(ctx, tab, d_vflag, lut, jobs, n_jobs, live, argsort, log10_fn, out);
+  GK_REQUIRE(!any_special, "table-only jobs, searches on another job's table and per-step columns need float64 tables "
+                           "with mismatch tables on one stream (the pipelined form)");
   return sample_search_lockstep(ctx, cx, tab, d_vflag, lut, jobs, n_jobs, live, argsort, log10_fn, out);
 }
 

@@ -844,7 +844,7 @@ struct Survivors {        // what gk_variant_surviving would fetch, asked for to
 }  // namespace
 
 static int sample_prepare(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_vflag, gk_dptr d_cnt, gk_dptr d_rows,
-                          int64_t* gene_off_out, const Survivors* surv);
+                          int64_t* gene_off_out, const Survivors* surv, bool keep_vflag = false, int rounds = 1);
 
 int gk_sample_prepare(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_vflag, gk_dptr d_cnt, gk_dptr d_rows,
                       int64_t* gene_off_out) {
@@ -865,8 +865,21 @@ int gk_sample_prepare_all(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_
   return sample_prepare(ctx, tab, multiple, d_vflag, d_cnt, d_rows, gene_off_out, &s);
 }
 
+/* The preamble of the EXON model of every gene (AlleleTypingExonFirst, typing_mulit_allele.py:640-664): d_vflag comes in
+ * holding 3 for every variant outside the exons (removeIntronVariant 703-714: their ids are dropped from every list) and
+ * the error correction runs TWICE on what is left (644-645, then once more inside the base class, 664), then the rows
+ * without a surviving id are removed and the surviving tallies fetched -- as gk_sample_prepare_all does for the full model. */
+int gk_sample_prepare_exon(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_vflag, gk_dptr d_cnt, gk_dptr d_rows,
+                           int64_t* gene_off_out, int64_t max_out, int32_t* ord_out, uint32_t* pos_out, uint32_t* neg_out,
+                           int64_t* n_out) {
+  GK_REQUIRE(ord_out && pos_out && neg_out && n_out && max_out >= 0, "null pointer");
+  Survivors s;
+  s.max_out = max_out; s.ord = ord_out; s.pos = pos_out; s.neg = neg_out; s.n_out = n_out; s.novel_key = nullptr;
+  return sample_prepare(ctx, tab, multiple, d_vflag, d_cnt, d_rows, gene_off_out, &s, true, 2);
+}
+
 static int sample_prepare(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_vflag, gk_dptr d_cnt, gk_dptr d_rows,
-                          int64_t* gene_off_out, const Survivors* surv) {
+                          int64_t* gene_off_out, const Survivors* surv, bool keep_vflag, int rounds) {
   gk_bind(ctx);
   GK_REQUIRE(ctx && tab && tab->idx && d_vflag && d_cnt && d_rows && gene_off_out, "null pointer");
   if (surv) *surv->n_out = 0;
@@ -874,7 +887,7 @@ static int sample_prepare(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_
   const int64_t nv = (int64_t)tab->n_var + tab->n_novel;
   hipStream_t st = ctx->stream;
   for (int g = 0; g <= n_gene; ++g) gene_off_out[g] = 0;
-  GK_HIP(hipMemsetAsync(gk_ptr<void>(d_vflag), 0, (size_t)std::max<int64_t>(nv, 1), st));
+  if (!keep_vflag) GK_HIP(hipMemsetAsync(gk_ptr<void>(d_vflag), 0, (size_t)std::max<int64_t>(nv, 1), st));
   GK_HIP(hipMemsetAsync(gk_ptr<void>(d_cnt), 0, (size_t)std::max<int64_t>(2 * nv, 1) * sizeof(uint32_t), st));
   auto novel_only = [&]() -> int {          // nothing to tally: no variant survives; the novel keys may still be wanted
     if (surv && surv->novel_key && tab->n_novel > 0)
@@ -922,11 +935,14 @@ static int sample_prepare(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_
   }
   uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
   uint8_t* vflag = gk_ptr<uint8_t>(d_vflag);
-  GK_PROF(ctx, GK_K_COUNT_IDS,
-          GK_KERNEL(count_ids_genes, dim3((unsigned)n_wg), dim3(kThreads), (size_t)max_local * 8, st, part.d_rows,
-                    (const int32_t*)d_tab, (const int64_t*)(d_tab + o_row0), (const int64_t*)(d_tab + o_row1),
-                    tab->idx->d_gene_vbeg, max_local, tab->d_off, tab->d_ids, vflag, cnt, cnt + nv));
-  GK_PROF(ctx, GK_K_COUNT_IDS, GK_KERNEL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, st, cnt, cnt + nv, nv, vflag));
+  for (int round = 0; round < rounds; ++round) {      // the exon model corrects its lists twice (typing_mulit_allele.py:644-645, 664)
+    if (round) GK_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * nv) * sizeof(uint32_t), st));
+    GK_PROF(ctx, GK_K_COUNT_IDS,
+            GK_KERNEL(count_ids_genes, dim3((unsigned)n_wg), dim3(kThreads), (size_t)max_local * 8, st, part.d_rows,
+                      (const int32_t*)d_tab, (const int64_t*)(d_tab + o_row0), (const int64_t*)(d_tab + o_row1),
+                      tab->idx->d_gene_vbeg, max_local, tab->d_off, tab->d_ids, vflag, cnt, cnt + nv));
+    GK_PROF(ctx, GK_K_COUNT_IDS, GK_KERNEL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, st, cnt, cnt + nv, nv, vflag));
+  }
   // rows with a surviving id, compacted in place of the grouping (stable: the groups stay contiguous and ordered)
   uint32_t *flag = nullptr, *kept = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)n_rows * sizeof(uint32_t)));

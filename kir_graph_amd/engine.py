@@ -130,9 +130,11 @@ class Tabulation:
             lib().gk_tab_destroy(self.handle)
         self.handle = None
 
-    def prepared(self, dev: Device, multiple: bool = False):
+    def prepared(self, dev: Device, multiple: bool = False, exon: bool = False):
         """Error correction + removal of empty reads of EVERY gene at once (``gk_sample_prepare``), computed by
         the first caller and shared by all gene threads: (drop flags, tallies, rows grouped by gene, bounds).
+        ``exon``: the same for the EXON model of every gene (``gk_sample_prepare_exon``: ids outside the exons dropped
+        from every list, the correction applied twice, typing_mulit_allele.py:640-664).
         None for tabulations that were not made by ``gk_tabulate`` (no index handle / novel keys on the device)."""
         if self.dindex is None or not self.info.d_pair_src:      # host lists / compact files: no index handle in the library
             return None
@@ -141,7 +143,28 @@ class Tabulation:
         lock = root.__dict__.setdefault("_prep_lock", threading.Lock())
         store = root.__dict__.setdefault("_prepared", {})
         with lock:
-            prep = store.get(bool(multiple))
+            prep = store.get((bool(multiple), True) if exon else bool(multiple))
+            if prep is None and exon:
+                nv = max(self.n_var_total, 1)
+                host = self.dindex.host
+                flags = np.full(nv, 3, dtype=np.uint8)           # novel variants are never in an exon
+                flags[:host.n_variant][host.in_exon.astype(bool)] = 0
+                vflag = dev.put(flags)
+                cnt = dev.alloc(2 * nv, np.uint32)
+                rows = dev.alloc(max(self.n_valid, 1), np.int32)
+                off = np.zeros(len(host.genes) + 1, dtype=np.int64)
+                o, p, q = (np.empty(nv, dtype=t) for t in (np.int32, np.uint32, np.uint32))
+                n_surv = C.c_int64()
+                check(lib().gk_sample_prepare_exon(dev.ctx, self.handle, int(multiple), vflag.ptr, cnt.ptr, rows.ptr,
+                                                   off.ctypes.data, nv, o.ctypes.data, p.ctypes.data, q.ctypes.data,
+                                                   C.byref(n_surv)))
+                o, p, q = o[:n_surv.value], p[:n_surv.value], q[:n_surv.value]
+                gene_of = np.searchsorted(host.gene_vbeg, o, side="right") - 1
+                order = np.argsort(gene_of, kind="stable")
+                bounds = np.searchsorted(gene_of[order], np.arange(len(host.genes) + 1)).astype(np.int64)
+                grouped = (np.ascontiguousarray(o[order], dtype=np.int32), np.ascontiguousarray(p[order], dtype=np.uint32),
+                           np.ascontiguousarray(q[order], dtype=np.uint32), bounds)
+                prep = store[(bool(multiple), True)] = (vflag, cnt, rows, off, grouped)
             if prep is None:
                 nv = max(self.n_var_total, 1)
                 vflag = dev.alloc(nv, np.uint8)

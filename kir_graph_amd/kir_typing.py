@@ -236,7 +236,180 @@ class TypingWithPosNegAllele(_GenesInParallel):
         Anything else (exon-first, no correction, GK_SAMPLE_SEARCH=0) keeps a thread and a stream per gene."""
         if self._wholeSample():
             return self._typingWholeSample(gene_cn, min_reads_num)
+        if self._wholeSampleExonFirst():
+            return self._typingWholeSampleExonFirst(gene_cn, min_reads_num)
         return super().typing(gene_cn, min_reads_num)
+
+    def _wholeSampleExonFirst(self) -> bool:
+        import os
+        from .engine import searchMode
+        from .typing_mulit_allele import nativeSearch
+        return (self._exon_first and not self._exon_only and batchedPreamble() and nativeSearch()
+                and os.environ.get("GK_SAMPLE_SEARCH", "1") != "0" and os.environ.get("GK_SAMPLE_EXONFIRST", "1") != "0"
+                and os.environ.get("GK_INDEX_TABLE", "0") != "1" and searchMode() == "bound")
+
+    def _typingWholeSampleExonFirst(self, gene_cn: dict[str, int], min_reads_num: int) -> tuple[list[str], list[str]]:
+        """Exon-first for ALL genes of the sample on this thread and ONE stream, in two ``gk_sample_search`` calls
+        (typing_mulit_allele.py:622-797 per gene; kir_typing.py:103-132 is the gene loop):
+
+        1. the EXON models -- ids outside the exons dropped, the lists corrected twice (``Tabulation.prepared(exon=True)``),
+           alleles with one exon-variant set merged into groups -- tables and searches of every gene, pipelined;
+        2. the FULL tables of every gene as table-only jobs, and for every exon set that reaches the threshold (774) a
+           candidate search on its gene's table whose k-th step offers the alleles of the set's k-th group (740-746),
+           all of them pipelined on the marks of the stream like the genes of the plain strategy.
+        A gene the two calls do not cover (no exon reads: the reference falls back to the full model there; no reads at
+        all; not in the index) takes the per-gene path on this thread.  Same results as ``AlleleTypingExonFirst``."""
+        import ctypes as C
+        import os
+        from . import _lib
+        from ._lib import check, lib
+        from .typing_mulit_allele import AlleleTypingExonFirst
+        tab, logs = self._context()
+        udev = tab.dev.urgent() if os.environ.get("GK_URGENT_PREAMBLE", "1") != "0" else tab.dev
+        prep_f = tab.prepared(udev, self._multiple)
+        if prep_f is None:
+            return super().typing(gene_cn, min_reads_num)
+        prep_e = tab.prepared(udev, self._multiple, exon=True)
+        top_n, threshold = self._top_n, self._exon_candidate_threshold
+        todo = [(gene, int(cn)) for gene, cn in gene_cn.items() if cn]
+        views = [_GeneView(self._data, gene, self._multiple, tab=tab) for gene, _ in todo]
+        verd_e = self._zygosityVerdicts(tab, prep_e, [(v.g, cn) for v, (_, cn) in zip(views, todo)])
+
+        def slice_of(prep, view):
+            vflag, cnt, rows_all, off = prep[:4]
+            a, b = int(off[view.g]), int(off[view.g + 1])
+            rows = _lib_slice(rows_all, a, b - a, tab.dev)
+            return rows, b - a, vflag, (rows, b - a, vflag, cnt, (view.g, view.vbeg, view.vbeg + view.n_span),
+                                        type(tab).survivingOfGene(prep, view.g))
+
+        def run(jobs_list, vflag):
+            jobs = (_lib.GeneJob * len(jobs_list))(*jobs_list)
+            handles = (C.c_void_p * len(jobs_list))()
+            with _searchSlot():
+                check(lib().gk_sample_search(tab.dev.ctx, None, 0, tab.handle, vflag.ptr, logs.handle, jobs, len(jobs_list),
+                                             _lib.NUMPY_ARGSORT, _lib.NUMPY_LOG10, handles))
+            return jobs, handles
+
+        def destroy(handles):
+            for h in handles:
+                if h:
+                    lib().gk_search_destroy(C.c_void_p(h))
+
+        # ---- 1. the exon models
+        plan: dict[int, dict] = {}             # position in todo -> what the two calls hold for the gene
+        jobs1 = []
+        for k, ((gene, cn), view) in enumerate(zip(todo, views)):
+            if view.g is None or not view.alleles:
+                continue
+            rows_e, n_e, vflag_e, prepared_e = slice_of(prep_e, view)
+            rows_f, n_f, vflag_f, prepared_f = slice_of(prep_f, view)
+            if n_e == 0 or n_f == 0:
+                continue                        # the per-gene path below (the reference's fall-backs live there)
+            allele_group, grouped, group_names, exon_mask = AlleleTypingExonFirst.exonGroups(
+                view.variants, view.n_span, view.groupCache(), tab.dev)
+            force = False if isHetrozygous(gene) else None
+            typ_e = AlleleTyping(ReadSet(tab, rows_e, n_e, vflag_e), grouped, force_homo=force, top_n=top_n,
+                                 variant_correction=True, logs=logs, _vbeg=view.vbeg, _n_span=view.n_span, _mask=exon_mask,
+                                 _alleles=group_names, _novel=view.novel, _prepared=prepared_e, _defer_launch=True)
+            job, homo = typ_e.geneJob(cn, verd_e.get(view.g) if cn > 1 else False)
+            plan[k] = {"typ_e": typ_e, "homo_e": homo, "job1": len(jobs1), "groups": allele_group,
+                       "full": (rows_f, n_f, vflag_f, prepared_f), "force": force}
+            jobs1.append(job)
+        self.tables_rewritten = self.tables_patched = 0
+        if jobs1:
+            jobs, handles = run(jobs1, prep_e[0])
+            try:
+                for k, p in plan.items():
+                    q = p["job1"]
+                    p["typ_e"].adoptJob(jobs[q], C.c_void_p(handles[q]), todo[k][1], p["homo_e"])
+                    self.tables_rewritten += max(0, int(jobs[q].passes) - 1)
+                    self.tables_patched += int(jobs[q].patches)
+            finally:
+                destroy(handles)
+        # ---- 2. the full tables and the candidate searches on them
+        jobs2, keep_alive = [], []
+        for k, p in plan.items():
+            (gene, cn), view = todo[k], views[k]
+            result = p["typ_e"].result[-1]
+            result.setNameGroup(p["groups"])
+            rows_f, n_f, vflag_f, prepared_f = p["full"]
+            full = AlleleTyping(ReadSet(tab, rows_f, n_f, vflag_f), view.variants, force_homo=p["force"], top_n=top_n // 5,
+                                variant_correction=True, logs=logs, _vbeg=view.vbeg, _n_span=view.n_span, _mask=view.mask,
+                                _alleles=view.alleles, _novel=view.novel, _prepared=prepared_f, _defer_launch=True)
+            p["full_model"] = full
+            if not result.value.shape[0]:
+                # no exon set: the reference types the gene with the full model (typing_mulit_allele.py:757-759)
+                logger.warning("[Allele] Cannot typing with exon-only reads. Typing with exon+intron")
+                p["fallback"] = True
+                continue
+            ranks = list(result.topRank(threshold=threshold))
+            if len(ranks) > 48:                 # a flood of exon sets (a threshold near 0): the per-gene path batches them
+                p["per_gene"] = True
+                continue
+            job, _ = full.geneJob(cn, False)
+            job.n_steps = 0                     # table + column sums; the searches are the jobs behind it
+            p["job2"] = len(jobs2)
+            jobs2.append(job)
+            p["cands"] = []
+            for i in ranks:
+                steps = [np.ascontiguousarray([full.allele_to_id[a] for a in names], dtype=np.int32)
+                         for names in result.allele_name_group[i]]
+                cols = np.ascontiguousarray(np.concatenate(steps), dtype=np.int32)
+                offs = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(x) for x in steps])]), dtype=np.int32)
+                keep_alive += [cols, offs]
+                cand = _lib.GeneJob(d_rows=job.d_rows, n_rows=job.n_rows, d_mask=job.d_mask, d_L=0, d_miss8=0, ldm=job.ldm,
+                                    d_msum=0, d_flags=0, d_lidx=0, vbeg=job.vbeg, vend=job.vend, words=job.words,
+                                    n_allele=job.n_allele, n_steps=len(steps), top_n=top_n // 5, bound_ok=0, passes=0,
+                                    indexed=0, patches=0, table_of=p["job2"], n_step_cols=len(steps),
+                                    step_cols=cols.ctypes.data, step_cols_off=offs.ctypes.data)
+                p["cands"].append((len(jobs2), len(steps)))
+                jobs2.append(cand)
+        if jobs2:
+            jobs, handles = run(jobs2, prep_f[0])
+            try:
+                for k, p in plan.items():
+                    if "job2" not in p:
+                        continue
+                    q = p["job2"]
+                    full = p["full_model"]
+                    full.adoptTable(jobs[q], C.c_void_p(handles[q]))
+                    self.tables_rewritten += max(0, int(jobs[q].passes) - 1)
+                    self.tables_patched += int(jobs[q].patches)
+                    finals, results = [], list(p["typ_e"].result)
+                    for qc, n_steps in p["cands"]:
+                        model = full.fork()
+                        model._adoptSearch(C.c_void_p(handles[qc]), n_steps)
+                        results.extend(model.result)
+                        finals.append(model.result[-1])
+                    merged = AlleleTypingExonFirst.mergeCandidates(finals)
+                    results.append(merged)
+                    merged.print()
+                    p["results"], p["final"] = results, merged
+            finally:
+                destroy(handles)
+        # ---- calls, in the order of the copy-number table
+        predict_alleles, warning_genes = [], []
+        self._result = {}
+        for k, ((gene, cn), view) in enumerate(zip(todo, views)):
+            p = plan.get(k)
+            pure_gene = gene.split("*")[0]
+            if p is None or p.get("per_gene"):
+                alleles, reads_num = self.typingPerGene(gene, cn)       # not in the index / no reads: the per-gene path
+            elif p.get("fallback"):
+                p["full_model"]._model._launchLog()                     # its table was left to a call that never came
+                res = p["full_model"].typing(cn)
+                self._result[gene] = p["full_model"].result
+                alleles = [x if x != "fail" else f"{pure_gene}*" for x in res.selectBest()]
+                reads_num = p["typ_e"].getReadsNum()
+            else:
+                self._result[gene] = p["results"]
+                alleles = [x if x != "fail" else f"{pure_gene}*" for x in p["final"].selectBest()]
+                reads_num = p["typ_e"].getReadsNum()
+            predict_alleles.extend(alleles)
+            if reads_num < min_reads_num:
+                warning_genes.append(gene)
+        self._result = {gene: self._result[gene] for gene, _ in todo if gene in self._result}
+        return predict_alleles, warning_genes
 
     def _wholeSample(self) -> bool:
         import os

@@ -554,7 +554,8 @@ class AlleleTyping:
                       d_miss8=m.miss8.ptr if m.miss8 else 0, ldm=m.ldm, d_msum=m.msum.ptr if m.msum else 0,
                       d_flags=m._bound_flags.ptr if m._bound_flags else 0, d_lidx=m.lidx.ptr if m.lidx else 0,
                       vbeg=vbeg, vend=vend, words=words, n_allele=m.n_allele, n_steps=1 if homo else cn,
-                      top_n=self.top_n, bound_ok=0, passes=0, indexed=0, patches=0)
+                      top_n=self.top_n, bound_ok=0, passes=0, indexed=0, patches=0, table_of=-1, n_step_cols=0,
+                      step_cols=None, step_cols_off=None)
         return job, homo
 
     def adoptJob(self, job, handle, cn: int, homo: bool) -> TypingResult:
@@ -573,6 +574,23 @@ class AlleleTyping:
             self.addHomoResultForCn(cn)
         self.result[-1].print()
         return self.result[-1]
+
+    def adoptTable(self, job, handle) -> None:
+        """A table-only job of ``gk_sample_search`` (n_steps == 0): the model's table is final and its column sums are
+        known; the searches on it were other jobs of the call."""
+        import ctypes as C
+        from ._lib import check, lib
+        m = self._model
+        m._bound_ok = bool(job.bound_ok)
+        m._indexed = False
+        m._known_at_launch = -1
+        if m.dev.call_log is not None:
+            per_row = m.tab.n_ids / max(m.tab.n_valid, 1)
+            for _ in range(max(1, int(job.passes))):
+                m.dev.call_log.append(("compat_kernel", m.n_rows, m.n_allele, per_row * m.n_rows, 8))
+        self._colsum_all = np.empty(m.n_allele, dtype=np.float64)
+        check(lib().gk_search_colsum(handle, self._colsum_all.ctypes.data))
+        self.result = []
 
     def addHomoResultForCn(self, cn: int) -> None:
         if cn > 1:
@@ -968,25 +986,7 @@ class AlleleTypingExonFirst(AlleleTyping):
         exon_set = ReadSet(tab, base.rows, base.n_rows, exon_flags)
 
         # alleles sharing one exon-variant set become one group (649-659)
-        cache = _group_cache if _group_cache is not None else {}
-        with _GROUP_CACHE_LOCK:       # the lanes of a process type the same gene of different samples at the same time
-            if "device_mask" not in cache:
-                exon_variants = [v for v in variants if v.in_exon]
-                groups = self.aggrVariantsByAllele(exon_variants)
-                rest = self.collectAlleleNames(variants) - self.collectAlleleNames(exon_variants)
-                if rest:
-                    groups[tuple()] = sorted(rest)
-                cache["allele_group"] = {"|".join(a): a for a in groups.values()}
-                inverse = self.createInverseMapping(cache["allele_group"])
-                cache["grouped"] = self.removeDuplicateAllele(variants, inverse)
-                cache["group_names"] = sorted(self.collectAlleleNames(cache["grouped"]))
-                cache["mask"] = buildMask(cache["grouped"][:n_span], cache["group_names"])
-                cache["device_mask"] = {}
-            self.allele_group = cache["allele_group"]
-            grouped, group_names = cache["grouped"], cache["group_names"]
-            exon_mask = cache["device_mask"].get(dev.ordinal)
-            if exon_mask is None:
-                exon_mask = cache["device_mask"][dev.ordinal] = dev.put(cache["mask"])
+        self.allele_group, grouped, group_names, exon_mask = self.exonGroups(variants, n_span, _group_cache, dev)
         # the base class runs errorCorrection once more on the exon lists (line 664: default True)
         super().__init__(exon_set, grouped, force_homo=force_homo, top_n=top_n, logs=logs,
                          _vbeg=_vbeg, _n_span=n_span, _mask=exon_mask, _alleles=group_names, _defer_log=True, _novel=_novel)
@@ -1004,6 +1004,44 @@ class AlleleTypingExonFirst(AlleleTyping):
         self.finish()
         if self.full_model is not None:
             self.full_model.finish()
+
+    @classmethod
+    def exonGroups(cls, variants: list[Variant], n_span: int, cache: dict | None, dev: Device):
+        """(group name -> member alleles, the variants with their alleles regrouped, sorted group names, their bit rows on
+        ``dev``'s GPU) of a gene (649-659): index-only data, computed once per gene and process (``cache``: a dict the
+        caller owns, one per gene of an index)."""
+        cache = cache if cache is not None else {}
+        with _GROUP_CACHE_LOCK:       # the lanes of a process type the same gene of different samples at the same time
+            if "device_mask" not in cache:
+                exon_variants = [v for v in variants if v.in_exon]
+                groups = cls.aggrVariantsByAllele(exon_variants)
+                rest = cls.collectAlleleNames(variants) - cls.collectAlleleNames(exon_variants)
+                if rest:
+                    groups[tuple()] = sorted(rest)
+                cache["allele_group"] = {"|".join(a): a for a in groups.values()}
+                inverse = cls.createInverseMapping(cache["allele_group"])
+                cache["grouped"] = cls.removeDuplicateAllele(variants, inverse)
+                cache["group_names"] = sorted(cls.collectAlleleNames(cache["grouped"]))
+                cache["mask"] = buildMask(cache["grouped"][:n_span], cache["group_names"])
+                cache["device_mask"] = {}
+            exon_mask = cache["device_mask"].get(dev.ordinal)
+            if exon_mask is None:
+                exon_mask = cache["device_mask"][dev.ordinal] = dev.put(cache["mask"])
+            return cache["allele_group"], cache["grouped"], cache["group_names"], exon_mask
+
+    @staticmethod
+    def mergeCandidates(finals: list["TypingResult"]) -> "TypingResult":
+        """The final results of the candidate searches, concatenated and ranked again (783-793)."""
+        return TypingResult(
+            n=finals[0].n,
+            value=np.concatenate([f.value for f in finals]),
+            value_sum_indv=np.concatenate([f.value_sum_indv for f in finals]),
+            allele_id=np.concatenate([f.allele_id for f in finals]),
+            allele_name=list(chain.from_iterable(f.allele_name for f in finals)),
+            allele_prob=LazyAlleleProb([p for f in finals for p in f.allele_prob.parts]),
+            fraction=np.concatenate([f.fraction for f in finals]),
+            fraction_uniq=np.concatenate([f.fraction for f in finals]),
+        ).sortByScoreAndEveness()
 
     @staticmethod
     def aggrVariantsByAllele(variants: list[Variant]) -> dict[tuple[str, ...], list[str]]:
@@ -1060,16 +1098,7 @@ class AlleleTypingExonFirst(AlleleTyping):
             self.result.extend(model.result)
             finals.append(model.result[-1])
         logger.debug(f"[Allele] Intron Candidate {len(finals)} Done")
-        merged = TypingResult(
-            n=finals[0].n,
-            value=np.concatenate([f.value for f in finals]),
-            value_sum_indv=np.concatenate([f.value_sum_indv for f in finals]),
-            allele_id=np.concatenate([f.allele_id for f in finals]),
-            allele_name=list(chain.from_iterable(f.allele_name for f in finals)),
-            allele_prob=LazyAlleleProb([p for f in finals for p in f.allele_prob.parts]),
-            fraction=np.concatenate([f.fraction for f in finals]),
-            fraction_uniq=np.concatenate([f.fraction for f in finals]),
-        ).sortByScoreAndEveness()
+        merged = self.mergeCandidates(finals)
         self.result.append(merged)
         logger.debug("[Allele] Typing intron + exon")
         merged.print()

@@ -331,3 +331,26 @@ def test_em_of_all_genes_in_one_call_equals_the_per_gene_calls(tabulated, monkey
     assert list(got["1"][1]) == list(got["0"][1])
     assert got["1"][1] == got["0"][1]
     assert got["1"][2] == got["0"][2] and any(v["iterations"] > 0 for v in got["1"][2].values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["exonfirst_1", "exonfirst_0.9"])
+def test_exon_first_of_all_genes_in_two_calls_equals_the_per_gene_path(tabulated, monkeypatch, method):
+    """Exon-first through gk_sample_search twice (exon models of every gene; full tables + the candidate searches, each
+    step offering the alleles of one exon group) gives every field of every result of the per-gene path
+    (AlleleTypingExonFirst on a thread per gene): exon steps, candidate steps, the merged ranking, calls, warnings."""
+    data, ref, sample = tabulated
+    got = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("GK_SAMPLE_EXONFIRST", form)
+        typer = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
+        assert typer._wholeSampleExonFirst() == (form == "1")
+        got[form] = (typer.typing(sample.gene_cn), typer._result, typer.getAllPossibleTyping())
+    assert got["1"][0] == got["0"][0]
+    assert got["1"][2] == got["0"][2]
+    assert list(got["1"][1]) == list(got["0"][1])
+    for gene, want in got["0"][1].items():
+        have = got["1"][1][gene]
+        assert len(have) == len(want), gene
+        for a, b in zip(have, want):
+            same_result(a, b)
