@@ -316,6 +316,7 @@ class TypingWithPosNegAllele(_GenesInParallel):
                        "full": (rows_f, n_f, vflag_f, prepared_f), "force": force}
             jobs1.append(job)
         self.tables_rewritten = self.tables_patched = 0
+        self.exon_info: dict[str, dict] = {}     # per gene: exon groups, exon sets found, candidate searches run
         if jobs1:
             jobs, handles = run(jobs1, prep_e[0])
             try:
@@ -343,8 +344,10 @@ class TypingWithPosNegAllele(_GenesInParallel):
                 p["fallback"] = True
                 continue
             ranks = list(result.topRank(threshold=threshold))
-            if len(ranks) > 48:                 # a flood of exon sets (a threshold near 0): the per-gene path batches them
-                p["per_gene"] = True
+            self.exon_info[gene] = {"exon_groups": len(p["groups"]), "exon_sets": int(result.value.shape[0]),
+                                    "candidates": len(ranks)}
+            if len(ranks) > int(os.environ.get("GK_EXON_CANDIDATES_MAX", "1024")):
+                p["per_gene"] = True            # a flood of tied exon sets: the per-gene path stacks their searches per launch
                 continue
             job, _ = full.geneJob(cn, False)
             job.n_steps = 0                     # table + column sums; the searches are the jobs behind it

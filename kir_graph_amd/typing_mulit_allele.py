@@ -109,7 +109,9 @@ class TypingResult:
         logger.debug("[Allele] " + "\n".join(lines))
 
     def setNameGroup(self, allele_group_mapping: dict[str, list[str]]) -> None:
-        self.allele_name_group = [[allele_group_mapping[a] for a in row] for row in self.allele_name]
+        """``allele_name_group[i][j]`` = the member alleles of the j-th group of row i (166-169).  Rows are built when they
+        are read: exon-first reads the few rows that reach its threshold, the table has up to top_n."""
+        self.allele_name_group = _GroupRows(self.allele_name, allele_group_mapping)
 
     def sortByScoreAndEveness(self, preserve_topn: int = -1) -> "TypingResult":
         if preserve_topn == -1:
@@ -130,6 +132,27 @@ class TypingResult:
         if self.isFail():
             return []
         return [(self.value[r], self.allele_name[r]) for r in self.topRank(threshold)]
+
+
+class _GroupRows:
+    """``[[mapping[a] for a in row] for row in names]`` as a sequence whose rows are built on access."""
+
+    def __init__(self, names, mapping: dict[str, list[str]]):
+        self._names, self._mapping = names, mapping
+
+    def __len__(self) -> int:
+        return len(self._names)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        return [self._mapping[a] for a in self._names[i]]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __eq__(self, other) -> bool:
+        return list(self) == list(other)
 
 
 class LazyAlleleProb:
