@@ -839,12 +839,19 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
   SearchClock clock("pipelined", (int)live.size());
   std::vector<uint32_t> flags((size_t)n_jobs, 0);
   std::vector<std::unique_ptr<GeneSearch>> gs((size_t)n_jobs);
-  enum { kTable, kBound, kSums };
+  enum { kTable, kBound, kSums, kOneSet };
   struct Item { int gene, stage; uint64_t mark; };
   std::deque<Item> queue;
+  // Candidate searches whose every step offers ONE allele (exon groups of one member -- the usual case of a flood of tied
+  // exon sets): step k has one candidate, the set of the first k alleles, so the search IS that chain of sets.  The exact
+  // sums of the k-allele prefixes of all such searches of a gene are ONE set-sum call per k (the kernels and the tree of a
+  // search step: same bits), instead of a bound + a selection + a set sum of one set per search and step.
+  struct OneSetBatch { GkSumCall call; std::vector<int> deps; int k = 0; std::vector<int32_t> ids; };
+  std::vector<std::unique_ptr<OneSetBatch>> batches;
   auto fail = [&](int code) {
     gk_fetch_cancel(ctx);                        // copies still queued point into the searches that go away now
     for (auto& g : gs) if (g) g->abandon();
+    for (auto& b : batches) if (b) gk_release(ctx, b->call.temps);
     return code;
   };
   auto push = [&](int gene, int stage) {
@@ -919,10 +926,11 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
     rc = wait_mark(ctx, it.mark);
     clock.lap(true);
     if (rc) return fail(rc);
-    gk_gene_job& j = jobs[it.gene];
-    GeneSearch& g = *gs[it.gene];
+    const int at = it.stage == kOneSet ? batches[(size_t)it.gene]->deps[0] : it.gene;
+    gk_gene_job& j = jobs[at];
+    GeneSearch& g = *gs[at];
     switch (it.stage) {
-      case kTable:
+      case kTable: {
         if (flags[it.gene] & 4u) {
           // the kernel met a product without a log10 and left the product in its place (a sample that brings new values):
           // define what is stored by now -- this gene's kernel has completed, so its own keys are -- and patch THIS gene's
@@ -945,10 +953,30 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
           rc = g.first_step();
           if (rc == GK_OK) rc = advance(it.gene, true);
         }
+        std::vector<int> one_set;                        // the dependents whose steps offer one allele each
         for (int d : dependents[(size_t)it.gene]) {      // the table is final: the searches that read it begin
           if (rc) break;
           gk_gene_job& jd = jobs[d];
           jd.bound_ok = j.bound_ok;
+          bool single = jd.n_step_cols >= jd.n_steps && jd.n_steps >= 1;
+          for (int q = 0; q < jd.n_steps && single; ++q) single = jd.step_cols_off[q + 1] - jd.step_cols_off[q] == 1;
+          if (single) {
+            gs[d].reset(new GeneSearch());
+            gs[d]->S.reset(new gk_search());
+            gs[d]->S->n_allele = j.n_allele;
+            gs[d]->S->colsum = g.S->colsum;
+            const int32_t a0 = jd.step_cols[jd.step_cols_off[0]];
+            if (a0 < 0 || a0 >= j.n_allele) { gk_set_error("candidate allele out of range"); rc = GK_ERR_ARG; break; }
+            Step s1;
+            s1.n = 1;
+            s1.value.push_back(g.S->colsum[(size_t)a0]);
+            s1.sum_indv.push_back(g.S->colsum[(size_t)a0]);
+            s1.ids.push_back(a0);
+            s1.frac.push_back(1.0);
+            gs[d]->S->steps.push_back(std::move(s1));
+            if (jd.n_steps >= 2) one_set.push_back(d);
+            continue;
+          }
           gs[d].reset(new GeneSearch());
           std::vector<int32_t> every((size_t)j.n_allele);
           std::iota(every.begin(), every.end(), 0);
@@ -967,7 +995,50 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
             if (rc == GK_OK) rc = advance(d, true);
           }
         }
+        for (int k = 2; k <= 8 && rc == GK_OK; ++k) {     // the k-allele prefixes of every one-set search, one call per k
+          std::unique_ptr<OneSetBatch> b(new OneSetBatch());
+          b->k = k;
+          for (int d : one_set) {
+            if (jobs[d].n_steps < k) continue;
+            for (int q = 0; q < k; ++q) {
+              const int32_t a = jobs[d].step_cols[jobs[d].step_cols_off[q]];
+              if (a < 0 || a >= j.n_allele) { gk_set_error("candidate allele out of range"); rc = GK_ERR_ARG; }
+              b->ids.push_back(a);
+            }
+            b->deps.push_back(d);
+          }
+          if (rc || b->deps.empty()) break;
+          rc = gk_shares_enqueue(ctx, GkTable{j.d_L, j.n_rows, nullptr}, j.n_rows, b->ids.data(), (int32_t)b->deps.size(), k, true,
+                                 b->call);
+          if (rc) break;
+          gs[b->deps[0]]->S->note(2, j.n_rows, (int64_t)b->deps.size(), k, gs[b->deps[0]]->S->distinct(b->ids.data(), b->ids.size()), 0, 0);
+          batches.push_back(std::move(b));
+          rc = push((int)batches.size() - 1, kOneSet);
+        }
         break;
+      }
+      case kOneSet: {
+        OneSetBatch& b = *batches[(size_t)it.gene];
+        const int k = b.k;
+        std::vector<double> value(b.deps.size()), frac(b.deps.size() * (size_t)k);
+        gk_shares_collect(ctx, b.call, value.data(), frac.data());
+        for (size_t x = 0; x < b.deps.size(); ++x) {
+          gk_search& S = *gs[b.deps[x]]->S;
+          Step st;
+          st.n = k;
+          st.bounded = 1;
+          st.value.push_back(value[x]);
+          for (int q = 0; q < k; ++q) {
+            const int32_t a = b.ids[x * (size_t)k + q];
+            st.ids.push_back(a);
+            st.sum_indv.push_back(S.colsum[(size_t)a]);
+            st.frac.push_back(frac[x * (size_t)k + q]);
+          }
+          // the steps of a search arrive in order: the batches of a gene were queued k = 2, 3, ... on one stream
+          S.steps.push_back(std::move(st));
+        }
+        break;
+      }
       case kBound:
         rc = g.after_bound();
         if (rc == GK_OK) rc = g.sums_in_flight ? push(it.gene, kSums) : advance(it.gene, false);
