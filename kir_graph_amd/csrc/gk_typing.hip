@@ -458,6 +458,8 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
         // A thread keeps to ONE read (its alleles share a handful of values: most lookups end in the two registers).
         uint64_t key0 = kLutEmptyKey, key1 = kLutEmptyKey;   // the two most recent values of this thread's read
         double val0 = 0.0, val1 = 0.0;
+        uint32_t raise = 0;      // flag bits this thread wants raised: ONE atomic per wave below, not one per entry (the
+                                 // first sample of a run meets nothing but new products: 150 M atomics on one word)
         for (int idx = tid; idx < n_pass * kTileRows; idx += kCompatThreads) {
           const int al = idx / kTileRows, r = idx % kTileRows;
           if (r >= n_r) continue;
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
                 gk_lut_insert(lut, key);
                 if (bound_flags) {
                   const bool marks = (int64_t)key > 0;
-                  atomicOr(bound_flags, marks ? 4u : 12u);
+                  raise |= marks ? 4u : 12u;
                   if (marks) val = __longlong_as_double((long long)key);
                 }
               }
@@ -486,6 +488,10 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
             key0 = key; val0 = val;
           }
           *cell = val0;
+        }
+        if (bound_flags) {
+          const uint32_t pend = __ballot((raise & 4u) != 0) ? 4u : 0u, zero = __ballot((raise & 8u) != 0) ? 8u : 0u;
+          if ((pend | zero) && lane == 0) atomicOr(bound_flags, pend | zero);
         }
         __syncthreads();
       }

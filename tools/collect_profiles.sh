@@ -12,7 +12,7 @@ cd $R
 #    same mode as the bench's own serial pass (children are not allowed under the profiler on this pool)
 cd /tmp && export TMPDIR=/tmp
 export GK_PROCS_PER_GPU=1 GK_THREADS=1 GK_PREFETCH=0 GK_SAMPLE_LANES=1 GK_SAMPLE_STREAMS=1
-SERIAL="python3 $R/bench.py --cpu-pairs 0 --steps 6 --warmup 2 --serial-steps 2 --inputs hbm --one-kind --legs 1 --cli-samples 0"
+SERIAL="python3 $R/bench.py --cpu-pairs 0 --steps 40 --warmup 8 --serial-steps 2 --inputs hbm --one-kind --legs 1 --cli-samples 0"
 rocprofv3 --kernel-trace --stats -d $O/stats -o b --output-format csv -- $SERIAL > $O/bench_under_rocprof.json 2> $O/stats.err
 echo "[collect] kernel stats done"
 # 2. HBM traffic of every kernel over the same command: FETCH_SIZE and WRITE_SIZE in separate passes (the guide's
