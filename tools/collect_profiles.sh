@@ -15,6 +15,8 @@ export GK_PROCS_PER_GPU=1 GK_THREADS=1 GK_PREFETCH=0 GK_SAMPLE_LANES=1 GK_SAMPLE
 SERIAL="python3 $R/bench.py --cpu-pairs 0 --steps 40 --warmup 8 --serial-steps 2 --inputs hbm --one-kind --legs 1 --cli-samples 0"
 rocprofv3 --kernel-trace --stats -d $O/stats -o b --output-format csv -- $SERIAL > $O/bench_under_rocprof.json 2> $O/stats.err
 echo "[collect] kernel stats done"
+# the counter passes run fewer steps: their figures are per-launch averages and the raw per-dispatch CSVs are large
+SERIAL="python3 $R/bench.py --cpu-pairs 0 --steps 16 --warmup 4 --serial-steps 2 --inputs hbm --one-kind --legs 1 --cli-samples 0"
 # 2. HBM traffic of every kernel over the same command: FETCH_SIZE and WRITE_SIZE in separate passes (the guide's
 #    recipe; FETCH_SIZE counts half of coalesced reads on gfx950, corrected in tools/pmc_traffic.py)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/bench_fetch -o p --output-format csv -- $SERIAL > /dev/null 2>&1
@@ -28,6 +30,8 @@ for k in compat_kernel tab_count minsum_sad setsum_leaves fraction_chunks maxsum
   python3 $R/tools/pmc_traffic.py $O/bench_fetch/p_counter_collection.csv $O/bench_write/p_counter_collection.csv $k > $O/traffic_$k.json
   python3 $R/tools/pmc_summary.py $O $k > $O/pmc_$k.txt
 done
+# gpurun merges at most 64 MiB back: the raw per-dispatch counter files have been summarised above
+rm -f $O/bench_fetch/*.csv $O/bench_write/*.csv $O/pmc_sq1/*.csv $O/pmc_sq2/*.csv
 # 4. the driver's own command, AFTER the traffic files of this code are in place (bench.py only reports a traffic
 #    figure whose recorded source digest is the running code's): throughput line with roofline (serial pass) and CPU baseline
 cd $R
