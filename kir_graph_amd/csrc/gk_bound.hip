@@ -97,9 +97,13 @@ __global__ __launch_bounds__(kThreads, 2) void minsum_sad(const uint8_t* __restr
                                                           const uint8_t* __restrict__ Cbase, int64_t ldc,
                                                           const int32_t* __restrict__ cols, int n_cols, int64_t n16,
                                                           int blocks_per_slice, int tiles_a,
-                                                          uint32_t* __restrict__ partial) {
+                                                          uint32_t* __restrict__ partial, uint32_t* zero_state,
+                                                          int n_zero_words) {
   __shared__ uint4 lds[(kBT + kBA) * kLd];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // the selection state of the kernels that follow this one on the stream starts at zero (was a fill of its own)
+  if (blockIdx.x == 0 && blockIdx.y == 0)
+    for (int w = tid; w < n_zero_words; w += kThreads) zero_state[w] = 0;
   const int tile_t = blockIdx.x / tiles_a, tile_a = blockIdx.x % tiles_a;
   const int t0 = tile_t * kBT, c0 = tile_a * kBA;
   const int64_t blk0 = (int64_t)blockIdx.y * blocks_per_slice;
@@ -433,8 +437,8 @@ int gk_bound_enqueue(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, 
   GK_PROF_EXACT(ctx, GK_K_MINSUM,
                 GK_KERNEL(minsum_sad, dim3((unsigned)(tiles_t * tiles_a), (unsigned)n_slices), dim3(kThreads), 0, st,
                           c_prev >= 2 ? d_P : miss, ldm, c_prev >= 2 ? (const int32_t*)nullptr : d_ids, n_sets, miss,
-                          ldm, d_cols, n_cols, n16, blocks_per_slice, tiles_a, d_partial));
-  GK_HIP(hipMemsetAsync(d_state, 0, sizeof(SelState), st));
+                          ldm, d_cols, n_cols, n16, blocks_per_slice, tiles_a, d_partial, (uint32_t*)d_state,
+                          (int)(sizeof(SelState) / sizeof(uint32_t))));
   const dim3 per_elem((unsigned)((n_out + kThreads - 1) / kThreads));
   GK_PROF(ctx, GK_K_SELECT_CUT,
           GK_KERNEL(minsum_finish, per_elem, dim3(kThreads), 0, st, d_partial, n_slices, n_out, n_cols, d_psum,

@@ -117,8 +117,10 @@ __global__ __launch_bounds__(kThreads) void apply_correction(const uint32_t* cnt
 }
 
 __global__ __launch_bounds__(kThreads) void flag_nonempty(const int32_t* rows, int64_t n_rows, const uint32_t* off,
-                                                          const uint32_t* ids, const uint8_t* vflag, uint32_t* flag) {
+                                                          const uint32_t* ids, const uint8_t* vflag, uint32_t* flag,
+                                                          uint32_t* zero, int n_zero) {
   const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (zero && i < n_zero) zero[i] = 0;      // the per-gene counters of the launch that follows
   if (i >= n_rows) return;
   const int64_t row = rows[i];
   const uint32_t b = off[4 * row], mid = off[4 * row + 2], e = off[4 * row + 4];
@@ -145,35 +147,65 @@ __global__ __launch_bounds__(kThreads) void count_ids_genes(const int32_t* __res
   const int n_local = min(gene_vbeg[g + 1] - vbeg, max_local);
   for (int i = threadIdx.x; i < 2 * n_local; i += kThreads) hist[i] = 0;
   __syncthreads();
-  constexpr int kGroup = 16;
+  // Sixteen lanes per row.  The loads of a row depend on each other (row number -> list offsets -> ids -> drop flags) and
+  // a list has 30 - 100 ids: the offsets of the group's NEXT row are requested before this row's ids are walked, and the
+  // ids are taken 64 at a time (four loads per lane in flight, then their four flags) -- the kernel waits for memory,
+  // not for the LDS counters.
+  constexpr int kGroup = 16, kDeep = 4;
   const int lane = threadIdx.x & (kGroup - 1);
   const int64_t r0 = wg_row0[blockIdx.x], r1 = wg_row1[blockIdx.x];
-  for (int64_t i = r0 + threadIdx.x / kGroup; i < r1; i += kThreads / kGroup) {
+  constexpr int64_t kStep = kThreads / kGroup;
+  int64_t i = r0 + threadIdx.x / kGroup;
+  uint32_t b = 0, mid = 0, e = 0;
+  if (i < r1) {
     const int64_t row = rows[i];
-    const uint32_t b = off[4 * row], mid = off[4 * row + 2], e = off[4 * row + 4];
-    for (uint32_t k = b + lane; k < e; k += kGroup) {
-      const uint32_t v = ids[k];
-      const bool positive = k < mid;
-      if (vflag[v] & (positive ? 1 : 2)) continue;
-      const uint32_t l = v - (uint32_t)vbeg;
-      if (l < (uint32_t)n_local) atomicAdd(&hist[(positive ? 0 : n_local) + l], 1u);
-      else atomicAdd(positive ? &cnt_pos[v] : &cnt_neg[v], 1u);
+    b = off[4 * row]; mid = off[4 * row + 2]; e = off[4 * row + 4];
+  }
+  for (; i < r1; i += kStep) {
+    uint32_t nb = 0, nmid = 0, ne = 0;
+    if (i + kStep < r1) {
+      const int64_t row = rows[i + kStep];
+      nb = off[4 * row]; nmid = off[4 * row + 2]; ne = off[4 * row + 4];
     }
+    for (uint32_t k0 = b + lane; k0 < e; k0 += kGroup * kDeep) {
+      uint32_t v[kDeep];
+      uint8_t f[kDeep];
+#pragma unroll
+      for (int j = 0; j < kDeep; ++j) v[j] = k0 + kGroup * j < e ? ids[k0 + kGroup * j] : 0u;
+#pragma unroll
+      for (int j = 0; j < kDeep; ++j) f[j] = k0 + kGroup * j < e ? vflag[v[j]] : (uint8_t)3;
+#pragma unroll
+      for (int j = 0; j < kDeep; ++j) {
+        const uint32_t k = k0 + kGroup * j;
+        if (k >= e) break;
+        const bool positive = k < mid;
+        if (f[j] & (positive ? 1 : 2)) continue;
+        const uint32_t l = v[j] - (uint32_t)vbeg;
+        if (l < (uint32_t)n_local) atomicAdd(&hist[(positive ? 0 : n_local) + l], 1u);
+        else atomicAdd(positive ? &cnt_pos[v[j]] : &cnt_neg[v[j]], 1u);
+      }
+    }
+    b = nb; mid = nmid; e = ne;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * n_local; i += kThreads) {
-    const uint32_t c = hist[i];
-    if (c) atomicAdd(i < n_local ? &cnt_pos[vbeg + i] : &cnt_neg[vbeg + i - n_local], c);
+  for (int i2 = threadIdx.x; i2 < 2 * n_local; i2 += kThreads) {
+    const uint32_t c = hist[i2];
+    if (c) atomicAdd(i2 < n_local ? &cnt_pos[vbeg + i2] : &cnt_neg[vbeg + i2 - n_local], c);
   }
 }
 
-// kept[g] = rows of gene g with flag != 0 (rows grouped by gene: [gene_off[g], gene_off[g + 1]))
+// kept[g] += rows of gene g with flag != 0 (rows grouped by gene: [gene_off[g], gene_off[g + 1])); gridDim.y workgroups
+// share a gene (one workgroup per gene spent 70 us waiting for its own loads); `kept` is zero before the launch
+constexpr int kFlagSlices = 16;
 __global__ __launch_bounds__(kThreads) void count_flags_per_gene(const uint32_t* __restrict__ flag,
                                                                  const int64_t* __restrict__ gene_off,
                                                                  uint32_t* __restrict__ kept) {
   const int g = blockIdx.x;
+  const int64_t g0 = gene_off[g], g1 = gene_off[g + 1];
+  const int64_t per = (g1 - g0 + gridDim.y - 1) / gridDim.y;
+  const int64_t a = g0 + per * blockIdx.y, b = min(g1, a + per);
   uint32_t c = 0;
-  for (int64_t i = gene_off[g] + threadIdx.x; i < gene_off[g + 1]; i += kThreads) c += flag[i] != 0;
+  for (int64_t i = a + threadIdx.x; i < b; i += kThreads) c += flag[i] != 0;
   __shared__ uint32_t part[kThreads];
   part[threadIdx.x] = c;
   __syncthreads();
@@ -181,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void count_flags_per_gene(const uint32_t*
     if (threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2];
     __syncthreads();
   }
-  if (threadIdx.x == 0) kept[g] = part[0];
+  if (threadIdx.x == 0 && part[0]) atomicAdd(&kept[g], part[0]);
 }
 
 constexpr int kMaxSlots = 4;   // alleles per lane and pass: up to 256 alleles per pass
@@ -193,7 +225,9 @@ constexpr int kTileLd = kTileRows + 1;   // padded LDS stride (doubles) of the t
 // bit matrix [variant][words] -> [word][variant]: in the compatibility kernel lane k reads word w of the
 // k-th variant of a window, and windows are runs of consecutive ordinals, so the word-major copy turns
 // 64 strided row reads into one coalesced 256-byte read per word
-__global__ __launch_bounds__(kThreads) void transpose_mask(const uint32_t* mask, int n_span, int words, uint32_t* out) {
+__global__ __launch_bounds__(kThreads) void transpose_mask(const uint32_t* mask, int n_span, int words, uint32_t* out,
+                                                           uint32_t* zero_word) {
+  if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;   // the flag word of the launches that follow
   const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (i >= (int64_t)n_span * words) return;
   const int w = (int)(i / n_span), v = (int)(i % n_span);
@@ -535,6 +569,16 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
         }
       }
     }
+    if (kLog && miss8 && tile_i == n_tiles - 1) {
+      // rows of the mismatch table past the last tile, up to its stride (a multiple of 64 rows): zero, they add nothing
+      // to any |a - b| sum of the bound
+      const int64_t pad0 = n_tiles * kTileRows;
+      const int n_pad = (int)((ldm - pad0) / 4);
+      for (int it = tid; it < n_pass * n_pad; it += kCompatThreads) {
+        const int al = it / n_pad, w = it % n_pad;
+        *reinterpret_cast<uint32_t*>(miss8 + (int64_t)(a_base + al) * ldm + pad0 + 4 * w) = 0u;
+      }
+    }
     __syncthreads();
   }
 }
@@ -579,9 +623,12 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
   const int64_t n_mask = (int64_t)(vend - vbeg) * words;
   uint32_t* mask_t = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&mask_t, (size_t)std::max<int64_t>(n_mask, 1) * sizeof(uint32_t)));
+  // the flag word starts at zero: cleared by the transposition when there is one (a fill of its own otherwise)
   if (n_mask > 0)
     GK_KERNEL(transpose_mask, dim3((unsigned)((n_mask + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
-              gk_ptr<uint32_t>(d_mask), vend - vbeg, words, mask_t);
+              gk_ptr<uint32_t>(d_mask), vend - vbeg, words, mask_t, bound_flags);
+  else if (bound_flags)
+    GK_HIP(hipMemsetAsync(bound_flags, 0, sizeof(uint32_t), ctx->stream));
   // GK_COMPAT_FORM = select (default) | fma: how a factor is chosen, see compat_kernel (the fma form measured 1 - 2 %
   // slower on the bench sample, profiles/r03_compat_variants.txt: the factor loop is 56 % of the kernel's VALU work)
   // timing probe (tools/compat_phases.sh): honoured only together with GK_TIMING_PROBES=1, and never quietly
@@ -692,7 +739,7 @@ int gk_select_nonempty(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows,
   uint32_t* flag = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)n_rows * sizeof(uint32_t)));
   GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(flag_nonempty, dim3(nblk(n_rows)), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
-                     n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), flag));
+                     n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), flag, (uint32_t*)nullptr, 0));
   int rc = gk_compact(ctx, flag, gk_ptr<int32_t>(d_rows), n_rows, gk_ptr<int32_t>(d_rows_out), n_out);
   gk_pool_free(ctx,flag);
   return rc;
@@ -954,8 +1001,8 @@ static int sample_prepare(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_
   GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)n_rows * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&kept, (size_t)n_gene * sizeof(uint32_t)));
   GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(flag_nonempty, dim3(nblk(n_rows)), dim3(kThreads), 0, st, part.d_rows, n_rows,
-                                      tab->d_off, tab->d_ids, vflag, flag));
-  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(count_flags_per_gene, dim3((unsigned)n_gene), dim3(kThreads), 0, st, flag,
+                                      tab->d_off, tab->d_ids, vflag, flag, kept, n_gene));
+  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(count_flags_per_gene, dim3((unsigned)n_gene, kFlagSlices), dim3(kThreads), 0, st, flag,
                                       (const int64_t*)(d_tab + o_goff), kept));
   GK_HIP(hipGetLastError());
   // everything below is queued, then ONE wait: the compaction of the rows, the rows kept per gene, and -- when asked for --
@@ -1052,9 +1099,8 @@ int gk_compat_log_miss(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows,
   if (n_rows == 0 || n_allele == 0) return GK_OK;
   GK_REQUIRE(d_log && d_miss8 && d_flags, "null output");
   GK_REQUIRE(ldm >= n_rows && ldm % 64 == 0, "mismatch table stride must be a multiple of 64 rows");
-  // rows past the end of every column are zero, and so is the flag word, before the kernel writes
-  GK_HIP(hipMemsetAsync(gk_ptr<void>(d_miss8), 0, (size_t)n_allele * (size_t)ldm, ctx->stream));
-  GK_HIP(hipMemsetAsync(gk_ptr<void>(d_flags), 0, sizeof(uint32_t), ctx->stream));
+  // rows past the end of every column are zero (the workgroup of the last tile writes them), and so is the flag word
+  // before the kernel raises bits in it (launch_compat)
   return launch_compat<true>(ctx, tab, d_rows, n_rows, d_vflag, vbeg, vend, d_mask, words, n_allele,
                              gk_ptr<double>(d_log), nullptr, nullptr, gk_lut_view(lut), keep_empty,
                              gk_ptr<uint8_t>(d_miss8), ldm, gk_ptr<uint32_t>(d_flags));
@@ -1093,8 +1139,6 @@ int gk_compat_index(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk
   if (n_rows == 0 || n_allele == 0) return GK_OK;
   GK_REQUIRE(d_lidx && d_miss8 && d_flags, "null output");
   GK_REQUIRE(ldm >= n_rows && ldm % 64 == 0, "table stride must be a multiple of 64 rows");
-  GK_HIP(hipMemsetAsync(gk_ptr<void>(d_miss8), 0, (size_t)n_allele * (size_t)ldm, ctx->stream));
-  GK_HIP(hipMemsetAsync(gk_ptr<void>(d_flags), 0, sizeof(uint32_t), ctx->stream));
   return launch_compat<true>(ctx, tab, d_rows, n_rows, d_vflag, vbeg, vend, d_mask, words, n_allele, nullptr, nullptr,
                              nullptr, gk_lut_view(lut), keep_empty, gk_ptr<uint8_t>(d_miss8), ldm,
                              gk_ptr<uint32_t>(d_flags), gk_ptr<uint16_t>(d_lidx));
