@@ -530,7 +530,7 @@ __global__ __launch_bounds__(kLeafThreads) void setsum_leaves(const double* __re
   for (int s = 0; s < kS; ++s) {
     const int k = g + kLeafGroups * s;
 #pragma unroll
-    for (int q = 0; q < kC; ++q) loc[s][q] = (k < n_sets ? ids[k * kC + q] : 0) * kStageLd;
+    for (int q = 0; q < kC; ++q) loc[s][q] = (k < n_sets ? ids[k * kC + q] : 0) * kStageLd + j;   // the lane's first row
 #pragma unroll
     for (int q = 0; q < kO; ++q) acc[s][q] = 0.0;
     hits[s][0] = hits[s][1] = 0u;
@@ -543,7 +543,9 @@ __global__ __launch_bounds__(kLeafThreads) void setsum_leaves(const double* __re
   // the next block rides in registers (and a column's lane offset fits 32 bits: 31 columns of ld rows)
   const bool carried = n_elem <= kStagePrefetch * kLeafThreads && (uint64_t)ld * 32u * sizeof(double) < (1ull << 32);
 
-  // set s at staged row r: shares of the row's maximum (1 / number of alleles that reach it) + the maximum itself
+  // set s at staged row j + r (r a constant in the unrolled walk of a block: the LDS reads then carry it as their
+  // immediate offset and the loop has no address arithmetic at all): shares of the row's maximum (1 / number of alleles
+  // that reach it) + the maximum itself
   auto add_terms = [&](int r) {
 #pragma unroll
     for (int s = 0; s < kS; ++s) {
@@ -607,7 +609,17 @@ __global__ __launch_bounds__(kLeafThreads) void setsum_leaves(const double* __re
     }
     __syncthreads();
     if (carried && sb + 1 < n_stage) fetch(b0 + kStageRows, min(kStageRows, n8 - b0 - kStageRows));
-    for (int r = j; r < rows_in; r += 8) add_terms(r);
+    if (kS * kC <= 10 && rows_in == kStageRows) {       // (larger forms do not fit the registers unrolled)
+#pragma unroll
+      for (int k = 0; k < kStageRows / 8; ++k) {
+        add_terms(8 * k);
+        // the LDS reads of two rows in flight at a time where the registers allow it, of one row otherwise
+        if (kS * kC >= 10 || (k & 1)) __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll 1
+      for (int k = 0; k < rows_in / 8; ++k) add_terms(8 * k);      // rows_in is a multiple of 8 (n8 and the blocks are)
+    }
   }
   if (n8) {
 #pragma unroll
@@ -633,7 +645,7 @@ __global__ __launch_bounds__(kLeafThreads) void setsum_leaves(const double* __re
       if (n8 + t < len) sbuf[col * kStageLd + t] = base[(int64_t)col * ld + n8 + t];
     }
     __syncthreads();
-    for (int r = 0; r < len - n8; ++r) add_terms(r);   // same in every lane
+    for (int r = 0; r < len - n8; ++r) add_terms(r - j);   // row r, the same in every lane
   }
   if (kC == 2) {
 #pragma unroll
