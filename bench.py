@@ -611,14 +611,14 @@ def main():
     args.pinned_to = pinned          # handed to the workers (vars(args)): they bind the runtime's threads after the warm-up
     # Worker processes of this rank on its GPU (see worker()): started first, before anything touches HIP.
     # A sample is typed by ONE host thread on one stream (gk_sample_search: its genes pipelined on marks of the stream),
-    # three samples at a time (GK_SAMPLE_LANES) plus the staging thread(s): ONE process keeps the GPU fed from two to
-    # three host cores (profiles/r03_host_budget.txt, profiles/r03_default_layout.txt); GK_PROCS_PER_GPU=2 adds a second
-    # worker process (the default until the end of round 3).  Waits block instead of spinning: a rank of an 8-GPU
-    # node may have about two cores.
+    # three to five samples at a time (GK_SAMPLE_LANES: by the host cores the rank has, cohort.pipelineDefaults) plus the
+    # staging thread(s): ONE process keeps the GPU fed from two to four host cores (profiles/r04_sample_lanes.txt);
+    # GK_PROCS_PER_GPU=2 adds a second worker process.  Waits block instead of spinning: a rank of an 8-GPU node may
+    # have about two cores.
     procs = max(1, int(os.environ.get("GK_PROCS_PER_GPU", "1")))
     procs = min(procs, max(1, args.steps))
-    # blocking waits, three sample lanes, two search slots, the preamble on a high-priority stream: the package's own
-    # defaults for a process that types a cohort (kir_graph_amd.main sets the same ones)
+    # blocking waits, sample lanes and search slots by the rank's host cores, the preamble on a high-priority stream: the
+    # package's own defaults for a process that types a cohort (kir_graph_amd.main sets the same ones)
     from kir_graph_amd import cohort
     cohort.pipelineDefaults(procs)
     own_threads = procs > 1 and "GK_THREADS" not in os.environ and os.environ.get("GK_SAMPLE_SEARCH") == "0"
@@ -760,6 +760,8 @@ def main():
                        "cores_per_gpu": args.cores_per_gpu or None, "pinned_to": pinned,
                        "cores_allowed": len(cores_before), "cgroup_quota_cores": cgroup_cores(),
                        "worker_processes": procs, "sample_lanes": int(os.environ.get("GK_SAMPLE_LANES", "2")),
+                       "search_slots": int(os.environ.get("GK_SEARCH_SLOTS", "0") or 0),
+                       "cores_per_rank": cohort.hostCoresPerRank(),
                        "wait_policy": os.environ.get("GK_WAIT_POLICY", "runtime default"),
                        "note": "user + system time of rank 0's worker processes over the reported leg (getrusage); "
                                "a host thread that spins on the GPU counts as busy"}

@@ -70,18 +70,41 @@ def overlapped(items, work, lanes: int = 2):
             yield pending.pop(0).result()
 
 
-def pipelineDefaults(procs: int = 1) -> None:
+def hostCoresPerRank() -> int:
+    """Host cores this process may count on: the cores it is allowed on (affinity), capped by the container's CPU quota
+    (cgroup v2 ``cpu.max``), shared between the ranks of this node (LOCAL_WORLD_SIZE / WORLD_SIZE of any launcher)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    pinned = cores < (os.cpu_count() or cores)          # an affinity of its own (bench.py --cores-per-gpu): not shared
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    ranks = 1 if pinned else max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
+    return max(1, cores // ranks)
+
+
+def pipelineDefaults(procs: int = 1, cores: int | None = None) -> None:
     """Environment defaults of the sample pipeline, set before the first HIP call of the process (the wait policy is
-    read when a context is made).  ``main._runCohort`` and ``bench.py`` both call this: ONE worker process per GPU types
-    three samples at a time (``GK_SAMPLE_LANES``), two of them inside their search (``GK_SEARCH_SLOTS``), the sample
-    preamble on a high-priority stream, waits that put the thread to sleep (a rank of an 8-GPU node has about two
-    cores).  With several worker processes on a GPU (``procs`` > 1) two lanes each and a plain preamble measured
-    better (profiles/r03_stream_priority.txt, r03_search_slots.txt).  Anything the user set stays."""
+    read when a context is made).  ``main.main`` and ``bench.py`` both call this: ONE worker process per GPU types
+    several samples at a time (``GK_SAMPLE_LANES``), some of them inside their search (``GK_SEARCH_SLOTS``), the sample
+    preamble on a high-priority stream, waits that put the thread to sleep.  How many depends on the host cores the rank
+    has (``cores``, default ``hostCoresPerRank()``): five lanes and three searches where it has six or more (7.7 ms per
+    configs[1] sample on 3.8 busy cores), four and two from three cores (8.0 ms on 2.8), three and two below that
+    (8.3 ms on 2.6; a rank of an 8-GPU node on a 16-core quota has two) -- profiles/r04_sample_lanes.txt.  With several
+    worker processes on a GPU (``procs`` > 1) two lanes each and a plain preamble measured better
+    (profiles/r03_stream_priority.txt, r03_search_slots.txt).  Anything the user set stays."""
+    cores = hostCoresPerRank() if cores is None else cores
+    lanes, slots = (5, 3) if cores >= 6 else (4, 2) if cores >= 3 else (3, 2)
     os.environ.setdefault("GK_WAIT_POLICY", "block")
     os.environ.setdefault("GK_URGENT_PREAMBLE", "1" if procs == 1 else "0")
-    os.environ.setdefault("GK_SAMPLE_LANES", "3" if procs == 1 else "2")
+    os.environ.setdefault("GK_SAMPLE_LANES", str(lanes) if procs == 1 else "2")
     if procs == 1:
-        os.environ.setdefault("GK_SEARCH_SLOTS", "2")
+        os.environ.setdefault("GK_SEARCH_SLOTS", str(slots))
 
 
 def sampleLanes() -> int:

@@ -43,7 +43,9 @@ def test_one_gpu_line_keeps_the_contract(device):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert "traffic" in r and "kernel" in r and r["avg_launch_ms"] > 0
     h = d["host"]
-    assert h["host_core_s_per_step"] > 0 and h["worker_processes"] == 1 and h["sample_lanes"] == 3
+    assert h["host_core_s_per_step"] > 0 and h["worker_processes"] == 1
+    # lanes x searches follow the host cores the rank has (cohort.pipelineDefaults)
+    assert (h["sample_lanes"], h["search_slots"]) in ((5, 3), (4, 2), (3, 2))
     p = d["hbm_resident"]
     assert p["unit"] == "reads/s" and p["value"] > 0 and p["ms_per_step"] > 0 and len(p["legs"]) == 3
     assert d["search_steps"]["bounded"] > 0
@@ -67,8 +69,10 @@ def test_cli_typing_stage_keeps_pace_with_the_bench(device):
     """The command line's typing stage (main.alleleTyping: copy-number files, typing lanes, the two files per sample) on 12
     configs[1] samples against the bench's step on the same samples in the same process: one code path
     (cohort.SampleTyper), so the CLI may cost at most 1.3 x the measured step."""
+    # three lanes for both: with five (the default where a rank has six cores or more) the fill and drain of the pipeline
+    # are a third of a 12-sample run, which says nothing about the code path
     d = _run(["--steps", "12", "--warmup", "4", "--distinct", "4", "--cpu-pairs", "0", "--serial-steps", "0", "--legs", "1",
-              "--cli-samples", "12"], timeout=900)
+              "--cli-samples", "12"], env={"GK_SAMPLE_LANES": "3", "GK_SEARCH_SLOTS": "2"}, timeout=900)
     c = d["cli_typing_stage"]
     assert c["samples"] == 12 and c["ms_per_sample"] > 0
     assert c["ms_per_sample"] <= 1.3 * d["ms_per_step"], (c["ms_per_sample"], d["ms_per_step"])
