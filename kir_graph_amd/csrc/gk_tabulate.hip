@@ -247,14 +247,52 @@ struct Walked {
   int lo, hi;            // ordinals of the window [lo, hi)
 };
 
+// Where a walk keeps its event words.  EvPtr: a row of words the negative filter reads back (LDS in tab_emit, global for
+// the wide format), and optionally the saved form of pass 1 beside it.  EvRow (tab_count): ONE word per event -- the saved
+// form (ordinal, or kEvNovel | slot of the novel table) with the N flag on top -- the first four in registers, the rest in
+// the mate's overflow row; a row of 22 words per mate and array used to be written a few words at a time, which cost a
+// full line of HBM traffic (and its read-modify-write) per mate and array.
+constexpr int kEvRegs = 4;
+constexpr int kEvMore = kMaxEv - kEvRegs;
+struct EvPtr {
+  uint32_t* evw;
+  uint32_t* out;
+  __device__ void put(int n, uint32_t word, uint32_t saved, bool) const {
+    evw[n] = word;
+    if (out) out[n] = saved;
+  }
+};
+struct EvView {      // read side of a row of event words in the filter's own form
+  const uint32_t* evw;
+  __device__ uint32_t get(int e) const { return evw[e]; }
+  __device__ uint32_t n_pos(uint32_t w, const IndexView& ix) const {
+    return (w & kEvNovel) ? (w & 0xFFFFFFu) : gk_key_pos(ix.key[w & kEvOrdMask]);
+  }
+};
+struct EvRow {
+  uint32_t r[kEvRegs];
+  uint32_t* more;        // the mate's overflow row: events kEvRegs .. kMaxEv - 1
+  const uint64_t* novel_keys;
+  __device__ void put(int n, uint32_t, uint32_t saved, bool is_n) {
+    const uint32_t w = saved | (is_n ? kEvIsN : 0u);
+    if (n == 0) r[0] = w; else if (n == 1) r[1] = w; else if (n == 2) r[2] = w; else if (n == 3) r[3] = w;
+    else more[n - kEvRegs] = w;
+  }
+  __device__ uint32_t get(int e) const {   // a novel event carries bit 31 in either form: far outside any window
+    return e == 0 ? r[0] : e == 1 ? r[1] : e == 2 ? r[2] : e == 3 ? r[3] : more[e - kEvRegs];
+  }
+  __device__ uint32_t n_pos(uint32_t w, const IndexView& ix) const {      // position of an event that reads N
+    return (w & kEvNovel) ? gk_key_pos(novel_keys[w & 0xFFFFFFu]) : gk_key_pos(ix.key[w & kEvOrdMask]);
+  }
+};
+
 // ev_out (pass 1 only, may be null): the positive list of the mate as it will be emitted -- the ordinal of a
 // known variant, kEvNovel | slot of the novel table otherwise -- so that pass 2 need not walk again.
 // sequence numbers of novel variants are mate << 16 | event (first appearance = smallest), whatever the record format;
 // the stride is the event capacity of the widest record format present in the sample.
-template <bool kEmit, typename View>
+template <bool kEmit, typename View, typename Ev>
 __device__ inline void walk_mate(const View& r, const IndexView& ix, const NovelTable& nt, int64_t m,
-                                 uint32_t* evw, uint32_t* ids, uint32_t o_pos, uint32_t o_pos_end, uint32_t* ev_out,
-                                 Walked& wk) {
+                                 Ev& ev, uint32_t* ids, uint32_t o_pos, uint32_t o_pos_end, Walked& wk) {
   wk.n = 0; wk.clipped = false; wk.overflow = false; wk.drop = false; wk.any_n = 0; wk.bad_window = false;
   wk.lo = wk.hi = 0; wk.right = 0;
   const int n_cig = min((int)r.n_cig(), View::kCapCig);
@@ -295,16 +333,16 @@ __device__ inline void walk_mate(const View& r, const IndexView& ix, const Novel
     }
     const bool is_n = typ == GK_TYP_SINGLE && val == 'N';
     if (is_n) wk.any_n = 1;
-    evw[wk.n] = (known ? (uint32_t)i : (kEvNovel | (pos & 0xFFFFFFu))) | (is_n ? kEvIsN : 0u);
+    const uint32_t word = (known ? (uint32_t)i : (kEvNovel | (pos & 0xFFFFFFu))) | (is_n ? kEvIsN : 0u);
     if (!known && typ != GK_TYP_SINGLE) wk.drop = true;   // novel insertion / deletion: mate yields ([], [])
+    uint32_t saved = (uint32_t)i;
     if (kEmit) {
       if (o_pos + wk.n < o_pos_end)
         ids[o_pos + wk.n] = known ? (uint32_t)i : (uint32_t)ix.n_var + novel_rank(nt, k);
     } else {
-      uint32_t saved = (uint32_t)i;
       if (!known) saved = kEvNovel | novel_insert(nt, k, ((uint64_t)m << 16) | (uint64_t)wk.n);
-      if (ev_out) ev_out[wk.n] = saved;
     }
+    ev.put(wk.n, word, saved, is_n);
     last_pos = pos; last_len = len; last_novel = !known;
     wk.n++;
   };
@@ -339,17 +377,17 @@ __device__ inline void walk_mate(const View& r, const IndexView& ix, const Novel
   wk.bad_window = wk.lo > wk.hi;
 }
 
-__device__ inline bool negative_kept(uint64_t k, int i, const IndexView& ix, const uint32_t* evw, int n_ev,
+template <typename Ev>
+__device__ inline bool negative_kept(uint64_t k, int i, const IndexView& ix, const Ev& ev, int n_ev,
                                      uint32_t any_n, uint32_t right) {
   const uint32_t typ = gk_key_typ(k), pos = gk_key_pos(k), val = gk_key_val(k);
   for (int e = 0; e < n_ev; ++e)
-    if ((evw[e] & ~kEvIsN) == (uint32_t)i) return false;   // a positive of this mate
+    if ((ev.get(e) & ~kEvIsN) == (uint32_t)i) return false;   // a positive of this mate
   if (any_n && typ == GK_TYP_SINGLE && (val == 'A' || val == 'C' || val == 'G' || val == 'T')) {
     for (int e = 0; e < n_ev; ++e) {
-      const uint32_t w = evw[e];
+      const uint32_t w = ev.get(e);
       if (!(w & kEvIsN)) continue;
-      const uint32_t p = (w & kEvNovel) ? (w & 0xFFFFFFu) : gk_key_pos(ix.key[w & kEvOrdMask]);
-      if (p == pos) return false;                           // the read says N here
+      if (ev.n_pos(w, ix) == pos) return false;             // the read says N here
     }
   }
   if (typ == GK_TYP_DEL && pos + val + 10u >= right) return false;
@@ -406,8 +444,8 @@ __device__ inline uint32_t cooperative_negatives(WaveNeg& wv, const IndexView& i
     uint32_t i = 0;
     if (active) {
       i = wv.lo[owner] + (c - start);
-      keep = negative_kept(ix.key[i], (int)i, ix, evs_wave + owner * kEvLd, (int)wv.n_ev[owner], wv.any_n[owner],
-                           wv.right[owner]);
+      keep = negative_kept(ix.key[i], (int)i, ix, EvView{evs_wave + owner * kEvLd}, (int)wv.n_ev[owner],
+                           wv.any_n[owner], wv.right[owner]);
     }
     if (!kEmit && keep && c - start < 32u * kMaskWords) atomicOr(&wv.mask[owner][(c - start) >> 5], 1u << ((c - start) & 31u));
     // candidates of one owner are a run of consecutive lanes
@@ -429,8 +467,14 @@ __device__ inline uint32_t cooperative_negatives(WaveNeg& wv, const IndexView& i
 // through the index's static deletion bitmap -- are looked at one by one for the right-edge rule.  Substitutions to N
 // (which exclude the four bases at their position) and windows beyond the saved 256 bits are rare and take the
 // candidate-by-candidate loop.  The kept bits land in `words` (LDS, kMaskWords per lane); returns the kept count.
-__device__ inline uint32_t window_negatives(const IndexView& ix, const uint32_t* evw, int n_ev, uint32_t any_n,
-                                            uint32_t right, uint32_t lo, uint32_t len, uint32_t* words) {
+constexpr int kMaskRegs = 4;     // kept bits of the first 128 candidates ride in registers (one dense 16-byte store per mate)
+__device__ inline uint32_t window_negatives(const IndexView& ix, const EvRow& ev, int n_ev, uint32_t any_n,
+                                            uint32_t right, uint32_t lo, uint32_t len, uint32_t (&first)[kMaskRegs],
+                                            uint32_t* more /* words kMaskRegs .. kMaskWords - 1 of the mate */) {
+  auto keep_word = [&](uint32_t w, uint32_t word) {
+    if (w == 0) first[0] = word; else if (w == 1) first[1] = word; else if (w == 2) first[2] = word;
+    else if (w == 3) first[3] = word; else more[w - kMaskRegs] = word;
+  };
   // `evw` (the mate's event words) and `words` (its kMaskWords words of kept bits) are per-mate rows in GLOBAL memory:
   // a word is built in a register and stored once, the events are few and read back from L2 -- the 33 KB of LDS the
   // two arrays took per workgroup halved the kernel's occupancy (2 waves per SIMD)
@@ -439,12 +483,12 @@ __device__ inline uint32_t window_negatives(const IndexView& ix, const uint32_t*
     uint32_t kept = 0, cur = 0;
     for (uint32_t c = 0; c < len; ++c) {
       const uint32_t i = lo + c;
-      if (negative_kept(ix.key[i], (int)i, ix, evw, n_ev, any_n, right)) {
+      if (negative_kept(ix.key[i], (int)i, ix, ev, n_ev, any_n, right)) {
         ++kept;
         cur |= 1u << (c & 31u);
       }
       if ((c & 31u) == 31u || c + 1 == len) {
-        if (c < 32u * kMaskWords) words[c >> 5] = cur;
+        if (c < 32u * kMaskWords) keep_word(c >> 5, cur);
         cur = 0;
       }
     }
@@ -453,7 +497,7 @@ __device__ inline uint32_t window_negatives(const IndexView& ix, const uint32_t*
   // the first events relative to the window, in registers (novel events carry bit 31: far outside any window)
   uint32_t rel4[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) rel4[q] = q < n_ev ? (evw[q] & ~kEvIsN) - lo : 0xFFFFFFFFu;
+  for (int q = 0; q < 4; ++q) rel4[q] = q < n_ev ? (ev.r[q] & ~kEvIsN) - lo : 0xFFFFFFFFu;
   const uint32_t n_words = (len + 31u) >> 5;
   uint32_t kept = 0;
   for (uint32_t w = 0; w < n_words; ++w) {
@@ -465,7 +509,7 @@ __device__ inline uint32_t window_negatives(const IndexView& ix, const uint32_t*
       if (rel < 32u) word &= ~(1u << rel);
     }
     for (int e = 4; e < n_ev; ++e) {
-      const uint32_t rel = (evw[e] & ~kEvIsN) - lo - 32u * w;
+      const uint32_t rel = (ev.more[e - kEvRegs] & ~kEvIsN) - lo - 32u * w;
       if (rel < 32u) word &= ~(1u << rel);
     }
     // deletions reaching within 10 bases of the right edge
@@ -479,7 +523,7 @@ __device__ inline uint32_t window_negatives(const IndexView& ix, const uint32_t*
       if (gk_key_pos(k) + gk_key_val(k) + 10u >= right) word &= ~(1u << bit);
     }
     kept += (uint32_t)__popc(word);
-    words[w] = word;
+    keep_word(w, word);
   }
   return kept;
 }
@@ -489,19 +533,21 @@ __device__ inline uint32_t window_negatives(const IndexView& ix, const uint32_t*
 __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int64_t n_mates, IndexView ix,
                                                       NovelTable nt, uint32_t* cnt /*[4*n_pairs+1]*/,
                                                       uint32_t* valid /*[n_pairs]*/, int* err_flags,
-                                                      uint32_t* ev_save /*[n_mates][kMaxEv]*/,
+                                                      uint4* ev_save /*[n_mates]: events 0 .. 3*/,
+                                                      uint32_t* ev_more /*[n_mates][kEvMore]: the rest*/,
                                                       uint32_t* lo_save /*[n_mates]*/,
-                                                      uint32_t* mask_save /*[n_mates][kMaskWords]*/,
-                                                      uint32_t* ev_words /*[n_mates][kMaxEv]: the walk's event words*/) {
-  // LDS holds the heads of the staged records only (17 KB per workgroup); a mate's event words and the kept bits of
-  // its window live in its rows of `ev_words` / `mask_save`
+                                                      uint4* mask_save /*[n_mates]: kept bits of candidates 0 .. 127*/,
+                                                      uint32_t* mask_more /*[n_mates][kMaskWords - kMaskRegs]*/) {
+  // LDS holds the heads of the staged records only (17 KB per workgroup); a mate's first four event words and the kept
+  // bits of the first 128 candidates of its window ride in registers and leave as ONE dense 16-byte store each (a wave
+  // writes 1 KB of full lines); what goes beyond (rare) lives in the mate's overflow rows
   __shared__ uint32_t rec[kThreads * kHeadLd];
   const int64_t m0 = (int64_t)blockIdx.x * kThreads;
   stage_heads(mates, m0, n_mates, rec);
   const int64_t m = m0 + threadIdx.x;
   const bool in = m < n_mates;
   const HeadView r{rec + threadIdx.x * kHeadLd, reinterpret_cast<const uint32_t*>(mates + (in ? m : 0))};
-  uint32_t* evw = ev_words + (in ? m : 0) * kMaxEv;
+  EvRow ev{{0u, 0u, 0u, 0u}, ev_more + (in ? m : 0) * kEvMore, nt.keys};
   const bool ok = in && r.passes() && !r.spilled();   // wide pairs: tab_count_wide writes their counts afterwards
   const bool ok_other = __shfl_xor((int)ok, 1, 64) != 0;
   const bool pair_ok = ok && ok_other;
@@ -512,7 +558,7 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
   wk.n = 0; wk.lo = wk.hi = 0; wk.right = 0; wk.any_n = 0;
   bool enumerate = false;
   if (pair_ok) {
-    walk_mate<false>(r, ix, nt, m, evw, nullptr, 0, 0, ev_save + m * kMaxEv, wk);
+    walk_mate<false>(r, ix, nt, m, ev, nullptr, 0, 0, wk);
     if (wk.overflow) atomicOr(err_flags, 2);
     if (wk.clipped) {
     } else if (wk.bad_window) {
@@ -522,20 +568,22 @@ __global__ __launch_bounds__(kThreads) void tab_count(const gk_mate* mates, int6
       enumerate = true;
     }
   }
-  // the kept bits of the window go straight to the mate's row of mask_save (what pass 2 needs to write the negative
-  // list without enumerating the window again)
-  const uint32_t n_neg = enumerate ? window_negatives(ix, evw, wk.n, wk.any_n, wk.right, (uint32_t)wk.lo,
-                                                      (uint32_t)(wk.hi - wk.lo), mask_save + m * kMaskWords)
+  // the kept bits of the window: what pass 2 needs to write the negative list without enumerating the window again
+  uint32_t kept_bits[kMaskRegs] = {0u, 0u, 0u, 0u};
+  const uint32_t n_neg = enumerate ? window_negatives(ix, ev, wk.n, wk.any_n, wk.right, (uint32_t)wk.lo,
+                                                      (uint32_t)(wk.hi - wk.lo), kept_bits,
+                                                      mask_more + (in ? m : 0) * (kMaskWords - kMaskRegs))
                                    : 0u;
   if (!in) return;
   cnt[4 * pair + side] = n_pos;
   cnt[4 * pair + 2 + side] = n_neg;
   if (side == 0) valid[pair] = pair_ok ? 1u : 0u;
-  if (enumerate) {
-    const uint32_t len = (uint32_t)(wk.hi - wk.lo);
-    if (len > 32u * kMaskWords) atomicOr(err_flags, 4);   // does not fit the saved bits: the host takes the two-walk path
-    lo_save[m] = (uint32_t)wk.lo;
-  }
+  if (enumerate && (uint32_t)(wk.hi - wk.lo) > 32u * kMaskWords)
+    atomicOr(err_flags, 4);   // does not fit the saved bits: the host takes the two-walk path
+  // dense stores, every mate (pass 2 only reads the rows of mates that have lists)
+  ev_save[m] = make_uint4(ev.r[0], ev.r[1], ev.r[2], ev.r[3]);
+  mask_save[m] = make_uint4(kept_bits[0], kept_bits[1], kept_bits[2], kept_bits[3]);
+  lo_save[m] = (uint32_t)wk.lo;
 }
 
 // pass 2 without a second walk: the lists are written from what pass 1 saved -- the positive list as
@@ -550,8 +598,9 @@ constexpr uint32_t kExpandCap = 4096;   // ids staged per wavefront (16 KB)
 
 __global__ __launch_bounds__(kExpandThreads) void tab_expand(int64_t n_mates, int n_var, const uint32_t* rank,
                                                              const uint32_t* off, const uint32_t* valid,
-                                                             const uint32_t* ev_save, const uint32_t* lo_save,
-                                                             const uint32_t* mask_save, uint32_t* ids) {
+                                                             const uint4* ev_save, const uint32_t* ev_more,
+                                                             const uint32_t* lo_save, const uint4* mask_save,
+                                                             const uint32_t* mask_more, uint32_t* ids) {
   __shared__ uint32_t stage[kExpandWaves][kExpandCap];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -572,15 +621,21 @@ __global__ __launch_bounds__(kExpandThreads) void tab_expand(int64_t n_mates, in
     if (valid[pair] == 1u) {      // 2 = a pair of the wide format: pass 1 saved nothing for it, tab_emit_wide writes its lists
       const uint32_t o_pos = off[4 * pair + side], n_pos = off[4 * pair + side + 1] - o_pos;
       const uint32_t o_neg = off[4 * pair + 2 + side], n_neg = off[4 * pair + 2 + side + 1] - o_neg;
-      for (uint32_t e = 0; e < n_pos; ++e) {
-        const uint32_t w = ev_save[m * kMaxEv + e];
-        put(o_pos + e, (w & kEvNovel) ? (uint32_t)n_var + rank[w & 0xFFFFFFu] : w);
+      if (n_pos) {
+        const uint4 e4 = ev_save[m];
+        const uint32_t first[kEvRegs] = {e4.x, e4.y, e4.z, e4.w};
+        for (uint32_t e = 0; e < n_pos; ++e) {
+          const uint32_t w = (e < (uint32_t)kEvRegs ? first[e] : ev_more[m * kEvMore + e - kEvRegs]) & ~kEvIsN;
+          put(o_pos + e, (w & kEvNovel) ? (uint32_t)n_var + rank[w & 0xFFFFFFu] : w);
+        }
       }
       if (n_neg) {
         const uint32_t lo = lo_save[m];
+        const uint4 m4 = mask_save[m];
+        const uint32_t firstw[kMaskRegs] = {m4.x, m4.y, m4.z, m4.w};
         uint32_t j = 0;
         for (int w = 0; w < kMaskWords && j < n_neg; ++w) {
-          uint32_t bits = mask_save[m * kMaskWords + w];
+          uint32_t bits = w < kMaskRegs ? firstw[w] : mask_more[m * (kMaskWords - kMaskRegs) + w - kMaskRegs];
           while (bits) {
             const int b = __ffs(bits) - 1;
             bits &= bits - 1;
@@ -679,7 +734,8 @@ __global__ __launch_bounds__(kThreads) void tab_emit(const gk_mate* mates, int64
   uint32_t* evw = evs + threadIdx.x * kEvLd;
   Walked wk;
   wk.n = 0; wk.lo = wk.hi = 0; wk.right = 0; wk.any_n = 0;
-  if (o_pos != o_pos_end || o_neg != o_neg_end) walk_mate<true>(r, ix, nt, m, evw, ids, o_pos, o_pos_end, nullptr, wk);
+  EvPtr ev{evw, nullptr};
+  if (o_pos != o_pos_end || o_neg != o_neg_end) walk_mate<true>(r, ix, nt, m, ev, ids, o_pos, o_pos_end, wk);
   const int wid = threadIdx.x >> 6;
   // a mate with an empty negative list has nothing to enumerate (its window may still be non-empty)
   cooperative_negatives<true>(wneg[wid], ix, evs + wid * 64 * kEvLd, o_neg != o_neg_end ? (uint32_t)(wk.hi - wk.lo) : 0u,
@@ -705,7 +761,8 @@ __global__ __launch_bounds__(64) void tab_count_wide(const gk_mate_wide* wide, c
   uint32_t n_pos = 0, n_neg = 0;
   if (pair_ok) {
     Walked wk;
-    walk_mate<false>(r, ix, nt, 2 * pair + side, evw, nullptr, 0, 0, nullptr, wk);
+    EvPtr ev{evw, nullptr};
+    walk_mate<false>(r, ix, nt, 2 * pair + side, ev, nullptr, 0, 0, wk);
     if (wk.overflow) atomicOr(err_flags, 2);
     if (wk.clipped) {
     } else if (wk.bad_window) {
@@ -713,7 +770,7 @@ __global__ __launch_bounds__(64) void tab_count_wide(const gk_mate_wide* wide, c
     } else if (!wk.drop) {
       n_pos = (uint32_t)wk.n;
       for (int i = wk.lo; i < wk.hi; ++i)
-        n_neg += negative_kept(ix.key[i], i, ix, evw, wk.n, wk.any_n, wk.right) ? 1u : 0u;
+        n_neg += negative_kept(ix.key[i], i, ix, EvView{evw}, wk.n, wk.any_n, wk.right) ? 1u : 0u;
     }
   }
   cnt[4 * pair + side] = n_pos;
@@ -735,10 +792,11 @@ __global__ __launch_bounds__(64) void tab_emit_wide(const gk_mate_wide* wide, co
   const WideView r{wide + t};
   uint32_t* evw = evw_all + t * GK_WIDE_EVENTS;
   Walked wk;
-  walk_mate<true>(r, ix, nt, 2 * pair + side, evw, ids, o_pos, o_pos_end, nullptr, wk);
+  EvPtr ev{evw, nullptr};
+  walk_mate<true>(r, ix, nt, 2 * pair + side, ev, ids, o_pos, o_pos_end, wk);
   uint32_t at = o_neg;
   for (int i = wk.lo; i < wk.hi && at < o_neg_end; ++i)
-    if (negative_kept(ix.key[i], i, ix, evw, wk.n, wk.any_n, wk.right)) ids[at++] = (uint32_t)i;
+    if (negative_kept(ix.key[i], i, ix, EvView{evw}, wk.n, wk.any_n, wk.right)) ids[at++] = (uint32_t)i;
 }
 
 __global__ __launch_bounds__(kThreads) void gather_pairs(const gk_mate* mates, const int32_t* pair_src, int64_t n_valid,
@@ -981,12 +1039,16 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
   GK_HIP(hipMemsetAsync(nt.keys, 0xFF, cap * sizeof(uint64_t), st));
   GK_HIP(hipMemsetAsync(nt.seq, 0xFF, cap * sizeof(uint64_t), st));
 
-  uint32_t *cnt = nullptr, *valid = nullptr, *ev_save = nullptr, *lo_save = nullptr, *mask_save = nullptr, *ev_words = nullptr;
+  uint32_t *cnt = nullptr, *valid = nullptr, *lo_save = nullptr, *ev_more = nullptr, *mask_more = nullptr;
+  uint4 *ev_save = nullptr, *mask_save = nullptr;
   int* d_err = nullptr;
-  GK_HIP(gk_pool_malloc(ctx, (void**)&ev_save, (size_t)(n_mates + 1) * kMaxEv * sizeof(uint32_t)));
-  GK_HIP(gk_pool_malloc(ctx, (void**)&ev_words, (size_t)(n_mates + 1) * kMaxEv * sizeof(uint32_t)));
+  // what pass 1 saves for pass 2: per mate 16 dense bytes of event words, 16 of kept bits, the window's first ordinal, and
+  // overflow rows that a mate with more than four events / a window beyond 128 candidates writes
+  GK_HIP(gk_pool_malloc(ctx, (void**)&ev_save, (size_t)(n_mates + 1) * sizeof(uint4)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&ev_more, (size_t)(n_mates + 1) * kEvMore * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&lo_save, (size_t)(n_mates + 1) * sizeof(uint32_t)));
-  GK_HIP(gk_pool_malloc(ctx, (void**)&mask_save, (size_t)(n_mates + 1) * kMaskWords * sizeof(uint32_t)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&mask_save, (size_t)(n_mates + 1) * sizeof(uint4)));
+  GK_HIP(gk_pool_malloc(ctx, (void**)&mask_more, (size_t)(n_mates + 1) * (kMaskWords - kMaskRegs) * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&cnt, (size_t)(4 * n_pairs + 2) * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&valid, (size_t)(n_pairs + 1) * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_err, sizeof(int)));
@@ -998,7 +1060,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
                      idx->d_gene_pbase, idx->d_snp_ord};
   if (n_mates) {
     GK_PROF(ctx, GK_K_TAB_COUNT, GK_KERNEL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
-                       nt, cnt, valid, d_err, ev_save, lo_save, mask_save, ev_words));
+                       nt, cnt, valid, d_err, ev_save, ev_more, lo_save, mask_save, mask_more));
   }
   int64_t* d_spill_pair = nullptr;
   uint32_t* wide_ev = nullptr;
@@ -1047,7 +1109,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
     *table_too_small = true;
     GK_HIP(hipStreamSynchronize(st));
     gk_pool_free(ctx,cnt); gk_pool_free(ctx,valid); gk_pool_free(ctx,d_err); gk_pool_free(ctx,bitmap); gk_pool_free(ctx,prefix); gk_pool_free(ctx,wide_bits);
-    gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save); gk_pool_free(ctx,ev_words);
+    gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save); gk_pool_free(ctx,ev_more); gk_pool_free(ctx,mask_more);
     gk_pool_free(ctx,d_spill_pair); gk_pool_free(ctx,wide_ev);
     gk_pool_free(ctx,nt.keys); gk_pool_free(ctx,nt.seq); gk_pool_free(ctx,nt.rank);
     gk_tab_destroy(tab);
@@ -1067,7 +1129,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
                          cnt, valid, tab->d_ids));
     } else {
       GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_expand, dim3(nblk(n_mates, kExpandThreads)), dim3(kExpandThreads), 0, st, n_mates, idx->n_var,
-                         nt.rank, cnt, valid, ev_save, lo_save, mask_save, tab->d_ids));
+                         nt.rank, cnt, valid, ev_save, ev_more, lo_save, mask_save, mask_more, tab->d_ids));
     }
     // the pairs of the wide format, AFTER the kernel above (tab_expand copies a wavefront's whole run of lists out of LDS,
     // the slots of a wide pair included; tab_emit leaves them alone): their lists overwrite whatever lies there
@@ -1087,7 +1149,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
   GK_HIP(hipGetLastError());
   GK_HIP(hipStreamSynchronize(st));
   gk_pool_free(ctx,cnt); gk_pool_free(ctx,valid); gk_pool_free(ctx,d_err); gk_pool_free(ctx,bitmap); gk_pool_free(ctx,prefix); gk_pool_free(ctx,wide_bits);
-  gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save); gk_pool_free(ctx,ev_words);
+  gk_pool_free(ctx,ev_save); gk_pool_free(ctx,lo_save); gk_pool_free(ctx,mask_save); gk_pool_free(ctx,ev_more); gk_pool_free(ctx,mask_more);
   gk_pool_free(ctx,d_spill_pair); gk_pool_free(ctx,wide_ev);
   gk_pool_free(ctx,nt.keys); gk_pool_free(ctx,nt.seq); gk_pool_free(ctx,nt.rank);
   if (err & 2) {
