@@ -1107,3 +1107,38 @@ def test_compact_records_on_the_host_hold_exactly_the_used_words():
         assert np.array_equal(cm.words[:len(rec) + 1], np.array(offsets, dtype=np.uint32))
         assert np.array_equal(cm.words[len(rec) + 1:], want)
         assert cm.nbytes * 4 < rec.nbytes
+
+
+def test_pipeline_defaults_follow_the_cores_of_the_rank(monkeypatch):
+    """cohort.pipelineDefaults: sample lanes x searches at a time by the host cores a rank has (the affinity, shared by the
+    ranks of the node unless the rank was pinned to cores of its own); whatever the user set stays."""
+    from kir_graph_amd import cohort
+    for name in ("GK_SAMPLE_LANES", "GK_SEARCH_SLOTS", "GK_WAIT_POLICY", "GK_URGENT_PREAMBLE", "WORLD_SIZE", "LOCAL_WORLD_SIZE"):
+        monkeypatch.delenv(name, raising=False)
+    monkeypatch.setattr(os, "cpu_count", lambda: 64)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
+    quota = cohort.hostCoresPerRank()                  # the container's cgroup quota may cap the 64
+    assert 1 <= quota <= 64
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert cohort.hostCoresPerRank() == max(1, quota // 8)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")         # two nodes of four ranks
+    assert cohort.hostCoresPerRank() == max(1, quota // 4)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {0, 1, 2}, raising=False)   # pinned: cores of its own
+    assert cohort.hostCoresPerRank() == min(3, quota)
+    for cores, want in ((16, ("5", "3")), (6, ("5", "3")), (4, ("4", "2")), (3, ("4", "2")), (2, ("3", "2"))):
+        monkeypatch.delenv("GK_SAMPLE_LANES", raising=False)
+        monkeypatch.delenv("GK_SEARCH_SLOTS", raising=False)
+        cohort.pipelineDefaults(cores=cores)
+        assert (os.environ["GK_SAMPLE_LANES"], os.environ["GK_SEARCH_SLOTS"]) == want, cores
+        assert os.environ["GK_WAIT_POLICY"] == "block"
+    monkeypatch.setenv("GK_SAMPLE_LANES", "2")          # the user's choice stays
+    monkeypatch.delenv("GK_SEARCH_SLOTS", raising=False)
+    cohort.pipelineDefaults(cores=16)
+    assert os.environ["GK_SAMPLE_LANES"] == "2" and os.environ["GK_SEARCH_SLOTS"] == "3"
+    monkeypatch.delenv("GK_SAMPLE_LANES", raising=False)
+    monkeypatch.delenv("GK_SEARCH_SLOTS", raising=False)
+    monkeypatch.delenv("GK_URGENT_PREAMBLE", raising=False)
+    cohort.pipelineDefaults(procs=2, cores=16)          # several worker processes on one GPU: two lanes each
+    assert os.environ["GK_SAMPLE_LANES"] == "2" and "GK_SEARCH_SLOTS" not in os.environ
+    for name in ("GK_SAMPLE_LANES", "GK_SEARCH_SLOTS", "GK_WAIT_POLICY", "GK_URGENT_PREAMBLE"):
+        os.environ.pop(name, None)                      # set by pipelineDefaults itself, not through monkeypatch
