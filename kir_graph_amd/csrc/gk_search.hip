@@ -506,7 +506,10 @@ constexpr int kLeafThreads = 1024;
 constexpr int kLeafGroups = kLeafThreads / 8;        // 128 lane groups = sets in flight per "slot"
 constexpr int kLeafSlots = 6;                        // sets per lane group at most: up to 768 sets per launch
 constexpr int kStageRows = 32;
-constexpr int kStageLd = kStageRows + 1;             // odd stride: the 8 groups of a wavefront read different banks
+#ifndef GK_STAGE_LD
+#define GK_STAGE_LD (kStageRows + 1)
+#endif
+constexpr int kStageLd = GK_STAGE_LD;                // odd stride: the 8 groups of a wavefront read different banks
 constexpr int kStagePrefetch = 8;                    // staged values a thread carries in registers: <= 256 columns
 constexpr int kFoldOut = 64;                         // outputs per workgroup of fold_leaves
 constexpr int kMaxChunkLeaves = kChunkRows / 64;     // a leaf of a split node has >= 64 rows
