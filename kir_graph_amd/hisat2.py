@@ -334,14 +334,58 @@ def writeCompact(data: SampleData, filename: str, index_ref: str = "", backgroun
     return background.submit(np.savez, path, **fields)
 
 
+RECORDS_FORMAT = "graphkir-records-1"
+
+
+def writeCompactRecords(compact, pack: dict, novel_base: int, index: GkIndex, filename: str, index_ref: str = "",
+                        background=None):
+    """The hand-off as the sample's PACKED RECORDS in their compact form (``packed.CompactMates``: ~30 bytes per mate --
+    70 MB for 2 M reads where the tabulated lists of ``writeCompact`` are 250 MB that first have to come back from the
+    device): what the command line writes when the records are at hand.  ``loadCompact`` expands and tabulates them
+    again -- same records, same index, same first novel id: the same lists (0.9 ms per million pairs on the device).
+    ``pack``: the dictionary of ``packAlignments`` (pairs beyond the 128-byte record, inserted strings)."""
+    path = filename if filename.endswith(".npz") else filename + ".npz"
+    spill = pack["counts"].get("spill")
+    strings = pack["strings"]
+    fields = dict(
+        format=np.array(RECORDS_FORMAT), index_ref=np.array(index_ref), fingerprint=indexFingerprint(index),
+        genes=np.array(index.genes), words=np.asarray(compact.words), n_mates=np.array(compact.n_mates),
+        novel_base=np.array(novel_base), ins_strings=np.array(strings if strings else [""]),
+        n_ins=np.array(len(strings or [])),
+        spill_wide=(np.ascontiguousarray(spill[0]).view(np.uint8).reshape(-1) if spill is not None else np.zeros(0, np.uint8)),
+        spill_pair=(np.ascontiguousarray(spill[1], dtype=np.int64) if spill is not None else np.zeros(0, np.int64)))
+    if background is None:
+        np.savez(path, **fields)
+        return None
+    return background.submit(np.savez, path, **fields)
+
+
+def _loadCompactRecords(z, filename: str, dev: Device, index: GkIndex, dindex: DeviceIndex) -> SampleData:
+    from . import _lib as gl
+    from .packed import CompactMates
+    compact = CompactMates.__new__(CompactMates)
+    compact.words = np.ascontiguousarray(z["words"], np.uint32)
+    compact.n_mates = int(z["n_mates"])
+    spill = None
+    if len(z["spill_pair"]):
+        spill = (np.ascontiguousarray(z["spill_wide"]).view(gl.MATE_WIDE_DTYPE), np.ascontiguousarray(z["spill_pair"], np.int64))
+    mates = compact.toDevice(dev, wait=True)
+    tab = Tabulation(dindex, mates, novel_base=int(z["novel_base"]), dev=dev, spill=spill)
+    mates.free()
+    tab.mates = None
+    strings = [str(x) for x in z["ins_strings"][:int(z["n_ins"])]]
+    return SampleData(tab, index, None, ins_strings=strings)
+
+
 _index_cache: dict[str, GkIndex] = {}
 
 
 def loadCompact(filename: str, dev: Device | None = None, index: GkIndex | None = None,
                 dindex: DeviceIndex | None = None) -> SampleData:
-    """Load ``writeCompact`` output as a device CSR (no re-tabulation, no Variant objects built)."""
+    """Load a hand-off file: ``writeCompact`` output as a device CSR (no re-tabulation, no Variant objects built), or
+    ``writeCompactRecords`` output (the packed records: expanded and tabulated again on the device)."""
     z = np.load(filename, allow_pickle=False)
-    if str(z["format"]) != COMPACT_FORMAT:
+    if str(z["format"]) not in (COMPACT_FORMAT, RECORDS_FORMAT):
         raise ValueError(f"{filename}: unknown format {z['format']!r}")
     if index is None:
         ref = str(z["index_ref"])
@@ -354,6 +398,8 @@ def loadCompact(filename: str, dev: Device | None = None, index: GkIndex | None 
         raise ValueError(f"{filename} was tabulated against a different index")
     dev = dev or Device()
     dindex = dindex or DeviceIndex(dev, index)
+    if str(z["format"]) == RECORDS_FORMAT:
+        return _loadCompactRecords(z, filename, dev, index, dindex)
     off, ids = np.ascontiguousarray(z["off"], np.uint32), np.ascontiguousarray(z["ids"], np.uint32)
     gene, nh = np.ascontiguousarray(z["pair_gene"], np.uint8), np.ascontiguousarray(z["pair_nh"], np.uint8)
     novel_key = np.ascontiguousarray(z["novel_key"], np.uint64)

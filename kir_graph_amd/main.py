@@ -31,7 +31,7 @@ from . import cohort
 from .external_tools import setEngine
 from .hisat2 import (ParkedRecords, SampleData, extractVariant, extractVariantFromPacked, extractVariantFromText,  # noqa: F401
                      packAlignments, readExons, readPair,
-                     saveReadsToBam, writeCompact,
+                     saveReadsToBam, writeCompact, writeCompactRecords,
                      writeReadsAndVariantsData, writeSampleJson)
 from .index import GkIndex
 from .kir_cn import filterDepth, loadCN, predictSamplesCN
@@ -124,11 +124,19 @@ def _mapLoop(names, prepare, ahead, gk, gene_len, staging, dindex, index_ref, ex
     for name, source, pack in cohort.prefetched(range(len(names)), prepare, depth=ahead, workers=ahead):
         name += ".variant"
         logger.info(f"[Graph] Filter mapping ({name})")
+        handed_off = False
         if pack is not None:
             # pinned records -> HBM on the copier's stream: compact words copied and expanded there, or the 128-byte records
             compact = pack.pop("compact", None)
             mates = compact.toDevice(copier, wait=True) if compact is not None else copier.put(pack["records"])
             data = extractVariantFromPacked(pack, gk, dev=dev, dindex=dindex, mates=mates)
+            if (compact is not None and not write_json and os.environ.get("GK_HANDOFF", "always") != "lazy"
+                    and os.environ.get("GK_HANDOFF_FORM", "records") == "records"):
+                # the hand-off as the compact records that are in host memory anyway (70 MB for 2 M reads) instead of the
+                # tabulated lists fetched back from the device (250 MB): hisat2.writeCompactRecords / loadCompact
+                writes.append(writeCompactRecords(compact, pack, data.tab.novel_base, gk, name + ".npz",
+                                                  index_ref=index_ref, background=writer))
+                handed_off = True
         else:   # BAM name-collated through samtools like the reference (hisat2.readBam)
             data = extractVariant(readPair(source), gk, dev=dev, dindex=dindex)
         del pack
@@ -137,6 +145,8 @@ def _mapLoop(names, prepare, ahead, gk, gene_len, staging, dindex, index_ref, ex
             # the reference also rewrites the filtered pairs as BAM (hisat2.py:936-940)
             saveReadsToBam(data, name, source)
             saveReadsToBam(data, name + ".no_multi", source, filter_multi_mapped=True)
+        elif handed_off:
+            pass
         elif os.environ.get("GK_HANDOFF", "always") != "lazy":
             # compact hand-off instead: CSR + string table, no SAM text (hisat2.writeCompact).  GK_HANDOFF=lazy: only
             # for a sample that has to leave HBM before it is typed (main(): the --cn-cohort retention budget) -- a

@@ -184,3 +184,36 @@ def test_compact_side_format_round_trip(device, tmp_path):
     other = synth.makeIndex(seed=13, n_genes=3, var_range=(200, 300), allele_range=(12, 20))
     with pytest.raises(ValueError):
         loadCompact(path, device, index=GkIndex.fromVariants(other.variants, genes=other.genes, exons=other.exons))
+
+
+def test_records_side_format_round_trip(device, tmp_path):
+    """hisat2.writeCompactRecords / loadCompact: the hand-off as the sample's packed records in compact form (what the
+    command line writes with --no-variant-json) gives the tabulation it was written beside -- lists, novel numbering,
+    pairs of the wide record format included -- and types like it."""
+    from kir_graph_amd.hisat2 import extractVariantFromPacked, loadCompact, packAlignments, writeCompactRecords
+    from kir_graph_amd.kir_typing import selectKirTypingModel
+    from kir_graph_amd.packed import CompactMates
+    sidx = synth.makeIndex(seed=14, n_genes=3, var_range=(200, 300), allele_range=(12, 20))
+    prefix = str(tmp_path / "idx")
+    sidx.write(prefix)
+    gidx = GkIndex.load(prefix)
+    s = synth.makeSample(sidx, seed=9, n_pairs=3000, err_rate=0.004)
+    rng = np.random.default_rng(5)
+    lines = synth.withManyMismatches(synth.toSamLines(s), sidx, rng.choice(s.n_pairs, size=5, replace=False).tolist(), rng)
+    sam = tmp_path / "s.sam"
+    sam.write_text("\n".join(lines) + "\n")
+    pack = packAlignments(str(sam), gidx, keep_text=False)
+    assert pack["counts"].get("spill") is not None and len(pack["counts"]["spill"][1]) > 0
+    compact = CompactMates(pack["records"], threads=2)
+    data = extractVariantFromPacked(pack, gidx, dev=device, mates=compact.toDevice(device, wait=True))
+    path = str(tmp_path / "s.variant.npz")
+    writeCompactRecords(compact, pack, data.tab.novel_base, gidx, path, index_ref=prefix)
+    back = loadCompact(path, device)
+    assert back.tab.n_valid == data.tab.n_valid and back.tab.n_novel == data.tab.n_novel and back.tab.n_novel > 0
+    assert np.array_equal(back.tab.ids(), data.tab.ids()) and np.array_equal(back.tab.offsets(), data.tab.offsets())
+    assert [str(v.id) for v in back.novel] == [str(v.id) for v in data.novel]
+    want = selectKirTypingModel("pv", data, top_n=600, variant_correction=True).typing(s.gene_cn)
+    assert selectKirTypingModel("pv", path, top_n=600, variant_correction=True).typing(s.gene_cn) == want
+    other = synth.makeIndex(seed=13, n_genes=3, var_range=(200, 300), allele_range=(12, 20))
+    with pytest.raises(ValueError):
+        loadCompact(path, device, index=GkIndex.fromVariants(other.variants, genes=other.genes, exons=other.exons))
