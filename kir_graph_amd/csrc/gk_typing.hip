@@ -274,8 +274,16 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
                                                                 const uint32_t* mask_t, int words, int n_allele, int a_base,
                                                                 double* probs, uint8_t* miss_out, uint16_t* nvar_out,
                                                                 LutView lut, double empty_p, uint8_t* miss8, int64_t ldm,
-                                                                uint32_t* bound_flags, uint16_t* lidx, int probe,
+                                                                uint32_t* bound_flags, uint16_t* lidx, int probe_arg,
                                                                 int uniform_cut) {
+  // The timing probe is compiled OUT of the shipped kernel: it exists only in a library built with -DGK_TIMING_PROBES=1
+  // (GK_EXTRA_HIPCC_FLAGS, tools/compat_phases.sh); otherwise `probe` is the constant 0 and its branches are gone.
+#if defined(GK_TIMING_PROBES) && GK_TIMING_PROBES
+  const int probe = probe_arg;
+#else
+  constexpr int probe = 0;
+  (void)probe_arg;
+#endif
   // probe (tools/compat_phases.sh, GK_COMPAT_PROBE): 1 = leave out the walk over the kept variants, 2 = leave out the way
   // out of a tile, 3 = only its second pass (the stores), 4 = only its first (the value-table look-ups) -- WRONG results, for timing the two halves of the kernel only; 0 in every real launch
   const int n_span = vend - vbeg;   // mask_t: [words][n_span], see transpose_mask
@@ -631,10 +639,15 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
     GK_HIP(hipMemsetAsync(bound_flags, 0, sizeof(uint32_t), ctx->stream));
   // GK_COMPAT_FORM = select (default) | fma: how a factor is chosen, see compat_kernel (the fma form measured 1 - 2 %
   // slower on the bench sample, profiles/r03_compat_variants.txt: the factor loop is 56 % of the kernel's VALU work)
-  // timing probe (tools/compat_phases.sh): honoured only together with GK_TIMING_PROBES=1, and never quietly
+  // timing probe (tools/compat_phases.sh): only in a library built with -DGK_TIMING_PROBES=1, there only together with
+  // GK_TIMING_PROBES=1 in the environment, and never quietly
+#if defined(GK_TIMING_PROBES) && GK_TIMING_PROBES
   const char* const probe_env = getenv("GK_COMPAT_PROBE");
   const char* const probes_on = getenv("GK_TIMING_PROBES");
   const int probe = (probe_env && probes_on && !strcmp(probes_on, "1")) ? atoi(probe_env) : 0;
+#else
+  const int probe = 0;
+#endif
   if (probe) {
     static std::once_flag warned;
     std::call_once(warned, [&] {
