@@ -384,7 +384,8 @@ class Device:
         self.ordinal = ordinal
         self._urgent: "Device | None" = None
         self.call_log: list[tuple] | None = None   # set to [] to record launch geometry (bench roofline)
-        self._workers: list["Device"] = []
+        self._workers: dict[int, "Device"] = {}
+        self._workers_lock = threading.Lock()
         Device.instances.append(self)
 
     instances: list["Device"] = []
@@ -392,9 +393,11 @@ class Device:
     def worker(self, k: int, urgent: bool = False) -> "Device":
         """k-th extra context (own stream + allocator) on the same GPU, for per-gene host threads (``urgent`` counts
         when the context is made: see ``Device``)."""
-        while len(self._workers) <= k:
-            self._workers.append(Device(self.ordinal, urgent=urgent and len(self._workers) == k))
-        return self._workers[k]
+        with self._workers_lock:        # made on first use: the lanes of a process use a few of the slots they own
+            w = self._workers.get(k)
+            if w is None:
+                w = self._workers[k] = Device(self.ordinal, urgent=urgent)
+            return w
 
     def urgent(self) -> "Device":
         """This context's high-priority sibling (made on first use): for the short preamble of a sample, whose small
