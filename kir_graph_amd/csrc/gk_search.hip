@@ -507,9 +507,12 @@ constexpr int kLeafGroups = kLeafThreads / 8;        // 128 lane groups = sets i
 constexpr int kLeafSlots = 6;                        // sets per lane group at most: up to 768 sets per launch
 constexpr int kStageRows = 32;
 #ifndef GK_STAGE_LD
-#define GK_STAGE_LD (kStageRows + 1)
+#define GK_STAGE_LD (kStageRows + 8)
 #endif
-constexpr int kStageLd = GK_STAGE_LD;                // odd stride: the 8 groups of a wavefront read different banks
+// 40 doubles: a column's 16-bank window (8 lanes x 8 bytes) starts at a multiple of 16 banks, so the two lane groups of an
+// LDS pass collide only when their columns' distance is a multiple of 4 (with the odd stride 33 the windows overlapped for
+// 15 of 32 distances: 46 % of the LDS cycles were conflicts) -- 2 % of the kernel, profiles/r04_compat_experiments.txt
+constexpr int kStageLd = GK_STAGE_LD;
 constexpr int kStagePrefetch = 8;                    // staged values a thread carries in registers: <= 256 columns
 constexpr int kFoldOut = 64;                         // outputs per workgroup of fold_leaves
 constexpr int kMaxChunkLeaves = kChunkRows / 64;     // a leaf of a split node has >= 64 rows

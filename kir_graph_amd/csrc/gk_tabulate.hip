@@ -466,7 +466,8 @@ __device__ inline uint32_t cooperative_negatives(WaveNeg& wv, const IndexView& i
 // ones; its own positives are cleared by ordinal (a handful of events), and only the DELETIONS of the window -- found
 // through the index's static deletion bitmap -- are looked at one by one for the right-edge rule.  Substitutions to N
 // (which exclude the four bases at their position) and windows beyond the saved 256 bits are rare and take the
-// candidate-by-candidate loop.  The kept bits land in `words` (LDS, kMaskWords per lane); returns the kept count.
+// candidate-by-candidate loop.  The kept bits of the first 128 candidates land in `first` (registers), the rest in the
+// mate's overflow row `more`; returns the kept count.
 constexpr int kMaskRegs = 4;     // kept bits of the first 128 candidates ride in registers (one dense 16-byte store per mate)
 __device__ inline uint32_t window_negatives(const IndexView& ix, const EvRow& ev, int n_ev, uint32_t any_n,
                                             uint32_t right, uint32_t lo, uint32_t len, uint32_t (&first)[kMaskRegs],
@@ -475,9 +476,8 @@ __device__ inline uint32_t window_negatives(const IndexView& ix, const EvRow& ev
     if (w == 0) first[0] = word; else if (w == 1) first[1] = word; else if (w == 2) first[2] = word;
     else if (w == 3) first[3] = word; else more[w - kMaskRegs] = word;
   };
-  // `evw` (the mate's event words) and `words` (its kMaskWords words of kept bits) are per-mate rows in GLOBAL memory:
-  // a word is built in a register and stored once, the events are few and read back from L2 -- the 33 KB of LDS the
-  // two arrays took per workgroup halved the kernel's occupancy (2 waves per SIMD)
+  // the mate's event words come from `ev` (four registers + its overflow row); a word of kept bits is built in a register
+  // and kept there (or stored once, beyond the fourth)
   if (len == 0) return 0;
   if (any_n || len > 32u * kMaskWords) {
     uint32_t kept = 0, cur = 0;
