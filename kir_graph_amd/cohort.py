@@ -93,8 +93,8 @@ def pipelineDefaults(procs: int = 1, cores: int | None = None) -> None:
     read when a context is made).  ``main.main`` and ``bench.py`` both call this: ONE worker process per GPU types
     several samples at a time (``GK_SAMPLE_LANES``), some of them inside their search (``GK_SEARCH_SLOTS``), the sample
     preamble on a high-priority stream, waits that put the thread to sleep.  How many depends on the host cores the rank
-    has (``cores``, default ``hostCoresPerRank()``): five lanes and three searches where it has six or more (7.7 ms per
-    configs[1] sample on 3.8 busy cores), four and two from three cores (8.0 ms on 2.8), three and two below that
+    has (``cores``, default ``hostCoresPerRank()``): five lanes and three searches where it has six or more (7.2 - 7.7 ms per
+    configs[1] sample on 3 - 4 busy cores), four and two from three cores (8.0 ms on 2.8), three and two below that
     (8.3 ms on 2.6; a rank of an 8-GPU node on a 16-core quota has two) -- profiles/r04_sample_lanes.txt.  With several
     worker processes on a GPU (``procs`` > 1) two lanes each and a plain preamble measured better
     (profiles/r03_stream_priority.txt, r03_search_slots.txt).  Anything the user set stays."""
