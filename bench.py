@@ -2,12 +2,20 @@
 """
 bench.py -- typed 150 bp PE reads/s of the Graph-KIR hot path on MI355X.
 
-One "step" = one synthetic sample (BASELINE.json configs[1]: 2 M reads = 1 M pairs, ~2 k alleles in 15 genes,
---allele-strategy pv == full, top_n 600, variant correction on) taken from packed alignment records to per-gene allele
-calls on the host: the tabulation (gk_tabulate), the sample preamble (error correction, empty reads, zygosity tallies),
-per gene the compatibility table through the log10 value table and the greedy multi-allele likelihood search
-(gk_sample_search), and the allele selection.  The steps run through the package's own sample pipeline
-(kir_graph_amd.cohort: stagedSamples -> typeSamples), the one `python -m kir_graph_amd.main` types a cohort with.
+One "step" = one synthetic sample taken from packed alignment records to per-gene allele calls on the host: the tabulation
+(gk_tabulate), the sample preamble (error correction, empty reads, zygosity tallies), per gene the compatibility table
+through the log10 value table and the allele selection of the strategy -- the greedy multi-allele likelihood search
+(gk_sample_search: pv; exon-first: the exon models, then the candidate searches on the full tables) or the EM
+(gk_sample_em).  The steps run through the package's own sample pipeline (kir_graph_amd.cohort: stagedSamples ->
+typeSamples), the one `python -m kir_graph_amd.main` types a cohort with.
+
+Workloads.  Without --pairs / --method the line's headline (`value`) is BASELINE.json configs[2] -- 20 M reads = 10 M
+pairs per sample, --allele-strategy exonfirst (what the reference's own pipeline runs, kir/graphkir.py:76-87) -- and, on one
+GPU, two more workloads are measured the same way and reported as objects of the same line: `em` (configs[2],
+--allele-strategy em: EM to convergence) and `configs1_pv` (configs[1]: 2 M reads, --allele-strategy pv -- the headline of
+rounds 1 - 4).  Each carries its own legs, `kernels_serial`, `roofline` and `cpu_baseline`.  With --pairs and / or --method:
+that one workload.  All use the synthetic example_index-shaped index (~2.4 k alleles in 15 genes), top_n 600, variant
+correction on.
 
 Two kinds of timed leg over the same K steps, each bracketed by a barrier + device synchronise on both sides, each kind
 timed `--legs` times (default 3) with the MEDIAN leg reported:
@@ -16,9 +24,9 @@ timed `--legs` times (default 3) with the MEDIAN leg reported:
                           records are inside the region (SURVEY.md section 8(d)), staged two samples ahead of the typing;
   hbm   (`hbm_resident`)  the records of the distinct samples are resident in HBM before the clock starts.
 `--inputs hbm` swaps the two (`value` from resident records, `pcie_inclusive` beside it).
-Consecutive steps take DIFFERENT samples: `--distinct N` (default 8) distinct ones per rank in rotation, seeds
-1031 + 7 rank + i.  With N >= steps + warmup the first leg types only samples nobody has typed before -- `legs[0]`
-then says what a NEW sample costs (value_table_new_per_sample, samples_repeated_pass), the later legs what a repeated one.
+Consecutive steps take DIFFERENT samples: `--distinct N` distinct ones per rank in rotation (2 at configs[2] size -- a
+sample takes ~30 s to make -- 8 below), seeds 1031 + 7 rank + i.  With N >= steps + warmup the first leg types only samples
+nobody has typed before -- `legs[0]` then says what a NEW sample costs (value_table_new_per_sample, samples_repeated_pass).
 
 ``--gpus N``: N ranks, one per GPU, every rank types its own samples (cohort sharding: weak scaling, no
 data-path collective); value = reads of all ranks / max-over-ranks time.  Started without a launcher
@@ -27,18 +35,20 @@ anything here touches the GPU -- and relays rank 0's line; under `torchrun` (RAN
 is one of the ranks.  Ranks meet through kir_graph_amd/comm.py (RCCL: barrier + max of the times).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline        the dominant kernel of the step, from a ONE-PROCESS, SERIAL pass (one sample at a time on one
-                  stream, no prefetch) run right after the timed legs: HIP-event time per launch, algorithmic
-                  bytes / operations per launch (kir_graph_amd/roofmodel.py); `roofline.step` =
-                  the algorithmic bytes of ALL launches of a step over the reported ms_per_step against 8 TB/s
-  kernels_serial  per-kernel launches and time per step of that pass (the basis rocprofv3 reproduces, profiles/)
+  roofline        the dominant kernel of the step, from a SERIAL pass (one sample at a time on one stream, no prefetch)
+                  run right after the timed legs: HIP-event time per launch, algorithmic bytes / operations per launch
+                  (kir_graph_amd/roofmodel.py); `roofline.step` = the algorithmic bytes of ALL
+                  launches of a step over the reported ms_per_step against 8 TB/s; `traffic` = HBM bytes per launch from the
+                  committed PMC passes of the same workload on the same device sources (profiles/)
+  kernels_serial  per-kernel launches and time per step of that pass, under the kernels' own names (the basis rocprofv3
+                  reproduces, profiles/)
   legs            every timed leg of the headline kind in the order they ran
-  cpu_baseline    the oracle (CPU restatement of the reference) on a bounded sample of the same
-                  workload, one core and N-way over the host's cores
-  host            what the step costs on the host: core-seconds per step (user + system time of every worker
-                  process of rank 0 over the reported leg, getrusage), cores busy on average, the cores the rank was
-                  allowed (``--cores-per-gpu K`` pins every rank and its workers to K cores of its own before
-                  anything touches HIP: the budget an 8-GPU node leaves each rank)
+  cpu_baseline    the oracle (CPU restatement of the reference) on a bounded sample of the same workload and strategy,
+                  one core and (headline) N-way over the host's cores
+  host            what the step costs on the host: core-seconds per step (user + system time of rank 0's process over the
+                  reported leg, getrusage), cores busy on average, the cores the rank was allowed (``--cores-per-gpu K``
+                  pins every rank to K cores of its own before anything touches HIP: the budget an 8-GPU node leaves a rank)
+  em, configs1_pv the other two workloads (see above)
 """
 from __future__ import annotations
 
@@ -87,6 +97,7 @@ def pin_rank(local_rank: int, k: int) -> list[int]:
     cores = allowed_cores()
     mine = [cores[(local_rank * k + i) % len(cores)] for i in range(min(k, len(cores)))]
     os.sched_setaffinity(0, set(mine))
+    os.environ["GK_PRIVATE_CORES"] = "1"      # cohort.hostCoresPerRank: this affinity is the rank's own, not the node's
     return sorted(set(mine))
 
 
@@ -288,7 +299,11 @@ def _oracle_leg(job, barrier=None, out=None):
     t0 = time.time()
     data = ot.tabulateLines(lines, gidx.variants)
     t1 = time.time()
-    typer = oty.makeTyper("full" if method in ("pv", "full") else method, data, top_n=600, variant_correction=True)
+    if method in ("em", "report"):
+        from oracle import em as oem
+        typer = oem.ReportTyper(data)
+    else:     # the command line types `exonfirst` as exonfirst_1 (main.py:186-187)
+        typer = oty.makeTyper({"pv": "full", "exonfirst": "exonfirst_1"}.get(method, method), data, top_n=600, variant_correction=True)
     typer.typing(sample.gene_cn)
     t2 = time.time()
     if out is not None:
@@ -296,9 +311,9 @@ def _oracle_leg(job, barrier=None, out=None):
     return t1 - t0, t2 - t1
 
 
-def cpu_baseline(method, n_pairs):
-    """Oracle on a bounded sample of the same workload: one core, then N-way (one sample per core, the way the
-    reference's own speed test runs it: research/test_speed.graphkir.par.sh, `parallel -j 14 --thread 1`)."""
+def cpu_baseline(method, n_pairs, n_way=True):
+    """Oracle on a bounded sample of the same workload: one core, then (``n_way``) N-way -- one sample per core, the way
+    the reference's own speed test runs it: research/test_speed.graphkir.par.sh, `parallel -j 14 --thread 1`."""
     import multiprocessing as mp
     t_tab, t_typ = _oracle_leg((99, n_pairs, method))
     single = 2 * n_pairs / (t_tab + t_typ)
@@ -306,10 +321,10 @@ def cpu_baseline(method, n_pairs):
     quota = cgroup_cores()      # a container's CPU quota: the cores that can really run at once
     if quota is not None:
         cores = max(1, min(cores, quota))
-    n_way = max(1, min(cores, 32))
+    n_way = max(1, min(cores, 32)) if n_way else 1
     out = {"value": single, "unit": "reads/s", "cores": 1, "kind": "port",
-           "sample": f"{n_pairs} pairs of the same synthetic workload (R_g <= 8 k per gene: the reference's own "
-                     f"real-depth regime); oracle: tabulate {t_tab:.1f}s + typing {t_typ:.1f}s on one core",
+           "sample": f"{n_pairs} pairs of the same synthetic workload, --allele-strategy {method} (R_g <= 8 k per gene: the "
+                     f"reference's own real-depth regime); oracle: tabulate {t_tab:.1f}s + typing {t_typ:.1f}s on one core",
            "host_cores": cores}
     if n_way > 1:
         ctx = mp.get_context("spawn")
@@ -327,116 +342,114 @@ def cpu_baseline(method, n_pairs):
     return out
 
 
-# ------------------------------------------------------------------------------------------ one worker process
-def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=None):
-    """Worker j of `procs` on this rank's GPU: builds the inputs, warms up, then types its share of the
-    rank's `steps` samples between the common start and end.
+# ------------------------------------------------------------------------------------------ workloads
+WORKLOADS = {
+    # name in the JSON line -> (configs[] entry of BASELINE.json, pairs per sample, --allele-strategy, distinct samples)
+    "configs2_exonfirst": ("configs[2]", 10_000_000, "exonfirst", 2),
+    "em": ("configs[2]", 10_000_000, "em", 2),
+    "configs1_pv": ("configs[1]", 1_000_000, "pv", 8),
+}
 
-    One Python process drives the GPU through ~25 host threads at most (gene workers, prefetch) and its
-    interpreter lock serialises their host work; samples are independent, so a rank may run
-    GK_PROCS_PER_GPU processes on its GPU, the same way a cohort run may place several ranks on one GPU.
-    Worker 0 is the rank's own process and keeps the clock: the timed region starts when every worker
-    (and every rank) is ready and ends when every worker's last sample is typed."""
-    from types import SimpleNamespace
-    args = SimpleNamespace(**opts)
-    # the host threads of a process (sample lanes, ingest) hold the interpreter lock only between library calls: a short
-    # switch interval keeps one lane's Python from delaying another lane's next launch by the default 5 ms
-    sys.setswitchinterval(float(os.environ.get("GK_SWITCH_INTERVAL", "0.0005")))
-    if j and os.environ.get("GK_BENCH_KILL_WORKER") == str(j):   # test hook: this worker dies at once
-        os._exit(3)
-    from kir_graph_amd import _lib, comm as gk_comm
-    from kir_graph_amd.engine import DeviceIndex
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_dev = _lib.deviceCount()
-    if n_dev == 0:
-        raise RuntimeError("bench.py: no HIP device visible (the typing path has no CPU fallback)")
-    backend = {"nccl": "rccl", "gloo": "file"}.get(os.environ.get("GK_BENCH_BACKEND", "rccl"),
-                                                   os.environ.get("GK_BENCH_BACKEND", "rccl"))
-    if world > 1 and backend == "rccl" and world > n_dev:
-        raise RuntimeError(f"bench.py: {world} ranks but {n_dev} GPU(s): one rank per GPU "
-                           "(GK_BENCH_BACKEND=file rehearses the multi-rank path on fewer GPUs)")
-    dev = _lib.Device(local_rank % n_dev)
-    sidx, gidx, by_gene = build_index()
-    t_in = time.time()
-    inputs, samples = [], []
-    for i in range(max(1, min(args.distinct, args.steps + args.warmup))):
-        sample, rec, table = build_sample(sidx, gidx, by_gene, 1031 + 7 * rank + i, args.pairs)
-        inputs.append((PinnedRecords(rec), table, sample.gene_cn))
-        samples.append(sample)
-        del rec
-    log(f"[bench] rank {rank} worker {j}: {len(inputs)} samples of {args.pairs} pairs in pinned memory, "
-        f"{inputs[0][0].nbytes / 1e6:.0f} MB each in compact form ({inputs[0][0].record_bytes / 1e6:.0f} MB as 128-byte records; "
-        f"{time.time() - t_in:.1f}s)")
-    dindex = DeviceIndex(dev, gidx)
-    dev.sync()
-    comm = None
-    if j == 0 and world > 1:
-        # a scaling run must not quietly measure something else: when the RCCL communicator cannot be made on some
-        # rank every rank stops with a non-zero code (the file backend is used only when it was asked for)
-        try:
-            comm = gk_comm.initFromEnv(dev=dev, backend=backend, fallback=False)
-        except gk_comm.CommError as e:
-            log(f"[bench] rank {rank}: {e}; not falling back (GK_BENCH_BACKEND=file rehearses the launch without RCCL)")
-            os._exit(4)
-        if comm.world != args.gpus or comm.backend != backend:
-            raise RuntimeError(f"bench.py: --gpus {args.gpus} on {backend} but {comm.world} ranks joined on {comm.backend}")
 
-    def claims():
-        """Samples of the timed region for this worker: all of them, or whatever it gets from the shared counter."""
-        if gang is None:
-            yield from range(args.steps)
-            return
-        while True:
-            with gang["next"].get_lock():
-                k = gang["next"].value
-                gang["next"].value = k + 1
-            if k >= args.steps:
-                return
-            yield k
+def configName(pairs: int) -> str:
+    return "configs[1]" if pairs == 1_000_000 else "configs[2]" if pairs == 10_000_000 else "custom"
 
-    def all_devices():
+
+def make_inputs(sidx, gidx, by_gene, rank: int, pairs: int, distinct: int, threads: int = 1):
+    """``distinct`` synthetic samples of ``pairs`` pairs as (pinned compact records, string table, copy numbers), seeds
+    1031 + 7 rank + i.  ``threads`` > 1: that many samples are made at a time (numpy releases the interpreter lock in
+    its large operations; a 10 M-pair sample takes ~30 s and ~12 GB of host memory while it is made)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(i):
+        sample, rec, table = build_sample(sidx, gidx, by_gene, 1031 + 7 * rank + i, pairs)
+        pinned = PinnedRecords(rec)
+        return pinned, table, sample.gene_cn
+
+    t0 = time.time()
+    if threads > 1 and distinct > 1:
+        with ThreadPoolExecutor(max_workers=min(threads, distinct)) as pool:
+            inputs = list(pool.map(one, range(distinct)))
+    else:
+        inputs = [one(i) for i in range(distinct)]
+    log(f"[bench] rank {rank}: {len(inputs)} samples of {pairs} pairs in pinned memory, {inputs[0][0].nbytes / 1e6:.0f} MB each "
+        f"in compact form ({inputs[0][0].record_bytes / 1e6:.0f} MB as 128-byte records; {time.time() - t0:.1f}s)")
+    return inputs
+
+
+class RankContext:
+    """What a rank keeps across its workloads: the device, the index on it, the communicator."""
+
+    def __init__(self, args, rank: int, local_rank: int):
+        from kir_graph_amd import _lib, comm as gk_comm
+        from kir_graph_amd.engine import DeviceIndex
+        self.args, self.rank = args, rank
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        n_dev = _lib.deviceCount()
+        if n_dev == 0:
+            raise RuntimeError("bench.py: no HIP device visible (the typing path has no CPU fallback)")
+        backend = {"nccl": "rccl", "gloo": "file"}.get(os.environ.get("GK_BENCH_BACKEND", "rccl"),
+                                                       os.environ.get("GK_BENCH_BACKEND", "rccl"))
+        if self.world > 1 and backend == "rccl" and self.world > n_dev:
+            raise RuntimeError(f"bench.py: {self.world} ranks but {n_dev} GPU(s): one rank per GPU "
+                               "(GK_BENCH_BACKEND=file rehearses the multi-rank path on fewer GPUs)")
+        self.dev = _lib.Device(local_rank % n_dev)
+        self.sidx, self.gidx, self.by_gene = build_index()
+        self.dindex = DeviceIndex(self.dev, self.gidx)
+        self.dev.sync()
+        self.comm = None
+        if self.world > 1:
+            # a scaling run must not quietly measure something else: when the RCCL communicator cannot be made on some
+            # rank every rank stops with a non-zero code (the file backend is used only when it was asked for)
+            try:
+                self.comm = gk_comm.initFromEnv(dev=self.dev, backend=backend, fallback=False)
+            except gk_comm.CommError as e:
+                log(f"[bench] rank {rank}: {e}; not falling back (GK_BENCH_BACKEND=file rehearses the launch without RCCL)")
+                os._exit(4)
+            if self.comm.world != args.gpus or self.comm.backend != backend:
+                raise RuntimeError(f"bench.py: --gpus {args.gpus} on {backend} but {self.comm.world} ranks joined on {self.comm.backend}")
+
+    def devices(self):
+        from kir_graph_amd import _lib
         return list(_lib.Device.instances)
 
-    def gang_wait(name):
-        if gang is not None:
-            gang[name].wait(timeout=600)
-
-    def profiled(on):
-        for d in all_devices():
+    def profiled(self, on):
+        for d in self.devices():
             d.profEnable(on)
             if on:
                 d.profCollect()
                 d.call_log = []
 
-    def collect():
+    def collect(self):
         prof, call_log = {}, []
-        for d in all_devices():
+        for d in self.devices():
             for k, (n, ms) in d.profCollect().items():
                 n0, ms0 = prof.get(k, (0, 0.0))
                 prof[k] = (n0 + n, ms0 + ms)
             call_log += d.call_log or []
         return prof, call_log
 
-    # Two kinds of timed leg over the same steps.  "host": every sample's packed records start in pinned host memory, the
-    # host-to-device copy (compact records) + expansion are inside the region (SURVEY.md section 8(d): the metric) -- `value`.  "hbm": the records
-    # of the distinct samples are resident in HBM before any clock starts, a step = tabulation + typing + calls --
-    # `hbm_resident`.  Each kind is timed `--legs` times (alternating), the median leg is reported.
-    from kir_graph_amd.typing_mulit_allele import sharedLogTable
+
+def measure(rc: RankContext, inputs, pairs: int, method: str, opts) -> dict:
+    """One workload on this rank: warm-up, the timed legs (two kinds, ``opts.legs`` each), the command line's typing stage
+    and the one-process serial pass the roofline is taken from.  Returns what the JSON object of the workload is made of."""
+    from kir_graph_amd.typing_mulit_allele import sharedLogTable, SEARCH_STATS
+    args, dev, dindex, gidx, comm = rc.args, rc.dev, rc.dindex, rc.gidx, rc.comm
     resident = [pinned.toDevice(dev) for pinned, _, _ in inputs]
     dev.sync()
     n_valid = 0
-    if args.warmup:
-        n_valid = run_steps(args.warmup, dev, dindex, gidx, inputs, args.method, resident=resident)[2]
-        run_steps(min(args.warmup, 4), dev, dindex, gidx, inputs, args.method)      # the copy path's contexts and pools
+    if opts.warmup:
+        n_valid = run_steps(opts.warmup, dev, dindex, gidx, inputs, method, resident=resident)[2]
+        run_steps(min(opts.warmup, 4), dev, dindex, gidx, inputs, method)      # the copy path's contexts and pools
     if getattr(args, "pinned_to", None):      # --cores-per-gpu: the runtime's own threads too (they exist by now)
         pin_all_threads(args.pinned_to)
-    if j == 0 and getattr(args, "profile_host", False):
+    if getattr(args, "profile_host", False):
         import cProfile
         import pstats
         n_prof = int(os.environ.get("GK_PROFILE_STEPS", "1"))     # with GK_SAMPLE_LANES=1 GK_PREFETCH=0 everything is on this thread
         pr = cProfile.Profile()
         pr.enable()
-        run_steps(n_prof, dev, dindex, gidx, inputs, args.method, resident=resident)
+        run_steps(n_prof, dev, dindex, gidx, inputs, method, resident=resident)
         pr.disable()
         log(f"[bench] host profile of {n_prof} step(s)")
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
@@ -446,96 +459,204 @@ def worker(j, procs, opts, rank, local_rank, gang, timing=None, helpers_done=Non
     in_region = bool(getattr(args, "verbose", False)) or os.environ.get("GK_BENCH_PROFILE") == "1"
 
     def timed_leg(leg_resident):
-        """EXACTLY args.steps steps between a barrier + device synchronise on both sides; (seconds, host CPU seconds of
-        this worker, the last step's result, what the value table and the searches did)."""
-        if j == 0 and gang is not None:
-            gang["next"].value = 0          # nobody claims before the "go" barrier below
-        dev.sync()
-        gang_wait("ready")
+        """EXACTLY opts.steps steps between a barrier + device synchronise on both sides; (seconds, host CPU seconds of
+        this rank, the last step's result, what the value table and the searches did)."""
+        for d in rc.devices():
+            d.sync()
         if comm is not None:
             comm.barrier()          # RCCL all-reduce + stream synchronise: every rank is ready
-        gang_wait("go")
         stats = {"value_table_at_start": sharedLogTable(dev).known()}
         t0 = time.perf_counter()
         cpu0 = cpu_seconds()
         by_thread0 = {tid: c for _, tid, c in thread_cpu_table()} if os.environ.get("GK_BENCH_TRACE") == "1" else None
-        last = run_steps(claims(), dev, dindex, gidx, inputs, args.method, resident=leg_resident, stats=stats)
-        for d in all_devices():
+        last = run_steps(opts.steps, dev, dindex, gidx, inputs, method, resident=leg_resident, stats=stats)
+        for d in rc.devices():
             d.sync()
-        cpu = cpu_seconds() - cpu0          # this worker's host time for its share of the steps (waits that spin included)
+        cpu = cpu_seconds() - cpu0          # this rank's host time for the steps (waits that spin included)
         if by_thread0 is not None:          # GK_BENCH_TRACE=1: which threads the host time of the leg went to
             rows = sorted(((c - by_thread0.get(tid, 0.0), name, tid) for name, tid, c in thread_cpu_table()), reverse=True)
             log("[trace] host CPU of the leg by thread (ms per step): " +
-                ", ".join(f"{name}/{tid} {1e3 * c / max(args.steps, 1):.2f}" for c, name, tid in rows if c > 0))
-        gang_wait("done")
+                ", ".join(f"{name}/{tid} {1e3 * c / max(opts.steps, 1):.2f}" for c, name, tid in rows if c > 0))
         if comm is not None:
             comm.barrier()
         elapsed = time.perf_counter() - t0
         stats["value_table_new"] = sharedLogTable(dev).known() - stats.pop("value_table_at_start")
         return elapsed, cpu, last, stats
 
-    kinds = [k for k in ("host", "hbm") if k == args.inputs or args.both_legs]
-    kinds.sort(key=lambda k: k != args.inputs)          # the headline's kind first: its first leg meets the new samples
+    kinds = [k for k in ("host", "hbm") if k == opts.inputs or opts.both_legs]
+    kinds.sort(key=lambda k: k != opts.inputs)          # the headline's kind first: its first leg meets the new samples
     legs = {k: [] for k in kinds}
     prof, call_log = {}, []
-    for n in range(max(1, args.legs)):
+    for n in range(max(1, opts.legs)):
         for kind in kinds:
-            profile_this = in_region and n == 0 and kind == args.inputs
+            profile_this = in_region and n == 0 and kind == opts.inputs
             if profile_this:
-                profiled(True)
+                rc.profiled(True)
             elapsed, cpu_s, last, stats = timed_leg(resident if kind == "hbm" else None)
             if profile_this:
-                prof, call_log = collect()
-                profiled(False)
+                prof, call_log = rc.collect()
+                rc.profiled(False)
             if last is not None:
                 n_valid = last[2]
             if comm is not None:
                 elapsed = comm.maxF64(elapsed)
             legs[kind].append(dict(stats, elapsed=elapsed, cpu_s=cpu_s))
-    if j:
-        gang["results"].put({"prof": prof, "call_log": call_log, "legs": legs})
-        return None
-    timing["legs"] = legs
-    others = helpers_done() if helpers_done is not None else []      # the other workers have left the GPU
     cli_stage = None
-    if args.cli_samples > 0 and rank == 0 and world == 1:
-        cli_stage = cli_typing_stage(args.cli_samples, dev, dindex, gidx, inputs, resident, args.method)
-    # ---- the roofline basis: the same step in ONE process, ONE gene thread, no prefetch (kernels back to back)
+    if opts.cli_samples > 0 and rc.rank == 0 and rc.world == 1:
+        cli_stage = cli_typing_stage(opts.cli_samples, dev, dindex, gidx, inputs, resident, method)
+    # ---- the roofline basis: the same step one sample at a time on ONE stream, no prefetch (kernels back to back)
     serial = None
-    if args.serial_steps > 0 and rank == 0:
-        keep = os.environ.get("GK_THREADS")
-        keep_streams = os.environ.get("GK_SAMPLE_STREAMS")
+    if opts.serial_steps > 0 and rc.rank == 0:
+        keep = {name: os.environ.get(name) for name in ("GK_THREADS", "GK_SAMPLE_STREAMS")}
         os.environ["GK_THREADS"] = "1"
         os.environ["GK_SAMPLE_STREAMS"] = "1"       # one stream: the kernels of a sample run back to back
         try:
-            run_steps(1, dev, dindex, gidx, inputs, args.method, depth=0, resident=resident)      # contexts of this mode warm
-            profiled(True)
+            run_steps(1, dev, dindex, gidx, inputs, method, depth=0, resident=resident)      # contexts of this mode warm
+            rc.profiled(True)
             t1 = time.perf_counter()
-            run_steps(args.serial_steps, dev, dindex, gidx, inputs, args.method, depth=0, resident=resident)
-            for d in all_devices():
+            run_steps(opts.serial_steps, dev, dindex, gidx, inputs, method, depth=0, resident=resident)
+            for d in rc.devices():
                 d.sync()
             s_elapsed = time.perf_counter() - t1
-            s_prof, s_log = collect()
-            profiled(False)
-            serial = {"prof": s_prof, "call_log": s_log, "steps": args.serial_steps,
-                      "ms_per_step": 1e3 * s_elapsed / args.serial_steps}
+            s_prof, s_log = rc.collect()
+            rc.profiled(False)
+            serial = {"prof": s_prof, "call_log": s_log, "steps": opts.serial_steps,
+                      "ms_per_step": 1e3 * s_elapsed / opts.serial_steps}
         finally:
-            for name, val in (("GK_THREADS", keep), ("GK_SAMPLE_STREAMS", keep_streams)):
+            for name, val in keep.items():
                 if val is None:
                     os.environ.pop(name, None)
                 else:
                     os.environ[name] = val
-    from kir_graph_amd.typing_mulit_allele import SEARCH_STATS
-    n_values = sharedLogTable(dev).known()      # distinct probabilities met so far = entries of the log10 value table
-    for other in others:                        # the other worker processes of this rank: their host time counts too
-        for kind, rows in other.get("legs", {}).items():
-            for mine, theirs in zip(legs.get(kind, []), rows):
-                mine["cpu_s"] += theirs["cpu_s"]
-                for key in ("samples", "samples_repeated_pass", "tables_rewritten", "tables_patched", "value_table_new"):
-                    mine[key] = mine.get(key, 0) + theirs.get(key, 0)
-    return {"prof": prof, "call_log": call_log, "n_valid": n_valid, "gidx": gidx, "serial": serial, "comm": comm, "n_values": n_values,
-            "search_steps": dict(SEARCH_STATS), "others": others, "cli_stage": cli_stage,
-            "h2d_bytes": inputs[0][0].nbytes, "record_bytes": inputs[0][0].record_bytes}
+    for buf in resident:
+        buf.free()
+    return {"legs": legs, "prof": prof, "call_log": call_log, "n_valid": n_valid, "serial": serial,
+            "n_values": sharedLogTable(dev).known(),      # distinct probabilities met so far = entries of the log10 value table
+            "search_steps": dict(SEARCH_STATS), "cli_stage": cli_stage,
+            "h2d_bytes": inputs[0][0].nbytes, "record_bytes": inputs[0][0].record_bytes,
+            "pairs": pairs, "method": method, "distinct": len(inputs), "opts": opts}
+
+
+def report(rc: RankContext, res: dict, name: str, pinned, cores_before, head: bool) -> dict:
+    """The JSON object of one workload (rank 0): the contract's keys for the headline, the same measurements under the
+    workload's name for the others."""
+    from kir_graph_amd import cohort, roofmodel
+    args, opts, legs = rc.args, res["opts"], res["legs"]
+    world, pairs, method, gidx = rc.world, res["pairs"], res["method"], rc.gidx
+
+    def median_leg(kind):
+        """The leg of ``kind`` with the median time (the slower of the middle two for an even count)."""
+        rows = sorted(legs[kind], key=lambda r: r["elapsed"])
+        return rows[len(rows) // 2]
+
+    lead = median_leg(opts.inputs)
+    elapsed = lead["elapsed"]
+    ms_per_step = 1e3 * elapsed / opts.steps
+    reads_per_step = 2 * pairs * world
+    value = reads_per_step / (elapsed / opts.steps)
+    prof, call_log = res["prof"], res["call_log"]
+    if args.verbose:
+        for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+            log(f"[bench] {k:18s} launches {n:6d}  total {ms:9.3f} ms  avg {ms / n:8.4f} ms")
+        log(f"[bench] kernel time {sum(v[1] for v in prof.values()) / opts.steps:.2f} ms of {ms_per_step:.2f} ms per step")
+    lanes = os.environ.get("GK_SAMPLE_LANES", "3")
+    out = {
+        "metric": "typed 150 bp PE reads/s (pileup+EM) per GPU; achieved HBM GB/s vs roofline",
+        "value": value, "unit": "reads/s", "n_gpus": world, "steps": opts.steps, "warmup": opts.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{configName(pairs)}: 1 synthetic sample per step and GPU ({res['distinct']} distinct samples in "
+                               f"rotation), {2 * pairs} 150 bp PE reads, synthetic example_index-shaped index "
+                               f"({sum(len(t.alleles) for t in gidx.tables)} alleles, 15 genes), "
+                               f"--allele-strategy {method}, top_n 600; "
+                               + ("a step starts with the sample's packed records in pinned host memory: host-to-device "
+                                  "copy + tabulation + typing + calls inside the timed region (SURVEY.md 8(d)); "
+                                  "hbm_resident: the same steps with the records resident in HBM"
+                                  if opts.inputs == "host" else
+                                  "a step starts with the sample's records resident in HBM (tabulation + typing + calls "
+                                  "inside the timed region); pcie_inclusive: the same steps from pinned host memory")
+                               + f"; median of {len(legs[opts.inputs])} timed legs of {opts.steps} steps",
+                   "inputs": opts.inputs, "allele_strategy": method,
+                   "h2d_bytes_per_sample": res.get("h2d_bytes"), "record_bytes_per_sample": res.get("record_bytes"),
+                   "pairs_per_sample": pairs, "pairs_passing_filter": int(res["n_valid"]),
+                   "parallelism": f"samples sharded over {world} GPU(s), no data-path collective; one process per GPU, "
+                                  f"{lanes} samples in flight (one host thread and one stream per sample: "
+                                  + ("gk_sample_em)" if method in ("em", "report") else "gk_sample_search)"),
+                   "rank_barrier": (rc.comm.backend if rc.comm is not None else None)},
+    }
+    serial = res.get("serial")
+    if serial:
+        s_prof, steps = serial["prof"], serial["steps"]
+        table = {k: {"launches_per_step": n / steps, "ms_per_step": ms / steps, "avg_launch_ms": ms / n}
+                 for k, (n, ms) in sorted(s_prof.items(), key=lambda kv: -kv[1][1])}
+        out["kernels_serial"] = {"ms_per_step_wall": serial["ms_per_step"],
+                                 "kernel_ms_per_step": sum(v[1] for v in s_prof.values()) / steps,
+                                 "mode": "one sample at a time on one stream, no prefetch (GK_SAMPLE_LANES=1 "
+                                         "GK_SAMPLE_STREAMS=1 GK_PREFETCH=0): kernels run back to back; names are the "
+                                         "kernels' own (rocprofv3 --kernel-trace --stats lists the same names)",
+                                 "kernels": table}
+        out["roofline"] = roofmodel.dominant(s_prof, serial["call_log"])
+        out["roofline"]["step"] = roofmodel.stepRoofline(serial["call_log"], steps, ms_per_step)
+    else:
+        out["roofline"] = roofmodel.dominant(prof, call_log)
+        out["roofline"]["note_basis"] = "launch times taken inside the timed region (other samples share the GPU)"
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(out["roofline"].get("kernel"), pairs, method)
+    if prof:     # --verbose: launch times inside the timed region (kernels of the samples in flight overlap there)
+        out["kernel_ms_per_step"] = {k: v[1] / opts.steps for k, v in prof.items()}
+    out["search_steps"] = res.get("search_steps")    # steps bounded by integers / redone with f64 only (so far in this process)
+    out["value_table_entries"] = res.get("n_values")  # distinct probabilities = log10 evaluations on the host
+    cpu_s = float(lead["cpu_s"])
+    out["host"] = {"host_core_s_per_step": cpu_s / opts.steps, "cores_busy": cpu_s / elapsed if elapsed else None,
+                   "cores_per_gpu": args.cores_per_gpu or None, "pinned_to": pinned,
+                   "cores_allowed": len(cores_before), "cgroup_quota_cores": cgroup_cores(),
+                   "worker_processes": 1, "sample_lanes": int(lanes),
+                   "search_slots": int(os.environ.get("GK_SEARCH_SLOTS", "0") or 0),
+                   "cores_per_rank": cohort.hostCoresPerRank(),
+                   "wait_policy": os.environ.get("GK_WAIT_POLICY", "runtime default"),
+                   "note": "user + system time of rank 0's process over the reported leg (getrusage); "
+                           "a host thread that spins on the GPU counts as busy"}
+
+    def leg_rows(kind):
+        """Every timed leg of a kind, in the order they ran: what a NEW sample costs shows in the first leg of a run
+        with --distinct >= steps + warmup (value_table_new > 0 there, 0 in the later legs, which meet the same samples
+        again); samples_repeated_pass = samples of the leg that brought a product without a log10, tables_patched = the
+        gene tables that got those values patched in (gk_compat_patch: one pass over the table), tables_rewritten = the
+        ones written again by the compatibility kernel."""
+        return [{"ms_per_step": 1e3 * r["elapsed"] / opts.steps, "value_table_new": r.get("value_table_new", 0),
+                 "value_table_new_per_sample": r.get("value_table_new", 0) / max(opts.steps, 1),
+                 "samples_repeated_pass": r.get("samples_repeated_pass", 0),
+                 "tables_rewritten": r.get("tables_rewritten", 0),
+                 "tables_patched": r.get("tables_patched", 0)} for r in legs[kind]]
+
+    out["legs"] = leg_rows(opts.inputs)
+    first = legs[opts.inputs][0]
+    out["value_table_new_per_sample"] = first.get("value_table_new", 0) / max(opts.steps, 1)
+    out["samples_repeated_pass"] = first.get("samples_repeated_pass", 0)
+    out["distinct_samples"] = res["distinct"]
+    other_kind = [k for k in legs if k != opts.inputs]
+    if other_kind:
+        kind = other_kind[0]
+        o = median_leg(kind)
+        key = "pcie_inclusive" if kind == "host" else "hbm_resident"
+        out[key] = {
+            "value": reads_per_step / (o["elapsed"] / opts.steps), "unit": "reads/s",
+            "ms_per_step": 1e3 * o["elapsed"] / opts.steps,
+            "host_core_s_per_step": float(o["cpu_s"]) / opts.steps,
+            "legs": leg_rows(kind),
+            "note": (f"the same {opts.steps} steps with every sample's packed records starting in pinned host memory: "
+                     "the host-to-device copy of each sample (compact records) and their expansion are inside the timed "
+                     "region (staged two samples ahead of the typing)" if kind == "host" else
+                     f"the same {opts.steps} steps with the records of the distinct samples resident in HBM before the "
+                     "clock starts (a step = tabulation + typing + calls)") + f"; median of {len(legs[kind])} legs"}
+    if res.get("cli_stage"):
+        out["cli_typing_stage"] = dict(res["cli_stage"], vs_bench_step=res["cli_stage"]["ms_per_sample"] / ms_per_step)
+    if opts.cpu_pairs and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
+        out["cpu_baseline"] = cpu_baseline(method, opts.cpu_pairs, n_way=head)
+    if not head:        # a secondary workload: the contract's run-level keys stay with the headline
+        for key in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "search_steps", "value_table_entries"):
+            out.pop(key, None)
+        out["workload"] = name
+    return out
 
 
 # ------------------------------------------------------------------------------------------ launcher
@@ -570,13 +691,16 @@ def launch_ranks(args, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)     # long enough for the ramp and the uneven finish of the workers not to show (1 % at 96 steps, 4 % at 24)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per sample (config 2: 1e6)")
-    ap.add_argument("--method", default="pv")
-    ap.add_argument("--distinct", type=int, default=N_DISTINCT,
-                    help="distinct samples a rank rotates through (a cohort types every sample once: with N >= steps + "
-                         "warmup the first leg only meets samples nobody has typed before; 3.4 s of generation each)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=None,
+                    help="read pairs per sample: 10000000 = configs[2], 1000000 = configs[1].  Given (or --method given): "
+                         "that ONE workload.  Neither given: configs[2] with --allele-strategy exonfirst as the line's "
+                         "headline, and -- on one GPU -- `em` (configs[2]) and `configs1_pv` (configs[1]) as objects beside it")
+    ap.add_argument("--method", default=None, help="--allele-strategy of the typing: pv, exonfirst, em")
+    ap.add_argument("--distinct", type=int, default=None,
+                    help="distinct samples a rank rotates through (default: 2 at configs[2] size, 8 below; a cohort types "
+                         "every sample once: with N >= steps + warmup the first leg only meets samples nobody has typed before)")
     ap.add_argument("--legs", type=int, default=3, help="timed legs per kind of input; the median leg is reported")
     ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs for the CPU baseline sample (0 = skip)")
     ap.add_argument("--serial-steps", type=int, default=2,
@@ -590,9 +714,13 @@ def main():
     ap.add_argument("--cli-samples", type=int, default=12,
                     help="samples for the command line's typing stage (main.alleleTyping), timed after the legs as "
                          "`cli_typing_stage` (rank 0 of the one-GPU run only; 0 = skip)")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
+                    help="the headline workload only (no `em` / `configs1_pv` objects)")
+    ap.add_argument("--synth-threads", type=int, default=0,
+                    help="samples synthesised at a time (0: by the host cores and ranks of the node)")
     ap.add_argument("--cores-per-gpu", type=int, default=0,
-                    help="pin every rank (its worker processes and threads) to this many host cores of its own, "
-                         "before anything touches HIP (0 = no pinning)")
+                    help="pin every rank (its threads) to this many host cores of its own, before anything touches HIP "
+                         "(0 = no pinning)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--profile-host", action="store_true", help="cProfile one extra step to stderr")
     args = ap.parse_args()
@@ -608,215 +736,70 @@ def main():
         sys.exit(2)
     cores_before = allowed_cores()
     pinned = pin_rank(local_rank, args.cores_per_gpu) if args.cores_per_gpu > 0 else None
-    args.pinned_to = pinned          # handed to the workers (vars(args)): they bind the runtime's threads after the warm-up
-    # Worker processes of this rank on its GPU (see worker()): started first, before anything touches HIP.
-    # A sample is typed by ONE host thread on one stream (gk_sample_search: its genes pipelined on marks of the stream),
-    # three to five samples at a time (GK_SAMPLE_LANES: by the host cores the rank has, cohort.pipelineDefaults) plus the
-    # staging thread(s): ONE process keeps the GPU fed from two to four host cores (profiles/r04_sample_lanes.txt);
-    # GK_PROCS_PER_GPU=2 adds a second worker process.  Waits block instead of spinning: a rank of an 8-GPU node may
-    # have about two cores.
-    procs = max(1, int(os.environ.get("GK_PROCS_PER_GPU", "1")))
-    procs = min(procs, max(1, args.steps))
+    args.pinned_to = pinned
+    # the host threads of a process (sample lanes, ingest) hold the interpreter lock only between library calls: a short
+    # switch interval keeps one lane's Python from delaying another lane's next launch by the default 5 ms
+    sys.setswitchinterval(float(os.environ.get("GK_SWITCH_INTERVAL", "0.0005")))
     # blocking waits, sample lanes and search slots by the rank's host cores, the preamble on a high-priority stream: the
-    # package's own defaults for a process that types a cohort (kir_graph_amd.main sets the same ones)
+    # package's own defaults for a process that types a cohort (kir_graph_amd.main sets the same ones).  ONE process per
+    # GPU: a sample is typed by one host thread on one stream, three to five samples at a time (GK_SAMPLE_LANES)
     from kir_graph_amd import cohort
-    cohort.pipelineDefaults(procs)
-    own_threads = procs > 1 and "GK_THREADS" not in os.environ and os.environ.get("GK_SAMPLE_SEARCH") == "0"
-    if own_threads:
-        os.environ["GK_THREADS"] = "3"   # per-gene threads (the round-2 path): four processes of three shared the host cores
-    gang, helpers = None, []
-    if procs > 1:
-        import multiprocessing as mp
-        ctx = mp.get_context("spawn")
-        gang = {"ready": ctx.Barrier(procs), "go": ctx.Barrier(procs), "done": ctx.Barrier(procs), "results": ctx.Queue(),
-                "next": ctx.Value("i", 0)}   # the samples of the timed region are handed out one by one
-        helpers = [ctx.Process(target=worker, args=(j, procs, vars(args), rank, local_rank, gang), daemon=True)
-                   for j in range(1, procs)]
-        try:
-            for h in helpers:
-                h.start()
-        except OSError as e:   # no child processes here (e.g. under a profiler that forbids them): one process
-            log(f"[bench] cannot start worker processes ({e}); running in one process")
-            for h in helpers:
-                if h.is_alive():
-                    h.terminate()
-            procs, gang = 1, None
-            if own_threads:
-                del os.environ["GK_THREADS"]
+    cohort.pipelineDefaults(1)
 
-    finished = threading.Event()
-    if gang is not None:
-        def watch():   # a worker that exits early breaks the barriers at once instead of after their timeout
-            while not finished.wait(0.5):
-                if any(h.exitcode not in (None, 0) for h in helpers):
-                    for name in ("ready", "go", "done"):
-                        gang[name].abort()
-                    return
-        threading.Thread(target=watch, daemon=True).start()
-
-    def helpers_done():
-        """Results of the other workers, collected as soon as the timed region is over; the workers have exited
-        (and released the GPU) when this returns."""
-        got = [gang["results"].get(timeout=600) for _ in range(len(helpers))] if gang is not None else []
-        for h in helpers:
-            h.join(timeout=60)
-        return got
-
-    timing = {}
-    try:
-        res = worker(0, procs, vars(args), rank, local_rank, gang, timing=timing, helpers_done=helpers_done)
-    except threading.BrokenBarrierError:
-        # a worker process died or never came up; a single-GPU run starts over in one process, a multi-rank
-        # run cannot (the other ranks are past their barriers)
-        for h in helpers:
-            if h.is_alive():
-                h.terminate()
-        if world > 1:
-            raise
-        log("[bench] a worker process failed; running the measurement in one process")
-        procs, gang = 1, None
-        if own_threads:
-            del os.environ["GK_THREADS"]
-        res = worker(0, 1, vars(args), rank, local_rank, None, timing=timing)
-    legs = timing["legs"]
-
-    def median_leg(kind):
-        """The leg of ``kind`` with the median time (the slower of the middle two for an even count)."""
-        rows = sorted(legs[kind], key=lambda r: r["elapsed"])
-        return rows[len(rows) // 2]
-
-    head = median_leg(args.inputs)
-    elapsed = head["elapsed"]
-    prof, call_log, n_valid, gidx = res["prof"], res["call_log"], res["n_valid"], res["gidx"]
-    for other in res.get("others", []):
-        for k, (n, ms) in other["prof"].items():
-            n0, ms0 = prof.get(k, (0, 0.0))
-            prof[k] = (n0 + n, ms0 + ms)
-        call_log += other["call_log"]
-    finished.set()
-    if gang is not None:
-        for h in helpers:
-            h.join(timeout=30)
-
+    if args.pairs is None and args.method is None:
+        scale = float(os.environ.get("GK_BENCH_PAIRS_SCALE", "1"))      # tests: the three workloads at a fraction of their size
+        names = ["configs2_exonfirst"] + (["em", "configs1_pv"] if args.secondary and world == 1 else [])
+        plan = [(name, max(1000, int(WORKLOADS[name][1] * scale)), WORKLOADS[name][2], WORKLOADS[name][3]) for name in names]
+    else:
+        pairs = 1_000_000 if args.pairs is None else args.pairs
+        plan = [("custom", pairs, args.method or "pv", 2 if pairs >= 5_000_000 else N_DISTINCT)]
+    rc = RankContext(args, rank, local_rank)
+    threads = args.synth_threads or max(1, min(4, cohort.hostCoresPerRank() // 3))
+    results, by_size = [], {}
+    from types import SimpleNamespace
+    for k, (name, pairs, method, distinct) in enumerate(plan):
+        distinct = max(1, min(args.distinct or distinct, args.steps + args.warmup))
+        if (pairs, distinct) not in by_size:
+            by_size.clear()                     # the samples of the workload before go (their pinned memory with them)
+            by_size[(pairs, distinct)] = make_inputs(rc.sidx, rc.gidx, rc.by_gene, rank, pairs, distinct, threads)
+        head = k == 0
+        opts = SimpleNamespace(steps=args.steps, warmup=args.warmup, legs=args.legs if head else min(args.legs, 3),
+                               inputs=args.inputs, both_legs=args.both_legs, serial_steps=args.serial_steps,
+                               cli_samples=args.cli_samples if (head or name == "configs1_pv") else 0, cpu_pairs=args.cpu_pairs)
+        t0 = time.time()
+        res = measure(rc, by_size[(pairs, distinct)], pairs, method, opts)
+        log(f"[bench] rank {rank}: workload {name} ({configName(pairs)}, {method}) measured in {time.time() - t0:.1f}s")
+        results.append((name, res))
     if rank == 0:
-        from kir_graph_amd import roofmodel
-        ms_per_step = 1e3 * elapsed / args.steps
-        reads_per_step = 2 * args.pairs * world
-        value = reads_per_step / (elapsed / args.steps)
-        if args.verbose:
-            for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
-                log(f"[bench] {k:18s} launches {n:6d}  total {ms:9.3f} ms  avg {ms / n:8.4f} ms")
-            log(f"[bench] kernel time {sum(v[1] for v in prof.values()) / args.steps:.2f} ms of {ms_per_step:.2f} ms per step")
-        out = {
-            "metric": "typed 150 bp PE reads/s (pileup+EM) per GPU; achieved HBM GB/s vs roofline",
-            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{'configs[1]' if args.pairs == 1_000_000 else 'configs[2]' if args.pairs == 10_000_000 else 'custom'}: "
-                                   f"1 synthetic sample per step and GPU ({args.distinct} distinct samples in "
-                                   f"rotation), {2 * args.pairs} 150 bp PE reads, synthetic example_index-shaped index "
-                                   f"({sum(len(t.alleles) for t in gidx.tables)} alleles, 15 genes), "
-                                   f"--allele-strategy {args.method}, top_n 600; "
-                                   + ("a step starts with the sample's packed records in pinned host memory: host-to-device "
-                                      "copy + tabulation + typing + calls inside the timed region (SURVEY.md 8(d)); "
-                                      "hbm_resident: the same steps with the records resident in HBM"
-                                      if args.inputs == "host" else
-                                      "a step starts with the sample's records resident in HBM (tabulation + typing + calls "
-                                      "inside the timed region); pcie_inclusive: the same steps from pinned host memory")
-                                   + f"; median of {len(legs[args.inputs])} timed legs of {args.steps} steps",
-                       "inputs": args.inputs,
-                       "h2d_bytes_per_sample": res.get("h2d_bytes"), "record_bytes_per_sample": res.get("record_bytes"),
-                       "pairs_per_sample": args.pairs, "pairs_passing_filter": int(n_valid),
-                       "parallelism": f"samples sharded over {world} GPU(s), no data-path collective; "
-                                      f"{procs} worker process(es) per GPU, {os.environ.get('GK_SAMPLE_LANES', '2')} samples in flight "
-                                      "each (one host thread and one stream per sample: gk_sample_search)"
-                                      if os.environ.get("GK_SAMPLE_SEARCH") != "0" else
-                                      f"samples sharded over {world} GPU(s), no data-path collective; {procs} worker "
-                                      f"process(es) per GPU, {os.environ.get('GK_THREADS', '6')} gene threads each",
-                       "rank_barrier": (res["comm"].backend if res.get("comm") is not None else None)},
-        }
-        serial = res.get("serial")
-        if serial:
-            s_prof, steps = serial["prof"], serial["steps"]
-            table = {k: {"launches_per_step": n / steps, "ms_per_step": ms / steps, "avg_launch_ms": ms / n}
-                     for k, (n, ms) in sorted(s_prof.items(), key=lambda kv: -kv[1][1])}
-            out["kernels_serial"] = {"ms_per_step_wall": serial["ms_per_step"],
-                                     "kernel_ms_per_step": sum(v[1] for v in s_prof.values()) / steps,
-                                     "mode": "one process, one sample at a time on one stream, no prefetch (GK_PROCS_PER_GPU=1 "
-                                             "GK_SAMPLE_LANES=1 GK_SAMPLE_STREAMS=1 GK_PREFETCH=0): kernels run back to back",
-                                     "kernels": table}
-            out["roofline"] = roofmodel.dominant(s_prof, serial["call_log"])
-            out["roofline"]["step"] = roofmodel.stepRoofline(serial["call_log"], steps, ms_per_step)
-        else:
-            out["roofline"] = roofmodel.dominant(prof, call_log)
-            out["roofline"]["note_basis"] = "launch times taken inside the timed region (other workers share the GPU)"
-        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(out["roofline"].get("kernel"))
-        if prof:     # --verbose: launch times inside the timed region (kernels of all workers overlap there)
-            out["kernel_ms_per_step"] = {k: v[1] / args.steps for k, v in prof.items()}
-        out["search_steps"] = res.get("search_steps")    # worker 0: steps bounded by integers / redone with f64 only
-        out["value_table_entries"] = res.get("n_values")  # worker 0: distinct probabilities = log10 evaluations on the host
-        cpu_s = float(head["cpu_s"])
-        out["host"] = {"host_core_s_per_step": cpu_s / args.steps, "cores_busy": cpu_s / elapsed if elapsed else None,
-                       "cores_per_gpu": args.cores_per_gpu or None, "pinned_to": pinned,
-                       "cores_allowed": len(cores_before), "cgroup_quota_cores": cgroup_cores(),
-                       "worker_processes": procs, "sample_lanes": int(os.environ.get("GK_SAMPLE_LANES", "2")),
-                       "search_slots": int(os.environ.get("GK_SEARCH_SLOTS", "0") or 0),
-                       "cores_per_rank": cohort.hostCoresPerRank(),
-                       "wait_policy": os.environ.get("GK_WAIT_POLICY", "runtime default"),
-                       "note": "user + system time of rank 0's worker processes over the reported leg (getrusage); "
-                               "a host thread that spins on the GPU counts as busy"}
-
-        def leg_rows(kind):
-            """Every timed leg of a kind, in the order they ran: what a NEW sample costs shows in the first leg of a run
-            with --distinct >= steps + warmup (value_table_new > 0 there, 0 in the later legs, which meet the same samples
-            again); samples_repeated_pass = samples of the leg that brought a product without a log10, tables_patched = the
-            gene tables that got those values patched in (gk_compat_patch: one pass over the table), tables_rewritten = the
-            ones written again by the compatibility kernel."""
-            return [{"ms_per_step": 1e3 * r["elapsed"] / args.steps, "value_table_new": r.get("value_table_new", 0),
-                     "value_table_new_per_sample": r.get("value_table_new", 0) / max(args.steps, 1),
-                     "samples_repeated_pass": r.get("samples_repeated_pass", 0),
-                     "tables_rewritten": r.get("tables_rewritten", 0),
-                     "tables_patched": r.get("tables_patched", 0)} for r in legs[kind]]
-
-        out["legs"] = leg_rows(args.inputs)
-        first = legs[args.inputs][0]
-        out["value_table_new_per_sample"] = first.get("value_table_new", 0) / max(args.steps, 1)
-        out["samples_repeated_pass"] = first.get("samples_repeated_pass", 0)
-        out["distinct_samples"] = args.distinct
-        other_kind = [k for k in legs if k != args.inputs]
-        if other_kind:
-            kind = other_kind[0]
-            o = median_leg(kind)
-            name = "pcie_inclusive" if kind == "host" else "hbm_resident"
-            out[name] = {
-                "value": reads_per_step / (o["elapsed"] / args.steps), "unit": "reads/s",
-                "ms_per_step": 1e3 * o["elapsed"] / args.steps,
-                "host_core_s_per_step": float(o["cpu_s"]) / args.steps,
-                "legs": leg_rows(kind),
-                "note": (f"the same {args.steps} steps with every sample's packed records starting in pinned host memory: "
-                         "the host-to-device copy of each sample (compact records) and their expansion are inside the timed "
-                         "region (staged two samples ahead of the typing)" if kind == "host" else
-                         f"the same {args.steps} steps with the records of the distinct samples resident in HBM before the "
-                         "clock starts (a step = tabulation + typing + calls)") + f"; median of {len(legs[kind])} legs"}
-        if res.get("cli_stage"):
-            out["cli_typing_stage"] = dict(res["cli_stage"], vs_bench_step=res["cli_stage"]["ms_per_sample"] / ms_per_step)
-        if args.cpu_pairs and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
-            out["cpu_baseline"] = cpu_baseline(args.method, args.cpu_pairs)
+        out = None
+        for k, (name, res) in enumerate(results):
+            obj = report(rc, res, name, pinned, cores_before, head=(k == 0))
+            if k == 0:
+                out = obj
+            else:
+                out[name] = obj
         print(json.dumps(out), flush=True)
-    if res.get("comm") is not None:
-        res["comm"].close()
+    if rc.comm is not None:
+        rc.comm.close()
 
 
-def measured_traffic(kernel):
+def workloadTag(pairs: int, method: str) -> str:
+    """Name of a workload in the file names under profiles/: cfg2_exonfirst, cfg2_em, cfg1_pv, ..."""
+    size = {1_000_000: "cfg1", 10_000_000: "cfg2"}.get(pairs, f"p{pairs}")
+    return f"{size}_{method}"
+
+
+def measured_traffic(kernel, pairs, method):
     """(HBM bytes per launch of ``kernel``, where the figure comes from) from the committed PMC passes over the serial
-    form of this command (profiles/rNN_traffic_<kernel>.json, made by tools/collect_profiles.sh) -- but only from a
-    file that was measured on THIS code: the file records the digest of the device sources it ran
+    form of this workload (profiles/rNN_traffic_<workload>_<kernel>.json, made by tools/collect_profiles.sh) -- but only
+    from a file that was measured on THIS code: the file records the digest of the device sources it ran
     (kir_graph_amd.build.sourceDigest) and a file with another digest, or none, is refused.  (None, why) then."""
     import glob
     from kir_graph_amd.build import sourceDigest
     digest = sourceDigest(kernel)
+    tag = workloadTag(pairs, method)
     stale = []
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{kernel}.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{tag}_{kernel}.json")), reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
@@ -826,11 +809,11 @@ def measured_traffic(kernel):
                 stale.append(os.path.basename(path))
                 continue
             return float(t["traffic_bytes_per_launch"]), (f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / "
-                                                          f"WRITE_SIZE passes of this command, one process, serial; "
+                                                          f"WRITE_SIZE passes of this workload, one sample at a time; "
                                                           f"device sources {digest} = the running code)")
         except (OSError, ValueError, KeyError):
             continue
-    return None, (f"no PMC pass of the running device sources ({digest}) is committed"
+    return None, (f"no PMC pass of workload {tag} on the running device sources ({digest}) is committed"
                   + (f"; refused as stale: {', '.join(stale)}" if stale else ""))
 
 

@@ -72,19 +72,22 @@ def overlapped(items, work, lanes: int = 2):
 
 def hostCoresPerRank() -> int:
     """Host cores this process may count on: the cores it is allowed on (affinity), capped by the container's CPU quota
-    (cgroup v2 ``cpu.max``), shared between the ranks of this node (LOCAL_WORLD_SIZE / WORLD_SIZE of any launcher)."""
+    (cgroup v2 ``cpu.max``), shared between the ranks of this node (LOCAL_WORLD_SIZE / WORLD_SIZE of any launcher).
+    An affinity smaller than the machine is NOT taken for a private one -- a cpuset-limited container or a Slurm cgroup
+    gives every rank of the node the same smaller set; a launcher that pins each rank to cores of its own says so with
+    GK_PRIVATE_CORES=1 (``bench.py --cores-per-gpu`` does)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         cores = os.cpu_count() or 1
-    pinned = cores < (os.cpu_count() or cores)          # an affinity of its own (bench.py --cores-per-gpu): not shared
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if quota != "max":
             cores = min(cores, max(1, int(quota) // int(period)))
     except (OSError, ValueError):
         pass
-    ranks = 1 if pinned else max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
+    private = os.environ.get("GK_PRIVATE_CORES") == "1"
+    ranks = 1 if private else max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
     return max(1, cores // ranks)
 
 

@@ -67,6 +67,17 @@ def rendezvousDir() -> str:
     return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gk_rdzv_{launchToken()}")
 
 
+def _hostIdentity() -> str:
+    """Where a pid means something: host name + pid namespace (a rendezvous directory may be shared between nodes or
+    mounted into several containers)."""
+    import socket
+    try:
+        ns = os.readlink("/proc/self/ns/pid")
+    except OSError:
+        ns = "?"
+    return f"{socket.gethostname()} {ns}"
+
+
 class FileStore:
     """Write-once keys in a directory: ``set`` is atomic (rename), ``get`` waits for the key.  File names start with
     the launch token: a directory that still holds the keys of a dead run (a reused ``GK_RDZV_DIR``) cannot feed
@@ -127,14 +138,16 @@ class FileStore:
 
     def claim(self) -> None:
         """Rank 0: record the pid that owns this launch's keys (what ``purgeOthers`` of a later launch looks at)."""
-        self.set("owner", str(os.getpid()).encode())
+        self.set("owner", f"{os.getpid()} {_hostIdentity()}".encode())
 
     def purgeOthers(self, older_than: float = 600.0) -> int:
         """Remove the keys a DEAD launch left behind in a shared rendezvous directory; returns how many.  Hygiene only
         -- keys of other tokens are never read.  Only files that look like this package's keys are touched, and only
-        those of a token whose owner (the pid in its ``owner`` key) no longer exists; a token without an owner key is
-        left alone unless all its files are older than ``older_than`` AND that is more than its ``get`` timeout --
-        a live launch may hold a key for as long as a peer types (a rank parked in a round while another works)."""
+        those of a token whose owner no longer exists.  The ``owner`` key holds rank 0's pid AND where that pid means
+        something (host name + pid namespace): the pid is asked only on that host; for a launch of another host or
+        container (a shared directory), and for a token without an owner key, only age counts -- all its files older
+        than ``older_than`` AND than twice the ``get`` timeout (a live launch may hold a key for as long as a peer
+        types).  A pid that still exists protects its keys for a day (pid numbers are reused)."""
         n = 0
         now = time.time()
         try:
@@ -149,24 +162,29 @@ class FileStore:
         for token, files in by_token.items():
             owner = os.path.join(self.path, f"{token}.owner")
             try:
-                pid = int(open(owner, "rb").read().decode() or "0")
-            except (OSError, ValueError):
-                pid = 0
-            if pid > 0:
+                fields = open(owner, "rb").read().decode().split()
+                pid, where = int(fields[0]), " ".join(fields[1:])
+            except (OSError, ValueError, IndexError):
+                pid, where = 0, ""
+            try:
+                newest = max(os.path.getmtime(os.path.join(self.path, f)) for f in files)
+            except OSError:
+                continue
+            aged = now - newest >= max(older_than, 2 * self.timeout)
+            if pid > 0 and where == _hostIdentity():
+                # same host and pid namespace: the pid says whether the launch lives -- unless the number was handed
+                # to another process since, which the age of the keys catches (a live launch touches its keys)
                 try:
                     os.kill(pid, 0)
-                    continue                      # the launch is alive (or the pid was reused: leave it alone)
+                    alive = True
                 except ProcessLookupError:
-                    pass
+                    alive = False
                 except OSError:
-                    continue
-            else:
-                try:
-                    newest = max(os.path.getmtime(os.path.join(self.path, f)) for f in files)
-                except OSError:
-                    continue
-                if now - newest < max(older_than, 2 * self.timeout):
-                    continue
+                    alive = True
+                if alive and now - newest < max(86400.0, 4 * self.timeout):
+                    continue                      # a day without a key touched: the pid is somebody else's by now
+            elif not aged:
+                continue                          # another host / namespace, or no owner key: only the age rule
             for f in files:
                 try:
                     os.remove(os.path.join(self.path, f))

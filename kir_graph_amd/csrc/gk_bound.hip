@@ -413,7 +413,7 @@ int gk_bound_enqueue(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, 
   if (c_prev >= 2) {   // previous sets of two or more alleles become one column each
     GK_HIP(take((void**)&d_P, (size_t)n_sets * (size_t)ldm));
     GK_HIP(take((void**)&d_psum, (size_t)n_sets * sizeof(uint32_t)));
-    GK_PROF(ctx, GK_K_SETMIN, GK_KERNEL(setmin_u8, dim3((unsigned)n_sets), dim3(kThreads), 0, st, miss, ldm, d_ids,
+    GK_PROF(ctx, "setmin_u8", GK_KERNEL(setmin_u8, dim3((unsigned)n_sets), dim3(kThreads), 0, st, miss, ldm, d_ids,
                                         c_prev, d_P, d_psum));
   }
   const int64_t n16 = ldm / 16;
@@ -434,20 +434,20 @@ int gk_bound_enqueue(gk_ctx* ctx, gk_dptr d_miss8, int64_t ldm, int64_t n_rows, 
   SelState* d_state = (SelState*)d_sel;
   int32_t* d_idx = (int32_t*)(d_sel + sizeof(SelState));
   uint32_t* d_mout = (uint32_t*)(d_idx + cap);
-  GK_PROF_EXACT(ctx, GK_K_MINSUM,
+  GK_PROF_EXACT(ctx, "minsum_sad",
                 GK_KERNEL(minsum_sad, dim3((unsigned)(tiles_t * tiles_a), (unsigned)n_slices), dim3(kThreads), 0, st,
                           c_prev >= 2 ? d_P : miss, ldm, c_prev >= 2 ? (const int32_t*)nullptr : d_ids, n_sets, miss,
                           ldm, d_cols, n_cols, n16, blocks_per_slice, tiles_a, d_partial, (uint32_t*)d_state,
                           (int)(sizeof(SelState) / sizeof(uint32_t))));
   const dim3 per_elem((unsigned)((n_out + kThreads - 1) / kThreads));
-  GK_PROF(ctx, GK_K_SELECT_CUT,
+  GK_PROF(ctx, "minsum_finish",
           GK_KERNEL(minsum_finish, per_elem, dim3(kThreads), 0, st, d_partial, n_slices, n_out, n_cols, d_psum,
                     c_prev >= 2 ? (const int32_t*)nullptr : d_ids, gk_ptr<uint32_t>(d_msum), d_cols, d_first, d_M,
                     d_state));
   const dim3 strided((unsigned)std::min<int64_t>(kSelBlocks, (n_out + kThreads - 1) / kThreads));
-  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_hist1, strided, dim3(kThreads), 0, st, d_M, n_out, d_state));
-  GK_PROF(ctx, GK_K_SELECT_CUT, GK_KERNEL(select_hist2, strided, dim3(kThreads), 0, st, d_M, n_out, top_n, d_state));
-  GK_PROF(ctx, GK_K_SELECT_CUT,
+  GK_PROF(ctx, "select_hist1", GK_KERNEL(select_hist1, strided, dim3(kThreads), 0, st, d_M, n_out, d_state));
+  GK_PROF(ctx, "select_hist2", GK_KERNEL(select_hist2, strided, dim3(kThreads), 0, st, d_M, n_out, top_n, d_state));
+  GK_PROF(ctx, "select_append",
           GK_KERNEL(select_append, per_elem, dim3(kThreads), 0, st, d_M, n_out, top_n, cap, d_state, d_idx, d_mout));
   GK_HIP(hipGetLastError());
   // one copy: the header first, then the entries (the three parts are adjacent)

@@ -35,6 +35,7 @@ struct GkSumCall {
   int64_t n_rows = 0;
   int32_t n_sets = 0, c = 0;
   bool with_value = false;
+  bool leafwise = false;           // served by setsum_leaves (every column through LDS once), else by tiles of sets
 };
 // value + shares (value_out != nullptr at collect) or shares only of the given sets (gk_setsum / gk_fraction)
 int gk_shares_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32_t* ids, int32_t n_sets, int32_t c,

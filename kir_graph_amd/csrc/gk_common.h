@@ -73,12 +73,10 @@ struct gk_ctx {
   std::vector<hipEvent_t> prof_pool;
 };
 
-// kernel ids for gk_prof_*
-enum {
-  GK_K_TAB_COUNT = 0, GK_K_TAB_EMIT, GK_K_SCAN, GK_K_NOVEL, GK_K_COUNT_IDS, GK_K_SELECT, GK_K_COMPAT,
-  GK_K_LUT_COLLECT, GK_K_LUT_APPLY, GK_K_MAXSUM, GK_K_COMBINE, GK_K_FRACTION, GK_K_SETMAX, GK_K_EM_SETS,
-  GK_K_EM_RUN, GK_K_SETMIN, GK_K_MINSUM, GK_K_SELECT_CUT, GK_K_COMPAT_PATCH, GK_K_N
-};
+// Per-kernel timing is kept under the kernel's own name (template arguments dropped): GK_PROF(ctx, "name", launch).  A
+// name gets its id on first use (gk_prof_register, thread-safe); at most GK_PROF_MAX names.
+constexpr int GK_PROF_MAX = 128;
+int gk_prof_register(const char* name);
 // Per-kernel timing.  GK_PROF brackets a launch with two events recorded on the stream (cheap; under
 // multi-stream load the span also counts the time the kernel waits for CUs that other streams are using).
 // GK_PROF_EXACT hands the events to hipExtLaunchKernelGGL, which binds them to the kernel's own begin
@@ -88,17 +86,19 @@ void gk_prof_begin(gk_ctx* ctx, int id, int exact);
 void gk_prof_end(gk_ctx* ctx);
 hipEvent_t gk_prof_start_event();   // events of the exact span opened on this thread, else nullptr
 hipEvent_t gk_prof_stop_event();
-#define GK_PROF(ctx, id, launch)   \
-  do {                             \
-    gk_prof_begin((ctx), (id), 0); \
-    launch;                        \
-    gk_prof_end((ctx));            \
+#define GK_PROF(ctx, name, launch)                          \
+  do {                                                      \
+    static const int gk_prof_id_ = gk_prof_register(name);  \
+    gk_prof_begin((ctx), gk_prof_id_, 0);                   \
+    launch;                                                 \
+    gk_prof_end((ctx));                                     \
   } while (0)
-#define GK_PROF_EXACT(ctx, id, launch) \
-  do {                                 \
-    gk_prof_begin((ctx), (id), 1);     \
-    launch;                            \
-    gk_prof_end((ctx));                \
+#define GK_PROF_EXACT(ctx, name, launch)                    \
+  do {                                                      \
+    static const int gk_prof_id_ = gk_prof_register(name);  \
+    gk_prof_begin((ctx), gk_prof_id_, 1);                   \
+    launch;                                                 \
+    gk_prof_end((ctx));                                     \
   } while (0)
 #define GK_KERNEL(kernel, grid, block, lds, stream, ...) \
   hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, gk_prof_start_event(), gk_prof_stop_event(), 0, __VA_ARGS__)

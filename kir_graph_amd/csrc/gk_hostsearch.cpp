@@ -183,7 +183,7 @@ struct gk_search {
   std::vector<double> colsum;
   std::vector<Step> steps;
   // launch geometries for the roofline accounting (kir_graph_amd/roofmodel.py): 7 numbers per device call --
-  // kind (0 maxsum, 1 minsum, 2 set sums), then the model's arguments
+  // kind (0 maxsum / column sums, 1 minsum, 2 set sums by tiles, 3 set sums leaf by leaf), then the model's arguments
   std::vector<int64_t> log;
   int64_t distinct(const int32_t* ids, size_t n) const {
     std::vector<char> seen((size_t)n_allele, 0);
@@ -382,7 +382,7 @@ struct GeneSearch {
     }
     int rc = gk_shares_enqueue(ctx, table, n_rows, sel.ids.data(), (int32_t)n_sel, c, true, scall);
     if (rc) return rc;
-    S->note(2, n_rows, n_sel, c, S->distinct(sel.ids.data(), sel.ids.size()), 0, 0);
+    S->note(scall.leafwise ? 3 : 2, n_rows, n_sel, c, S->distinct(sel.ids.data(), sel.ids.size()), 0, 0);
     sums_in_flight = true;
     return GK_OK;
   }
@@ -1011,7 +1011,7 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
           rc = gk_shares_enqueue(ctx, GkTable{j.d_L, j.n_rows, nullptr}, j.n_rows, b->ids.data(), (int32_t)b->deps.size(), k, true,
                                  b->call);
           if (rc) break;
-          gs[b->deps[0]]->S->note(2, j.n_rows, (int64_t)b->deps.size(), k, gs[b->deps[0]]->S->distinct(b->ids.data(), b->ids.size()), 0, 0);
+          gs[b->deps[0]]->S->note(b->call.leafwise ? 3 : 2, j.n_rows, (int64_t)b->deps.size(), k, gs[b->deps[0]]->S->distinct(b->ids.data(), b->ids.size()), 0, 0);
           batches.push_back(std::move(b));
           rc = push((int)batches.size() - 1, kOneSet);
         }

@@ -133,7 +133,7 @@ int gk_lut_collect(gk_lut* l, gk_dptr d_vals, int64_t n) {
   int64_t want = (n + kThreads - 1) / kThreads;
   unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
   gk_ctx* ctx = l->ctx;
-  GK_PROF(ctx, GK_K_LUT_COLLECT, GK_KERNEL(lut_collect, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_vals), n,
+  GK_PROF(ctx, "lut_collect", GK_KERNEL(lut_collect, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_vals), n,
                      l->d_keys, l->d_slot_idx, l->d_list, l->d_count, (uint32_t)((1ull << l->log2cap) - 1)));
   GK_HIP(hipGetLastError());
   return GK_OK;
@@ -244,7 +244,7 @@ int gk_lut_apply(gk_lut* l, gk_dptr d_in, gk_dptr d_out, int64_t n) {
   int64_t want = (n + kThreads - 1) / kThreads;
   unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
   gk_ctx* ctx = l->ctx;
-  GK_PROF(ctx, GK_K_LUT_APPLY, GK_KERNEL(lut_apply, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_in),
+  GK_PROF(ctx, "lut_apply", GK_KERNEL(lut_apply, dim3(blocks), dim3(kThreads), 0, l->ctx->stream, gk_ptr<uint64_t>(d_in),
                      gk_ptr<double>(d_out), n, l->d_keys, l->d_slot_idx, l->d_vals,
                      (uint32_t)((1ull << l->log2cap) - 1)));
   GK_HIP(hipGetLastError());

@@ -6,6 +6,7 @@
 
 #include <mutex>
 #include <cstring>
+#include <string>
 
 #include "gk_common.h"
 
@@ -401,10 +402,22 @@ void gk_prof_end(gk_ctx* ctx) {
   hipEventRecord(ctx->prof_spans.back().b, ctx->stream);
 }
 
-static const char* kKernelNames[GK_K_N] = {
-    "tab_count", "tab_emit", "scan", "novel_rank", "count_ids", "select", "compat_kernel", "lut_collect",
-    "lut_apply", "maxsum_chunks", "combine_chunks", "fraction_chunks", "setmax_kernel", "em_sets_kernel", "em_kernel",
-    "setmin_u8", "minsum_sad", "select_cut", "patch_pending"};
+// names of the timed kernels, in the order they were first launched
+static std::mutex g_prof_names_mutex;
+static std::vector<std::string>& prof_names() {
+  static std::vector<std::string> v;
+  return v;
+}
+
+int gk_prof_register(const char* name) {
+  std::lock_guard<std::mutex> lock(g_prof_names_mutex);
+  auto& v = prof_names();
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i] == name) return (int)i;
+  if ((int)v.size() >= GK_PROF_MAX) return GK_PROF_MAX - 1;     // cannot happen with the kernels this library has
+  v.emplace_back(name);
+  return (int)v.size() - 1;
+}
 
 extern "C" int gk_prof_enable(gk_ctx* ctx, int on) {
   gk_bind(ctx);
@@ -413,15 +426,21 @@ extern "C" int gk_prof_enable(gk_ctx* ctx, int on) {
   return GK_OK;
 }
 
-extern "C" int gk_prof_kernel_count(void) { return GK_K_N; }
-extern "C" const char* gk_prof_kernel_name(int id) { return id >= 0 && id < GK_K_N ? kKernelNames[id] : ""; }
+// the capacity of the two arrays gk_prof_collect fills (names register as kernels are first launched)
+extern "C" int gk_prof_kernel_count(void) { return GK_PROF_MAX; }
+extern "C" const char* gk_prof_kernel_name(int id) {
+  static thread_local std::string name;
+  std::lock_guard<std::mutex> lock(g_prof_names_mutex);
+  name = id >= 0 && id < (int)prof_names().size() ? prof_names()[(size_t)id] : "";
+  return name.c_str();
+}
 
-// launches[id], total_ms[id] for id < GK_K_N; clears the recorded spans
+// launches[id], total_ms[id] for id < gk_prof_kernel_count(); clears the recorded spans
 extern "C" int gk_prof_collect(gk_ctx* ctx, int64_t* launches, double* total_ms) {
   gk_bind(ctx);
   GK_REQUIRE(ctx && launches && total_ms, "null pointer");
   GK_HIP(hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < GK_K_N; ++i) { launches[i] = 0; total_ms[i] = 0.0; }
+  for (int i = 0; i < GK_PROF_MAX; ++i) { launches[i] = 0; total_ms[i] = 0.0; }
   for (auto& sp : ctx->prof_spans) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {

@@ -126,11 +126,11 @@ static int scan_rec(gk_ctx* ctx, uint32_t* d, int64_t n, uint32_t* sums_area, ui
     if (d_total) GK_HIP(hipMemsetAsync(d_total, 0, sizeof(uint32_t), ctx->stream));
     return GK_OK;
   }
-  GK_PROF(ctx, GK_K_SCAN, GK_KERNEL(scan_tiles, dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, d, n, sums_area));
+  GK_PROF(ctx, "scan_tiles", GK_KERNEL(scan_tiles, dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, d, n, sums_area));
   if (tiles > 1) {
     int rc = scan_rec(ctx, sums_area, tiles, sums_area + tiles, d_total);
     if (rc) return rc;
-    GK_PROF(ctx, GK_K_SCAN, GK_KERNEL(add_tile_offsets, dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, d, n, sums_area));
+    GK_PROF(ctx, "add_tile_offsets", GK_KERNEL(add_tile_offsets, dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, d, n, sums_area));
   } else if (d_total) {
     GK_HIP(hipMemcpyAsync(d_total, sums_area, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
   }
@@ -163,9 +163,9 @@ int gk_compact_enqueue(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_val
     uint32_t* cnt = nullptr;
     GK_HIP(gk_pool_malloc(ctx, (void**)&cnt, (size_t)(blocks2 + 1) * sizeof(uint32_t)));
     temps.push_back(cnt);
-    GK_PROF(ctx, GK_K_SCAN, GK_KERNEL(compact_count, dim3((unsigned)blocks2), dim3(kThreads), 0, ctx->stream,
+    GK_PROF(ctx, "compact_count", GK_KERNEL(compact_count, dim3((unsigned)blocks2), dim3(kThreads), 0, ctx->stream,
                                              d_flag, n, cnt));
-    GK_PROF(ctx, GK_K_SCAN, GK_KERNEL(compact_scatter, dim3((unsigned)blocks2), dim3(kThreads), 0, ctx->stream,
+    GK_PROF(ctx, "compact_scatter", GK_KERNEL(compact_scatter, dim3((unsigned)blocks2), dim3(kThreads), 0, ctx->stream,
                                              d_flag, d_values, n, cnt, d_out, cnt + blocks2));
     GK_HIP(hipGetLastError());
     *d_total_out = cnt + blocks2;
@@ -175,10 +175,10 @@ int gk_compact_enqueue(gk_ctx* ctx, const uint32_t* d_flag, const int32_t* d_val
   GK_HIP(gk_pool_malloc(ctx, (void**)&pos, (size_t)(n + 1) * sizeof(uint32_t)));
   temps.push_back(pos);
   unsigned blocks = (unsigned)((n + kThreads - 1) / kThreads);
-  GK_PROF(ctx, GK_K_SCAN, GK_KERNEL(flags_to_u32, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, n));
+  GK_PROF(ctx, "flags_to_u32", GK_KERNEL(flags_to_u32, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, n));
   int rc = gk_scan_u32(ctx, pos, n, pos + n);
   if (rc) return rc;
-  GK_PROF(ctx, GK_K_SCAN, GK_KERNEL(scatter_selected, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, d_values, n, d_out));
+  GK_PROF(ctx, "scatter_selected", GK_KERNEL(scatter_selected, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_flag, pos, d_values, n, d_out));
   GK_HIP(hipGetLastError());
   *d_total_out = pos + n;
   return GK_OK;

@@ -1015,22 +1015,22 @@ int gk_maxsum(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   const int tiles_t = (n_sets + kTileT - 1) / kTileT, tiles_a = (n_cols + kTileA - 1) / kTileA;
   const dim3 grid((unsigned)(tiles_t * tiles_a * dp.n_spans));
   if (c_prev) {
-    GK_PROF_EXACT(ctx, GK_K_MAXSUM,
+    GK_PROF_EXACT(ctx, "maxsum_chunks",
             GK_KERNEL(maxsum_chunks<true>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
                                c_prev >= 2 ? d_P : gk_ptr<double>(d_L), ld, dp.ids, n_sets, dp.cols, n_cols, dp.spans,
                                dp.leaves, tiles_t * tiles_a, symmetric ? 1 : 0, d_partial));
   } else if (n_sets == 1) {
-    GK_PROF_EXACT(ctx, GK_K_MAXSUM,
+    GK_PROF_EXACT(ctx, "colsum_chunks",
             GK_KERNEL(colsum_chunks<double>, dim3((unsigned)((n_cols + kColsPerGroup - 1) / kColsPerGroup), (unsigned)dp.n_spans),
                       dim3(kThreads), 0, st, TableView<double>{gk_ptr<double>(d_L), nullptr}, ld, dp.cols, n_cols, dp.spans,
                       dp.leaves, d_partial));
   } else {
-    GK_PROF_EXACT(ctx, GK_K_MAXSUM,
+    GK_PROF_EXACT(ctx, "maxsum_chunks",
             GK_KERNEL(maxsum_chunks<false>, grid, dim3(kThreads), 0, st, gk_ptr<double>(d_L), ld,
                                gk_ptr<double>(d_L), ld, (const int32_t*)nullptr, n_sets, dp.cols, n_cols, dp.spans,
                                dp.leaves, tiles_t * tiles_a, 0, d_partial));
   }
-  GK_PROF(ctx, GK_K_COMBINE,
+  GK_PROF(ctx, "combine_chunks",
           GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st,
                              d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, 0.0, d_out));
   GK_HIP(hipGetLastError());
@@ -1086,7 +1086,7 @@ int gk_setmax(gk_ctx* ctx, gk_dptr d_L, int64_t n_rows, int64_t ld, const int32_
   GK_HIP(gk_send(ctx, d_ids, ids, (size_t)n_sets * c * sizeof(int32_t)));
   int64_t want = (n_rows + kThreads - 1) / kThreads;
   unsigned bx = (unsigned)(want < 1024 ? want : 1024);
-  GK_PROF(ctx, GK_K_SETMAX,
+  GK_PROF(ctx, "setmax_kernel",
           GK_KERNEL(setmax_kernel, dim3(bx, (unsigned)n_sets), dim3(kThreads), 0, st, gk_ptr<double>(d_L), n_rows,
                              ld, d_ids, n_sets, c, gk_ptr<double>(d_P)));
   GK_HIP(hipGetLastError());
@@ -1126,7 +1126,7 @@ static int shares_leafwise(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const 
   {                                                                                                                       \
     if (lds > 48 * 1024)                                                                                                  \
       GK_HIP(hipFuncSetAttribute((const void*)setsum_leaves<C, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    GK_PROF(ctx, GK_K_FRACTION,                                                                                           \
+    GK_PROF(ctx, "setsum_leaves",                                                                                           \
             GK_KERNEL((setsum_leaves<C, S>), grid, dim3(kLeafThreads), lds, st, gk_ptr<double>(L.d), L.ld, n_cols,         \
                       dp.ids + (size_t)set0 * C, n_here, n_sets, dp.flat, d_partial + (size_t)set0 * (C + 1)));           \
   }
@@ -1158,11 +1158,11 @@ static int shares_leafwise(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const 
   const size_t fold_lds = (size_t)dp.max_chunk_leaves * kFoldOut * sizeof(double);
   if (fold_lds > 48 * 1024)
     GK_HIP(hipFuncSetAttribute((const void*)fold_leaves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds));
-  GK_PROF(ctx, GK_K_COMBINE,
+  GK_PROF(ctx, "fold_leaves",
           GK_KERNEL(fold_leaves, dim3((unsigned)((n_out + kFoldOut - 1) / kFoldOut), (unsigned)dp.n_chunks), dim3(kFoldOut),
                     fold_lds, st, d_partial, n_out, dp.chunk_leaf0, dp.chunk_lop0, dp.lops, d_chunk));
   // the chunk sums in sequence (numpy's outer reduce loop); the shares are handed back undivided (collect divides)
-  GK_PROF(ctx, GK_K_COMBINE,
+  GK_PROF(ctx, "combine_chunks",
           GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st, d_chunk,
                     n_out, dp.n_chunks, dp.unit0, dp.zero0, dp.top, 0.0, d_out));
   GK_HIP(hipGetLastError());
@@ -1170,6 +1170,7 @@ static int shares_leafwise(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const 
   call.n_sets = n_sets;
   call.c = c;
   call.with_value = true;
+  call.leafwise = true;
   call.back.resize((size_t)n_out);
   GK_HIP(gk_fetch_queue(ctx, call.back.data(), d_out, (size_t)n_out * sizeof(double)));
   return GK_OK;
@@ -1259,7 +1260,7 @@ int gk_shares_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32
     if (lds > 48 * 1024)                                                                                             \
       GK_HIP(hipFuncSetAttribute((const void*)fraction_chunks<C, V, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  (int)lds));                                                                         \
-    GK_PROF(ctx, GK_K_FRACTION,                                                                                      \
+    GK_PROF(ctx, "fraction_chunks",                                                                                      \
             GK_KERNEL((fraction_chunks<C, V, TL>), grid, dim3(kThreads), lds, st, VIEW, ld, dp.ids, dp.ids + o_cols, \
                       dp.ids + o_local, dp.ids + o_perm, n_sets, dp.spans, dp.leaves, d_partial));                   \
   }
@@ -1283,7 +1284,7 @@ int gk_shares_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32
 #undef GK_FRAC_LAUNCH_V
 #undef GK_FRAC_GO
   // with the value riding along the sums are handed back undivided (collect divides the shares by n_rows)
-  GK_PROF(ctx, GK_K_COMBINE,
+  GK_PROF(ctx, "combine_chunks",
           GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st,
                              d_partial, n_out, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top,
                              with_value ? 0.0 : (double)n_rows, d_out));
@@ -1331,16 +1332,16 @@ int gk_colsum_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32
   call.temps.push_back(d_out);
   const dim3 cgrid((unsigned)((n_cols + kColsPerGroup - 1) / kColsPerGroup), (unsigned)dp.n_spans);
   if (L.indexed())
-    GK_PROF_EXACT(ctx, GK_K_MAXSUM,
+    GK_PROF_EXACT(ctx, "colsum_chunks",
                   GK_KERNEL(colsum_chunks<uint16_t>, cgrid, dim3(kThreads), 0, st,
                             TableView<uint16_t>{gk_ptr<uint16_t>(L.d), L.vals}, ld, dp.cols, n_cols, dp.spans, dp.leaves,
                             d_partial));
   else
-    GK_PROF_EXACT(ctx, GK_K_MAXSUM,
+    GK_PROF_EXACT(ctx, "colsum_chunks",
                   GK_KERNEL(colsum_chunks<double>, cgrid, dim3(kThreads), 0, st,
                             TableView<double>{gk_ptr<double>(L.d), nullptr}, ld, dp.cols, n_cols, dp.spans, dp.leaves,
                             d_partial));
-  GK_PROF(ctx, GK_K_COMBINE,
+  GK_PROF(ctx, "combine_chunks",
           GK_KERNEL(combine_chunks, dim3((unsigned)((n_cols + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st,
                              d_partial, (int64_t)n_cols, dp.n_chunks, dp.chunk_span0, dp.chunk_op0, dp.top, 0.0, d_out));
   GK_HIP(hipGetLastError());

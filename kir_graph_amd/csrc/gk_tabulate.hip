@@ -43,6 +43,7 @@ constexpr int kMaskWords = 8;            // kept-candidate bits saved per mate b
 constexpr uint32_t kEvNovel = 1u << 31;   // not an index variant; low 24 bits = position
 constexpr uint32_t kEvIsN = 1u << 30;     // substitution to 'N'
 constexpr uint32_t kEvOrdMask = (1u << 26) - 1;
+constexpr uint32_t kEvSlotMask = (1u << 30) - 1;   // saved form of a novel event: kEvNovel | slot of the novel table (at most 2^30 slots)
 
 // a staged record, read out of LDS
 struct MateView {
@@ -282,7 +283,10 @@ struct EvRow {
     return e == 0 ? r[0] : e == 1 ? r[1] : e == 2 ? r[2] : e == 3 ? r[3] : more[e - kEvRegs];
   }
   __device__ uint32_t n_pos(uint32_t w, const IndexView& ix) const {      // position of an event that reads N
-    return (w & kEvNovel) ? gk_key_pos(novel_keys[w & 0xFFFFFFu]) : gk_key_pos(ix.key[w & kEvOrdMask]);
+    // the slot's key was stored by an atomicCAS of this very launch (at L2): a plain load may be served by a line the
+    // CU's L1 took when the slot was still empty, so the key is read at agent scope
+    return (w & kEvNovel) ? gk_key_pos(__hip_atomic_load(&novel_keys[w & kEvSlotMask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                          : gk_key_pos(ix.key[w & kEvOrdMask]);
   }
 };
 
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(kExpandThreads) void tab_expand(int64_t n_mates, in
         const uint32_t first[kEvRegs] = {e4.x, e4.y, e4.z, e4.w};
         for (uint32_t e = 0; e < n_pos; ++e) {
           const uint32_t w = (e < (uint32_t)kEvRegs ? first[e] : ev_more[m * kEvMore + e - kEvRegs]) & ~kEvIsN;
-          put(o_pos + e, (w & kEvNovel) ? (uint32_t)n_var + rank[w & 0xFFFFFFu] : w);
+          put(o_pos + e, (w & kEvNovel) ? (uint32_t)n_var + rank[w & kEvSlotMask] : w);
         }
       }
       if (n_neg) {
@@ -1001,7 +1005,7 @@ int gk_tabulate_spilled(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n
   while ((1ull << log2cap) < (uint64_t)(2 * std::max<int64_t>(n_pairs, 0)) && log2cap < 22) ++log2cap;   // at most 4 M slots to begin with
   if (const char* e = getenv("GK_NOVEL_LOG2CAP")) log2cap = (uint32_t)std::min(30, std::max(4, atoi(e)));   // tests: force the retries
   uint32_t log2max = 16;
-  while ((1ull << log2max) < (uint64_t)(2 * std::max<int64_t>(n_pairs, 0)) * GK_WIDE_EVENTS * 2 && log2max < 31) ++log2max;
+  while ((1ull << log2max) < (uint64_t)(2 * std::max<int64_t>(n_pairs, 0)) * GK_WIDE_EVENTS * 2 && log2max < 30) ++log2max;   // a slot number is 30 bits of an event word
   for (;;) {
     bool too_small = false;
     const int rc = tabulate_with_table(ctx, idx, d_mates_p, n_pairs, d_corr, d_gene_pos0, wide, spill_pair, n_spill, log2cap,
@@ -1059,7 +1063,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
                      gk_ptr<uint8_t>(d_corr), gk_ptr<int64_t>(d_gene_pos0), idx->d_del_bits, idx->d_lb_a, idx->d_lb_t,
                      idx->d_gene_pbase, idx->d_snp_ord};
   if (n_mates) {
-    GK_PROF(ctx, GK_K_TAB_COUNT, GK_KERNEL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
+    GK_PROF(ctx, "tab_count", GK_KERNEL(tab_count, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix,
                        nt, cnt, valid, d_err, ev_save, ev_more, lo_save, mask_save, mask_more));
   }
   int64_t* d_spill_pair = nullptr;
@@ -1087,9 +1091,9 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
   GK_HIP(gk_pool_malloc(ctx, (void**)&wide_bits, (size_t)(2 * n_spill + 1) * kWideWords * sizeof(uint32_t)));
   GK_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_words * sizeof(uint32_t), st));
   GK_HIP(hipMemsetAsync(wide_bits, 0, (size_t)(2 * n_spill + 1) * kWideWords * sizeof(uint32_t), st));
-  GK_PROF(ctx, GK_K_NOVEL, GK_KERNEL(novel_mark, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap, wide_bits,
+  GK_PROF(ctx, "novel_mark", GK_KERNEL(novel_mark, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap, wide_bits,
                                      d_spill_pair, n_spill));
-  GK_PROF(ctx, GK_K_NOVEL, GK_KERNEL(novel_count, dim3(nblk(n_words)), dim3(kThreads), 0, st, bitmap, prefix, n_words));
+  GK_PROF(ctx, "novel_count", GK_KERNEL(novel_count, dim3(nblk(n_words)), dim3(kThreads), 0, st, bitmap, prefix, n_words));
   if (n_spill)
     GK_KERNEL(novel_count_wide, dim3(nblk(2 * n_spill)), dim3(kThreads), 0, st, wide_bits, d_spill_pair, n_spill, prefix);
   rc = gk_scan_u32(ctx, prefix, n_words, prefix + n_words);
@@ -1117,7 +1121,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
   }
 
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_novel_key, (size_t)(tab->n_novel + 1) * sizeof(uint64_t)));
-  GK_PROF(ctx, GK_K_NOVEL, GK_KERNEL(novel_assign, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap, wide_bits,
+  GK_PROF(ctx, "novel_assign", GK_KERNEL(novel_assign, dim3(nblk((int64_t)cap)), dim3(kThreads), 0, st, nt, bitmap, wide_bits,
                      d_spill_pair, n_spill, prefix, tab->d_novel_key));
 
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_ids, (size_t)(tab->n_ids + 1) * sizeof(uint32_t)));
@@ -1125,10 +1129,10 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
     // pass 2: from what pass 1 saved; the second walk only when some window did not fit the saved bits
     const bool two_walks = getenv("GK_TAB_TWO_WALKS") != nullptr;   // development / test switch
     if ((err & 4) || two_walks) {
-      GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix, nt,
+      GK_PROF(ctx, "tab_emit", GK_KERNEL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix, nt,
                          cnt, valid, tab->d_ids));
     } else {
-      GK_PROF(ctx, GK_K_TAB_EMIT, GK_KERNEL(tab_expand, dim3(nblk(n_mates, kExpandThreads)), dim3(kExpandThreads), 0, st, n_mates, idx->n_var,
+      GK_PROF(ctx, "tab_expand", GK_KERNEL(tab_expand, dim3(nblk(n_mates, kExpandThreads)), dim3(kExpandThreads), 0, st, n_mates, idx->n_var,
                          nt.rank, cnt, valid, ev_save, ev_more, lo_save, mask_save, mask_more, tab->d_ids));
     }
     // the pairs of the wide format, AFTER the kernel above (tab_expand copies a wavefront's whole run of lists out of LDS,
@@ -1144,7 +1148,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_off, (size_t)(4 * tab->n_valid + 1) * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_pair_gene, (size_t)tab->n_valid + 1));
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_pair_nh, (size_t)tab->n_valid + 1));
-  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(gather_pairs, dim3(nblk(tab->n_valid + 1)), dim3(kThreads), 0, st, mates, tab->d_pair_src,
+  GK_PROF(ctx, "gather_pairs", GK_KERNEL(gather_pairs, dim3(nblk(tab->n_valid + 1)), dim3(kThreads), 0, st, mates, tab->d_pair_src,
                      tab->n_valid, cnt, tab->d_off, tab->d_pair_gene, tab->d_pair_nh, (uint32_t)tab->n_ids));
   GK_HIP(hipGetLastError());
   GK_HIP(hipStreamSynchronize(st));

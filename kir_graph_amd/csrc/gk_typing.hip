@@ -234,20 +234,18 @@ __global__ __launch_bounds__(kThreads) void transpose_mask(const uint32_t* mask,
   out[i] = mask[(int64_t)v * words + w];
 }
 
-// clear bit `t` of a wave-uniform bit set (one s_bitset0_b64 instead of the add / addc / and of x &= x - 1)
-__device__ __forceinline__ uint64_t clear_bit(uint64_t set, int t) {
-  asm("s_bitset0_b64 %0, %1" : "+s"(set) : "s"(t));
-  return set;
-}
-
 // One wavefront per read pair, lanes = alleles (kSlots allele slots per lane; a gene of <= 256
 // alleles is one pass, and the last pass of a wider gene only carries the slots it needs).  Per chunk
 // of 64 variant ordinals, lane k loads ordinal k, its drop flag and the 2*kSlots bit-row words of
 // that variant that this pass needs (windows are runs of consecutive ordinals, so these are coalesced row reads of the
-// L2-resident, word-major bit matrix) and lays them down in LDS.  The kept variants of the chunk are a scalar bit set
-// walked in order; per factor and slot a lane reads the word holding its allele's bit (the next variant's words are
-// already in flight), sign-extends the bit into a select mask (v_bfe_i32), picks the factor's halves (2 x v_bfi_b32)
-// and multiplies -- 0.999 / 0.001 in the reference's order.
+// L2-resident, word-major bit matrix).  The KEPT variants of the chunk are laid down in LDS back to back, in list order
+// (a lane's place = the kept lanes below it: v_mbcnt), the rows of the negative ones inverted -- a set bit then means
+// "allele and read agree" for both signs -- so the walk over them is a counted loop of straight-line code, four variants
+// per round: per factor and slot a lane reads the word holding its allele's bit (a two-address broadcast read),
+// sign-extends the bit into a select mask (v_bfe_i32), picks the factor's halves (2 x v_bfi_b32) and multiplies --
+// 0.999 / 0.001 in the reference's order.  (Rounds 2 - 4 walked a scalar bit set of the kept variants with a branch per
+// variant and, from round 4, a test and two branches per slot for slots nobody carries the variant in: ~19 scalar
+// instructions and 4 - 7 taken branches per 12 vector ones.)
 // Results of a 16-row tile are transposed through LDS so that the column-major [allele][row]
 // output is written as runs instead of one store per (allele, row).
 //
@@ -261,31 +259,13 @@ __device__ __forceinline__ uint64_t clear_bit(uint64_t set, int t) {
 // beyond 65534 raises bit 1 of the flag word: the caller then takes the float64 form for this gene.
 constexpr uint16_t kNoIndex = 0xFFFFu;   // "log10 not defined yet" in the index table (rewritten by the next pass)
 
-// kFma: the factor as 0.001 + b * 0.998 in ONE fused multiply-add (b = 1.0 where the allele agrees with the read: the
-// selected bit moved into the exponent field of a double whose low word stays 0): fl(0.001 + 0.998) == 0.999 exactly,
-// so the factors are the reference's two constants bit for bit.  v_bfe_i32 + v_and_b32 + v_fma_f64 + v_mul_f64 issue in
-// 16.05 cycles per factor and slot where the two v_bfi_b32 of the select form take 18.05 (profiles/r03_valu_rate.txt);
-// in the kernel the form measured no faster (3.18 - 3.21 against 3.15 ms per sample), it stays as an option.
-// The bit rows of the NEGATIVE variants are inverted when they are laid down in LDS (once per variant, not per factor
-// and slot), so that one walk in list order serves both signs.
-template <bool kLog, int kSlots, bool kMiss, bool kIdx, bool kFma = false>
+template <bool kLog, int kSlots, bool kMiss, bool kIdx>
 __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* rows, int64_t n_rows, const uint32_t* off,
                                                                 const uint32_t* ids, const uint8_t* vflag, int vbeg, int vend,
                                                                 const uint32_t* mask_t, int words, int n_allele, int a_base,
                                                                 double* probs, uint8_t* miss_out, uint16_t* nvar_out,
                                                                 LutView lut, double empty_p, uint8_t* miss8, int64_t ldm,
-                                                                uint32_t* bound_flags, uint16_t* lidx, int probe_arg,
-                                                                int uniform_cut) {
-  // The timing probe is compiled OUT of the shipped kernel: it exists only in a library built with -DGK_TIMING_PROBES=1
-  // (GK_EXTRA_HIPCC_FLAGS, tools/compat_phases.sh); otherwise `probe` is the constant 0 and its branches are gone.
-#if defined(GK_TIMING_PROBES) && GK_TIMING_PROBES
-  const int probe = probe_arg;
-#else
-  constexpr int probe = 0;
-  (void)probe_arg;
-#endif
-  // probe (tools/compat_phases.sh, GK_COMPAT_PROBE): 1 = leave out the walk over the kept variants, 2 = leave out the way
-  // out of a tile, 3 = only its second pass (the stores), 4 = only its first (the value-table look-ups) -- WRONG results, for timing the two halves of the kernel only; 0 in every real launch
+                                                                uint32_t* bound_flags, uint16_t* lidx) {
   const int n_span = vend - vbeg;   // mask_t: [words][n_span], see transpose_mask
   constexpr int kPassAlleles = 64 * kSlots;
   constexpr int kPassWords = 2 * kSlots;   // bit-row words covering one pass
@@ -316,11 +296,14 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
       const uint32_t b = __builtin_amdgcn_readfirstlane(off[4 * row]);
       const uint32_t mid = __builtin_amdgcn_readfirstlane(off[4 * row + 2]);
       const uint32_t e = __builtin_amdgcn_readfirstlane(off[4 * row + 4]);
-      double p[kSlots], agree[kSlots];
+      double p[kSlots];
       uint32_t miss[kSlots];
       uint32_t nvar = 0;
 #pragma unroll
-      for (int s = 0; s < kSlots; ++s) { p[s] = 1.0; miss[s] = 0; agree[s] = 0.0; }
+      for (int s = 0; s < kSlots; ++s) { p[s] = 1.0; miss[s] = 0; }
+      // this lane's word of the t-th kept variant and slot s: wave's base + the lane's half + t * kPassWords + 2 s
+      const uint32_t* const my_words = &wave_rows[wid][lane >> 5];
+      const int my_bit = lane & 31;
       for (uint32_t base = b; base < e; base += 64) {
         const uint32_t k = base + lane;
         bool my_keep = false;
@@ -337,96 +320,47 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
               if (w_base + w < words) mrow[w] = src[(int64_t)w * n_span];
           }
           my_keep = !(vflag[v] & (k < mid ? 1 : 2));
-          if (kFma && k >= mid) {
+          if (k >= mid) {
 #pragma unroll
             for (int w = 0; w < kPassWords; ++w) mrow[w] = ~mrow[w];     // "the allele lacks it" = agreement with a negative id
           }
         }
-        // A variant that NO allele of a slot carries gives every lane of that slot the same factor (0.001 for a positive
-        // id, 0.999 for a negative one): one multiply by a constant instead of word read + bit test + two selects +
-        // multiply.  36 % of the (variant, slot) pairs of the bench index are such, and nearly all of a last slot that
-        // holds a few alleles only -- the padding lanes of a gene cost a quarter this way.  nz[s] = variants of the
-        // chunk with at least one allele in slot s, as a scalar bit set (all ones when the short cut is off).
-        uint64_t nz[kSlots];
-#pragma unroll
-        for (int s = 0; s < kSlots; ++s)
-          nz[s] = (kFma || !uniform_cut) ? ~0ull : __ballot((mrow[2 * s] | mrow[2 * s + 1]) != 0u);
-        // kept variants of the chunk as scalar bit sets, walked in order: the positive ones (ordinals
-        // below `mid`) come first, then the negative ones, whose factors are swapped
+        // the kept variants of the chunk back to back in LDS, in list order (positives, then negatives)
         const uint64_t kept = __ballot(my_keep);
-        nvar += (uint32_t)__builtin_popcountll(kept);
-        const uint32_t n_pos = mid > base ? min(mid - base, 64u) : 0u;
-        const uint64_t pos_lanes = n_pos >= 64 ? ~0ull : ((1ull << n_pos) - 1ull);
-        // The bit rows of the chunk go through LDS ([variant][word], per wave): for variant t every lane reads
-        // the word that holds its allele's bit (a two-address broadcast read), sign-extends that bit into a
-        // select mask (v_bfe_i32) and picks the factor's two halves with v_bfi_b32 -- 4 VALU operations per
-        // factor and slot, none of them cross-lane.
-        uint32_t* const wrows = &wave_rows[wid][0];
+        const int n_kept = __builtin_popcountll(kept);
+        nvar += (uint32_t)n_kept;
+        if (my_keep) {
+          const uint32_t place = __builtin_amdgcn_mbcnt_hi((uint32_t)(kept >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kept, 0u));
+          uint32_t* const dst = &wave_rows[wid][place * kPassWords];
 #pragma unroll
-        for (int w = 0; w < kPassWords; ++w) wrows[lane * kPassWords + w] = mrow[w];
+          for (int w = 0; w < kPassWords; ++w) dst[w] = mrow[w];
+        }
         __builtin_amdgcn_wave_barrier();   // LDS operations of a wave are executed in order
-        // this lane's word of variant t and slot s: a 32-bit LDS index (wave's base + the lane's half) + a scalar t * stride
-        const int my_word0 = wid * (64 * kPassWords) + (lane >> 5);
-        const int my_bit = lane & 31;
-        // one variant's words for the lane's slots / the factor they select; the walk reads the words of the
-        // next kept variant before it multiplies the current one in (two register sets, no copies)
-        auto fetch = [&](int t, uint32_t (&w)[kSlots]) {
-          int t_off;      // t * words per variant, on the scalar unit (the compiler would otherwise spend a 64-bit VALU multiply-add on it)
-          asm("s_mul_i32 %0, %1, %2" : "=s"(t_off) : "s"(t), "n"(kPassWords));
-#pragma unroll
-          for (int s = 0; s < kSlots; ++s) w[s] = (&wave_rows[0][0])[my_word0 + t_off + 2 * s];
-        };
-        auto apply = [&](const uint32_t (&w)[kSlots], int t, bool positive) {
+        // one factor per slot: bit -> select mask -> the factor's two halves -> multiply (1.0 * f == f)
+        auto apply = [&](const uint32_t (&w)[kSlots]) {
 #pragma unroll
           for (int s = 0; s < kSlots; ++s) {
-            if (!((nz[s] >> t) & 1ull)) {      // wave-uniform: nobody in this slot has variant t
-              // ONE multiply by a scalar constant, issued here (written as an instruction so that the compiler does not
-              // turn it into "move the constant, join the other path's multiply": two VALU operations)
-              const double c = positive ? 0.001 : 0.999;
-              asm volatile("v_mul_f64 %0, %0, %1" : "+v"(p[s]) : "s"(c));
-              if (kMiss && positive) miss[s] += 1u;
-              continue;
-            }
-            const int32_t m = __builtin_amdgcn_sbfe((int32_t)w[s], my_bit, 1);   // -1: the allele has the variant
-            if (kFma) {
-              agree[s] = __hiloint2double(m & 0x3FF00000, __double2loint(agree[s]));   // 1.0 / 0.0: only the high word changes
-              p[s] *= __builtin_fma(agree[s], 0.998, 0.001);
-              if (kMiss) miss[s] += (uint32_t)(m + 1);
-            } else if (positive) {
-              p[s] *= __hiloint2double((m & kHi999) | (~m & kHi001), (m & kLo999) | (~m & kLo001));   // 1.0 * f == f
-              if (kMiss) miss[s] += (uint32_t)(m + 1);
-            } else {
-              p[s] *= __hiloint2double((m & kHi001) | (~m & kHi999), (m & kLo001) | (~m & kLo999));
-              if (kMiss) miss[s] += (uint32_t)(-m);
-            }
+            const int32_t m = __builtin_amdgcn_sbfe((int32_t)w[s], my_bit, 1);   // -1: allele and read agree
+            p[s] *= __hiloint2double((m & kHi999) | (~m & kHi001), (m & kLo999) | (~m & kLo001));
+            if (kMiss) miss[s] += (uint32_t)(m + 1);
           }
         };
-        auto walk = [&](uint64_t todo, bool positive) {
-          if (!todo) return;
-          uint32_t wa[kSlots], wb[kSlots];
-          int ta = __builtin_ctzll(todo), tb;
-          todo = clear_bit(todo, ta);
-          fetch(ta, wa);
-          for (;;) {
-            if (!todo) { apply(wa, ta, positive); break; }
-            tb = __builtin_ctzll(todo);
-            todo = clear_bit(todo, tb);
-            fetch(tb, wb);
-            apply(wa, ta, positive);
-            if (!todo) { apply(wb, tb, positive); break; }
-            ta = __builtin_ctzll(todo);
-            todo = clear_bit(todo, ta);
-            fetch(ta, wa);
-            apply(wb, tb, positive);
-          }
-        };
-        if (probe == 1) {
-          // timing probe: no factors
-        } else if (kFma) {
-          walk(kept, true);
-        } else {
-          walk(kept & pos_lanes, true);
-          walk(kept & ~pos_lanes, false);
+        int t = 0;
+        for (; t + 4 <= n_kept; t += 4) {      // four variants per round: their words requested together, then 16 x kSlots VALU
+          uint32_t w4[4][kSlots];
+          const uint32_t* const at = my_words + t * kPassWords;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) w4[j][s] = at[j * kPassWords + 2 * s];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) apply(w4[j]);
+        }
+        for (; t < n_kept; ++t) {
+          uint32_t w1[kSlots];
+#pragma unroll
+          for (int s = 0; s < kSlots; ++s) w1[s] = my_words[t * kPassWords + 2 * s];
+          apply(w1);
         }
         __builtin_amdgcn_wave_barrier();   // the next chunk overwrites the rows
       }
@@ -493,9 +427,9 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
         }
       }
     } else
-    if (probs && probe != 2) {
+    if (probs) {
       const int n_r = (int)min<int64_t>(kTileRows, n_rows - row0);
-      if (kLog && probe != 4) {
+      if (kLog) {
         // Pass 1 of the way out: every product of the tile is replaced, in place, by its log10 from the value table.
         // A thread keeps to ONE read (its alleles share a handful of values: most lookups end in the two registers).
         uint64_t key0 = kLutEmptyKey, key1 = kLutEmptyKey;   // the two most recent values of this thread's read
@@ -544,7 +478,7 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
       // |a - b| sum).  A count >= 100 (the product is about to leave the normal range / underflow, L = -inf) raises the
       // flag that sends the gene to the exact search; NaN (log10 not defined yet) is rewritten by the next pass.
       constexpr int kQuads = kTileRows / 4;
-      for (int it = tid; it < (probe == 3 ? 0 : n_pass * kQuads); it += kCompatThreads) {
+      for (int it = tid; it < n_pass * kQuads; it += kCompatThreads) {
         const int al = it / kQuads, r0 = 4 * (it % kQuads);
         const double* const cell = &tile[al * kTileLd + r0];
         double v[4];
@@ -637,39 +571,16 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
               gk_ptr<uint32_t>(d_mask), vend - vbeg, words, mask_t, bound_flags);
   else if (bound_flags)
     GK_HIP(hipMemsetAsync(bound_flags, 0, sizeof(uint32_t), ctx->stream));
-  // GK_COMPAT_FORM = select (default) | fma: how a factor is chosen, see compat_kernel (the fma form measured 1 - 2 %
-  // slower on the bench sample, profiles/r03_compat_variants.txt: the factor loop is 56 % of the kernel's VALU work)
-  // timing probe (tools/compat_phases.sh): only in a library built with -DGK_TIMING_PROBES=1, there only together with
-  // GK_TIMING_PROBES=1 in the environment, and never quietly
-#if defined(GK_TIMING_PROBES) && GK_TIMING_PROBES
-  const char* const probe_env = getenv("GK_COMPAT_PROBE");
-  const char* const probes_on = getenv("GK_TIMING_PROBES");
-  const int probe = (probe_env && probes_on && !strcmp(probes_on, "1")) ? atoi(probe_env) : 0;
-#else
-  const int probe = 0;
-#endif
-  if (probe) {
-    static std::once_flag warned;
-    std::call_once(warned, [&] {
-      fprintf(stderr, "[graphkir_hip] GK_COMPAT_PROBE=%d: parts of the compatibility kernel are left out -- the tables are "
-                      "WRONG, this run is good for timing only\n", probe);
-    });
-  }
-  const char* const cut_env = getenv("GK_COMPAT_UNIFORM");     // 0: every factor through the bit test (for comparisons)
-  const int uniform_cut = !(cut_env && !strcmp(cut_env, "0"));
-  const char* const form_env = getenv("GK_COMPAT_FORM");      // read per call: the tests compare both forms in one process
-  const bool fma_form = form_env && !strcmp(form_env, "fma");
   for (int a_base = 0; a_base < n_allele; a_base += 64 * kMaxSlots) {
     const int slots = std::min(kMaxSlots, (n_allele - a_base + 63) / 64);
-#define GK_COMPAT_GO(S, IDX, FMA)                                                                                     \
-  GK_KERNEL((compat_kernel<kLog, S, !kLog, IDX, FMA>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows,  \
-            tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, mask_t, words, n_allele, a_base, out,       \
-            miss, nvar, view, empty_p, miss8, ldm, bound_flags, lidx, probe, uniform_cut)
-#define GK_COMPAT_LAUNCH(S)                                       \
-  GK_PROF(ctx, GK_K_COMPAT, {                                     \
-    if (kLog && lidx) GK_COMPAT_GO(S, (kLog && true), false);     \
-    else if (kLog && fma_form) GK_COMPAT_GO(S, false, (kLog && true)); \
-    else GK_COMPAT_GO(S, false, false);                           \
+#define GK_COMPAT_GO(S, IDX)                                                                                        \
+  GK_KERNEL((compat_kernel<kLog, S, !kLog, IDX>), grid, block, 0, ctx->stream, gk_ptr<int32_t>(d_rows), n_rows,     \
+            tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), vbeg, vend, mask_t, words, n_allele, a_base, out,     \
+            miss, nvar, view, empty_p, miss8, ldm, bound_flags, lidx)
+#define GK_COMPAT_LAUNCH(S)                              \
+  GK_PROF(ctx, "compat_kernel", {                        \
+    if (kLog && lidx) GK_COMPAT_GO(S, (kLog && true));   \
+    else GK_COMPAT_GO(S, false);                         \
   })
     switch (slots) {
       case 1: GK_COMPAT_LAUNCH(1); break;
@@ -701,12 +612,12 @@ static int build_partition(gk_ctx* ctx, gk_tab* tab, int multiple) {
   GK_HIP(gk_pool_malloc(ctx, (void**)&part.d_rows, (size_t)(n + 1) * sizeof(int32_t)));
   part.owner = ctx;
   GK_HIP(hipMemsetAsync(hist, 0, n_hist * sizeof(uint32_t), ctx->stream));
-  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(part_pass<false>, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream,
+  GK_PROF(ctx, "part_pass", GK_KERNEL(part_pass<false>, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream,
                                                tab->d_pair_gene, tab->d_pair_nh, n, multiple, n_bins, n_tiles, hist,
                                                (int32_t*)nullptr));
   int rc = gk_scan_u32(ctx, hist, (int64_t)n_hist, hist + n_hist);
   if (rc) return rc;
-  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(part_pass<true>, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream,
+  GK_PROF(ctx, "part_pass", GK_KERNEL(part_pass<true>, dim3(nblk(n)), dim3(kThreads), 0, ctx->stream,
                                                tab->d_pair_gene, tab->d_pair_nh, n, multiple, n_bins, n_tiles, hist,
                                                part.d_rows));
   GK_KERNEL(part_offsets, dim3((unsigned)(n_bins / 256 + 1)), dim3(256), 0, ctx->stream, hist, hist + n_hist,
@@ -751,7 +662,7 @@ int gk_select_nonempty(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows,
   if (n_rows == 0) { *n_out = 0; return GK_OK; }
   uint32_t* flag = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)n_rows * sizeof(uint32_t)));
-  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(flag_nonempty, dim3(nblk(n_rows)), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
+  GK_PROF(ctx, "flag_nonempty", GK_KERNEL(flag_nonempty, dim3(nblk(n_rows)), dim3(kThreads), 0, ctx->stream, gk_ptr<int32_t>(d_rows),
                      n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), flag, (uint32_t*)nullptr, 0));
   int rc = gk_compact(ctx, flag, gk_ptr<int32_t>(d_rows), n_rows, gk_ptr<int32_t>(d_rows_out), n_out);
   gk_pool_free(ctx,flag);
@@ -778,7 +689,7 @@ int gk_variant_count_range(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_r
   if (n_rows) {
     unsigned blocks = nblk(16 * n_rows);   // 16 lanes per row
     if (blocks > 1024) blocks = 1024;      // grid-stride: many rows per workgroup before the LDS flush (measured optimum)
-    GK_PROF(ctx, GK_K_COUNT_IDS,
+    GK_PROF(ctx, "count_ids",
             GK_KERNEL(count_ids, dim3(blocks), dim3(kThreads), (size_t)n_local * 8, ctx->stream,
                                gk_ptr<int32_t>(d_rows), n_rows, tab->d_off, tab->d_ids, gk_ptr<uint8_t>(d_vflag), cnt,
                                cnt + nv, vbeg, n_local));
@@ -793,7 +704,7 @@ int gk_variant_correct(gk_ctx* ctx, gk_tab* tab, gk_dptr d_cnt, gk_dptr d_vflag)
   const int64_t nv = (int64_t)tab->n_var + tab->n_novel;
   uint32_t* cnt = gk_ptr<uint32_t>(d_cnt);
   if (nv)
-    GK_PROF(ctx, GK_K_COUNT_IDS, GK_KERNEL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, ctx->stream, cnt, cnt + nv, nv,
+    GK_PROF(ctx, "apply_correction", GK_KERNEL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, ctx->stream, cnt, cnt + nv, nv,
                        gk_ptr<uint8_t>(d_vflag)));
   GK_HIP(hipGetLastError());
   return GK_OK;
@@ -1003,19 +914,19 @@ static int sample_prepare(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_
   uint8_t* vflag = gk_ptr<uint8_t>(d_vflag);
   for (int round = 0; round < rounds; ++round) {      // the exon model corrects its lists twice (typing_mulit_allele.py:644-645, 664)
     if (round) GK_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * nv) * sizeof(uint32_t), st));
-    GK_PROF(ctx, GK_K_COUNT_IDS,
+    GK_PROF(ctx, "count_ids_genes",
             GK_KERNEL(count_ids_genes, dim3((unsigned)n_wg), dim3(kThreads), (size_t)max_local * 8, st, part.d_rows,
                       (const int32_t*)d_tab, (const int64_t*)(d_tab + o_row0), (const int64_t*)(d_tab + o_row1),
                       tab->idx->d_gene_vbeg, max_local, tab->d_off, tab->d_ids, vflag, cnt, cnt + nv));
-    GK_PROF(ctx, GK_K_COUNT_IDS, GK_KERNEL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, st, cnt, cnt + nv, nv, vflag));
+    GK_PROF(ctx, "apply_correction", GK_KERNEL(apply_correction, dim3(nblk(nv)), dim3(kThreads), 0, st, cnt, cnt + nv, nv, vflag));
   }
   // rows with a surviving id, compacted in place of the grouping (stable: the groups stay contiguous and ordered)
   uint32_t *flag = nullptr, *kept = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&flag, (size_t)n_rows * sizeof(uint32_t)));
   GK_HIP(gk_pool_malloc(ctx, (void**)&kept, (size_t)n_gene * sizeof(uint32_t)));
-  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(flag_nonempty, dim3(nblk(n_rows)), dim3(kThreads), 0, st, part.d_rows, n_rows,
+  GK_PROF(ctx, "flag_nonempty", GK_KERNEL(flag_nonempty, dim3(nblk(n_rows)), dim3(kThreads), 0, st, part.d_rows, n_rows,
                                       tab->d_off, tab->d_ids, vflag, flag, kept, n_gene));
-  GK_PROF(ctx, GK_K_SELECT, GK_KERNEL(count_flags_per_gene, dim3((unsigned)n_gene, kFlagSlices), dim3(kThreads), 0, st, flag,
+  GK_PROF(ctx, "count_flags_per_gene", GK_KERNEL(count_flags_per_gene, dim3((unsigned)n_gene, kFlagSlices), dim3(kThreads), 0, st, flag,
                                       (const int64_t*)(d_tab + o_goff), kept));
   GK_HIP(hipGetLastError());
   // everything below is queued, then ONE wait: the compaction of the rows, the rows kept per gene, and -- when asked for --
@@ -1131,7 +1042,7 @@ int gk_compat_patch(gk_ctx* ctx, gk_lut* lut, gk_dptr d_log, int64_t n_rows, int
   if (n_rows == 0 || n_allele == 0) return GK_OK;
   const int64_t n = n_rows * (int64_t)n_allele;
   const int64_t want = (n + kThreads - 1) / kThreads;
-  GK_PROF(ctx, GK_K_COMPAT_PATCH,
+  GK_PROF(ctx, "patch_pending",
           GK_KERNEL(patch_pending, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(kThreads), 0, ctx->stream,
                     gk_ptr<double>(d_log), n_rows, n_allele, gk_lut_view(lut), gk_ptr<uint8_t>(d_miss8), ldm,
                     gk_ptr<uint32_t>(d_flags)));

@@ -610,7 +610,8 @@ class DeviceModel:
         value = np.empty(ids.shape[0], dtype=np.float64)
         frac = np.empty(ids.shape, dtype=np.float64)
         if self.dev.call_log is not None:
-            self.dev.call_log.append(("fraction_chunks", self.n_rows, ids.shape[0], ids.shape[1], len(np.unique(ids))))
+            self.dev.call_log.append(("setsum_leaves" if 2 <= ids.shape[1] <= 4 else "fraction_chunks", self.n_rows,
+                                      ids.shape[0], ids.shape[1], len(np.unique(ids))))
         check(lib().gk_setsum(self.dev.ctx, self.L.ptr, self.n_rows, self.n_rows, ids.ctypes.data, ids.shape[0],
                               ids.shape[1], value.ctypes.data, frac.ctypes.data))
         return value, frac
@@ -630,7 +631,8 @@ class DeviceModel:
             # the library runs the second allele of the search as a symmetric table (gk_search.hip: gk_maxsum)
             symmetric = bool(c_prev == 1 and n_sets == len(cols) and n_sets > 32 and
                              np.array_equal(np.sort(prev_ids.ravel()), np.sort(cols)) and len(np.unique(cols)) == n_sets)
-            self.dev.call_log.append(("maxsum_chunks", self.n_rows, n_sets, c_prev, len(cols), n_prev_cols, symmetric))
+            self.dev.call_log.append(("colsum_chunks" if ids_p is None and n_sets == 1 else "maxsum_chunks", self.n_rows,
+                                      n_sets, c_prev, len(cols), n_prev_cols, symmetric))
         check(lib().gk_maxsum(self.dev.ctx, self.L.ptr, self.n_rows, self.n_rows, ids_p, n_sets, c_prev,
                               cols.ctypes.data, len(cols), out.ctypes.data))
         return out

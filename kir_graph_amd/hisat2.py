@@ -269,6 +269,9 @@ class ParkedRecords:
         ptr, nbytes = C.c_uint64(), C.c_int64()
         check(lib().gk_mates_compact(self.dev.ctx, tab.mates.ptr, 2 * self.n_pairs, C.byref(ptr), C.byref(nbytes)))
         self.ptr, self.nbytes = ptr.value, int(nbytes.value)
+        # the records came from another context's pool (the copier's) and a pool orders reuse on its own stream only: the
+        # packing kernel on this stream must be through with them before the block can be handed out again
+        self.dev.sync()
         tab.mates.free()
         tab.mates = None
         tab.close()

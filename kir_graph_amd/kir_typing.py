@@ -34,13 +34,24 @@ def defaultDevice() -> Device:
     return _device
 
 
+_LOAD_LOCK = threading.Lock()
+
+
 def _sample(source, dev: Device | None) -> SampleData:
+    """A sample that is a hand-off file is uploaded (and tabulated) on ``dev`` or the process's default context.  A
+    context serves one host thread at a time and the typing lanes of a process (cohort.SampleTyper) all come here with
+    the same one, so the upload of one file at a time: the lock is held until the context's stream has drained."""
     if isinstance(source, SampleData):
         return source
-    if str(source).endswith(".npz"):     # compact side-format (hisat2.writeCompact)
-        from .hisat2 import loadCompact
-        return loadCompact(str(source), dev or defaultDevice())
-    return SampleData.fromHost(dev or defaultDevice(), loadReadsAndVariantsData(source))
+    dev = dev or defaultDevice()
+    with _LOAD_LOCK:
+        if str(source).endswith(".npz"):     # compact side-format (hisat2.writeCompact)
+            from .hisat2 import loadCompact
+            data = loadCompact(str(source), dev)
+        else:
+            data = SampleData.fromHost(dev, loadReadsAndVariantsData(source))
+        dev.sync()
+    return data
 
 
 class Typing:
@@ -401,7 +412,9 @@ class TypingWithPosNegAllele(_GenesInParallel):
             elif p.get("fallback"):
                 p["full_model"]._model._launchLog()                     # its table was left to a call that never came
                 res = p["full_model"].typing(cn)
-                self._result[gene] = p["full_model"].result
+                # the reference keeps the exon-first object's (failed) result here (kir_typing.py:126): no rows of this
+                # gene in .possible.tsv, the calls from the full model
+                self._result[gene] = p["typ_e"].result
                 alleles = [x if x != "fail" else f"{pure_gene}*" for x in res.selectBest()]
                 reads_num = p["typ_e"].getReadsNum()
             else:
@@ -612,6 +625,11 @@ class TypingWithReport(_GenesInParallel):
             if rc == -5:                    # GK_ERR_CAPACITY: a gene with a flood of distinct sets -- the per-gene calls size for it
                 return super().typing(gene_cn, min_reads_num)
             _lib.check(rc)
+            if tab.dev.call_log is not None:     # launch geometries for the roofline accounting (roofmodel.emSetsLaunch)
+                n_rows = sum(views[k].n_rows for k in live)
+                set_words = sum(views[k].n_rows * int(jobs[q].words) for q, k in enumerate(live))
+                tab.dev.call_log.append(("em_sets_groups", n_rows, tab.n_ids / max(tab.n_valid, 1) * n_rows, set_words))
+                tab.dev.call_log.append(("em_sets_verify", n_rows, 0, set_words))
             at = 0
             for q, k in enumerate(live):
                 names = views[k].alleles

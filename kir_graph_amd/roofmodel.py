@@ -102,6 +102,17 @@ def setsumLaunch(n_rows: int, n_sets: int, c: int, n_distinct: int) -> tuple[flo
     return 8.0 * n_rows * n_distinct + 8.0 * n_sets * (c + 1), float(n_rows) * n_sets * (c + 1)
 
 
+def emSetsLaunch(n_rows: int, n_ids: float, set_words: int) -> tuple[float, float]:
+    """candidate sets of the pairs of all genes of a sample (one launch): per pair its position (4 B), five list offsets
+    (20 B) and its ids (4 B each) read, its set (4 B per word) written; the bit rows come out of LDS."""
+    return 24.0 * n_rows + 4.0 * n_ids + 4.0 * set_words, 0.0
+
+
+def emVerifyLaunch(set_words: int) -> tuple[float, float]:
+    """every set read once more and compared with the first set of its hash (those come out of L2)."""
+    return 4.0 * set_words, 0.0
+
+
 def _priced(kernel: str, calls: list[tuple]) -> tuple[float, float, str, float]:
     """(bytes, ops, bound, ops peak) summed over the recorded launches of ``kernel``."""
     by = ops = 0.0
@@ -109,10 +120,13 @@ def _priced(kernel: str, calls: list[tuple]) -> tuple[float, float, str, float]:
     for c in calls:
         if kernel == "maxsum_chunks":
             b, o = maxsumLaunch(*c[1:7])
-            if c[2] == 1 and c[3] == 0:      # column sums (colsum_chunks): one add per element, a pure HBM stream
-                o = 0.0
-            else:
-                bound, peak = "valu", laneOpsPeak("maxsum_chunks")
+            bound, peak = "valu", laneOpsPeak("maxsum_chunks")
+        elif kernel == "colsum_chunks":      # column sums: one add per element, a pure HBM stream
+            b, o = 8.0 * c[1] * c[4] + 8.0 * c[4], 0.0
+        elif kernel == "em_sets_groups":
+            b, o = emSetsLaunch(*c[1:4])
+        elif kernel == "em_sets_verify":
+            b, o = emVerifyLaunch(c[3])
         elif kernel == "minsum_sad":
             b, o = minsumLaunch(*c[1:6])
             bound, peak = "valu", laneOpsPeak("minsum_sad")
@@ -121,7 +135,7 @@ def _priced(kernel: str, calls: list[tuple]) -> tuple[float, float, str, float]:
             bound, peak = "valu", laneOpsPeak("compat_kernel")
         elif kernel == "tab_count":
             b, o = tabLaunch(*c[1:4])
-        elif kernel in ("fraction_chunks", "setsum_chunks"):
+        elif kernel in ("fraction_chunks", "setsum_leaves"):
             b, o = setsumLaunch(*c[1:5])
         else:
             return 0.0, 0.0, "hbm", 0.0

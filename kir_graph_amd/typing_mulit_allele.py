@@ -553,12 +553,12 @@ class AlleleTyping:
             raw = np.empty(n_log.value, dtype=np.int64)
             check(lib().gk_search_log(h, raw.ctypes.data, len(raw), C.byref(n_log)))
             for kind, a, b, c_, d, e, f in raw.reshape(-1, 7).tolist():
-                if kind == 0:
-                    m.dev.call_log.append(("maxsum_chunks", a, b, c_, d, e, bool(f)))
+                if kind == 0:      # column sums are a launch of their own kernel (no previous sets, one "set")
+                    m.dev.call_log.append(("colsum_chunks" if b == 1 and c_ == 0 else "maxsum_chunks", a, b, c_, d, e, bool(f)))
                 elif kind == 1:
                     m.dev.call_log.append(("minsum_sad", a, b, c_, d, False))
                 else:
-                    m.dev.call_log.append(("fraction_chunks", a, b, c_, d))
+                    m.dev.call_log.append(("setsum_leaves" if kind == 3 else "fraction_chunks", a, b, c_, d))
 
     def geneJob(self, cn: int, verdict: bool | None = None):
         """(``_lib.GeneJob`` for ``gk_sample_search``, homozygous?) of a model built with ``_defer_launch``: the

@@ -25,7 +25,7 @@ def test_without_a_launcher_the_ranks_are_started_and_a_dead_rank_fails_the_run(
     """`python bench.py --gpus 2` starts two rank processes itself; here they find no GPU and exit, and the
     parent reports the failure instead of printing a line for fewer ranks."""
     res = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--pairs", "2000", "--cpu-pairs", "0"],
-               {"GK_PROCS_PER_GPU": "1"})
+               {})
     assert res.returncode == 1
     assert "rank exit codes" in res.stderr and "fewer than 2 ranks finished" in res.stderr
     assert not res.stdout.strip()

@@ -301,7 +301,7 @@ def test_purge_only_removes_the_keys_of_dead_launches(tmp_path):
     gone = subprocess.Popen([sys.executable, "-c", "pass"])
     gone.wait()
     dead = comm.FileStore(str(d), token="dead22")
-    dead.set("owner", str(gone.pid).encode())       # a launch whose rank 0 has exited
+    dead.set("owner", f"{gone.pid} {comm._hostIdentity()}".encode())       # a launch whose rank 0 has exited
     dead.set("x0.r0", b"old")
     dead.set("abort", b"why")
     (d / "notes.txt").write_text("not a key of this package")
@@ -315,3 +315,35 @@ def test_purge_only_removes_the_keys_of_dead_launches(tmp_path):
     assert removed == 3 and not any(n.startswith("dead22.") for n in left)
     assert {"alive1.x3.r1", "alive1.rccl_ok.r0", "alive1.owner", "notes.txt", "orphan9.x1.r0"} <= set(left)
     assert alive.get("x3.r1") == b"payload"
+
+
+def test_purge_trusts_a_pid_only_on_its_own_host(tmp_path):
+    """The directory may be shared between nodes or containers: a pid of another host / pid namespace says nothing
+    here, so such a launch's keys go by age alone; and a pid that exists protects keys for a day, not for ever (the
+    number may have been handed to another process)."""
+    import time
+    from kir_graph_amd import comm
+    d = tmp_path / "rdzv"
+    gone = subprocess.Popen([sys.executable, "-c", "pass"])
+    gone.wait()
+    far = comm.FileStore(str(d), token="far001")              # a LIVE launch on another node: its pid does not exist here
+    far.set("owner", f"{gone.pid} othernode pid:[4026531836]".encode())
+    far.set("rccl_id", b"id")
+    far.set("x2.r1", b"fresh")
+    legacy = comm.FileStore(str(d), token="old002")           # an owner key without an identity (an older launch)
+    legacy.set("owner", str(gone.pid).encode())
+    legacy.set("x0.r0", b"fresh")
+    stale = comm.FileStore(str(d), token="far003")            # another node's launch, silent for an hour
+    stale.set("owner", f"{gone.pid} othernode pid:[4026531836]".encode())
+    stale.set("x9.r0", b"old")
+    reused = comm.FileStore(str(d), token="pid004")           # this process's pid, keys untouched for two days
+    reused.claim()
+    reused.set("x1.r0", b"ancient")
+    now = time.time()
+    for name, age in (("far003.owner", 3600), ("far003.x9.r0", 3600), ("pid004.owner", 2 * 86400), ("pid004.x1.r0", 2 * 86400)):
+        os.utime(d / name, (now - age, now - age))
+    removed = comm.FileStore(str(d), token="mine05", timeout=60.0).purgeOthers()
+    left = {p.name for p in d.iterdir()}
+    assert removed == 4
+    assert {"far001.owner", "far001.rccl_id", "far001.x2.r1", "old002.owner", "old002.x0.r0"} <= left
+    assert not any(n.startswith(("far003.", "pid004.")) for n in left)

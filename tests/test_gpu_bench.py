@@ -51,11 +51,32 @@ def test_one_gpu_line_keeps_the_contract(device):
     assert d["search_steps"]["bounded"] > 0
 
 
-def test_steps_from_hbm_and_two_worker_processes(device):
+def test_steps_from_hbm_only(device):
     d = _run(["--steps", "4", "--warmup", "2", "--pairs", "20000", "--cpu-pairs", "0", "--serial-steps", "0", "--inputs", "hbm",
-              "--one-kind", "--legs", "1"], env={"GK_PROCS_PER_GPU": "2"})
+              "--one-kind", "--legs", "1"])
     assert d["config"]["inputs"] == "hbm" and "pcie_inclusive" not in d and "hbm_resident" not in d and len(d["legs"]) == 1
-    assert d["host"]["worker_processes"] == 2 and d["host"]["sample_lanes"] == 2 and d["value"] > 0
+    assert d["host"]["worker_processes"] == 1 and d["value"] > 0
+
+
+def test_default_run_reports_the_three_workloads(device):
+    """Without --pairs / --method the line is configs[2] exon-first with `em` and `configs1_pv` beside it, each with its
+    own legs, serial kernel table, roofline and CPU baseline (here at 1 / 500 of the sizes: the structure, not the
+    numbers; the names of the kernels are their own, so the EM kernels and the set sums show under them)."""
+    d = _run(["--steps", "3", "--warmup", "1", "--cpu-pairs", "5000", "--serial-steps", "1", "--legs", "1", "--cli-samples", "0"],
+             env={"GK_BENCH_PAIRS_SCALE": "0.002"}, timeout=900)
+    assert d["config"]["allele_strategy"] == "exonfirst" and d["config"]["pairs_per_sample"] == 20000
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port"
+    for name, method, pairs in (("em", "em", 20000), ("configs1_pv", "pv", 2000)):
+        o = d[name]
+        assert o["workload"] == name and o["config"]["allele_strategy"] == method and o["config"]["pairs_per_sample"] == pairs
+        assert o["value"] > 0 and o["unit"] == "reads/s" and len(o["legs"]) == 1
+        assert o["kernels_serial"]["kernels"] and o["roofline"]["kernel"] in o["kernels_serial"]["kernels"]
+        assert o["cpu_baseline"]["value"] > 0 and o["cpu_baseline"]["cores"] == 1
+    em_kernels = d["em"]["kernels_serial"]["kernels"]
+    assert {"em_sets_groups", "em_sets_verify", "em_sets_emit", "em_kernel_genes"} <= set(em_kernels)
+    assert "compat_kernel" in d["kernels_serial"]["kernels"] and "compat_kernel" not in em_kernels
+    # kernels are timed under their own names: no collective labels left
+    assert not {"select_cut", "select", "scan", "count_ids"} & set(d["kernels_serial"]["kernels"])
 
 
 def test_two_ranks_on_one_gpu_through_the_file_backend(device):
@@ -71,8 +92,8 @@ def test_cli_typing_stage_keeps_pace_with_the_bench(device):
     (cohort.SampleTyper), so the CLI may cost at most 1.3 x the measured step."""
     # three lanes for both: with five (the default where a rank has six cores or more) the fill and drain of the pipeline
     # are a third of a 12-sample run, which says nothing about the code path
-    d = _run(["--steps", "12", "--warmup", "4", "--distinct", "4", "--cpu-pairs", "0", "--serial-steps", "0", "--legs", "1",
-              "--cli-samples", "12"], env={"GK_SAMPLE_LANES": "3", "GK_SEARCH_SLOTS": "2"}, timeout=900)
+    d = _run(["--steps", "12", "--warmup", "4", "--pairs", "1000000", "--method", "pv", "--distinct", "4", "--cpu-pairs", "0",
+              "--serial-steps", "0", "--legs", "1", "--cli-samples", "12"], env={"GK_SAMPLE_LANES": "3", "GK_SEARCH_SLOTS": "2"}, timeout=900)
     c = d["cli_typing_stage"]
     assert c["samples"] == 12 and c["ms_per_sample"] > 0
     assert c["ms_per_sample"] <= 1.3 * d["ms_per_step"], (c["ms_per_sample"], d["ms_per_step"])

@@ -1113,7 +1113,8 @@ def test_pipeline_defaults_follow_the_cores_of_the_rank(monkeypatch):
     """cohort.pipelineDefaults: sample lanes x searches at a time by the host cores a rank has (the affinity, shared by the
     ranks of the node unless the rank was pinned to cores of its own); whatever the user set stays."""
     from kir_graph_amd import cohort
-    for name in ("GK_SAMPLE_LANES", "GK_SEARCH_SLOTS", "GK_WAIT_POLICY", "GK_URGENT_PREAMBLE", "WORLD_SIZE", "LOCAL_WORLD_SIZE"):
+    for name in ("GK_SAMPLE_LANES", "GK_SEARCH_SLOTS", "GK_WAIT_POLICY", "GK_URGENT_PREAMBLE", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
+                 "GK_PRIVATE_CORES"):
         monkeypatch.delenv(name, raising=False)
     monkeypatch.setattr(os, "cpu_count", lambda: 64)
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
@@ -1123,7 +1124,11 @@ def test_pipeline_defaults_follow_the_cores_of_the_rank(monkeypatch):
     assert cohort.hostCoresPerRank() == max(1, quota // 8)
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")         # two nodes of four ranks
     assert cohort.hostCoresPerRank() == max(1, quota // 4)
-    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {0, 1, 2}, raising=False)   # pinned: cores of its own
+    monkeypatch.delenv("GK_PRIVATE_CORES", raising=False)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)), raising=False)   # a cpuset of the NODE: shared
+    assert cohort.hostCoresPerRank() == max(1, min(16, quota) // 4)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {0, 1, 2}, raising=False)
+    monkeypatch.setenv("GK_PRIVATE_CORES", "1")         # pinned by the launcher: cores of its own
     assert cohort.hostCoresPerRank() == min(3, quota)
     for cores, want in ((16, ("5", "3")), (6, ("5", "3")), (4, ("4", "2")), (3, ("4", "2")), (2, ("3", "2"))):
         monkeypatch.delenv("GK_SAMPLE_LANES", raising=False)
