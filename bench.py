@@ -235,7 +235,7 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
             stats["samples_repeated_pass"] = stats.get("samples_repeated_pass", 0) + (1 if again else 0)
             stats["tables_rewritten"] = stats.get("tables_rewritten", 0) + getattr(typer, "tables_rewritten", 0)
             stats["tables_patched"] = stats.get("tables_patched", 0) + getattr(typer, "tables_patched", 0)
-        return calls, warn, n_valid, typer
+        return calls, warn, n_valid, None        # the typer (and the tables of its genes) ends with its lane's turn
 
     items = range(items) if isinstance(items, int) else items
     staged = cohort.stagedSamples(items, None if resident is not None else copy_in, tabulate, depth=depth)

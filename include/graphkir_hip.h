@@ -112,6 +112,9 @@ int gk_ctx_create(int device, gk_ctx** out);
 int gk_ctx_create_priority(int device, int urgent, gk_ctx** out);
 int gk_ctx_destroy(gk_ctx* ctx);
 int gk_sync(gk_ctx* ctx);
+/* device memory as the runtime reports it (free, total) and the bytes the pools of this process's contexts hold idle;
+ * cohort.SampleTyper admits samples by it (the reference holds one sample at a time, main.py:171-220) */
+int gk_device_memory(gk_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes, int64_t* pool_cached_bytes);
 int gk_malloc(gk_ctx* ctx, size_t bytes, gk_dptr* out);
 int gk_free(gk_ctx* ctx, gk_dptr p);
 int gk_memset(gk_ctx* ctx, gk_dptr p, int value, size_t bytes);
@@ -374,6 +377,12 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
 int gk_search_steps(gk_search* s, int32_t* n_steps);
 int gk_search_info(gk_search* s, int32_t step, int32_t* n, int64_t* rows, int32_t* bounded);
 int gk_search_copy(gk_search* s, int32_t step, double* value, double* sum_indv, int32_t* ids, double* frac);
+/* every step of many searches in one call (the candidate searches of exon-first, typing_mulit_allele.py:740-797, are
+ * adopted by the hundred): totals[3] = steps, rows, cells (rows x set size) over the listed searches; with the arrays
+ * given, meta = [steps of search 0 .. n - 1 | per step (set size, rows, bounded)] and value [rows], sum_indv / frac / ids
+ * [cells] hold the rows of the steps back to back in (search, step) order (gk_search_copy's columns) */
+int gk_search_export(gk_search* const* s, int32_t n, int64_t* totals, int64_t* meta, double* value, double* sum_indv,
+                     double* frac, int32_t* ids);
 int gk_search_colsum(gk_search* s, double* out);
 /* launch geometries of the run, 7 int64 per device call: kind (0 gk_maxsum, 1 gk_bound_step, 2 gk_setsum /
  * gk_fraction) and the arguments of the roofline model (kir_graph_amd/roofmodel.py) */

@@ -91,6 +91,7 @@ _SIGS = {
     "gk_ctx_create_priority": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "gk_ctx_destroy": (C.c_int, [C.c_void_p]),
     "gk_sync": (C.c_int, [C.c_void_p]),
+    "gk_device_memory": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gk_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "gk_free": (C.c_int, [C.c_void_p, C.c_uint64]),
     "gk_memset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_size_t]),
@@ -215,6 +216,7 @@ _SIGS = {
     "gk_search_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                  C.POINTER(C.c_int32)]),
     "gk_search_copy": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gk_search_export": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gk_search_colsum": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gk_search_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "gk_search_destroy": (C.c_int, [C.c_void_p]),
@@ -422,6 +424,12 @@ class Device:
 
     def sync(self) -> None:
         check(lib().gk_sync(self.ctx))
+
+    def memory(self) -> tuple[int, int, int]:
+        """(free, total) bytes of the device as the runtime reports them, bytes this process's pools hold idle."""
+        f, t, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib().gk_device_memory(self.ctx, C.byref(f), C.byref(t), C.byref(c)))
+        return int(f.value), int(t.value), int(c.value)
 
     def timerStart(self) -> None:
         check(lib().gk_timer_start(self.ctx))

@@ -149,6 +149,42 @@ def stagedSamples(items, copy_in, tabulate, depth: int | None = None, copy_ahead
         yield from prefetched(items, lambda item: tabulate(copy_in(item)), depth=depth)
 
 
+def sampleFootprint(data, method: str) -> int:
+    """Bytes of HBM the typing of a tabulated sample holds at its peak, estimated before it starts: the compatibility
+    tables of its genes (a float64 and a mismatch byte per read and allele; twice for exon-first, whose exon model's tables
+    stand beside the full ones; candidate bit sets only for the EM), its lists and its records.  0 for a sample that is
+    still a file."""
+    tab = getattr(data, "tab", None)
+    if tab is None:
+        return 0
+    tables = getattr(data.index, "tables", None) or []
+    mean_alleles = sum(t.n_allele for t in tables) / max(len(tables), 1)
+    n = int(tab.n_valid)
+    if method in ("em", "report"):
+        per_read = 4.0 * (mean_alleles / 32 + 1) + 16
+    else:
+        per_read = 9.2 * mean_alleles * (2 if method.startswith(("exonfirst", "pv_exonfirst")) else 1)
+    lists = 4.0 * int(tab.n_ids) + 48.0 * n
+    records = 256.0 * int(tab.n_pairs) if getattr(tab, "mates", None) is not None else 0.0
+    return int(1.15 * per_read * n + lists + records)
+
+
+def hbmBudget(dev=None) -> int:
+    """Bytes of HBM the samples in flight of this process may hold together (``sampleFootprint``): GK_HBM_BUDGET_GB, else
+    55 % of the device -- the rest is for the samples staged ahead, the blocks the pools keep idle and the ranks that may
+    share the card."""
+    env = os.environ.get("GK_HBM_BUDGET_GB")
+    if env:
+        return int(float(env) * (1 << 30))
+    try:
+        if dev is None:
+            from .kir_typing import defaultDevice
+            dev = defaultDevice()
+        return int(0.55 * dev.memory()[1])
+    except Exception:
+        return 0                  # unknown: no admission control
+
+
 class SampleTyper:
     """The typing stage of one process: ``submit`` hands a tabulated sample to one of ``lanes`` host threads (each
     with its own block of device contexts: ``typer.slot_base``), results come back in submission order.
@@ -174,6 +210,31 @@ class SampleTyper:
         for lane in range(self.lanes):
             self._free.put(lane)
         self._pending: list = []
+        # admission by memory: a sample starts when the samples in flight leave room for it (one sample always may) --
+        # the lanes follow the host cores, but five 20 M-read samples typed exon-first do not fit one card
+        import threading
+        self._room = threading.Condition()
+        self._inflight_bytes, self._budget = 0, None
+
+    def _admit(self, data) -> int:
+        need = sampleFootprint(data, self.method)
+        if need <= 0 or self._pool is None:
+            return 0
+        if self._budget is None:
+            self._budget = hbmBudget(getattr(getattr(data, "tab", None), "dev", None))
+        if self._budget <= 0:
+            return 0
+        with self._room:
+            while self._inflight_bytes > 0 and self._inflight_bytes + need > self._budget:
+                self._room.wait(timeout=1.0)
+            self._inflight_bytes += need
+        return need
+
+    def _release(self, need: int) -> None:
+        if need:
+            with self._room:
+                self._inflight_bytes -= need
+                self._room.notify_all()
 
     def typeOne(self, data, gene_cn, item=None, lane: int = 0):
         """One sample on the calling thread, on lane ``lane``'s contexts."""
@@ -185,19 +246,20 @@ class SampleTyper:
             return self.finish(typer, calls, warnings, item)
         return calls, warnings, typer
 
-    def _run(self, data, gene_cn, item):
+    def _run(self, data, gene_cn, item, need: int = 0):
         lane = self._free.get()
         try:
             return self.typeOne(data, gene_cn, item, lane)
         finally:
             self._free.put(lane)
+            self._release(need)
 
     def submit(self, data, gene_cn, item=None) -> None:
         """Queue a sample (``gene_cn``: the copy numbers, or a callable that returns them on the lane's thread)."""
         if self._pool is None:
             self._pending.append(_Done(self.typeOne(data, gene_cn, item, 0)))
         else:
-            self._pending.append(self._pool.submit(self._run, data, gene_cn, item))
+            self._pending.append(self._pool.submit(self._run, data, gene_cn, item, self._admit(data)))
 
     def inFlight(self) -> int:
         return len(self._pending)

@@ -1145,6 +1145,36 @@ int gk_search_copy(gk_search* s, int32_t step, double* value, double* sum_indv, 
   return GK_OK;
 }
 
+/* Every step of MANY searches in one call (exon-first adopts hundreds of candidate searches per sample: a call per search
+ * and step was a third of the typing's host time).  totals[3] = steps, rows, cells (rows x set size) over all listed
+ * searches; with the arrays given: meta = [steps of search 0 .. n - 1 | per step (set size, rows, bounded)] and the rows of
+ * the steps back to back in (search, step) order. */
+int gk_search_export(gk_search* const* s, int32_t n, int64_t* totals, int64_t* meta, double* value, double* sum_indv,
+                     double* frac, int32_t* ids) {
+  GK_REQUIRE(s && n >= 0 && totals, "null pointer");
+  int64_t steps = 0, rows = 0, cells = 0;
+  for (int q = 0; q < n; ++q) {
+    GK_REQUIRE(s[q], "null search");
+    for (const Step& st : s[q]->steps) { ++steps; rows += st.rows(); cells += st.rows() * st.n; }
+  }
+  totals[0] = steps; totals[1] = rows; totals[2] = cells;
+  if (!meta) return GK_OK;
+  GK_REQUIRE(value && sum_indv && frac && ids, "null pointer");
+  int64_t* triple = meta + n;
+  for (int q = 0; q < n; ++q) {
+    meta[q] = (int64_t)s[q]->steps.size();
+    for (const Step& st : s[q]->steps) {
+      triple[0] = st.n; triple[1] = st.rows(); triple[2] = st.bounded;
+      triple += 3;
+      value = std::copy(st.value.begin(), st.value.end(), value);
+      sum_indv = std::copy(st.sum_indv.begin(), st.sum_indv.end(), sum_indv);
+      frac = std::copy(st.frac.begin(), st.frac.end(), frac);
+      ids = std::copy(st.ids.begin(), st.ids.end(), ids);
+    }
+  }
+  return GK_OK;
+}
+
 int gk_search_colsum(gk_search* s, double* out) {
   GK_REQUIRE(s && out, "null pointer");
   std::copy(s->colsum.begin(), s->colsum.end(), out);

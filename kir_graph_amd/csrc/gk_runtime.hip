@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <atomic>
 #include <mutex>
 #include <cstring>
 #include <string>
@@ -11,6 +12,15 @@
 #include "gk_common.h"
 
 static thread_local char g_err[512] = "";
+
+// every context of the process (their pools are flushed together when the device runs out of memory) and the bytes their
+// pools hold idle
+static std::mutex g_ctx_mutex;
+static std::vector<gk_ctx*>& all_contexts() {
+  static std::vector<gk_ctx*> v;
+  return v;
+}
+static std::atomic<size_t> g_pool_cached{0};
 
 void gk_set_error(const char* fmt, ...) {
   va_list ap;
@@ -72,6 +82,10 @@ int gk_ctx_create_priority(int device, int urgent, gk_ctx** out) {
   }
   GK_HIP(hipEventCreate(&ctx->ev0));
   GK_HIP(hipEventCreate(&ctx->ev1));
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    all_contexts().push_back(ctx);
+  }
   *out = ctx;
   return GK_OK;
 }
@@ -81,6 +95,12 @@ int gk_ctx_destroy(gk_ctx* ctx) {
   if (!ctx) return GK_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    auto& v = all_contexts();
+    v.erase(std::remove(v.begin(), v.end(), ctx), v.end());
+  }
+  g_pool_cached -= ctx->pool_cached_bytes;
   for (auto& kv : ctx->pool_free) hipFree(kv.second);
   for (auto& kv : ctx->pool_live) hipFree(kv.first);
   if (ctx->scratch) hipFree(ctx->scratch);
@@ -324,51 +344,103 @@ static size_t pool_class(size_t bytes) {
   return (bytes + step - 1) / step * step;
 }
 
+// the idle blocks of one context back to the device (its stream drained first: a cached block may still be read by work
+// queued before it was freed); the caller holds no pool lock
+static size_t flush_pool(gk_ctx* c) {
+  std::lock_guard<std::mutex> lock(c->pool_mutex);
+  if (c->pool_free.empty()) return 0;
+  hipStreamSynchronize(c->stream);
+  const size_t bytes = c->pool_cached_bytes;
+  for (auto& kv : c->pool_free) hipFree(kv.second);
+  c->pool_free.clear();
+  c->pool_cached_bytes = 0;
+  g_pool_cached -= bytes;
+  return bytes;
+}
+
+// idle blocks a process may keep across all its contexts (GK_POOL_CACHE_GB, default 48): beyond it a context that frees
+// a block gives its whole cache back.  The lanes of a process keep blocks of the sizes their samples had; samples of a
+// cohort differ in size, and what one lane's pool holds idle no other lane can use.
+static size_t pool_cache_limit() {
+  static const size_t v = [] {
+    const char* e = getenv("GK_POOL_CACHE_GB");
+    const double gb = e ? atof(e) : 48.0;
+    return (size_t)(std::max(gb, 0.0) * (double)(1ull << 30));
+  }();
+  return v;
+}
+
 hipError_t gk_pool_malloc(gk_ctx* ctx, void** out, size_t bytes) {
-  std::lock_guard<std::mutex> lock(ctx->pool_mutex);
   const size_t cls = pool_class(bytes);
-  // the smallest cached block that holds the request, if it is not more than a quarter too large
-  auto it = ctx->pool_free.lower_bound(cls);
-  if (it != ctx->pool_free.end() && it->first <= cls + cls / 4) {
-    const size_t have = it->first;
-    *out = it->second;
-    ctx->pool_free.erase(it);
-    ctx->pool_cached_bytes -= have;
-    ctx->pool_live[*out] = have;
-    return hipSuccess;
-  }
   static const bool trace = getenv("GK_POOL_TRACE") != nullptr;      // dev: every large pool miss and what it costs
-  const auto t0 = std::chrono::steady_clock::now();
-  hipError_t e = hipMalloc(out, cls);
-  if (trace && cls >= ((size_t)32 << 20))
-    fprintf(stderr, "[gk_pool] ctx %p: hipMalloc of %zu MB took %.0f us (cached %zu MB in %zu blocks)\n", (void*)ctx, cls >> 20,
-            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(),
-            ctx->pool_cached_bytes >> 20, ctx->pool_free.size());
-  if (e != hipSuccess && ctx->pool_cached_bytes) {   // give the cache back and retry once
-    if (trace) fprintf(stderr, "[gk_pool] ctx %p: hipMalloc of %zu MB FAILED, flushing %zu MB of cached blocks\n", (void*)ctx,
-                       cls >> 20, ctx->pool_cached_bytes >> 20);
-    hipStreamSynchronize(ctx->stream);
-    for (auto& kv : ctx->pool_free) hipFree(kv.second);
-    ctx->pool_free.clear();
-    ctx->pool_cached_bytes = 0;
-    e = hipMalloc(out, cls);
+  {
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    // the smallest cached block that holds the request, if it is not more than a quarter too large
+    auto it = ctx->pool_free.lower_bound(cls);
+    if (it != ctx->pool_free.end() && it->first <= cls + cls / 4) {
+      const size_t have = it->first;
+      *out = it->second;
+      ctx->pool_free.erase(it);
+      ctx->pool_cached_bytes -= have;
+      g_pool_cached -= have;
+      ctx->pool_live[*out] = have;
+      return hipSuccess;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e = hipMalloc(out, cls);
+    if (trace && cls >= ((size_t)32 << 20))
+      fprintf(stderr, "[gk_pool] ctx %p: hipMalloc of %zu MB took %.0f us (cached %zu MB in %zu blocks, %zu MB in all pools)\n",
+              (void*)ctx, cls >> 20, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(),
+              ctx->pool_cached_bytes >> 20, ctx->pool_free.size(), g_pool_cached.load() >> 20);
+    if (e == hipSuccess) {
+      ctx->pool_live[*out] = cls;
+      return e;
+    }
+    (void)hipGetLastError();
   }
+  // out of device memory: the idle blocks of EVERY context of the process go back, then once more
+  size_t given = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    for (gk_ctx* c : all_contexts())
+      if (c->device == ctx->device) given += flush_pool(c);
+  }
+  if (trace) fprintf(stderr, "[gk_pool] ctx %p: hipMalloc of %zu MB FAILED, %zu MB of cached blocks of all contexts given back\n",
+                     (void*)ctx, cls >> 20, given >> 20);
+  std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+  hipError_t e = hipMalloc(out, cls);
   if (e == hipSuccess) ctx->pool_live[*out] = cls;
   return e;
 }
 
 void gk_pool_free(gk_ctx* ctx, void* p) {
   if (!p) return;
-  std::lock_guard<std::mutex> lock(ctx->pool_mutex);
-  auto it = ctx->pool_live.find(p);
-  if (it == ctx->pool_live.end()) {   // not ours
-    hipFree(p);
-    return;
+  bool over = false;
+  {
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    auto it = ctx->pool_live.find(p);
+    if (it == ctx->pool_live.end()) {   // not ours
+      hipFree(p);
+      return;
+    }
+    const size_t cls = it->second;
+    ctx->pool_live.erase(it);
+    ctx->pool_free.emplace(cls, p);
+    ctx->pool_cached_bytes += cls;
+    over = (g_pool_cached += cls) > pool_cache_limit();
   }
-  const size_t cls = it->second;
-  ctx->pool_live.erase(it);
-  ctx->pool_free.emplace(cls, p);
-  ctx->pool_cached_bytes += cls;
+  if (over) flush_pool(ctx);
+}
+
+extern "C" int gk_device_memory(gk_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes, int64_t* pool_cached_bytes) {
+  gk_bind(ctx);
+  GK_REQUIRE(ctx && free_bytes && total_bytes, "null pointer");
+  size_t f = 0, t = 0;
+  GK_HIP(hipMemGetInfo(&f, &t));
+  *free_bytes = (int64_t)f;
+  *total_bytes = (int64_t)t;
+  if (pool_cached_bytes) *pool_cached_bytes = (int64_t)g_pool_cached.load();
+  return GK_OK;
 }
 
 static thread_local gk_ctx::ProfSpan* t_span = nullptr;   // span whose events the next GK_KERNEL launch takes

@@ -19,7 +19,7 @@ import numpy as np
 from ._lib import Device
 from .hisat2 import SampleData, loadReadsAndVariantsData
 from .typing_em import Hisat2AlleleResult, hisat2TypingPerGene
-from .typing_mulit_allele import (AlleleTyping, AlleleTypingExonFirst, ReadSet, isHetrozygous,
+from .typing_mulit_allele import (AlleleTyping, AlleleTypingExonFirst, ReadSet, StepList, isHetrozygous,
                                   sharedLogTable)
 from .utils import NumpyEncoder, logger
 
@@ -76,7 +76,7 @@ class Typing:
 
     def save(self, filename: str) -> None:
         with open(filename, "w") as f:
-            json.dump(self._result, f, cls=NumpyEncoder)
+            json.dump({gene: list(steps) for gene, steps in self._result.items()}, f, cls=NumpyEncoder)
 
     def getAllPossibleTyping(self) -> list[dict[Any, Any]]:
         raise NotImplementedError
@@ -389,15 +389,10 @@ class TypingWithPosNegAllele(_GenesInParallel):
                     full.adoptTable(jobs[q], C.c_void_p(handles[q]))
                     self.tables_rewritten += max(0, int(jobs[q].passes) - 1)
                     self.tables_patched += int(jobs[q].patches)
-                    finals, results = [], list(p["typ_e"].result)
-                    for qc, n_steps in p["cands"]:
-                        model = full.fork()
-                        model._adoptSearch(C.c_void_p(handles[qc]), n_steps)
-                        results.extend(model.result)
-                        finals.append(model.result[-1])
-                    merged = AlleleTypingExonFirst.mergeCandidates(finals)
-                    results.append(merged)
+                    steps = full.adoptSearches([handles[qc] for qc, _ in p["cands"]])
+                    merged = steps.lastSteps().sortByScoreAndEveness()          # mergeCandidates (783-793)
                     merged.print()
+                    results = StepList(p["typ_e"].result, steps, [merged])
                     p["results"], p["final"] = results, merged
             finally:
                 destroy(handles)

@@ -155,6 +155,92 @@ class _GroupRows:
         return list(self) == list(other)
 
 
+class SearchSteps:
+    """The steps of many native searches on one table (``AlleleTyping.adoptSearches``) as a sequence of ``TypingResult`` in
+    (search, step) order; a step is built from the packed columns when it is read."""
+
+    def __init__(self, typing, steps_of: np.ndarray, meta: np.ndarray, value, sum_indv, frac, ids):
+        self._typing = typing
+        self.steps_of = steps_of                                   # steps per search
+        self.set_size, self.rows, self.bounded = meta[:, 0], meta[:, 1], meta[:, 2]
+        self._value, self._sum_indv, self._frac, self._ids = value, sum_indv, frac, ids
+        self.row0 = np.concatenate([[0], np.cumsum(self.rows)])
+        self.cell0 = np.concatenate([[0], np.cumsum(self.rows * self.set_size)])
+        self.first_step = np.concatenate([[0], np.cumsum(steps_of)])          # of search q: its steps are first_step[q] ..
+        self.step_in_search = np.arange(len(self.rows)) - np.repeat(self.first_step[:-1], steps_of)
+        self._made: dict[int, TypingResult] = {}
+
+    def __len__(self) -> int:
+        return len(self.rows)
+
+    def __getitem__(self, j):
+        if isinstance(j, slice):
+            return [self[k] for k in range(*j.indices(len(self)))]
+        if j < 0:
+            j += len(self)
+        got = self._made.get(j)
+        if got is None:
+            t = self._typing
+            k, c = int(self.rows[j]), int(self.set_size[j])
+            r0, c0 = int(self.row0[j]), int(self.cell0[j])
+            ids = self._ids[c0:c0 + k * c].reshape(k, c)
+            frac = self._frac[c0:c0 + k * c].reshape(k, c)
+            got = self._made[j] = TypingResult(
+                n=c, value=self._value[r0:r0 + k], value_sum_indv=self._sum_indv[c0:c0 + k * c].reshape(k, c), allele_id=ids,
+                allele_name=LazyNames(ids, t.id_to_allele), allele_prob=LazyAlleleProb([(t._model, ids)]),
+                fraction=frac if self.step_in_search[j] else np.ones(ids.shape), fraction_uniq=np.ones(ids.shape))
+        return got
+
+    def __iter__(self):
+        return (self[j] for j in range(len(self)))
+
+    def lastSteps(self) -> "TypingResult":
+        """The last steps of all searches as ONE result, rows in search order (what ``mergeCandidates`` concatenates)."""
+        last = self.first_step[1:] - 1
+        c = int(self.set_size[last[0]])
+        assert np.all(self.set_size[last] == c)
+        k = self.rows[last]
+        within = np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k)
+        rows = np.repeat(self.row0[last], k) + within
+        cells = (np.repeat(self.cell0[last], k) + within * c)[:, None] + np.arange(c)[None, :]
+        ids, t = self._ids[cells], self._typing
+        return TypingResult(n=c, value=self._value[rows], value_sum_indv=self._sum_indv[cells], allele_id=ids,
+                            allele_name=LazyNames(ids, t.id_to_allele), allele_prob=LazyAlleleProb([(t._model, ids)]),
+                            fraction=self._frac[cells], fraction_uniq=self._frac[cells])
+
+
+class StepList:
+    """``result`` of a gene typed exon-first: the exon model's steps, the steps of every candidate search (built when
+    read), the merged final result -- a sequence like the reference's list (typing_mulit_allele.py:776-796)."""
+
+    def __init__(self, head: list, steps: SearchSteps, tail: list):
+        self._head, self._steps, self._tail = list(head), steps, list(tail)
+
+    def __len__(self) -> int:
+        return len(self._head) + len(self._steps) + len(self._tail)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        if i < len(self._head):
+            return self._head[i]
+        i -= len(self._head)
+        if i < len(self._steps):
+            return self._steps[i]
+        return self._tail[i - len(self._steps)]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __bool__(self) -> bool:
+        return len(self) > 0
+
+
 class LazyAlleleProb:
     """``allele_prob`` (reads x sets) evaluated on the device only when it is read."""
 
@@ -548,17 +634,51 @@ class AlleleTyping:
                 allele_name=LazyNames(ids, self.id_to_allele), allele_prob=LazyAlleleProb([(m, ids)]),
                 fraction=frac if step else np.ones(ids.shape), fraction_uniq=np.ones(ids.shape)))
         if m.dev.call_log is not None:
-            n_log = C.c_int64()
-            check(lib().gk_search_log(h, None, 0, C.byref(n_log)))
-            raw = np.empty(n_log.value, dtype=np.int64)
-            check(lib().gk_search_log(h, raw.ctypes.data, len(raw), C.byref(n_log)))
-            for kind, a, b, c_, d, e, f in raw.reshape(-1, 7).tolist():
-                if kind == 0:      # column sums are a launch of their own kernel (no previous sets, one "set")
-                    m.dev.call_log.append(("colsum_chunks" if b == 1 and c_ == 0 else "maxsum_chunks", a, b, c_, d, e, bool(f)))
-                elif kind == 1:
-                    m.dev.call_log.append(("minsum_sad", a, b, c_, d, False))
-                else:
-                    m.dev.call_log.append(("setsum_leaves" if kind == 3 else "fraction_chunks", a, b, c_, d))
+            self._logLaunches(h)
+
+    def adoptSearches(self, handles: list, keep_log: bool = True) -> "SearchSteps":
+        """Every step of MANY native searches on this model's table (the candidate searches of exon-first: hundreds per
+        sample) through ONE library call (``gk_search_export``); the steps become ``TypingResult`` objects when they are
+        read (``SearchSteps``)."""
+        import ctypes as C
+        from ._lib import check, lib
+        m = self._model
+        n = len(handles)
+        arr = (C.c_void_p * max(n, 1))(*handles)
+        totals = np.zeros(3, dtype=np.int64)
+        check(lib().gk_search_export(arr, n, totals.ctypes.data, None, None, None, None, None))
+        n_steps, n_rows, n_cells = (int(x) for x in totals)
+        meta = np.zeros(n + 3 * n_steps, dtype=np.int64)
+        value = np.empty(n_rows, dtype=np.float64)
+        sum_indv, frac = np.empty(n_cells, dtype=np.float64), np.empty(n_cells, dtype=np.float64)
+        ids = np.empty(n_cells, dtype=np.int32)
+        check(lib().gk_search_export(arr, n, totals.ctypes.data, meta.ctypes.data, value.ctypes.data, sum_indv.ctypes.data,
+                                     frac.ctypes.data, ids.ctypes.data))
+        steps = SearchSteps(self, meta[:n], meta[n:].reshape(-1, 3), value, sum_indv, frac, ids.astype(np.int64))
+        later = steps.step_in_search > 0
+        SEARCH_STATS["bounded"] += int(np.count_nonzero(later & (steps.bounded != 0)))
+        SEARCH_STATS["redone_exactly"] += int(np.count_nonzero(later & (steps.bounded == 0)))
+        if keep_log and m.dev.call_log is not None:
+            for h in handles:
+                self._logLaunches(C.c_void_p(h))
+        return steps
+
+    def _logLaunches(self, h) -> None:
+        """Launch geometries of a native search into the device's call log (bench roofline)."""
+        import ctypes as C
+        from ._lib import check, lib
+        m = self._model
+        n_log = C.c_int64()
+        check(lib().gk_search_log(h, None, 0, C.byref(n_log)))
+        raw = np.empty(n_log.value, dtype=np.int64)
+        check(lib().gk_search_log(h, raw.ctypes.data, len(raw), C.byref(n_log)))
+        for kind, a, b, c_, d, e, f in raw.reshape(-1, 7).tolist():
+            if kind == 0:      # column sums are a launch of their own kernel (no previous sets, one "set")
+                m.dev.call_log.append(("colsum_chunks" if b == 1 and c_ == 0 else "maxsum_chunks", a, b, c_, d, e, bool(f)))
+            elif kind == 1:
+                m.dev.call_log.append(("minsum_sad", a, b, c_, d, False))
+            else:
+                m.dev.call_log.append(("setsum_leaves" if kind == 3 else "fraction_chunks", a, b, c_, d))
 
     def geneJob(self, cn: int, verdict: bool | None = None):
         """(``_lib.GeneJob`` for ``gk_sample_search``, homozygous?) of a model built with ``_defer_launch``: the
