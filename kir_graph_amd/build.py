@@ -31,17 +31,29 @@ def outOfDate(lib: Path) -> bool:
 # device source files a kernel's code comes from (everything under csrc/ for a kernel that is not listed)
 KERNEL_SOURCES = {
     "compat_kernel": ["gk_typing.hip", "gk_lut.h", "gk_common.h"],
-    "count_ids": ["gk_typing.hip", "gk_common.h"],
+    "patch_pending": ["gk_typing.hip", "gk_lut.h", "gk_common.h"],
+    "count_ids_genes": ["gk_typing.hip", "gk_common.h"],
+    "flag_nonempty": ["gk_typing.hip", "gk_common.h"],
     "tab_count": ["gk_tabulate.hip", "gk_common.h"],
     "tab_emit": ["gk_tabulate.hip", "gk_common.h"],
+    "tab_expand": ["gk_tabulate.hip", "gk_common.h"],
     "minsum_sad": ["gk_bound.hip", "gk_common.h"],
-    "select_cut": ["gk_bound.hip", "gk_common.h"],
+    "minsum_finish": ["gk_bound.hip", "gk_common.h"],
+    "select_hist1": ["gk_bound.hip", "gk_common.h"],
+    "select_hist2": ["gk_bound.hip", "gk_common.h"],
+    "select_append": ["gk_bound.hip", "gk_common.h"],
     "setmin_u8": ["gk_bound.hip", "gk_common.h"],
     "fraction_chunks": ["gk_search.hip", "gk_common.h"],
     "setsum_leaves": ["gk_search.hip", "gk_common.h"],
-    "patch_pending": ["gk_typing.hip", "gk_lut.h", "gk_common.h"],
+    "fold_leaves": ["gk_search.hip", "gk_common.h"],
+    "colsum_chunks": ["gk_search.hip", "gk_common.h"],
     "maxsum_chunks": ["gk_search.hip", "gk_common.h"],
     "combine_chunks": ["gk_search.hip", "gk_common.h"],
+    "em_sets_groups": ["gk_em.hip", "gk_common.h"],
+    "em_sets_hash": ["gk_em.hip", "gk_common.h"],
+    "em_sets_verify": ["gk_em.hip", "gk_common.h"],
+    "em_sets_emit": ["gk_em.hip", "gk_common.h"],
+    "em_kernel_genes": ["gk_em.hip", "gk_common.h"],
 }
 
 

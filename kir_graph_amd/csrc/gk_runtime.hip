@@ -22,6 +22,21 @@ static std::vector<gk_ctx*>& all_contexts() {
 }
 static std::atomic<size_t> g_pool_cached{0};
 
+// large blocks live in one pool per device (see gk_pool_malloc)
+constexpr size_t kBigBlock = (size_t)32 << 20;
+struct BigBlock { void* p; hipEvent_t ev; gk_ctx* by; };
+struct DevicePool {
+  std::mutex m;
+  std::multimap<size_t, BigBlock> idle;
+  std::vector<hipEvent_t> events;
+  size_t cached = 0;
+};
+static DevicePool& big_pool(int device) {
+  static DevicePool pools[64];
+  return pools[device & 63];
+}
+
+
 void gk_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -101,6 +116,12 @@ int gk_ctx_destroy(gk_ctx* ctx) {
     v.erase(std::remove(v.begin(), v.end(), ctx), v.end());
   }
   g_pool_cached -= ctx->pool_cached_bytes;
+  {
+    DevicePool& dp = big_pool(ctx->device);      // its idle large blocks stay for the others (the stream has drained)
+    std::lock_guard<std::mutex> lock(dp.m);
+    for (auto& kv : dp.idle)
+      if (kv.second.by == ctx) kv.second.by = nullptr;
+  }
   for (auto& kv : ctx->pool_free) hipFree(kv.second);
   for (auto& kv : ctx->pool_live) hipFree(kv.first);
   if (ctx->scratch) hipFree(ctx->scratch);
@@ -344,12 +365,27 @@ static size_t pool_class(size_t bytes) {
   return (bytes + step - 1) / step * step;
 }
 
-// the idle blocks of one context back to the device (its stream drained first: a cached block may still be read by work
-// queued before it was freed); the caller holds no pool lock
+// ---- large blocks: ONE pool per device, shared by the contexts of the process.  The lanes of a process type samples of
+// different sizes: a pool per context kept, idle, a set of gigabyte tables per lane that no other lane could use (five
+// lanes of 20 M-read samples typed exon-first: more than the card).  A large block goes back with an EVENT recorded on the
+// stream that last used it; a context that takes a block another context freed makes its stream wait for that event
+// (hipStreamWaitEvent: a dependency on the GPU, no host wait), so reuse stays stream-ordered across streams.
+// idle large blocks a process may keep per device (GK_POOL_CACHE_GB; default: no limit -- they are reused by whichever
+// context asks next, and all of them go back when the device runs out): beyond it the largest idle blocks are released
+static size_t pool_cache_limit() {
+  static const size_t v = [] {
+    const char* e = getenv("GK_POOL_CACHE_GB");
+    if (!e) return (size_t)-1;
+    return (size_t)(std::max(atof(e), 0.0) * (double)(1ull << 30));
+  }();
+  return v;
+}
+
+// the idle blocks of one context's own (small-block) pool back to the device; the caller holds no pool lock
 static size_t flush_pool(gk_ctx* c) {
   std::lock_guard<std::mutex> lock(c->pool_mutex);
   if (c->pool_free.empty()) return 0;
-  hipStreamSynchronize(c->stream);
+  hipStreamSynchronize(c->stream);      // a cached block may still be read by work queued before it was freed
   const size_t bytes = c->pool_cached_bytes;
   for (auto& kv : c->pool_free) hipFree(kv.second);
   c->pool_free.clear();
@@ -358,24 +394,54 @@ static size_t flush_pool(gk_ctx* c) {
   return bytes;
 }
 
-// idle blocks a process may keep across all its contexts (GK_POOL_CACHE_GB, default 48): beyond it a context that frees
-// a block gives its whole cache back.  The lanes of a process keep blocks of the sizes their samples had; samples of a
-// cohort differ in size, and what one lane's pool holds idle no other lane can use.
-static size_t pool_cache_limit() {
-  static const size_t v = [] {
-    const char* e = getenv("GK_POOL_CACHE_GB");
-    const double gb = e ? atof(e) : 48.0;
-    return (size_t)(std::max(gb, 0.0) * (double)(1ull << 30));
-  }();
-  return v;
+// idle large blocks of a device back to it, the largest first, until at most `keep` bytes stay
+static size_t release_big(int device, size_t keep) {
+  DevicePool& dp = big_pool(device);
+  std::lock_guard<std::mutex> lock(dp.m);
+  size_t given = 0;
+  while (!dp.idle.empty() && dp.cached > keep) {
+    auto it = std::prev(dp.idle.end());
+    hipEventSynchronize(it->second.ev);
+    hipFree(it->second.p);
+    dp.events.push_back(it->second.ev);
+    dp.cached -= it->first;
+    g_pool_cached -= it->first;
+    given += it->first;
+    dp.idle.erase(it);
+  }
+  return given;
 }
 
 hipError_t gk_pool_malloc(gk_ctx* ctx, void** out, size_t bytes) {
   const size_t cls = pool_class(bytes);
   static const bool trace = getenv("GK_POOL_TRACE") != nullptr;      // dev: every large pool miss and what it costs
-  {
+  const bool big = cls >= kBigBlock;
+  if (big) {
+    DevicePool& dp = big_pool(ctx->device);
+    std::lock_guard<std::mutex> lock(dp.m);
+    // the smallest idle block that holds the request, if it is not more than a quarter too large; one this context
+    // freed itself if there is one among the first few (no dependency between streams then)
+    auto it = dp.idle.lower_bound(cls);
+    auto pick = dp.idle.end();
+    for (int tries = 0; it != dp.idle.end() && it->first <= cls + cls / 4 && tries < 8; ++it, ++tries) {
+      if (pick == dp.idle.end()) pick = it;
+      if (it->second.by == ctx) { pick = it; break; }
+    }
+    if (pick != dp.idle.end()) {
+      const BigBlock blk = pick->second;
+      const size_t have = pick->first;
+      dp.idle.erase(pick);
+      dp.cached -= have;
+      g_pool_cached -= have;
+      if (blk.by != ctx) (void)hipStreamWaitEvent(ctx->stream, blk.ev, 0);
+      dp.events.push_back(blk.ev);
+      *out = blk.p;
+      std::lock_guard<std::mutex> mine(ctx->pool_mutex);
+      ctx->pool_live[*out] = have;
+      return hipSuccess;
+    }
+  } else {
     std::lock_guard<std::mutex> lock(ctx->pool_mutex);
-    // the smallest cached block that holds the request, if it is not more than a quarter too large
     auto it = ctx->pool_free.lower_bound(cls);
     if (it != ctx->pool_free.end() && it->first <= cls + cls / 4) {
       const size_t have = it->first;
@@ -386,36 +452,35 @@ hipError_t gk_pool_malloc(gk_ctx* ctx, void** out, size_t bytes) {
       ctx->pool_live[*out] = have;
       return hipSuccess;
     }
-    const auto t0 = std::chrono::steady_clock::now();
-    hipError_t e = hipMalloc(out, cls);
-    if (trace && cls >= ((size_t)32 << 20))
-      fprintf(stderr, "[gk_pool] ctx %p: hipMalloc of %zu MB took %.0f us (cached %zu MB in %zu blocks, %zu MB in all pools)\n",
-              (void*)ctx, cls >> 20, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(),
-              ctx->pool_cached_bytes >> 20, ctx->pool_free.size(), g_pool_cached.load() >> 20);
-    if (e == hipSuccess) {
-      ctx->pool_live[*out] = cls;
-      return e;
-    }
-    (void)hipGetLastError();
   }
-  // out of device memory: the idle blocks of EVERY context of the process go back, then once more
-  size_t given = 0;
-  {
-    std::lock_guard<std::mutex> lock(g_ctx_mutex);
-    for (gk_ctx* c : all_contexts())
-      if (c->device == ctx->device) given += flush_pool(c);
-  }
-  if (trace) fprintf(stderr, "[gk_pool] ctx %p: hipMalloc of %zu MB FAILED, %zu MB of cached blocks of all contexts given back\n",
-                     (void*)ctx, cls >> 20, given >> 20);
-  std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(out, cls);
-  if (e == hipSuccess) ctx->pool_live[*out] = cls;
+  if (trace && big)
+    fprintf(stderr, "[gk_pool] ctx %p: hipMalloc of %zu MB took %.0f us (%zu MB idle in all pools)\n", (void*)ctx, cls >> 20,
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), g_pool_cached.load() >> 20);
+  if (e != hipSuccess) {
+    // out of device memory: every idle block of the process on this device goes back, then once more
+    (void)hipGetLastError();
+    size_t given = release_big(ctx->device, 0);
+    {
+      std::lock_guard<std::mutex> lock(g_ctx_mutex);
+      for (gk_ctx* c : all_contexts())
+        if (c->device == ctx->device) given += flush_pool(c);
+    }
+    if (trace) fprintf(stderr, "[gk_pool] ctx %p: hipMalloc of %zu MB FAILED, %zu MB of idle blocks given back\n", (void*)ctx,
+                       cls >> 20, given >> 20);
+    e = hipMalloc(out, cls);
+  }
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    ctx->pool_live[*out] = cls;
+  }
   return e;
 }
 
 void gk_pool_free(gk_ctx* ctx, void* p) {
   if (!p) return;
-  bool over = false;
+  size_t cls = 0;
   {
     std::lock_guard<std::mutex> lock(ctx->pool_mutex);
     auto it = ctx->pool_live.find(p);
@@ -423,13 +488,36 @@ void gk_pool_free(gk_ctx* ctx, void* p) {
       hipFree(p);
       return;
     }
-    const size_t cls = it->second;
+    cls = it->second;
     ctx->pool_live.erase(it);
-    ctx->pool_free.emplace(cls, p);
-    ctx->pool_cached_bytes += cls;
-    over = (g_pool_cached += cls) > pool_cache_limit();
+    if (cls < kBigBlock) {
+      ctx->pool_free.emplace(cls, p);
+      ctx->pool_cached_bytes += cls;
+      g_pool_cached += cls;
+      return;
+    }
   }
-  if (over) flush_pool(ctx);
+  (void)hipSetDevice(ctx->device);      // frees may come from a thread that never chose a device (Python's collector)
+  DevicePool& dp = big_pool(ctx->device);
+  bool over = false;
+  {
+    std::lock_guard<std::mutex> lock(dp.m);
+    hipEvent_t ev = nullptr;
+    if (!dp.events.empty()) { ev = dp.events.back(); dp.events.pop_back(); }
+    else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+    if (!ev || hipEventRecord(ev, ctx->stream) != hipSuccess) {      // cannot mark the point of the stream: give it back
+      if (ev) dp.events.push_back(ev);
+      (void)hipGetLastError();
+      hipStreamSynchronize(ctx->stream);
+      hipFree(p);
+      return;
+    }
+    dp.idle.emplace(cls, BigBlock{p, ev, ctx});
+    dp.cached += cls;
+    g_pool_cached += cls;
+    over = dp.cached > pool_cache_limit();
+  }
+  if (over) release_big(ctx->device, pool_cache_limit());
 }
 
 extern "C" int gk_device_memory(gk_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes, int64_t* pool_cached_bytes) {

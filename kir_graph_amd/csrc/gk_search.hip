@@ -1192,8 +1192,16 @@ int gk_shares_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32
     const char* const form = getenv("GK_SETSUM");        // read per call: the tests compare both forms in one process
     const int n_cols = max_id + 1;
     const size_t lds = (size_t)n_cols * kStageLd * sizeof(double);
+    // the leaf kernel stages EVERY column below the largest id of the selection: right for a step's few hundred sets,
+    // which name most of the gene's alleles -- a handful of sets (exon-first's one-set steps) name a few columns of a
+    // gigabyte table, and the tiles read just those
+    std::vector<char> named((size_t)n_cols, 0);
+    int distinct = 0;
+    for (int64_t i = 0; i < (int64_t)n_sets * c; ++i)
+      if (!named[ids[i]]) { named[ids[i]] = 1; ++distinct; }
+    const bool dense = n_sets >= 64 || distinct * 4 >= n_cols;
     if (with_value && !L.indexed() && c >= 2 && c <= 4 && n_sets <= 4 * kLeafGroups * kLeafSlots && lds <= 158 * 1024 &&
-        !(form && !strcmp(form, "tiles")))
+        ((dense && !(form && !strcmp(form, "tiles"))) || (form && !strcmp(form, "leaves"))))
       return shares_leafwise(ctx, L, n_rows, ids, n_sets, c, n_cols, lds, call);
   }
   // Order the sets so that tiles of 32 share columns: the best sets pair a few strong alleles with

@@ -17,7 +17,9 @@ def total(path, counter, kernel):
 
 fetch, n_f = total(sys.argv[1], "FETCH_SIZE", sys.argv[3])
 write, n_w = total(sys.argv[2], "WRITE_SIZE", sys.argv[3])
-print(json.dumps({"kernel": sys.argv[3], "csrc_sha16": sourceDigest(sys.argv[3]), "launches": n_f, "fetch_size_kib": fetch, "write_size_kib": write,
+workload = sys.argv[4] if len(sys.argv) > 4 else None
+print(json.dumps({"kernel": sys.argv[3], "workload": workload, "csrc_sha16": sourceDigest(sys.argv[3]), "launches": n_f, "fetch_size_kib": fetch, "write_size_kib": write,
                   "traffic_bytes_per_launch": (2 * fetch / max(n_f, 1) + write / max(n_w, 1)) * 1024,
-                  "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python bench.py`; "
+                  "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over the workload's serial form "
+                            "(tools/collect_profiles.sh); "
                             "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024"}))
