@@ -61,6 +61,10 @@ struct gk_ctx {
     int n_spans, n_chunks, n_leaves, max_chunk_leaves;
   };
   std::map<int64_t, TreeHead> tree_heads;
+  // tickets of kernels whose last workgroup continues the work (gk_ctx_tickets): zero between launches -- the
+  // workgroup that takes the last ticket of a group puts the counter back
+  uint32_t* tickets = nullptr;
+  size_t n_tickets = 0;
   // caching allocator state (gk_pool_*)
   std::mutex pool_mutex;   // frees may come from another host thread (Python GC)
   std::multimap<size_t, void*> pool_free;
@@ -104,6 +108,8 @@ hipEvent_t gk_prof_stop_event();
   hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, gk_prof_start_event(), gk_prof_stop_event(), 0, __VA_ARGS__)
 
 int gk_ctx_scratch(gk_ctx* ctx, size_t bytes, void** out);
+// `n` counters that are zero whenever no kernel of this context's stream is using them (see gk_ctx::tickets)
+int gk_ctx_tickets(gk_ctx* ctx, size_t n, uint32_t** out);
 
 // host -> device through the context's pinned ring: queued on the stream, `src` may be reused at once -- unless the
 // transfer is larger than gk_stage_direct() bytes: that one is queued straight from `src`, which must then stay valid

@@ -125,6 +125,7 @@ int gk_ctx_destroy(gk_ctx* ctx) {
   for (auto& kv : ctx->pool_free) hipFree(kv.second);
   for (auto& kv : ctx->pool_live) hipFree(kv.first);
   if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->tickets) hipFree(ctx->tickets);
   if (ctx->send_ring.base) hipHostFree(ctx->send_ring.base);
   if (ctx->fetch_ring.base) hipHostFree(ctx->fetch_ring.base);
   for (const auto& m : ctx->marks) hipEventDestroy(m.ev);
@@ -612,6 +613,20 @@ extern "C" int gk_prof_collect(gk_ctx* ctx, int64_t* launches, double* total_ms)
   }
   ctx->prof_spans.clear();
   (void)hipGetLastError();   // a span whose kernel never ran leaves an error behind; it is not the caller's
+  return GK_OK;
+}
+
+int gk_ctx_tickets(gk_ctx* ctx, size_t n, uint32_t** out) {
+  gk_bind(ctx);
+  if (n > ctx->n_tickets) {
+    GK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->tickets) GK_HIP(hipFree(ctx->tickets));
+    const size_t want = std::max<size_t>(4096, n * 2);
+    GK_HIP(hipMalloc((void**)&ctx->tickets, want * sizeof(uint32_t)));
+    GK_HIP(hipMemsetAsync(ctx->tickets, 0, want * sizeof(uint32_t), ctx->stream));
+    ctx->n_tickets = want;
+  }
+  *out = ctx->tickets;
   return GK_OK;
 }
 

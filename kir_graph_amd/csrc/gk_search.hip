@@ -675,11 +675,14 @@ __global__ __launch_bounds__(kLeafThreads) void setsum_leaves(const double* __re
 }
 
 // the leaves of chunk blockIdx.y, added up in the order of numpy's pairwise recursion (lops: dst += src over the
-// chunk's leaves, post-order); a thread owns one output, its leaf sums sit in its own LDS column (all loads in flight)
+// chunk's leaves, post-order); a thread owns one output, its leaf sums sit in its own LDS column (all loads in flight).
+// The workgroup that finishes LAST for its 64 outputs (a ticket per output group, put back to zero by the taker) adds the
+// chunk sums in chunk order -- numpy's outer reduce loop -- into `out` (a launch of its own, combine_chunks, until round 4).
 __global__ __launch_bounds__(kFoldOut) void fold_leaves(const double* __restrict__ partial, int64_t n_out,
                                                         const int32_t* __restrict__ chunk_leaf0,
                                                         const int32_t* __restrict__ chunk_lop0,
-                                                        const TopOp* __restrict__ lops, double* __restrict__ chunk_sums) {
+                                                        const TopOp* __restrict__ lops, double* chunk_sums, int n_chunks,
+                                                        uint32_t* __restrict__ tickets, double* __restrict__ out) {
   extern __shared__ double lsum[];   // [leaf of the chunk][kFoldOut]
   const int t = threadIdx.x, q = blockIdx.y;
   const int64_t o = (int64_t)blockIdx.x * kFoldOut + t;
@@ -690,6 +693,23 @@ __global__ __launch_bounds__(kFoldOut) void fold_leaves(const double* __restrict
   }
   for (int k = chunk_lop0[q]; k < chunk_lop0[q + 1]; ++k) lsum[lops[k].dst * kFoldOut + t] += lsum[lops[k].src * kFoldOut + t];
   if (o < n_out) chunk_sums[(int64_t)q * n_out + o] = lsum[t];
+  __shared__ uint32_t s_last;
+  __threadfence();                       // this chunk's sums are visible before the ticket is taken
+  __syncthreads();
+  if (t == 0) {
+    const uint32_t ticket = atomicAdd(&tickets[blockIdx.x], 1u);
+    s_last = ticket == (uint32_t)n_chunks - 1 ? 1u : 0u;
+    if (s_last) tickets[blockIdx.x] = 0u;                     // for the next launch on this stream
+  }
+  __syncthreads();
+  if (!s_last || o >= n_out) return;
+  __threadfence();
+  double total = 0.0;
+  for (int c = 0; c < n_chunks; ++c) {
+    const double v = __hip_atomic_load(&chunk_sums[(int64_t)c * n_out + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    total = c == 0 ? v : total + v;
+  }
+  out[o] = total;
 }
 
 // Column sums log_probs[:, cols].sum(axis=0) (typing_mulit_allele.py:514) with numpy's tree.  An 8-lane group
@@ -1158,13 +1178,14 @@ static int shares_leafwise(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const 
   const size_t fold_lds = (size_t)dp.max_chunk_leaves * kFoldOut * sizeof(double);
   if (fold_lds > 48 * 1024)
     GK_HIP(hipFuncSetAttribute((const void*)fold_leaves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds));
+  uint32_t* tickets = nullptr;
+  const unsigned fold_groups = (unsigned)((n_out + kFoldOut - 1) / kFoldOut);
+  { const int trc = gk_ctx_tickets(ctx, fold_groups, &tickets); if (trc) return trc; }
+  // the leaves of every chunk in the order of the pairwise recursion, then -- in the workgroup that comes last -- the
+  // chunk sums in sequence (numpy's outer reduce loop); the shares are handed back undivided (collect divides)
   GK_PROF(ctx, "fold_leaves",
-          GK_KERNEL(fold_leaves, dim3((unsigned)((n_out + kFoldOut - 1) / kFoldOut), (unsigned)dp.n_chunks), dim3(kFoldOut),
-                    fold_lds, st, d_partial, n_out, dp.chunk_leaf0, dp.chunk_lop0, dp.lops, d_chunk));
-  // the chunk sums in sequence (numpy's outer reduce loop); the shares are handed back undivided (collect divides)
-  GK_PROF(ctx, "combine_chunks",
-          GK_KERNEL(combine_chunks, dim3((unsigned)((n_out + kCombOut - 1) / kCombOut)), dim3(kThreads), 0, st, d_chunk,
-                    n_out, dp.n_chunks, dp.unit0, dp.zero0, dp.top, 0.0, d_out));
+          GK_KERNEL(fold_leaves, dim3(fold_groups, (unsigned)dp.n_chunks), dim3(kFoldOut), fold_lds, st, d_partial, n_out,
+                    dp.chunk_leaf0, dp.chunk_lop0, dp.lops, d_chunk, dp.n_chunks, tickets, d_out));
   GK_HIP(hipGetLastError());
   call.n_rows = n_rows;
   call.n_sets = n_sets;

@@ -286,7 +286,19 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
   }
   const int n_pass = min(kPassAlleles, n_allele - a_base);
   const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
-  for (int64_t tile_i = blockIdx.x; tile_i < n_tiles; tile_i += gridDim.x) {
+  // Tiles to workgroups, XCD by XCD: a 128-byte line of the mismatch table holds the bytes of EIGHT consecutive tiles
+  // (16 rows each).  Workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD has an L2 of its own, and a line
+  // whose pieces are written through different L2s leaves each of them as a masked partial write (a read-modify-write
+  // at the memory side: 1.7 x the kernel's algorithmic traffic in round 4).  So the tiles of a line go to workgroups of
+  // ONE XCD, whose write-back L2 puts the line together: group g = tiles 8 g .. 8 g + 7 belongs to XCD g % 8, and the
+  // workgroups of an XCD share out the tiles of its groups one by one.  The grid is a multiple of 8 workgroups.
+  const int64_t n_groups = (n_tiles + 7) / 8;
+  const int xcd = blockIdx.x & 7;
+  const int64_t my_groups = n_groups > xcd ? (n_groups - xcd + 7) / 8 : 0;
+  const int64_t wg_per_xcd = gridDim.x >> 3;
+  for (int64_t u = blockIdx.x >> 3; u < 8 * my_groups; u += wg_per_xcd) {
+    const int64_t tile_i = 8 * (xcd + 8 * (u >> 3)) + (u & 7);
+    if (tile_i >= n_tiles) continue;
     const int64_t row0 = tile_i * kTileRows;
     for (int q = 0; q < kTileRows / kCompatWaves; ++q) {
       const int rt = wid * (kTileRows / kCompatWaves) + q;   // row inside the tile
@@ -560,8 +572,8 @@ int launch_compat(gk_ctx* ctx, gk_tab* tab, gk_dptr d_rows, int64_t n_rows, gk_d
                   int keep_empty, uint8_t* miss8 = nullptr, int64_t ldm = 0, uint32_t* bound_flags = nullptr,
                   uint16_t* lidx = nullptr) {
   const double empty_p = keep_empty ? 0.999 : 1.0;
-  int64_t want = (n_rows + kTileRows - 1) / kTileRows;
-  const dim3 grid((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048)), block(kCompatThreads);
+  int64_t want = ((n_rows + kTileRows - 1) / kTileRows + 7) / 8 * 8;      // a multiple of 8: see the tile order in the kernel
+  const dim3 grid((unsigned)(want < 2048 ? (want < 8 ? 8 : want) : 2048)), block(kCompatThreads);
   const int64_t n_mask = (int64_t)(vend - vbeg) * words;
   uint32_t* mask_t = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&mask_t, (size_t)std::max<int64_t>(n_mask, 1) * sizeof(uint32_t)));

@@ -146,9 +146,18 @@ def _predictPerGene(tables: list[pd.DataFrame], samples_depth_tsv: list[str], cl
     diploid-depth file, no 3DL3 assumption.  The reference keys the depths of one gene by ``gene + "-" + depth file``
     and maps a key back to its sample with ``key.split("-")[1]`` (line 217): a depth-file path that contains ``-``
     raises ``KeyError`` there, and so it does here."""
-    if comm is not None:
-        raise NotImplementedError("per_gene copy numbers fit every gene over the whole cohort: run them on one rank")
     from .utils import NumpyEncoder
+    mine = None
+    if comm is not None:
+        # every gene is fitted over the WHOLE cohort: the per-gene depths of all ranks' samples are gathered in cohort
+        # order (the order one process would read them in), every rank runs the same fits and keeps its own samples
+        rows = comm.gatherInCohortOrder([(name, [str(g) for g in t["gene"]], [float(d) for d in t["depth"]])
+                                         for name, t in zip(samples_depth_tsv, tables)])
+        mine = [samples_depth_tsv.index(name) if name in samples_depth_tsv else -1 for name, _, _ in rows]
+        tables = [pd.DataFrame({"gene": genes, "depth": depths, "depth_file": name}) for name, genes, depths in rows]
+        samples_depth_tsv = [name for name, _, _ in rows]
+        if comm.rank != 0:
+            save_cn_model_path = None
     file_index = {name: i for i, name in enumerate(samples_depth_tsv)}
     df_depths = pd.concat(tables)
     df_depths["gene_sampleid"] = df_depths["gene"] + "-" + df_depths["depth_file"]
@@ -172,6 +181,9 @@ def _predictPerGene(tables: list[pd.DataFrame], samples_depth_tsv: list[str], cl
                 json.dump(data[-1], f, cls=NumpyEncoder)
         with open(save_cn_model_path, "w") as f:
             json.dump(data, f, cls=NumpyEncoder)
+    if mine is not None:          # this rank's samples, in the order they were given
+        own = [(k, i) for i, k in enumerate(mine) if k >= 0]
+        return [cns[i] for _, i in sorted(own)]
     return cns
 
 

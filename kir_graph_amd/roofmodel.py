@@ -193,10 +193,16 @@ def dominant(prof: dict[str, tuple[int, float]], call_log: list[tuple]) -> dict:
     """Roofline entry of the kernel with the largest total time in ``prof`` ({name: (launches, ms)})."""
     if not prof:
         return summarise([], "none", 0.0, 0)
-    name, (launches, total_ms) = max(prof.items(), key=lambda kv: kv[1][1])
+    # the kernel with the largest time among those this module prices (tiny samples put an unpriced launch-bound kernel
+    # on top: it is named beside the entry)
+    priced = {k: v for k, v in prof.items() if _priced(k, [c for c in call_log if c[0] == k])[0] > 0}
+    top = max(prof.items(), key=lambda kv: kv[1][1])[0]
+    name, (launches, total_ms) = max((priced or prof).items(), key=lambda kv: kv[1][1])
     out = summarise(call_log, name, total_ms, launches)
     total = sum(v[1] for v in prof.values())
     out["share_of_kernel_time"] = total_ms / total if total else None
+    if top != name:
+        out["largest_kernel_by_time"] = top
     # the other priced kernels, for the record
     others = {}
     for k, (n, ms) in prof.items():

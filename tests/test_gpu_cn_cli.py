@@ -186,6 +186,38 @@ def test_compact_side_format_round_trip(device, tmp_path):
         loadCompact(path, device, index=GkIndex.fromVariants(other.variants, genes=other.genes, exons=other.exons))
 
 
+def test_hand_off_files_through_three_lanes(device, tmp_path, monkeypatch):
+    """main.alleleTyping with FILE entries and three sample lanes: every lane uploads its file on the process's default
+    context, one at a time (kir_typing._sample holds a lock until the stream has drained); the files written are the ones
+    a one-lane run writes."""
+    from kir_graph_amd import main as cli
+    from kir_graph_amd.hisat2 import extractVariantFromText, writeCompact
+    sidx = synth.makeIndex(seed=21, n_genes=3, var_range=(200, 300), allele_range=(12, 20))
+    prefix = str(tmp_path / "idx")
+    sidx.write(prefix)
+    gidx = GkIndex.load(prefix)
+    names, cn_files = [], []
+    for k in range(6):
+        s = synth.makeSample(sidx, seed=30 + k, n_pairs=2500, gene_cn={g: 1 + (k + j) % 2 for j, g in enumerate(sidx.genes)})
+        text = ("\n".join(synth.toSamLines(s)) + "\n").encode()
+        data = extractVariantFromText([text], gidx, dev=device, keep_text=False)
+        name = str(tmp_path / f"s{k}.variant")
+        writeCompact(data, name + ".npz", index_ref=prefix)
+        data.tab.close()
+        cn = name + ".cn.tsv"
+        with open(cn, "w") as f:
+            f.write("gene\tcn\tdepth\n" + "".join(f"{g}\t{c}\t{30.0 * c}\n" for g, c in s.gene_cn.items()))
+        names.append(name)
+        cn_files.append(cn)
+    out = {}
+    for lanes in ("1", "3"):
+        monkeypatch.setenv("GK_SAMPLE_LANES", lanes)
+        files = cli.alleleTyping([(n, n + ".npz") for n in names], cn_files, method="full")
+        out[lanes] = [open(f).read() for f in files] + [open(f[:-4] + ".possible.tsv").read() for f in files]
+        assert len(files) == 6 and all("*" in text for text in out[lanes][:6])
+    assert out["1"] == out["3"]
+
+
 def test_records_side_format_round_trip(device, tmp_path):
     """hisat2.writeCompactRecords / loadCompact: the hand-off as the sample's packed records in compact form (what the
     command line writes with --no-variant-json) gives the tabulation it was written beside -- lists, novel numbering,

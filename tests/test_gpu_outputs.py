@@ -163,6 +163,47 @@ def test_predict_samples_cn_per_gene_writes_the_references_tsv(device, tmp_path)
     shutil.rmtree(d, ignore_errors=True)
 
 
+def test_per_gene_copy_numbers_over_two_ranks_equal_one_process(device):
+    """``per_gene=True`` with the cohort sharded over ranks (kir_cn.py:195-222 fits every gene over ALL samples): every rank
+    gathers the per-gene depths of the whole cohort in cohort order, runs the same fits and writes the CN files of its
+    own samples -- the reference's TSVs, whatever the shard."""
+    import shutil
+    import tempfile
+    from kir_graph_amd.kir_cn import aggrDepths, readSamtoolsDepth
+    t8 = load("t8_cn.json.gz")
+    d = tempfile.mkdtemp(dir="/tmp", prefix="gkpergene2r")
+    assert "-" not in d
+    for si, rows in enumerate(t8["depth_tables"] + t8["per_gene"]["depth_tables_extra"]):
+        pd.DataFrame(rows, columns=["gene", "pos", "depth"]).to_csv(f"{d}/s{si}.depth.tsv", sep="\t", header=False,
+                                                                    index=False)
+    shards = [[0, 2, 5], [1, 3, 4]]
+
+    class OtherRanks:
+        """What ``cohort.Comm.gatherInCohortOrder`` returns on rank ``rank``: its own items and the ones the other rank
+        would have sent (the same construction on the other shard's files), in cohort order."""
+        def __init__(self, rank):
+            self.rank, self.world, self.mine = rank, 2, shards[rank]
+
+        def gatherInCohortOrder(self, mine):
+            out = [None] * 6
+            for gi, item in zip(self.mine, mine):
+                out[gi] = item
+            for gi in shards[1 - self.rank]:
+                t = aggrDepths(readSamtoolsDepth(f"{d}/s{gi}.depth.tsv"), select_mode="p75")
+                out[gi] = (f"{d}/s{gi}.depth.tsv", [str(g) for g in t["gene"]], [float(x) for x in t["depth"]])
+            return out
+
+    want = t8["per_gene"]["KDE"]
+    for rank in (0, 1):
+        predictSamplesCN([f"{d}/s{si}.depth.tsv" for si in shards[rank]], [f"{d}/r{si}.cn.tsv" for si in shards[rank]],
+                         cluster_method="KDE", save_cn_model_path=f"{d}/m{rank}.json", select_mode="p75", per_gene=True,
+                         comm=OtherRanks(rank))
+    for si, text in enumerate(want["tsv"]):
+        assert open(f"{d}/r{si}.cn.tsv").read() == text, si
+    assert os.path.exists(f"{d}/m0.json") and not os.path.exists(f"{d}/m1.json")      # rank 0 keeps the models
+    shutil.rmtree(d, ignore_errors=True)
+
+
 def _cohort(tmp_path, n_samples=3, n_pairs=6000):
     """Synthetic index with all 15 genes (KIR3DL3 among them) + samples as SAM text + their truth."""
     sidx = synth.makeIndex(seed=21, n_genes=15, var_range=(60, 120), allele_range=(6, 12), len_range=(2500, 4000))
