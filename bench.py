@@ -200,7 +200,8 @@ def run_steps(items, dev, dindex, gidx, inputs, method, depth=None, threads=None
     from kir_graph_amd.hisat2 import SampleData
     lanes = cohort.sampleLanes() if depth is None or depth > 0 else 1
     copier, ingest = cohort.stagingContexts(dev, cohort.sampleLanes())
-    trace = os.environ.get("GK_BENCH_TRACE") == "1"      # a timeline of the host threads on stderr (tools/host_timeline.py)
+    from kir_graph_amd.utils import traceOn
+    trace = traceOn("bench")      # GK_TRACE=bench: a timeline of the host threads on stderr (tools/host_timeline.py)
 
     def note(what, k, t0):
         if trace:
@@ -388,11 +389,11 @@ class RankContext:
         n_dev = _lib.deviceCount()
         if n_dev == 0:
             raise RuntimeError("bench.py: no HIP device visible (the typing path has no CPU fallback)")
-        backend = {"nccl": "rccl", "gloo": "file"}.get(os.environ.get("GK_BENCH_BACKEND", "rccl"),
-                                                       os.environ.get("GK_BENCH_BACKEND", "rccl"))
+        backend = {"nccl": "rccl", "gloo": "file"}.get(os.environ.get("GK_COMM_BACKEND", "rccl"),
+                                                       os.environ.get("GK_COMM_BACKEND", "rccl"))
         if self.world > 1 and backend == "rccl" and self.world > n_dev:
             raise RuntimeError(f"bench.py: {self.world} ranks but {n_dev} GPU(s): one rank per GPU "
-                               "(GK_BENCH_BACKEND=file rehearses the multi-rank path on fewer GPUs)")
+                               "(GK_COMM_BACKEND=file rehearses the multi-rank path on fewer GPUs)")
         self.dev = _lib.Device(local_rank % n_dev)
         self.sidx, self.gidx, self.by_gene = build_index()
         self.dindex = DeviceIndex(self.dev, self.gidx)
@@ -404,7 +405,7 @@ class RankContext:
             try:
                 self.comm = gk_comm.initFromEnv(dev=self.dev, backend=backend, fallback=False)
             except gk_comm.CommError as e:
-                log(f"[bench] rank {rank}: {e}; not falling back (GK_BENCH_BACKEND=file rehearses the launch without RCCL)")
+                log(f"[bench] rank {rank}: {e}; not falling back (GK_COMM_BACKEND=file rehearses the launch without RCCL)")
                 os._exit(4)
             if self.comm.world != args.gpus or self.comm.backend != backend:
                 raise RuntimeError(f"bench.py: --gpus {args.gpus} on {backend} but {self.comm.world} ranks joined on {self.comm.backend}")
@@ -446,7 +447,7 @@ def measure(rc: RankContext, inputs, pairs: int, method: str, opts) -> dict:
     if getattr(args, "profile_host", False):
         import cProfile
         import pstats
-        n_prof = int(os.environ.get("GK_PROFILE_STEPS", "1"))     # with GK_SAMPLE_LANES=1 GK_PREFETCH=0 everything is on this thread
+        n_prof = 1     # with GK_SAMPLE_LANES=1 GK_PREFETCH=0 everything is on this thread
         pr = cProfile.Profile()
         pr.enable()
         run_steps(n_prof, dev, dindex, gidx, inputs, method, resident=resident)
@@ -456,7 +457,7 @@ def measure(rc: RankContext, inputs, pairs: int, method: str, opts) -> dict:
         pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(45)
     # per-kernel events inside the timed region cost ~3 ms per step (a profiling signal per dispatch): only on request;
     # the roofline comes from the serial pass after the region
-    in_region = bool(getattr(args, "verbose", False)) or os.environ.get("GK_BENCH_PROFILE") == "1"
+    in_region = bool(getattr(args, "verbose", False))
 
     def timed_leg(leg_resident):
         """EXACTLY opts.steps steps between a barrier + device synchronise on both sides; (seconds, host CPU seconds of
@@ -468,12 +469,12 @@ def measure(rc: RankContext, inputs, pairs: int, method: str, opts) -> dict:
         stats = {"value_table_at_start": sharedLogTable(dev).known()}
         t0 = time.perf_counter()
         cpu0 = cpu_seconds()
-        by_thread0 = {tid: c for _, tid, c in thread_cpu_table()} if os.environ.get("GK_BENCH_TRACE") == "1" else None
+        by_thread0 = {tid: c for _, tid, c in thread_cpu_table()} if traceOn("bench") else None
         last = run_steps(opts.steps, dev, dindex, gidx, inputs, method, resident=leg_resident, stats=stats)
         for d in rc.devices():
             d.sync()
         cpu = cpu_seconds() - cpu0          # this rank's host time for the steps (waits that spin included)
-        if by_thread0 is not None:          # GK_BENCH_TRACE=1: which threads the host time of the leg went to
+        if by_thread0 is not None:          # GK_TRACE=bench: which threads the host time of the leg went to
             rows = sorted(((c - by_thread0.get(tid, 0.0), name, tid) for name, tid, c in thread_cpu_table()), reverse=True)
             log("[trace] host CPU of the leg by thread (ms per step): " +
                 ", ".join(f"{name}/{tid} {1e3 * c / max(opts.steps, 1):.2f}" for c, name, tid in rows if c > 0))
@@ -507,27 +508,17 @@ def measure(rc: RankContext, inputs, pairs: int, method: str, opts) -> dict:
     # ---- the roofline basis: the same step one sample at a time on ONE stream, no prefetch (kernels back to back)
     serial = None
     if opts.serial_steps > 0 and rc.rank == 0:
-        keep = {name: os.environ.get(name) for name in ("GK_THREADS", "GK_SAMPLE_STREAMS")}
-        os.environ["GK_THREADS"] = "1"
-        os.environ["GK_SAMPLE_STREAMS"] = "1"       # one stream: the kernels of a sample run back to back
-        try:
-            run_steps(1, dev, dindex, gidx, inputs, method, depth=0, resident=resident)      # contexts of this mode warm
-            rc.profiled(True)
-            t1 = time.perf_counter()
-            run_steps(opts.serial_steps, dev, dindex, gidx, inputs, method, depth=0, resident=resident)
-            for d in rc.devices():
-                d.sync()
-            s_elapsed = time.perf_counter() - t1
-            s_prof, s_log = rc.collect()
-            rc.profiled(False)
-            serial = {"prof": s_prof, "call_log": s_log, "steps": opts.serial_steps,
-                      "ms_per_step": 1e3 * s_elapsed / opts.serial_steps}
-        finally:
-            for name, val in keep.items():
-                if val is None:
-                    os.environ.pop(name, None)
-                else:
-                    os.environ[name] = val
+        run_steps(1, dev, dindex, gidx, inputs, method, depth=0, resident=resident)      # contexts of this mode warm
+        rc.profiled(True)
+        t1 = time.perf_counter()
+        run_steps(opts.serial_steps, dev, dindex, gidx, inputs, method, depth=0, resident=resident)
+        for d in rc.devices():
+            d.sync()
+        s_elapsed = time.perf_counter() - t1
+        s_prof, s_log = rc.collect()
+        rc.profiled(False)
+        serial = {"prof": s_prof, "call_log": s_log, "steps": opts.serial_steps,
+                  "ms_per_step": 1e3 * s_elapsed / opts.serial_steps}
     for buf in resident:
         buf.free()
     return {"legs": legs, "prof": prof, "call_log": call_log, "n_valid": n_valid, "serial": serial,
@@ -592,7 +583,7 @@ def report(rc: RankContext, res: dict, name: str, pinned, cores_before, head: bo
         out["kernels_serial"] = {"ms_per_step_wall": serial["ms_per_step"],
                                  "kernel_ms_per_step": sum(v[1] for v in s_prof.values()) / steps,
                                  "mode": "one sample at a time on one stream, no prefetch (GK_SAMPLE_LANES=1 "
-                                         "GK_SAMPLE_STREAMS=1 GK_PREFETCH=0): kernels run back to back; names are the "
+                                         "GK_PREFETCH=0): kernels run back to back; names are the "
                                          "kernels' own (rocprofv3 --kernel-trace --stats lists the same names)",
                                  "kernels": table}
         out["roofline"] = roofmodel.dominant(s_prof, serial["call_log"])
@@ -714,6 +705,7 @@ def main():
     ap.add_argument("--cli-samples", type=int, default=12,
                     help="samples for the command line's typing stage (main.alleleTyping), timed after the legs as "
                          "`cli_typing_stage` (rank 0 of the one-GPU run only; 0 = skip)")
+    ap.add_argument("--pairs-scale", type=float, default=1.0, help=argparse.SUPPRESS)      # tests: the default workloads, smaller
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
                     help="the headline workload only (no `em` / `configs1_pv` objects)")
     ap.add_argument("--synth-threads", type=int, default=0,
@@ -739,7 +731,7 @@ def main():
     args.pinned_to = pinned
     # the host threads of a process (sample lanes, ingest) hold the interpreter lock only between library calls: a short
     # switch interval keeps one lane's Python from delaying another lane's next launch by the default 5 ms
-    sys.setswitchinterval(float(os.environ.get("GK_SWITCH_INTERVAL", "0.0005")))
+    sys.setswitchinterval(0.0005)
     # blocking waits, sample lanes and search slots by the rank's host cores, the preamble on a high-priority stream: the
     # package's own defaults for a process that types a cohort (kir_graph_amd.main sets the same ones).  ONE process per
     # GPU: a sample is typed by one host thread on one stream, three to five samples at a time (GK_SAMPLE_LANES)
@@ -747,7 +739,7 @@ def main():
     cohort.pipelineDefaults(1)
 
     if args.pairs is None and args.method is None:
-        scale = float(os.environ.get("GK_BENCH_PAIRS_SCALE", "1"))      # tests: the three workloads at a fraction of their size
+        scale = args.pairs_scale      # tests: the three workloads at a fraction of their size
         names = ["configs2_exonfirst"] + (["em", "configs1_pv"] if args.secondary and world == 1 else [])
         plan = [(name, max(1000, int(WORKLOADS[name][1] * scale)), WORKLOADS[name][2], WORKLOADS[name][3]) for name in names]
     else:

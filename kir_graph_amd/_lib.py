@@ -380,7 +380,6 @@ class Device:
             n = deviceCount()
             ordinal = ordinal % n if n else 0
         ctx = C.c_void_p()
-        urgent = urgent and os.environ.get("GK_STREAM_PRIORITY", "1") != "0"
         check(lib().gk_ctx_create_priority(ordinal, int(urgent), C.byref(ctx)))
         self.ctx = ctx
         self.ordinal = ordinal
@@ -460,7 +459,7 @@ class Device:
 _pinned_ok: bool | None = None
 # Pinning and unpinning hundreds of megabytes costs tens of milliseconds each way and holds the runtime's lock
 # meanwhile (measured: 48 ms + 44 ms for a sample's id array), so blocks go back to a pool instead of to the
-# runtime: a few size classes per order of magnitude, GK_PINNED_POOL_GB (default 4) of idle blocks at most.
+# runtime: a few size classes per order of magnitude, 4 GB of idle blocks at most.
 _pool_lock = threading.Lock()
 _pool: dict[int, list[int]] = {}
 _pool_idle = 0
@@ -489,7 +488,7 @@ def _pinnedTake(nbytes: int) -> tuple[int, int]:
 
 def _pinnedGive(address: int, cls: int) -> None:
     global _pool_idle
-    limit = int(float(os.environ.get("GK_PINNED_POOL_GB", "4")) * (1 << 30))
+    limit = 4 << 30
     with _pool_lock:
         if _pool_idle + cls <= limit:
             _pool.setdefault(cls, []).append(address)

@@ -88,7 +88,6 @@ def buildNative(force: bool = False, verbose: bool = False) -> Path:
     objdir.mkdir(exist_ok=True)
     base = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value",
             "-Wno-unused-result", f"-I{ROOT / 'include'}", f"-I{PKG / 'csrc'}"]
-    base += os.environ.get("GK_EXTRA_HIPCC_FLAGS", "").split()      # development: -D switches of an experiment
     jobs = []
     for src in SOURCES:
         obj = objdir / (src.rsplit(".", 1)[0] + ".o")

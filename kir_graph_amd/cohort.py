@@ -93,21 +93,18 @@ def hostCoresPerRank() -> int:
 
 def pipelineDefaults(procs: int = 1, cores: int | None = None) -> None:
     """Environment defaults of the sample pipeline, set before the first HIP call of the process (the wait policy is
-    read when a context is made).  ``main.main`` and ``bench.py`` both call this: ONE worker process per GPU types
-    several samples at a time (``GK_SAMPLE_LANES``), some of them inside their search (``GK_SEARCH_SLOTS``), the sample
-    preamble on a high-priority stream, waits that put the thread to sleep.  How many depends on the host cores the rank
-    has (``cores``, default ``hostCoresPerRank()``): five lanes and three searches where it has six or more (7.2 - 7.7 ms per
+    read when a context is made).  ``main.main`` and ``bench.py`` both call this: ONE process per GPU types several
+    samples at a time (``GK_SAMPLE_LANES``), some of them inside their search (``GK_SEARCH_SLOTS``), the sample preamble
+    on a high-priority stream, waits that put the thread to sleep.  How many depends on the host cores the rank has
+    (``cores``, default ``hostCoresPerRank()``): five lanes and three searches where it has six or more (7.2 - 7.7 ms per
     configs[1] sample on 3 - 4 busy cores), four and two from three cores (8.0 ms on 2.8), three and two below that
-    (8.3 ms on 2.6; a rank of an 8-GPU node on a 16-core quota has two) -- profiles/r04_sample_lanes.txt.  With several
-    worker processes on a GPU (``procs`` > 1) two lanes each and a plain preamble measured better
-    (profiles/r03_stream_priority.txt, r03_search_slots.txt).  Anything the user set stays."""
+    (8.3 ms on 2.6; a rank of an 8-GPU node on a 16-core quota has two) -- profiles/r04_sample_lanes.txt.  Anything the
+    user set stays."""
     cores = hostCoresPerRank() if cores is None else cores
     lanes, slots = (5, 3) if cores >= 6 else (4, 2) if cores >= 3 else (3, 2)
     os.environ.setdefault("GK_WAIT_POLICY", "block")
-    os.environ.setdefault("GK_URGENT_PREAMBLE", "1" if procs == 1 else "0")
-    os.environ.setdefault("GK_SAMPLE_LANES", str(lanes) if procs == 1 else "2")
-    if procs == 1:
-        os.environ.setdefault("GK_SEARCH_SLOTS", str(slots))
+    os.environ.setdefault("GK_SAMPLE_LANES", str(lanes))
+    os.environ.setdefault("GK_SEARCH_SLOTS", str(slots))
 
 
 def sampleLanes() -> int:
@@ -116,37 +113,31 @@ def sampleLanes() -> int:
 
 
 def stagingContexts(dev, lanes: int | None = None):
-    """(copier, ingest): the two device contexts of the staging stages, beyond the blocks of the typing lanes
-    (workers 0 .. lanes * hostThreads() - 1 belong to those): one stream for the copy of a sample's records into
+    """(copier, ingest): the two device contexts of the staging stages, beyond the contexts of the typing lanes
+    (workers 0 .. lanes - 1 belong to those): one stream for the copy of a sample's records into
     HBM, one -- of the device's highest priority -- for its tabulation, whose short kernels would otherwise sit behind
     the long kernels of the samples being typed."""
-    from .kir_typing import hostThreads
     lanes = sampleLanes() if lanes is None else lanes
-    base = lanes * hostThreads()
+    base = lanes
     ingest = dev.worker(base, urgent=True)       # made first: a context's priority is fixed when it is made
     return dev.worker(base + 1), ingest
 
 
-def stagedSamples(items, copy_in, tabulate, depth: int | None = None, copy_ahead: bool | None = None):
+def stagedSamples(items, copy_in, tabulate, depth: int | None = None):
     """Yield ``tabulate(copy_in(item))`` for every item, in order, staged ahead of the consumer as a two-stage
     pipeline: while sample k is typed, sample k + 1 is tabulated and the records of k + 2 are on their way to HBM,
-    each stage on a thread (and a device context, ``stagingContexts``) of its own.  ``copy_ahead=False``
-    (GK_COPY_AHEAD=0): both stages in one (6 - 7 ms of wall time per configs[1] sample next to the typing kernels, 80 % of
-    a process's budget).  ``copy_in=None``: the records are in HBM already, one stage.  ``depth`` <= 0 (GK_PREFETCH=0):
-    nothing ahead, everything on the calling thread."""
+    each stage on a thread (and a device context, ``stagingContexts``) of its own (both stages in one took 6 - 7 ms of
+    wall time per configs[1] sample next to the typing kernels, 80 % of a process's budget).  ``copy_in=None``: the records
+    are in HBM already, one stage.  ``depth`` <= 0 (GK_PREFETCH=0): nothing ahead, everything on the calling thread."""
     depth = int(os.environ.get("GK_PREFETCH", "1")) if depth is None else depth
-    if copy_ahead is None:
-        copy_ahead = os.environ.get("GK_COPY_AHEAD", "1") != "0"
     if depth <= 0:
         for item in items:
             yield tabulate(item if copy_in is None else copy_in(item))
         return
     if copy_in is None:
         yield from prefetched(items, tabulate, depth=depth)
-    elif copy_ahead:
-        yield from prefetched(prefetched(items, copy_in, depth=depth), tabulate, depth=depth)
     else:
-        yield from prefetched(items, lambda item: tabulate(copy_in(item)), depth=depth)
+        yield from prefetched(prefetched(items, copy_in, depth=depth), tabulate, depth=depth)
 
 
 def sampleFootprint(data, method: str) -> int:
@@ -238,9 +229,9 @@ class SampleTyper:
 
     def typeOne(self, data, gene_cn, item=None, lane: int = 0):
         """One sample on the calling thread, on lane ``lane``'s contexts."""
-        from .kir_typing import hostThreads, selectKirTypingModel
+        from .kir_typing import selectKirTypingModel
         typer = selectKirTypingModel(self.method, data, top_n=self.top_n, variant_correction=self.variant_correction)
-        typer.slot_base = lane * hostThreads()
+        typer.slot_base = lane
         calls, warnings = typer.typing(gene_cn() if callable(gene_cn) else gene_cn)
         if self.finish is not None:
             return self.finish(typer, calls, warnings, item)

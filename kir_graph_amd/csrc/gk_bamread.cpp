@@ -30,6 +30,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "gk_env.h"
 #include "gk_ingest.h"
 #include "graphkir_hip.h"
 
@@ -46,10 +47,7 @@ struct BlockPool {
   std::mutex lock;
   std::vector<std::pair<void*, size_t>> idle;
   size_t idle_bytes = 0;
-  static size_t limit() {
-    const char* e = getenv("GK_BLOCK_POOL_GB");
-    return (size_t)((e ? atof(e) : 6.0) * (double)((size_t)1 << 30));
-  }
+  static size_t limit() { return (size_t)6 << 30; }      // idle inflate buffers kept for the next file
   void* take(size_t n, size_t& cap) {
     {
       std::lock_guard<std::mutex> g(lock);
@@ -200,7 +198,7 @@ struct FastInflate {
 
 const FastInflate* fast_inflate() {
   static const FastInflate* found = []() -> const FastInflate* {
-    if (getenv("GK_NO_LIBDEFLATE")) return nullptr;
+    if (gk_test_hook("no_libdeflate")) return nullptr;
     void* lib = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
     if (!lib) return nullptr;
     static FastInflate f;
@@ -600,7 +598,7 @@ static int bam_open_impl(const char* path, int32_t name_sorted, gk_bam** out) {
   };
   const size_t span = n_bytes - o;
   size_t n_seg = std::min<size_t>((size_t)ingest_threads() * 4, std::max<size_t>(span >> 20, 1));
-  if (getenv("GK_BAM_INDEX_SEGMENTS")) n_seg = std::max<size_t>(1, (size_t)atol(getenv("GK_BAM_INDEX_SEGMENTS")));   // tests: many small segments
+  n_seg = std::max<size_t>(1, (size_t)gk_test_hook_value("bam_segments", (long)n_seg));   // tests: many small segments
   std::vector<Segment> seg(n_seg);
   for (size_t t = 0; t < n_seg; ++t) { seg[t].lo = o + span * t / n_seg; seg[t].hi = o + span * (t + 1) / n_seg; }
   auto chase = [&](Segment& sg, bool known_start) {
@@ -826,13 +824,9 @@ static int bam_open_impl(const char* path, int32_t name_sorted, gk_bam** out) {
       for (size_t k = part(t); k < part(t + 1); ++k) b->recs[k] = {sorted[k].off, sorted[k].size};
     });
     clock.lap("name sort");
-    // GK_BAM_COLLATE=1: the records themselves into name order, back to back.  Pairing and decoding touch every record in
-    // name order, scattered over the 300 MB of the inflated stream; one gather -- plain copies whose sources are known far
-    // ahead -- turns them into two walks of a stream front to back.  On the build container (8 cores, small caches) that
-    // is 9 % less CPU time for the ingest (0.89 against 0.98 s per 1 M records on one thread); on the GPU boxes (large
-    // last-level cache, first-touch page faults on the second 300 MB block) it costs 7 % more (1.65 - 1.68 against 1.55
-    // core-s per sample for the whole command line), so it is off by default.
-    static const bool collate = [] { const char* e = getenv("GK_BAM_COLLATE"); return e && !strcmp(e, "1"); }();
+    // (Not done: gathering the records themselves into name order, back to back -- 9 % less CPU for the ingest on a small
+    // host, 7 % more on the GPU boxes, where the second 300 MB block costs first-touch page faults: round 3.)
+    constexpr bool collate = false;
     if (collate && n > 0) {
       std::vector<uint64_t> first((size_t)n_thr + 1, 0);      // bytes of the records before part(t)
       on_all([&](int t) {

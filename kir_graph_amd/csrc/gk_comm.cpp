@@ -185,15 +185,11 @@ int gk_h2d_async(gk_ctx* ctx, gk_dptr dst, const void* src, size_t bytes) {
   gk_bind(ctx);
   GK_REQUIRE(ctx, "null context");
   if (!bytes) return GK_OK;
-  // A bulk copy goes out in pieces (GK_H2D_CHUNK_MB, default 8; 0 = one call): the DMA engine that serves host-to-device
+  // A bulk copy goes out in pieces of 8 MB: the DMA engine that serves host-to-device
   // copies also carries the small parameter blocks of the samples being typed, and it arbitrates between queues at
   // command boundaries -- behind ONE 700 MB command (a configs[2] sample) every search stage of the other lanes waited
   // for the whole transfer.
-  static const size_t chunk = [] {
-    const char* e = getenv("GK_H2D_CHUNK_MB");
-    const long mb = e ? atol(e) : 8;
-    return mb > 0 ? (size_t)mb << 20 : (size_t)0;
-  }();
+  constexpr size_t chunk = (size_t)8 << 20;
   if (!chunk || bytes <= chunk) {
     GK_HIP(hipMemcpyAsync(gk_ptr<void>(dst), src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return GK_OK;

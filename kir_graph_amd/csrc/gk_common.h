@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "graphkir_hip.h"
+#include "gk_env.h"
 
 void gk_set_error(const char* fmt, ...);
 

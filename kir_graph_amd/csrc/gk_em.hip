@@ -150,23 +150,27 @@ __device__ inline void sets_of_rows(const EmSetsJob& J, const uint32_t* __restri
     }
     uint32_t side0 = (word_lane && o1 > o0) ? 0xFFFFFFFFu : 0u;      // a mate without positives names nobody
     uint32_t side1 = (word_lane && o2 > o1) ? 0xFFFFFFFFu : 0u;
-    for (uint32_t k0 = o0; k0 < o4; k0 += G) {
-      const uint32_t idv = k0 + (uint32_t)l < o4 ? ids[k0 + l] : 0xFFFFFFFFu;
+    // one list at a time (its sign and its mate are then fixed: an id costs the row's address, one LDS read and one
+    // AND / AND-NOT): the group reads G ids of the list, coalesced, and hands them round
+    auto walk = [&](uint32_t begin, uint32_t end, uint32_t& side, bool negative) {
+      for (uint32_t k0 = begin; k0 < end; k0 += G) {
+        const uint32_t idv = k0 + (uint32_t)l < end ? ids[k0 + l] : 0xFFFFFFFFu;      // past the end: outside every gene
 #pragma unroll
-      for (int j = 0; j < G; ++j) {
-        const uint32_t v = __shfl(idv, j, G);
-        const uint32_t k = k0 + (uint32_t)j;
-        const uint32_t rel = v - vbeg;
-        uint32_t m = 0u;                                   // a variant outside the index (novel) has no allele
-        if (rel < n_span && word_lane) m = M[rel * (uint32_t)words + (uint32_t)l];
-        const bool neg = k >= o2;
-        const bool right = neg ? k >= o3 : k >= o1;
-        uint32_t x = neg ? ~m : m;                         // positives intersect, negatives (of the index) subtract
-        x = k < o4 ? x : 0xFFFFFFFFu;
-        side0 &= right ? 0xFFFFFFFFu : x;
-        side1 &= right ? x : 0xFFFFFFFFu;
+        for (int j = 0; j < G; ++j) {
+          const uint32_t rel = (uint32_t)__shfl(idv, j, G) - vbeg;
+          uint32_t m = 0u;                                   // a variant outside the index (novel) has no allele
+          if (rel < n_span && word_lane) m = M[rel * (uint32_t)words + (uint32_t)l];
+          // positives intersect (a novel one leaves nobody); negatives of the index subtract (a novel one, or the
+          // padding past the list's end: m == 0, nothing happens)
+          if (negative) side &= ~m;
+          else if (k0 + (uint32_t)j < end) side &= m;
+        }
       }
-    }
+    };
+    walk(o0, o1, side0, false);
+    walk(o1, o2, side1, false);
+    walk(o2, o3, side0, true);
+    walk(o3, o4, side1, true);
     const uint32_t twice = side0 & side1;
     const unsigned long long named = __ballot(twice != 0u);
     const bool both = ((named >> (wl & ~(G - 1))) & ((1ull << G) - 1ull)) != 0ull;

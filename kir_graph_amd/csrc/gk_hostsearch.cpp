@@ -570,7 +570,7 @@ int set_mark(gk_ctx* ctx, uint64_t* mark) {
   return GK_OK;
 }
 
-// GK_SEARCH_TIMING=1: where the calling thread spends a gk_sample_search call (host work between the waits / the waits)
+// GK_TRACE=search: where the calling thread spends a gk_sample_search call (host work between the waits / the waits)
 struct SearchClock {
   using clk = std::chrono::steady_clock;
   const bool on;
@@ -580,7 +580,7 @@ struct SearchClock {
   int n_wait = 0;
   clk::time_point mark = clk::now();
   const clk::time_point begin = mark;
-  SearchClock(const char* f, int g) : on(getenv("GK_SEARCH_TIMING") != nullptr), form(f), genes(g) {}
+  SearchClock(const char* f, int g) : on(gk_trace("search")), form(f), genes(g) {}
   void lap(bool waited) {
     if (!on) return;
     const auto now = clk::now();
@@ -1108,13 +1108,11 @@ int gk_sample_search(gk_ctx* ctx, gk_ctx** more_ctx, int32_t n_more, gk_tab* tab
     }
   }
   if (live.empty()) return GK_OK;
-  const char* const form = getenv("GK_SAMPLE_PIPELINE");      // read per call: the tests compare both forms in one process
-  const bool pipeline = !(form && !strcmp(form, "0"));
   bool float_tables = true;
   for (int i : live) if (jobs[i].table_of < 0) float_tables = float_tables && jobs[i].d_L && !jobs[i].d_lidx;
   bool flagged = true;               // every table comes with the flag word that reports products without a log10
   for (int i : live) if (jobs[i].table_of < 0) flagged = flagged && jobs[i].d_miss8 && jobs[i].d_flags;
-  if ((pipeline || any_special) && n_more == 0 && float_tables && flagged)
+  if (n_more == 0 && float_tables && flagged)
     return sample_search_pipelined(ctx, tab, d_vflag, lut, jobs, n_jobs, live, argsort, log10_fn, out);
   GK_REQUIRE(!any_special, "table-only jobs, searches on another job's table and per-step columns need float64 tables "
                            "with mismatch tables on one stream (the pipelined form)");

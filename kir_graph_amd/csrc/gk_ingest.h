@@ -16,6 +16,8 @@
 
 #include <thread>
 
+#include "gk_env.h"
+
 struct gk_packer;
 
 // allocator whose resize() leaves new elements uninitialised: buffers of hundreds of megabytes that the
@@ -36,12 +38,12 @@ inline int gk_ingest_threads() {
   return (int)std::max<long>(1, std::min<long>(n, 64));
 }
 
-// GK_INGEST_TIMING=1: phase times of the host ingest on stderr (development aid)
+// GK_TRACE=ingest: phase times of the host ingest on stderr (development aid)
 struct GkPhaseClock {
   const char* what;
   bool on;
   std::chrono::steady_clock::time_point t;
-  explicit GkPhaseClock(const char* w) : what(w), on(getenv("GK_INGEST_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  explicit GkPhaseClock(const char* w) : what(w), on(gk_trace("ingest")), t(std::chrono::steady_clock::now()) {}
   void lap(const char* phase) {
     if (!on) return;
     const auto now = std::chrono::steady_clock::now();

@@ -415,7 +415,7 @@ static size_t release_big(int device, size_t keep) {
 
 hipError_t gk_pool_malloc(gk_ctx* ctx, void** out, size_t bytes) {
   const size_t cls = pool_class(bytes);
-  static const bool trace = getenv("GK_POOL_TRACE") != nullptr;      // dev: every large pool miss and what it costs
+  static const bool trace = gk_trace("pool");      // dev: every large pool miss and what it costs
   const bool big = cls >= kBigBlock;
   if (big) {
     DevicePool& dp = big_pool(ctx->device);

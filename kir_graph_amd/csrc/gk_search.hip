@@ -1210,7 +1210,8 @@ int gk_shares_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32
   }
   // value + shares of a step's selection, leaf by leaf: every column of the table through LDS once (setsum_leaves)
   {
-    const char* const form = getenv("GK_SETSUM");        // read per call: the tests compare both forms in one process
+    char form_buf[16];
+    const char* const form = gk_test_hook("setsum", form_buf, sizeof(form_buf)) ? form_buf : nullptr;      // tests compare both forms
     const int n_cols = max_id + 1;
     const size_t lds = (size_t)n_cols * kStageLd * sizeof(double);
     // the leaf kernel stages EVERY column below the largest id of the selection: right for a step's few hundred sets,

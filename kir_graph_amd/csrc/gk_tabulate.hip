@@ -1003,7 +1003,7 @@ int gk_tabulate_spilled(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, int64_t n
   // is tabulated again with a table eight times the size.
   uint32_t log2cap = 16;
   while ((1ull << log2cap) < (uint64_t)(2 * std::max<int64_t>(n_pairs, 0)) && log2cap < 22) ++log2cap;   // at most 4 M slots to begin with
-  if (const char* e = getenv("GK_NOVEL_LOG2CAP")) log2cap = (uint32_t)std::min(30, std::max(4, atoi(e)));   // tests: force the retries
+  log2cap = (uint32_t)std::min<long>(30, std::max<long>(4, gk_test_hook_value("novel_log2cap", (long)log2cap)));   // tests: force the retries
   uint32_t log2max = 16;
   while ((1ull << log2max) < (uint64_t)(2 * std::max<int64_t>(n_pairs, 0)) * GK_WIDE_EVENTS * 2 && log2max < 30) ++log2max;   // a slot number is 30 bits of an event word
   for (;;) {
@@ -1127,7 +1127,7 @@ static int tabulate_with_table(gk_ctx* ctx, gk_index* idx, gk_dptr d_mates_p, in
   GK_HIP(gk_pool_malloc(ctx, (void**)&tab->d_ids, (size_t)(tab->n_ids + 1) * sizeof(uint32_t)));
   if (n_mates) {
     // pass 2: from what pass 1 saved; the second walk only when some window did not fit the saved bits
-    const bool two_walks = getenv("GK_TAB_TWO_WALKS") != nullptr;   // development / test switch
+    const bool two_walks = gk_test_hook("two_walks");   // tests: the second walk for every sample
     if ((err & 4) || two_walks) {
       GK_PROF(ctx, "tab_emit", GK_KERNEL(tab_emit, dim3(nblk(n_mates)), dim3(kThreads), 0, st, mates, n_mates, ix, nt,
                          cnt, valid, tab->d_ids));

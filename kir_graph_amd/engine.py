@@ -174,22 +174,16 @@ class Tabulation:
                 # error correction, empty reads, the surviving tallies of every gene (isHomozygous reads them per gene) and
                 # the sample's novel keys in ONE library call with two waits (gk_sample_prepare_all; six when the three
                 # were separate calls -- each wait sits behind the long kernels of the samples typed next to this one)
-                if os.environ.get("GK_PREAMBLE_ONE_CALL", "1") != "0":
-                    o, p, q = (np.empty(nv, dtype=t) for t in (np.int32, np.uint32, np.uint32))
-                    n_surv = C.c_int64()
-                    want_novel = self._novel_keys is None and self.n_novel > 0
-                    novel_keys = np.empty(self.n_novel, dtype=np.uint64) if want_novel else None
-                    check(lib().gk_sample_prepare_all(dev.ctx, self.handle, int(multiple), vflag.ptr, cnt.ptr, rows.ptr,
-                                                      off.ctypes.data, nv, o.ctypes.data, p.ctypes.data, q.ctypes.data,
-                                                      C.byref(n_surv), novel_keys.ctypes.data if want_novel else None))
-                    o, p, q = o[:n_surv.value], p[:n_surv.value], q[:n_surv.value]
-                    if want_novel:
-                        self._novel_keys = root._novel_keys = novel_keys
-                else:      # the three calls one after the other (six waits): kept for comparison
-                    check(lib().gk_sample_prepare(dev.ctx, self.handle, int(multiple), vflag.ptr, cnt.ptr, rows.ptr,
-                                                  off.ctypes.data))
-                    dev.sync()
-                    o, p, q = Tabulation.survivingCounts(self.on(dev), cnt, vflag)
+                o, p, q = (np.empty(nv, dtype=t) for t in (np.int32, np.uint32, np.uint32))
+                n_surv = C.c_int64()
+                want_novel = self._novel_keys is None and self.n_novel > 0
+                novel_keys = np.empty(self.n_novel, dtype=np.uint64) if want_novel else None
+                check(lib().gk_sample_prepare_all(dev.ctx, self.handle, int(multiple), vflag.ptr, cnt.ptr, rows.ptr,
+                                                  off.ctypes.data, nv, o.ctypes.data, p.ctypes.data, q.ctypes.data,
+                                                  C.byref(n_surv), novel_keys.ctypes.data if want_novel else None))
+                o, p, q = o[:n_surv.value], p[:n_surv.value], q[:n_surv.value]
+                if want_novel:
+                    self._novel_keys = root._novel_keys = novel_keys
                 n_index = self.dindex.host.n_variant
                 gene_of = np.searchsorted(self.dindex.host.gene_vbeg, o, side="right") - 1
                 if len(o) and int(o[-1]) >= n_index:

@@ -69,12 +69,12 @@ def readBam(bam_file: str) -> Iterable[str]:
     """Name-collated SAM lines of an alignment file (hisat2.py:103-110).
 
     ``.sam`` / ``.sam.gz`` are read directly (they must already be name-collated); ``.bam`` is
-    decoded and name-sorted natively (``packed.bamChunks``).  ``GK_BAM_READER=samtools`` runs
-    ``samtools sort -n`` like the reference instead."""
+    decoded and name-sorted natively (``packed.bamChunks``).  ``GK_TEST_HOOKS=bam_reader=samtools`` runs
+    ``samtools sort -n`` like the reference instead (the cross-check of tools/check_against_samtools.sh)."""
     if bam_file.endswith((".sam", ".sam.gz")):
         return readSamLines(bam_file)
-    import os
-    if os.environ.get("GK_BAM_READER", "native") == "samtools":
+    from .utils import testHook
+    if testHook("bam_reader") == "samtools":
         from .external_tools import runTool
         proc = runTool("samtools", ["samtools", "sort", "-n", bam_file, "-O", "SAM"], capture_output=True)
         return str(proc.stdout).split("\n")

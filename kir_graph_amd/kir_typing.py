@@ -82,22 +82,9 @@ class Typing:
         raise NotImplementedError
 
 
-def batchedPreamble() -> bool:
-    """Error correction + empty-read removal for all genes of a sample at once (``gk_sample_prepare``);
-    GK_BATCH_PREAMBLE=0 keeps the per-gene calls."""
-    import os
-    return os.environ.get("GK_BATCH_PREAMBLE", "1") != "0"
-
-
 def _lib_slice(buf, offset: int, count: int, dev):
     from ._lib import DeviceSlice
     return DeviceSlice(buf, offset, count, dev)
-
-
-def hostThreads() -> int:
-    """Host threads that type genes concurrently (each with its own HIP stream); GK_THREADS overrides."""
-    import os
-    return max(1, int(os.environ.get("GK_THREADS", "6")))
 
 
 class _GeneView:
@@ -150,13 +137,13 @@ class _GeneView:
         return flags
 
 
-class _GenesInParallel(Typing):
-    """Gene loop on a few host threads, each with its own HIP stream (needs ``self._data``)."""
+class _OnLane(Typing):
+    """A typer that runs on one typing lane of the process: its device context, its log table (needs ``self._data``)."""
 
     def __init__(self) -> None:
         super().__init__()
         self._local = threading.local()
-        self.slot_base = 0     # first worker context of this typer (cohort.SampleTyper gives every lane its own block)
+        self.slot_base = 0     # worker context of this typer (cohort.SampleTyper gives every lane its own)
         self.tables_rewritten = 0   # compatibility tables written again because the sample brought products without a log10
         self.tables_patched = 0     # ... and tables whose new products were patched in place (gk_compat_patch)
 
@@ -165,46 +152,12 @@ class _GenesInParallel(Typing):
         tab = getattr(self._local, "tab", None)
         if tab is None:
             base = self._data.tab
-            k = getattr(self._local, "slot", None)
             # never the tabulation's own context: a cohort run may already be tabulating the next
             # sample there (cohort.prefetched), and a context serves one host thread at a time
-            dev = base.dev.worker(self.slot_base + (0 if k is None else k))
+            dev = base.dev.worker(self.slot_base)
             tab = self._local.tab = base.on(dev)
             self._local.logs = sharedLogTable(dev)
         return tab, self._local.logs
-
-    def typing(self, gene_cn: dict[str, int], min_reads_num: int = 100) -> tuple[list[str], list[str]]:
-        """Genes are independent: type them on a few host threads, each with its own HIP stream, so the
-        ranking work of one gene (numpy, host) overlaps the reductions of another (device).  Results
-        are assembled in CN-table order, exactly like the sequential loop (kir_typing.py:42-62)."""
-        todo = [(gene, int(cn)) for gene, cn in gene_cn.items() if cn]
-        n_threads = min(hostThreads(), len(todo))
-        if n_threads <= 1:
-            return super().typing(gene_cn, min_reads_num)
-        slots = iter(range(n_threads))
-        lock = threading.Lock()
-
-        def init():
-            with lock:
-                self._local.slot = next(slots)
-                self._data.tab.dev.worker(self.slot_base + self._local.slot)   # create the context under the lock
-
-        with ThreadPoolExecutor(max_workers=n_threads, initializer=init) as pool:
-            # largest genes first (they dominate the makespan); order of results is restored below
-            order = sorted(range(len(todo)), key=lambda i: -self._geneWeight(todo[i][0]))
-            futures = {i: pool.submit(self.typingPerGene, *todo[i]) for i in order}
-            results = [futures[i].result() for i in range(len(todo))]
-        self._result = {gene: self._result[gene] for gene, _ in todo if gene in self._result}
-        predict_alleles, warning_genes = [], []
-        for (gene, _), (alleles, reads_num) in zip(todo, results):
-            predict_alleles.extend(alleles)
-            if reads_num < min_reads_num:
-                warning_genes.append(gene)
-        return predict_alleles, warning_genes
-
-    def _geneWeight(self, gene: str) -> int:
-        g = self._data.index.gene_id.get(gene)
-        return 0 if g is None else self._data.index.tables[g].n_allele ** 2
 
 
 _SEARCH_SLOTS: dict = {}
@@ -227,7 +180,7 @@ def _searchSlot():
     return sem
 
 
-class TypingWithPosNegAllele(_GenesInParallel):
+class TypingWithPosNegAllele(_OnLane):
     """Likelihood typing with positive / negative variants (77-150)."""
 
     def __init__(self, filename_variant_json, top_n: int = 300, multiple: bool = False, exon_first: bool = False,
@@ -244,7 +197,7 @@ class TypingWithPosNegAllele(_GenesInParallel):
     def typing(self, gene_cn: dict[str, int], min_reads_num: int = 100) -> tuple[list[str], list[str]]:
         """The plain likelihood strategy with the sample-wide preamble goes through ``gk_sample_search``: every gene's
         table and search in ONE library call on one stream (the genes advance in lock-step; ~10 waits per sample).
-        Anything else (exon-first, no correction, GK_SAMPLE_SEARCH=0) keeps a thread and a stream per gene."""
+        Anything else (exon-only, no correction, index tables) types gene after gene on this lane (``typingPerGene``)."""
         if self._wholeSample():
             return self._typingWholeSample(gene_cn, min_reads_num)
         if self._wholeSampleExonFirst():
@@ -254,10 +207,8 @@ class TypingWithPosNegAllele(_GenesInParallel):
     def _wholeSampleExonFirst(self) -> bool:
         import os
         from .engine import searchMode
-        from .typing_mulit_allele import nativeSearch
-        return (self._exon_first and not self._exon_only and batchedPreamble() and nativeSearch()
-                and os.environ.get("GK_SAMPLE_SEARCH", "1") != "0" and os.environ.get("GK_SAMPLE_EXONFIRST", "1") != "0"
-                and os.environ.get("GK_INDEX_TABLE", "0") != "1" and searchMode() == "bound")
+        return (self._exon_first and not self._exon_only and os.environ.get("GK_INDEX_TABLE", "0") != "1"
+                and searchMode() == "bound")
 
     def _typingWholeSampleExonFirst(self, gene_cn: dict[str, int], min_reads_num: int) -> tuple[list[str], list[str]]:
         """Exon-first for ALL genes of the sample on this thread and ONE stream, in two ``gk_sample_search`` calls
@@ -276,7 +227,7 @@ class TypingWithPosNegAllele(_GenesInParallel):
         from ._lib import check, lib
         from .typing_mulit_allele import AlleleTypingExonFirst
         tab, logs = self._context()
-        udev = tab.dev.urgent() if os.environ.get("GK_URGENT_PREAMBLE", "1") != "0" else tab.dev
+        udev = tab.dev.urgent()
         prep_f = tab.prepared(udev, self._multiple)
         if prep_f is None:
             return super().typing(gene_cn, min_reads_num)
@@ -357,7 +308,7 @@ class TypingWithPosNegAllele(_GenesInParallel):
             ranks = list(result.topRank(threshold=threshold))
             self.exon_info[gene] = {"exon_groups": len(p["groups"]), "exon_sets": int(result.value.shape[0]),
                                     "candidates": len(ranks)}
-            if len(ranks) > int(os.environ.get("GK_EXON_CANDIDATES_MAX", "1024")):
+            if len(ranks) > 1024:
                 p["per_gene"] = True            # a flood of tied exon sets: the per-gene path stacks their searches per launch
                 continue
             job, _ = full.geneJob(cn, False)
@@ -425,9 +376,7 @@ class TypingWithPosNegAllele(_GenesInParallel):
     def _wholeSample(self) -> bool:
         import os
         from .engine import searchMode
-        from .typing_mulit_allele import nativeSearch
-        return (not self._exon_first and not self._exon_only and self._variant_correction and batchedPreamble()
-                and nativeSearch() and os.environ.get("GK_SAMPLE_SEARCH", "1") != "0" and searchMode() in ("bound", "exact"))
+        return not self._exon_first and not self._exon_only and self._variant_correction and searchMode() in ("bound", "exact")
 
     def _typingWholeSample(self, gene_cn: dict[str, int], min_reads_num: int) -> tuple[list[str], list[str]]:
         import ctypes as C
@@ -435,12 +384,13 @@ class TypingWithPosNegAllele(_GenesInParallel):
         from . import _lib
         from ._lib import check, lib
         import time
-        trace = os.environ.get("GK_BENCH_TRACE") == "1"     # host timeline on stderr (tools/host_timeline.py)
+        from .utils import traceOn
+        trace = traceOn("bench")     # host timeline on stderr (tools/host_timeline.py)
         t_in = time.perf_counter()
         tab, logs = self._context()
         # the sample-wide preamble (error correction, empty reads, tallies: small kernels and four waits) on the lane's
         # high-priority stream: next to another sample's search it took 8 ms instead of 1.5 on a stream like any other
-        prep = tab.prepared(tab.dev.urgent() if os.environ.get("GK_URGENT_PREAMBLE", "1") != "0" else tab.dev, self._multiple)
+        prep = tab.prepared(tab.dev.urgent(), self._multiple)
         if prep is None:                 # not a gk_tabulate tabulation (host lists / compact files)
             return super().typing(gene_cn, min_reads_num)
         t_prep = time.perf_counter()
@@ -470,19 +420,13 @@ class TypingWithPosNegAllele(_GenesInParallel):
         if live:
             jobs = (_lib.GeneJob * len(live))(*[e[3] for e in live])
             handles = (C.c_void_p * len(live))()
-            # further contexts (streams) of this lane (GK_SAMPLE_STREAMS > 1): the genes' kernels may overlap on the GPU while
-            # the host thread stays one.  Off by default: with two lanes and two processes already sharing the GPU, four
-            # streams per sample measured 10 % slower than one (10.3 against 9.3 ms per sample on one box)
-            n_streams = max(1, min(int(os.environ.get("GK_SAMPLE_STREAMS", "1")), hostThreads(), len(live)))
-            base_slot = self.slot_base + (getattr(self._local, "slot", None) or 0)
-            extra = [self._data.tab.dev.worker(base_slot + k) for k in range(1, n_streams)]
-            more = (C.c_void_p * max(len(extra), 1))(*[d.ctx for d in extra])
+            more = (C.c_void_p * 1)()
             if trace:
                 import sys
                 import threading
                 print(f"[trace] pre {threading.get_native_id()} {t_in:.6f} {t_prep:.6f} {time.perf_counter():.6f}", file=sys.stderr, flush=True)
             with _searchSlot():
-                check(lib().gk_sample_search(tab.dev.ctx, more, len(extra), tab.handle, vflag.ptr, logs.handle, jobs, len(live),
+                check(lib().gk_sample_search(tab.dev.ctx, more, 0, tab.handle, vflag.ptr, logs.handle, jobs, len(live),
                                              _lib.NUMPY_ARGSORT, _lib.NUMPY_LOG10, handles))
             self.tables_rewritten = sum(max(0, int(jobs[k].passes) - 1) for k in range(len(live)))
             self.tables_patched = sum(int(jobs[k].patches) for k in range(len(live)))
@@ -543,7 +487,7 @@ class TypingWithPosNegAllele(_GenesInParallel):
             self._result[gene] = []
             return [f"{pure_gene}*"] * cn, 0
         if not self._exon_first and not self._exon_only:
-            prep = tab.prepared(tab.dev, self._multiple) if self._variant_correction and batchedPreamble() else None
+            prep = tab.prepared(tab.dev, self._multiple) if self._variant_correction else None
             if prep is not None:
                 # error correction and empty-read removal were done for every gene of the sample in one go
                 vflag, cnt, rows_all, off = prep[:4]
@@ -584,7 +528,7 @@ class TypingWithPosNegAllele(_GenesInParallel):
         return rows
 
 
-class TypingWithReport(_GenesInParallel):
+class TypingWithReport(_OnLane):
     """Abundance typing by the HISAT-genotype EM (153-204)."""
 
     def __init__(self, filename_variant_json, device: Device | None = None):
@@ -595,14 +539,12 @@ class TypingWithReport(_GenesInParallel):
     def typing(self, gene_cn: dict[str, int], min_reads_num: int = 100) -> tuple[list[str], list[str]]:
         """All genes of the sample through ``gk_sample_em``: candidate sets, distinct sets and the SQUAREM loops of every
         gene in ONE library call on one host thread and one stream (a workgroup per gene solves its EM), instead of a
-        thread and a stream per gene with three waits each.  GK_SAMPLE_EM=0 (or a gene with more than 2^18 distinct
-        candidate sets) keeps the per-gene calls.  Same reports either way (kir_typing.py:163-195)."""
+        thread and a stream per gene with three waits each.  A gene with more than 2^18 distinct candidate sets sends the
+        sample to the per-gene calls (``typingPerGene``: they size for it).  Same reports either way (kir_typing.py:163-195)."""
         import ctypes as C
         import os
         from . import _lib
         from ._lib import lib
-        if os.environ.get("GK_SAMPLE_EM", "1") == "0":
-            return super().typing(gene_cn, min_reads_num)
         tab, _ = self._context()
         todo = [(gene, int(cn)) for gene, cn in gene_cn.items() if cn]
         views = [_GeneView(self._data, gene, multiple=False, tab=tab) for gene, _ in todo]

@@ -37,7 +37,7 @@ from .index import GkIndex
 from .kir_cn import filterDepth, loadCN, predictSamplesCN
 from .kir_typing import defaultDevice, selectKirTypingModel
 from .samtools_utils import depthOfSample, readLocusLengths
-from .utils import getThreads, logger, mergeAllele, mergeCN, setThreads
+from .utils import testHook, getThreads, logger, mergeAllele, mergeCN, setThreads
 
 
 def getCommonName(r1: str, r2: str) -> str:
@@ -94,18 +94,17 @@ def mapSamples(names, reads, index, index_ref, exon_region_only=False, alignment
             hisatMap(index, reads[k][0], reads[k][1], name + ".bam", threads=getThreads())
             source = name + ".bam"
         pack = None
-        if source.endswith((".sam", ".sam.gz")) or os.environ.get("GK_BAM_READER", "native") != "samtools":
+        if source.endswith((".sam", ".sam.gz")) or testHook("bam_reader") != "samtools":
             # SAM text, or BAM decoded + name-collated natively (packed.bamChunks / packBam), packed natively
             pack = packAlignments(source, gk, keep_text=write_json)
-            if os.environ.get("GK_COMPACT_H2D", "1") != "0":
-                # the records cross PCIe in compact form (~30 bytes per mate instead of 128), like the bench's steps
-                from .packed import CompactMates
-                pack["compact"] = CompactMates(pack["records"], threads=2)
+            # the records cross PCIe in compact form (~30 bytes per mate instead of 128), like the bench's steps
+            from .packed import CompactMates
+            pack["compact"] = CompactMates(pack["records"], threads=2)
         return name, source, pack
 
     # the next sample is mapped / packed on a helper thread while this one is tabulated and written out
     # (three samples ahead on three threads: the serial stretches of one ingest leave cores to the others)
-    ahead = max(1, int(os.environ.get("GK_INGEST_AHEAD", "3")))
+    ahead = 3
     from concurrent.futures import ThreadPoolExecutor
     writer = ThreadPoolExecutor(max_workers=2, thread_name_prefix="gk-write")   # compact hand-off files, off this thread
     writes = []
@@ -130,8 +129,7 @@ def _mapLoop(names, prepare, ahead, gk, gene_len, staging, dindex, index_ref, ex
             compact = pack.pop("compact", None)
             mates = compact.toDevice(copier, wait=True) if compact is not None else copier.put(pack["records"])
             data = extractVariantFromPacked(pack, gk, dev=dev, dindex=dindex, mates=mates)
-            if (compact is not None and not write_json and os.environ.get("GK_HANDOFF", "always") != "lazy"
-                    and os.environ.get("GK_HANDOFF_FORM", "records") == "records"):
+            if compact is not None and not write_json and os.environ.get("GK_HANDOFF", "always") != "lazy":
                 # the hand-off as the compact records that are in host memory anyway (70 MB for 2 M reads) instead of the
                 # tabulated lists fetched back from the device (250 MB): hisat2.writeCompactRecords / loadCompact
                 writes.append(writeCompactRecords(compact, pack, data.tab.novel_base, gk, name + ".npz",

@@ -41,9 +41,9 @@ _default_logs_lock = threading.Lock()
 
 
 def nativeSearch() -> bool:
-    """The steps of a gene's search run inside the library (``gk_search_run``) unless GK_NATIVE_SEARCH=0."""
-    import os
-    return os.environ.get("GK_NATIVE_SEARCH", "1") != "0"
+    """The steps of a gene's search run inside the library (``gk_search_run``); ``addCandidate`` remains as the
+    reference's API for a step with given candidates."""
+    return True
 
 
 _GROUP_CACHE_LOCK = threading.Lock()      # guards the per-gene exon-group caches (AlleleTypingExonFirst)
@@ -572,15 +572,7 @@ class AlleleTyping:
             self.addCandidate()
             self.addHomoResultForCn(cn)
         else:
-            if cn >= 2 and 32 < self._model.n_allele <= self.top_n and self._model.n_rows \
-                    and not self._model.boundOk and not nativeSearch():
-                # Every allele survives the first step, so the second step scores all allele pairs:
-                # the symmetric table is computed first -- its diagonal sum max(L_a, L_a) = sum L_a IS
-                # the first step's column sum (same terms, same summation tree), so no separate
-                # column-sum launch is needed and the second step reads its scores out of the table.
-                self._pair_table = self._model.pairTable()
-                self._colsum_all = np.ascontiguousarray(np.diagonal(self._pair_table))
-            if nativeSearch() and self._model.n_rows:
+            if self._model.n_rows:
                 self._searchNatively(cn)
             else:
                 for _ in range(cn):
@@ -1038,7 +1030,7 @@ class AlleleTyping:
             return False
         seen, pos, neg = self._variantCounts()       # surviving variants only, compacted on the device
         tab = self._readset.tab
-        tables = tab.labelTables() if nativeSearch() else None
+        tables = tab.labelTables()
         if tables is not None:      # labels, the screen of lines 835-840 and the verdict in one native call
             import ctypes as C
             from ._lib import check, lib
@@ -1063,16 +1055,14 @@ class AlleleTyping:
             ent_code = np.concatenate([code[hp], code[hn]])
             ent_neg = np.concatenate([np.zeros(int(hp.sum()), bool), np.ones(int(hn.sum()), bool)])
             ent_cnt = np.concatenate([pos[hp], neg[hn]])
-            if nativeSearch():
-                import ctypes as C
-                from ._lib import check, lib
-                p_, c_ = np.ascontiguousarray(ent_pos, dtype=np.int64), np.ascontiguousarray(ent_code, dtype=np.int64)
-                n_, k_ = np.ascontiguousarray(ent_neg, dtype=np.uint8), np.ascontiguousarray(ent_cnt, dtype=np.int64)
-                verdict = C.c_int32()
-                check(lib().gk_site_verdict(p_.ctypes.data, c_.ctypes.data, n_.ctypes.data, k_.ctypes.data, len(p_), cn,
-                                            C.byref(verdict)))
-                return bool(verdict.value)
-            return self._siteVerdict(ent_pos, ent_code, ent_neg, ent_cnt, cn)
+            import ctypes as C
+            from ._lib import check, lib
+            p_, c_ = np.ascontiguousarray(ent_pos, dtype=np.int64), np.ascontiguousarray(ent_code, dtype=np.int64)
+            n_, k_ = np.ascontiguousarray(ent_neg, dtype=np.uint8), np.ascontiguousarray(ent_cnt, dtype=np.int64)
+            verdict = C.c_int32()
+            check(lib().gk_site_verdict(p_.ctypes.data, c_.ctypes.data, n_.ctypes.data, k_.ctypes.data, len(p_), cn,
+                                        C.byref(verdict)))
+            return bool(verdict.value)
         else:
             site = defaultdict(lambda: defaultdict(int))
             for (vpos, typ, label), np_, nn_ in zip(tab.describe(seen), pos.tolist(), neg.tolist()):

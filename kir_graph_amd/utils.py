@@ -76,3 +76,26 @@ def mergeCN(cn_result_files: list[str], final_result_file: str) -> pd.DataFrame:
     df = df.fillna(0).astype(int)
     df.to_csv(final_result_file, sep="\t")
     return df
+
+
+def _envList(var: str) -> dict[str, str]:
+    """``name`` / ``name=value`` entries of a comma-separated environment variable."""
+    import os
+    out: dict[str, str] = {}
+    for item in os.environ.get(var, "").split(","):
+        item = item.strip()
+        if item:
+            name, _, value = item.partition("=")
+            out[name] = value
+    return out
+
+
+def traceOn(what: str) -> bool:
+    """GK_TRACE lists the development traces that are on (pool, search, ingest, bench): csrc/gk_env.h."""
+    return what in _envList("GK_TRACE")
+
+
+def testHook(name: str, default: str | None = None) -> str | None:
+    """GK_TEST_HOOKS: switches the tests use to force rarely taken paths (csrc/gk_env.h); the value of ``name=value``, ""
+    for a bare ``name``, ``default`` when it is not listed."""
+    return _envList("GK_TEST_HOOKS").get(name, default)

@@ -62,8 +62,8 @@ def test_default_run_reports_the_three_workloads(device):
     """Without --pairs / --method the line is configs[2] exon-first with `em` and `configs1_pv` beside it, each with its
     own legs, serial kernel table, roofline and CPU baseline (here at 1 / 500 of the sizes: the structure, not the
     numbers; the names of the kernels are their own, so the EM kernels and the set sums show under them)."""
-    d = _run(["--steps", "3", "--warmup", "1", "--cpu-pairs", "5000", "--serial-steps", "1", "--legs", "1", "--cli-samples", "0"],
-             env={"GK_BENCH_PAIRS_SCALE": "0.002"}, timeout=900)
+    d = _run(["--steps", "3", "--warmup", "1", "--cpu-pairs", "5000", "--serial-steps", "1", "--legs", "1", "--cli-samples", "0",
+              "--pairs-scale", "0.002"], timeout=900)
     assert d["config"]["allele_strategy"] == "exonfirst" and d["config"]["pairs_per_sample"] == 20000
     assert d["n_gpus"] == 1 and d["value"] > 0 and "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port"
     for name, method, pairs in (("em", "em", 20000), ("configs1_pv", "pv", 2000)):
@@ -81,7 +81,7 @@ def test_default_run_reports_the_three_workloads(device):
 
 def test_two_ranks_on_one_gpu_through_the_file_backend(device):
     d = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--pairs", "20000", "--cpu-pairs", "0", "--serial-steps", "0",
-              "--one-kind"], env={"GK_BENCH_BACKEND": "file"})
+              "--one-kind"], env={"GK_COMM_BACKEND": "file"})
     assert d["n_gpus"] == 2 and d["config"]["rank_barrier"] == "file" and "hbm_resident" not in d
     assert abs(d["value"] - 2 * 2 * 20000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9       # both ranks' reads / the slower rank's time
 

@@ -92,17 +92,15 @@ def test_typing_recovers_the_planted_genotype_and_is_deterministic(full):
 
 def test_forms_of_the_gene_loop_agree_at_full_size(full, monkeypatch):
     """configs[1] typed with the genes of the sample pipelined on marks of one stream (the default; at this size the
-    staging rings go round while marks are outstanding), in lock-step (GK_SAMPLE_PIPELINE=0) and with a thread and a
-    stream per gene (GK_SAMPLE_SEARCH=0): the same bits in every field of every copy-number step of every gene."""
+    staging rings go round while marks are outstanding) and gene after gene (Typing.typing -> typingPerGene: a table and
+    a gk_search_run per gene): the same bits in every field of every copy-number step of every gene."""
+    from kir_graph_amd.kir_typing import Typing, selectKirTypingModel
     sidx, gidx, sample, rec, data = full
     results = {}
-    for name, env in (("pipelined", {}), ("lock-step", {"GK_SAMPLE_PIPELINE": "0"}), ("per gene", {"GK_SAMPLE_SEARCH": "0"})):
-        for k in ("GK_SAMPLE_PIPELINE", "GK_SAMPLE_SEARCH"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        typer, calls, _ = _type(data, sample)
-        results[name] = (calls, typer._result)
+    typer, calls, _ = _type(data, sample)
+    results["pipelined"] = (calls, typer._result)
+    typer = selectKirTypingModel("pv", data, top_n=600, variant_correction=True)
+    results["gene after gene"] = (Typing.typing(typer, sample.gene_cn), typer._result)
     want_calls, want = results["pipelined"]
     for name, (calls, got) in results.items():
         assert calls == want_calls, name

@@ -23,7 +23,6 @@ def _fuzz():
 def test_fixed_seed_slice_of_the_randomised_parity_run(device, monkeypatch):
     from kir_graph_amd.typing_mulit_allele import SEARCH_STATS
     monkeypatch.setenv("GK_SEARCH", "bound")
-    monkeypatch.setenv("GK_NATIVE_SEARCH", "1")
     fp = _fuzz()
     before = dict(SEARCH_STATS)
     t0 = time.time()

@@ -317,7 +317,7 @@ def test_ranks_flag_starts_the_ranks_itself(device, tmp_path):
            "--output-folder", str(two), "--allele-strategy", "pv", "--no-variant-json", "--cn-cohort", "--ranks", "2",
            "--log-level", "WARNING"] + [x for s in sams for x in ("--alignment", s)]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    res = subprocess.run(cmd, env=dict(env, PYTHONPATH=root, GK_THREADS="2"), cwd=root, capture_output=True, text=True,
+    res = subprocess.run(cmd, env=dict(env, PYTHONPATH=root), cwd=root, capture_output=True, text=True,
                          timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     for name in ("cohort.cn.tsv", "cohort.allele.tsv"):

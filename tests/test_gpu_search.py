@@ -172,7 +172,7 @@ def test_leafwise_setsum_equals_the_tiled_form_and_numpy(device, monkeypatch, n_
     ids[-1, :] = n_allele - 1                         # the last column is used
     got = {}
     for form in ("leaves", "tiles"):
-        monkeypatch.setenv("GK_SETSUM", form)
+        monkeypatch.setenv("GK_TEST_HOOKS", f"setsum={form}")
         value, frac = np.empty(n_sets), np.empty((n_sets, c))
         check(lib().gk_setsum(device.ctx, dL.ptr, n_rows, n_rows, ids.ctypes.data, n_sets, c, value.ctypes.data,
                               frac.ctypes.data))

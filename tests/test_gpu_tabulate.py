@@ -202,9 +202,9 @@ def test_both_second_passes_give_the_same_tabulation(device, small_case, monkeyp
         got = []
         for two_walks in (False, True):
             if two_walks:
-                monkeypatch.setenv("GK_TAB_TWO_WALKS", "1")
+                monkeypatch.setenv("GK_TEST_HOOKS", "two_walks")
             else:
-                monkeypatch.delenv("GK_TAB_TWO_WALKS", raising=False)
+                monkeypatch.delenv("GK_TEST_HOOKS", raising=False)
             tab = Tabulation(dindex, rec)
             got.append((tab.offsets().tobytes(), tab.ids().tobytes(), tab.n_novel))
             longest = int(np.diff(tab.offsets()).max())
@@ -371,7 +371,7 @@ def test_a_novel_table_that_fills_up_is_retried_larger(device, small_case, monke
     want = (want_tab.offsets().tolist(), want_tab.ids().tolist(), want_tab.novelKeys().tolist())
     assert want_tab.n_novel > 8          # more than half of 16 slots: the first attempts must fail
     want_tab.close()
-    monkeypatch.setenv("GK_NOVEL_LOG2CAP", "4")
+    monkeypatch.setenv("GK_TEST_HOOKS", "novel_log2cap=4")
     tab = Tabulation(dindex, rec)
     assert (tab.offsets().tolist(), tab.ids().tolist(), tab.novelKeys().tolist()) == want
     tab.close()

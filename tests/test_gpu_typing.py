@@ -131,25 +131,21 @@ def test_bounded_search_equals_exact_search(device, small_case, monkeypatch):
     results = {}
     from kir_graph_amd.typing_mulit_allele import SEARCH_STATS
     stats = {}
-    # exact = float64 sums for every candidate, python host (the round-1 path); the others must give its bits:
-    # the integer bound, and the search loop run natively inside the library (gk_search_run), bounded or not
-    # ("exact" also keeps the per-gene error correction / empty-read removal; the others take them from the one
-    # pass over the whole sample, gk_sample_prepare)
-    for mode, search, native in (("exact", "exact", "0"), ("bound", "bound", "0"), ("native", "bound", "1"),
-                                 ("native_exact", "exact", "1")):
+    # exact = float64 sums for every candidate; the others must give its bits: the integer bound through the whole-sample
+    # calls (gk_sample_search) and through the gene-after-gene path (Typing.typing -> typingPerGene -> gk_search_run)
+    from kir_graph_amd.kir_typing import Typing
+    for mode, search, per_gene in (("exact", "exact", False), ("bound", "bound", False), ("per_gene", "bound", True),
+                                   ("per_gene_exact", "exact", True)):
         monkeypatch.setenv("GK_SEARCH", search)
-        monkeypatch.setenv("GK_NATIVE_SEARCH", native)
-        monkeypatch.setenv("GK_BATCH_PREAMBLE", "0" if mode == "exact" else "1")
-        monkeypatch.setenv("GK_THREADS", "1")
         before = dict(SEARCH_STATS)
         for method, top_n in (("full", 600), ("full", 7), ("exonfirst_1", 60)):
             typer = selectKirTypingModel(method, data, top_n=top_n, variant_correction=True)
-            calls = typer.typing(gene_cn)
+            calls = Typing.typing(typer, gene_cn) if per_gene else typer.typing(gene_cn)
             results[(mode, method, top_n)] = (calls, typer._result)
         stats[mode] = {k: SEARCH_STATS[k] - before[k] for k in before}
     # the comparison below covers both routes of a step only if both were taken: steps served by the integer bound
     # and steps it handed back to the exact kernels (ties across a cut / rows equal in all three keys)
-    for mode in ("bound", "native"):
+    for mode in ("bound", "per_gene"):
         assert stats[mode]["bounded"] > 0 and stats[mode]["redone_exactly"] > 0, (mode, stats)
     for (mode, method, top_n), (calls, res) in results.items():
         if mode == "exact":
@@ -250,25 +246,21 @@ def test_index_table_equals_the_float_table(device, small_case, monkeypatch):
 
 @pytest.mark.gpu
 def test_forms_of_the_sample_search_and_of_the_factor_agree(device, small_case, monkeypatch):
-    """A whole sample typed four ways gives the same bits in every field of every copy-number step: the gene loop
-    pipelined on one stream (marks; the default) or in lock-step (GK_SAMPLE_PIPELINE=0), the factor of the
-    compatibility kernel chosen by bit-field selects (default) or by one fused multiply-add (GK_COMPAT_FORM=fma), and
-    the sample preamble on the urgent stream or on the lane's own."""
+    """A whole sample typed two ways gives the same bits in every field of every copy-number step: all genes pipelined on
+    one stream in one library call (gk_sample_search: the default), or gene after gene (Typing.typing -> typingPerGene:
+    a table and a gk_search_run per gene).  (The lock-step form of the gene loop serves index tables:
+    test_index_table_equals_the_float_table.)"""
     from kir_graph_amd.hisat2 import extractVariant, pairLines
     monkeypatch.setenv("GK_SEARCH", "bound")
     sidx, gidx, sample = small_case
     data = extractVariant(pairLines(synth.toSamLines(sample)), gidx, dev=device)
     gene_cn = {g: (k % 4) + 1 for k, g in enumerate(sidx.genes)}
     results = {}
-    for name, env in (("default", {}), ("lock-step", {"GK_SAMPLE_PIPELINE": "0"}), ("fma", {"GK_COMPAT_FORM": "fma"}),
-                      ("plain preamble", {"GK_URGENT_PREAMBLE": "0"})):
-        for k in ("GK_SAMPLE_PIPELINE", "GK_COMPAT_FORM", "GK_URGENT_PREAMBLE"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    from kir_graph_amd.kir_typing import Typing
+    for name in ("default", "gene after gene"):
         typer = selectKirTypingModel("full", data, top_n=600, variant_correction=True)
         assert typer._wholeSample()
-        results[name] = (typer.typing(gene_cn), typer._result)
+        results[name] = (typer.typing(gene_cn) if name == "default" else Typing.typing(typer, gene_cn), typer._result)
     want_calls, want = results["default"]
     assert any(len(steps) > 1 for steps in want.values())
     for name, (calls, got) in results.items():
@@ -288,7 +280,6 @@ def test_new_values_settle_per_gene_and_give_the_same_bits(device, small_case, m
     form's and the oracle's.  The samples grow (more pairs, more errors), so later ones do bring new products."""
     from kir_graph_amd.hisat2 import extractVariant, pairLines
     monkeypatch.setenv("GK_SEARCH", "bound")
-    monkeypatch.delenv("GK_SAMPLE_PIPELINE", raising=False)
     sidx, gidx, _ = small_case
     rewritten, n_genes = [], []
     for k, (pairs, err) in enumerate(((1500, 0.0), (2500, 0.001), (4000, 0.004), (4000, 0.004), (6000, 0.01))):
@@ -321,10 +312,10 @@ def test_em_of_all_genes_in_one_call_equals_the_per_gene_calls(tabulated, monkey
     same loop), read counts, iterations, distinct sets -- and the same calls and warnings."""
     data, ref, sample = tabulated
     got = {}
+    from kir_graph_amd.kir_typing import Typing
     for form in ("1", "0"):
-        monkeypatch.setenv("GK_SAMPLE_EM", form)
         typer = selectKirTypingModel("em", data)
-        calls = typer.typing(sample.gene_cn)
+        calls = typer.typing(sample.gene_cn) if form == "1" else Typing.typing(typer, sample.gene_cn)
         got[form] = (calls, {g: [(r.allele, r.count, r.prob, r.cn) for r in rep] for g, rep in typer._result.items()},
                      dict(typer.em_info))
     assert got["1"][0] == got["0"][0]
@@ -341,11 +332,12 @@ def test_exon_first_of_all_genes_in_two_calls_equals_the_per_gene_path(tabulated
     (AlleleTypingExonFirst on a thread per gene): exon steps, candidate steps, the merged ranking, calls, warnings."""
     data, ref, sample = tabulated
     got = {}
+    from kir_graph_amd.kir_typing import Typing
     for form in ("1", "0"):
-        monkeypatch.setenv("GK_SAMPLE_EXONFIRST", form)
         typer = selectKirTypingModel(method, data, top_n=600, variant_correction=True)
-        assert typer._wholeSampleExonFirst() == (form == "1")
-        got[form] = (typer.typing(sample.gene_cn), typer._result, typer.getAllPossibleTyping())
+        assert typer._wholeSampleExonFirst()
+        calls = typer.typing(sample.gene_cn) if form == "1" else Typing.typing(typer, sample.gene_cn)
+        got[form] = (calls, typer._result, typer.getAllPossibleTyping())
     assert got["1"][0] == got["0"][0]
     assert got["1"][2] == got["0"][2]
     assert list(got["1"][1]) == list(got["0"][1])

@@ -864,7 +864,7 @@ def test_record_index_is_the_same_however_the_stream_is_cut(tmp_path, monkeypatc
     good = write(raw, "good.bam")
     want = None
     for n_seg in ("1", "2", "5", "64", "1000", "100000"):
-        monkeypatch.setenv("GK_BAM_INDEX_SEGMENTS", n_seg)
+        monkeypatch.setenv("GK_TEST_HOOKS", f"bam_segments={n_seg}")
         got = b"".join(packed.bamChunks(good, name_sorted=False))
         want = want or got
         assert got == want, n_seg
@@ -882,7 +882,7 @@ def test_record_index_is_the_same_however_the_stream_is_cut(tmp_path, monkeypatc
         bad[at:at + 4] = struct.pack("<I", value if value is not None else size + 9)
         path = write(bytes(bad), f"bad{which}.bam")
         for n_seg in ("1", "3", "64", "1000"):
-            monkeypatch.setenv("GK_BAM_INDEX_SEGMENTS", n_seg)
+            monkeypatch.setenv("GK_TEST_HOOKS", f"bam_segments={n_seg}")
             with pytest.raises(_lib.GkError, match="malformed BAM"):
                 list(packed.bamChunks(path, name_sorted=False))
 
@@ -1113,7 +1113,7 @@ def test_pipeline_defaults_follow_the_cores_of_the_rank(monkeypatch):
     """cohort.pipelineDefaults: sample lanes x searches at a time by the host cores a rank has (the affinity, shared by the
     ranks of the node unless the rank was pinned to cores of its own); whatever the user set stays."""
     from kir_graph_amd import cohort
-    for name in ("GK_SAMPLE_LANES", "GK_SEARCH_SLOTS", "GK_WAIT_POLICY", "GK_URGENT_PREAMBLE", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
+    for name in ("GK_SAMPLE_LANES", "GK_SEARCH_SLOTS", "GK_WAIT_POLICY", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
                  "GK_PRIVATE_CORES"):
         monkeypatch.delenv(name, raising=False)
     monkeypatch.setattr(os, "cpu_count", lambda: 64)
@@ -1140,10 +1140,5 @@ def test_pipeline_defaults_follow_the_cores_of_the_rank(monkeypatch):
     monkeypatch.delenv("GK_SEARCH_SLOTS", raising=False)
     cohort.pipelineDefaults(cores=16)
     assert os.environ["GK_SAMPLE_LANES"] == "2" and os.environ["GK_SEARCH_SLOTS"] == "3"
-    monkeypatch.delenv("GK_SAMPLE_LANES", raising=False)
-    monkeypatch.delenv("GK_SEARCH_SLOTS", raising=False)
-    monkeypatch.delenv("GK_URGENT_PREAMBLE", raising=False)
-    cohort.pipelineDefaults(procs=2, cores=16)          # several worker processes on one GPU: two lanes each
-    assert os.environ["GK_SAMPLE_LANES"] == "2" and "GK_SEARCH_SLOTS" not in os.environ
-    for name in ("GK_SAMPLE_LANES", "GK_SEARCH_SLOTS", "GK_WAIT_POLICY", "GK_URGENT_PREAMBLE"):
+    for name in ("GK_SAMPLE_LANES", "GK_SEARCH_SLOTS", "GK_WAIT_POLICY"):
         os.environ.pop(name, None)                      # set by pipelineDefaults itself, not through monkeypatch

@@ -2,7 +2,6 @@
 """Dev tool: launch geometry of one bench step (maxsum / fraction calls per gene)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GK_THREADS", "1")
 import bench
 from kir_graph_amd import _lib, kir_typing
 from kir_graph_amd.engine import DeviceIndex, Tabulation

@@ -20,7 +20,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 KERNELS="compat_kernel tab_count tab_expand minsum_sad setsum_leaves colsum_chunks count_ids_genes flag_nonempty fraction_chunks maxsum_chunks patch_pending em_sets_groups em_sets_verify em_sets_emit em_kernel_genes"
 cd /tmp && export TMPDIR=/tmp
-export GK_THREADS=1 GK_PREFETCH=0 GK_SAMPLE_LANES=1 GK_SAMPLE_STREAMS=1
+export GK_PREFETCH=0 GK_SAMPLE_LANES=1
 for W in $WORKLOADS; do
   case $W in
     cfg2_*) PAIRS=10000000; STEPS=6; PSTEPS=3;;
@@ -52,7 +52,7 @@ for W in $WORKLOADS; do
     cp $f $R/profiles/${TAG}_traffic_${W}_$k.json
   done
 done
-unset GK_THREADS GK_PREFETCH GK_SAMPLE_LANES GK_SAMPLE_STREAMS      # the serial mode was for the profiler only
+unset GK_PREFETCH GK_SAMPLE_LANES      # the serial mode was for the profiler only
 if [ "$RUN_BENCH" = "1" ]; then
   cd $R
   python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err

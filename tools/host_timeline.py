@@ -1,4 +1,4 @@
-"""Timeline of the host threads of ONE bench worker process (GK_BENCH_TRACE=1 GK_SEARCH_TIMING=1, stderr of bench.py):
+"""Timeline of the host threads of ONE bench worker process (GK_TRACE=bench,search, stderr of bench.py):
 per sample the staging (copy + tabulation), the Python before the search call, the call, the Python after it; and how
 the searches of the lanes overlap.     python3 tools/host_timeline.py bench.err [samples to skip at the start]
 """

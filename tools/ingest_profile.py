@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev tool: the native BAM ingest alone (coordinate-sorted BAM -> packed records, no GPU work) on a synthetic sample:
-wall time and process CPU time of `packed.packBam`, and the phases the library reports (GK_INGEST_TIMING=1), with one
+wall time and process CPU time of `packed.packBam`, and the phases the library reports (GK_TRACE=ingest), with one
 thread and with the default thread count.     python tools/ingest_profile.py [pairs, default 500000] [repeats, default 4]
 """
 import os
@@ -46,7 +46,7 @@ def main():
         packed.writeBam(path, "\n".join(header + synth.toSamLines(s)) + "\n")
         print(f"wrote {path} in {time.time() - t:.0f}s, {os.path.getsize(path) / 1e6:.0f} MB")
     for threads in ("1", None):
-        env = dict(os.environ, GK_INGEST_TIMING="1")
+        env = dict(os.environ, GK_TRACE="ingest")
         if threads:
             env["GK_PACK_THREADS"] = threads
         print(f"== GK_PACK_THREADS={threads or 'default'}")

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool: where one process spends a sample's typing time -- cProfile of the typing of a few bench samples on ONE
-gene thread (GK_THREADS=1), native calls (ctypes) against interpreter time."""
+native calls (ctypes) against interpreter time."""
 import cProfile, os, pstats, sys, time
-os.environ.setdefault("GK_THREADS", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from kir_graph_amd import _lib

@@ -2,7 +2,6 @@
 """Dev tool: cProfile of one single-threaded bench step sorted by own time (host hot spots)."""
 import cProfile, io, os, pstats, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["GK_THREADS"] = "1"
 import bench
 from kir_graph_amd import _lib, kir_typing
 from kir_graph_amd.engine import DeviceIndex, Tabulation

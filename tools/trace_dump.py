@@ -1,4 +1,4 @@
-"""Dev tool: the [trace] lines of a bench run (GK_BENCH_TRACE=1) as a table relative to the first event, one line per
+"""Dev tool: the [trace] lines of a bench run (GK_TRACE=bench) as a table relative to the first event, one line per
 stage of a sample: which thread, from when to when (ms).   python3 tools/trace_dump.py bench.err [last N lines]"""
 import re
 import sys
