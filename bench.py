@@ -435,6 +435,7 @@ def measure(rc: RankContext, inputs, pairs: int, method: str, opts) -> dict:
     """One workload on this rank: warm-up, the timed legs (two kinds, ``opts.legs`` each), the command line's typing stage
     and the one-process serial pass the roofline is taken from.  Returns what the JSON object of the workload is made of."""
     from kir_graph_amd.typing_mulit_allele import sharedLogTable, SEARCH_STATS
+    from kir_graph_amd.utils import traceOn
     args, dev, dindex, gidx, comm = rc.args, rc.dev, rc.dindex, rc.gidx, rc.comm
     resident = [pinned.toDevice(dev) for pinned, _, _ in inputs]
     dev.sync()

@@ -37,7 +37,7 @@ constexpr int kLocalSlots = 2048;        // the workgroup's own table of (hash, 
 constexpr int kLocalProbes = 8;
 constexpr uint32_t kTableProbes = 1u << 12;
 constexpr size_t kLocalBytes = (size_t)kLocalSlots * (8 + 4 + 4);
-constexpr size_t kMaskLdsMax = 120 * 1024;    // bit rows of a gene staged in LDS up to this size, read from HBM / L2 beyond
+constexpr size_t kMaskLdsMax = 100 * 1024;    // bit rows of a gene staged in LDS up to this size, read from HBM / L2 beyond
 
 struct EmSetsJob {     // one gene of a launch (blockIdx.y)
   const int32_t* rows;
@@ -47,7 +47,7 @@ struct EmSetsJob {     // one gene of a launch (blockIdx.y)
   uint32_t* sets;                  // [n_rows][words]
   unsigned long long* tag;         // the gene's table of hashes (nullptr: sets only), 0 = free
   uint32_t* cnt;
-  uint32_t* row;                   // first pair (smallest position in `rows`) of the hash
+  uint32_t* row;                   // a pair of the hash (the one whose workgroup claimed the slot): what the others are compared with
   uint32_t slot_mask, seed;
   uint32_t* flags;                 // bit 0: table full; bit 1: two different sets with one hash
   uint32_t* out_sets;              // emit: distinct sets, multiplicities, their number
@@ -94,7 +94,7 @@ __device__ inline void table_add(const EmSetsJob& J, uint64_t h, uint32_t n, uin
     if (old == 0ull) old = atomicCAS(&J.tag[s], 0ull, (unsigned long long)h);
     if (old == 0ull || old == h) {
       atomicAdd(&J.cnt[s], n);
-      atomicMin(&J.row[s], first_row);
+      if (old == 0ull) J.row[s] = first_row;      // whoever claims the slot names the pair the others are compared with
       return;
     }
     s = (s + 1) & J.slot_mask;
@@ -116,7 +116,7 @@ struct LocalTable {
       if (old == 0ull) old = atomicCAS(&tag[s], 0ull, (unsigned long long)h);
       if (old == 0ull || old == h) {
         atomicAdd(&cnt[s], 1u);
-        atomicMin(&row[s], i);
+        if (old == 0ull) row[s] = i;
         return;
       }
       s = (s + 1) & (kLocalSlots - 1);
@@ -129,41 +129,63 @@ struct LocalTable {
   }
 };
 
-// the rows of job J that this workgroup takes: their candidate sets written, their hashes counted
-template <int G>
+// the rows of job J that this workgroup takes: their candidate sets written, their hashes counted.  A group of G lanes
+// per pair, TWO words of both mate sets per lane (a 64-bit LDS read per id and lane: the LDS pipe -- the hand-round of the
+// ids and the row reads -- is what bounds this kernel, and a wave carries twice the pairs this way).  `M`: the bit rows,
+// `stride` words per variant (even in LDS, so that a lane's pair of words is one aligned 8-byte read).
+template <int G, bool kLds>
 __device__ inline void sets_of_rows(const EmSetsJob& J, const uint32_t* __restrict__ off, const uint32_t* __restrict__ ids,
-                                    const uint32_t* M, LocalTable& lt) {
+                                    const uint32_t* M, int stride, LocalTable& lt) {
   constexpr int kGroups = kSetThreads / G;
   const int tid = threadIdx.x, l = tid & (G - 1), grp = tid / G, wl = tid & 63;
   const int words = J.words;
   const uint32_t vbeg = (uint32_t)J.vbeg, n_span = (uint32_t)J.n_span;
-  const bool word_lane = l < words;
+  const bool lo_lane = 2 * l < words, hi_lane = 2 * l + 1 < words;
   const bool hashing = J.tag != nullptr;
-  for (int64_t base = (int64_t)blockIdx.x * kGroups; base < J.n_rows; base += (int64_t)J.n_blocks * kGroups) {
+  // The loads of a pair depend on each other (position -> list offsets -> ids) and the kernel runs at four waves per SIMD
+  // (the bit rows take most of the LDS): the offsets of the group's NEXT pair are requested before this pair's lists are
+  // walked, and a lane takes FOUR ids per request (4 G ids of a list in flight at once instead of G).
+  auto offsets_of = [&](int64_t i, uint32_t (&o)[5]) {
+    o[0] = o[1] = o[2] = o[3] = o[4] = 0u;
+    if (i < J.n_rows) {      // list order in the CSR: lpv, rpv, lnv, rnv -- back to back
+      const uint32_t* p = off + 4 * (int64_t)J.rows[i];
+      const uint4 q = *reinterpret_cast<const uint4*>(p);
+      o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; o[4] = p[4];
+    }
+  };
+  const int64_t step = (int64_t)J.n_blocks * kGroups;
+  uint32_t nxt[5];
+  offsets_of((int64_t)blockIdx.x * kGroups + grp, nxt);
+  for (int64_t base = (int64_t)blockIdx.x * kGroups; base < J.n_rows; base += step) {
     const int64_t i = base + grp;
     const bool live = i < J.n_rows;
-    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
-    if (live) {      // list order in the CSR: lpv, rpv, lnv, rnv -- back to back
-      const uint32_t* o = off + 4 * (int64_t)J.rows[i];
-      const uint4 q = *reinterpret_cast<const uint4*>(o);
-      o0 = q.x; o1 = q.y; o2 = q.z; o3 = q.w; o4 = o[4];
-    }
-    uint32_t side0 = (word_lane && o1 > o0) ? 0xFFFFFFFFu : 0u;      // a mate without positives names nobody
-    uint32_t side1 = (word_lane && o2 > o1) ? 0xFFFFFFFFu : 0u;
-    // one list at a time (its sign and its mate are then fixed: an id costs the row's address, one LDS read and one
-    // AND / AND-NOT): the group reads G ids of the list, coalesced, and hands them round
-    auto walk = [&](uint32_t begin, uint32_t end, uint32_t& side, bool negative) {
-      for (uint32_t k0 = begin; k0 < end; k0 += G) {
-        const uint32_t idv = k0 + (uint32_t)l < end ? ids[k0 + l] : 0xFFFFFFFFu;      // past the end: outside every gene
+    const uint32_t o0 = nxt[0], o1 = nxt[1], o2 = nxt[2], o3 = nxt[3], o4 = nxt[4];
+    offsets_of(i + step, nxt);
+    // a mate without positives names nobody; words past the gene's last one stay zero
+    uint2 side0 = make_uint2((lo_lane && o1 > o0) ? 0xFFFFFFFFu : 0u, (hi_lane && o1 > o0) ? 0xFFFFFFFFu : 0u);
+    uint2 side1 = make_uint2((lo_lane && o2 > o1) ? 0xFFFFFFFFu : 0u, (hi_lane && o2 > o1) ? 0xFFFFFFFFu : 0u);
+    // one list at a time (its sign and its mate are then fixed): the group reads 4 G ids of the list and hands them round
+    auto walk = [&](uint32_t begin, uint32_t end, uint2& side, bool negative) {
+      for (uint32_t k0 = begin; k0 < end; k0 += 4 * G) {
+        uint32_t idv[4];
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-          const uint32_t rel = (uint32_t)__shfl(idv, j, G) - vbeg;
-          uint32_t m = 0u;                                   // a variant outside the index (novel) has no allele
-          if (rel < n_span && word_lane) m = M[rel * (uint32_t)words + (uint32_t)l];
-          // positives intersect (a novel one leaves nobody); negatives of the index subtract (a novel one, or the
-          // padding past the list's end: m == 0, nothing happens)
-          if (negative) side &= ~m;
-          else if (k0 + (uint32_t)j < end) side &= m;
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t k = k0 + 4u * (uint32_t)l + (uint32_t)q;
+          idv[q] = k < end ? ids[k] : 0xFFFFFFFFu;      // past the end: outside every gene
+        }
+#pragma unroll
+        for (int j = 0; j < 4 * G; ++j) {
+          if (k0 + (uint32_t)j >= end) break;            // uniform within the group
+          const uint32_t rel = (uint32_t)__shfl(idv[j & 3], j >> 2, G) - vbeg;
+          uint2 m = make_uint2(0u, 0u);                      // a variant outside the index (novel) has no allele
+          if (rel < n_span && lo_lane) {
+            const uint32_t* at = M + rel * (uint32_t)stride + 2u * (uint32_t)l;
+            if (kLds) m = *reinterpret_cast<const uint2*>(at);      // the padding word of an odd gene is zero
+            else { m.x = at[0]; m.y = hi_lane ? at[1] : 0u; }
+          }
+          // positives intersect (a novel one leaves nobody); negatives of the index subtract (a novel one: nothing)
+          if (negative) { side.x &= ~m.x; side.y &= ~m.y; }
+          else { side.x &= m.x; side.y &= m.y; }
         }
       }
     };
@@ -171,13 +193,15 @@ __device__ inline void sets_of_rows(const EmSetsJob& J, const uint32_t* __restri
     walk(o1, o2, side1, false);
     walk(o2, o3, side0, true);
     walk(o3, o4, side1, true);
-    const uint32_t twice = side0 & side1;
-    const unsigned long long named = __ballot(twice != 0u);
+    const uint2 twice = make_uint2(side0.x & side1.x, side0.y & side1.y);
+    const unsigned long long named = __ballot((twice.x | twice.y) != 0u);
     const bool both = ((named >> (wl & ~(G - 1))) & ((1ull << G) - 1ull)) != 0ull;
-    const uint32_t w = both ? twice : (side0 | side1);
-    if (live && word_lane) J.sets[i * words + l] = w;
+    const uint2 w = both ? twice : make_uint2(side0.x | side1.x, side0.y | side1.y);
+    if (live && lo_lane) J.sets[i * words + 2 * l] = w.x;
+    if (live && hi_lane) J.sets[i * words + 2 * l + 1] = w.y;
     if (hashing) {
-      const uint64_t h = finish_hash(group_sum<G>(word_lane ? mix_word(w, l, J.seed) : 0ull));
+      const uint64_t mine = (lo_lane ? mix_word(w.x, 2 * l, J.seed) : 0ull) + (hi_lane ? mix_word(w.y, 2 * l + 1, J.seed) : 0ull);
+      const uint64_t h = finish_hash(group_sum<G>(mine));
       if (live && l == 0) lt.add(J, h, (uint32_t)i);
     }
   }
@@ -193,12 +217,16 @@ __global__ __launch_bounds__(kSetThreads) void em_sets_groups(const EmSetsJob* _
                 (uint32_t*)(em_lds + (size_t)kLocalSlots * 12)};
   uint32_t* lmask = (uint32_t*)(em_lds + kLocalBytes);
   const int tid = threadIdx.x;
+  const int stride = (J.words + 1) & ~1;      // rows of an even number of words in LDS
   if (J.tag) lt.clear(tid);
   if (J.mask_in_lds)
-    for (int e = tid; e < J.n_span * J.words; e += kSetThreads) lmask[e] = J.mask[e];
+    for (int e = tid; e < J.n_span * stride; e += kSetThreads) {
+      const int v = e / stride, w = e - v * stride;
+      lmask[e] = w < J.words ? J.mask[v * J.words + w] : 0u;
+    }
   __syncthreads();
-  if (J.mask_in_lds) sets_of_rows<G>(J, off, ids, lmask, lt);      // two copies of the loop: LDS reads / global reads
-  else sets_of_rows<G>(J, off, ids, J.mask, lt);
+  if (J.mask_in_lds) sets_of_rows<G, true>(J, off, ids, lmask, stride, lt);      // two copies of the loop: LDS reads / global reads
+  else sets_of_rows<G, false>(J, off, ids, J.mask, J.words, lt);
   __syncthreads();
   if (J.tag) lt.flush(J, tid);
 }
@@ -407,7 +435,8 @@ __global__ __launch_bounds__(kEmThreads) void em_kernel_genes(const EmGene* __re
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-int lanes_per_pair(int words) { return words <= 4 ? 4 : words <= 8 ? 8 : 16; }
+int lanes_per_pair(int words) { return words <= 4 ? 4 : words <= 8 ? 8 : 16; }      // one word per lane (hash / verify)
+int lanes_per_pair2(int words) { return words <= 4 ? 2 : words <= 8 ? 4 : 8; }      // two words per lane (candidate sets)
 
 uint32_t blocks_for(int64_t n_rows, int G) {
   const int64_t per_block = (int64_t)(kSetThreads / G) * 16;      // at least 16 rounds of rows per workgroup
@@ -430,7 +459,7 @@ Geometry geometry_of(const std::vector<EmSetsJob>& jobs) {
     words = std::max(words, j.words);
     g.blocks = std::max(g.blocks, j.n_blocks);
     g.slots = std::max(g.slots, j.slot_mask);
-    if (j.mask_in_lds) g.lds = std::max(g.lds, kLocalBytes + (size_t)j.n_span * j.words * sizeof(uint32_t));
+    if (j.mask_in_lds) g.lds = std::max(g.lds, kLocalBytes + (size_t)j.n_span * (size_t)((j.words + 1) & ~1) * sizeof(uint32_t));
   }
   g.G = lanes_per_pair(words);
   return g;
@@ -440,7 +469,7 @@ Geometry geometry_of(const std::vector<EmSetsJob>& jobs) {
 int launch_sets(gk_ctx* ctx, gk_tab* tab, const std::vector<EmSetsJob>& jobs, const EmSetsJob* d_jobs) {
   const Geometry geo = geometry_of(jobs);
   int rc = GK_OK;
-  by_group(geo.G, [&](auto g) {
+  auto go = [&](auto g) {
     constexpr int G = decltype(g)::value;
     if (geo.lds > 48 * 1024 && hipFuncSetAttribute((const void*)em_sets_groups<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)geo.lds) != hipSuccess) {
@@ -448,9 +477,15 @@ int launch_sets(gk_ctx* ctx, gk_tab* tab, const std::vector<EmSetsJob>& jobs, co
       rc = GK_ERR_HIP;
       return;
     }
+    // the workgroups of a gene were counted for groups of geo.G lanes: with half as many lanes per pair a workgroup
+    // takes twice the pairs per round -- the same grid then makes eight rounds instead of sixteen
     GK_PROF(ctx, "em_sets_groups", GK_KERNEL(em_sets_groups<G>, dim3(geo.blocks, (unsigned)jobs.size()), dim3(kSetThreads),
                                              geo.lds, ctx->stream, d_jobs, tab->d_off, tab->d_ids));
-  });
+  };
+  const int G2 = geo.G / 2;      // two words per lane
+  if (G2 == 2) go(std::integral_constant<int, 2>());
+  else if (G2 == 4) go(std::integral_constant<int, 4>());
+  else go(std::integral_constant<int, 8>());
   return rc;
 }
 
