@@ -1142,3 +1142,70 @@ def test_pipeline_defaults_follow_the_cores_of_the_rank(monkeypatch):
     assert os.environ["GK_SAMPLE_LANES"] == "2" and os.environ["GK_SEARCH_SLOTS"] == "3"
     for name in ("GK_SAMPLE_LANES", "GK_SEARCH_SLOTS", "GK_WAIT_POLICY"):
         os.environ.pop(name, None)                      # set by pipelineDefaults itself, not through monkeypatch
+
+
+def test_trace_and_test_hook_lists(monkeypatch):
+    """GK_TRACE / GK_TEST_HOOKS are comma-separated lists (csrc/gk_env.h reads them the same way on the native side)."""
+    from kir_graph_amd.utils import testHook, traceOn
+    monkeypatch.delenv("GK_TRACE", raising=False)
+    monkeypatch.delenv("GK_TEST_HOOKS", raising=False)
+    assert not traceOn("pool") and testHook("two_walks") is None and testHook("setsum", "leaves") == "leaves"
+    monkeypatch.setenv("GK_TRACE", "pool, search")
+    assert traceOn("pool") and traceOn("search") and not traceOn("ingest") and not traceOn("poo")
+    monkeypatch.setenv("GK_TEST_HOOKS", "two_walks,novel_log2cap=4,setsum=tiles")
+    assert testHook("two_walks") == "" and testHook("novel_log2cap") == "4" and testHook("setsum") == "tiles"
+    assert testHook("bam_segments") is None and testHook("novel") is None
+
+
+def test_roofline_entry_is_the_largest_priced_kernel():
+    """roofmodel.dominant: kernels are timed under their own names, so on a tiny sample a launch-bound kernel without a
+    model can be the largest by time -- the entry is then the largest PRICED one, the other is named beside it."""
+    from kir_graph_amd import roofmodel
+    prof = {"scan_tiles": (10, 5.0), "compat_kernel": (2, 3.0), "tab_count": (1, 1.0), "em_sets_groups": (1, 0.5)}
+    log = [("compat_kernel", 1000, 100, 60000.0, 8), ("compat_kernel", 1000, 100, 60000.0, 8), ("tab_count", 500, 480, 30000),
+           ("em_sets_groups", 1000, 60000.0, 4000)]
+    r = roofmodel.dominant(prof, log)
+    assert r["kernel"] == "compat_kernel" and r["largest_kernel_by_time"] == "scan_tiles"
+    assert r["bound"] == "valu" and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert "em_sets_groups" not in r.get("other_kernels", {}) or r["other_kernels"]["em_sets_groups"]["bound"] == "hbm"
+    by, ops = roofmodel.emSetsLaunch(1000, 60000.0, 4000)
+    assert by == 24.0 * 1000 + 4.0 * 60000.0 + 4.0 * 4000 and ops == 0.0
+    step = roofmodel.stepRoofline(log, 1, 2.0)
+    assert step["kernels"]["em_sets_groups"]["bytes_per_step"] == by
+
+
+def test_samples_are_admitted_to_the_lanes_by_their_footprint():
+    """cohort.SampleTyper: a sample starts when the samples in flight leave room for its estimated HBM footprint; one sample
+    always may; a sample that is still a file (no tabulation to size) is not held back."""
+    import threading
+    import time
+    from types import SimpleNamespace
+    from kir_graph_amd import cohort
+
+    def fake(n_valid, n_alleles=100, n_genes=2):
+        tab = SimpleNamespace(n_valid=n_valid, n_ids=60 * n_valid, n_pairs=n_valid, mates=None, dev=None)
+        return SimpleNamespace(tab=tab, index=SimpleNamespace(tables=[SimpleNamespace(n_allele=n_alleles)] * n_genes))
+
+    big = fake(1_000_000)
+    fp = cohort.sampleFootprint(big, "pv")
+    assert fp > 9.2 * 100 * 1_000_000 and cohort.sampleFootprint(big, "exonfirst_1") > 1.9 * fp - 1e9
+    assert cohort.sampleFootprint(big, "em") < fp / 3 and cohort.sampleFootprint("s.variant.npz", "pv") == 0      # lists dominate the EM
+    typer = cohort.SampleTyper("pv", lanes=3)
+    typer._budget = int(2.5 * fp)
+    a, b = typer._admit(big), typer._admit(big)            # two fit
+    assert a == b == fp and typer._inflight_bytes == 2 * fp
+    got = []
+    th = threading.Thread(target=lambda: got.append(typer._admit(big)))     # the third waits for room
+    th.start()
+    time.sleep(0.3)
+    assert th.is_alive() and not got
+    typer._release(a)
+    th.join(5)
+    assert got == [fp] and typer._inflight_bytes == 2 * fp
+    assert typer._admit("sample.variant.npz") == 0                          # a file: nothing to size
+    typer._release(b)
+    typer._release(fp)
+    typer._budget = 1                                                       # smaller than any sample: one at a time still runs
+    assert typer._admit(big) == fp
+    typer._release(fp)
+    typer.close()
