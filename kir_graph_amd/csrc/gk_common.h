@@ -121,6 +121,8 @@ size_t gk_stage_direct();
 // them delivered to their destinations; gk_fetch = queue + wait.  `dst` must stay valid until the delivery.
 hipError_t gk_fetch_queue(gk_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
 hipError_t gk_fetch_wait(gk_ctx* ctx);
+// a slot of the pinned result ring that a kernel writes itself (no copy): see gk_runtime.hip
+hipError_t gk_fetch_direct(gk_ctx* ctx, void* dst, size_t bytes, void** dev_out);
 // A mark is a point of the stream: gk_fetch_wait_mark returns when the stream has passed it, with every copy queued
 // before it delivered -- work queued after the mark keeps running, so a caller that drives several independent
 // sequences on one stream (the genes of a sample, gk_sample_search) waits for one without draining the others.

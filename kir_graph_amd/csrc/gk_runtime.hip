@@ -316,6 +316,22 @@ hipError_t gk_fetch_queue(gk_ctx* ctx, void* dst, const void* src_dev, size_t by
   return hipMemcpyAsync((char*)ctx->fetch_ring.base + off, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
 }
 
+// A result that a kernel writes ITSELF into the pinned ring (device-visible host memory): no copy is queued -- a copy per
+// fetch was ~85 runtime calls and as many 5 us copy kernels per configs[1] sample.  `*dev_out` is where the kernel
+// (queued on this context's stream by the caller, after this call) stores `bytes` bytes; they are delivered to `dst`
+// like a queued copy when the stream has passed the next mark / wait.  Only for results up to gk_stage_direct() bytes
+// that ONE kernel writes once (state that kernels update with atomics stays in device memory and is copied).
+hipError_t gk_fetch_direct(gk_ctx* ctx, void* dst, size_t bytes, void** dev_out) {
+  *dev_out = nullptr;
+  if (!bytes || bytes > kStageDirect) return hipErrorInvalidValue;
+  size_t off = 0;
+  hipError_t e = ring_take(ctx, ctx->fetch_ring, (bytes + 63) / 64 * 64, (size_t)8 << 20, &off);
+  if (e != hipSuccess) return e;
+  ctx->fetches.push_back({dst, off, bytes, ctx->fetch_ring.head});
+  *dev_out = (char*)ctx->fetch_ring.base + off;
+  return hipSuccess;
+}
+
 hipError_t gk_fetch_wait(gk_ctx* ctx) { return drain(ctx, true); }
 
 void gk_fetch_cancel(gk_ctx* ctx) { (void)drain(ctx, false); }

@@ -1133,8 +1133,9 @@ static int shares_leafwise(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const 
   call.temps.push_back(d_partial);
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_chunk, (size_t)n_out * dp.n_chunks * sizeof(double)));
   call.temps.push_back(d_chunk);
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_out * sizeof(double)));
-  call.temps.push_back(d_out);
+  // the sums go straight into the pinned result ring (fold_leaves' last workgroups store them there): no copy to queue
+  call.back.resize((size_t)n_out);
+  GK_HIP(gk_fetch_direct(ctx, call.back.data(), (size_t)n_out * sizeof(double), (void**)&d_out));
   // accumulators per lane group: (c + 1) float64 per set within 128 VGPRs -- 6 sets of 2 alleles, 4 of 3, 3 of 4; a
   // selection beyond 128 x that many sets goes in batches (each batch streams the table once more)
   const int max_slots = c == 2 ? 6 : c == 3 ? 4 : 3;
@@ -1192,8 +1193,6 @@ static int shares_leafwise(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const 
   call.c = c;
   call.with_value = true;
   call.leafwise = true;
-  call.back.resize((size_t)n_out);
-  GK_HIP(gk_fetch_queue(ctx, call.back.data(), d_out, (size_t)n_out * sizeof(double)));
   return GK_OK;
 }
 
@@ -1281,8 +1280,8 @@ int gk_shares_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32
   const int64_t n_out = (int64_t)n_sets * per_set;
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_out * dp.n_spans * sizeof(double)));
   call.temps.push_back(d_partial);
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_out * sizeof(double)));
-  call.temps.push_back(d_out);
+  call.back.resize((size_t)n_out);
+  GK_HIP(gk_fetch_direct(ctx, call.back.data(), (size_t)n_out * sizeof(double), (void**)&d_out));      // combine_chunks stores into the result ring
   const dim3 grid((unsigned)n_tiles, (unsigned)dp.n_spans);
   const size_t lds = (size_t)max_dist * kFracLd * sizeof(double);   // <= 256 columns * 41 * 8 = 84 KB
 #define GK_FRAC_GO(C, V, TL, VIEW)                                                                                   \
@@ -1323,8 +1322,6 @@ int gk_shares_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32
   call.n_sets = n_sets;
   call.c = c;
   call.with_value = with_value;
-  call.back.resize((size_t)n_out);
-  GK_HIP(gk_fetch_queue(ctx, call.back.data(), d_out, (size_t)n_out * sizeof(double)));
   return GK_OK;
 }
 
@@ -1358,8 +1355,8 @@ int gk_colsum_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32
   double *d_partial = nullptr, *d_out = nullptr;
   GK_HIP(gk_pool_malloc(ctx, (void**)&d_partial, (size_t)n_cols * dp.n_spans * sizeof(double)));
   call.temps.push_back(d_partial);
-  GK_HIP(gk_pool_malloc(ctx, (void**)&d_out, (size_t)n_cols * sizeof(double)));
-  call.temps.push_back(d_out);
+  call.back.resize((size_t)n_cols);
+  GK_HIP(gk_fetch_direct(ctx, call.back.data(), (size_t)n_cols * sizeof(double), (void**)&d_out));      // combine_chunks stores into the result ring
   const dim3 cgrid((unsigned)((n_cols + kColsPerGroup - 1) / kColsPerGroup), (unsigned)dp.n_spans);
   if (L.indexed())
     GK_PROF_EXACT(ctx, "colsum_chunks",
@@ -1377,8 +1374,6 @@ int gk_colsum_enqueue(gk_ctx* ctx, const GkTable& L, int64_t n_rows, const int32
   GK_HIP(hipGetLastError());
   call.n_rows = n_rows;
   call.n_sets = n_cols;
-  call.back.resize((size_t)n_cols);
-  GK_HIP(gk_fetch_queue(ctx, call.back.data(), d_out, (size_t)n_cols * sizeof(double)));
   return GK_OK;
 }
 

@@ -448,9 +448,14 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
         double val0 = 0.0, val1 = 0.0;
         uint32_t raise = 0;      // flag bits this thread wants raised: ONE atomic per wave below, not one per entry (the
                                  // first sample of a run meets nothing but new products: 150 M atomics on one word)
-        for (int idx = tid; idx < n_pass * kTileRows; idx += kCompatThreads) {
-          const int al = idx / kTileRows, r = idx % kTileRows;
-          if (r >= n_r) continue;
+        // a thread keeps to one read and takes CONSECUTIVE alleles of it (neighbours in the index differ in a few variants
+        // and mostly share their product: the two registers answer; alleles 32 apart, as the stride of the tile's
+        // threads would give, rarely do)
+        constexpr int kRowThreads = kCompatThreads / kTileRows;
+        const int per_thread = (n_pass + kRowThreads - 1) / kRowThreads;
+        const int r = tid % kTileRows, al0 = (tid / kTileRows) * per_thread;
+        for (int al = al0; al < min(al0 + per_thread, n_pass); ++al) {
+          if (r >= n_r) break;
           double* const cell = &tile[al * kTileLd + r];
           const uint64_t key = (uint64_t)__double_as_longlong(*cell);
           if (key != key0) {

@@ -319,7 +319,6 @@ def createParser() -> argparse.ArgumentParser:
 def main(args: argparse.Namespace) -> None:
     if getattr(args, "cn_cohort", False):
         os.environ.setdefault("GK_SAMPLE_LANES", "3")      # samples wait in HBM for the pooled fit: the lanes' working sets stay small
-        os.environ.setdefault("GK_POOL_CACHE_GB", "6")     # ... and so do the blocks the pools keep idle between samples
     cohort.pipelineDefaults()       # before the first HIP call: blocking waits, sample lanes, search slots (as bench.py)
     setThreads(args.thread)
     setEngine(args.engine)
