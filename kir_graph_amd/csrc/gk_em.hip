@@ -164,24 +164,37 @@ __device__ inline void sets_of_rows(const EmSetsJob& J, const uint32_t* __restri
     // a mate without positives names nobody; words past the gene's last one stay zero
     uint2 side0 = make_uint2((lo_lane && o1 > o0) ? 0xFFFFFFFFu : 0u, (hi_lane && o1 > o0) ? 0xFFFFFFFFu : 0u);
     uint2 side1 = make_uint2((lo_lane && o2 > o1) ? 0xFFFFFFFFu : 0u, (hi_lane && o2 > o1) ? 0xFFFFFFFFu : 0u);
-    // one list at a time (its sign and its mate are then fixed): the group reads 4 G ids of the list and hands them round
+    // one list at a time (its sign and its mate are then fixed): the group reads 4 G ids of the list and hands them round.
+    // With the bit rows in LDS a step is branch-free: two rows stand behind the gene's own -- row n_span all zeros, row
+    // n_span + 1 all ones -- every id outside the gene (a novel variant, the padding past a list's end) lands on the zero
+    // row through ONE v_min_u32, and the padding of a POSITIVE list (spelled 0xFFFFFFFF: bit 31 set, which no ordinal has)
+    // steps on to the row of ones (AND with ones: nothing happens): no test per step, and the lanes of a group whose
+    // list has ended run the padded steps with the others
+    // (a break per step cost ~27 scalar instructions of exec-mask bookkeeping per id: 1.08e9 per configs[2] launch).
     auto walk = [&](uint32_t begin, uint32_t end, uint2& side, bool negative) {
       for (uint32_t k0 = begin; k0 < end; k0 += 4 * G) {
         uint32_t idv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint32_t k = k0 + 4u * (uint32_t)l + (uint32_t)q;
-          idv[q] = k < end ? ids[k] : 0xFFFFFFFFu;      // past the end: outside every gene
+          idv[q] = k < end ? ids[k] : 0xFFFFFFFFu;      // past the end of the list (ordinals stay below 2^31)
         }
 #pragma unroll
         for (int j = 0; j < 4 * G; ++j) {
-          if (k0 + (uint32_t)j >= end) break;            // uniform within the group
-          const uint32_t rel = (uint32_t)__shfl(idv[j & 3], j >> 2, G) - vbeg;
+          const uint32_t v = (uint32_t)__shfl(idv[j & 3], j >> 2, G);
+          const uint32_t rel = v - vbeg;
           uint2 m = make_uint2(0u, 0u);                      // a variant outside the index (novel) has no allele
-          if (rel < n_span && lo_lane) {
-            const uint32_t* at = M + rel * (uint32_t)stride + 2u * (uint32_t)l;
-            if (kLds) m = *reinterpret_cast<const uint2*>(at);      // the padding word of an odd gene is zero
-            else { m.x = at[0]; m.y = hi_lane ? at[1] : 0u; }
+          if (kLds) {
+            uint32_t at = min(rel, n_span);                 // outside the gene (rel >= n_span): the zero row
+            if (!negative) at += v >> 31;                   // ... but the padding of a positive list: the row of ones behind it
+            m = *reinterpret_cast<const uint2*>(M + at * (uint32_t)stride + 2u * (uint32_t)l);
+          } else {
+            if (k0 + (uint32_t)j >= end) break;            // uniform within the group
+            if (rel < n_span && lo_lane) {
+              const uint32_t* at = M + rel * (uint32_t)stride + 2u * (uint32_t)l;
+              m.x = at[0];
+              m.y = hi_lane ? at[1] : 0u;
+            }
           }
           // positives intersect (a novel one leaves nobody); negatives of the index subtract (a novel one: nothing)
           if (negative) { side.x &= ~m.x; side.y &= ~m.y; }
@@ -219,11 +232,17 @@ __global__ __launch_bounds__(kSetThreads) void em_sets_groups(const EmSetsJob* _
   const int tid = threadIdx.x;
   const int stride = (J.words + 1) & ~1;      // rows of an even number of words in LDS
   if (J.tag) lt.clear(tid);
-  if (J.mask_in_lds)
+  if (J.mask_in_lds) {
     for (int e = tid; e < J.n_span * stride; e += kSetThreads) {
       const int v = e / stride, w = e - v * stride;
       lmask[e] = w < J.words ? J.mask[v * J.words + w] : 0u;
     }
+    // the two rows behind the gene's own: all zeros (anything outside the gene), all ones (padding of a positive list);
+    // a lane whose words lie beyond the row reads on into these or the following bytes: its sets are zero from the start
+    // and stay so under AND and AND-NOT alike
+    for (int e = tid; e < 2 * stride + 2 * kMaxWords; e += kSetThreads)
+      lmask[J.n_span * stride + e] = (e >= stride && e < 2 * stride) ? 0xFFFFFFFFu : 0u;
+  }
   __syncthreads();
   if (J.mask_in_lds) sets_of_rows<G, true>(J, off, ids, lmask, stride, lt);      // two copies of the loop: LDS reads / global reads
   else sets_of_rows<G, false>(J, off, ids, J.mask, J.words, lt);
@@ -459,7 +478,8 @@ Geometry geometry_of(const std::vector<EmSetsJob>& jobs) {
     words = std::max(words, j.words);
     g.blocks = std::max(g.blocks, j.n_blocks);
     g.slots = std::max(g.slots, j.slot_mask);
-    if (j.mask_in_lds) g.lds = std::max(g.lds, kLocalBytes + (size_t)j.n_span * (size_t)((j.words + 1) & ~1) * sizeof(uint32_t));
+    if (j.mask_in_lds)      // the gene's rows, the two rows behind them, room for the lanes that read past a row's end
+      g.lds = std::max(g.lds, kLocalBytes + ((size_t)(j.n_span + 2) * (size_t)((j.words + 1) & ~1) + 2 * kMaxWords) * sizeof(uint32_t));
   }
   g.G = lanes_per_pair(words);
   return g;
