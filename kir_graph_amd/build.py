@@ -34,6 +34,8 @@ KERNEL_SOURCES = {
     "patch_pending": ["gk_typing.hip", "gk_lut.h", "gk_common.h"],
     "count_ids_genes": ["gk_typing.hip", "gk_common.h"],
     "flag_nonempty": ["gk_typing.hip", "gk_common.h"],
+    "flag_pairs": ["gk_typing.hip", "gk_common.h"],
+    "gather_pair_flags": ["gk_typing.hip", "gk_common.h"],
     "tab_count": ["gk_tabulate.hip", "gk_common.h"],
     "tab_emit": ["gk_tabulate.hip", "gk_common.h"],
     "tab_expand": ["gk_tabulate.hip", "gk_common.h"],

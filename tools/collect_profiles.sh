@@ -18,7 +18,7 @@ WORKLOADS=${2:-"cfg2_exonfirst cfg2_em cfg1_pv"}
 RUN_BENCH=${3:-1}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-KERNELS="compat_kernel tab_count tab_expand minsum_sad setsum_leaves colsum_chunks count_ids_genes flag_nonempty fraction_chunks maxsum_chunks patch_pending em_sets_groups em_sets_verify em_sets_emit em_kernel_genes"
+KERNELS="compat_kernel tab_count tab_expand minsum_sad setsum_leaves colsum_chunks count_ids_genes flag_nonempty flag_pairs fraction_chunks maxsum_chunks patch_pending em_sets_groups em_sets_verify em_sets_emit em_kernel_genes"
 cd /tmp && export TMPDIR=/tmp
 export GK_PREFETCH=0 GK_SAMPLE_LANES=1
 for W in $WORKLOADS; do
