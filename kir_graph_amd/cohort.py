@@ -183,7 +183,7 @@ class SampleTyper:
     This is the one code path behind ``main.alleleTyping`` / ``main._runCohort`` (the command line) and ``bench.py``
     (the measurement): a sample is typed by ONE host thread on one stream (``gk_sample_search``), up to ``lanes``
     samples at a time, at most GK_SEARCH_SLOTS of them inside their search (``kir_typing._searchSlot``), the
-    preamble of a sample on the lane's high-priority stream (GK_URGENT_PREAMBLE), waits that block.
+    preamble of a sample on the lane's high-priority stream, waits that block.
 
     ``finish(typer, calls, warnings, item)`` runs on the lane's thread once the sample is typed (write its files,
     release its HBM); its return value is the sample's result."""

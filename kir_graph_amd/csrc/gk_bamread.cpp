@@ -40,7 +40,7 @@ void gk_set_error(const char* fmt, ...);
 // Blocks of hundreds of megabytes (the inflated stream, the file, the sort's records) are handed back to a pool
 // when a file is closed and taken from it when the next one is opened: a fresh block of that size costs a page
 // fault per 4 KiB when it is first written (measured on the GPU box: 0.6 s of system time per 2 M-read sample,
-// a quarter of the ingest's CPU time), a recycled one is already mapped.  GK_BLOCK_POOL_GB (default 6) of idle
+// a quarter of the ingest's CPU time), a recycled one is already mapped.  6 GB of idle
 // blocks at most; a request takes the smallest idle block that holds it and is not more than twice its size.
 namespace {
 struct BlockPool {
@@ -189,7 +189,7 @@ bool inflate_members(const Bytes& in, Bytes& out) {
 
 // libdeflate inflates BGZF blocks 2-3 times faster than zlib.  The image ships its runtime library without
 // the header, so the three entry points used are bound by name at first use (signatures of libdeflate.h,
-// stable since 1.0); without the library, or with GK_NO_LIBDEFLATE set, zlib does the work.
+// stable since 1.0); without the library, or under the test hook no_libdeflate (GK_TEST_HOOKS), zlib does the work.
 struct FastInflate {
   void* (*alloc)() = nullptr;
   int (*run)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;   // 0 = LIBDEFLATE_SUCCESS

@@ -1063,8 +1063,8 @@ int sample_search_pipelined(gk_ctx* ctx, gk_tab* tab, gk_dptr d_vflag, gk_lut* l
 extern "C" {
 
 /* The searches of ALL genes of a sample on the calling thread: the compatibility tables, then the column sums, then
- * step 2, 3, ... of every gene that has one -- pipelined on one stream (sample_search_pipelined; GK_SAMPLE_PIPELINE=0
- * turns it off) or in lock-step (several streams, index tables, a value table that is still growing), so that one host
+ * step 2, 3, ... of every gene that has one -- pipelined on one stream (sample_search_pipelined)
+ * or in lock-step (several streams, index tables, a value table that is still growing), so that one host
  * thread keeps the GPU fed (typing_mulit_allele.py:340-381 + 478-598 per gene; kir_typing.py:103-132 is the gene loop).
  * jobs[i] describes gene i (tables allocated by the caller); out[i] receives its search (gk_search_*), NULL for a
  * gene without rows.  `log10_fn` = numpy.log10 (value table, see gk_lut_resolve), `argsort` = numpy.argsort. */
