@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
   constexpr int kPassAlleles = 64 * kSlots;
   constexpr int kPassWords = 2 * kSlots;   // bit-row words covering one pass
   __shared__ double tile[kPassAlleles * kTileLd];
-  __shared__ uint32_t wave_rows[kCompatWaves][64 * kPassWords];
+  __shared__ uint32_t wave_rows[kCompatWaves][65 * kPassWords];      // 64 kept rows of a chunk + one nobody reads
   // 0.999 = 0x3FEFF7CED916872B, 0.001 = 0x3F50624DD2F1A9FC
   constexpr int32_t kHi999 = 0x3FEFF7CE, kLo999 = (int32_t)0xD916872B, kHi001 = 0x3F50624D, kLo001 = (int32_t)0xD2F1A9FC;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -338,14 +338,30 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
     const int64_t tile_i = 8 * (xcd + 8 * (u >> 3)) + (u & 7);
     if (tile_i >= n_tiles) continue;
     const int64_t row0 = tile_i * kTileRows;
-    for (int q = 0; q < kTileRows / kCompatWaves; ++q) {
-      const int rt = wid * (kTileRows / kCompatWaves) + q;   // row inside the tile
+    // the list offsets of the wave's rows of this tile, requested together (row number -> offsets -> ids -> bit rows is a
+    // chain of four loads per row; the second row's first two links ride on the first row's)
+    constexpr int kRowsPerWave = kTileRows / kCompatWaves;
+    uint32_t row_b[kRowsPerWave], row_mid[kRowsPerWave], row_e[kRowsPerWave];
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; ++q) {
+      const int64_t i = row0 + wid * kRowsPerWave + q;
+      const int64_t row = rows[i < n_rows ? i : n_rows - 1];
+      row_b[q] = off[4 * row]; row_mid[q] = off[4 * row + 2]; row_e[q] = off[4 * row + 4];
+    }
+    uint32_t first_id[kRowsPerWave];      // a lane's id of each row's first chunk: the third link, for all rows at once
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; ++q) {
+      const uint32_t k = row_b[q] + (uint32_t)lane;
+      first_id[q] = ids[k < row_e[q] ? k : (row_e[q] ? row_e[q] - 1u : 0u)];
+    }
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; ++q) {
+      const int rt = wid * kRowsPerWave + q;   // row inside the tile
       const int64_t i = row0 + rt;
       if (i >= n_rows) break;                                   // wave-uniform
-      const int64_t row = rows[i];
-      const uint32_t b = __builtin_amdgcn_readfirstlane(off[4 * row]);
-      const uint32_t mid = __builtin_amdgcn_readfirstlane(off[4 * row + 2]);
-      const uint32_t e = __builtin_amdgcn_readfirstlane(off[4 * row + 4]);
+      const uint32_t b = __builtin_amdgcn_readfirstlane(row_b[q]);
+      const uint32_t mid = __builtin_amdgcn_readfirstlane(row_mid[q]);
+      const uint32_t e = __builtin_amdgcn_readfirstlane(row_e[q]);
       double p[kSlots];
       uint32_t miss[kSlots];
       uint32_t nvar = 0;
@@ -356,32 +372,34 @@ __global__ __launch_bounds__(kCompatThreads) void compat_kernel(const int32_t* r
       const int my_bit = lane & 31;
       for (uint32_t base = b; base < e; base += 64) {
         const uint32_t k = base + lane;
-        bool my_keep = false;
+        // Straight-line loads (no branch per word: the compiler then waits for the first word before it asks for the
+        // second, and keeps the uniform guards in spilled scalars): a lane past the end of the list repeats the last id
+        // and keeps nothing; a variant outside the gene's span (novel: no allele carries it) reads row 0 and takes zeros;
+        // only the LAST word of a pass can lie beyond the gene's words (kSlots is the number of slots the pass needs).
+        const bool in = k < e;
+        const uint32_t v = base == b ? first_id[q] : ids[in ? k : e - 1u];
+        const uint32_t local = v - (uint32_t)vbeg;
+        const bool indexed = local < (uint32_t)n_span;
+        const uint32_t at = indexed ? local : 0u;
+        const uint8_t dropped = vflag[v];
+        const uint32_t flip = k >= mid ? 0xFFFFFFFFu : 0u;     // "the allele lacks it" = agreement with a negative id
         uint32_t mrow[kPassWords];
 #pragma unroll
-        for (int w = 0; w < kPassWords; ++w) mrow[w] = 0;
-        if (k < e) {
-          const uint32_t v = ids[k];
-          const int local = (int)v - vbeg;
-          if ((int)v < vend && local >= 0) {   // novel variants carry no allele: all-zero row
-            const uint32_t* src = mask_t + (int64_t)w_base * n_span + local;
-#pragma unroll
-            for (int w = 0; w < kPassWords; ++w)
-              if (w_base + w < words) mrow[w] = src[(int64_t)w * n_span];
-          }
-          my_keep = !(vflag[v] & (k < mid ? 1 : 2));
-          if (k >= mid) {
-#pragma unroll
-            for (int w = 0; w < kPassWords; ++w) mrow[w] = ~mrow[w];     // "the allele lacks it" = agreement with a negative id
-          }
+        for (int w = 0; w < kPassWords; ++w) {
+          const bool has = w + 1 < kPassWords || w_base + w < words;                     // uniform
+          const uint32_t* const col = mask_t + (int64_t)(has ? w_base + w : 0) * n_span;     // uniform
+          const uint32_t x = col[at];
+          mrow[w] = ((indexed && has) ? x : 0u) ^ flip;
         }
+        const bool my_keep = in && !(dropped & (k < mid ? 1 : 2));
         // the kept variants of the chunk back to back in LDS, in list order (positives, then negatives)
         const uint64_t kept = __ballot(my_keep);
         const int n_kept = __builtin_popcountll(kept);
         nvar += (uint32_t)n_kept;
-        if (my_keep) {
+        {      // every lane stores (a lane that keeps nothing into the row behind the 64: the loads above are then not
+               // sunk below the keep test, where they would wait for the drop flag first)
           const uint32_t place = __builtin_amdgcn_mbcnt_hi((uint32_t)(kept >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kept, 0u));
-          uint32_t* const dst = &wave_rows[wid][place * kPassWords];
+          uint32_t* const dst = &wave_rows[wid][(my_keep ? place : 64u) * kPassWords];
 #pragma unroll
           for (int w = 0; w < kPassWords; ++w) dst[w] = mrow[w];
         }
