@@ -179,51 +179,67 @@ __global__ __launch_bounds__(kThreads) void count_ids_genes(const int32_t* __res
   const int n_local = min(gene_vbeg[g + 1] - vbeg, max_local);
   for (int i = threadIdx.x; i < 2 * n_local; i += kThreads) hist[i] = 0;
   __syncthreads();
-  // Sixteen lanes per row.  The loads of a row depend on each other (row number -> list offsets -> ids -> drop flags) and
-  // a list has 30 - 100 ids: the offsets of the group's NEXT row are requested before this row's ids are walked, and the
-  // ids are taken 64 at a time (four loads per lane in flight, then their four flags) -- the kernel waits for memory,
-  // not for the LDS counters.
+  // Sixteen lanes per row.  The loads of a row depend on each other (row number -> list offsets -> ids -> drop flags): as
+  // a loop with a test per id the compiler put a wait behind every link and sank the flag loads into the branches that
+  // use them (five dependent waits per row: 6.6 us per iteration at configs[2]).  So the walk is straight-line code in
+  // which every load is unconditional (clamped indices) and every counter update too (an id that does not count adds to a
+  // spare counter of the lane): per row the first 64 ids are requested FIRST, behind them the offsets of the group's next
+  // row and the number of the row after that; then the four flags; two waits per row.  A list beyond 64 ids takes the rest
+  // 64 at a time.
   constexpr int kGroup = 16, kDeep = 4;
   const int lane = threadIdx.x & (kGroup - 1);
-  const int64_t r0 = wg_row0[blockIdx.x], r1 = wg_row1[blockIdx.x];
+  uint32_t* const spare = hist + 2 * max_local + threadIdx.x;      // a counter nobody reads, one per thread
+  const int64_t r0 = wg_row0[blockIdx.x], r1 = wg_row1[blockIdx.x];      // r1 > r0
   constexpr int64_t kStep = kThreads / kGroup;
   int64_t i = r0 + threadIdx.x / kGroup;
-  uint32_t b = 0, mid = 0, e = 0;
-  if (i < r1) {
-    const int64_t row = rows[i];
-    b = off[4 * row]; mid = off[4 * row + 2]; e = off[4 * row + 4];
-  }
-  for (; i < r1; i += kStep) {
-    uint32_t nb = 0, nmid = 0, ne = 0;
-    if (i + kStep < r1) {
-      const int64_t row = rows[i + kStep];
-      nb = off[4 * row]; nmid = off[4 * row + 2]; ne = off[4 * row + 4];
+  auto row_at = [&](int64_t j) { return rows[j < r1 ? j : r1 - 1]; };
+  int32_t row = row_at(i), row1 = row_at(i + kStep);
+  uint32_t b = off[4 * (int64_t)row], mid = off[4 * (int64_t)row + 2], e = off[4 * (int64_t)row + 4];
+  if (i >= r1) b = mid = e = 0u;
+  // the tally of up to 64 ids (k0 + 16 j of this lane) whose flags are at hand
+  auto tally = [&](uint32_t k0, const uint32_t (&v)[kDeep], const uint8_t (&f)[kDeep]) {
+    bool counted = false;
+#pragma unroll
+    for (int j = 0; j < kDeep; ++j) {
+      const uint32_t k = k0 + kGroup * j;
+      const bool positive = k < mid;
+      const bool counts = k < e && !(f[j] & (positive ? 1 : 2));
+      const uint32_t l = v[j] - (uint32_t)vbeg;
+      const bool local = l < (uint32_t)n_local;
+      atomicAdd((counts && local) ? &hist[(positive ? 0 : n_local) + l] : spare, (counts && local) ? 1u : 0u);
+      if (counts && !local) atomicAdd(positive ? &cnt_pos[v[j]] : &cnt_neg[v[j]], 1u);      // a novel variant
+      counted = counted || counts;
     }
-    bool counted = false;      // an id of this row went into a tally: the row may outlive the correction (flag_pairs)
-    for (uint32_t k0 = b + lane; k0 < e; k0 += kGroup * kDeep) {
-      uint32_t v[kDeep];
-      uint8_t f[kDeep];
+    return counted;
+  };
+  auto ids_of = [&](uint32_t k0, uint32_t (&v)[kDeep]) {
+    const uint32_t last = e ? e - 1u : 0u;
 #pragma unroll
-      for (int j = 0; j < kDeep; ++j) v[j] = k0 + kGroup * j < e ? ids[k0 + kGroup * j] : 0u;
+    for (int j = 0; j < kDeep; ++j) v[j] = ids[k0 + kGroup * j < e ? k0 + kGroup * j : last];
+  };
+  for (; i < r1; i += kStep) {
+    uint32_t v[kDeep];
+    uint8_t f[kDeep];
+    ids_of(b + lane, v);
+    const int64_t next = row1;                                  // arrived: requested an iteration ago
+    const uint32_t nb = off[4 * next], nmid = off[4 * next + 2], ne = off[4 * next + 4];
+    row1 = row_at(i + 2 * kStep);
 #pragma unroll
-      for (int j = 0; j < kDeep; ++j) f[j] = k0 + kGroup * j < e ? vflag[v[j]] : (uint8_t)3;
+    for (int j = 0; j < kDeep; ++j) f[j] = vflag[v[j]];
+    bool counted = tally(b + lane, v, f);      // an id of this row went into a tally: the row may outlive the correction (flag_pairs)
+    for (uint32_t k0 = b + kGroup * kDeep + lane; k0 < e; k0 += kGroup * kDeep) {
+      ids_of(k0, v);
 #pragma unroll
-      for (int j = 0; j < kDeep; ++j) {
-        const uint32_t k = k0 + kGroup * j;
-        if (k >= e) break;
-        const bool positive = k < mid;
-        if (f[j] & (positive ? 1 : 2)) continue;
-        counted = true;
-        const uint32_t l = v[j] - (uint32_t)vbeg;
-        if (l < (uint32_t)n_local) atomicAdd(&hist[(positive ? 0 : n_local) + l], 1u);
-        else atomicAdd(positive ? &cnt_pos[v[j]] : &cnt_neg[v[j]], 1u);
-      }
+      for (int j = 0; j < kDeep; ++j) f[j] = vflag[v[j]];
+      counted = tally(k0, v, f) || counted;
     }
     if (maybe) {
       const bool any = ((__ballot(counted) >> ((threadIdx.x & 63) & ~(kGroup - 1))) & 0xFFFFull) != 0ull;
-      if (lane == 0) maybe[rows[i]] = any ? 1 : 0;
+      if (lane == 0) maybe[row] = any ? 1 : 0;
     }
-    b = nb; mid = nmid; e = ne;
+    row = (int32_t)next;
+    const bool more = i + kStep < r1;
+    b = more ? nb : 0u; mid = more ? nmid : 0u; e = more ? ne : 0u;
   }
   __syncthreads();
   for (int i2 = threadIdx.x; i2 < 2 * n_local; i2 += kThreads) {
@@ -993,7 +1009,7 @@ static int sample_prepare(gk_ctx* ctx, gk_tab* tab, int32_t multiple, gk_dptr d_
   for (int round = 0; round < rounds; ++round) {      // the exon model corrects its lists twice (typing_mulit_allele.py:644-645, 664)
     if (round) GK_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * nv) * sizeof(uint32_t), st));
     GK_PROF(ctx, "count_ids_genes",
-            GK_KERNEL(count_ids_genes, dim3((unsigned)n_wg), dim3(kThreads), (size_t)max_local * 8, st, part.d_rows,
+            GK_KERNEL(count_ids_genes, dim3((unsigned)n_wg), dim3(kThreads), (size_t)max_local * 8 + kThreads * sizeof(uint32_t), st, part.d_rows,
                       (const int32_t*)d_tab, (const int64_t*)(d_tab + o_row0), (const int64_t*)(d_tab + o_row1),
                       tab->idx->d_gene_vbeg, max_local, tab->d_off, tab->d_ids, vflag, cnt, cnt + nv,
                       round == rounds - 1 ? maybe : (uint8_t*)nullptr));
