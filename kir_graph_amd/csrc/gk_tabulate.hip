@@ -619,23 +619,40 @@ __global__ __launch_bounds__(kExpandThreads) void tab_expand(int64_t n_mates, in
     if (staged) mine[slot - run0] = v;                                  // (wave-uniform choice; ds_write, in order with the reads below)
     else ids[slot] = v;
   };
-  if (m < n_mates) {
-    const int64_t pair = m >> 1;
-    const int side = (int)(m & 1);
-    if (valid[pair] == 1u) {      // 2 = a pair of the wide format: pass 1 saved nothing for it, tab_emit_wide writes its lists
-      const uint32_t o_pos = off[4 * pair + side], n_pos = off[4 * pair + side + 1] - o_pos;
-      const uint32_t o_neg = off[4 * pair + 2 + side], n_neg = off[4 * pair + 2 + side + 1] - o_neg;
-      if (n_pos) {
-        const uint4 e4 = ev_save[m];
-        const uint32_t first[kEvRegs] = {e4.x, e4.y, e4.z, e4.w};
-        for (uint32_t e = 0; e < n_pos; ++e) {
-          const uint32_t w = (e < (uint32_t)kEvRegs ? first[e] : ev_more[m * kEvMore + e - kEvRegs]) & ~kEvIsN;
+  {
+    // Everything a mate needs is requested at once, for every lane (a lane past the end repeats the last mate and writes
+    // nothing): its pair's flag and five offsets, the saved event words, window start and kept bits; then the ranks of the
+    // novel events among its first four -- two waits.  (With a test around each load the compiler waited for the flag,
+    // then the offsets, then the events, then for every rank on its own: eight dependent waits per wave at ten waves per
+    // CU.)  The empty asm statements keep the loads from being sunk into the branches that use their results.
+    const int64_t mc = m < n_mates ? m : n_mates - 1;
+    const int64_t pair = mc >> 1;
+    const int side = (int)(mc & 1);
+    const uint32_t flag = valid[pair];
+    const uint4 o4 = *reinterpret_cast<const uint4*>(off + 4 * pair);
+    const uint32_t o5 = off[4 * pair + 4];
+    const uint4 e4 = ev_save[mc];
+    const uint32_t lo = lo_save[mc];
+    const uint4 m4 = mask_save[mc];
+    asm volatile("" ::"v"(flag), "v"(o4.x), "v"(o5), "v"(e4.x), "v"(lo), "v"(m4.x));
+    const uint32_t first[kEvRegs] = {e4.x, e4.y, e4.z, e4.w};
+    uint32_t first_rank[kEvRegs];
+#pragma unroll
+    for (int e = 0; e < kEvRegs; ++e) first_rank[e] = rank[(first[e] & kEvNovel) ? (first[e] & kEvSlotMask) : 0u];
+    asm volatile("" ::"v"(first_rank[0]), "v"(first_rank[1]), "v"(first_rank[2]), "v"(first_rank[3]));
+    if (m < n_mates && flag == 1u) {      // 2 = a pair of the wide format: pass 1 saved nothing for it, tab_emit_wide writes its lists
+      const uint32_t o_pos = side ? o4.y : o4.x, n_pos = (side ? o4.z : o4.y) - o_pos;
+      const uint32_t o_neg = side ? o4.w : o4.z, n_neg = (side ? o5 : o4.w) - o_neg;
+      for (uint32_t e = 0; e < n_pos; ++e) {
+        if (e < (uint32_t)kEvRegs) {
+          const uint32_t w = first[e] & ~kEvIsN;
+          put(o_pos + e, (w & kEvNovel) ? (uint32_t)n_var + first_rank[e] : w);
+        } else {
+          const uint32_t w = ev_more[m * kEvMore + e - kEvRegs] & ~kEvIsN;
           put(o_pos + e, (w & kEvNovel) ? (uint32_t)n_var + rank[w & kEvSlotMask] : w);
         }
       }
       if (n_neg) {
-        const uint32_t lo = lo_save[m];
-        const uint4 m4 = mask_save[m];
         const uint32_t firstw[kMaskRegs] = {m4.x, m4.y, m4.z, m4.w};
         uint32_t j = 0;
         for (int w = 0; w < kMaskWords && j < n_neg; ++w) {
