@@ -723,6 +723,7 @@ class AlleleTyping:
             per_row = m.tab.n_ids / max(m.tab.n_valid, 1)
             for _ in range(max(1, int(job.passes))):
                 m.dev.call_log.append(("compat_kernel", m.n_rows, m.n_allele, per_row * m.n_rows, 8))
+            self._logLaunches(handle)       # the column sums of the whole table: this job's launch, nobody else logs it
         self._colsum_all = np.empty(m.n_allele, dtype=np.float64)
         check(lib().gk_search_colsum(handle, self._colsum_all.ctypes.data))
         self.result = []
