@@ -1209,3 +1209,24 @@ def test_samples_are_admitted_to_the_lanes_by_their_footprint():
     assert typer._admit(big) == fp
     typer._release(fp)
     typer.close()
+
+
+def test_pair_lists_of_the_pairing_threads_join_in_stream_order(tmp_path, monkeypatch):
+    """gk_packer_feed_records on a name-collated stream large enough for several pairing threads (more than 4096 records
+    each, 2^16 list entries or more): the pieces' pair lists are joined by one thread per piece into a block that is not
+    zero-filled first -- records, line numbers of the pairs and counts are those of the one-piece text path
+    (hisat2.py:248-270 pairs in stream order)."""
+    sidx = synth.makeIndex(seed=5, n_genes=3, var_range=(200, 300), allele_range=(10, 20))
+    gidx = GkIndex.fromVariants(sidx.variants, genes=sidx.genes, exons=sidx.exons)
+    sample = synth.makeSample(sidx, seed=77, n_pairs=36000)
+    lines = synth.toSamLines(sample)
+    header = ["@HD\tVN:1.0\tSO:coordinate"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+    path = str(tmp_path / "big.bam")
+    packed.writeBam(path, "\n".join(header + lines) + "\n")
+    monkeypatch.setenv("GK_PACK_THREADS", "4")
+    rec_b, table_b, pl_b, counts_b = packed.packBam(path, gidx)
+    rec_t, table_t, pl_t, counts_t = packed.packText(packed.bamChunks(path), gidx)
+    assert counts_b == counts_t and counts_b["pairs"] >= 32768
+    assert rec_b.tobytes() == rec_t.tobytes()
+    assert pl_b.tolist() == pl_t.tolist()
+    assert table_b.strings == table_t.strings
