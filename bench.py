@@ -398,17 +398,25 @@ class RankContext:
         self.sidx, self.gidx, self.by_gene = build_index()
         self.dindex = DeviceIndex(self.dev, self.gidx)
         self.dev.sync()
-        self.comm = None
+        self.comm, self.comm_note = None, None
         if self.world > 1:
-            # a scaling run must not quietly measure something else: when the RCCL communicator cannot be made on some
-            # rank every rank stops with a non-zero code (the file backend is used only when it was asked for)
+            # The data path has no collective: the communicator only carries the barriers around the timed legs and the
+            # max over ranks.  When the RCCL communicator cannot be made on some rank (RCCL with more than one rank has
+            # never run on the builder's one-GPU boxes) all ranks agree to carry those few messages through the
+            # rendezvous directory instead -- and the line SAYS so (config.rank_barrier = "file" + rank_barrier_note)
+            # rather than the run producing no number at all.  A set-up that never returns counts as failed after 90 s.
+            os.environ.setdefault("GK_RCCL_INIT_TIMEOUT", "90")
             try:
-                self.comm = gk_comm.initFromEnv(dev=self.dev, backend=backend, fallback=False)
+                self.comm = gk_comm.initFromEnv(dev=self.dev, backend=backend, fallback=True)
             except gk_comm.CommError as e:
-                log(f"[bench] rank {rank}: {e}; not falling back (GK_COMM_BACKEND=file rehearses the launch without RCCL)")
+                log(f"[bench] rank {rank}: {e}")
                 os._exit(4)
-            if self.comm.world != args.gpus or self.comm.backend != backend:
-                raise RuntimeError(f"bench.py: --gpus {args.gpus} on {backend} but {self.comm.world} ranks joined on {self.comm.backend}")
+            if self.comm.world != args.gpus:
+                raise RuntimeError(f"bench.py: --gpus {args.gpus} but {self.comm.world} ranks joined")
+            if self.comm.backend != backend:
+                self.comm_note = (f"the {backend} communicator could not be made on every rank: barriers and the max over "
+                                  f"ranks went through the rendezvous directory ({self.comm.backend} backend); the data path "
+                                  "has no collective either way")
 
     def devices(self):
         from kir_graph_amd import _lib
@@ -574,7 +582,8 @@ def report(rc: RankContext, res: dict, name: str, pinned, cores_before, head: bo
                    "parallelism": f"samples sharded over {world} GPU(s), no data-path collective; one process per GPU, "
                                   f"{lanes} samples in flight (one host thread and one stream per sample: "
                                   + ("gk_sample_em)" if method in ("em", "report") else "gk_sample_search)"),
-                   "rank_barrier": (rc.comm.backend if rc.comm is not None else None)},
+                   "rank_barrier": (rc.comm.backend if rc.comm is not None else None),
+                   "rank_barrier_note": rc.comm_note},
     }
     serial = res.get("serial")
     if serial:

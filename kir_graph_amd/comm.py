@@ -354,8 +354,8 @@ def initFromEnv(dev=None, backend: str | None = None, fallback: bool = True) -> 
     rccl when every local rank has a GPU of its own, file otherwise.  ``fallback``: when the RCCL communicator
     cannot be set up on some rank (no librccl, no device, initialisation error) ALL ranks agree -- through the
     rendezvous directory -- to carry the few control messages over the file backend instead, and say so; with
-    ``fallback=False`` (``bench.py --gpus N``: a scaling run must not quietly measure something else) every rank
-    raises ``CommError`` instead."""
+    ``fallback=False`` every rank raises ``CommError`` instead.  (``bench.py --gpus N`` falls back too and says so in
+    its line -- ``config.rank_barrier`` / ``rank_barrier_note``: the timed data path has no collective.)"""
     rank, world, _ = worldFromEnv()
     if world <= 1:
         return None
