@@ -285,7 +285,7 @@ def test_two_ranks_cn_cohort_equals_one_process(device, tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE="2",
-                   GK_COMM_BACKEND="file", GK_RDZV_DIR=str(tmp_path / "rdzv"), PYTHONPATH=root, GK_THREADS="2")
+                   GK_COMM_BACKEND="file", GK_RDZV_DIR=str(tmp_path / "rdzv"), PYTHONPATH=root)
         procs.append(subprocess.Popen(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (_, err) in zip(procs, outs):
@@ -341,7 +341,7 @@ def test_configs3_in_small_sixteen_samples_over_five_ranks(device, tmp_path):
     cmd = [sys.executable, "-m", "kir_graph_amd.main", "--step-skip-extraction", "--index-folder", folder,
            "--output-folder", str(many), "--allele-strategy", "pv", "--no-variant-json", "--cn-cohort", "--ranks", "5",
            "--log-level", "WARNING"] + [x for s in sams for x in ("--alignment", s)]
-    res = subprocess.run(cmd, env=dict(os.environ, GK_COMM_BACKEND="file", PYTHONPATH=root, GK_THREADS="2"), cwd=root,
+    res = subprocess.run(cmd, env=dict(os.environ, GK_COMM_BACKEND="file", PYTHONPATH=root), cwd=root,
                          capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     names = sorted(p.name for p in one.iterdir())

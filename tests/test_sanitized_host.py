@@ -34,11 +34,11 @@ def sanitized_library(tmp_path_factory):
 @pytest.mark.parametrize("seed", [1, 2])
 def test_parsers_survive_mutated_inputs_under_asan_ubsan(sanitized_library, seed):
     if seed == 2:   # the record index cut into many segments: guessed chains, meetings, serial stretches
-        os.environ["GK_BAM_INDEX_SEGMENTS"] = "9"
+        os.environ["GK_TEST_HOOKS"] = "bam_segments=9"
     env = dict(os.environ, LD_PRELOAD=_libasan(), GK_PACK_THREADS="2",
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asan", "driver.py"), sanitized_library, "250",
                           str(seed)], env=env, capture_output=True, text=True, timeout=900)
-    os.environ.pop("GK_BAM_INDEX_SEGMENTS", None)
+    os.environ.pop("GK_TEST_HOOKS", None)
     assert res.returncode == 0 and "OK mutants" in res.stdout, (res.stdout[-500:], res.stderr[-4000:])

@@ -1,5 +1,5 @@
 # Dev tool: SQ / scalar-cache counters of the compatibility kernel over tools/bench_compat.py (separate --pmc passes).
-#   bash tools/pmc_compat.sh [output tag under gpurun_out/, default compat_pmc]     (GK_COMPAT selects the kernel form)
+#   bash tools/pmc_compat.sh [output tag under gpurun_out/, default compat_pmc]
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-compat_pmc}
