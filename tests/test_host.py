@@ -1230,3 +1230,25 @@ def test_pair_lists_of_the_pairing_threads_join_in_stream_order(tmp_path, monkey
     assert rec_b.tobytes() == rec_t.tobytes()
     assert pl_b.tolist() == pl_t.tolist()
     assert table_b.strings == table_t.strings
+
+
+def test_bgzf_blocks_inflate_the_same_with_zlib_as_with_libdeflate(tmp_path):
+    """csrc/gk_bamread.cpp binds libdeflate by name when the image has its runtime library and falls back to zlib
+    otherwise (test hook no_libdeflate): the name-collated text of a BAM file (hisat2.py:103-110) is the same either way.
+    The choice is made once per process, so the zlib run is a child process."""
+    import hashlib
+    import subprocess
+    import sys
+    sidx = synth.makeIndex(seed=5, n_genes=3, var_range=(200, 300), allele_range=(10, 20))
+    sample = synth.makeSample(sidx, seed=3, n_pairs=3000)
+    header = ["@HD\tVN:1.0\tSO:coordinate"] + [f"@SQ\tSN:{g}\tLN:{len(sidx.backbone[g])}" for g in sidx.genes]
+    path = str(tmp_path / "z.bam")
+    packed.writeBam(path, "\n".join(header + synth.toSamLines(sample)) + "\n")
+    here = hashlib.sha256(b"".join(packed.bamChunks(path))).hexdigest()
+    code = ("import hashlib, sys; from kir_graph_amd import packed; "
+            "print(hashlib.sha256(b''.join(packed.bamChunks(sys.argv[1]))).hexdigest())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=300, cwd=root,
+                         env=dict(os.environ, GK_TEST_HOOKS="no_libdeflate", GK_TRACE="ingest", PYTHONPATH=root))
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert res.stdout.strip() == here
