@@ -5,7 +5,7 @@
 //   GK_TEST_HOOKS  switches the TESTS use to force rarely taken paths, comma-separated `name` or `name=value`:
 //                  two_walks (tabulation: second walk instead of the saved words), novel_log2cap=N (size of the first
 //                  novel-variant table), bam_segments=N (segments of the BAM record index), setsum=tiles|leaves,
-//                  no_libdeflate (zlib for BGZF)
+//                  no_libdeflate (zlib for BGZF); read by the Python side only: bam_reader=samtools, ingest_ahead=N
 #pragma once
 #include <cstdlib>
 #include <cstring>
