@@ -712,7 +712,7 @@ int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
   // when equal names are contiguous (a name-collated stream) the stream is cut at name changes and
   // the pieces are paired independently; their emission lists, concatenated, are the sequential one.
   struct Wait { int64_t index; long flag; };
-  struct Piece { std::vector<int64_t> pairs; int64_t n_reads = 0, n_strange = 0; };
+  struct Piece { std::vector<int64_t, GkRawInit<int64_t>> pairs; int64_t n_reads = 0, n_strange = 0; };
   auto pair_range = [&](int64_t a, int64_t b, Piece& out) {
     out.pairs.reserve((size_t)(b - a));          // a pair takes two records: the list never grows past this (no reallocation)
     std::unordered_map<std::string, Wait> waiting;
@@ -819,15 +819,17 @@ int gk_packer_feed_records(gk_packer* pk, int64_t n, bool names_contiguous,
       pk->n_strange += pc.n_strange;
       pk->n_pairs += (int64_t)pc.pairs.size() / 2;
     }
-    pairs.resize(at.back());
     auto place = [&](size_t t) {
       if (!pieces[t].pairs.empty()) memcpy(pairs.data() + at[t], pieces[t].pairs.data(), pieces[t].pairs.size() * sizeof(int64_t));
     };
-    if (pieces.size() == 1 || pairs.size() < (size_t)1 << 16) {
-      for (size_t t = 0; t < pieces.size(); ++t) place(t);
+    if (pieces.size() == 1) {
+      pairs.swap(pieces[0].pairs);                // one piece: its list is the list
     } else {
+      pairs.resize(at.back());
       std::vector<std::thread> pool;
-      for (size_t t = 1; t < pieces.size(); ++t) pool.emplace_back(place, t);
+      if (pairs.size() >= (size_t)1 << 16)
+        for (size_t t = 1; t < pieces.size(); ++t) pool.emplace_back(place, t);
+      for (size_t t = pool.empty() ? 1 : pieces.size(); t < pieces.size(); ++t) place(t);
       place(0);
       for (auto& th : pool) th.join();
     }
