@@ -520,7 +520,12 @@ static int bam_open_impl(const char* path, int32_t name_sorted, gk_bam** out) {
     size_t have = 0;
     raw.resize(fstat(fileno(f), &st) == 0 && st.st_size > 0 ? (size_t)st.st_size : (size_t)1 << 22);
     for (;;) {   // whole file, whatever fstat said
-      if (have == raw.size()) raw.resize(raw.size() * 2);
+      if (have == raw.size()) {          // the usual end: the block fstat sized is full -- look before growing (and copying) it
+        const int c = fgetc(f);
+        if (c == EOF) break;
+        raw.resize(raw.size() * 2);
+        raw[have++] = (uint8_t)c;
+      }
       const size_t n = fread(raw.data() + have, 1, raw.size() - have, f);
       if (!n) break;
       have += n;
