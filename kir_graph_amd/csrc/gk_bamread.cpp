@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <climits>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -1125,6 +1126,7 @@ bool parse_ll(std::string_view s, long long& v) {
   long long x = 0;
   for (; i < s.size(); ++i) {
     if (!isdigit((unsigned char)s[i])) return false;
+    if (x > (LLONG_MAX - 9) / 10) return false;     // no field of an alignment line is that large
     x = x * 10 + (s[i] - '0');
   }
   v = neg ? -x : x;
@@ -1208,14 +1210,19 @@ bool encode_record(std::string_view line, const std::vector<std::string>& ref_na
   };
   ref_id = f[2] == "*" ? -1 : find_ref(f[2]);
   const int32_t next_id = f[6] == "=" ? ref_id : (f[6] == "*" ? -1 : find_ref(f[6]));
-  pos0 = (int32_t)pos - 1;
+  pos0 = (int32_t)(pos - 1);                      // 64-bit arithmetic first: POS / PNEXT of a damaged line may be INT32_MIN
   std::vector<uint32_t> cig;
   int64_t ref_len = 0;
   if (f[5] != "*") {
     long long n = 0;
     bool have = false;
     for (char c : f[5]) {
-      if (isdigit((unsigned char)c)) { n = n * 10 + (c - '0'); have = true; continue; }
+      if (isdigit((unsigned char)c)) {
+        n = n * 10 + (c - '0');
+        have = true;
+        if (n > 0xFFFFFFF) return false;           // a BAM op length has 28 bits (and n must not overflow)
+        continue;
+      }
       const char* ops = "MIDNSHP=X";
       const char* at = strchr(ops, c);
       if (!at || !have) return false;
@@ -1237,7 +1244,7 @@ bool encode_record(std::string_view line, const std::vector<std::string>& ref_na
   put16(body, (uint32_t)flag);
   put32(body, l_seq);
   put32(body, (uint32_t)next_id);
-  put32(body, (uint32_t)((int32_t)pnext - 1));
+  put32(body, (uint32_t)(int32_t)(pnext - 1));
   put32(body, (uint32_t)(int32_t)tlen);
   body.append(f[0]); body.push_back('\0');
   for (uint32_t c : cig) put32(body, c);
@@ -1512,26 +1519,33 @@ extern "C" int gk_bam_pileup(gk_bam* b, const int64_t* gene_off, int32_t n_gene,
     if ((flag & 1u) && !(flag & 2u)) return false;
     return rds32(p) >= 0 && rds32(p) < n_gene;
   };
+  // Only positions inside the reference are kept (nothing else is ever counted, and a mate's overlap with its partner
+  // only matters where both are counted): a damaged record -- an I / S run longer than the read, a D or N run of 2^28
+  // bases -- then costs neither a read outside its block nor memory for positions that do not exist.
   auto cover = [&](const uint8_t* p, std::vector<Cov>& out) {
     out.clear();
     const uint32_t l_name = p[8], n_cig = rd16(p + 12), l_seq = rd32(p + 16);
     const uint8_t* cig = p + 32 + l_name;
     const uint8_t* seq = cig + 4ull * n_cig;
     const uint8_t* qual = seq + (l_seq + 1) / 2;
-    int32_t pos = rds32(p + 4);
-    uint32_t ri = 0;
+    const int64_t ref_len = std::min<int64_t>(gene_off[rds32(p) + 1] - gene_off[rds32(p)], INT32_MAX);
+    int64_t pos = rds32(p + 4);
+    uint32_t ri = 0;                                  // bases of the read consumed, never more than l_seq
     for (uint32_t c = 0; c < n_cig; ++c) {
       const uint32_t v = rd32(cig + 4ull * c), op = v & 15u, len = v >> 4;
       if (op == 0 || op == 7 || op == 8) {
         for (uint32_t k = 0; k < len && ri < l_seq; ++k, ++ri, ++pos)
-          out.push_back({pos, code_of((seq[ri >> 1] >> ((~ri & 1u) << 2)) & 15u), qual[ri] == 0xFF ? (uint8_t)255 : qual[ri], false});
+          if (pos >= 0 && pos < ref_len)
+            out.push_back({(int32_t)pos, code_of((seq[ri >> 1] >> ((~ri & 1u) << 2)) & 15u), qual[ri] == 0xFF ? (uint8_t)255 : qual[ri], false});
       } else if (op == 2) {
         const uint8_t q = ri ? (qual[ri - 1] == 0xFF ? (uint8_t)255 : qual[ri - 1]) : (uint8_t)255;
-        for (uint32_t k = 0; k < len; ++k, ++pos) out.push_back({pos, 5, q, true});
+        const int64_t stop = std::min<int64_t>(pos + (int64_t)len, ref_len);
+        for (int64_t at = std::max<int64_t>(pos, 0); at < stop; ++at) out.push_back({(int32_t)at, 5, q, true});
+        pos += (int64_t)len;
       } else if (op == 1 || op == 4) {
-        ri += len;
+        ri = (uint32_t)std::min<uint64_t>((uint64_t)ri + len, l_seq);
       } else if (op == 3) {
-        pos += (int32_t)len;
+        pos += (int64_t)len;
       }
     }
   };

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <climits>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -109,6 +110,13 @@ void split_tabs(sv s, std::vector<sv>& out) {
   }
 }
 
+// x * 10 + digit that stops growing instead of overflowing: a run of twenty digits in a damaged line is a number no
+// check downstream accepts either way (Python's int() would hold it; what follows only compares it)
+inline long push_digit(long x, char c) {
+  constexpr long kTop = (LONG_MAX - 9) / 10;
+  return x > kTop ? x : x * 10 + (c - '0');
+}
+
 bool to_long(sv s, long& v) {   // Python int(): optional sign, digits, surrounding blanks
   s = strip(s);
   if (s.empty()) return false;
@@ -119,7 +127,7 @@ bool to_long(sv s, long& v) {   // Python int(): optional sign, digits, surround
   long x = 0;
   for (; i < s.size(); ++i) {
     if (!isdigit((unsigned char)s[i])) return false;
-    x = x * 10 + (s[i] - '0');
+    x = push_digit(x, s[i]);
   }
   v = neg ? -x : x;
   return true;
@@ -166,7 +174,7 @@ struct TextSource {
       if (!isdigit((unsigned char)cigar[i])) { ++i; continue; }
       long n = 0;
       size_t j = i;
-      while (j < cigar.size() && isdigit((unsigned char)cigar[j])) n = n * 10 + (cigar[j++] - '0');
+      while (j < cigar.size() && isdigit((unsigned char)cigar[j])) n = push_digit(n, cigar[j++]);
       if (j >= cigar.size() || !(isalnum((unsigned char)cigar[j]) || cigar[j] == '_')) {
         // regex backtracking: with no word character after the digits, "\d+" gives its last digit to "\w"
         if (j - i < 2) { i = j; continue; }
@@ -231,7 +239,7 @@ bool walk_alignment(const Source& src, bool has_md, sv md_s, bool has_zs, sv zs_
     for (size_t i = 0; i < md_s.size();) {
       if (isdigit((unsigned char)md_s[i])) {
         long x = 0;
-        while (i < md_s.size() && isdigit((unsigned char)md_s[i])) x = x * 10 + (md_s[i++] - '0');
+        while (i < md_s.size() && isdigit((unsigned char)md_s[i])) x = push_digit(x, md_s[i++]);
         md.push_back({0, x, 0});
       } else {
         md.push_back({1, 0, md_s[i++]});
@@ -355,7 +363,7 @@ bool parse_record(sv line, GkAlnRecord& p, Fail& f) {
     size_t d = at + 5;
     if (d < line.size() && isdigit((unsigned char)line[d])) {
       long x = 0;
-      while (d < line.size() && isdigit((unsigned char)line[d])) x = x * 10 + (line[d++] - '0');
+      while (d < line.size() && isdigit((unsigned char)line[d])) x = push_digit(x, line[d++]);
       p.nh = x;
       break;
     }
@@ -459,7 +467,7 @@ void decode_records(const gk_packer* pk, const GkAlnRecord* pr, const int64_t* i
         for (size_t i = 0; i < cg.size();) {
           if (!isdigit((unsigned char)cg[i])) { ++i; continue; }
           long n = 0;
-          while (i < cg.size() && isdigit((unsigned char)cg[i])) n = n * 10 + (cg[i++] - '0');
+          while (i < cg.size() && isdigit((unsigned char)cg[i])) n = push_digit(n, cg[i++]);
           if (i >= cg.size()) break;
           add(cg[i++], n);
         }

@@ -121,8 +121,15 @@ def main():
     assert exercise(good) == 0, lib.gk_last_error()
     opened = refused = 0
     first_rec = raw.index(b"r0\0") - 36 if b"r0\0" in raw else 64
+    recs, o = [], first_rec                     # offset of every record's fixed fields in the uncompressed stream
+    while o + 36 <= len(raw):
+        size = struct.unpack_from("<I", raw, o)[0]
+        if size < 32 or o + 4 + size > len(raw):
+            break
+        recs.append(o + 4)
+        o += 4 + size
     for k in range(n_mutants):
-        kind = rng.randrange(7)
+        kind = rng.randrange(8)
         path = os.path.join(tmp, f"m{k % 8}.bam")
         if kind == 0:      # truncated uncompressed stream
             write_bgzf(raw[:rng.randrange(0, len(raw))], path)
@@ -148,6 +155,16 @@ def main():
                 z = f.read()
             with open(path, "wb") as f:
                 f.write(z[:rng.randrange(len(z))])
+        elif kind == 7 and recs:   # a well-formed record whose CIGAR lies: I / S runs longer than the read, D / N runs of 2^28 bases
+            b = bytearray(raw)
+            for _ in range(rng.randrange(1, 4)):
+                r = rng.choice(recs)
+                l_name, n_cig = b[r + 8], struct.unpack_from("<H", b, r + 12)[0]
+                if n_cig:
+                    at = r + 32 + l_name + 4 * rng.randrange(n_cig)
+                    run = rng.choice([151, 400, 1 << 20, (1 << 28) - 1])
+                    b[at:at + 4] = struct.pack("<I", run << 4 | rng.choice([1, 4, 2, 3, 0]))
+            write_bgzf(bytes(b), path)
         elif kind == 5:    # header damage: magic, l_text, n_ref, reference names
             b = bytearray(raw)
             at = rng.randrange(0, first_rec)
@@ -162,20 +179,36 @@ def main():
             refused += 1
     # SAM text straight into the packer: damaged lines must end in an error code, never in a bad read
     names = (C.c_char_p * len(GENES))(*[g.encode() for g in GENES])
-    lines = sam_lines(rng, 60)[3:]
+    all_lines = sam_lines(rng, 60)
+    header_lines, lines = all_lines[:3], all_lines[3:]
     for k in range(n_mutants):
         bad = list(lines)
         for _ in range(rng.randrange(1, 5)):
             i = rng.randrange(len(bad))
             s = bytearray(bad[i].encode())
             if s:
-                how = rng.randrange(3)
-                if how == 0:
+                how = rng.randrange(4)
+                if how == 3:      # numbers of more digits than a long holds: CIGAR run, POS / PNEXT, MD
+                    f = s.split(b"\t")
+                    if len(f) > 8:
+                        big = b"9" * rng.randrange(19, 40)
+                        which = rng.randrange(4)
+                        if which == 0:
+                            f[5] = big + b"M"
+                        elif which == 1:
+                            f[3] = big
+                        elif which == 2:
+                            f[7] = b"-" + big
+                        else:
+                            f = [x if not x.startswith(b"MD:Z:") else b"MD:Z:" + big for x in f]
+                        s = bytearray(b"\t".join(f))
+                elif how == 0:
                     s[rng.randrange(len(s))] = rng.choice(b"\t:0A^|,*\x00\xff")
                 elif how == 1:
                     del s[rng.randrange(len(s)):]
                 else:
-                    s += b"\t" + rng.choice([b"Zs:Z:", b"Zs:Z:9|S", b"MD:Z:", b"NM:i:", b"NH:i:99999999999", b"Zs:Z:|||"])
+                    s += b"\t" + rng.choice([b"Zs:Z:", b"Zs:Z:9|S", b"MD:Z:", b"NM:i:", b"NH:i:99999999999", b"Zs:Z:|||",
+                                             b"NH:i:" + b"9" * 30, b"NM:i:" + b"9" * 30, b"Zs:Z:" + b"9" * 30 + b"|S|x"])
             bad[i] = s.decode("latin1")
         blob = ("\n".join(bad) + ("\n" if rng.random() < 0.8 else "")).encode("latin1")
         pk = C.c_void_p()
@@ -184,6 +217,9 @@ def main():
         lib.gk_packer_feed(pk, blob[:cut], cut, 0)
         lib.gk_packer_feed(pk, blob[cut:], len(blob) - cut, 1)
         lib.gk_packer_destroy(pk)
+        if k % 4 == 0:     # the same damaged lines through the BAM writer (its own number and CIGAR parsing)
+            sam = ("\n".join(header_lines) + "\n").encode() + blob
+            lib.gk_bam_write(os.path.join(tmp, "damaged.bam").encode(), sam, len(sam), k % 8 == 0)
     print(f"OK mutants {n_mutants}: {opened} opened and walked, {refused} refused")
 
 
