@@ -33,6 +33,21 @@ def test_abi_library_exports_every_declared_symbol():
     assert lib.gk_abi_version() == 1
 
 
+def test_ctypes_signatures_take_as_many_arguments_as_the_header_declares():
+    """Every prototype of include/graphkir_hip.h against the binding table of kir_graph_amd/_lib.py: same names, same
+    number of arguments (a call with one argument too few reads a register of garbage: nothing else would say so)."""
+    header = open(os.path.join(os.path.dirname(GOLD), "..", "include", "graphkir_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|const char\*|void)\s+(gk_\w+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(re.split(r",(?![^()]*\))", args))
+    assert len(protos) > 100
+    assert set(protos) == set(_lib._SIGS), set(protos) ^ set(_lib._SIGS)
+    wrong = {n: (protos[n], len(_lib._SIGS[n][1])) for n in protos if protos[n] != len(_lib._SIGS[n][1])}
+    assert not wrong, wrong
+
+
 def test_no_device_is_a_loud_error():
     """Without a HIP device the typing path must raise, not fall back."""
     if _lib.deviceCount() > 0:
