@@ -64,6 +64,51 @@ def write_bgzf(raw: bytes, path: str, block=5000):
         f.write(_bgzf_block(b""))
 
 
+def packed_pairs(pk, ext, blob: bytes, header: bytes, path: str) -> None:
+    """What the host does with a packer's result: the records and the pairs' line numbers, the wide pairs, the compact
+    form that crosses PCIe, the BAM rewrite of the pairs' lines and the "reads" array of a .variant.json."""
+    n_lines, n_reads, n_pairs, n_strange, n_str = (C.c_int64() for _ in range(5))
+    lib.gk_packer_counts(pk, C.byref(n_lines), C.byref(n_reads), C.byref(n_pairs), C.byref(n_strange), C.byref(n_str))
+    kind, line = C.c_int32(), C.c_int64()
+    lib.gk_packer_error(pk, C.byref(kind), C.byref(line))
+    n = n_pairs.value
+    own = None if ext is not None else (C.c_uint8 * (128 * max(2 * n, 1)))()
+    pair_lines = (C.c_int64 * max(2 * n, 1))()
+    if lib.gk_packer_records(pk, own, pair_lines if n else None):
+        return
+    n_spill = C.c_int64()
+    lib.gk_packer_spilled(pk, C.byref(n_spill))
+    if n_spill.value:
+        wide = (C.c_uint8 * (2048 * 2 * n_spill.value))()
+        which = (C.c_int64 * n_spill.value)()
+        lib.gk_packer_spill_records(pk, wide, which)
+    if not n:
+        return
+    rec = ext if ext is not None else own
+    words = C.c_int64()
+    if lib.gk_mates_compact_size(rec, C.c_int64(2 * n), 2, C.byref(words)) == 0:
+        out = (C.c_uint32 * (2 * n + 1 + words.value))()
+        lib.gk_mates_compact_host(rec, C.c_int64(2 * n), 2, out, C.c_int64(len(out)))
+    # every second pair's two lines as a BAM file of their own; every pair as a row of the JSON hand-off
+    sel = []
+    for k in range(0, 2 * n, 4):
+        sel += [pair_lines[k], pair_lines[k + 1]]
+    pick = (C.c_int64 * len(sel))(*sel)
+    lib.gk_bam_write_lines((path + ".lines.bam").encode(), header, C.c_int64(len(header)), blob, C.c_int64(len(blob)),
+                           pick, C.c_int64(len(sel)), 1)
+    src = (C.c_int64 * n)(*range(n))
+    off = (C.c_uint32 * (4 * n + 1))(*[(k + 3) // 4 for k in range(4 * n + 1)])      # one id per row, in its lpv list
+    ids = (C.c_uint32 * n)(*[k % 3 for k in range(n)])
+    names = (C.c_char_p * 3)(b"KIR2DL1*v1", b"KIR2DL1*\"q\"", b"KIR3DL3*\xc3\xa9")
+    genes = (C.c_char_p * len(GENES))(*[g.encode() for g in GENES])
+    gene_of = (C.c_uint8 * n)(*[k % len(GENES) for k in range(n)])
+    nh = (C.c_uint8 * n)(*[1 + k % 3 for k in range(n)])
+    js = path + ".reads.json"
+    open(js, "wb").close()
+    lib.gk_json_write_reads(js.encode(), blob, C.c_int64(len(blob)), pair_lines, C.c_int64(n), src, C.c_int64(n), off, ids,
+                            names, C.c_int64(3), genes, len(GENES), gene_of, nh)
+
+
 def exercise(path: str) -> int:
     """Open + every walker of the reader on one file; returns the open() code."""
     names = (C.c_char_p * len(GENES))(*[g.encode() for g in GENES])
@@ -93,6 +138,7 @@ def exercise(path: str) -> int:
                     out_buf = (C.c_uint8 * (128 * max(n_rec.value, 1)))()
                     lib.gk_packer_set_output(pk, out_buf, C.c_int64(n_rec.value))
                 lib.gk_bam_pack(h, pk)
+                packed_pairs(pk, out_buf if name_sorted else None, b"".join(text), hdr.raw[:n_hdr.value], path)
                 lib.gk_packer_destroy(pk)
             off = (C.c_int64 * (n_ref.value + 1))(*[9000 * i for i in range(n_ref.value + 1)])
             counts = (C.c_uint32 * (9000 * max(n_ref.value, 1) * 6))()
