@@ -29,3 +29,17 @@ def test_without_a_launcher_the_ranks_are_started_and_a_dead_rank_fails_the_run(
     assert res.returncode == 1
     assert "rank exit codes" in res.stderr and "fewer than 2 ranks finished" in res.stderr
     assert not res.stdout.strip()
+
+
+def test_committed_pmc_traffic_belongs_to_the_device_sources_in_the_tree():
+    """bench.py reports `roofline.traffic` only from a committed PMC pass whose recorded digest of the device sources
+    equals the running code's (bench.measured_traffic): an edit to a kernel's source after the last profile run would
+    silently turn the figure into null.  The dominant kernels of the three workloads of the default line must resolve."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    for kernel, pairs, method in (("compat_kernel", 10_000_000, "exonfirst"), ("tab_count", 10_000_000, "em"),
+                                  ("compat_kernel", 1_000_000, "pv"), ("setsum_leaves", 10_000_000, "exonfirst"),
+                                  ("em_sets_groups", 10_000_000, "em")):
+        traffic, why = bench.measured_traffic(kernel, pairs, method)
+        assert traffic and traffic > 0, (kernel, pairs, method, why)
