@@ -104,7 +104,7 @@ def mapSamples(names, reads, index, index_ref, exon_region_only=False, alignment
 
     # the next sample is mapped / packed on a helper thread while this one is tabulated and written out
     # (three samples ahead on three threads: the serial stretches of one ingest leave cores to the others)
-    ahead = max(1, int(testHook("ingest_ahead", "3")))
+    ahead = max(1, int(testHook("ingest_ahead") or 3))       # samples packed ahead of the typing (the hook: tools/ingest_cli_sweep.sh)
     from concurrent.futures import ThreadPoolExecutor
     writer = ThreadPoolExecutor(max_workers=2, thread_name_prefix="gk-write")   # compact hand-off files, off this thread
     writes = []
